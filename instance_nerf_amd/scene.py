@@ -1,0 +1,134 @@
+"""Synthetic 3D-FRONT-like room used for measurement.
+
+No dataset is available offline, so throughput and parity runs use this
+analytic scene: a wall/floor/ceiling shell at |coord| in [0.90, 0.94] plus 12
+axis-aligned boxes (centres U(-0.7,0.7), half extents U(0.05,0.25),
+``numpy.random.default_rng(0)``); instance id = box index + 1, walls = 0.
+Cameras: 800x800, fx = fy = 400, cx = cy = 400; 8 poses (seed 1) with the eye
+in U(-0.5,0.5)^3 looking at the origin, up = +z.
+
+This is data generation, not part of the render algorithm; both the product
+code (bench) and the tests use it.  numpy only.
+"""
+import numpy as np
+
+F32 = np.float32
+WALL_IN, WALL_OUT = 0.90, 0.94
+
+
+class RoomScene:
+    def __init__(self, n_boxes=12, seed=0):
+        rng = np.random.default_rng(seed)
+        self.centres = rng.uniform(-0.7, 0.7, size=(n_boxes, 3))
+        self.halves = rng.uniform(0.05, 0.25, size=(n_boxes, 3))
+        self.lo = np.maximum(self.centres - self.halves, -WALL_IN)
+        self.hi = np.minimum(self.centres + self.halves, WALL_IN)
+        pal = np.random.default_rng(seed + 100).uniform(0.15, 0.95, size=(n_boxes + 1, 3))
+        pal[0] = (0.8, 0.8, 0.75)
+        self.palette = pal.astype(F32)
+
+    # ------------------------------------------------------------------ occupancy
+    def occupancy_grid(self, H=128, bound=1.0):
+        """bool[H,H,H] indexed [x,y,z]: cell overlaps geometry (cascade 0 only)."""
+        edges = -bound + 2.0 * bound * np.arange(H + 1) / H
+        lo_e, hi_e = edges[:-1], edges[1:]
+
+        def overlap(a, b):            # cells whose [lo,hi] interval overlaps [a,b]
+            return (hi_e > a) & (lo_e < b)
+
+        occ = np.zeros((H, H, H), dtype=bool)
+        inside = overlap(-WALL_OUT, WALL_OUT)
+        wall = overlap(WALL_IN, WALL_OUT) | overlap(-WALL_OUT, -WALL_IN)
+        ix, iy, iz = inside[:, None, None], inside[None, :, None], inside[None, None, :]
+        occ |= wall[:, None, None] & iy & iz
+        occ |= wall[None, :, None] & ix & iz
+        occ |= wall[None, None, :] & ix & iy
+        for lo, hi in zip(self.lo, self.hi):
+            m = [overlap(lo[a], hi[a]) for a in range(3)]
+            occ |= m[0][:, None, None] & m[1][None, :, None] & m[2][None, None, :]
+        return occ
+
+    def density_bitfield(self, H=128, bound=1.0):
+        """u8[H^3/8] in Morton order (bit i of byte k = cell with morton code 8k+i)."""
+        occ = self.occupancy_grid(H, bound)
+        r = np.arange(H, dtype=np.uint32)
+
+        def ex(v):
+            v = (v * np.uint32(0x00010001)) & np.uint32(0xFF0000FF)
+            v = (v * np.uint32(0x00000101)) & np.uint32(0x0F00F00F)
+            v = (v * np.uint32(0x00000011)) & np.uint32(0xC30C30C3)
+            v = (v * np.uint32(0x00000005)) & np.uint32(0x49249249)
+            return v
+        e = ex(r)
+        code = (e[:, None, None] | (e[None, :, None] << np.uint32(1))
+                | (e[None, None, :] << np.uint32(2))).astype(np.int64)
+        flat = np.zeros(H ** 3, dtype=np.uint8)
+        flat[code.ravel()] = occ.ravel().astype(np.uint8)
+        return np.packbits(flat.reshape(-1, 8), axis=1, bitorder="little").ravel()
+
+    # ------------------------------------------------------------------ cameras
+    @staticmethod
+    def look_at(eye, target=(0, 0, 0), up=(0, 0, 1)):
+        eye = np.asarray(eye, dtype=np.float64)
+        fwd = np.asarray(target, dtype=np.float64) - eye
+        fwd /= np.linalg.norm(fwd)
+        right = np.cross(fwd, np.asarray(up, dtype=np.float64))
+        if np.linalg.norm(right) < 1e-8:
+            right = np.cross(fwd, np.array([0.0, 1.0, 0.0]))
+        right /= np.linalg.norm(right)
+        down = np.cross(fwd, right)
+        pose = np.eye(4)
+        pose[:3, 0], pose[:3, 1], pose[:3, 2], pose[:3, 3] = right, down, fwd, eye
+        return pose.astype(F32)
+
+    def cameras(self, n=8, seed=1, H=800, W=800, focal=400.0):
+        rng = np.random.default_rng(seed)
+        eyes = rng.uniform(-0.5, 0.5, size=(n, 3))
+        poses = np.stack([self.look_at(e) for e in eyes])
+        return poses, (focal, focal, W / 2.0, H / 2.0), H, W
+
+    # ------------------------------------------------------------------ ground truth
+    def trace(self, rays_o, rays_d):
+        """Analytic first hit.  Returns (rgb f32[N,3], instance i64[N], t f32[N])."""
+        o = np.asarray(rays_o, dtype=np.float64)
+        d = np.asarray(rays_d, dtype=np.float64)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            rd = 1.0 / d
+            # walls: exit point of the inner room box [-WALL_IN, WALL_IN]^3
+            t_exit = np.min(np.where(d > 0, (WALL_IN - o) * rd, (-WALL_IN - o) * rd), axis=1)
+            best_t = t_exit.copy()
+            best_id = np.zeros(o.shape[0], dtype=np.int64)
+            axis_hit = np.argmin(np.where(d > 0, (WALL_IN - o) * rd, (-WALL_IN - o) * rd), axis=1)
+            for b, (lo, hi) in enumerate(zip(self.lo, self.hi)):
+                t0 = (lo - o) * rd
+                t1 = (hi - o) * rd
+                tn = np.max(np.minimum(t0, t1), axis=1)
+                tf = np.min(np.maximum(t0, t1), axis=1)
+                hit = (tn <= tf) & (tf > 0)
+                tb = np.where(tn > 0, tn, 0.0)
+                upd = hit & (tb < best_t)
+                ax = np.argmax(np.minimum(t0, t1), axis=1)
+                best_t = np.where(upd, tb, best_t)
+                best_id = np.where(upd, b + 1, best_id)
+                axis_hit = np.where(upd, ax, axis_hit)
+        shade = np.asarray([1.0, 0.85, 0.7])[axis_hit]
+        rgb = self.palette[best_id] * shade[:, None]
+        return rgb.astype(F32), best_id, best_t.astype(F32)
+
+    def instance_of_points(self, x):
+        """Instance id of points (0 = wall/empty, b+1 inside box b; first box wins)."""
+        x = np.asarray(x, dtype=np.float64)
+        ids = np.zeros(x.shape[0], dtype=np.int64)
+        for b in reversed(range(len(self.lo))):
+            inside = np.all((x >= self.lo[b]) & (x <= self.hi[b]), axis=1)
+            ids = np.where(inside, b + 1, ids)
+        return ids
+
+
+def blender_poses(n=100, radius=4.0311, seed=0):
+    """Config #1 style poses: cameras on a sphere looking at the origin."""
+    rng = np.random.default_rng(seed)
+    v = rng.normal(size=(n, 3))
+    v[:, 2] = np.abs(v[:, 2])
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    return np.stack([RoomScene.look_at(radius * e) for e in v])

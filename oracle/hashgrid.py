@@ -1,0 +1,120 @@
+"""Multiresolution hash-grid encoding (oracle; test infrastructure only).
+
+Follows SURVEY.md section 8a rows a6-a8 and Appendix A.1 "Hash grid"
+(upstream ``gridencoder.GridEncoder`` / ``kernel_grid`` / ``kernel_grid_backward``
+of the un-vendored submodule pinned at /root/reference/README.md:27,59; the
+hash is the Instant-NGP spatial hash, Mueller et al. 2022, eq. 4).
+Parity unpinned - see ``oracle/__init__``.
+
+Canonical choices (documented in DESIGN.md):
+* the per-level (scale, resolution, offset, hashed) table is computed on the
+  host (``level_table``) - float64 maths rounded once to float32 - and handed
+  to both the oracle and the HIP kernels;
+* corner order c = 0..7 with bit d of c selecting the +1 neighbour on axis d;
+  the corner weight is ((wx * wy) * wz); features accumulate in corner order.
+"""
+import numpy as np
+import torch
+
+PRIMES = (1, 2654435761, 805459861)
+
+
+def level_table(num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=19,
+                desired_resolution=2048, input_dim=3):
+    """Host-side level table.
+
+    per_level_scale = 2^(log2(desired/base)/(L-1));  resolution_l =
+    ceil(base * pls^l);  rows_l = min(2^log2_hashmap_size, (resolution_l+1)^3)
+    rounded up to a multiple of 8;  offsets = exclusive scan of rows.
+    scale_l = float32(base * pls^l - 1) and grid_res_l = ceil(scale_l) + 1 are
+    what the interpolation uses (== resolution_l).  A level is hashed iff
+    (grid_res_l + 1)^3 > rows_l.
+    """
+    pls = np.exp2(np.log2(desired_resolution / base_resolution) / max(num_levels - 1, 1))
+    max_params = 2 ** log2_hashmap_size
+    offsets, scales, ress, hashed = [0], [], [], []
+    for l in range(num_levels):
+        res = int(np.ceil(base_resolution * pls ** l))
+        rows = min(max_params, (res + 1) ** input_dim)
+        rows = int(np.ceil(rows / 8) * 8)
+        offsets.append(offsets[-1] + rows)
+        scale = np.float32(np.exp2(l * np.log2(pls)) * base_resolution - 1.0)
+        gres = int(np.ceil(scale)) + 1
+        scales.append(scale)
+        ress.append(gres)
+        hashed.append(1 if (gres + 1) ** input_dim > rows else 0)
+    return dict(num_levels=num_levels, level_dim=level_dim,
+                per_level_scale=float(pls),
+                offsets=np.asarray(offsets, dtype=np.uint32),
+                scales=np.asarray(scales, dtype=np.float32),
+                resolutions=np.asarray(ress, dtype=np.uint32),
+                hashed=np.asarray(hashed, dtype=np.uint32),
+                total_rows=int(offsets[-1]))
+
+
+def corner_indices_weights(x, bound, table):
+    """x f32[M,3] in [-bound,bound] -> (idx i64[M,L,8] absolute row, w f32[M,L,8]).
+
+    torch implementation (fp32 arithmetic, int64 index maths masked to uint32
+    where the hash needs wraparound).
+    """
+    x = torch.as_tensor(x, dtype=torch.float32)
+    M = x.shape[0]
+    L = table["num_levels"]
+    b = torch.tensor(float(bound), dtype=torch.float32)
+    x01 = (x + b) / (2 * b)
+    idx_all = torch.empty((M, L, 8), dtype=torch.int64)
+    w_all = torch.empty((M, L, 8), dtype=torch.float32)
+    for l in range(L):
+        scale = torch.tensor(float(table["scales"][l]), dtype=torch.float32)
+        res = int(table["resolutions"][l])
+        off = int(table["offsets"][l])
+        rows = int(table["offsets"][l + 1]) - off
+        pos = x01 * scale + 0.5
+        pg = torch.floor(pos)
+        fr = pos - pg
+        pg = pg.to(torch.int64)
+        for c in range(8):
+            cx = pg[:, 0] + ((c >> 0) & 1)
+            cy = pg[:, 1] + ((c >> 1) & 1)
+            cz = pg[:, 2] + ((c >> 2) & 1)
+            wx = fr[:, 0] if (c >> 0) & 1 else 1 - fr[:, 0]
+            wy = fr[:, 1] if (c >> 1) & 1 else 1 - fr[:, 1]
+            wz = fr[:, 2] if (c >> 2) & 1 else 1 - fr[:, 2]
+            if table["hashed"][l]:
+                h = ((cx * PRIMES[0]) & 0xFFFFFFFF) ^ ((cy * PRIMES[1]) & 0xFFFFFFFF) \
+                    ^ ((cz * PRIMES[2]) & 0xFFFFFFFF)
+                i = h % rows
+            else:
+                s = res + 1
+                i = (cx + cy * s + cz * s * s) % rows
+            idx_all[:, l, c] = i + off
+            w_all[:, l, c] = (wx * wy) * wz
+    return idx_all, w_all
+
+
+def encode(x, embeddings, bound, table):
+    """x f32[M,3], embeddings f32[T,F] -> f32[M, L*F] (level-major features).
+
+    Differentiable w.r.t. ``embeddings`` through torch autograd (the backward
+    is the scatter-add of row a8).
+    """
+    idx, w = corner_indices_weights(x.detach() if torch.is_tensor(x) else x, bound, table)
+    M, L, _ = idx.shape
+    F = embeddings.shape[1]
+    out = torch.zeros((M, L, F), dtype=torch.float32)
+    for c in range(8):                      # accumulate in corner order
+        out = out + w[:, :, c, None] * embeddings[idx[:, :, c]]
+    return out.reshape(M, L * F)
+
+
+def encode_backward_table(x, grad_out, bound, table):
+    """Analytic table gradient: grad f32[T,F] = scatter_add(w * grad_out)."""
+    idx, w = corner_indices_weights(x, bound, table)
+    M, L, _ = idx.shape
+    F = table["level_dim"]
+    g = torch.as_tensor(grad_out, dtype=torch.float32).reshape(M, L, 1, F)
+    contrib = (w[..., None] * g).reshape(-1, F)
+    grad = torch.zeros((table["total_rows"], F), dtype=torch.float32)
+    grad.index_add_(0, idx.reshape(-1), contrib)
+    return grad

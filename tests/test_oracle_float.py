@@ -1,0 +1,154 @@
+"""Oracle self-consistency: floating-point parts (CPU)."""
+import numpy as np
+import torch
+
+from oracle import composite, field, hashgrid, render, sh
+from conftest import scene_rays
+
+
+def test_level_table_matches_survey(level_table):
+    t = level_table
+    assert t["resolutions"].tolist() == [16, 23, 31, 43, 59, 81, 112, 154, 213, 295, 407, 562, 777, 1073, 1483, 2048]
+    rows = np.diff(t["offsets"].astype(np.int64)).tolist()
+    assert rows[:5] == [4920, 13824, 32768, 85184, 216000] and set(rows[5:]) == {524288}
+    assert t["total_rows"] == 6119864
+    assert t["hashed"].tolist() == [0] * 5 + [1] * 11
+
+
+def test_hash_indices_in_range_and_weights_sum_to_one(level_table):
+    x = torch.rand(2000, 3, generator=torch.Generator().manual_seed(0)) * 2 - 1
+    x[:8] = torch.tensor([[-1., -1, -1], [1, 1, 1], [1, -1, 1], [0, 0, 0], [-1, 1, 0.5], [1, 0, 0], [0, 1, 0], [0, 0, 1]])
+    idx, w = hashgrid.corner_indices_weights(x, 1.0, level_table)
+    off = level_table["offsets"].astype(np.int64)
+    for l in range(16):
+        assert (idx[:, l] >= off[l]).all() and (idx[:, l] < off[l + 1]).all()
+    assert torch.allclose(w.sum(-1), torch.ones(2000, 16), atol=1e-5)
+    assert (w >= 0).all()
+
+
+def test_dense_levels_are_collision_free(level_table):
+    """On a dense level distinct lattice corners map to distinct rows."""
+    res = int(level_table["resolutions"][0])
+    g = torch.stack(torch.meshgrid(*[torch.arange(res + 1)] * 3, indexing="ij"), -1).reshape(-1, 3)
+    x = (g.float() - 0.5 + 0.25) / float(level_table["scales"][0]) * 2 - 1  # inside cell -> floor = g-? just probe
+    idx, _ = hashgrid.corner_indices_weights(x.clamp(-1, 1), 1.0, level_table)
+    lvl0 = idx[:, 0, 0]
+    s = res + 1
+    assert lvl0.max() < s ** 3
+
+
+def test_encode_table_grad_matches_autograd(level_table):
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(300, 3, generator=g) * 2 - 1
+    emb = ((torch.rand(level_table["total_rows"], 2, generator=g) * 2 - 1)).requires_grad_(True)
+    out = hashgrid.encode(x, emb, 1.0, level_table)
+    go = torch.randn(out.shape, generator=g)
+    out.backward(go)
+    ana = hashgrid.encode_backward_table(x, go, 1.0, level_table)
+    assert torch.allclose(emb.grad, ana, atol=1e-5)
+    assert (emb.grad != 0).any()
+
+
+def test_encode_is_continuous_trilinear(level_table):
+    """At a lattice point of level l the level-l feature equals that table row."""
+    emb = torch.arange(level_table["total_rows"] * 2, dtype=torch.float32).reshape(-1, 2) % 977
+    l = 2
+    scale = float(level_table["scales"][l])
+    gp = torch.tensor([[3., 5., 7.]])
+    x = ((gp - 0.5) / scale) * 2 - 1 + 1e-7
+    idx, w = hashgrid.corner_indices_weights(x, 1.0, level_table)
+    out = hashgrid.encode(x, emb, 1.0, level_table)
+    s = int(level_table["resolutions"][l]) + 1
+    row = int(level_table["offsets"][l]) + 3 + 5 * s + 7 * s * s
+    assert torch.allclose(out[0, 2 * l:2 * l + 2], emb[row], atol=2e-2)
+
+
+def test_sh_orthonormal_monte_carlo():
+    g = torch.Generator().manual_seed(0)
+    d = torch.randn(200000, 3, generator=g, dtype=torch.float64)
+    d = (d / d.norm(dim=1, keepdim=True)).float()
+    Y = sh.sh_encode(d).double()
+    gram = (Y.t() @ Y) / d.shape[0] * 4 * np.pi
+    assert torch.allclose(gram, torch.eye(16, dtype=torch.float64), atol=0.03)
+
+
+def test_trunc_exp_grad_is_clamped():
+    x = torch.tensor([-20.0, 0.0, 3.0, 20.0], requires_grad=True)
+    y = field.trunc_exp(x)
+    y.sum().backward()
+    assert torch.allclose(y, torch.exp(x.detach()))
+    assert torch.allclose(x.grad, torch.exp(x.detach().clamp(-15, 15)))
+
+
+def _toy_samples(seed=0, N=12, maxc=20):
+    rng = np.random.default_rng(seed)
+    cnt = rng.integers(0, maxc, size=N)
+    cnt[3] = 0
+    off = np.concatenate([[0], np.cumsum(cnt)[:-1]])
+    M = int(cnt.sum())
+    rays = np.stack([rng.permutation(N), off, cnt], -1).astype(np.int32)
+    sig = (rng.random(M) * 60).astype(np.float32)
+    rgb = rng.random((M, 3)).astype(np.float32)
+    dl = np.stack([np.full(M, 0.02), rng.random(M) * 0.05 + 0.02], -1).astype(np.float32)
+    return rays, sig, rgb, dl
+
+
+def test_composite_weights_sum_identity_and_termination():
+    rays, sig, rgb, dl = _toy_samples()
+    out = composite.composite_rays_train(sig, rgb, dl, rays, T_thresh=1e-4)
+    for rid, off, cnt in rays:
+        T, ws, img = 1.0, 0.0, np.zeros(3)
+        for i in range(off, off + cnt):
+            a = 1 - np.exp(-float(sig[i]) * float(dl[i, 0]))
+            ws += a * T
+            img += a * T * rgb[i]
+            T *= 1 - a
+            if T < 1e-4:
+                break
+        assert abs(out["weights_sum"][rid].item() - ws) < 1e-5
+        assert abs(out["weights_sum"][rid].item() - (1 - T)) < 1e-5
+        assert np.allclose(out["image"][rid].numpy(), img, atol=1e-5)
+
+
+def test_composite_analytic_backward_matches_autograd():
+    rays, sig, rgb, dl = _toy_samples(seed=4)
+    s = torch.tensor(sig, requires_grad=True)
+    c = torch.tensor(rgb, requires_grad=True)
+    out = composite.composite_rays_train(s, c, dl, rays, T_thresh=1e-4)
+    g = torch.Generator().manual_seed(1)
+    gws = torch.randn(len(rays), generator=g)
+    gim = torch.randn(len(rays), 3, generator=g)
+    ((out["weights_sum"] * gws).sum() + (out["image"] * gim).sum()).backward()
+    gs, gc = composite.composite_backward_analytic(gws.numpy(), gim.numpy(), sig, rgb, dl, rays,
+                                                   out["weights_sum"].detach().numpy(),
+                                                   out["image"].detach().numpy())
+    assert np.allclose(gs, s.grad.numpy(), atol=2e-5, rtol=1e-4)
+    assert np.allclose(gc, c.grad.numpy(), atol=1e-6)
+
+
+def test_train_and_infer_renders_agree(room, room_bitfield, level_table, params_k8):
+    ro, rd = scene_rays(room, n=96, seed=9)
+    a = render.render_train(ro, rd, params_k8, level_table, room_bitfield, min_near=0.05, with_instance=True)
+    b = render.render_infer(ro, rd, params_k8, level_table, room_bitfield, min_near=0.05, with_instance=True)
+    assert np.allclose(a["image"].detach().numpy(), b["image"], atol=1e-5)
+    assert np.allclose(a["weights_sum"].detach().numpy(), b["weights_sum"], atol=1e-5)
+    assert np.allclose(a["instance"].detach().numpy(), b["instance"], atol=1e-5)
+
+
+def test_instance_training_reduces_loss(room, room_bitfield, level_table):
+    """A few Adam steps of the instance field on analytic labels lower the CE loss."""
+    p = field.init_params(seed=1, table=level_table, table_std=1e-4, K=16)
+    p["embeddings"] = (torch.rand(p["embeddings"].shape, generator=torch.Generator().manual_seed(5)) * 2 - 1)
+    train = [p[k].requires_grad_(True) for k in ("inst_embeddings", "inst_w0", "inst_w1", "inst_w2")]
+    opt = torch.optim.Adam(train, lr=1e-2, betas=(0.9, 0.99), eps=1e-15)
+    ro, rd = scene_rays(room, n=128, seed=11)
+    _, labels, _ = room.trace(ro, rd)
+    losses = []
+    for _ in range(6):
+        out = render.render_train(ro, rd, p, level_table, room_bitfield, min_near=0.05, with_instance=True)
+        loss = render.instance_ce_loss(out["instance"], labels)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert losses[-1] < losses[0]
