@@ -1,0 +1,171 @@
+/*
+ * inr.h - C ABI of libinr_hip.so: the MI355X (gfx950) implementation of the
+ * instance-field NeRF render/train hot path.
+ *
+ * This is the drop-in boundary.  Every entry point
+ * replaces one function of the reference's torch-ngp extension modules.  Those
+ * modules are an UN-VENDORED SUBMODULE of the reference
+ * (/root/reference/.gitmodules:4-6, pinned in prose at
+ * /root/reference/README.md:27,59 to zymk9/torch-ngp @ 6be6af19), so the
+ * "replaces" notes below name the upstream extension symbol and the survey
+ * row instead of a file:line
+ * inside /root/reference.  The one FFI call site that IS in the reference tree,
+ * roi_align_3d (/root/reference/nerf_rcnn/model/utils.py:608), belongs to the
+ * "next" rows (section 8f) and is not part of this header yet.
+ *
+ * Conventions (chosen to fix the flaws of the reference's only in-tree
+ * extension, /root/reference/nerf_rcnn/model/rotated_iou/cuda_op/):
+ *   - plain pointers and sizes only; all pointers are DEVICE pointers unless
+ *     marked "host"; buffers are owned and sized by the caller; nothing is
+ *     allocated or freed inside the library;
+ *   - every launch goes onto the stream passed in (cf. the default-stream bug at
+ *     sort_vert_kernel.cu:137-138); no call synchronises the device;
+ *   - return value 0 = success, negative = INR_E*; never exit()/abort()
+ *     (cf. cuda_utils.h:26-35); inr_last_error() gives a message for the
+ *     calling thread;
+ *   - arrays are dense row-major, fp32 unless stated.
+ */
+#ifndef INR_H
+#define INR_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define INR_ABI_VERSION 1
+#define INR_MAX_LEVELS 16
+
+enum {
+  INR_OK = 0,
+  INR_EINVAL = -1,   /* bad argument (null pointer, size, unsupported shape) */
+  INR_ELAUNCH = -2,  /* hipLaunch / runtime error, see inr_last_error()       */
+  INR_ENODEV = -3    /* no usable gfx950 device                                */
+};
+
+typedef void* inr_stream_t; /* a hipStream_t; NULL = the null stream */
+
+/* Host-side description of a multiresolution hash grid.  Filled by
+ * the caller (instance_nerf_amd.gridencoder.level_table) so host and device
+ * index from the same numbers. */
+typedef struct inr_grid_desc {
+  int32_t num_levels;                    /* L <= INR_MAX_LEVELS                     */
+  int32_t level_dim;                     /* F, features per row; 2 supported        */
+  uint32_t offsets[INR_MAX_LEVELS + 1];  /* first row of each level; [L] = T        */
+  float scales[INR_MAX_LEVELS];          /* pos = x01 * scale + 0.5                 */
+  uint32_t resolutions[INR_MAX_LEVELS];  /* ceil(scale) + 1; dense stride = res + 1 */
+  uint32_t hashed[INR_MAX_LEVELS];       /* 1: spatial hash, 0: dense index         */
+} inr_grid_desc;
+
+int inr_abi_version(void);
+const char* inr_last_error(void);
+/* Fills props[0..3] = {CU count, wavefront size, LDS bytes per CU, gcn arch number}. */
+int inr_device_info(int32_t device, int64_t* props);
+
+/* ---- rays (replaces raymarching.near_far_from_aabb) ------------------ */
+int inr_near_far_from_aabb(const float* rays_o, const float* rays_d, const float* aabb /*[6]*/,
+                           int64_t N, float min_near, float* nears, float* fars, inr_stream_t s);
+
+/* ---- occupancy helpers (replace raymarching.morton3D / morton3D_invert / packbits, a3) */
+int inr_morton3D(const int32_t* coords /*[N,3]*/, int64_t N, int32_t* indices, inr_stream_t s);
+int inr_morton3D_invert(const int32_t* indices, int64_t N, int32_t* coords /*[N,3]*/, inr_stream_t s);
+/* bitfield[k] bit i = grid[8k+i] > thresh; n_bytes = cells / 8 */
+int inr_packbits(const float* grid, int64_t n_bytes, float thresh, uint8_t* bitfield, inr_stream_t s);
+
+/* ---- training march (replaces raymarching.march_rays_train, a4) ----------------------
+ * Deterministic: sample slots are an exclusive scan of the per-ray counts in ray
+ * order.  Call inr_march_rays_train_count first (fills counts/offsets and
+ * counter[0] = total samples, counter[1] = N), size the outputs (M rows), then
+ * inr_march_rays_train_write.  A ray whose offset + count > M is dropped (its
+ * rays row is still written).  workspace: inr_march_workspace_bytes(N).        */
+int64_t inr_march_workspace_bytes(int64_t N);
+int inr_march_rays_train_count(const float* rays_o, const float* rays_d, const uint8_t* bitfield,
+                               float bound, float dt_gamma, int32_t max_steps, int64_t N,
+                               int32_t cascade, int32_t H, const float* nears, const float* fars,
+                               const float* noises /*nullable*/, int32_t* rays /*[N,3]*/,
+                               int32_t* counter /*[2]*/, void* workspace, inr_stream_t s);
+int inr_march_rays_train_write(const float* rays_o, const float* rays_d, const uint8_t* bitfield,
+                               float bound, float dt_gamma, int32_t max_steps, int64_t N,
+                               int32_t cascade, int32_t H, int64_t M, const float* nears,
+                               const float* fars, const float* noises /*nullable*/,
+                               const int32_t* rays /*[N,3] from _count*/, float* xyzs /*[M,3]*/,
+                               float* dirs /*[M,3]*/, float* deltas /*[M,2]*/, inr_stream_t s);
+
+/* ---- inference march/composite (replace raymarching.march_rays / composite_rays, a5) */
+int inr_march_rays(int64_t n_alive, int32_t n_step, const int32_t* rays_alive, const float* rays_t,
+                   const float* rays_o, const float* rays_d, float bound, float dt_gamma,
+                   int32_t max_steps, int32_t cascade, int32_t H, const uint8_t* bitfield,
+                   const float* nears, const float* fars, float* xyzs, float* dirs, float* deltas,
+                   inr_stream_t s);
+int inr_composite_rays(int64_t n_alive, int32_t n_step, int32_t* rays_alive, float* rays_t,
+                       const float* sigmas, const float* rgbs, const float* deltas,
+                       float* weights_sum, float* depth, float* image, float T_thresh,
+                       const float* extra /*[n_alive*n_step,K] nullable*/, float* extra_acc /*[N,K]*/,
+                       int32_t K, inr_stream_t s);
+/* order-preserving compaction of rays_alive >= 0; n_out (device int32) = survivors */
+int inr_compact_alive(const int32_t* rays_alive, int64_t n_alive, int32_t* out, int32_t* n_out,
+                      inr_stream_t s);
+
+/* ---- compositing for training (replaces raymarching.composite_rays_train fwd/bwd, a12/a13) */
+int inr_composite_rays_train_forward(const float* sigmas, const float* rgbs, const float* deltas,
+                                     const int32_t* rays, int64_t N, float T_thresh,
+                                     const float* extra /*[M,K] nullable*/, int32_t K,
+                                     float* weights_sum, float* depth, float* image,
+                                     float* extra_out /*[N,K]*/, inr_stream_t s);
+int inr_composite_rays_train_backward(const float* grad_weights_sum, const float* grad_image,
+                                      const float* grad_extra_out /*nullable*/, const float* sigmas,
+                                      const float* rgbs, const float* extra, const float* deltas,
+                                      const int32_t* rays, const float* weights_sum,
+                                      const float* image, int64_t N, float T_thresh, int32_t K,
+                                      float* grad_sigmas, float* grad_rgbs,
+                                      float* grad_extra /*[M,K] nullable*/, inr_stream_t s);
+
+/* ---- hash grid (replaces gridencoder grid_encode_forward / _backward, a7/a8) -------- */
+int inr_grid_encode_forward(const float* x /*[M,3]*/, const float* embeddings /*[T,F]*/,
+                            const inr_grid_desc* desc /*host*/, int64_t M, float bound,
+                            float* out /*[M,L*F]*/, inr_stream_t s);
+/* grad_embeddings is ACCUMULATED into (caller zeroes it) */
+int inr_grid_encode_backward(const float* x, const float* grad_out /*[M,L*F]*/,
+                             const inr_grid_desc* desc /*host*/, int64_t M, float bound,
+                             float* grad_embeddings /*[T,F]*/, inr_stream_t s);
+
+/* ---- SH (replaces shencoder sh_encode_forward / _backward, a10) ------------------------ */
+int inr_sh_encode_forward(const float* d /*[M,3]*/, int64_t M, int32_t degree, float* out, inr_stream_t s);
+int inr_sh_encode_backward(const float* grad_out, const float* d, int64_t M, int32_t degree,
+                           float* grad_d, inr_stream_t s);
+
+/* ---- fused field evaluation (replaces NeRFNetwork.forward/density + the fork's
+ * instance head, a9/a13; the MFMA kernel the north star asks for) ---------------------------
+ * Weights are nn.Linear [out,in] row-major fp32, no bias:
+ *   sigma_w0[64,32] sigma_w1[16,64] color_w0[64,31] color_w1[64,64] color_w2[3,64]
+ *   inst_w0[64,32] inst_w1[64,64] inst_w2[K,64] (K <= 64, K % 16 == 0)
+ * inr_field_pack_* reorder them (on the host) into MFMA fragment order; the
+ * packed buffer is then copied to the device by the caller.                              */
+int64_t inr_nerf_packed_floats(void);
+int inr_nerf_pack_weights(const float* sigma_w0, const float* sigma_w1, const float* color_w0,
+                          const float* color_w1, const float* color_w2, float* packed /*host*/);
+int64_t inr_instance_packed_floats(int32_t K);
+int inr_instance_pack_weights(const float* w0, const float* w1, const float* w2, int32_t K,
+                              float* packed /*host*/);
+/* sigma[M] (= exp(h0) * density_scale), rgb[M,3] (nullable -> density only),
+ * geo_feat[M,15] (nullable).  n_samples_dev: optional device int32 holding the
+ * live row count (<= M); rows past it are skipped.                                           */
+int inr_nerf_forward(const float* x, const float* d, int64_t M, const int32_t* n_samples_dev,
+                     float bound, const float* embeddings, const inr_grid_desc* desc /*host*/,
+                     const float* packed /*device*/, float density_scale, float* sigma, float* rgb,
+                     float* geo_feat, inr_stream_t s);
+int inr_instance_forward(const float* x, int64_t M, const int32_t* n_samples_dev, float bound,
+                         const float* embeddings, const inr_grid_desc* desc /*host*/,
+                         const float* packed /*device*/, int32_t K, float* logits /*[M,K]*/,
+                         inr_stream_t s);
+
+/* ---- optimiser (replaces the Trainer's torch.optim.Adam sweep over the table, a15) ------ */
+int inr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                  float lr, float beta1, float beta2, float eps, int32_t step, float grad_scale,
+                  inr_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* INR_H */

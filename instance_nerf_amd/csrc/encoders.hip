@@ -1,0 +1,224 @@
+// Stand-alone encoders and the optimiser sweep for gfx950:
+//   hash-grid forward / backward, SH-4 forward / backward (a10), fused Adam (a15).
+// Compiled with -ffp-contract=off so that cell selection (floor of x01*scale+0.5) is the same
+// decision the CPU oracle takes; value blending uses explicit fmaf where it pays.
+//
+// These are the API-parity kernels (gridencoder / shencoder modules).  The render hot path
+// uses the fused kernel in field_fused.hip, which shares grid_common.h with this file.
+#include "common.h"
+#include "grid_common.h"
+
+namespace inr {
+
+// One lane per (sample, level): 16 consecutive lanes write one sample's 128-byte feature row,
+// so the [M, L*F] output is written fully coalesced; gathers are 8 B (float2) per corner.
+__global__ void __launch_bounds__(256) k_grid_fwd(const float* __restrict__ x, const float2* __restrict__ emb,
+                                                  GridDesc G, int64_t M, float bound, float2* __restrict__ out) {
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int L = G.num_levels;
+  const int64_t m = tid / L;
+  const int l = (int)(tid - m * L);
+  if (m >= M) return;
+  const float rb = 2.0f * bound;
+  const float x0 = (x[m * 3 + 0] + bound) / rb;
+  const float x1 = (x[m * 3 + 1] + bound) / rb;
+  const float x2 = (x[m * 3 + 2] + bound) / rb;
+  Cell c;
+  locate(G, l, x0, x1, x2, c);
+  float2 acc = make_float2(0.f, 0.f);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float w = corner_weight(c, k);
+    const float2 v = emb[G.offsets[l] + corner_index(G, l, c, k)];
+    acc.x = fmaf(w, v.x, acc.x);
+    acc.y = fmaf(w, v.y, acc.y);
+  }
+  out[m * L + l] = acc;
+}
+
+// Scatter-add of w * dL/dy into the table gradient.  Hardware fp32 atomics
+// (-munsafe-fp-atomics -> global_atomic_add_f32, executed at L2).
+__global__ void __launch_bounds__(256) k_grid_bwd(const float* __restrict__ x, const float2* __restrict__ gout,
+                                                  GridDesc G, int64_t M, float bound, float* __restrict__ gemb) {
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int L = G.num_levels;
+  const int64_t m = tid / L;
+  const int l = (int)(tid - m * L);
+  if (m >= M) return;
+  const float rb = 2.0f * bound;
+  const float x0 = (x[m * 3 + 0] + bound) / rb;
+  const float x1 = (x[m * 3 + 1] + bound) / rb;
+  const float x2 = (x[m * 3 + 2] + bound) / rb;
+  Cell c;
+  locate(G, l, x0, x1, x2, c);
+  const float2 g = gout[m * L + l];
+  if (g.x == 0.0f && g.y == 0.0f) return;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float w = corner_weight(c, k);
+    float* p = gemb + 2 * (size_t)(G.offsets[l] + corner_index(G, l, c, k));
+    atomicAdd(p, w * g.x);
+    atomicAdd(p + 1, w * g.y);
+  }
+}
+
+// ---- SH ------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_sh_fwd(const float* __restrict__ d, int64_t M, int degree,
+                                                float* __restrict__ out) {
+  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  float v[16];
+  sh4(d[m * 3], d[m * 3 + 1], d[m * 3 + 2], v);
+  const int C = degree * degree;
+  for (int i = 0; i < C; ++i) out[m * C + i] = v[i];
+}
+
+__global__ void __launch_bounds__(256) k_sh_bwd(const float* __restrict__ go, const float* __restrict__ d,
+                                                int64_t M, int degree, float* __restrict__ gd) {
+  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  const float x = d[m * 3], y = d[m * 3 + 1], z = d[m * 3 + 2];
+  const int C = degree * degree;
+  const float* g = go + m * C;
+  float gx = 0, gy = 0, gz = 0;
+  if (degree > 1) {
+    gy += -0.48860251190291987f * g[1];
+    gz += 0.48860251190291987f * g[2];
+    gx += -0.48860251190291987f * g[3];
+  }
+  if (degree > 2) {
+    gx += 1.0925484305920792f * y * g[4];  gy += 1.0925484305920792f * x * g[4];
+    gy += -1.0925484305920792f * z * g[5]; gz += -1.0925484305920792f * y * g[5];
+    gz += 2.0f * 0.94617469575755997f * z * g[6];
+    gx += -1.0925484305920792f * z * g[7]; gz += -1.0925484305920792f * x * g[7];
+    gx += 2.0f * 0.54627421529603959f * x * g[8]; gy += -2.0f * 0.54627421529603959f * y * g[8];
+  }
+  if (degree > 3) {
+    const float x2 = x * x, y2 = y * y, z2 = z * z;
+    // 9: a*y*(-3x^2+y^2)
+    gx += 0.59004358992664352f * (-6.0f * x * y) * g[9];
+    gy += 0.59004358992664352f * (-3.0f * x2 + 3.0f * y2) * g[9];
+    // 10: b*x*y*z
+    gx += 2.8906114426405538f * y * z * g[10]; gy += 2.8906114426405538f * x * z * g[10];
+    gz += 2.8906114426405538f * x * y * g[10];
+    // 11: c*y*(1-5z^2)
+    gy += 0.45704579946446572f * (1.0f - 5.0f * z2) * g[11]; gz += 0.45704579946446572f * (-10.0f * y * z) * g[11];
+    // 12: e*z*(5z^2-3)
+    gz += 0.3731763325901154f * (15.0f * z2 - 3.0f) * g[12];
+    // 13: c*x*(1-5z^2)
+    gx += 0.45704579946446572f * (1.0f - 5.0f * z2) * g[13]; gz += 0.45704579946446572f * (-10.0f * x * z) * g[13];
+    // 14: f*z*(x^2-y^2)
+    gx += 1.4453057213202769f * 2.0f * x * z * g[14]; gy += -1.4453057213202769f * 2.0f * y * z * g[14];
+    gz += 1.4453057213202769f * (x2 - y2) * g[14];
+    // 15: a*x*(-x^2+3y^2)
+    gx += 0.59004358992664352f * (-3.0f * x2 + 3.0f * y2) * g[15];
+    gy += 0.59004358992664352f * (6.0f * x * y) * g[15];
+  }
+  gd[m * 3] = gx; gd[m * 3 + 1] = gy; gd[m * 3 + 2] = gz;
+}
+
+// ---- Adam: one read of p,g,m,v and one write of p,m,v per element, 16 B per lane -------------
+__global__ void __launch_bounds__(256) k_adam(float4* __restrict__ p, const float4* __restrict__ g,
+                                              float4* __restrict__ m, float4* __restrict__ v, int64_t n4,
+                                              float lr_t, float b1, float b2, float eps_t, float gscale) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    float4 pp = p[i], gg = g[i], mm = m[i], vv = v[i];
+#define INR_ADAM1(c)                                   \
+  {                                                    \
+    const float gr = gg.c * gscale;                    \
+    mm.c = b1 * mm.c + (1.0f - b1) * gr;               \
+    vv.c = b2 * vv.c + (1.0f - b2) * gr * gr;          \
+    pp.c = pp.c - lr_t * mm.c / (sqrtf(vv.c) + eps_t); \
+  }
+    INR_ADAM1(x) INR_ADAM1(y) INR_ADAM1(z) INR_ADAM1(w)
+#undef INR_ADAM1
+    p[i] = pp; m[i] = mm; v[i] = vv;
+  }
+}
+__global__ void k_adam_tail(float* p, const float* g, float* m, float* v, int64_t start, int64_t n, float lr_t,
+                            float b1, float b2, float eps_t, float gscale) {
+  const int64_t i = start + threadIdx.x;
+  if (i >= n) return;
+  const float gr = g[i] * gscale;
+  const float mm = b1 * m[i] + (1.0f - b1) * gr;
+  const float vv = b2 * v[i] + (1.0f - b2) * gr * gr;
+  m[i] = mm; v[i] = vv;
+  p[i] = p[i] - lr_t * mm / (sqrtf(vv) + eps_t);
+}
+
+}  // namespace inr
+
+using namespace inr;
+
+extern "C" {
+
+int inr_grid_encode_forward(const float* x, const float* embeddings, const inr_grid_desc* desc, int64_t M,
+                            float bound, float* out, inr_stream_t s) {
+  INR_REQUIRE(x && embeddings && desc && out && M >= 0, "bad argument");
+  GridDesc G;
+  int rc = make_grid_desc(desc, G);
+  if (rc) return rc;
+  INR_REQUIRE(((uintptr_t)embeddings & 7) == 0 && ((uintptr_t)out & 7) == 0, "embeddings/out must be 8-byte aligned");
+  if (M == 0) return INR_OK;
+  const int64_t total = M * G.num_levels;
+  k_grid_fwd<<<blocks_for(total, 256), 256, 0, as_stream(s)>>>(x, reinterpret_cast<const float2*>(embeddings), G, M,
+                                                               bound, reinterpret_cast<float2*>(out));
+  return check_launch("grid_encode_forward");
+}
+
+int inr_grid_encode_backward(const float* x, const float* grad_out, const inr_grid_desc* desc, int64_t M, float bound,
+                             float* grad_embeddings, inr_stream_t s) {
+  INR_REQUIRE(x && grad_out && desc && grad_embeddings && M >= 0, "bad argument");
+  GridDesc G;
+  int rc = make_grid_desc(desc, G);
+  if (rc) return rc;
+  INR_REQUIRE(((uintptr_t)grad_out & 7) == 0, "grad_out must be 8-byte aligned");
+  if (M == 0) return INR_OK;
+  const int64_t total = M * G.num_levels;
+  k_grid_bwd<<<blocks_for(total, 256), 256, 0, as_stream(s)>>>(x, reinterpret_cast<const float2*>(grad_out), G, M,
+                                                               bound, grad_embeddings);
+  return check_launch("grid_encode_backward");
+}
+
+int inr_sh_encode_forward(const float* d, int64_t M, int32_t degree, float* out, inr_stream_t s) {
+  INR_REQUIRE(d && out && M >= 0, "bad argument");
+  INR_REQUIRE(degree >= 1 && degree <= 4, "degree must be 1..4");
+  if (M == 0) return INR_OK;
+  k_sh_fwd<<<blocks_for(M, 256), 256, 0, as_stream(s)>>>(d, M, degree, out);
+  return check_launch("sh_encode_forward");
+}
+
+int inr_sh_encode_backward(const float* grad_out, const float* d, int64_t M, int32_t degree, float* grad_d,
+                           inr_stream_t s) {
+  INR_REQUIRE(grad_out && d && grad_d && M >= 0, "bad argument");
+  INR_REQUIRE(degree >= 1 && degree <= 4, "degree must be 1..4");
+  if (M == 0) return INR_OK;
+  k_sh_bwd<<<blocks_for(M, 256), 256, 0, as_stream(s)>>>(grad_out, d, M, degree, grad_d);
+  return check_launch("sh_encode_backward");
+}
+
+int inr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                  float beta1, float beta2, float eps, int32_t step, float grad_scale, inr_stream_t s) {
+  INR_REQUIRE(param && grad && exp_avg && exp_avg_sq && n >= 0 && step >= 1, "bad argument");
+  if (n == 0) return INR_OK;
+  // torch.optim.Adam: p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
+  //                     = (lr*sqrt(bc2)/bc1) * m / (sqrt(v) + eps*sqrt(bc2))
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  const float lr_t = (float)(lr * sqrt(bc2) / bc1);
+  const float eps_t = (float)(eps * sqrt(bc2));
+  const bool aligned = (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0;
+  const int64_t n4 = aligned ? n / 4 : 0;
+  hipStream_t st = as_stream(s);
+  if (n4) {
+    const unsigned nb = (unsigned)std::min<int64_t>((n4 + 255) / 256, 256 * 16);
+    k_adam<<<nb, 256, 0, st>>>(reinterpret_cast<float4*>(param), reinterpret_cast<const float4*>(grad),
+                               reinterpret_cast<float4*>(exp_avg), reinterpret_cast<float4*>(exp_avg_sq), n4, lr_t,
+                               beta1, beta2, eps_t, grad_scale);
+  }
+  for (int64_t start = n4 * 4; start < n; start += 1024)
+    k_adam_tail<<<1, 1024, 0, st>>>(param, grad, exp_avg, exp_avg_sq, start, std::min<int64_t>(n, start + 1024), lr_t,
+                                    beta1, beta2, eps_t, grad_scale);
+  return check_launch("adam_step");
+}
+
+}  // extern "C"

@@ -1,0 +1,325 @@
+// Fused field evaluation for gfx950 (SURVEY a7 + a9 + a10 + a13): hash-grid gather, SH-4 and
+// the sigma / colour / instance MLPs in ONE kernel; the 32 encoded features and all hidden
+// activations live in registers and never touch HBM.
+//
+// MLP on the matrix cores, exact fp32: v_mfma_f32_16x16x4_f32 (A, B one f32 VGPR per lane;
+// A[i=lane&15][k=lane>>4], B[k=lane>>4][j=lane&15], D[i=4*(lane>>4)+r][j=lane&15]).
+//
+// Transposed formulation - H^T = W * X^T - with a 16-sample tile per wave:
+//   * B operand = activations: lane (q = lane>>4, j = lane&15) holds input k-slot q of sample j;
+//   * A operand = weights:     lane holds W[out = 16*mt + j][k-slot q], pre-packed on the host
+//     into fragment order and staged once per workgroup in LDS (40 KB, ds_read_b128);
+//   * D = 16 outputs x 16 samples: lane (q, j), register r holds output 4q+r of sample j.
+// A dot product does not care in which order k is visited, so the k-step (nt, r) of the next
+// layer is DEFINED to cover inputs {16nt + 4q + r : q = 0..3}: that is exactly register r of
+// output tile nt of the previous layer.  Layer outputs therefore feed the next layer's B
+// operand in place - no LDS transpose, no cross-lane traffic between layers.
+// The same trick places the encoder: lane q of a sample owns levels {2q, 2q+1, 8+2q, 9+2q}
+// (features 16*(s>>2) + 4q + (s&3), s = 0..7), so four lanes share one sample's 128 gathers.
+//
+// Compiled with -ffp-contract=off (cell selection is the oracle's decision); blending and the
+// MFMA chain are explicit fmaf / MFMA.
+#include "common.h"
+#include "grid_common.h"
+
+namespace inr {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kHidden = 64;
+// packed-buffer section offsets, in floats
+constexpr int kSig0 = 0;                       // 64 x 32  : 4 mt x 8 ks
+constexpr int kSig1 = kSig0 + 64 * 32;         // 16 x 64  : 1 mt x 16 ks
+constexpr int kCol0 = kSig1 + 16 * 64;         // 64 x 32  : 4 mt x 8 ks   (16 sh + 16 sigma-net rows)
+constexpr int kCol1 = kCol0 + 64 * 32;         // 64 x 64  : 4 mt x 16 ks
+constexpr int kCol2 = kCol1 + 64 * 64;         // 16 x 64  : 1 mt x 16 ks  (3 live rows)
+constexpr int kNerfFloats = kCol2 + 16 * 64;   // 10240 floats = 40 KB
+constexpr int kIns0 = 0;                       // 64 x 32
+constexpr int kIns1 = kIns0 + 64 * 32;         // 64 x 64
+constexpr int kIns2 = kIns1 + 64 * 64;         // K x 64   : K/16 mt x 16 ks
+
+// position of fragment value (mt, ks, lane) inside a section with n_ks k-steps
+__host__ __device__ inline int frag_pos(int mt, int ks, int lane, int n_ks) {
+  return ((mt * (n_ks / 4) + ks / 4) * 64 + lane) * 4 + (ks & 3);
+}
+
+__device__ __forceinline__ f32x4 mfma4(const float4 a, const f32x4 b, f32x4 c) {
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b[0], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b[1], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b[2], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b[3], c, 0, 0, 0);
+  return c;
+}
+__device__ __forceinline__ f32x4 relu4(f32x4 v) {
+  v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+  return v;
+}
+
+// One lane's share of the encoder: 4 levels x 8 corners x float2 for sample x01.
+// out[s], s = 0..7 <-> feature 16*(s>>2) + 4q + (s&3).
+__device__ __forceinline__ void encode_quarter(const GridDesc& G, const float2* __restrict__ emb, int q, float x0,
+                                               float x1, float x2, f32x4& lo, f32x4& hi) {
+  float f[8];
+#pragma unroll
+  for (int li = 0; li < 4; ++li) {
+    const int l = (li >> 1) * 8 + 2 * q + (li & 1);
+    float ax = 0.f, ay = 0.f;
+    if (l < G.num_levels) {
+      Cell c;
+      locate(G, l, x0, x1, x2, c);
+      const float2* base = emb + G.offsets[l];
+      float2 v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = base[corner_index(G, l, c, k)];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float w = corner_weight(c, k);
+        ax = fmaf(w, v[k].x, ax);
+        ay = fmaf(w, v[k].y, ay);
+      }
+    }
+    f[2 * li] = ax;
+    f[2 * li + 1] = ay;
+  }
+  lo[0] = f[0]; lo[1] = f[1]; lo[2] = f[2]; lo[3] = f[3];
+  hi[0] = f[4]; hi[1] = f[5]; hi[2] = f[6]; hi[3] = f[7];
+}
+
+// 64-wide layer: out[mt] = sum over n_in4 groups of 4 k-steps.  in[g] is the B operand of group g.
+template <int N_MT, int N_G>
+__device__ __forceinline__ void layer(const float4* __restrict__ w, int lane, const f32x4* in, f32x4* out) {
+#pragma unroll
+  for (int mt = 0; mt < N_MT; ++mt) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < N_G; ++g) acc = mfma4(w[(mt * N_G + g) * 64 + lane], in[g], acc);
+    out[mt] = acc;
+  }
+}
+
+__device__ __forceinline__ float select4(int q, float a, float b, float c, float d) {
+  return q == 0 ? a : (q == 1 ? b : (q == 2 ? c : d));
+}
+
+template <bool kColor>
+__global__ void __launch_bounds__(256) k_nerf_fwd(const float* __restrict__ x, const float* __restrict__ d,
+                                                  int64_t M, const int32_t* __restrict__ n_dev, float bound,
+                                                  const float2* __restrict__ emb, GridDesc G,
+                                                  const float4* __restrict__ packed, float density_scale,
+                                                  float* __restrict__ sigma, float* __restrict__ rgb,
+                                                  float* __restrict__ geo) {
+  extern __shared__ __attribute__((aligned(16))) float4 wl[];
+  constexpr int kStage = (kColor ? kNerfFloats : kCol0) / 4;
+  for (int i = threadIdx.x; i < kStage; i += 256) wl[i] = packed[i];
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, q = lane >> 4, j = lane & 15;
+  int64_t n = M;
+  if (n_dev) n = min((int64_t)*n_dev, M);
+  const int64_t n_tiles = (n + 15) >> 4;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * 4;
+  const float rb = 2.0f * bound;
+
+  for (int64_t tile = wave; tile < n_tiles; tile += n_waves) {
+    const int64_t m = tile * 16 + j;
+    const bool valid = m < n;
+    const int64_t mc = valid ? m : n - 1;
+    const float x0 = (x[mc * 3 + 0] + bound) / rb;
+    const float x1 = (x[mc * 3 + 1] + bound) / rb;
+    const float x2 = (x[mc * 3 + 2] + bound) / rb;
+
+    f32x4 enc[2];
+    encode_quarter(G, emb, q, x0, x1, x2, enc[0], enc[1]);
+
+    f32x4 h1[4];
+    layer<4, 2>(wl + kSig0 / 4, lane, enc, h1);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) h1[t] = relu4(h1[t]);
+    f32x4 h2[1];
+    layer<1, 4>(wl + kSig1 / 4, lane, h1, h2);      // row 0 = raw density, rows 1..15 = geo features
+
+    if (valid) {
+      if (q == 0) sigma[m] = expf(h2[0][0]) * density_scale;
+      if (geo) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 4 * q + r;
+          if (row >= 1) geo[m * 15 + row - 1] = h2[0][r];
+        }
+      }
+    }
+
+    if constexpr (kColor) {
+      float sh[16];
+      sh4(d[mc * 3], d[mc * 3 + 1], d[mc * 3 + 2], sh);
+      f32x4 cin[2];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) cin[0][ks] = select4(q, sh[4 * ks], sh[4 * ks + 1], sh[4 * ks + 2], sh[4 * ks + 3]);
+      cin[1] = h2[0];                                 // k-slot (q, r) = sigma-net row 4q+r (row 0 has zero weight)
+      f32x4 c1[4], c2[4], o[1];
+      layer<4, 2>(wl + kCol0 / 4, lane, cin, c1);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) c1[t] = relu4(c1[t]);
+      layer<4, 4>(wl + kCol1 / 4, lane, c1, c2);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) c2[t] = relu4(c2[t]);
+      layer<1, 4>(wl + kCol2 / 4, lane, c2, o);
+      if (valid && q == 0) {
+        rgb[m * 3 + 0] = 1.0f / (1.0f + expf(-o[0][0]));
+        rgb[m * 3 + 1] = 1.0f / (1.0f + expf(-o[0][1]));
+        rgb[m * 3 + 2] = 1.0f / (1.0f + expf(-o[0][2]));
+      }
+    }
+  }
+}
+
+template <int K_MT>
+__global__ void __launch_bounds__(256) k_instance_fwd(const float* __restrict__ x, int64_t M,
+                                                      const int32_t* __restrict__ n_dev, float bound,
+                                                      const float2* __restrict__ emb, GridDesc G,
+                                                      const float4* __restrict__ packed, float* __restrict__ logits) {
+  extern __shared__ __attribute__((aligned(16))) float4 wl[];
+  constexpr int K = K_MT * 16;
+  constexpr int kStage = (kIns2 + K * 64) / 4;
+  for (int i = threadIdx.x; i < kStage; i += 256) wl[i] = packed[i];
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, q = lane >> 4, j = lane & 15;
+  int64_t n = M;
+  if (n_dev) n = min((int64_t)*n_dev, M);
+  const int64_t n_tiles = (n + 15) >> 4;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * 4;
+  const float rb = 2.0f * bound;
+
+  for (int64_t tile = wave; tile < n_tiles; tile += n_waves) {
+    const int64_t m = tile * 16 + j;
+    const bool valid = m < n;
+    const int64_t mc = valid ? m : n - 1;
+    const float x0 = (x[mc * 3 + 0] + bound) / rb;
+    const float x1 = (x[mc * 3 + 1] + bound) / rb;
+    const float x2 = (x[mc * 3 + 2] + bound) / rb;
+    f32x4 enc[2];
+    encode_quarter(G, emb, q, x0, x1, x2, enc[0], enc[1]);
+    f32x4 h1[4], h2[4], o[K_MT];
+    layer<4, 2>(wl + kIns0 / 4, lane, enc, h1);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) h1[t] = relu4(h1[t]);
+    layer<4, 4>(wl + kIns1 / 4, lane, h1, h2);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) h2[t] = relu4(h2[t]);
+    layer<K_MT, 4>(wl + kIns2 / 4, lane, h2, o);
+    if (valid) {
+#pragma unroll
+      for (int mt = 0; mt < K_MT; ++mt) {
+        float4 v = make_float4(o[mt][0], o[mt][1], o[mt][2], o[mt][3]);
+        *reinterpret_cast<float4*>(logits + m * K + 16 * mt + 4 * q) = v;
+      }
+    }
+  }
+}
+
+// ---- host-side packing into fragment order ------------------------------------------------------
+// W is [n_out, n_in] row-major.  kidx(ks, q) -> input column (or -1 for a zero slot).
+template <class KIdx>
+static void pack_section(float* dst, const float* W, int n_out, int n_in, int n_mt, int n_ks, KIdx kidx) {
+  for (int mt = 0; mt < n_mt; ++mt)
+    for (int ks = 0; ks < n_ks; ++ks)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int row = 16 * mt + (lane & 15);
+        const int col = kidx(ks, lane >> 4);
+        float v = 0.f;
+        if (row < n_out && col >= 0 && col < n_in) v = W[(size_t)row * n_in + col];
+        dst[frag_pos(mt, ks, lane, n_ks)] = v;
+      }
+}
+static int kidx_enc(int ks, int q) { return 16 * (ks >> 2) + 4 * q + (ks & 3); }      // encoder features
+static int kidx_hidden(int ks, int q) { return 16 * (ks >> 2) + 4 * q + (ks & 3); }   // previous D registers
+static int kidx_color_in(int ks, int q) {
+  if (ks < 4) return 4 * ks + q;                 // sh component
+  const int row = 4 * q + (ks - 4);              // sigma-net output row feeding this slot
+  return row >= 1 ? 16 + row - 1 : -1;           // row 0 is the raw density: not an input
+}
+
+static int grid_for(int64_t n_tiles) {
+  // persistent waves: 256 CUs x up to 3 workgroups (40 KB LDS, ~<=168 VGPRs each)
+  const int64_t want = (n_tiles + 3) / 4;
+  return (int)std::max<int64_t>(1, std::min<int64_t>(want, 256 * 3));
+}
+
+}  // namespace inr
+
+using namespace inr;
+
+extern "C" {
+
+int64_t inr_nerf_packed_floats(void) { return kNerfFloats; }
+
+int inr_nerf_pack_weights(const float* sigma_w0, const float* sigma_w1, const float* color_w0, const float* color_w1,
+                          const float* color_w2, float* packed) {
+  INR_REQUIRE(sigma_w0 && sigma_w1 && color_w0 && color_w1 && color_w2 && packed, "null pointer");
+  pack_section(packed + kSig0, sigma_w0, 64, 32, 4, 8, kidx_enc);
+  pack_section(packed + kSig1, sigma_w1, 16, 64, 1, 16, kidx_hidden);
+  pack_section(packed + kCol0, color_w0, 64, 31, 4, 8, kidx_color_in);
+  pack_section(packed + kCol1, color_w1, 64, 64, 4, 16, kidx_hidden);
+  pack_section(packed + kCol2, color_w2, 3, 64, 1, 16, kidx_hidden);
+  return INR_OK;
+}
+
+int64_t inr_instance_packed_floats(int32_t K) { return (K > 0 && K <= 64 && K % 16 == 0) ? kIns2 + K * 64 : -1; }
+
+int inr_instance_pack_weights(const float* w0, const float* w1, const float* w2, int32_t K, float* packed) {
+  INR_REQUIRE(w0 && w1 && w2 && packed, "null pointer");
+  INR_REQUIRE(K > 0 && K <= 64 && K % 16 == 0, "K must be 16, 32, 48 or 64");
+  pack_section(packed + kIns0, w0, 64, 32, 4, 8, kidx_enc);
+  pack_section(packed + kIns1, w1, 64, 64, 4, 16, kidx_hidden);
+  pack_section(packed + kIns2, w2, K, 64, K / 16, 16, kidx_hidden);
+  return INR_OK;
+}
+
+int inr_nerf_forward(const float* x, const float* d, int64_t M, const int32_t* n_samples_dev, float bound,
+                     const float* embeddings, const inr_grid_desc* desc, const float* packed, float density_scale,
+                     float* sigma, float* rgb, float* geo_feat, inr_stream_t s) {
+  INR_REQUIRE(x && embeddings && desc && packed && sigma && M >= 0, "bad argument");
+  INR_REQUIRE(!rgb || d, "rgb requested without view directions");
+  INR_REQUIRE(((uintptr_t)embeddings & 7) == 0 && ((uintptr_t)packed & 15) == 0, "embeddings/packed misaligned");
+  GridDesc G;
+  int rc = make_grid_desc(desc, G);
+  if (rc) return rc;
+  if (M == 0) return INR_OK;
+  const int grid = grid_for((M + 15) / 16);
+  const float2* e = reinterpret_cast<const float2*>(embeddings);
+  const float4* p = reinterpret_cast<const float4*>(packed);
+  if (rgb)
+    k_nerf_fwd<true><<<grid, 256, kNerfFloats * sizeof(float), as_stream(s)>>>(x, d, M, n_samples_dev, bound, e, G, p,
+                                                                             density_scale, sigma, rgb, geo_feat);
+  else
+    k_nerf_fwd<false><<<grid, 256, kCol0 * sizeof(float), as_stream(s)>>>(x, d, M, n_samples_dev, bound, e, G, p,
+                                                                        density_scale, sigma, nullptr, geo_feat);
+  return check_launch("nerf_forward");
+}
+
+int inr_instance_forward(const float* x, int64_t M, const int32_t* n_samples_dev, float bound, const float* embeddings,
+                         const inr_grid_desc* desc, const float* packed, int32_t K, float* logits, inr_stream_t s) {
+  INR_REQUIRE(x && embeddings && desc && packed && logits && M >= 0, "bad argument");
+  INR_REQUIRE(K > 0 && K <= 64 && K % 16 == 0, "K must be 16, 32, 48 or 64");
+  INR_REQUIRE(((uintptr_t)embeddings & 7) == 0 && ((uintptr_t)packed & 15) == 0 && ((uintptr_t)logits & 15) == 0,
+              "embeddings/packed/logits misaligned");
+  GridDesc G;
+  int rc = make_grid_desc(desc, G);
+  if (rc) return rc;
+  if (M == 0) return INR_OK;
+  const int grid = grid_for((M + 15) / 16);
+  const float2* e = reinterpret_cast<const float2*>(embeddings);
+  const float4* p = reinterpret_cast<const float4*>(packed);
+  const size_t lds = (size_t)(kIns2 + K * 64) * sizeof(float);
+  hipStream_t st = as_stream(s);
+  switch (K / 16) {
+    case 1: k_instance_fwd<1><<<grid, 256, lds, st>>>(x, M, n_samples_dev, bound, e, G, p, logits); break;
+    case 2: k_instance_fwd<2><<<grid, 256, lds, st>>>(x, M, n_samples_dev, bound, e, G, p, logits); break;
+    case 3: k_instance_fwd<3><<<grid, 256, lds, st>>>(x, M, n_samples_dev, bound, e, G, p, logits); break;
+    default: k_instance_fwd<4><<<grid, 256, lds, st>>>(x, M, n_samples_dev, bound, e, G, p, logits); break;
+  }
+  return check_launch("instance_forward");
+}
+
+}  // extern "C"

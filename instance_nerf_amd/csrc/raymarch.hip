@@ -1,0 +1,646 @@
+// Ray / occupancy-grid kernels for gfx950.
+//
+// This file is compiled with -ffp-contract=off: the ray-marching arithmetic is a
+// bit-exact contract with oracle/march.py (one IEEE binary32 operation per
+// written operation, no FMA), so sample positions, counts and offsets match the
+// CPU oracle exactly.  Integer/byte work here is HBM/latency bound - no MFMA.
+#include "common.h"
+
+namespace inr {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+constexpr int kRayBlock = 256;
+constexpr float kSqrt3x2 = 3.4641016151377544f;
+
+// ------------------------------------------------------------------------------------------
+// a2: ray / AABB slab test
+__global__ void __launch_bounds__(kRayBlock) k_near_far(const float* __restrict__ rays_o,
+                                                        const float* __restrict__ rays_d,
+                                                        const float* __restrict__ aabb, int64_t N,
+                                                        float min_near, float* __restrict__ nears,
+                                                        float* __restrict__ fars) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float near = -INFINITY, far = INFINITY;
+  bool miss = false;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float o = rays_o[n * 3 + a];
+    const float rd = 1.0f / rays_d[n * 3 + a];
+    const float t0 = (aabb[a] - o) * rd;
+    const float t1 = (aabb[a + 3] - o) * rd;
+    const float lo = t0 > t1 ? t1 : t0;
+    const float hi = t0 > t1 ? t0 : t1;
+    if (a > 0) miss = miss || (near > hi) || (lo > far);
+    near = lo > near ? lo : near;
+    far = hi < far ? hi : far;
+  }
+  if (near < min_near) near = min_near;
+  nears[n] = miss ? 3.402823466e+38f : near;
+  fars[n] = miss ? 3.402823466e+38f : far;
+}
+
+// ------------------------------------------------------------------------------------------
+// a3: morton / packbits
+__global__ void k_morton3D(const int32_t* __restrict__ coords, int64_t N, int32_t* __restrict__ out) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  out[n] = (int32_t)morton3((uint32_t)coords[n * 3], (uint32_t)coords[n * 3 + 1], (uint32_t)coords[n * 3 + 2]);
+}
+__global__ void k_morton3D_invert(const int32_t* __restrict__ idx, int64_t N, int32_t* __restrict__ coords) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const uint32_t m = (uint32_t)idx[n];
+  coords[n * 3 + 0] = (int32_t)compact_bits10(m);
+  coords[n * 3 + 1] = (int32_t)compact_bits10(m >> 1);
+  coords[n * 3 + 2] = (int32_t)compact_bits10(m >> 2);
+}
+__global__ void k_packbits(const float* __restrict__ grid, int64_t n_bytes, float thresh,
+                           uint8_t* __restrict__ bits) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= n_bytes) return;
+  const float4 a = reinterpret_cast<const float4*>(grid)[n * 2];
+  const float4 b = reinterpret_cast<const float4*>(grid)[n * 2 + 1];
+  uint32_t v = (a.x > thresh) | ((a.y > thresh) << 1) | ((a.z > thresh) << 2) | ((a.w > thresh) << 3) |
+               ((b.x > thresh) << 4) | ((b.y > thresh) << 5) | ((b.z > thresh) << 6) | ((b.w > thresh) << 7);
+  bits[n] = (uint8_t)v;
+}
+
+// ------------------------------------------------------------------------------------------
+// The marcher.  Operation order is the contract written at the top of oracle/march.py.
+struct MarchParams {
+  const uint8_t* bits;
+  float bound, dt_gamma, dt_min, dt_max, rH;
+  int C, H, H3;
+};
+
+struct Ray {
+  float ox, oy, oz, dx, dy, dz, rdx, rdy, rdz, sx, sy, sz;
+};
+
+__device__ __forceinline__ Ray load_ray(const float* __restrict__ o, const float* __restrict__ d, int64_t n) {
+  Ray r;
+  r.ox = o[n * 3]; r.oy = o[n * 3 + 1]; r.oz = o[n * 3 + 2];
+  r.dx = d[n * 3]; r.dy = d[n * 3 + 1]; r.dz = d[n * 3 + 2];
+  r.rdx = 1.0f / r.dx; r.rdy = 1.0f / r.dy; r.rdz = 1.0f / r.dz;
+  r.sx = copysignf(1.0f, r.dx); r.sy = copysignf(1.0f, r.dy); r.sz = copysignf(1.0f, r.dz);
+  return r;
+}
+
+__device__ __forceinline__ float step_dt(const MarchParams& P, float t) {
+  return clampf(t * P.dt_gamma, P.dt_min, P.dt_max);
+}
+
+// Marches from t until t >= far or max_emit samples were emitted.  emit(px,py,pz,dt,delta).
+template <class Emit>
+__device__ __forceinline__ int march_ray(const MarchParams& P, const Ray& r, float t, float far,
+                                         int max_emit, Emit&& emit) {
+  int n = 0;
+  float last_t = t;
+  while (t < far && n < max_emit) {
+    const float px = clampf(r.ox + t * r.dx, -P.bound, P.bound);
+    const float py = clampf(r.oy + t * r.dy, -P.bound, P.bound);
+    const float pz = clampf(r.oz + t * r.dz, -P.bound, P.bound);
+    const float dt = step_dt(P, t);
+    int e0, e1;
+    (void)frexpf(fmaxf(fabsf(px), fmaxf(fabsf(py), fabsf(pz))), &e0);
+    (void)frexpf(dt * (float)P.H * 0.5f, &e1);
+    const int level = max(clampi(e0, 0, P.C - 1), clampi(e1, 0, P.C - 1));
+    const float mb = fminf(ldexpf(1.0f, level), P.bound);
+    const float rmb = 1.0f / mb;
+    const int nx = clampi((int)(((px * rmb + 1.0f) * 0.5f) * (float)P.H), 0, P.H - 1);
+    const int ny = clampi((int)(((py * rmb + 1.0f) * 0.5f) * (float)P.H), 0, P.H - 1);
+    const int nz = clampi((int)(((pz * rmb + 1.0f) * 0.5f) * (float)P.H), 0, P.H - 1);
+    const uint32_t idx = (uint32_t)level * (uint32_t)P.H3 + morton3((uint32_t)nx, (uint32_t)ny, (uint32_t)nz);
+    const bool occ = (P.bits[idx >> 3] >> (idx & 7)) & 1;
+    if (occ) {
+      const float tn = t + dt;
+      emit(px, py, pz, dt, tn - last_t);
+      t = tn;
+      last_t = tn;
+      ++n;
+    } else {
+      const float ax = ((float)nx + 0.5f) + 0.5f * r.sx;
+      const float ay = ((float)ny + 0.5f) + 0.5f * r.sy;
+      const float az = ((float)nz + 0.5f) + 0.5f * r.sz;
+      const float cx = (((ax * P.rH) * 2.0f - 1.0f) * mb - px) * r.rdx;
+      const float cy = (((ay * P.rH) * 2.0f - 1.0f) * mb - py) * r.rdy;
+      const float cz = (((az * P.rH) * 2.0f - 1.0f) * mb - pz) * r.rdz;
+      const float tt = t + fmaxf(0.0f, fminf(cx, fminf(cy, cz)));
+      do {
+        t = t + step_dt(P, t);
+      } while (t < tt);
+    }
+  }
+  return n;
+}
+
+__device__ __forceinline__ float start_t(const MarchParams& P, float near, float noise) {
+  return near + step_dt(P, near) * noise;
+}
+
+// pass 1: per-ray sample counts + per-block sums
+__global__ void __launch_bounds__(kRayBlock) k_march_count(MarchParams P, const float* __restrict__ rays_o,
+                                                           const float* __restrict__ rays_d, int64_t N,
+                                                           int max_steps, const float* __restrict__ nears,
+                                                           const float* __restrict__ fars,
+                                                           const float* __restrict__ noises,
+                                                           int32_t* __restrict__ counts,
+                                                           int32_t* __restrict__ block_sums) {
+  __shared__ int32_t wsum[kRayBlock / 64];
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int cnt = 0;
+  if (n < N) {
+    const Ray r = load_ray(rays_o, rays_d, n);
+    const float t0 = start_t(P, nears[n], noises ? noises[n] : 0.0f);
+    cnt = march_ray(P, r, t0, fars[n], max_steps, [](float, float, float, float, float) {});
+    counts[n] = cnt;
+  }
+  const int incl = wave_inclusive_scan(cnt);
+  if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int s = 0;
+#pragma unroll
+    for (int w = 0; w < kRayBlock / 64; ++w) s += wsum[w];
+    block_sums[blockIdx.x] = s;
+  }
+}
+
+// pass 2: one workgroup turns block_sums into exclusive prefixes; counter = {total, N}
+__global__ void __launch_bounds__(1024) k_scan_block_sums(int32_t* __restrict__ block_sums, int n_blocks,
+                                                          int64_t N, int32_t* __restrict__ counter) {
+  __shared__ int32_t wsum[16];
+  __shared__ int32_t carry_s;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < n_blocks; base += 1024) {
+    const int i = base + threadIdx.x;
+    const int v = i < n_blocks ? block_sums[i] : 0;
+    const int incl = wave_inclusive_scan(v);
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    int wave_off = 0;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) wave_off += wsum[w];
+    const int carry = carry_s;
+    if (i < n_blocks) block_sums[i] = carry + wave_off + incl - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry_s = carry + wave_off + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    counter[0] = carry_s;
+    counter[1] = (int32_t)N;
+  }
+}
+
+// pass 3: rays[n] = (n, offset, count)
+__global__ void __launch_bounds__(kRayBlock) k_finalize_offsets(const int32_t* __restrict__ counts,
+                                                                const int32_t* __restrict__ block_prefix,
+                                                                int64_t N, int32_t* __restrict__ rays) {
+  __shared__ int32_t wsum[kRayBlock / 64];
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int cnt = n < N ? counts[n] : 0;
+  const int incl = wave_inclusive_scan(cnt);
+  if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+  __syncthreads();
+  int off = block_prefix[blockIdx.x] + incl - cnt;
+  for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) off += wsum[w];
+  if (n < N) {
+    rays[n * 3 + 0] = (int32_t)n;
+    rays[n * 3 + 1] = off;
+    rays[n * 3 + 2] = cnt;
+  }
+}
+
+// pass 4: re-march and write the samples into their slots
+__global__ void __launch_bounds__(kRayBlock) k_march_write(MarchParams P, const float* __restrict__ rays_o,
+                                                           const float* __restrict__ rays_d, int64_t N,
+                                                           int64_t M, const float* __restrict__ nears,
+                                                           const float* __restrict__ fars,
+                                                           const float* __restrict__ noises,
+                                                           const int32_t* __restrict__ rays,
+                                                           float* __restrict__ xyzs, float* __restrict__ dirs,
+                                                           float* __restrict__ deltas) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const int off = rays[n * 3 + 1];
+  const int cnt = rays[n * 3 + 2];
+  if (cnt == 0 || (int64_t)off + cnt > M) return;
+  const Ray r = load_ray(rays_o, rays_d, n);
+  const float t0 = start_t(P, nears[n], noises ? noises[n] : 0.0f);
+  int64_t i = off;
+  march_ray(P, r, t0, fars[n], cnt, [&](float px, float py, float pz, float dt, float delta) {
+    xyzs[i * 3 + 0] = px; xyzs[i * 3 + 1] = py; xyzs[i * 3 + 2] = pz;
+    dirs[i * 3 + 0] = r.dx; dirs[i * 3 + 1] = r.dy; dirs[i * 3 + 2] = r.dz;
+    deltas[i * 2 + 0] = dt; deltas[i * 2 + 1] = delta;
+    ++i;
+  });
+}
+
+// a5: inference march, up to n_step samples per live ray; buffers pre-zeroed by this kernel
+__global__ void __launch_bounds__(kRayBlock) k_march_rays(MarchParams P, int64_t n_alive, int n_step,
+                                                          const int32_t* __restrict__ rays_alive,
+                                                          const float* __restrict__ rays_t,
+                                                          const float* __restrict__ rays_o,
+                                                          const float* __restrict__ rays_d,
+                                                          const float* __restrict__ fars,
+                                                          float* __restrict__ xyzs, float* __restrict__ dirs,
+                                                          float* __restrict__ deltas) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= n_alive) return;
+  const int64_t base = n * n_step;
+  const int32_t ridx = rays_alive[n];
+  int written = 0;
+  if (ridx >= 0) {
+    const Ray r = load_ray(rays_o, rays_d, ridx);
+    int64_t i = base;
+    written = march_ray(P, r, rays_t[ridx], fars[ridx], n_step,
+                        [&](float px, float py, float pz, float dt, float delta) {
+                          xyzs[i * 3 + 0] = px; xyzs[i * 3 + 1] = py; xyzs[i * 3 + 2] = pz;
+                          dirs[i * 3 + 0] = r.dx; dirs[i * 3 + 1] = r.dy; dirs[i * 3 + 2] = r.dz;
+                          deltas[i * 2 + 0] = dt; deltas[i * 2 + 1] = delta;
+                          ++i;
+                        });
+  }
+  for (int64_t i = base + written; i < base + n_step; ++i) {
+    xyzs[i * 3 + 0] = 0.f; xyzs[i * 3 + 1] = 0.f; xyzs[i * 3 + 2] = 0.f;
+    dirs[i * 3 + 0] = 0.f; dirs[i * 3 + 1] = 0.f; dirs[i * 3 + 2] = 0.f;
+    deltas[i * 2 + 0] = 0.f; deltas[i * 2 + 1] = 0.f;
+  }
+}
+
+__global__ void __launch_bounds__(kRayBlock) k_composite_rays(int64_t n_alive, int n_step,
+                                                              int32_t* __restrict__ rays_alive,
+                                                              float* __restrict__ rays_t,
+                                                              const float* __restrict__ sigmas,
+                                                              const float* __restrict__ rgbs,
+                                                              const float* __restrict__ deltas,
+                                                              float* __restrict__ weights_sum,
+                                                              float* __restrict__ depth, float* __restrict__ image,
+                                                              float T_thresh, const float* __restrict__ extra,
+                                                              float* __restrict__ extra_acc, int K) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= n_alive) return;
+  const int32_t r = rays_alive[n];
+  if (r < 0) return;
+  float t = rays_t[r], ws = weights_sum[r], d = depth[r];
+  float cr = image[r * 3], cg = image[r * 3 + 1], cb = image[r * 3 + 2];
+  int step = 0;
+  bool dead = false;
+  while (step < n_step) {
+    const int64_t i = n * n_step + step;
+    const float d0 = deltas[i * 2];
+    if (d0 == 0.0f) { dead = true; break; }
+    const float alpha = 1.0f - expf(-sigmas[i] * d0);
+    const float T = 1.0f - ws;
+    const float w = alpha * T;
+    ws = ws + w;
+    t = t + deltas[i * 2 + 1];
+    d = d + w * t;
+    cr = cr + w * rgbs[i * 3]; cg = cg + w * rgbs[i * 3 + 1]; cb = cb + w * rgbs[i * 3 + 2];
+    if (extra) {
+      for (int k = 0; k < K; ++k) extra_acc[(int64_t)r * K + k] += w * extra[i * K + k];
+    }
+    ++step;
+    if (T * (1.0f - alpha) < T_thresh) { dead = true; break; }
+  }
+  if (dead) rays_alive[n] = -1; else rays_t[r] = t;
+  weights_sum[r] = ws; depth[r] = d;
+  image[r * 3] = cr; image[r * 3 + 1] = cg; image[r * 3 + 2] = cb;
+}
+
+// order-preserving compaction of live rays: wave ballot + prefix, one workgroup per 1024 rays
+// with a two-level scan (block sums scanned by k_scan_block_sums).
+__global__ void __launch_bounds__(kRayBlock) k_alive_flags(const int32_t* __restrict__ rays_alive,
+                                                           int64_t n, int32_t* __restrict__ counts,
+                                                           int32_t* __restrict__ block_sums) {
+  __shared__ int32_t wsum[kRayBlock / 64];
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int f = (i < n && rays_alive[i] >= 0) ? 1 : 0;
+  if (i < n) counts[i] = f;
+  const unsigned long long m = __ballot(f);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = __popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int s = 0;
+    for (int w = 0; w < kRayBlock / 64; ++w) s += wsum[w];
+    block_sums[blockIdx.x] = s;
+  }
+}
+__global__ void __launch_bounds__(kRayBlock) k_alive_scatter(const int32_t* __restrict__ rays_alive,
+                                                             int64_t n, const int32_t* __restrict__ block_prefix,
+                                                             int32_t* __restrict__ out) {
+  __shared__ int32_t wsum[kRayBlock / 64];
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int32_t v = i < n ? rays_alive[i] : -1;
+  const int f = v >= 0 ? 1 : 0;
+  const unsigned long long m = __ballot(f);
+  const int lane = threadIdx.x & 63;
+  const int rank = __popcll(m & ((1ull << lane) - 1ull));
+  if (lane == 0) wsum[threadIdx.x >> 6] = __popcll(m);
+  __syncthreads();
+  int off = block_prefix[blockIdx.x] + rank;
+  for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) off += wsum[w];
+  if (f) out[off] = v;
+}
+
+// ------------------------------------------------------------------------------------------
+// a12: training compositing, one lane per ray (sequential scan along the ray)
+__global__ void __launch_bounds__(kRayBlock) k_composite_train_fwd(const float* __restrict__ sigmas,
+                                                                   const float* __restrict__ rgbs,
+                                                                   const float* __restrict__ deltas,
+                                                                   const int32_t* __restrict__ rays, int64_t N,
+                                                                   float T_thresh, float* __restrict__ weights_sum,
+                                                                   float* __restrict__ depth,
+                                                                   float* __restrict__ image) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const int32_t rid = rays[n * 3], off = rays[n * 3 + 1], cnt = rays[n * 3 + 2];
+  float T = 1.0f, r = 0, g = 0, b = 0, ws = 0, t = 0, d = 0;
+  for (int s = 0; s < cnt; ++s) {
+    const int64_t i = (int64_t)off + s;
+    const float2 dl = reinterpret_cast<const float2*>(deltas)[i];
+    const float alpha = 1.0f - expf(-sigmas[i] * dl.x);
+    const float w = alpha * T;
+    r += w * rgbs[i * 3]; g += w * rgbs[i * 3 + 1]; b += w * rgbs[i * 3 + 2];
+    t += dl.y;
+    d += w * t;
+    ws += w;
+    T *= 1.0f - alpha;
+    if (T < T_thresh) break;
+  }
+  weights_sum[rid] = ws; depth[rid] = d;
+  image[rid * 3] = r; image[rid * 3 + 1] = g; image[rid * 3 + 2] = b;
+}
+
+// a13: K extra channels (instance logits), one wave per ray, lane = channel (coalesced rows)
+__global__ void __launch_bounds__(kRayBlock) k_composite_train_extra_fwd(const float* __restrict__ sigmas,
+                                                                         const float* __restrict__ deltas,
+                                                                         const float* __restrict__ extra,
+                                                                         const int32_t* __restrict__ rays, int64_t N,
+                                                                         float T_thresh, int K,
+                                                                         float* __restrict__ extra_out) {
+  const int64_t n = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (n >= N) return;
+  const int32_t rid = rays[n * 3], off = rays[n * 3 + 1], cnt = rays[n * 3 + 2];
+  float T = 1.0f, acc = 0.0f;
+  for (int s = 0; s < cnt; ++s) {
+    const int64_t i = (int64_t)off + s;
+    const float alpha = 1.0f - expf(-sigmas[i] * deltas[i * 2]);
+    const float w = alpha * T;
+    if (lane < K) acc += w * extra[i * K + lane];
+    T *= 1.0f - alpha;
+    if (T < T_thresh) break;
+  }
+  if (lane < K) extra_out[(int64_t)rid * K + lane] = acc;
+}
+
+__global__ void __launch_bounds__(kRayBlock) k_composite_train_bwd(
+    const float* __restrict__ g_ws, const float* __restrict__ g_img, const float* __restrict__ sigmas,
+    const float* __restrict__ rgbs, const float* __restrict__ deltas, const int32_t* __restrict__ rays,
+    const float* __restrict__ weights_sum, const float* __restrict__ image, int64_t N, float T_thresh,
+    float* __restrict__ grad_sigmas, float* __restrict__ grad_rgbs) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const int32_t rid = rays[n * 3], off = rays[n * 3 + 1], cnt = rays[n * 3 + 2];
+  const float gr = g_img[rid * 3], gg = g_img[rid * 3 + 1], gb = g_img[rid * 3 + 2];
+  const float gw = g_ws ? g_ws[rid] : 0.0f;
+  const float rf = image[rid * 3], gf = image[rid * 3 + 1], bf = image[rid * 3 + 2];
+  const float wsf = weights_sum[rid];
+  float T = 1.0f, r = 0, g = 0, b = 0;
+  int s = 0;
+  for (; s < cnt; ++s) {
+    const int64_t i = (int64_t)off + s;
+    const float d0 = deltas[i * 2];
+    const float alpha = 1.0f - expf(-sigmas[i] * d0);
+    const float w = alpha * T;
+    const float cr = rgbs[i * 3], cg = rgbs[i * 3 + 1], cb = rgbs[i * 3 + 2];
+    r += w * cr; g += w * cg; b += w * cb;
+    T *= 1.0f - alpha;
+    grad_rgbs[i * 3] = gr * w; grad_rgbs[i * 3 + 1] = gg * w; grad_rgbs[i * 3 + 2] = gb * w;
+    grad_sigmas[i] = d0 * (gr * (T * cr - (rf - r)) + gg * (T * cg - (gf - g)) + gb * (T * cb - (bf - b)) +
+                           gw * (1.0f - wsf));
+    if (T < T_thresh) { ++s; break; }
+  }
+  for (; s < cnt; ++s) {  // samples behind the termination point get zero gradient
+    const int64_t i = (int64_t)off + s;
+    grad_rgbs[i * 3] = 0.f; grad_rgbs[i * 3 + 1] = 0.f; grad_rgbs[i * 3 + 2] = 0.f;
+    grad_sigmas[i] = 0.f;
+  }
+}
+
+__global__ void __launch_bounds__(kRayBlock) k_composite_train_extra_bwd(
+    const float* __restrict__ g_extra_out, const float* __restrict__ sigmas, const float* __restrict__ deltas,
+    const int32_t* __restrict__ rays, int64_t N, float T_thresh, int K, float* __restrict__ grad_extra) {
+  const int64_t n = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (n >= N) return;
+  const int32_t rid = rays[n * 3], off = rays[n * 3 + 1], cnt = rays[n * 3 + 2];
+  const float g = lane < K ? g_extra_out[(int64_t)rid * K + lane] : 0.0f;
+  float T = 1.0f;
+  int s = 0;
+  for (; s < cnt; ++s) {
+    const int64_t i = (int64_t)off + s;
+    const float alpha = 1.0f - expf(-sigmas[i] * deltas[i * 2]);
+    const float w = alpha * T;
+    if (lane < K) grad_extra[i * K + lane] = w * g;
+    T *= 1.0f - alpha;
+    if (T < T_thresh) { ++s; break; }
+  }
+  for (; s < cnt; ++s)
+    if (lane < K) grad_extra[((int64_t)off + s) * K + lane] = 0.0f;
+}
+
+static MarchParams make_params(const uint8_t* bits, float bound, float dt_gamma, int max_steps, int C, int H) {
+  MarchParams P;
+  P.bits = bits;
+  P.bound = bound;
+  P.dt_gamma = dt_gamma;
+  P.dt_min = kSqrt3x2 / (float)max_steps;
+  P.dt_max = kSqrt3x2 * (float)(1 << (C - 1)) / (float)H;
+  P.rH = (float)(1.0 / H);
+  P.C = C;
+  P.H = H;
+  P.H3 = H * H * H;
+  return P;
+}
+
+}  // namespace inr
+
+using namespace inr;
+
+extern "C" {
+
+int inr_abi_version(void) { return INR_ABI_VERSION; }
+const char* inr_last_error(void) { return inr::g_err; }
+
+int inr_device_info(int32_t device, int64_t* props) {
+  INR_REQUIRE(props, "props is null");
+  hipDeviceProp_t p;
+  if (hipGetDeviceProperties(&p, device) != hipSuccess) {
+    set_error("inr_device_info: no device %d", device);
+    return INR_ENODEV;
+  }
+  props[0] = p.multiProcessorCount;
+  props[1] = p.warpSize;
+  props[2] = (int64_t)p.maxSharedMemoryPerMultiProcessor;
+  props[3] = p.gcnArchName[0] ? atoi(p.gcnArchName + 3) : 0;
+  return INR_OK;
+}
+
+int inr_near_far_from_aabb(const float* rays_o, const float* rays_d, const float* aabb, int64_t N,
+                           float min_near, float* nears, float* fars, inr_stream_t s) {
+  INR_REQUIRE(rays_o && rays_d && aabb && nears && fars, "null pointer");
+  INR_REQUIRE(N >= 0, "negative N");
+  if (N == 0) return INR_OK;
+  k_near_far<<<blocks_for(N, kRayBlock), kRayBlock, 0, as_stream(s)>>>(rays_o, rays_d, aabb, N, min_near, nears, fars);
+  return check_launch("near_far_from_aabb");
+}
+
+int inr_morton3D(const int32_t* coords, int64_t N, int32_t* indices, inr_stream_t s) {
+  INR_REQUIRE(coords && indices && N >= 0, "bad argument");
+  if (N == 0) return INR_OK;
+  k_morton3D<<<blocks_for(N, 256), 256, 0, as_stream(s)>>>(coords, N, indices);
+  return check_launch("morton3D");
+}
+int inr_morton3D_invert(const int32_t* indices, int64_t N, int32_t* coords, inr_stream_t s) {
+  INR_REQUIRE(coords && indices && N >= 0, "bad argument");
+  if (N == 0) return INR_OK;
+  k_morton3D_invert<<<blocks_for(N, 256), 256, 0, as_stream(s)>>>(indices, N, coords);
+  return check_launch("morton3D_invert");
+}
+int inr_packbits(const float* grid, int64_t n_bytes, float thresh, uint8_t* bitfield, inr_stream_t s) {
+  INR_REQUIRE(grid && bitfield && n_bytes >= 0, "bad argument");
+  INR_REQUIRE(((uintptr_t)grid & 15) == 0, "grid must be 16-byte aligned");
+  if (n_bytes == 0) return INR_OK;
+  k_packbits<<<blocks_for(n_bytes, 256), 256, 0, as_stream(s)>>>(grid, n_bytes, thresh, bitfield);
+  return check_launch("packbits");
+}
+
+int64_t inr_march_workspace_bytes(int64_t N) {
+  const int64_t nb = (N + kRayBlock - 1) / kRayBlock;
+  return (N + nb + 64) * (int64_t)sizeof(int32_t);
+}
+
+int inr_march_rays_train_count(const float* rays_o, const float* rays_d, const uint8_t* bitfield, float bound,
+                               float dt_gamma, int32_t max_steps, int64_t N, int32_t cascade, int32_t H,
+                               const float* nears, const float* fars, const float* noises, int32_t* rays,
+                               int32_t* counter, void* workspace, inr_stream_t s) {
+  INR_REQUIRE(rays_o && rays_d && bitfield && nears && fars && rays && counter && workspace, "null pointer");
+  INR_REQUIRE(N > 0 && N < (1ll << 31), "N out of range");
+  INR_REQUIRE(max_steps > 0 && cascade >= 1 && H >= 8 && H <= 1024, "bad grid parameters");
+  const MarchParams P = make_params(bitfield, bound, dt_gamma, max_steps, cascade, H);
+  const unsigned nb = blocks_for(N, kRayBlock);
+  int32_t* counts = reinterpret_cast<int32_t*>(workspace);
+  int32_t* block_sums = counts + N;
+  hipStream_t st = as_stream(s);
+  k_march_count<<<nb, kRayBlock, 0, st>>>(P, rays_o, rays_d, N, max_steps, nears, fars, noises, counts, block_sums);
+  k_scan_block_sums<<<1, 1024, 0, st>>>(block_sums, (int)nb, N, counter);
+  k_finalize_offsets<<<nb, kRayBlock, 0, st>>>(counts, block_sums, N, rays);
+  return check_launch("march_rays_train_count");
+}
+
+int inr_march_rays_train_write(const float* rays_o, const float* rays_d, const uint8_t* bitfield, float bound,
+                               float dt_gamma, int32_t max_steps, int64_t N, int32_t cascade, int32_t H, int64_t M,
+                               const float* nears, const float* fars, const float* noises, const int32_t* rays,
+                               float* xyzs, float* dirs, float* deltas, inr_stream_t s) {
+  INR_REQUIRE(rays_o && rays_d && bitfield && nears && fars && rays, "null pointer");
+  INR_REQUIRE(N > 0 && M >= 0, "bad sizes");
+  if (M == 0) return INR_OK;
+  INR_REQUIRE(xyzs && dirs && deltas, "null output");
+  const MarchParams P = make_params(bitfield, bound, dt_gamma, max_steps, cascade, H);
+  k_march_write<<<blocks_for(N, kRayBlock), kRayBlock, 0, as_stream(s)>>>(P, rays_o, rays_d, N, M, nears, fars, noises,
+                                                                          rays, xyzs, dirs, deltas);
+  return check_launch("march_rays_train_write");
+}
+
+int inr_march_rays(int64_t n_alive, int32_t n_step, const int32_t* rays_alive, const float* rays_t,
+                   const float* rays_o, const float* rays_d, float bound, float dt_gamma, int32_t max_steps,
+                   int32_t cascade, int32_t H, const uint8_t* bitfield, const float* nears, const float* fars,
+                   float* xyzs, float* dirs, float* deltas, inr_stream_t s) {
+  (void)nears;
+  INR_REQUIRE(rays_alive && rays_t && rays_o && rays_d && bitfield && fars && xyzs && dirs && deltas, "null pointer");
+  INR_REQUIRE(n_alive >= 0 && n_step > 0, "bad sizes");
+  if (n_alive == 0) return INR_OK;
+  const MarchParams P = make_params(bitfield, bound, dt_gamma, max_steps, cascade, H);
+  k_march_rays<<<blocks_for(n_alive, kRayBlock), kRayBlock, 0, as_stream(s)>>>(P, n_alive, n_step, rays_alive, rays_t,
+                                                                               rays_o, rays_d, fars, xyzs, dirs, deltas);
+  return check_launch("march_rays");
+}
+
+int inr_composite_rays(int64_t n_alive, int32_t n_step, int32_t* rays_alive, float* rays_t, const float* sigmas,
+                       const float* rgbs, const float* deltas, float* weights_sum, float* depth, float* image,
+                       float T_thresh, const float* extra, float* extra_acc, int32_t K, inr_stream_t s) {
+  INR_REQUIRE(rays_alive && rays_t && sigmas && rgbs && deltas && weights_sum && depth && image, "null pointer");
+  INR_REQUIRE(!extra || (extra_acc && K > 0), "extra given without extra_acc/K");
+  if (n_alive == 0) return INR_OK;
+  k_composite_rays<<<blocks_for(n_alive, kRayBlock), kRayBlock, 0, as_stream(s)>>>(
+      n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image, T_thresh, extra, extra_acc, K);
+  return check_launch("composite_rays");
+}
+
+int inr_compact_alive(const int32_t* rays_alive, int64_t n_alive, int32_t* out, int32_t* n_out, inr_stream_t s) {
+  // uses out[n_alive .. ] ? no: needs scratch; the caller passes `out` with room for
+  // n_alive + inr_march_workspace_bytes(n_alive)/4 int32 (compacted list first, scratch after).
+  INR_REQUIRE(rays_alive && out && n_out && n_alive >= 0, "bad argument");
+  if (n_alive == 0) {
+    hipMemsetAsync(n_out, 0, 2 * sizeof(int32_t), as_stream(s));
+    return check_launch("compact_alive");
+  }
+  const unsigned nb = blocks_for(n_alive, kRayBlock);
+  int32_t* counts = out + n_alive;
+  int32_t* block_sums = counts + n_alive;
+  hipStream_t st = as_stream(s);
+  k_alive_flags<<<nb, kRayBlock, 0, st>>>(rays_alive, n_alive, counts, block_sums);
+  k_scan_block_sums<<<1, 1024, 0, st>>>(block_sums, (int)nb, n_alive, n_out);
+  k_alive_scatter<<<nb, kRayBlock, 0, st>>>(rays_alive, n_alive, block_sums, out);
+  return check_launch("compact_alive");
+}
+
+int inr_composite_rays_train_forward(const float* sigmas, const float* rgbs, const float* deltas, const int32_t* rays,
+                                     int64_t N, float T_thresh, const float* extra, int32_t K, float* weights_sum,
+                                     float* depth, float* image, float* extra_out, inr_stream_t s) {
+  INR_REQUIRE(rays && weights_sum && depth && image && N >= 0, "bad argument");
+  INR_REQUIRE(!extra || (extra_out && K > 0 && K <= 64), "extra needs extra_out and 0 < K <= 64");
+  if (N == 0) return INR_OK;
+  INR_REQUIRE(sigmas && rgbs && deltas, "null sample arrays");
+  INR_REQUIRE(((uintptr_t)deltas & 7) == 0, "deltas must be 8-byte aligned");
+  hipStream_t st = as_stream(s);
+  k_composite_train_fwd<<<blocks_for(N, kRayBlock), kRayBlock, 0, st>>>(sigmas, rgbs, deltas, rays, N, T_thresh,
+                                                                        weights_sum, depth, image);
+  if (extra)
+    k_composite_train_extra_fwd<<<blocks_for(N * 64, kRayBlock), kRayBlock, 0, st>>>(sigmas, deltas, extra, rays, N,
+                                                                                     T_thresh, K, extra_out);
+  return check_launch("composite_rays_train_forward");
+}
+
+int inr_composite_rays_train_backward(const float* grad_weights_sum, const float* grad_image,
+                                      const float* grad_extra_out, const float* sigmas, const float* rgbs,
+                                      const float* extra, const float* deltas, const int32_t* rays,
+                                      const float* weights_sum, const float* image, int64_t N, float T_thresh,
+                                      int32_t K, float* grad_sigmas, float* grad_rgbs, float* grad_extra,
+                                      inr_stream_t s) {
+  (void)extra;
+  INR_REQUIRE(grad_image && rays && weights_sum && image && grad_sigmas && grad_rgbs && N >= 0, "bad argument");
+  INR_REQUIRE(!grad_extra_out || (grad_extra && K > 0 && K <= 64), "grad_extra_out needs grad_extra and 0 < K <= 64");
+  if (N == 0) return INR_OK;
+  hipStream_t st = as_stream(s);
+  k_composite_train_bwd<<<blocks_for(N, kRayBlock), kRayBlock, 0, st>>>(grad_weights_sum, grad_image, sigmas, rgbs,
+                                                                        deltas, rays, weights_sum, image, N, T_thresh,
+                                                                        grad_sigmas, grad_rgbs);
+  if (grad_extra_out)
+    k_composite_train_extra_bwd<<<blocks_for(N * 64, kRayBlock), kRayBlock, 0, st>>>(grad_extra_out, sigmas, deltas,
+                                                                                     rays, N, T_thresh, K, grad_extra);
+  return check_launch("composite_rays_train_backward");
+}
+
+}  // extern "C"

@@ -1,0 +1,184 @@
+"""``NeRFNetwork`` - hash-grid NeRF + instance field (8b).
+
+Constructor, parameter names (``encoder.embeddings``, ``sigma_net.N.weight``,
+``color_net.N.weight``) and the ``forward / density / color / get_params`` methods
+follow upstream ``nerf/network.py`` of the reference's un-vendored submodule
+(/root/reference/.gitmodules:4-6, README.md:27,59) so its checkpoints load.
+The instance head (``instance_encoder``, ``instance_net``, ``num_instances``) is
+this repository's reading of the fork's addition [U-fork]: a position-only
+hash-grid + MLP producing K raw logits.
+
+Two execution paths, both HIP:
+* no-grad (render / occupancy update / frozen NeRF under instance training):
+  ONE fused kernel per call - gather + SH + MLPs on fp32 MFMA
+  (csrc/field_fused.hip);
+* grad: hand-written HIP encoders (forward gather, backward atomic scatter) with
+  the tiny MLP GEMMs left to rocBLAS through ``nn.Linear`` - upstream's default
+  configuration (its ``--ff`` fused MLP is optional there too).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import _lib
+from .._lib import check, host_ptr, ptr, stream_ptr
+from ..activation import trunc_exp
+from ..encoding import get_encoder
+from .renderer import NeRFRenderer
+
+
+def _mlp(in_dim, hidden, out_dim, num_layers):
+    layers = []
+    for l in range(num_layers):
+        layers.append(nn.Linear(in_dim if l == 0 else hidden, out_dim if l == num_layers - 1 else hidden, bias=False))
+    return nn.ModuleList(layers)
+
+
+def _run_mlp(net, h):
+    for l, layer in enumerate(net):
+        h = layer(h)
+        if l != len(net) - 1:
+            h = F.relu(h, inplace=True)
+    return h
+
+
+class NeRFNetwork(NeRFRenderer):
+    def __init__(self, encoding="hashgrid", encoding_dir="sphere_harmonics", encoding_bg="hashgrid", num_layers=2,
+                 hidden_dim=64, geo_feat_dim=15, num_layers_color=3, hidden_dim_color=64, num_layers_bg=2,
+                 hidden_dim_bg=64, bound=1, num_instances=0, num_layers_instance=3, hidden_dim_instance=64,
+                 **kwargs):
+        super().__init__(bound, **kwargs)
+        self.num_layers, self.hidden_dim, self.geo_feat_dim = num_layers, hidden_dim, geo_feat_dim
+        self.encoder, self.in_dim = get_encoder(encoding, desired_resolution=2048 * bound)
+        self.sigma_net = _mlp(self.in_dim, hidden_dim, 1 + geo_feat_dim, num_layers)
+        self.num_layers_color, self.hidden_dim_color = num_layers_color, hidden_dim_color
+        self.encoder_dir, self.in_dim_dir = get_encoder(encoding_dir)
+        self.color_net = _mlp(self.in_dim_dir + geo_feat_dim, hidden_dim_color, 3, num_layers_color)
+        self.num_instances = int(num_instances)
+        if self.num_instances:
+            self.instance_encoder, in_dim_inst = get_encoder(encoding, desired_resolution=2048 * bound)
+            self.instance_net = _mlp(in_dim_inst, hidden_dim_instance, self.num_instances, num_layers_instance)
+        self._fusable = (encoding == "hashgrid" and encoding_dir == "sphere_harmonics" and num_layers == 2
+                         and hidden_dim == 64 and geo_feat_dim == 15 and num_layers_color == 3
+                         and hidden_dim_color == 64 and self.in_dim == 32)
+        self._fusable_inst = (self.num_instances in (16, 32, 48, 64) and num_layers_instance == 3
+                              and hidden_dim_instance == 64)
+        self._packed = {}
+
+    # ---- packed MFMA weights (cached until a weight tensor changes) ------------------------------
+    def _packed_weights(self, which):
+        lib = _lib.load()
+        if which == "nerf":
+            ws = [self.sigma_net[0].weight, self.sigma_net[1].weight, self.color_net[0].weight,
+                  self.color_net[1].weight, self.color_net[2].weight]
+        else:
+            ws = [l.weight for l in self.instance_net]
+        key = tuple((w.data_ptr(), w._version) for w in ws)
+        hit = self._packed.get(which)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        host = [w.detach().float().cpu().contiguous() for w in ws]
+        if which == "nerf":
+            buf = torch.empty(lib.inr_nerf_packed_floats(), dtype=torch.float32)
+            check(lib.inr_nerf_pack_weights(*[host_ptr(h, torch.float32) for h in host], host_ptr(buf, torch.float32)),
+                  "nerf_pack_weights")
+        else:
+            buf = torch.empty(lib.inr_instance_packed_floats(self.num_instances), dtype=torch.float32)
+            check(lib.inr_instance_pack_weights(*[host_ptr(h, torch.float32) for h in host], self.num_instances,
+                                                host_ptr(buf, torch.float32)), "instance_pack_weights")
+        dev = buf.to(ws[0].device)
+        self._packed[which] = (key, dev)
+        return dev
+
+    def _needs_grad(self, params):
+        return torch.is_grad_enabled() and any(p.requires_grad for p in params)
+
+    def _nerf_params(self):
+        return [self.encoder.embeddings] + [l.weight for l in self.sigma_net] + [l.weight for l in self.color_net]
+
+    def _fused_nerf(self, x, d, want_rgb, want_geo):
+        lib = _lib.load()
+        x = x.contiguous().float()
+        M = x.shape[0]
+        dev = x.device
+        sigma = torch.empty(M, dtype=torch.float32, device=dev)
+        rgb = torch.empty(M, 3, dtype=torch.float32, device=dev) if want_rgb else None
+        geo = torch.empty(M, self.geo_feat_dim, dtype=torch.float32, device=dev) if want_geo else None
+        if want_rgb:
+            d = d.contiguous().float()
+        check(lib.inr_nerf_forward(ptr(x, torch.float32, "x"), ptr(d, torch.float32, "d", allow_none=not want_rgb),
+                                   M, None, float(self.bound), ptr(self.encoder.embeddings.data, torch.float32),
+                                   self.encoder.desc, ptr(self._packed_weights("nerf")), 1.0, ptr(sigma),
+                                   ptr(rgb, allow_none=True), ptr(geo, allow_none=True), stream_ptr()),
+              "nerf_forward")
+        return sigma, rgb, geo
+
+    # ---- upstream API -----------------------------------------------------------------------------
+    def forward(self, x, d):
+        """x [M,3] in [-bound,bound], d [M,3] unit -> sigma [M], color [M,3]."""
+        if self._fusable and not self._needs_grad(self._nerf_params()):
+            sigma, rgb, _ = self._fused_nerf(x, d, True, False)
+            return sigma, rgb
+        h = _run_mlp(self.sigma_net, self.encoder(x, bound=self.bound))
+        sigma = trunc_exp(h[..., 0])
+        geo_feat = h[..., 1:]
+        h = torch.cat([self.encoder_dir(d), geo_feat], dim=-1)
+        color = torch.sigmoid(_run_mlp(self.color_net, h))
+        return sigma, color
+
+    def density(self, x):
+        """x [M,3] -> {'sigma': [M], 'geo_feat': [M,15]}."""
+        params = [self.encoder.embeddings] + [l.weight for l in self.sigma_net]
+        if self._fusable and not self._needs_grad(params):
+            sigma, _, geo = self._fused_nerf(x, None, False, True)
+            return {"sigma": sigma, "geo_feat": geo}
+        h = _run_mlp(self.sigma_net, self.encoder(x, bound=self.bound))
+        return {"sigma": trunc_exp(h[..., 0]), "geo_feat": h[..., 1:]}
+
+    def color(self, x, d, mask=None, geo_feat=None, **kwargs):
+        """rgb [M,3]; rows where ``mask`` is False are zero (upstream semantics)."""
+        if geo_feat is None:
+            geo_feat = self.density(x)["geo_feat"]
+        if mask is not None:
+            rgbs = torch.zeros(mask.shape[0], 3, dtype=x.dtype, device=x.device)
+            if not mask.any():
+                return rgbs
+            x, d, geo_feat = x[mask], d[mask], geo_feat[mask]
+        h = torch.cat([self.encoder_dir(d), geo_feat], dim=-1)
+        h = torch.sigmoid(_run_mlp(self.color_net, h))
+        if mask is not None:
+            rgbs[mask] = h.to(rgbs.dtype)
+            return rgbs
+        return h
+
+    def instance(self, x):
+        """x [M,3] -> raw instance logits [M,K] (None when the network has no instance head)."""
+        if not self.num_instances:
+            return None
+        params = [self.instance_encoder.embeddings] + [l.weight for l in self.instance_net]
+        if self._fusable_inst and not self._needs_grad(params):
+            lib = _lib.load()
+            x = x.contiguous().float()
+            M = x.shape[0]
+            out = torch.empty(M, self.num_instances, dtype=torch.float32, device=x.device)
+            check(lib.inr_instance_forward(ptr(x, torch.float32, "x"), M, None, float(self.bound),
+                                           ptr(self.instance_encoder.embeddings.data, torch.float32),
+                                           self.instance_encoder.desc, ptr(self._packed_weights("instance")),
+                                           self.num_instances, ptr(out), stream_ptr()), "instance_forward")
+            return out
+        return _run_mlp(self.instance_net, self.instance_encoder(x, bound=self.bound))
+
+    def get_params(self, lr):
+        params = [{"params": self.encoder.parameters(), "lr": lr},
+                  {"params": self.sigma_net.parameters(), "lr": lr},
+                  {"params": self.encoder_dir.parameters(), "lr": lr},
+                  {"params": self.color_net.parameters(), "lr": lr}]
+        if self.num_instances:
+            params += [{"params": self.instance_encoder.parameters(), "lr": lr},
+                       {"params": self.instance_net.parameters(), "lr": lr}]
+        return params
+
+    def freeze_nerf(self):
+        """Instance-field stage: the NeRF is loaded and frozen, only the instance head trains."""
+        for p in self._nerf_params():
+            p.requires_grad_(False)

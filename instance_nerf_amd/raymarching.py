@@ -1,0 +1,222 @@
+"""Host-side mirror of torch-ngp's ``raymarching`` extension module over the C ABI.
+
+Same function names, argument meaning and return shapes as the upstream module
+the reference's (un-vendored) ``instance_nerf`` submodule ships
+(/root/reference/.gitmodules:4-6, README.md:27,59), so
+``NeRFRenderer`` code written against it runs unchanged.  Every function is a
+thin wrapper: validate -> allocate outputs -> one or a few launches on the
+current torch stream.  No CPU fallback.
+
+Differences from upstream, all deliberate:
+* ``march_rays_train`` assigns sample slots by an exclusive scan in ray order
+  (deterministic) instead of racing atomics; ``rays[:,0]`` is therefore always
+  ``arange(N)``;
+* ``composite_rays_train`` optionally composites K extra channels (the fork's
+  instance logits) with the weights detached.
+"""
+import torch
+
+from . import _lib
+from ._lib import check, ptr, stream_ptr
+
+F32, I32, U8 = torch.float32, torch.int32, torch.uint8
+
+
+def _f(t):
+    return t.contiguous().float() if (t.dtype != F32 or not t.is_contiguous()) else t
+
+
+def near_far_from_aabb(rays_o, rays_d, aabb, min_near=0.2):
+    """rays_o, rays_d [N,3]; aabb [6] -> nears, fars [N]."""
+    lib = _lib.load()
+    rays_o, rays_d, aabb = _f(rays_o).view(-1, 3), _f(rays_d).view(-1, 3), _f(aabb)
+    N = rays_o.shape[0]
+    nears = torch.empty(N, dtype=F32, device=rays_o.device)
+    fars = torch.empty(N, dtype=F32, device=rays_o.device)
+    check(lib.inr_near_far_from_aabb(ptr(rays_o, F32, "rays_o"), ptr(rays_d, F32, "rays_d"), ptr(aabb, F32, "aabb"),
+                                     N, float(min_near), ptr(nears), ptr(fars), stream_ptr()), "near_far_from_aabb")
+    return nears, fars
+
+
+def morton3D(coords):
+    """coords int32 [N,3] (each < 1024) -> int32 [N]."""
+    lib = _lib.load()
+    coords = coords.int().contiguous()
+    N = coords.shape[0]
+    out = torch.empty(N, dtype=I32, device=coords.device)
+    check(lib.inr_morton3D(ptr(coords, I32, "coords"), N, ptr(out), stream_ptr()), "morton3D")
+    return out
+
+
+def morton3D_invert(indices):
+    """int32 [N] -> int32 [N,3]."""
+    lib = _lib.load()
+    indices = indices.int().contiguous()
+    N = indices.shape[0]
+    out = torch.empty(N, 3, dtype=I32, device=indices.device)
+    check(lib.inr_morton3D_invert(ptr(indices, I32, "indices"), N, ptr(out), stream_ptr()), "morton3D_invert")
+    return out
+
+
+def packbits(grid, thresh, bitfield=None):
+    """grid f32 [C, H^3] (or flat) -> uint8 [C*H^3/8]; bit i of byte k = grid[8k+i] > thresh."""
+    lib = _lib.load()
+    grid = _f(grid)
+    n = grid.numel()
+    if n % 8:
+        raise RuntimeError("packbits: number of cells must be a multiple of 8")
+    if bitfield is None:
+        bitfield = torch.empty(n // 8, dtype=U8, device=grid.device)
+    check(lib.inr_packbits(ptr(grid, F32, "grid"), n // 8, float(thresh), ptr(bitfield, U8, "bitfield"),
+                           stream_ptr()), "packbits")
+    return bitfield
+
+
+def march_rays_train(rays_o, rays_d, bound, density_bitfield, C, H, nears, fars, step_counter=None,
+                     mean_count=-1, perturb=False, align=-1, force_all_rays=False, dt_gamma=0, max_steps=1024,
+                     noises=None):
+    """-> xyzs [M,3], dirs [M,3], deltas [M,2], rays int32 [N,3] = (ray, offset, count).
+
+    With ``mean_count <= 0`` or ``force_all_rays`` the exact sample count is read
+    back (one 4-byte device->host copy, as upstream) and M is exact.  Otherwise M
+    = mean_count (aligned) and rays overflowing M are dropped; no host sync.
+    ``step_counter`` (int32 [2]) receives (total samples, N).
+    """
+    lib = _lib.load()
+    rays_o, rays_d = _f(rays_o).view(-1, 3), _f(rays_d).view(-1, 3)
+    dev = rays_o.device
+    N = rays_o.shape[0]
+    nears, fars = _f(nears), _f(fars)
+    if noises is None:
+        noises = torch.rand(N, dtype=F32, device=dev) if perturb else None
+    else:
+        noises = _f(noises)
+    if step_counter is None:
+        step_counter = torch.zeros(2, dtype=I32, device=dev)
+    rays = torch.empty(N, 3, dtype=I32, device=dev)
+    ws = torch.empty(lib.inr_march_workspace_bytes(N), dtype=U8, device=dev)
+    args = (ptr(rays_o, F32, "rays_o"), ptr(rays_d, F32, "rays_d"), ptr(density_bitfield, U8, "density_bitfield"),
+            float(bound), float(dt_gamma), int(max_steps), N, int(C), int(H))
+    check(lib.inr_march_rays_train_count(*args, ptr(nears, F32, "nears"), ptr(fars, F32, "fars"),
+                                         ptr(noises, F32, "noises", allow_none=True), ptr(rays),
+                                         ptr(step_counter, I32, "step_counter"), ptr(ws), stream_ptr()),
+          "march_rays_train_count")
+    if force_all_rays or mean_count <= 0:
+        M = int(step_counter[0].item())
+    else:
+        M = int(mean_count)
+    if align > 0:
+        M += align - M % align if M % align else 0
+    xyzs = torch.zeros(M, 3, dtype=F32, device=dev)
+    dirs = torch.zeros(M, 3, dtype=F32, device=dev)
+    deltas = torch.zeros(M, 2, dtype=F32, device=dev)
+    check(lib.inr_march_rays_train_write(*args, M, ptr(nears), ptr(fars), ptr(noises, F32, "noises", allow_none=True),
+                                         ptr(rays), ptr(xyzs), ptr(dirs), ptr(deltas), stream_ptr()),
+          "march_rays_train_write")
+    return xyzs, dirs, deltas, rays
+
+
+class _CompositeRaysTrain(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, sigmas, rgbs, extra, deltas, rays, T_thresh):
+        lib = _lib.load()
+        sigmas, rgbs, deltas = _f(sigmas), _f(rgbs), _f(deltas)
+        dev = sigmas.device
+        N = rays.shape[0]
+        K = 0 if extra is None else extra.shape[1]
+        if extra is not None:
+            extra = _f(extra)
+        ws = torch.zeros(N, dtype=F32, device=dev)
+        depth = torch.zeros(N, dtype=F32, device=dev)
+        image = torch.zeros(N, 3, dtype=F32, device=dev)
+        extra_out = torch.zeros(N, K, dtype=F32, device=dev) if K else None
+        check(lib.inr_composite_rays_train_forward(
+            ptr(sigmas, F32, "sigmas"), ptr(rgbs, F32, "rgbs"), ptr(deltas, F32, "deltas"), ptr(rays, I32, "rays"),
+            N, float(T_thresh), ptr(extra, F32, "extra", allow_none=True), K, ptr(ws), ptr(depth), ptr(image),
+            ptr(extra_out, allow_none=True), stream_ptr()), "composite_rays_train_forward")
+        ctx.save_for_backward(sigmas, rgbs, extra, deltas, rays, ws, image)
+        ctx.T_thresh = T_thresh
+        ctx.K = K
+        ctx.mark_non_differentiable(depth)
+        if K:
+            return ws, depth, image, extra_out
+        return ws, depth, image
+
+    @staticmethod
+    def backward(ctx, g_ws, g_depth, g_image, g_extra=None):
+        lib = _lib.load()
+        sigmas, rgbs, extra, deltas, rays, ws, image = ctx.saved_tensors
+        N = rays.shape[0]
+        K = ctx.K
+        dev = sigmas.device
+        g_ws = _f(g_ws) if g_ws is not None else torch.zeros(N, dtype=F32, device=dev)
+        g_image = _f(g_image) if g_image is not None else torch.zeros(N, 3, dtype=F32, device=dev)
+        gs = torch.zeros_like(sigmas)
+        gc = torch.zeros_like(rgbs)
+        ge = None
+        if K and g_extra is not None and ctx.needs_input_grad[2]:
+            g_extra = _f(g_extra)
+            ge = torch.zeros_like(extra)
+        else:
+            g_extra = None
+        check(lib.inr_composite_rays_train_backward(
+            ptr(g_ws), ptr(g_image), ptr(g_extra, allow_none=True), ptr(sigmas), ptr(rgbs),
+            ptr(extra, allow_none=True), ptr(deltas), ptr(rays), ptr(ws), ptr(image), N, float(ctx.T_thresh), K,
+            ptr(gs), ptr(gc), ptr(ge, allow_none=True), stream_ptr()), "composite_rays_train_backward")
+        return gs, gc, ge, None, None, None
+
+
+def composite_rays_train(sigmas, rgbs, deltas, rays, T_thresh=1e-4, extra=None):
+    """-> weights_sum [N], depth [N], image [N,3] (, extra_out [N,K] when ``extra`` [M,K] is given).
+
+    Differentiable w.r.t. sigmas, rgbs and extra.  The K extra channels are
+    composited with the weights detached (instance field vs. a frozen NeRF).
+    """
+    return _CompositeRaysTrain.apply(sigmas, rgbs, extra, deltas, rays, T_thresh)
+
+
+def march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, density_bitfield, C, H, near, far,
+               align=-1, perturb=False, dt_gamma=0, max_steps=1024):
+    """-> xyzs, dirs [n_alive*n_step,3], deltas [n_alive*n_step,2] (rows a ray did not fill are zero)."""
+    lib = _lib.load()
+    rays_o, rays_d = _f(rays_o).view(-1, 3), _f(rays_d).view(-1, 3)
+    dev = rays_o.device
+    M = n_alive * n_step
+    if align > 0 and M % align:
+        M += align - M % align
+    xyzs = torch.zeros(M, 3, dtype=F32, device=dev)
+    dirs = torch.zeros(M, 3, dtype=F32, device=dev)
+    deltas = torch.zeros(M, 2, dtype=F32, device=dev)
+    check(lib.inr_march_rays(n_alive, n_step, ptr(rays_alive, I32, "rays_alive"), ptr(rays_t, F32, "rays_t"),
+                             ptr(rays_o, F32, "rays_o"), ptr(rays_d, F32, "rays_d"), float(bound), float(dt_gamma),
+                             int(max_steps), int(C), int(H), ptr(density_bitfield, U8, "density_bitfield"),
+                             ptr(_f(near)), ptr(_f(far)), ptr(xyzs), ptr(dirs), ptr(deltas), stream_ptr()),
+          "march_rays")
+    return xyzs, dirs, deltas
+
+
+def composite_rays(n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image,
+                   T_thresh=1e-4, extra=None, extra_acc=None):
+    """In-place accumulate of one inference step; marks finished rays with -1 in rays_alive."""
+    lib = _lib.load()
+    sigmas, rgbs, deltas = _f(sigmas), _f(rgbs), _f(deltas)
+    K = 0 if extra is None else extra.shape[1]
+    check(lib.inr_composite_rays(n_alive, n_step, ptr(rays_alive, I32, "rays_alive"), ptr(rays_t, F32, "rays_t"),
+                                 ptr(sigmas), ptr(rgbs), ptr(deltas), ptr(weights_sum, F32, "weights_sum"),
+                                 ptr(depth, F32, "depth"), ptr(image, F32, "image"), float(T_thresh),
+                                 ptr(_f(extra) if extra is not None else None, allow_none=True),
+                                 ptr(extra_acc, F32, "extra_acc", allow_none=True), K, stream_ptr()),
+          "composite_rays")
+
+
+def compact_alive(rays_alive, n_alive):
+    """Order-preserving removal of dead (-1) entries.  Returns (compacted int32 [n_alive], n_out int)."""
+    lib = _lib.load()
+    dev = rays_alive.device
+    scratch = lib.inr_march_workspace_bytes(n_alive) // 4
+    out = torch.empty(n_alive + scratch, dtype=I32, device=dev)
+    n_out = torch.zeros(2, dtype=I32, device=dev)
+    check(lib.inr_compact_alive(ptr(rays_alive, I32, "rays_alive"), n_alive, ptr(out), ptr(n_out), stream_ptr()),
+          "compact_alive")
+    n = int(n_out[0].item())
+    return out[:n], n

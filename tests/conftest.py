@@ -30,10 +30,10 @@ def level_table():
 
 
 @pytest.fixture(scope="session")
-def params_k8(level_table):
-    """O(1)-output parity parameters (table U(-1,1)), K = 8 instance logits."""
+def params_k16(level_table):
+    """O(1)-output parity parameters (table U(-1,1)), K = 16 instance logits."""
     from oracle.field import init_params
-    return init_params(seed=0, table=level_table, table_std=1.0, K=8)
+    return init_params(seed=0, table=level_table, table_std=1.0, K=16)
 
 
 def scene_rays(room, n=256, cam=0, seed=2):

@@ -31,7 +31,7 @@ def main():
     room = RoomScene()
     bits = room.density_bitfield(128, 1.0)
     table = hashgrid.level_table()
-    p = field.init_params(seed=0, table=table, table_std=1.0, K=8)
+    p = field.init_params(seed=0, table=table, table_std=1.0, K=16)
     aabb = np.asarray([-1, -1, -1, 1, 1, 1], np.float32)
 
     # ---- marching ---------------------------------------------------------
@@ -73,7 +73,7 @@ def main():
     rr = np.stack([rng.permutation(N), off, cnt], -1).astype(np.int32)
     sig = (rng.random(M) * 40).astype(np.float32)
     col = rng.random((M, 3)).astype(np.float32)
-    ext = rng.normal(size=(M, 8)).astype(np.float32)
+    ext = rng.normal(size=(M, 16)).astype(np.float32)
     dl = np.stack([np.full(M, 0.0034), rng.random(M) * 0.02 + 0.0034], -1).astype(np.float32)
     s = torch.tensor(sig, requires_grad=True)
     c = torch.tensor(col, requires_grad=True)
@@ -81,7 +81,7 @@ def main():
     o = composite.composite_rays_train(s, c, dl, rr, 1e-4, extra=e)
     gws = rng.normal(size=N).astype(np.float32)
     gim = rng.normal(size=(N, 3)).astype(np.float32)
-    gex = rng.normal(size=(N, 8)).astype(np.float32)
+    gex = rng.normal(size=(N, 16)).astype(np.float32)
     ((o["weights_sum"] * torch.tensor(gws)).sum() + (o["image"] * torch.tensor(gim)).sum()
      + (o["extra"] * torch.tensor(gex)).sum()).backward()
     np.savez_compressed(os.path.join(OUT, "composite.npz"), rays=rr, sigmas=sig, rgbs=col, extra=ext, deltas=dl,

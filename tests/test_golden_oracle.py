@@ -30,9 +30,9 @@ def test_golden_march(room_bitfield):
         assert (m["deltas"] == g[f"{tag}_deltas"]).all()
 
 
-def test_golden_field(level_table, params_k8):
+def test_golden_field(level_table, params_k16):
     g = np.load(os.path.join(G, "field.npz"))
-    p = params_k8
+    p = params_k16
     assert str(g["emb_sha256"]) == _sha(p["embeddings"].numpy())
     x, d = torch.from_numpy(g["x"]), torch.from_numpy(g["d"])
     with torch.no_grad():
@@ -57,9 +57,9 @@ def test_golden_composite():
     assert np.allclose(gc, g["grad_rgbs"], atol=1e-6)
 
 
-def test_golden_render(room_bitfield, level_table, params_k8):
+def test_golden_render(room_bitfield, level_table, params_k16):
     g = np.load(os.path.join(G, "render.npz"))
-    a = render.render_train(g["rays_o"], g["rays_d"], params_k8, level_table, room_bitfield, min_near=0.05,
+    a = render.render_train(g["rays_o"], g["rays_d"], params_k16, level_table, room_bitfield, min_near=0.05,
                             with_instance=True)
     assert a["total"] == int(g["train_total"])
     assert np.allclose(a["image"].detach().numpy(), g["train_image"], atol=1e-5)

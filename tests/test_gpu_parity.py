@@ -1,0 +1,366 @@
+"""HIP path (through the C ABI) vs the CPU oracle and the golden vectors.  Needs an MI355X.
+
+Tolerances: integer / index / sample-position work is BIT-EXACT; floating-point
+field outputs are within 1e-3 of the fp32 oracle as BASELINE.json's north_star
+states (the assertions below use tighter bounds where the arithmetic allows).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import scene_rays
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+DEV = "cuda:0"
+
+
+def _t(a, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(a)).to(DEV)
+    return t if dtype is None else t.to(dtype)
+
+
+@pytest.fixture(scope="module")
+def rm():
+    from instance_nerf_amd import raymarching
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return raymarching
+
+
+@pytest.fixture(scope="module")
+def bits_dev(room_bitfield):
+    return _t(room_bitfield)
+
+
+def test_device_is_gfx950():
+    import ctypes
+    from instance_nerf_amd import _lib
+    props = (ctypes.c_int64 * 4)()
+    _lib.check(_lib.load().inr_device_info(0, props))
+    assert props[1] == 64 and props[3] == 950, list(props)
+
+
+# ---------------------------------------------------------------------------- integer work
+def test_near_far_bit_exact(rm, room):
+    from oracle import rays
+    ro, rd = scene_rays(room, n=4096, seed=3)
+    ro[:8] = [[0, 0, 0], [0, 0, -3], [0, 5, 0], [.5, .5, .5], [2, 2, 2], [0, 0, 0.99], [-3, 0, 0], [0, 0, 0]]
+    rd[:8] = [[0, 0, 1], [0, 0, 1], [1, 0, 0], [-1, 0, 0], [-.6, -.6, -.52915], [0, 1, 0], [1, 0, 0], [0, 1, 0]]
+    aabb = np.asarray([-1, -1, -1, 1, 1, 1], np.float32)
+    n, f = rays.near_far_from_aabb(ro, rd, aabb, 0.05)
+    gn, gf = rm.near_far_from_aabb(_t(ro), _t(rd), _t(aabb), 0.05)
+    assert (gn.cpu().numpy() == n).all() and (gf.cpu().numpy() == f).all()
+
+
+def test_morton_packbits_bit_exact(rm):
+    from oracle import occupancy
+    rng = np.random.default_rng(0)
+    c = rng.integers(0, 1024, size=(10000, 3)).astype(np.int32)
+    m = rm.morton3D(_t(c))
+    assert (m.cpu().numpy().astype(np.uint32) == occupancy.morton3D(c)).all()
+    assert (rm.morton3D_invert(m).cpu().numpy() == c).all()
+    g = rng.normal(size=(2, 4096)).astype(np.float32)
+    assert (rm.packbits(_t(g), 0.1).cpu().numpy() == occupancy.packbits(g.ravel(), 0.1)).all()
+    assert rm.morton3D(_t(c[:0])).numel() == 0          # empty input
+
+
+@pytest.mark.parametrize("tag,gamma", [("g0", 0.0), ("g1", 1.0 / 128)])
+def test_march_train_golden_bit_exact(rm, bits_dev, tag, gamma):
+    g = np.load(os.path.join(G, "march.npz"))
+    xyzs, dirs, deltas, rays = rm.march_rays_train(_t(g["rays_o"]), _t(g["rays_d"]), 1.0, bits_dev, 1, 128,
+                                                   _t(g["nears"]), _t(g["fars"]), dt_gamma=gamma, max_steps=1024,
+                                                   noises=_t(g["noises"]))
+    assert (rays.cpu().numpy() == g[f"{tag}_rays"]).all()
+    M = g[f"{tag}_xyzs"].shape[0]
+    assert (xyzs.cpu().numpy()[:M] == g[f"{tag}_xyzs"]).all()
+    assert (deltas.cpu().numpy()[:M] == g[f"{tag}_deltas"]).all()
+    d = dirs.cpu().numpy()
+    for n, off, cnt in g[f"{tag}_rays"]:
+        assert (d[off:off + cnt] == g["rays_d"][n]).all()
+
+
+def test_march_train_large_vs_oracle(rm, room, room_bitfield, bits_dev):
+    """2048 rays across two cameras: counts, offsets and every sample position bit-exact."""
+    from oracle import march, rays
+    ro = np.concatenate([scene_rays(room, 1024, cam=c, seed=30 + c)[0] for c in (0, 5)])
+    rd = np.concatenate([scene_rays(room, 1024, cam=c, seed=30 + c)[1] for c in (0, 5)])
+    aabb = np.asarray([-1, -1, -1, 1, 1, 1], np.float32)
+    nears, fars = rays.near_far_from_aabb(ro, rd, aabb, 0.05)
+    noises = np.random.default_rng(9).random(2048).astype(np.float32)
+    ref = march.march_rays_train(ro, rd, room_bitfield, 1.0, 1, 128, nears, fars, noises, 0.0, 1024)
+    counter = torch.zeros(2, dtype=torch.int32, device=DEV)
+    xyzs, dirs, deltas, rr = rm.march_rays_train(_t(ro), _t(rd), 1.0, bits_dev, 1, 128, _t(nears), _t(fars),
+                                                 counter, noises=_t(noises))
+    assert counter.cpu().tolist() == [ref["total"], 2048]
+    assert (rr.cpu().numpy() == ref["rays"]).all()
+    assert (xyzs.cpu().numpy()[:ref["total"]] == ref["xyzs"]).all()
+    assert (deltas.cpu().numpy()[:ref["total"]] == ref["deltas"]).all()
+    # overflow: M below the total drops exactly the trailing rays
+    M = int(ref["total"] * 0.5)
+    cut = march.march_rays_train(ro, rd, room_bitfield, 1.0, 1, 128, nears, fars, noises, 0.0, 1024, M=M)
+    x2, _, _, _ = rm.march_rays_train(_t(ro), _t(rd), 1.0, bits_dev, 1, 128, _t(nears), _t(fars), None, M,
+                                      noises=_t(noises))
+    assert (x2.cpu().numpy() == cut["xyzs"]).all()
+
+
+def test_march_infer_step_bit_exact(rm, room, room_bitfield, bits_dev):
+    from oracle import march, rays
+    ro, rd = scene_rays(room, 300, seed=41)
+    aabb = np.asarray([-1, -1, -1, 1, 1, 1], np.float32)
+    nears, fars = rays.near_far_from_aabb(ro, rd, aabb, 0.05)
+    alive = np.random.default_rng(0).permutation(300)[:200].astype(np.int32)
+    rays_t = (nears + np.random.default_rng(1).random(300).astype(np.float32) * 0.4).astype(np.float32)
+    x, d, dl = march.march_rays(200, 6, alive, rays_t, ro, rd, room_bitfield, 1.0, 1, 128, nears, fars)
+    gx, gd, gdl = rm.march_rays(200, 6, _t(alive), _t(rays_t), _t(ro), _t(rd), 1.0, bits_dev, 1, 128, _t(nears),
+                                _t(fars))
+    assert (gx.cpu().numpy()[:1200] == x).all() and (gdl.cpu().numpy()[:1200] == dl).all()
+    assert (gd.cpu().numpy()[:1200] == d).all()
+
+
+def test_compact_alive(rm):
+    a = np.random.default_rng(0).integers(-1, 50, size=5000).astype(np.int32)
+    a[a < 25] = -1
+    out, n = rm.compact_alive(_t(a), 5000)
+    assert n == int((a >= 0).sum()) and (out.cpu().numpy() == a[a >= 0]).all()
+    out, n = rm.compact_alive(_t(np.full(100, -1, np.int32)), 100)
+    assert n == 0
+
+
+# ---------------------------------------------------------------------------- encoders
+def _encoder(level_table):
+    from instance_nerf_amd.gridencoder import GridEncoder
+    enc = GridEncoder(desired_resolution=2048).to(DEV)
+    for k in ("offsets", "scales", "resolutions", "hashed"):
+        assert (enc.table[k] == level_table[k]).all(), k       # host table == oracle table
+    return enc
+
+
+def test_grid_indices_bit_exact(level_table):
+    """Table column 0 = row number (exact in fp32, T < 2^24): at lattice points the encoder
+    returns the row the oracle indexes, for dense and hashed levels alike."""
+    from oracle import hashgrid
+    enc = _encoder(level_table)
+    T = level_table["total_rows"]
+    emb = torch.zeros(T, 2)
+    emb[:, 0] = torch.arange(T, dtype=torch.float32)
+    enc.embeddings.data.copy_(emb)
+    rng = np.random.default_rng(0)
+    for l in (0, 3, 4, 5, 9, 15):
+        res = int(level_table["resolutions"][l])
+        scale = np.float64(level_table["scales"][l])
+        gp = rng.integers(1, res - 1, size=(256, 3))
+        x = torch.tensor(((gp - 0.5 + 1e-3) / scale * 2 - 1), dtype=torch.float32).clamp(-1, 1)
+        idx, w = hashgrid.corner_indices_weights(x, 1.0, level_table)
+        best = w[:, l].argmax(-1)
+        assert (w[:, l].max(-1).values > 0.97).all()
+        want = idx[torch.arange(256), l, best].float() - float(level_table["offsets"][l]) * 0
+        with torch.no_grad():
+            got = enc(x.to(DEV))[:, 2 * l].cpu()
+        ref = hashgrid.encode(x, emb, 1.0, level_table)[:, 2 * l]
+        assert torch.allclose(got, ref, rtol=1e-6, atol=0.5)
+        # nearest-row check: blending weight of the other corners is < 3%, rows differ by >= 1
+        assert ((got - want).abs() / want.clamp(min=1) < 0.2).float().mean() > 0.9
+
+
+def test_grid_encode_forward_golden(level_table, params_k16):
+    g = np.load(os.path.join(G, "field.npz"))
+    enc = _encoder(level_table)
+    enc.embeddings.data.copy_(params_k16["embeddings"])
+    with torch.no_grad():
+        out = enc(_t(g["x"])).cpu().numpy()
+    assert np.abs(out - g["enc"]).max() < 1e-5
+    with torch.no_grad():
+        assert enc(_t(g["x"][:0])).shape == (0, 32)            # empty input
+
+
+def test_grid_encode_backward_vs_oracle(level_table, params_k16):
+    from oracle import hashgrid
+    enc = _encoder(level_table)
+    enc.embeddings.data.copy_(params_k16["embeddings"])
+    gen = torch.Generator().manual_seed(5)
+    x = torch.rand(3000, 3, generator=gen) * 2 - 1
+    go = torch.randn(3000, 32, generator=gen)
+    out = enc(x.to(DEV))
+    out.backward(go.to(DEV))
+    ref = hashgrid.encode_backward_table(x, go, 1.0, level_table)
+    got = enc.embeddings.grad.cpu()
+    assert (got != 0).sum() > 100000
+    assert torch.allclose(got, ref, atol=2e-5, rtol=1e-4)      # float atomics: order-dependent rounding
+
+
+def test_sh_forward_backward(level_table):
+    from instance_nerf_amd.shencoder import SHEncoder
+    from oracle import sh
+    g = np.load(os.path.join(G, "field.npz"))
+    d = torch.tensor(g["d"], requires_grad=True)
+    ref = sh.sh_encode(d)
+    go = torch.randn(ref.shape, generator=torch.Generator().manual_seed(0))
+    ref.backward(go)
+    dd = _t(g["d"]).requires_grad_(True)
+    out = SHEncoder()(dd)
+    out.backward(go.to(DEV))
+    assert np.abs(out.detach().cpu().numpy() - g["sh"]).max() < 1e-6
+    assert torch.allclose(dd.grad.cpu(), d.grad, atol=1e-5)
+
+
+# ---------------------------------------------------------------------------- fused field (MFMA)
+def _network(params, K=16, **kw):
+    from instance_nerf_amd.nerf import NeRFNetwork
+    net = NeRFNetwork(cuda_ray=True, num_instances=K, min_near=0.05, **kw).to(DEV)
+    sd = {"encoder.embeddings": params["embeddings"], "sigma_net.0.weight": params["sigma_w0"],
+          "sigma_net.1.weight": params["sigma_w1"], "color_net.0.weight": params["color_w0"],
+          "color_net.1.weight": params["color_w1"], "color_net.2.weight": params["color_w2"]}
+    if K:
+        sd.update({"instance_encoder.embeddings": params["inst_embeddings"], "instance_net.0.weight": params["inst_w0"],
+                   "instance_net.1.weight": params["inst_w1"], "instance_net.2.weight": params["inst_w2"]})
+    missing, unexpected = net.load_state_dict(sd, strict=False)
+    assert not unexpected
+    return net
+
+
+def test_fused_field_golden(params_k16):
+    g = np.load(os.path.join(G, "field.npz"))
+    net = _network(params_k16).eval()
+    with torch.no_grad():
+        sigma, rgb = net(_t(g["x"]), _t(g["d"]))
+        den = net.density(_t(g["x"]))
+        logits = net.instance(_t(g["x"]))
+    assert np.allclose(sigma.cpu().numpy(), g["sigma"], rtol=1e-4, atol=1e-6)
+    assert np.abs(rgb.cpu().numpy() - g["rgb"]).max() < 1e-5
+    assert np.allclose(den["sigma"].cpu().numpy(), g["sigma"], rtol=1e-4, atol=1e-6)
+    assert np.abs(den["geo_feat"].cpu().numpy() - g["geo"]).max() < 1e-4
+    assert np.abs(logits.cpu().numpy() - g["logits"]).max() < 1e-4
+
+
+def test_fused_equals_unfused_and_ragged_sizes(params_k16):
+    """The MFMA path and the encoder+rocBLAS path agree; sizes that are not tile multiples work."""
+    net = _network(params_k16)
+    gen = torch.Generator().manual_seed(11)
+    for M in (1, 15, 16, 17, 1000, 4097):
+        x = (torch.rand(M, 3, generator=gen) * 2 - 1).to(DEV)
+        d = torch.nn.functional.normalize(torch.randn(M, 3, generator=gen), dim=1).to(DEV)
+        with torch.no_grad():
+            s0, c0 = net(x, d)
+            l0 = net.instance(x)
+        s1, c1 = net(x, d)                      # grad enabled -> unfused path
+        l1 = net.instance(x)
+        assert s1.requires_grad and not s0.requires_grad
+        assert torch.allclose(s0, s1.detach(), rtol=1e-4, atol=1e-6)
+        assert (c0 - c1.detach()).abs().max() < 1e-5
+        assert (l0 - l1.detach()).abs().max() < 1e-4
+    with torch.no_grad():
+        s, c = net(torch.zeros(0, 3, device=DEV), torch.zeros(0, 3, device=DEV))
+    assert s.shape == (0,) and c.shape == (0, 3)
+
+
+# ---------------------------------------------------------------------------- compositing
+def test_composite_train_golden(rm):
+    g = np.load(os.path.join(G, "composite.npz"))
+    s = _t(g["sigmas"]).requires_grad_(True)
+    c = _t(g["rgbs"]).requires_grad_(True)
+    e = _t(g["extra"]).requires_grad_(True)
+    ws, depth, img, ex = rm.composite_rays_train(s, c, _t(g["deltas"]), _t(g["rays"]), 1e-4, extra=e)
+    assert np.abs(ws.detach().cpu().numpy() - g["weights_sum"]).max() < 1e-5
+    assert np.abs(img.detach().cpu().numpy() - g["image"]).max() < 1e-5
+    assert np.abs(depth.cpu().numpy() - g["depth"]).max() < 1e-5
+    assert np.abs(ex.detach().cpu().numpy() - g["extra_out"]).max() < 1e-4
+    ((ws * _t(g["g_ws"])).sum() + (img * _t(g["g_img"])).sum() + (ex * _t(g["g_extra"])).sum()).backward()
+    assert np.allclose(s.grad.cpu().numpy(), g["grad_sigmas"], atol=3e-5, rtol=1e-3)
+    assert np.abs(c.grad.cpu().numpy() - g["grad_rgbs"]).max() < 1e-5
+    assert np.abs(e.grad.cpu().numpy() - g["grad_extra"]).max() < 1e-5
+    # no extra channels / zero-count rays only
+    ws2, _, img2 = rm.composite_rays_train(s.detach(), c.detach(), _t(g["deltas"]), _t(g["rays"]), 1e-4)
+    assert torch.equal(ws2, ws.detach()) and torch.equal(img2, img.detach())
+
+
+# ---------------------------------------------------------------------------- end to end
+@pytest.mark.parametrize("mode", ["fused", "wavefront"])
+def test_render_infer_golden(params_k16, room_bitfield, mode):
+    g = np.load(os.path.join(G, "render.npz"))
+    net = _network(params_k16).eval()
+    net.density_bitfield.copy_(_t(room_bitfield))
+    with torch.no_grad():
+        out = net.render(_t(g["rays_o"])[None], _t(g["rays_d"])[None], staged=False, bg_color=1, perturb=False,
+                         infer_mode=mode)
+    assert np.abs(out["image"][0].cpu().numpy() - g["infer_image"]).max() < 1e-4
+    assert np.abs(out["weights_sum"][0].cpu().numpy() - g["infer_ws"]).max() < 1e-4
+    assert np.abs(out["instance"][0].cpu().numpy() - g["infer_instance"]).max() < 1e-3
+    if mode == "fused":
+        assert int(out["num_samples"][0]) == int(g["train_total"])
+
+
+def test_render_train_golden_and_gradients(params_k16, room, room_bitfield, level_table):
+    """Instance-field training step: rendered logits and table/MLP gradients match the oracle."""
+    from oracle import render
+    g = np.load(os.path.join(G, "render.npz"))
+    net = _network(params_k16).train()
+    net.density_bitfield.copy_(_t(room_bitfield))
+    net.freeze_nerf()
+    out = net.render(_t(g["rays_o"])[None], _t(g["rays_d"])[None], bg_color=1, perturb=False, force_all_rays=True)
+    assert np.abs(out["image"][0].detach().cpu().numpy() - g["train_image"]).max() < 1e-4
+    assert np.abs(out["instance"][0].detach().cpu().numpy() - g["train_instance"]).max() < 1e-3
+    _, labels, _ = room.trace(g["rays_o"], g["rays_d"])
+    labels = np.where(np.arange(len(labels)) % 7 == 0, -1, labels % 16)
+    loss = torch.nn.functional.cross_entropy(out["instance"][0], _t(labels).long(), ignore_index=-1)
+    loss.backward()
+    p = {k: v.clone() for k, v in params_k16.items()}
+    for k in ("inst_embeddings", "inst_w0", "inst_w1", "inst_w2"):
+        p[k].requires_grad_(True)
+    ref = render.render_train(g["rays_o"], g["rays_d"], p, level_table, room_bitfield, min_near=0.05,
+                              with_instance=True)
+    rl = render.instance_ce_loss(ref["instance"], labels)
+    rl.backward()
+    assert abs(loss.item() - rl.item()) < 1e-4
+    assert torch.allclose(net.instance_net[2].weight.grad.cpu(), p["inst_w2"].grad, atol=1e-4, rtol=1e-3)
+    assert torch.allclose(net.instance_net[0].weight.grad.cpu(), p["inst_w0"].grad, atol=1e-4, rtol=1e-3)
+    ge, re_ = net.instance_encoder.embeddings.grad.cpu(), p["inst_embeddings"].grad
+    assert (re_ != 0).sum() > 1000
+    assert torch.allclose(ge, re_, atol=1e-5, rtol=1e-3)
+    assert net.encoder.embeddings.grad is None            # NeRF stayed frozen
+
+
+def test_adam_matches_torch():
+    import ctypes
+    from instance_nerf_amd import _lib
+    lib = _lib.load()
+    gen = torch.Generator().manual_seed(0)
+    for n in (4096, 1003):
+        p0 = torch.randn(n, generator=gen)
+        ref = p0.clone().requires_grad_(True)
+        opt = torch.optim.Adam([ref], lr=1e-2, betas=(0.9, 0.99), eps=1e-15)
+        p, m, v = p0.to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+        for step in range(1, 4):
+            g = torch.randn(n, generator=gen)
+            ref.grad = g.clone()
+            opt.step()
+            _lib.check(lib.inr_adam_step(_lib.ptr(p), _lib.ptr(g.to(DEV)), _lib.ptr(m), _lib.ptr(v), n, 1e-2, 0.9,
+                                         0.99, 1e-15, step, 1.0, _lib.stream_ptr()))
+        assert torch.allclose(p.cpu(), ref.detach(), atol=1e-6, rtol=1e-5)
+
+
+def test_occupancy_update_matches_oracle(params_k16, level_table):
+    """update_extra_state with the jitter disabled equals the oracle's grid/bitfield."""
+    from oracle import field, occupancy
+    net = _network(params_k16, K=0).eval()
+    torch.manual_seed(0)
+    import instance_nerf_amd.nerf.renderer as R
+    orig = torch.rand_like
+    try:
+        torch.rand_like = lambda t: torch.full_like(t, 0.5)       # jitter (2*0.5-1) = 0
+        net.update_extra_state()
+    finally:
+        torch.rand_like = orig
+    with torch.no_grad():
+        sig = lambda xyz: field.density(torch.from_numpy(xyz), params_k16, 1.0, level_table)["sigma"].numpy()
+        grid, bits, mean = occupancy.update_density_grid(np.zeros((1, 128 ** 3), np.float32), sig, 128, 1, 1.0,
+                                                         density_thresh=net.density_thresh)
+    got = net.density_grid.cpu().numpy()
+    assert np.allclose(got, grid, rtol=2e-4, atol=1e-6)
+    assert abs(net.mean_density - mean) / mean < 1e-4
+    # cells within float noise of the threshold may flip; everything else must agree bit for bit
+    thr = min(mean, net.density_thresh)
+    near = np.abs(grid.ravel() - thr) < 1e-3 * thr
+    diff = np.unpackbits(net.density_bitfield.cpu().numpy(), bitorder="little") != np.unpackbits(bits, bitorder="little")
+    assert not (diff & ~near).any()

@@ -126,10 +126,10 @@ def test_composite_analytic_backward_matches_autograd():
     assert np.allclose(gc, c.grad.numpy(), atol=1e-6)
 
 
-def test_train_and_infer_renders_agree(room, room_bitfield, level_table, params_k8):
+def test_train_and_infer_renders_agree(room, room_bitfield, level_table, params_k16):
     ro, rd = scene_rays(room, n=96, seed=9)
-    a = render.render_train(ro, rd, params_k8, level_table, room_bitfield, min_near=0.05, with_instance=True)
-    b = render.render_infer(ro, rd, params_k8, level_table, room_bitfield, min_near=0.05, with_instance=True)
+    a = render.render_train(ro, rd, params_k16, level_table, room_bitfield, min_near=0.05, with_instance=True)
+    b = render.render_infer(ro, rd, params_k16, level_table, room_bitfield, min_near=0.05, with_instance=True)
     assert np.allclose(a["image"].detach().numpy(), b["image"], atol=1e-5)
     assert np.allclose(a["weights_sum"].detach().numpy(), b["weights_sum"], atol=1e-5)
     assert np.allclose(a["instance"].detach().numpy(), b["instance"], atol=1e-5)
