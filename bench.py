@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""bench.py - Msamples/s of the render hot path on MI355X (contract: see DESIGN.md "Measurement").
+
+One step = one full 800x800 render of the synthetic 3D-FRONT-like room (BASELINE.json
+configs[1]: hash-grid NeRF L=16,F=2, sigma+colour, SURVEY.md section 8d scene and cameras):
+ray generation -> ray/AABB -> occupancy march (count, scan, write) -> fused hash-gather + SH +
+MLP (fp32 MFMA) -> alpha compositing, everything on the GPU with parameters, bitfield and
+poses resident in HBM before the timed region.  Samples = live (occupied) samples the field
+evaluated.  N > 1 ranks (torchrun, one process per GPU): every rank renders its own views -
+no data-path collective - and value = all samples / max-over-ranks time ("weak" scaling).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+BYTES_PER_SAMPLE = 1024         # 16 levels x 8 corners x 2 features x 4 B
+
+
+def build_network(dev, seed=0):
+    from instance_nerf_amd.nerf import NeRFNetwork
+    from instance_nerf_amd.scene import RoomScene
+    torch.manual_seed(seed)
+    net = NeRFNetwork(cuda_ray=True, bound=1, min_near=0.05, density_thresh=10).to(dev)   # upstream init U(-1e-4,1e-4)
+    room = RoomScene()
+    net.density_bitfield.copy_(torch.from_numpy(room.density_bitfield(128, 1.0)).to(dev))
+    return net.eval(), room
+
+
+def cpu_baseline(room, n_rays=2048):
+    """Oracle (kind 'port') on the host cores, bounded sample: n_rays rays of view 0, same field sizes.
+
+    The oracle is numpy + torch-CPU: its many small ops stop scaling (and then regress badly)
+    beyond ~16 threads, so it runs on min(cores, 16) threads; ``cores`` reports what was used."""
+    from oracle import field, hashgrid, render as orender, rays as orays
+    threads = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(threads)
+    table = hashgrid.level_table()
+    p = field.init_params(seed=0, table=table, table_std=1e-4)
+    bits = room.density_bitfield(128, 1.0)
+    poses, intr, H, W = room.cameras()
+    stride = int(np.sqrt(H * W / n_rays))
+    ii, jj = np.meshgrid(np.arange(0, W, stride), np.arange(0, H, stride))
+    inds = (jj * W + ii).ravel()[:n_rays]
+    r = orays.get_rays(poses[:1], intr, H, W, inds=inds)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        out = orender.render_train(r["rays_o"][0], r["rays_d"][0], p, table, bits, min_near=0.05)
+    dt = time.perf_counter() - t0
+    return {"value": round(out["total"] / dt / 1e6, 5), "unit": "Msamples/s", "cores": threads, "kind": "port",
+            "sample": f"{len(inds)} rays ({stride}-pixel strided crop of view 0, 800x800 camera), "
+                      f"{out['total']} samples, oracle march+field+composite, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--res", type=int, default=800)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        print(json.dumps({"error": "no GPU: bench.py measures the HIP path only (no CPU fallback)"}))
+        sys.exit(1)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from instance_nerf_amd.nerf.utils import get_rays
+    net, room = build_network(dev)
+    poses, intr, H, W = room.cameras(H=args.res, W=args.res, focal=args.res / 2.0)
+    poses_d = torch.from_numpy(poses).to(dev)
+    field_ms, samples = [], []
+
+    # events around the dominant kernel (fused field) on the stream it is launched on
+    orig_forward = net.forward
+    ev_pairs = []
+
+    def timed_forward(x, d):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = orig_forward(x, d)
+        e1.record()
+        ev_pairs.append((e0, e1, x.shape[0]))
+        return out
+    net.forward = timed_forward
+
+    def step(i):
+        view = (i * world + rank) % poses_d.shape[0]
+        r = get_rays(poses_d[view:view + 1], intr, H, W)
+        with torch.no_grad():
+            out = net.render(r["rays_o"], r["rays_d"], staged=False, bg_color=1, perturb=False, dt_gamma=0,
+                             max_steps=1024, T_thresh=1e-4)
+        return out
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    ev_pairs.clear()
+    counters = []
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step(args.warmup + i)
+        counters.append(out["num_samples"])
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    n_samples = int(sum(int(c[0]) for c in counters))
+    kernel_ms = sum(a.elapsed_time(b) for a, b, _ in ev_pairs)
+    n_launch = len(ev_pairs)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    tot = torch.tensor([float(n_samples)], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    elapsed_all, samples_all = float(tmax.item()), float(tot.item())
+
+    if rank == 0:
+        avg_kernel_s = kernel_ms / 1e3 / max(n_launch, 1)
+        achieved = (n_samples / max(n_launch, 1)) * BYTES_PER_SAMPLE / avg_kernel_s / 1e9
+        line = {
+            "metric": "Msamples/sec (train+infer) 3D-FRONT 800x800 at 1/2/4/8 MI355X; PSNR parity",
+            "value": round(samples_all / elapsed_all / 1e6, 3),
+            "unit": "Msamples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed_all / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"render {args.res}x{args.res} synthetic 3D-FRONT-like room, hash-grid NeRF "
+                                   "L=16 F=2 T=6119864 sigma+rgb (BASELINE configs[1]), one view per step per GPU",
+                       "samples_per_step": n_samples // args.steps, "rays_per_step": H * W,
+                       "parallelism": f"views sharded over {world} GPU(s), no data-path collective"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel": "k_nerf_fwd<true> (fused hash gather + SH + MLP)",
+                         "avg_launch_ms": round(avg_kernel_s * 1e3, 4), "launches": n_launch,
+                         "algorithmic_bytes_per_sample": BYTES_PER_SAMPLE},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(room)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -154,7 +154,9 @@ extern "C" {
 
 int inr_grid_encode_forward(const float* x, const float* embeddings, const inr_grid_desc* desc, int64_t M,
                             float bound, float* out, inr_stream_t s) {
-  INR_REQUIRE(x && embeddings && desc && out && M >= 0, "bad argument");
+  INR_REQUIRE(M >= 0 && desc, "bad argument");
+  if (M == 0) return INR_OK;
+  INR_REQUIRE(x && embeddings && out, "null pointer");
   GridDesc G;
   int rc = make_grid_desc(desc, G);
   if (rc) return rc;
@@ -168,7 +170,9 @@ int inr_grid_encode_forward(const float* x, const float* embeddings, const inr_g
 
 int inr_grid_encode_backward(const float* x, const float* grad_out, const inr_grid_desc* desc, int64_t M, float bound,
                              float* grad_embeddings, inr_stream_t s) {
-  INR_REQUIRE(x && grad_out && desc && grad_embeddings && M >= 0, "bad argument");
+  INR_REQUIRE(M >= 0 && desc, "bad argument");
+  if (M == 0) return INR_OK;
+  INR_REQUIRE(x && grad_out && grad_embeddings, "null pointer");
   GridDesc G;
   int rc = make_grid_desc(desc, G);
   if (rc) return rc;
@@ -181,26 +185,29 @@ int inr_grid_encode_backward(const float* x, const float* grad_out, const inr_gr
 }
 
 int inr_sh_encode_forward(const float* d, int64_t M, int32_t degree, float* out, inr_stream_t s) {
-  INR_REQUIRE(d && out && M >= 0, "bad argument");
+  INR_REQUIRE(M >= 0, "negative M");
   INR_REQUIRE(degree >= 1 && degree <= 4, "degree must be 1..4");
   if (M == 0) return INR_OK;
+  INR_REQUIRE(d && out, "null pointer");
   k_sh_fwd<<<blocks_for(M, 256), 256, 0, as_stream(s)>>>(d, M, degree, out);
   return check_launch("sh_encode_forward");
 }
 
 int inr_sh_encode_backward(const float* grad_out, const float* d, int64_t M, int32_t degree, float* grad_d,
                            inr_stream_t s) {
-  INR_REQUIRE(grad_out && d && grad_d && M >= 0, "bad argument");
+  INR_REQUIRE(M >= 0, "negative M");
   INR_REQUIRE(degree >= 1 && degree <= 4, "degree must be 1..4");
   if (M == 0) return INR_OK;
+  INR_REQUIRE(grad_out && d && grad_d, "null pointer");
   k_sh_bwd<<<blocks_for(M, 256), 256, 0, as_stream(s)>>>(grad_out, d, M, degree, grad_d);
   return check_launch("sh_encode_backward");
 }
 
 int inr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                   float beta1, float beta2, float eps, int32_t step, float grad_scale, inr_stream_t s) {
-  INR_REQUIRE(param && grad && exp_avg && exp_avg_sq && n >= 0 && step >= 1, "bad argument");
+  INR_REQUIRE(n >= 0 && step >= 1, "bad argument");
   if (n == 0) return INR_OK;
+  INR_REQUIRE(param && grad && exp_avg && exp_avg_sq, "null pointer");
   // torch.optim.Adam: p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
   //                     = (lr*sqrt(bc2)/bc1) * m / (sqrt(v) + eps*sqrt(bc2))
   const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);

@@ -26,7 +26,6 @@ namespace inr {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kHidden = 64;
 // packed-buffer section offsets, in floats
 constexpr int kSig0 = 0;                       // 64 x 32  : 4 mt x 8 ks
 constexpr int kSig1 = kSig0 + 64 * 32;         // 16 x 64  : 1 mt x 16 ks
@@ -279,7 +278,9 @@ int inr_instance_pack_weights(const float* w0, const float* w1, const float* w2,
 int inr_nerf_forward(const float* x, const float* d, int64_t M, const int32_t* n_samples_dev, float bound,
                      const float* embeddings, const inr_grid_desc* desc, const float* packed, float density_scale,
                      float* sigma, float* rgb, float* geo_feat, inr_stream_t s) {
-  INR_REQUIRE(x && embeddings && desc && packed && sigma && M >= 0, "bad argument");
+  INR_REQUIRE(M >= 0 && desc, "bad argument");
+  if (M == 0) return INR_OK;
+  INR_REQUIRE(x && embeddings && packed && sigma, "null pointer");
   INR_REQUIRE(!rgb || d, "rgb requested without view directions");
   INR_REQUIRE(((uintptr_t)embeddings & 7) == 0 && ((uintptr_t)packed & 15) == 0, "embeddings/packed misaligned");
   GridDesc G;
@@ -300,7 +301,9 @@ int inr_nerf_forward(const float* x, const float* d, int64_t M, const int32_t* n
 
 int inr_instance_forward(const float* x, int64_t M, const int32_t* n_samples_dev, float bound, const float* embeddings,
                          const inr_grid_desc* desc, const float* packed, int32_t K, float* logits, inr_stream_t s) {
-  INR_REQUIRE(x && embeddings && desc && packed && logits && M >= 0, "bad argument");
+  INR_REQUIRE(M >= 0 && desc, "bad argument");
+  if (M == 0) return INR_OK;
+  INR_REQUIRE(x && embeddings && packed && logits, "null pointer");
   INR_REQUIRE(K > 0 && K <= 64 && K % 16 == 0, "K must be 16, 32, 48 or 64");
   INR_REQUIRE(((uintptr_t)embeddings & 7) == 0 && ((uintptr_t)packed & 15) == 0 && ((uintptr_t)logits & 15) == 0,
               "embeddings/packed/logits misaligned");

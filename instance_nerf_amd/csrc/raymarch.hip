@@ -499,29 +499,32 @@ int inr_device_info(int32_t device, int64_t* props) {
 
 int inr_near_far_from_aabb(const float* rays_o, const float* rays_d, const float* aabb, int64_t N,
                            float min_near, float* nears, float* fars, inr_stream_t s) {
-  INR_REQUIRE(rays_o && rays_d && aabb && nears && fars, "null pointer");
   INR_REQUIRE(N >= 0, "negative N");
   if (N == 0) return INR_OK;
+  INR_REQUIRE(rays_o && rays_d && aabb && nears && fars, "null pointer");
   k_near_far<<<blocks_for(N, kRayBlock), kRayBlock, 0, as_stream(s)>>>(rays_o, rays_d, aabb, N, min_near, nears, fars);
   return check_launch("near_far_from_aabb");
 }
 
 int inr_morton3D(const int32_t* coords, int64_t N, int32_t* indices, inr_stream_t s) {
-  INR_REQUIRE(coords && indices && N >= 0, "bad argument");
+  INR_REQUIRE(N >= 0, "negative N");
   if (N == 0) return INR_OK;
+  INR_REQUIRE(coords && indices, "null pointer");
   k_morton3D<<<blocks_for(N, 256), 256, 0, as_stream(s)>>>(coords, N, indices);
   return check_launch("morton3D");
 }
 int inr_morton3D_invert(const int32_t* indices, int64_t N, int32_t* coords, inr_stream_t s) {
-  INR_REQUIRE(coords && indices && N >= 0, "bad argument");
+  INR_REQUIRE(N >= 0, "negative N");
   if (N == 0) return INR_OK;
+  INR_REQUIRE(coords && indices, "null pointer");
   k_morton3D_invert<<<blocks_for(N, 256), 256, 0, as_stream(s)>>>(indices, N, coords);
   return check_launch("morton3D_invert");
 }
 int inr_packbits(const float* grid, int64_t n_bytes, float thresh, uint8_t* bitfield, inr_stream_t s) {
-  INR_REQUIRE(grid && bitfield && n_bytes >= 0, "bad argument");
-  INR_REQUIRE(((uintptr_t)grid & 15) == 0, "grid must be 16-byte aligned");
+  INR_REQUIRE(n_bytes >= 0, "negative size");
   if (n_bytes == 0) return INR_OK;
+  INR_REQUIRE(grid && bitfield, "null pointer");
+  INR_REQUIRE(((uintptr_t)grid & 15) == 0, "grid must be 16-byte aligned");
   k_packbits<<<blocks_for(n_bytes, 256), 256, 0, as_stream(s)>>>(grid, n_bytes, thresh, bitfield);
   return check_launch("packbits");
 }
@@ -593,7 +596,7 @@ int inr_compact_alive(const int32_t* rays_alive, int64_t n_alive, int32_t* out, 
   // n_alive + inr_march_workspace_bytes(n_alive)/4 int32 (compacted list first, scratch after).
   INR_REQUIRE(rays_alive && out && n_out && n_alive >= 0, "bad argument");
   if (n_alive == 0) {
-    hipMemsetAsync(n_out, 0, 2 * sizeof(int32_t), as_stream(s));
+    (void)hipMemsetAsync(n_out, 0, 2 * sizeof(int32_t), as_stream(s));
     return check_launch("compact_alive");
   }
   const unsigned nb = blocks_for(n_alive, kRayBlock);

@@ -1,0 +1,183 @@
+"""Ray generation, metrics and the Trainer.
+
+``get_rays`` and the ``Trainer`` method names follow upstream ``nerf/utils.py`` of
+the reference's un-vendored submodule (/root/reference/.gitmodules:4-6,
+README.md:27,59).  The multi-GPU idiom (one process per GPU, NCCL==RCCL process
+group, barrier after construction) mirrors the only in-tree example,
+/root/reference/nerf_rcnn/run_rcnn.py:755-760,780,823-826.
+"""
+import math
+import os
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .. import _lib
+
+
+@torch.no_grad()
+def get_rays(poses, intrinsics, H, W, N=-1, error_map=None, inds=None):
+    """poses [B,4,4] (camera-to-world), intrinsics (fx,fy,cx,cy) -> dict(rays_o, rays_d [B,N,3], inds [B,N]).
+
+    Pixel centres at +0.5; dir = ((i-cx)/fx, (j-cy)/fy, 1) normalised, rotated by R; N>0 draws N
+    random pixels (shared across the batch).
+    """
+    device = poses.device
+    B = poses.shape[0]
+    fx, fy, cx, cy = intrinsics
+    if inds is None:
+        if N > 0:
+            inds = torch.randint(0, H * W, size=[N], device=device)
+        else:
+            inds = torch.arange(H * W, device=device)
+    i = (inds % W).float() + 0.5
+    j = torch.div(inds, W, rounding_mode="floor").float() + 0.5
+    xs = (i - cx) / fx
+    ys = (j - cy) / fy
+    zs = torch.ones_like(xs)
+    d = torch.stack([xs, ys, zs], -1)
+    d = d / torch.sqrt(d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1] + d[:, 2] * d[:, 2]).unsqueeze(-1)
+    R = poses[:, :3, :3].float()
+    rays_d = (d[None, :, None, 0] * R[:, None, :, 0] + d[None, :, None, 1] * R[:, None, :, 1]
+              + d[None, :, None, 2] * R[:, None, :, 2])
+    rays_o = poses[:, None, :3, 3].float().expand_as(rays_d).contiguous()
+    return {"rays_o": rays_o, "rays_d": rays_d.contiguous(), "inds": inds[None].expand(B, -1)}
+
+
+class PSNRMeter:
+    def __init__(self):
+        self.V, self.N = 0.0, 0
+
+    def clear(self):
+        self.V, self.N = 0.0, 0
+
+    def update(self, preds, truths):
+        mse = torch.mean((preds.detach().float() - truths.detach().float()) ** 2).item()
+        self.V += -10 * math.log10(max(mse, 1e-12))
+        self.N += 1
+
+    def measure(self):
+        return self.V / max(self.N, 1)
+
+    def report(self):
+        return f"PSNR = {self.measure():.6f}"
+
+
+class MIoUMeter:
+    """Mean IoU over instance ids present in the ground truth (ignore label -1)."""
+
+    def __init__(self, num_classes):
+        self.K = num_classes
+        self.clear()
+
+    def clear(self):
+        self.inter = torch.zeros(self.K, dtype=torch.float64)
+        self.union = torch.zeros(self.K, dtype=torch.float64)
+
+    def update(self, pred_ids, true_ids):
+        p, t = pred_ids.reshape(-1).cpu(), true_ids.reshape(-1).cpu()
+        keep = t >= 0
+        p, t = p[keep], t[keep]
+        for k in range(self.K):
+            pk, tk = p == k, t == k
+            self.inter[k] += (pk & tk).sum()
+            self.union[k] += (pk | tk).sum()
+
+    def measure(self):
+        present = self.union > 0
+        return float((self.inter[present] / self.union[present]).mean()) if present.any() else 0.0
+
+    def report(self):
+        return f"mIoU = {self.measure():.6f}"
+
+
+class FusedAdam:
+    """Adam(betas, eps) with one fused HIP sweep per tensor (reads p,g,m,v; writes p,m,v once).
+
+    Drop-in for ``torch.optim.Adam`` on the subset of its interface the Trainer uses
+    (``param_groups``, ``step``, ``zero_grad``, ``state_dict``/``load_state_dict``).
+    """
+
+    def __init__(self, params, lr=1e-2, betas=(0.9, 0.99), eps=1e-15):
+        groups = params if isinstance(params, (list, tuple)) and params and isinstance(params[0], dict) \
+            else [{"params": list(params)}]
+        self.param_groups = []
+        for g in groups:
+            g = dict(g)
+            g["params"] = [p for p in g["params"]]
+            g.setdefault("lr", lr)
+            g["initial_lr"] = g["lr"]
+            self.param_groups.append(g)
+        self.betas, self.eps = betas, eps
+        self.state = {}
+        self.step_count = 0
+
+    def zero_grad(self, set_to_none=True):
+        for g in self.param_groups:
+            for p in g["params"]:
+                if set_to_none:
+                    p.grad = None
+                elif p.grad is not None:
+                    p.grad.zero_()
+
+    @torch.no_grad()
+    def step(self, grad_scale=1.0):
+        lib = _lib.load()
+        self.step_count += 1
+        for g in self.param_groups:
+            for p in g["params"]:
+                if p.grad is None or not p.requires_grad:
+                    continue
+                st = self.state.get(p)
+                if st is None:
+                    st = self.state[p] = (torch.zeros_like(p.data), torch.zeros_like(p.data))
+                grad = p.grad.contiguous()
+                _lib.check(lib.inr_adam_step(_lib.ptr(p.data, torch.float32, "param"), _lib.ptr(grad, torch.float32, "grad"),
+                                             _lib.ptr(st[0]), _lib.ptr(st[1]), p.numel(), float(g["lr"]),
+                                             self.betas[0], self.betas[1], self.eps, self.step_count,
+                                             float(grad_scale), _lib.stream_ptr()), "adam_step")
+                # the C ABI wrote p in place behind autograd's back: bump the version counter so
+                # cached MFMA-packed weights (NeRFNetwork._packed_weights) are refreshed
+                torch.autograd.graph.increment_version(p)
+
+    def state_dict(self):
+        flat = [p for g in self.param_groups for p in g["params"]]
+        return {"step": self.step_count, "lrs": [g["lr"] for g in self.param_groups],
+                "state": {i: self.state[p] for i, p in enumerate(flat) if p in self.state}}
+
+    def load_state_dict(self, sd):
+        flat = [p for g in self.param_groups for p in g["params"]]
+        self.step_count = sd["step"]
+        for g, lr in zip(self.param_groups, sd["lrs"]):
+            g["lr"] = lr
+        for i, (m, v) in sd["state"].items():
+            self.state[flat[i]] = (m.to(flat[i].device), v.to(flat[i].device))
+
+
+def allreduce_gradients(params, world_size, bucket_bytes=64 << 20):
+    """Gradient all-reduce for ray-batch data parallelism: dense fp32 buckets over
+    RCCL (backend 'nccl' on ROCm) or gloo.  The hash-table gradient (49 MB) goes as ONE message;
+    small MLP gradients are flattened into one bucket."""
+    if world_size <= 1:
+        return
+    grads = [p.grad for p in params if p.grad is not None]
+    small, cur = [], 0
+    handles = []
+    for g in grads:
+        if g.numel() * 4 >= bucket_bytes // 4:
+            handles.append(dist.all_reduce(g, async_op=True))
+        else:
+            small.append(g)
+    if small:
+        flat = torch.cat([g.reshape(-1) for g in small])
+        dist.all_reduce(flat)
+        off = 0
+        for g in small:
+            g.copy_(flat[off:off + g.numel()].view_as(g))
+            off += g.numel()
+    for h in handles:
+        h.wait()
+    for g in grads:
+        g.div_(world_size)
