@@ -54,45 +54,138 @@ __device__ __forceinline__ f32x4 relu4(f32x4 v) {
   return v;
 }
 
-// One lane's share of the encoder: 4 levels x 8 corners x float2 for sample x01.
-// out[s], s = 0..7 <-> feature 16*(s>>2) + 4q + (s&3).
-__device__ __forceinline__ void encode_quarter(const GridDesc& G, const float2* __restrict__ emb, int q, float x0,
-                                               float x1, float x2, f32x4& lo, f32x4& hi) {
-  float f[8];
+// ---- encoder, one lane's quarter of a sample -----------------------------------------------------
+// Lane q owns levels {2q, 2q+1, 8+2q, 9+2q}; their constants are loaded ONCE per wave (they do
+// not depend on the tile).  Indexing is branch-free: the dense index cx + cy*s + cz*s^2 and the
+// hash cx ^ cy*p1 ^ cz*p2 share the two multiplies (pa, pb = strides or primes) and differ only
+// in the combining operator, selected per lane with v_cndmask; (cy+1)*pa = cy*pa + pa (mod 2^32).
+// Gathers are buffer loads: one 32-bit byte offset per corner against a wave-uniform descriptor
+// of the whole table (49 MB < 4 GB), so a corner costs ONE address VGPR and is bounds-checked.
+struct LaneLevels {
+  float scale[4];
+  uint32_t base[4];   // byte offset of the level's first row
+  uint32_t pa[4], pb[4], mask[4];
+  bool hashed[4];
+  bool live[4];
+};
+
+__device__ __forceinline__ void load_lane_levels(const GridDesc& G, int q, LaneLevels& L) {
 #pragma unroll
   for (int li = 0; li < 4; ++li) {
     const int l = (li >> 1) * 8 + 2 * q + (li & 1);
-    float ax = 0.f, ay = 0.f;
-    if (l < G.num_levels) {
-      Cell c;
-      locate(G, l, x0, x1, x2, c);
-      const float2* base = emb + G.offsets[l];
-      float2 v[8];
+    const bool live = l < G.num_levels;
+    const int lc = live ? l : 0;
+    const uint32_t m = G.mask[lc], s = G.res1[lc];
+    L.live[li] = live;
+    L.scale[li] = G.scales[lc];
+    L.base[li] = G.offsets[lc] * 8u;
+    L.hashed[li] = m != 0;
+    L.pa[li] = m ? 2654435761u : s;
+    L.pb[li] = m ? 805459861u : s * s;
+    L.mask[li] = m ? m : 0xFFFFFFFFu;
+  }
+}
+
+typedef unsigned int u32x2 __attribute__((__vector_size__(2 * sizeof(unsigned int))));
+
+struct Gathered {
+  u32x2 v[4][8];      // raw table rows (float2 bits), [level][corner]
+  float fx[4], fy[4], fz[4];
+};
+
+__device__ __forceinline__ void issue_gathers(const LaneLevels& L, __amdgpu_buffer_rsrc_t rsrc, float x0, float x1,
+                                              float x2, Gathered& g) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) v[k] = base[corner_index(G, l, c, k)];
+  for (int li = 0; li < 4; ++li) {
+    const float s = L.scale[li];
+    const float px = x0 * s + 0.5f, py = x1 * s + 0.5f, pz = x2 * s + 0.5f;   // mul, add: not fused
+    const float flx = floorf(px), fly = floorf(py), flz = floorf(pz);
+    g.fx[li] = px - flx; g.fy[li] = py - fly; g.fz[li] = pz - flz;
+    const uint32_t cx = (uint32_t)flx, cy = (uint32_t)fly, cz = (uint32_t)flz;
+    const bool h = L.hashed[li];
+    const uint32_t hy0 = cy * L.pa[li], hy1 = hy0 + L.pa[li];
+    const uint32_t hz0 = cz * L.pb[li], hz1 = hz0 + L.pb[li];
+    const uint32_t yz[4] = {h ? (hy0 ^ hz0) : (hy0 + hz0), h ? (hy1 ^ hz0) : (hy1 + hz0),
+                            h ? (hy0 ^ hz1) : (hy0 + hz1), h ? (hy1 ^ hz1) : (hy1 + hz1)};
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const float w = corner_weight(c, k);
-        ax = fmaf(w, v[k].x, ax);
-        ay = fmaf(w, v[k].y, ay);
-      }
+    for (int k = 0; k < 8; ++k) {
+      const uint32_t c = cx + (k & 1);
+      const uint32_t idx = (h ? (c ^ yz[k >> 1]) : (c + yz[k >> 1])) & L.mask[li];
+      const uint32_t off = L.live[li] ? L.base[li] + idx * 8u : 0u;
+      g.v[li][k] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)off, 0, 0);
     }
-    f[2 * li] = ax;
-    f[2 * li + 1] = ay;
+  }
+}
+
+// trilinear blend in corner order: weight = (wx*wy)*wz, accumulate with fmaf.
+// out[s], s = 0..7 <-> feature 16*(s>>2) + 4q + (s&3).
+__device__ __forceinline__ void blend(const LaneLevels& L, const Gathered& g, f32x4& lo, f32x4& hi) {
+  float f[8];
+#pragma unroll
+  for (int li = 0; li < 4; ++li) {
+    float ax = 0.f, ay = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float wx = (k & 1) ? g.fx[li] : 1.0f - g.fx[li];
+      const float wy = (k & 2) ? g.fy[li] : 1.0f - g.fy[li];
+      const float wz = (k & 4) ? g.fz[li] : 1.0f - g.fz[li];
+      const float w = (wx * wy) * wz;
+      // (extract to scalars first: __builtin_bit_cast on a vector-element expression reads
+      //  element 0 for every index with this clang)
+      const unsigned bx = g.v[li][k][0], by = g.v[li][k][1];
+      ax = fmaf(w, __uint_as_float(bx), ax);
+      ay = fmaf(w, __uint_as_float(by), ay);
+    }
+    f[2 * li] = L.live[li] ? ax : 0.f;
+    f[2 * li + 1] = L.live[li] ? ay : 0.f;
   }
   lo[0] = f[0]; lo[1] = f[1]; lo[2] = f[2]; lo[3] = f[3];
   hi[0] = f[4]; hi[1] = f[5]; hi[2] = f[6]; hi[3] = f[7];
 }
 
-// 64-wide layer: out[mt] = sum over n_in4 groups of 4 k-steps.  in[g] is the B operand of group g.
+// One MLP layer: out[mt] (N_MT output tiles) = W * in, K = 16 * N_G inputs.  in[g] is the B
+// operand of k-steps 4g..4g+3.  The N_MT accumulator chains are interleaved (independent
+// MFMAs back to back: the 16x16x4 f32 MFMA issues every 32 cycles but has a 40-cycle
+// dependent latency); a single-tile layer splits K over two accumulators instead.
 template <int N_MT, int N_G>
 __device__ __forceinline__ void layer(const float4* __restrict__ w, int lane, const f32x4* in, f32x4* out) {
+  if constexpr (N_MT == 1) {
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int mt = 0; mt < N_MT; ++mt) {
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int g = 0; g < N_G; g += 2) {
+      __builtin_amdgcn_sched_barrier(0);
+      const float4 w0 = w[g * 64 + lane], w1 = w[(g + 1) * 64 + lane];
+      a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.x, in[g][0], a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.x, in[g + 1][0], a1, 0, 0, 0);
+      a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.y, in[g][1], a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.y, in[g + 1][1], a1, 0, 0, 0);
+      a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.z, in[g][2], a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.z, in[g + 1][2], a1, 0, 0, 0);
+      a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.w, in[g][3], a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.w, in[g + 1][3], a1, 0, 0, 0);
+    }
+    out[0] = a0 + a1;
+  } else {
+    f32x4 acc[N_MT];
 #pragma unroll
-    for (int g = 0; g < N_G; ++g) acc = mfma4(w[(mt * N_G + g) * 64 + lane], in[g], acc);
-    out[mt] = acc;
+    for (int mt = 0; mt < N_MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < N_G; ++g) {
+      __builtin_amdgcn_sched_barrier(0);   // keep weight reads next to their MFMAs (register pressure)
+      float4 wv[N_MT];
+#pragma unroll
+      for (int mt = 0; mt < N_MT; ++mt) wv[mt] = w[(mt * N_G + g) * 64 + lane];
+#pragma unroll
+      for (int mt = 0; mt < N_MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[mt].x, in[g][0], acc[mt], 0, 0, 0);
+#pragma unroll
+      for (int mt = 0; mt < N_MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[mt].y, in[g][1], acc[mt], 0, 0, 0);
+#pragma unroll
+      for (int mt = 0; mt < N_MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[mt].z, in[g][2], acc[mt], 0, 0, 0);
+#pragma unroll
+      for (int mt = 0; mt < N_MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[mt].w, in[g][3], acc[mt], 0, 0, 0);
+    }
+#pragma unroll
+    for (int mt = 0; mt < N_MT; ++mt) out[mt] = acc[mt];
   }
 }
 
@@ -100,35 +193,67 @@ __device__ __forceinline__ float select4(int q, float a, float b, float c, float
   return q == 0 ? a : (q == 1 ? b : (q == 2 ? c : d));
 }
 
+struct TileIn {
+  float x0, x1, x2;   // x01
+  float d0, d1, d2;
+};
+
+template <bool kDir>
+__device__ __forceinline__ void load_tile_in(const float* __restrict__ x, const float* __restrict__ d, int64_t m,
+                                             float bound, float rb, TileIn& t) {
+  t.x0 = (x[m * 3 + 0] + bound) / rb;
+  t.x1 = (x[m * 3 + 1] + bound) / rb;
+  t.x2 = (x[m * 3 + 2] + bound) / rb;
+  if constexpr (kDir) {
+    t.d0 = d[m * 3]; t.d1 = d[m * 3 + 1]; t.d2 = d[m * 3 + 2];
+  }
+}
+
+// Latency hiding is by occupancy, not by a per-wave software pipeline: a tile's 32 gathers per
+// lane are all issued back to back (addresses first, then one wait), the MFMA phase that follows
+// needs far fewer registers than the gather phase, and the kernel is held to <= 128 VGPRs so that
+// 4 waves per SIMD (16 per CU) are resident: while one wave of a SIMD runs its ~160 MFMAs the
+// other three have their table reads in flight.  (A per-wave double-buffered variant was tried
+// first: it needs ~64 more live VGPRs and spilled 239 registers at the 256-register cap.)
+constexpr int kFieldThreads = 512;   // 8 waves share one 40 KB weight image in LDS; 2 workgroups / CU
+
 template <bool kColor>
-__global__ void __launch_bounds__(256) k_nerf_fwd(const float* __restrict__ x, const float* __restrict__ d,
-                                                  int64_t M, const int32_t* __restrict__ n_dev, float bound,
-                                                  const float2* __restrict__ emb, GridDesc G,
-                                                  const float4* __restrict__ packed, float density_scale,
-                                                  float* __restrict__ sigma, float* __restrict__ rgb,
-                                                  float* __restrict__ geo) {
+__global__ void __launch_bounds__(kFieldThreads, 4) k_nerf_fwd(const float* __restrict__ x, const float* __restrict__ d,
+                                                               int64_t M, const int32_t* __restrict__ n_dev, float bound,
+                                                               const float2* __restrict__ emb, uint32_t emb_bytes, GridDesc G,
+                                                               const float4* __restrict__ packed, float density_scale,
+                                                               float* __restrict__ sigma, float* __restrict__ rgb,
+                                                               float* __restrict__ geo) {
   extern __shared__ __attribute__((aligned(16))) float4 wl[];
   constexpr int kStage = (kColor ? kNerfFloats : kCol0) / 4;
-  for (int i = threadIdx.x; i < kStage; i += 256) wl[i] = packed[i];
+  for (int i = threadIdx.x; i < kStage; i += kFieldThreads) wl[i] = packed[i];
   __syncthreads();
 
+  constexpr int kWaves = kFieldThreads / 64;
   const int lane = threadIdx.x & 63, q = lane >> 4, j = lane & 15;
   int64_t n = M;
   if (n_dev) n = min((int64_t)*n_dev, M);
   const int64_t n_tiles = (n + 15) >> 4;
-  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * 4;
+  const int64_t wave = (int64_t)blockIdx.x * kWaves + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * kWaves;
   const float rb = 2.0f * bound;
+
+  LaneLevels L;
+  load_lane_levels(G, q, L);
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)emb, 0, (int)emb_bytes, 0x00020000);
 
   for (int64_t tile = wave; tile < n_tiles; tile += n_waves) {
     const int64_t m = tile * 16 + j;
     const bool valid = m < n;
-    const int64_t mc = valid ? m : n - 1;
-    const float x0 = (x[mc * 3 + 0] + bound) / rb;
-    const float x1 = (x[mc * 3 + 1] + bound) / rb;
-    const float x2 = (x[mc * 3 + 2] + bound) / rb;
+    TileIn me;
+    load_tile_in<kColor>(x, d, valid ? m : n - 1, bound, rb, me);
 
     f32x4 enc[2];
-    encode_quarter(G, emb, q, x0, x1, x2, enc[0], enc[1]);
+    {
+      Gathered g;
+      issue_gathers(L, rsrc, me.x0, me.x1, me.x2, g);
+      __builtin_amdgcn_sched_barrier(0);   // all 32 gathers in flight before the first blend waits
+      blend(L, g, enc[0], enc[1]);
+    }
 
     f32x4 h1[4];
     layer<4, 2>(wl + kSig0 / 4, lane, enc, h1);
@@ -150,7 +275,7 @@ __global__ void __launch_bounds__(256) k_nerf_fwd(const float* __restrict__ x, c
 
     if constexpr (kColor) {
       float sh[16];
-      sh4(d[mc * 3], d[mc * 3 + 1], d[mc * 3 + 2], sh);
+      sh4(me.d0, me.d1, me.d2, sh);
       f32x4 cin[2];
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) cin[0][ks] = select4(q, sh[4 * ks], sh[4 * ks + 1], sh[4 * ks + 2], sh[4 * ks + 3]);
@@ -173,32 +298,41 @@ __global__ void __launch_bounds__(256) k_nerf_fwd(const float* __restrict__ x, c
 }
 
 template <int K_MT>
-__global__ void __launch_bounds__(256) k_instance_fwd(const float* __restrict__ x, int64_t M,
-                                                      const int32_t* __restrict__ n_dev, float bound,
-                                                      const float2* __restrict__ emb, GridDesc G,
-                                                      const float4* __restrict__ packed, float* __restrict__ logits) {
+__global__ void __launch_bounds__(kFieldThreads, 4) k_instance_fwd(const float* __restrict__ x, int64_t M,
+                                                                   const int32_t* __restrict__ n_dev, float bound,
+                                                                   const float2* __restrict__ emb, uint32_t emb_bytes,
+                                                                   GridDesc G, const float4* __restrict__ packed,
+                                                                   float* __restrict__ logits) {
   extern __shared__ __attribute__((aligned(16))) float4 wl[];
   constexpr int K = K_MT * 16;
   constexpr int kStage = (kIns2 + K * 64) / 4;
-  for (int i = threadIdx.x; i < kStage; i += 256) wl[i] = packed[i];
+  for (int i = threadIdx.x; i < kStage; i += kFieldThreads) wl[i] = packed[i];
   __syncthreads();
 
+  constexpr int kWaves = kFieldThreads / 64;
   const int lane = threadIdx.x & 63, q = lane >> 4, j = lane & 15;
   int64_t n = M;
   if (n_dev) n = min((int64_t)*n_dev, M);
   const int64_t n_tiles = (n + 15) >> 4;
-  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * 4;
+  const int64_t wave = (int64_t)blockIdx.x * kWaves + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * kWaves;
   const float rb = 2.0f * bound;
+
+  LaneLevels L;
+  load_lane_levels(G, q, L);
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)emb, 0, (int)emb_bytes, 0x00020000);
 
   for (int64_t tile = wave; tile < n_tiles; tile += n_waves) {
     const int64_t m = tile * 16 + j;
     const bool valid = m < n;
-    const int64_t mc = valid ? m : n - 1;
-    const float x0 = (x[mc * 3 + 0] + bound) / rb;
-    const float x1 = (x[mc * 3 + 1] + bound) / rb;
-    const float x2 = (x[mc * 3 + 2] + bound) / rb;
+    TileIn me;
+    load_tile_in<false>(x, nullptr, valid ? m : n - 1, bound, rb, me);
     f32x4 enc[2];
-    encode_quarter(G, emb, q, x0, x1, x2, enc[0], enc[1]);
+    {
+      Gathered g;
+      issue_gathers(L, rsrc, me.x0, me.x1, me.x2, g);
+      __builtin_amdgcn_sched_barrier(0);   // all 32 gathers in flight before the first blend waits
+      blend(L, g, enc[0], enc[1]);
+    }
     f32x4 h1[4], h2[4], o[K_MT];
     layer<4, 2>(wl + kIns0 / 4, lane, enc, h1);
 #pragma unroll
@@ -239,10 +373,18 @@ static int kidx_color_in(int ks, int q) {
   return row >= 1 ? 16 + row - 1 : -1;           // row 0 is the raw density: not an input
 }
 
-static int grid_for(int64_t n_tiles) {
-  // persistent waves: 256 CUs x up to 3 workgroups (40 KB LDS, ~<=168 VGPRs each)
-  const int64_t want = (n_tiles + 3) / 4;
-  return (int)std::max<int64_t>(1, std::min<int64_t>(want, 256 * 3));
+// Persistent grid: exactly the number of workgroups that are co-resident (CUs x blocks/CU from
+// the occupancy query for THIS kernel), so no second partial round of blocks trails the first.
+template <class Kern>
+static int grid_for(Kern kern, size_t lds_bytes, int64_t n_tiles) {
+  int dev = 0, cus = 256, per_cu = 2;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount;
+  }
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kFieldThreads, lds_bytes) != hipSuccess || per_cu < 1) per_cu = 2;
+  const int64_t want = (n_tiles + kFieldThreads / 64 - 1) / (kFieldThreads / 64);
+  return (int)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)cus * per_cu));
 }
 
 }  // namespace inr
@@ -287,15 +429,23 @@ int inr_nerf_forward(const float* x, const float* d, int64_t M, const int32_t* n
   int rc = make_grid_desc(desc, G);
   if (rc) return rc;
   if (M == 0) return INR_OK;
-  const int grid = grid_for((M + 15) / 16);
   const float2* e = reinterpret_cast<const float2*>(embeddings);
   const float4* p = reinterpret_cast<const float4*>(packed);
-  if (rgb)
-    k_nerf_fwd<true><<<grid, 256, kNerfFloats * sizeof(float), as_stream(s)>>>(x, d, M, n_samples_dev, bound, e, G, p,
-                                                                             density_scale, sigma, rgb, geo_feat);
-  else
-    k_nerf_fwd<false><<<grid, 256, kCol0 * sizeof(float), as_stream(s)>>>(x, d, M, n_samples_dev, bound, e, G, p,
-                                                                        density_scale, sigma, nullptr, geo_feat);
+  const uint64_t emb_bytes64 = (uint64_t)desc->offsets[desc->num_levels] * 8ull;
+  INR_REQUIRE(emb_bytes64 < (1ull << 31), "table larger than 2 GiB is not addressable by the 32-bit gather offsets");
+  const uint32_t emb_bytes = (uint32_t)emb_bytes64;
+  const int64_t n_tiles = (M + 15) / 16;
+  if (rgb) {
+    const size_t lds = kNerfFloats * sizeof(float);
+    const int grid = grid_for(k_nerf_fwd<true>, lds, n_tiles);
+    k_nerf_fwd<true><<<grid, kFieldThreads, lds, as_stream(s)>>>(x, d, M, n_samples_dev, bound, e, emb_bytes, G, p,
+                                                      density_scale, sigma, rgb, geo_feat);
+  } else {
+    const size_t lds = kCol0 * sizeof(float);
+    const int grid = grid_for(k_nerf_fwd<false>, lds, n_tiles);
+    k_nerf_fwd<false><<<grid, kFieldThreads, lds, as_stream(s)>>>(x, d, M, n_samples_dev, bound, e, emb_bytes, G, p,
+                                                       density_scale, sigma, nullptr, geo_feat);
+  }
   return check_launch("nerf_forward");
 }
 
@@ -311,16 +461,19 @@ int inr_instance_forward(const float* x, int64_t M, const int32_t* n_samples_dev
   int rc = make_grid_desc(desc, G);
   if (rc) return rc;
   if (M == 0) return INR_OK;
-  const int grid = grid_for((M + 15) / 16);
   const float2* e = reinterpret_cast<const float2*>(embeddings);
   const float4* p = reinterpret_cast<const float4*>(packed);
+  const uint64_t emb_bytes64 = (uint64_t)desc->offsets[desc->num_levels] * 8ull;
+  INR_REQUIRE(emb_bytes64 < (1ull << 31), "table larger than 2 GiB is not addressable by the 32-bit gather offsets");
+  const uint32_t eb = (uint32_t)emb_bytes64;
   const size_t lds = (size_t)(kIns2 + K * 64) * sizeof(float);
+  const int64_t n_tiles = (M + 15) / 16;
   hipStream_t st = as_stream(s);
   switch (K / 16) {
-    case 1: k_instance_fwd<1><<<grid, 256, lds, st>>>(x, M, n_samples_dev, bound, e, G, p, logits); break;
-    case 2: k_instance_fwd<2><<<grid, 256, lds, st>>>(x, M, n_samples_dev, bound, e, G, p, logits); break;
-    case 3: k_instance_fwd<3><<<grid, 256, lds, st>>>(x, M, n_samples_dev, bound, e, G, p, logits); break;
-    default: k_instance_fwd<4><<<grid, 256, lds, st>>>(x, M, n_samples_dev, bound, e, G, p, logits); break;
+    case 1: k_instance_fwd<1><<<grid_for(k_instance_fwd<1>, lds, n_tiles), kFieldThreads, lds, st>>>(x, M, n_samples_dev, bound, e, eb, G, p, logits); break;
+    case 2: k_instance_fwd<2><<<grid_for(k_instance_fwd<2>, lds, n_tiles), kFieldThreads, lds, st>>>(x, M, n_samples_dev, bound, e, eb, G, p, logits); break;
+    case 3: k_instance_fwd<3><<<grid_for(k_instance_fwd<3>, lds, n_tiles), kFieldThreads, lds, st>>>(x, M, n_samples_dev, bound, e, eb, G, p, logits); break;
+    default: k_instance_fwd<4><<<grid_for(k_instance_fwd<4>, lds, n_tiles), kFieldThreads, lds, st>>>(x, M, n_samples_dev, bound, e, eb, G, p, logits); break;
   }
   return check_launch("instance_forward");
 }
