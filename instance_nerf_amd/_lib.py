@@ -13,7 +13,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_ui
 import torch  # noqa: F401  (must precede CDLL: shares the HIP runtime)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libinr_hip.so")
+LIB_PATH = os.environ.get("INR_LIB_PATH") or os.path.join(_HERE, "csrc", "libinr_hip.so")   # env override: profiling builds only
 MAX_LEVELS = 16
 
 

@@ -26,6 +26,13 @@ namespace inr {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Ablation builds for profiling only (tools/build_probe.py): 1 = no table gathers (features are
+// synthesised from x), 2 = no MLP (features are summed into sigma).  The shipped library is
+// always built with INR_PROBE_MODE == 0.
+#ifndef INR_PROBE_MODE
+#define INR_PROBE_MODE 0
+#endif
+
 // packed-buffer section offsets, in floats
 constexpr int kSig0 = 0;                       // 64 x 32  : 4 mt x 8 ks
 constexpr int kSig1 = kSig0 + 64 * 32;         // 16 x 64  : 1 mt x 16 ks
@@ -215,6 +222,28 @@ __device__ __forceinline__ void load_tile_in(const float* __restrict__ x, const 
 // 4 waves per SIMD (16 per CU) are resident: while one wave of a SIMD runs its ~160 MFMAs the
 // other three have their table reads in flight.  (A per-wave double-buffered variant was tried
 // first: it needs ~64 more live VGPRs and spilled 239 registers at the 256-register cap.)
+// XCD-aware persistent schedule.  Workgroup b runs on XCD b % 8 (observed dispatch order; used
+// for speed only - any placement gives the same results).  The sample stream is ray-major and
+// rays are image-ordered, so a contiguous range of tiles is a compact region of space: XCD k takes
+// the k-th eighth of the tiles and its workgroups stride through it, which keeps each XCD's
+// private 4 MB L2 on one part of the hash table's working set instead of all of it.
+__device__ __forceinline__ void xcd_tile_range(int64_t n_tiles, int waves_per_block, int64_t& begin, int64_t& end,
+                                               int64_t& step) {
+  const int nb = gridDim.x, b = blockIdx.x;
+  const int w = threadIdx.x >> 6;
+  if (nb % 8 == 0) {
+    const int xcd = b & 7, local = b >> 3, per = nb >> 3;
+    const int64_t lo = n_tiles * xcd / 8, hi = n_tiles * (xcd + 1) / 8;
+    begin = lo + (int64_t)local * waves_per_block + w;
+    end = hi;
+    step = (int64_t)per * waves_per_block;
+  } else {
+    begin = (int64_t)b * waves_per_block + w;
+    end = n_tiles;
+    step = (int64_t)nb * waves_per_block;
+  }
+}
+
 constexpr int kFieldThreads = 512;   // 8 waves share one 40 KB weight image in LDS; 2 workgroups / CU
 
 template <bool kColor>
@@ -234,26 +263,41 @@ __global__ void __launch_bounds__(kFieldThreads, 4) k_nerf_fwd(const float* __re
   int64_t n = M;
   if (n_dev) n = min((int64_t)*n_dev, M);
   const int64_t n_tiles = (n + 15) >> 4;
-  const int64_t wave = (int64_t)blockIdx.x * kWaves + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * kWaves;
   const float rb = 2.0f * bound;
+  int64_t tile_begin, tile_end, tile_step;
+  xcd_tile_range(n_tiles, kWaves, tile_begin, tile_end, tile_step);
 
   LaneLevels L;
   load_lane_levels(G, q, L);
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)emb, 0, (int)emb_bytes, 0x00020000);
 
-  for (int64_t tile = wave; tile < n_tiles; tile += n_waves) {
+  for (int64_t tile = tile_begin; tile < tile_end; tile += tile_step) {
     const int64_t m = tile * 16 + j;
     const bool valid = m < n;
     TileIn me;
     load_tile_in<kColor>(x, d, valid ? m : n - 1, bound, rb, me);
 
     f32x4 enc[2];
+#if INR_PROBE_MODE == 1
+    enc[0] = f32x4{me.x0, me.x1, me.x2, me.x0 * me.x1};
+    enc[1] = f32x4{me.x1 * me.x2, me.x2 * me.x0, me.x0 + me.x1, me.x2 - me.x1};
+#else
     {
       Gathered g;
       issue_gathers(L, rsrc, me.x0, me.x1, me.x2, g);
       __builtin_amdgcn_sched_barrier(0);   // all 32 gathers in flight before the first blend waits
       blend(L, g, enc[0], enc[1]);
     }
+#endif
+#if INR_PROBE_MODE == 2
+    {
+      float acc = 0.f;
+      for (int t = 0; t < 4; ++t) acc += enc[0][t] + enc[1][t];
+      acc += __shfl_xor(acc, 16); acc += __shfl_xor(acc, 32);
+      if (valid && q == 0) { sigma[m] = acc; if (rgb) { rgb[m * 3] = acc; rgb[m * 3 + 1] = me.d0; rgb[m * 3 + 2] = me.d1; } }
+      continue;
+    }
+#endif
 
     f32x4 h1[4];
     layer<4, 2>(wl + kSig0 / 4, lane, enc, h1);
@@ -314,14 +358,15 @@ __global__ void __launch_bounds__(kFieldThreads, 4) k_instance_fwd(const float* 
   int64_t n = M;
   if (n_dev) n = min((int64_t)*n_dev, M);
   const int64_t n_tiles = (n + 15) >> 4;
-  const int64_t wave = (int64_t)blockIdx.x * kWaves + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * kWaves;
   const float rb = 2.0f * bound;
+  int64_t tile_begin, tile_end, tile_step;
+  xcd_tile_range(n_tiles, kWaves, tile_begin, tile_end, tile_step);
 
   LaneLevels L;
   load_lane_levels(G, q, L);
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)emb, 0, (int)emb_bytes, 0x00020000);
 
-  for (int64_t tile = wave; tile < n_tiles; tile += n_waves) {
+  for (int64_t tile = tile_begin; tile < tile_end; tile += tile_step) {
     const int64_t m = tile * 16 + j;
     const bool valid = m < n;
     TileIn me;

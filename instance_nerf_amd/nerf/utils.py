@@ -181,3 +181,145 @@ def allreduce_gradients(params, world_size, bucket_bytes=64 << 20):
         h.wait()
     for g in grads:
         g.div_(world_size)
+
+
+class Trainer:
+    """Minimal counterpart of upstream's ``Trainer`` for the two stages the reference runs
+    (SURVEY.md section 3.1): NeRF training (MSE on rgb) and instance-field training (NeRF frozen,
+    cross entropy of rendered logits vs. matched-mask ids, ignore -1).
+
+    Same method names and step semantics as upstream (``train_step`` / ``eval_step`` / ``test_step``
+    / ``train`` / ``evaluate`` / ``save_checkpoint`` / ``load_checkpoint``); Adam(betas .9/.99,
+    eps 1e-15), LambdaLR 0.1^(step/iters), occupancy update every 16 steps.  One process per GPU;
+    with world_size > 1 each rank draws its own rays and gradients are all-reduced (RCCL).
+    """
+
+    def __init__(self, name, opt, model, criterion=None, optimizer=None, lr=1e-2, iters=30000,
+                 local_rank=0, world_size=1, device=None, workspace="workspace", fused_adam=True,
+                 stage="nerf", update_extra_interval=16):
+        self.name, self.opt, self.model = name, opt, model
+        self.world_size, self.local_rank = world_size, local_rank
+        self.device = device or (torch.device("cuda", local_rank) if torch.cuda.is_available() else torch.device("cpu"))
+        self.stage = stage
+        self.workspace = workspace
+        self.update_extra_interval = update_extra_interval
+        self.criterion = criterion or (torch.nn.MSELoss(reduction="none") if stage == "nerf" else None)
+        model.to(self.device)
+        if stage == "instance":
+            model.freeze_nerf()
+        groups = [{"params": [p for p in g["params"] if p.requires_grad], "lr": g["lr"]} for g in model.get_params(lr)]
+        groups = [g for g in groups if g["params"]]
+        if optimizer is not None:
+            self.optimizer = optimizer(groups)
+        elif fused_adam and self.device.type == "cuda":
+            self.optimizer = FusedAdam(groups, lr=lr, betas=(0.9, 0.99), eps=1e-15)
+        else:
+            self.optimizer = torch.optim.Adam(groups, lr=lr, betas=(0.9, 0.99), eps=1e-15)
+        self.iters = iters
+        self.base_lrs = [g["lr"] for g in self.optimizer.param_groups]
+        self.global_step = 0
+        self.epoch = 0
+        self.stats = {"loss": [], "results": []}
+        self.bg_color = 1
+
+    # -- steps -------------------------------------------------------------------------------
+    def _lr_step(self):
+        f = 0.1 ** min(self.global_step / self.iters, 1)
+        for g, b in zip(self.optimizer.param_groups, self.base_lrs):
+            g["lr"] = b * f
+
+    def train_step(self, data):
+        """data: rays_o, rays_d [B,N,3] and images [B,N,3] (stage 'nerf') or masks int64 [B,N] (stage 'instance')."""
+        outputs = self.model.render(data["rays_o"], data["rays_d"], staged=False, bg_color=self.bg_color, perturb=True,
+                                    force_all_rays=False, **vars(self.opt) if self.opt is not None else {})
+        if self.stage == "nerf":
+            pred = outputs["image"]
+            loss = self.criterion(pred, data["images"]).mean()
+            return pred, data["images"], loss
+        logits = outputs["instance"]
+        K = logits.shape[-1]
+        loss = torch.nn.functional.cross_entropy(logits.reshape(-1, K), data["masks"].reshape(-1).long(), ignore_index=-1)
+        return logits, data["masks"], loss
+
+    @torch.no_grad()
+    def eval_step(self, data):
+        outputs = self.model.render(data["rays_o"], data["rays_d"], staged=True, bg_color=self.bg_color, perturb=False,
+                                    **vars(self.opt) if self.opt is not None else {})
+        if self.stage == "nerf":
+            loss = self.criterion(outputs["image"], data["images"]).mean()
+            return outputs["image"], outputs["depth"], data["images"], loss
+        logits = outputs["instance"]
+        K = logits.shape[-1]
+        loss = torch.nn.functional.cross_entropy(logits.reshape(-1, K), data["masks"].reshape(-1).long(), ignore_index=-1)
+        return logits.argmax(-1), outputs["depth"], data["masks"], loss
+
+    @torch.no_grad()
+    def test_step(self, data, bg_color=None, perturb=False):
+        outputs = self.model.render(data["rays_o"], data["rays_d"], staged=True, bg_color=bg_color or self.bg_color,
+                                    perturb=perturb, **vars(self.opt) if self.opt is not None else {})
+        return outputs["image"], outputs["depth"], outputs.get("instance")
+
+    # -- loops -------------------------------------------------------------------------------
+    def train_one_step(self, data):
+        self.model.train()
+        if self.model.cuda_ray and self.global_step % self.update_extra_interval == 0:
+            self.model.update_extra_state()
+        self.global_step += 1
+        self.optimizer.zero_grad()
+        _, _, loss = self.train_step(data)
+        loss.backward()
+        params = [p for g in self.optimizer.param_groups for p in g["params"]]
+        allreduce_gradients(params, self.world_size)
+        self._lr_step()
+        self.optimizer.step()
+        return loss.detach()
+
+    def train(self, train_loader, valid_loader=None, max_epochs=1):
+        for epoch in range(max_epochs):
+            self.epoch += 1
+            total, n = 0.0, 0
+            for data in train_loader:
+                total += float(self.train_one_step(data))
+                n += 1
+            self.stats["loss"].append(total / max(n, 1))
+            if valid_loader is not None:
+                self.evaluate(valid_loader)
+
+    @torch.no_grad()
+    def evaluate(self, loader):
+        self.model.eval()
+        meter = PSNRMeter() if self.stage == "nerf" else MIoUMeter(self.model.num_instances)
+        for data in loader:
+            pred, _, truth, _ = self.eval_step(data)
+            meter.update(pred, truth)
+        result = meter.measure()
+        if self.world_size > 1:
+            t = torch.tensor([result], dtype=torch.float64, device=self.device)
+            dist.all_reduce(t)
+            result = float(t.item()) / self.world_size
+        self.stats["results"].append(result)
+        return result
+
+    # -- checkpoint (upstream keys: epoch, global_step, stats, model, optimizer, mean_count, mean_density) ----
+    def save_checkpoint(self, path=None):
+        path = path or os.path.join(self.workspace, "checkpoints", f"{self.name}_ep{self.epoch:04d}.pth")
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        state = {"epoch": self.epoch, "global_step": self.global_step, "stats": self.stats,
+                 "model": self.model.state_dict(), "optimizer": self.optimizer.state_dict()}
+        if self.model.cuda_ray:
+            state["mean_count"] = self.model.mean_count
+            state["mean_density"] = self.model.mean_density
+        if self.local_rank == 0:
+            torch.save(state, path)
+        return path
+
+    def load_checkpoint(self, path, model_only=False):
+        state = torch.load(path, map_location=self.device, weights_only=False)
+        self.model.load_state_dict(state["model"], strict=False)
+        if self.model.cuda_ray:
+            self.model.mean_count = state.get("mean_count", 0)
+            self.model.mean_density = state.get("mean_density", 0)
+        if model_only:
+            return
+        self.epoch, self.global_step, self.stats = state["epoch"], state["global_step"], state["stats"]
+        self.optimizer.load_state_dict(state["optimizer"])

@@ -1,0 +1,20 @@
+"""Builds ablation variants of the library for profiling (never shipped): gpurun_out-free, in tools/_probe/."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from instance_nerf_amd import build as b  # noqa: E402
+
+out = os.path.join(ROOT, "tools", "_probe")
+os.makedirs(out, exist_ok=True)
+for mode in sys.argv[1:] or ["1", "2"]:
+    objs = []
+    for src in b.SOURCES:
+        obj = os.path.join(out, f"{src[:-4]}.m{mode}.o")
+        subprocess.check_call(["hipcc", "-x", "hip", "-c", os.path.join(b.CSRC, src), "-o", obj, f"-DINR_PROBE_MODE={mode}"] + b.FLAGS)
+        objs.append(obj)
+    lib = os.path.join(out, f"libinr_probe{mode}.so")
+    subprocess.check_call(["hipcc", "-shared", "-o", lib] + objs + ["--offload-arch=gfx950"])
+    print(lib)
