@@ -2,8 +2,13 @@
 // the sigma / colour / instance MLPs in ONE kernel; the 32 encoded features and all hidden
 // activations live in registers and never touch HBM.
 //
-// MLP on the matrix cores, exact fp32: v_mfma_f32_16x16x4_f32 (A, B one f32 VGPR per lane;
-// A[i=lane&15][k=lane>>4], B[k=lane>>4][j=lane&15], D[i=4*(lane>>4)+r][j=lane&15]).
+// MLP on the matrix cores with fp32-class accuracy at bf16 rate: v_mfma_f32_16x16x32_bf16 with a
+// 3-term split  x*w ~= xh*wh + xh*wl + xl*wh  (xh/xl, wh/wl = bf16 head and remainder; the dropped
+// xl*wl term is 2^-16 relative; products are exact and accumulate in fp32).  60 MFMAs of ~16 cycles
+// per 16-sample tile instead of 160 fp32 MFMAs (v_mfma_f32_16x16x4_f32) of 32 cycles.  The exact-fp32
+// variant is kept behind -DINR_MLP_FP32=1 for A/B runs.
+// Operand maps (both shapes): A[i=lane&15][k-slot lane>>4], B[k-slot lane>>4][j=lane&15],
+// D[i=4*(lane>>4)+r][j=lane&15]; the bf16 shape carries 8 k values per slot, the f32 shape one.
 //
 // Transposed formulation - H^T = W * X^T - with a 16-sample tile per wave:
 //   * B operand = activations: lane (q = lane>>4, j = lane&15) holds input k-slot q of sample j;
@@ -25,6 +30,11 @@
 namespace inr {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#ifndef INR_MLP_FP32
+#define INR_MLP_FP32 0
+#endif
 
 // Ablation builds for profiling only (tools/build_probe.py): 1 = no table gathers (features are
 // synthesised from x), 2 = no MLP (features are summed into sigma).  The shipped library is
@@ -196,6 +206,88 @@ __device__ __forceinline__ void layer(const float4* __restrict__ w, int lane, co
   }
 }
 
+// ---- split-bf16 MLP ----------------------------------------------------------------------------------
+// Packed weights (host, inr_*_pack_weights): per section [mt][step][hi|lo][lane][8 bf16]; the 8 values
+// of lane (q, i) in step s are W[16mt + i][kidx(s, q, e)], e = 0..7, with
+//   hidden / encoder inputs: kidx = 16*(2s + (e>>2)) + 4q + (e&3)   (= D register e&3 of output tile 2s + (e>>2))
+// so the B operand of step s is registers {h[2s][0..3], h[2s+1][0..3]} of the previous layer, in place.
+struct SplitB {
+  uint4 hi, lo;   // 8 bf16 each
+};
+
+// bf16 head by truncation (v_perm_b32 packs the two high halves), remainder exactly in fp32, then truncated.
+__device__ __forceinline__ void split2(float x0, float x1, uint32_t& hi, uint32_t& lo) {
+  const uint32_t u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
+  hi = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+  const float l0 = x0 - __uint_as_float(u0 & 0xFFFF0000u);
+  const float l1 = x1 - __uint_as_float(u1 & 0xFFFF0000u);
+  lo = __builtin_amdgcn_perm(__float_as_uint(l1), __float_as_uint(l0), 0x07060302u);
+}
+__device__ __forceinline__ SplitB split8(const f32x4 a, const f32x4 b) {
+  SplitB r;
+  split2(a[0], a[1], r.hi.x, r.lo.x);
+  split2(a[2], a[3], r.hi.y, r.lo.y);
+  split2(b[0], b[1], r.hi.z, r.lo.z);
+  split2(b[2], b[3], r.hi.w, r.lo.w);
+  return r;
+}
+__device__ __forceinline__ f32x4 mfma_bf(const uint4 a, const uint4 b, const f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// out[mt] = W * in over N_S steps of 32 inputs.  w: section base (uint4 = 8 bf16), fragment (mt, s, hl) at
+// ((mt*N_S + s)*2 + hl)*64 + lane.  Independent accumulator chains are interleaved.
+template <int N_MT, int N_S>
+__device__ __forceinline__ void layer_bf(const uint4* __restrict__ w, int lane, const SplitB* in, f32x4* out) {
+  if constexpr (N_MT == 1) {
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0;
+#pragma unroll
+    for (int st = 0; st < N_S; ++st) {
+      __builtin_amdgcn_sched_barrier(0);
+      const uint4 wh = w[(st * 2 + 0) * 64 + lane], wlo = w[(st * 2 + 1) * 64 + lane];
+      a0 = mfma_bf(wh, in[st].hi, a0);
+      a1 = mfma_bf(wlo, in[st].hi, a1);
+      a2 = mfma_bf(wh, in[st].lo, a2);
+    }
+    out[0] = a0 + (a1 + a2);
+  } else {
+    f32x4 acc[N_MT];
+#pragma unroll
+    for (int mt = 0; mt < N_MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int st = 0; st < N_S; ++st) {
+      __builtin_amdgcn_sched_barrier(0);   // keep weight reads next to their MFMAs (register pressure)
+      uint4 wh[N_MT], wlo[N_MT];
+#pragma unroll
+      for (int mt = 0; mt < N_MT; ++mt) {
+        wh[mt] = w[((mt * N_S + st) * 2 + 0) * 64 + lane];
+        wlo[mt] = w[((mt * N_S + st) * 2 + 1) * 64 + lane];
+      }
+#pragma unroll
+      for (int mt = 0; mt < N_MT; ++mt) acc[mt] = mfma_bf(wh[mt], in[st].hi, acc[mt]);
+#pragma unroll
+      for (int mt = 0; mt < N_MT; ++mt) acc[mt] = mfma_bf(wlo[mt], in[st].hi, acc[mt]);
+#pragma unroll
+      for (int mt = 0; mt < N_MT; ++mt) acc[mt] = mfma_bf(wh[mt], in[st].lo, acc[mt]);
+    }
+#pragma unroll
+    for (int mt = 0; mt < N_MT; ++mt) out[mt] = acc[mt];
+  }
+}
+
+// Layer entry points used by the kernels: `in` is N_G groups of 4 registers (N_G = K/16).
+template <int N_MT, int N_G>
+__device__ __forceinline__ void mlp_layer(const float4* __restrict__ wsec, int lane, const f32x4* in, f32x4* out) {
+#if INR_MLP_FP32
+  layer<N_MT, N_G>(wsec, lane, in, out);
+#else
+  SplitB b[N_G / 2];
+#pragma unroll
+  for (int st = 0; st < N_G / 2; ++st) b[st] = split8(in[2 * st], in[2 * st + 1]);
+  layer_bf<N_MT, N_G / 2>(reinterpret_cast<const uint4*>(wsec), lane, b, out);
+#endif
+}
+
 __device__ __forceinline__ float select4(int q, float a, float b, float c, float d) {
   return q == 0 ? a : (q == 1 ? b : (q == 2 ? c : d));
 }
@@ -300,11 +392,11 @@ __global__ void __launch_bounds__(kFieldThreads, 4) k_nerf_fwd(const float* __re
 #endif
 
     f32x4 h1[4];
-    layer<4, 2>(wl + kSig0 / 4, lane, enc, h1);
+    mlp_layer<4, 2>(wl + kSig0 / 4, lane, enc, h1);
 #pragma unroll
     for (int t = 0; t < 4; ++t) h1[t] = relu4(h1[t]);
     f32x4 h2[1];
-    layer<1, 4>(wl + kSig1 / 4, lane, h1, h2);      // row 0 = raw density, rows 1..15 = geo features
+    mlp_layer<1, 4>(wl + kSig1 / 4, lane, h1, h2);      // row 0 = raw density, rows 1..15 = geo features
 
     if (valid) {
       if (q == 0) sigma[m] = expf(h2[0][0]) * density_scale;
@@ -325,13 +417,13 @@ __global__ void __launch_bounds__(kFieldThreads, 4) k_nerf_fwd(const float* __re
       for (int ks = 0; ks < 4; ++ks) cin[0][ks] = select4(q, sh[4 * ks], sh[4 * ks + 1], sh[4 * ks + 2], sh[4 * ks + 3]);
       cin[1] = h2[0];                                 // k-slot (q, r) = sigma-net row 4q+r (row 0 has zero weight)
       f32x4 c1[4], c2[4], o[1];
-      layer<4, 2>(wl + kCol0 / 4, lane, cin, c1);
+      mlp_layer<4, 2>(wl + kCol0 / 4, lane, cin, c1);
 #pragma unroll
       for (int t = 0; t < 4; ++t) c1[t] = relu4(c1[t]);
-      layer<4, 4>(wl + kCol1 / 4, lane, c1, c2);
+      mlp_layer<4, 4>(wl + kCol1 / 4, lane, c1, c2);
 #pragma unroll
       for (int t = 0; t < 4; ++t) c2[t] = relu4(c2[t]);
-      layer<1, 4>(wl + kCol2 / 4, lane, c2, o);
+      mlp_layer<1, 4>(wl + kCol2 / 4, lane, c2, o);
       if (valid && q == 0) {
         rgb[m * 3 + 0] = 1.0f / (1.0f + expf(-o[0][0]));
         rgb[m * 3 + 1] = 1.0f / (1.0f + expf(-o[0][1]));
@@ -379,13 +471,13 @@ __global__ void __launch_bounds__(kFieldThreads, 4) k_instance_fwd(const float* 
       blend(L, g, enc[0], enc[1]);
     }
     f32x4 h1[4], h2[4], o[K_MT];
-    layer<4, 2>(wl + kIns0 / 4, lane, enc, h1);
+    mlp_layer<4, 2>(wl + kIns0 / 4, lane, enc, h1);
 #pragma unroll
     for (int t = 0; t < 4; ++t) h1[t] = relu4(h1[t]);
-    layer<4, 4>(wl + kIns1 / 4, lane, h1, h2);
+    mlp_layer<4, 4>(wl + kIns1 / 4, lane, h1, h2);
 #pragma unroll
     for (int t = 0; t < 4; ++t) h2[t] = relu4(h2[t]);
-    layer<K_MT, 4>(wl + kIns2 / 4, lane, h2, o);
+    mlp_layer<K_MT, 4>(wl + kIns2 / 4, lane, h2, o);
     if (valid) {
 #pragma unroll
       for (int mt = 0; mt < K_MT; ++mt) {
@@ -398,8 +490,41 @@ __global__ void __launch_bounds__(kFieldThreads, 4) k_instance_fwd(const float* 
 
 // ---- host-side packing into fragment order ------------------------------------------------------
 // W is [n_out, n_in] row-major.  kidx(ks, q) -> input column (or -1 for a zero slot).
+static inline uint16_t bf16_rne(float x) {
+  uint32_t u;
+  memcpy(&u, &x, 4);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+static inline float bf16_to_f32(uint16_t h) {
+  uint32_t u = (uint32_t)h << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+// bf16 split layout: [mt][step][hi|lo][lane][8]; kidx(step*8 + e style) is expressed through the same
+// k-step functions as the fp32 layout: slot e of step s is fp32 k-step 4*(2s + (e>>2)) + (e&3).
 template <class KIdx>
-static void pack_section(float* dst, const float* W, int n_out, int n_in, int n_mt, int n_ks, KIdx kidx) {
+static void pack_section_bf16(float* dst_f, const float* W, int n_out, int n_in, int n_mt, int n_ks, KIdx kidx) {
+  uint16_t* dst = reinterpret_cast<uint16_t*>(dst_f);
+  const int n_s = n_ks / 8;
+  for (int mt = 0; mt < n_mt; ++mt)
+    for (int st = 0; st < n_s; ++st)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int e = 0; e < 8; ++e) {
+          const int row = 16 * mt + (lane & 15);
+          const int col = kidx(4 * (2 * st + (e >> 2)) + (e & 3), lane >> 4);
+          float v = 0.f;
+          if (row < n_out && col >= 0 && col < n_in) v = W[(size_t)row * n_in + col];
+          const uint16_t hi = bf16_rne(v);
+          const uint16_t lo = bf16_rne(v - bf16_to_f32(hi));
+          dst[((((size_t)(mt * n_s + st) * 2 + 0) * 64 + lane) * 8) + e] = hi;
+          dst[((((size_t)(mt * n_s + st) * 2 + 1) * 64 + lane) * 8) + e] = lo;
+        }
+}
+
+template <class KIdx>
+static void pack_section_f32(float* dst, const float* W, int n_out, int n_in, int n_mt, int n_ks, KIdx kidx) {
   for (int mt = 0; mt < n_mt; ++mt)
     for (int ks = 0; ks < n_ks; ++ks)
       for (int lane = 0; lane < 64; ++lane) {
@@ -409,6 +534,14 @@ static void pack_section(float* dst, const float* W, int n_out, int n_in, int n_
         if (row < n_out && col >= 0 && col < n_in) v = W[(size_t)row * n_in + col];
         dst[frag_pos(mt, ks, lane, n_ks)] = v;
       }
+}
+template <class KIdx>
+static void pack_section(float* dst, const float* W, int n_out, int n_in, int n_mt, int n_ks, KIdx kidx) {
+#if INR_MLP_FP32
+  pack_section_f32(dst, W, n_out, n_in, n_mt, n_ks, kidx);
+#else
+  pack_section_bf16(dst, W, n_out, n_in, n_mt, n_ks, kidx);
+#endif
 }
 static int kidx_enc(int ks, int q) { return 16 * (ks >> 2) + 4 * q + (ks & 3); }      // encoder features
 static int kidx_hidden(int ks, int q) { return 16 * (ks >> 2) + 4 * q + (ks & 3); }   // previous D registers

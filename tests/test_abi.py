@@ -38,7 +38,8 @@ def test_no_cpu_fallback():
 
 
 def test_host_side_packing_roundtrip():
-    """Weight packing is host code: every weight appears exactly once in fragment order."""
+    """Weight packing is host code.  Default build: bf16 head + remainder per weight
+    ([mt][step][hi|lo][lane][8]); every weight appears exactly once and hi + lo reproduces it to 2^-16."""
     import ctypes
     import numpy as np
     from instance_nerf_amd import _lib
@@ -48,9 +49,13 @@ def test_host_side_packing_roundtrip():
     out = np.zeros(lib.inr_nerf_packed_floats(), np.float32)
     rc = lib.inr_nerf_pack_weights(*[w.ctypes.data_as(ctypes.c_void_p) for w in ws], out.ctypes.data_as(ctypes.c_void_p))
     assert rc == 0
-    nz = np.sort(out[out != 0])
+    h = out.view(np.uint16).astype(np.uint32)
+    vals = (h << 16).view(np.float32).reshape(-1, 2, 64, 8)          # [mt*step, hi|lo, lane, e]
+    rec = (vals[:, 0] + vals[:, 1]).ravel()
+    nz = np.sort(rec[rec != 0])
     ref = np.sort(np.concatenate([w.ravel() for w in ws]))
-    assert nz.shape == ref.shape and (nz == ref).all()
+    assert nz.shape == ref.shape
+    assert np.allclose(nz, ref, rtol=2.0 ** -15, atol=1e-30)
 
 
 def test_product_never_imports_oracle():
