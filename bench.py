@@ -105,10 +105,13 @@ def main():
 
     def step(i):
         view = (i * world + rank) % poses_d.shape[0]
-        r = get_rays(poses_d[view:view + 1], intr, H, W)
+        r = get_rays(poses_d[view:view + 1], intr, H, W, patch=4)       # same rays, 4x4-patch order
         with torch.no_grad():
             out = net.render(r["rays_o"], r["rays_d"], staged=False, bg_color=1, perturb=False, dt_gamma=0,
                              max_steps=1024, T_thresh=1e-4)
+            frame = torch.empty(H * W, 3, device=dev)
+            frame[r["inds"][0]] = out["image"][0]                       # back to row-major pixels
+        out["frame"] = frame.view(H, W, 3)
         return out
 
     def barrier():

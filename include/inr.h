@@ -92,6 +92,25 @@ int inr_march_rays_train_write(const float* rays_o, const float* rays_d, const u
                                const int32_t* rays /*[N,3] from _count*/, float* xyzs /*[M,3]*/,
                                float* dirs /*[M,3]*/, float* deltas /*[M,2]*/, inr_stream_t s);
 
+/* ---- fused full-frame inference path (replaces the alive-ray loop of NeRFRenderer.run_cuda, a5) ----
+ * Same counting pass as training (inr_march_rays_train_count), then samples are written in the
+ * PATCH-INTERLEAVED layout: rays in groups of 16 consecutive rays; inside a group
+ *   slot(r, k) = rays[g0,1] + sum_i min(c_i, k) + #{ i < r : c_i > k }
+ * (all k-th samples of a group adjacent).  A group whose slots do not fit in M is dropped whole.
+ * inr_composite_rays_patch_forward composites that layout (per ray, in k order, stop at T < T_thresh;
+ * same arithmetic as inr_composite_rays_train_forward); extra_out must be zero-initialised.          */
+int inr_march_rays_patch_write(const float* rays_o, const float* rays_d, const uint8_t* bitfield,
+                               float bound, float dt_gamma, int32_t max_steps, int64_t N,
+                               int32_t cascade, int32_t H, int64_t M, const float* nears,
+                               const float* fars, const float* noises /*nullable*/,
+                               const int32_t* rays /*[N,3] from inr_march_rays_train_count*/,
+                               float* xyzs, float* dirs, float* deltas, inr_stream_t s);
+int inr_composite_rays_patch_forward(const float* sigmas, const float* rgbs, const float* deltas,
+                                     const int32_t* rays, int64_t N, int64_t M, float T_thresh,
+                                     const float* extra /*[M,K] nullable*/, int32_t K,
+                                     float* weights_sum, float* depth, float* image,
+                                     float* extra_out /*[N,K], zeroed*/, inr_stream_t s);
+
 /* ---- inference march/composite (replace raymarching.march_rays / composite_rays, a5) */
 int inr_march_rays(int64_t n_alive, int32_t n_step, const int32_t* rays_alive, const float* rays_t,
                    const float* rays_o, const float* rays_d, float bound, float dt_gamma,
@@ -103,7 +122,8 @@ int inr_composite_rays(int64_t n_alive, int32_t n_step, int32_t* rays_alive, flo
                        float* weights_sum, float* depth, float* image, float T_thresh,
                        const float* extra /*[n_alive*n_step,K] nullable*/, float* extra_acc /*[N,K]*/,
                        int32_t K, inr_stream_t s);
-/* order-preserving compaction of rays_alive >= 0; n_out (device int32) = survivors */
+/* order-preserving compaction of rays_alive >= 0; n_out (device int32[2]) = {survivors, n_alive};
+ * `out` needs room for n_alive + inr_march_workspace_bytes(n_alive)/4 int32 (list first, scratch after) */
 int inr_compact_alive(const int32_t* rays_alive, int64_t n_alive, int32_t* out, int32_t* n_out,
                       inr_stream_t s);
 

@@ -460,6 +460,130 @@ __global__ void __launch_bounds__(kRayBlock) k_composite_train_extra_bwd(
     if (lane < K) grad_extra[((int64_t)off + s) * K + lane] = 0.0f;
 }
 
+// ------------------------------------------------------------------------------------------
+// Patch-interleaved sample layout (fused full-frame inference path).
+//
+// Rays are taken in groups of 16 consecutive rays (the caller orders rays so that a group is a
+// 4x4 pixel patch; any order is CORRECT, a compact patch is FAST).  Inside a group the samples
+// are stored step-major: all k-th samples of the group's rays are adjacent,
+//     slot(r, k) = base_g + sum_i min(c_i, k) + #{ i < r : c_i > k }
+// (c_i = sample count of ray i of the group, base_g = exclusive scan of the counts at the group's
+// first ray - exactly what inr_march_rays_train_count leaves in rays[:,1]).  A 16-sample tile of
+// the field kernel is then a compact 4x4xfew-steps block of space instead of 16 steps along one
+// ray: neighbouring lanes hit the same hash-grid cells and 128-byte lines (measured: gather phase
+// 10.2 -> 6.8 ms per 37 M samples), and the compositing reads of a group are coalesced.
+constexpr int kGroup = 16;
+
+struct GroupCursor {
+  int c[kGroup];
+  int S;      // base + sum_i min(c_i, k) for the current k
+  int r;
+  int k;
+  __device__ __forceinline__ void init(int my_count, int my_offset) {
+    const int lane = threadIdx.x & 63, g0 = lane & ~(kGroup - 1);
+    r = lane & (kGroup - 1);
+#pragma unroll
+    for (int i = 0; i < kGroup; ++i) c[i] = __shfl(my_count, g0 + i, 64);
+    S = __shfl(my_offset, g0, 64);
+    k = 0;
+  }
+  __device__ __forceinline__ int total() const {
+    int t = 0;
+#pragma unroll
+    for (int i = 0; i < kGroup; ++i) t += c[i];
+    return t;
+  }
+  // slot of this ray's k-th sample; must be called for k = 0, 1, 2, ... in order
+  __device__ __forceinline__ int next() {
+    int nact = 0, rank = 0;
+#pragma unroll
+    for (int i = 0; i < kGroup; ++i) {
+      const int gt = c[i] > k ? 1 : 0;
+      nact += gt;
+      rank += (i < r) ? gt : 0;
+    }
+    const int slot = S + rank;
+    S += nact;
+    ++k;
+    return slot;
+  }
+};
+
+__global__ void __launch_bounds__(kRayBlock) k_march_write_patch(MarchParams P, const float* __restrict__ rays_o,
+                                                                 const float* __restrict__ rays_d, int64_t N, int64_t M,
+                                                                 const float* __restrict__ nears,
+                                                                 const float* __restrict__ fars,
+                                                                 const float* __restrict__ noises,
+                                                                 const int32_t* __restrict__ rays,
+                                                                 float* __restrict__ xyzs, float* __restrict__ dirs,
+                                                                 float* __restrict__ deltas) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int off = n < N ? rays[n * 3 + 1] : 0;
+  const int cnt = n < N ? rays[n * 3 + 2] : 0;
+  GroupCursor cur;
+  cur.init(cnt, off);                                   // all 64 lanes take part in the shuffles
+  if (cnt == 0 || (int64_t)cur.S + cur.total() > M) return;   // a group that does not fit is dropped whole
+  const Ray r = load_ray(rays_o, rays_d, n);
+  const float t0 = start_t(P, nears[n], noises ? noises[n] : 0.0f);
+  march_ray(P, r, t0, fars[n], cnt, [&](float px, float py, float pz, float dt, float delta) {
+    const int64_t i = cur.next();
+    xyzs[i * 3 + 0] = px; xyzs[i * 3 + 1] = py; xyzs[i * 3 + 2] = pz;
+    dirs[i * 3 + 0] = r.dx; dirs[i * 3 + 1] = r.dy; dirs[i * 3 + 2] = r.dz;
+    deltas[i * 2 + 0] = dt; deltas[i * 2 + 1] = delta;
+  });
+}
+
+// one lane per ray; the 16 lanes of a group walk k in lockstep, so slot ranks come from one ballot
+__global__ void __launch_bounds__(kRayBlock) k_composite_patch_fwd(const float* __restrict__ sigmas,
+                                                                   const float* __restrict__ rgbs,
+                                                                   const float* __restrict__ deltas,
+                                                                   const int32_t* __restrict__ rays, int64_t N, int64_t M,
+                                                                   float T_thresh, const float* __restrict__ extra, int K,
+                                                                   float* __restrict__ weights_sum,
+                                                                   float* __restrict__ depth, float* __restrict__ image,
+                                                                   float* __restrict__ extra_out) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63, g0 = lane & ~(kGroup - 1), rr = lane & (kGroup - 1);
+  const int32_t rid = n < N ? rays[n * 3] : 0;
+  const int off = n < N ? rays[n * 3 + 1] : 0;
+  int cnt = n < N ? rays[n * 3 + 2] : 0;
+  int S = __shfl(off, g0, 64);
+  int gtot = cnt;                                          // group total and wave-wide max count
+#pragma unroll
+  for (int d = 1; d < kGroup; d <<= 1) gtot += __shfl_xor(gtot, d, 64);
+  if ((int64_t)S + gtot > M) cnt = 0;                      // group was dropped by the writer
+  int maxc = cnt;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) maxc = max(maxc, __shfl_xor(maxc, d, 64));
+  float T = 1.0f, r = 0, g = 0, b = 0, ws = 0, t = 0, dsum = 0;
+  bool done = false;
+  for (int k = 0; k < maxc; ++k) {
+    const bool active = k < cnt;
+    const unsigned long long m = __ballot(active);
+    const unsigned field = (unsigned)(m >> g0) & 0xFFFFu;
+    if (active && !done) {
+      const int64_t i = (int64_t)S + __popc(field & ((1u << rr) - 1u));
+      const float2 dl = reinterpret_cast<const float2*>(deltas)[i];
+      const float alpha = 1.0f - expf(-sigmas[i] * dl.x);
+      const float w = alpha * T;
+      r += w * rgbs[i * 3]; g += w * rgbs[i * 3 + 1]; b += w * rgbs[i * 3 + 2];
+      t += dl.y;
+      dsum += w * t;
+      ws += w;
+      if (extra) {
+        for (int c = 0; c < K; ++c) extra_out[(int64_t)rid * K + c] += w * extra[i * K + c];
+      }
+      T *= 1.0f - alpha;
+      if (T < T_thresh) done = true;
+    }
+    S += __popc(field);
+  }
+  if (n < N) {
+    weights_sum[rid] = ws; depth[rid] = dsum;
+    image[rid * 3] = r; image[rid * 3 + 1] = g; image[rid * 3 + 2] = b;
+  }
+}
+
 static MarchParams make_params(const uint8_t* bits, float bound, float dt_gamma, int max_steps, int C, int H) {
   MarchParams P;
   P.bits = bits;
@@ -564,6 +688,35 @@ int inr_march_rays_train_write(const float* rays_o, const float* rays_d, const u
   k_march_write<<<blocks_for(N, kRayBlock), kRayBlock, 0, as_stream(s)>>>(P, rays_o, rays_d, N, M, nears, fars, noises,
                                                                           rays, xyzs, dirs, deltas);
   return check_launch("march_rays_train_write");
+}
+
+int inr_march_rays_patch_write(const float* rays_o, const float* rays_d, const uint8_t* bitfield, float bound,
+                               float dt_gamma, int32_t max_steps, int64_t N, int32_t cascade, int32_t H, int64_t M,
+                               const float* nears, const float* fars, const float* noises, const int32_t* rays,
+                               float* xyzs, float* dirs, float* deltas, inr_stream_t s) {
+  INR_REQUIRE(rays_o && rays_d && bitfield && nears && fars && rays, "null pointer");
+  INR_REQUIRE(N > 0 && M >= 0, "bad sizes");
+  if (M == 0) return INR_OK;
+  INR_REQUIRE(xyzs && dirs && deltas, "null output");
+  const MarchParams P = make_params(bitfield, bound, dt_gamma, max_steps, cascade, H);
+  k_march_write_patch<<<blocks_for(N, kRayBlock), kRayBlock, 0, as_stream(s)>>>(P, rays_o, rays_d, N, M, nears, fars,
+                                                                                noises, rays, xyzs, dirs, deltas);
+  return check_launch("march_rays_patch_write");
+}
+
+int inr_composite_rays_patch_forward(const float* sigmas, const float* rgbs, const float* deltas, const int32_t* rays,
+                                     int64_t N, int64_t M, float T_thresh, const float* extra, int32_t K,
+                                     float* weights_sum, float* depth, float* image, float* extra_out,
+                                     inr_stream_t s) {
+  INR_REQUIRE(N >= 0 && M >= 0, "bad sizes");
+  if (N == 0) return INR_OK;
+  INR_REQUIRE(rays && weights_sum && depth && image, "null pointer");
+  INR_REQUIRE(M == 0 || (sigmas && rgbs && deltas), "null sample arrays");
+  INR_REQUIRE(!extra || (extra_out && K > 0), "extra needs extra_out and K > 0 (extra_out must be zeroed)");
+  INR_REQUIRE(((uintptr_t)deltas & 7) == 0, "deltas must be 8-byte aligned");
+  k_composite_patch_fwd<<<blocks_for(N, kRayBlock), kRayBlock, 0, as_stream(s)>>>(
+      sigmas, rgbs, deltas, rays, N, M, T_thresh, extra, K, weights_sum, depth, image, extra_out);
+  return check_launch("composite_rays_patch_forward");
 }
 
 int inr_march_rays(int64_t n_alive, int32_t n_step, const int32_t* rays_alive, const float* rays_t,

@@ -94,7 +94,22 @@ class NeRFRenderer(nn.Module):
         results = {}
         with_instance = getattr(self, "num_instances", 0) > 0
 
-        if self.training or infer_mode == "fused":
+        if not self.training and infer_mode == "fused":
+            # full batch in four launches, patch-interleaved sample layout (csrc/raymarch.hip)
+            counter = torch.zeros(2, dtype=torch.int32, device=device)
+            xyzs, dirs, deltas, rays = raymarching.march_rays_patch(
+                rays_o, rays_d, self.bound, self.density_bitfield, self.cascade, self.grid_size, nears, fars,
+                dt_gamma, max_steps, noises=noises if perturb else None, counter=counter)
+            sigmas, rgbs = self(xyzs, dirs)
+            if self.density_scale != 1:
+                sigmas = self.density_scale * sigmas
+            extra = self.instance(xyzs) if with_instance else None
+            out = raymarching.composite_rays_patch(sigmas, rgbs, deltas, rays, T_thresh, extra=extra)
+            weights_sum, depth, image = out[0], out[1], out[2]
+            if with_instance:
+                results["instance"] = out[3].view(*prefix, -1)
+            results["num_samples"] = counter
+        elif self.training or infer_mode == "fused_raymajor":
             if self.training:
                 counter = self.step_counter[self.local_step % 16]
                 counter.zero_()

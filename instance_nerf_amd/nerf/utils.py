@@ -17,12 +17,30 @@ import torch.distributed as dist
 from .. import _lib
 
 
+_PATCH_INDS = {}
+
+
+def patch_order(H, W, patch, device):
+    """Flat pixel indices of an HxW image enumerated patch by patch (patch x patch pixels, row-major
+    inside a patch).  16 consecutive entries = one 4x4 patch = one group of the patch-interleaved
+    sample layout.  Cached per (H, W, patch, device)."""
+    key = (H, W, patch, str(device))
+    if key not in _PATCH_INDS:
+        jj, ii = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+        ii, jj = ii.reshape(-1), jj.reshape(-1)
+        k = ((jj // patch) * ((W + patch - 1) // patch) + (ii // patch)) * (patch * patch) + (jj % patch) * patch + (ii % patch)
+        _PATCH_INDS[key] = torch.argsort(k).to(device)
+    return _PATCH_INDS[key]
+
+
 @torch.no_grad()
-def get_rays(poses, intrinsics, H, W, N=-1, error_map=None, inds=None):
+def get_rays(poses, intrinsics, H, W, N=-1, error_map=None, inds=None, patch=0):
     """poses [B,4,4] (camera-to-world), intrinsics (fx,fy,cx,cy) -> dict(rays_o, rays_d [B,N,3], inds [B,N]).
 
     Pixel centres at +0.5; dir = ((i-cx)/fx, (j-cy)/fy, 1) normalised, rotated by R; N>0 draws N
-    random pixels (shared across the batch).
+    random pixels (shared across the batch).  ``patch=4`` (full images only) enumerates the pixels
+    4x4-patch by patch instead of row-major - same rays, an order the renderer's patch-interleaved
+    layout turns into compact tiles; scatter results back with ``image.view(-1,3)[inds] = pred``.
     """
     device = poses.device
     B = poses.shape[0]
@@ -30,6 +48,8 @@ def get_rays(poses, intrinsics, H, W, N=-1, error_map=None, inds=None):
     if inds is None:
         if N > 0:
             inds = torch.randint(0, H * W, size=[N], device=device)
+        elif patch:
+            inds = patch_order(H, W, patch, device)
         else:
             inds = torch.arange(H * W, device=device)
     i = (inds % W).float() + 0.5

@@ -116,6 +116,93 @@ def march_rays_train(rays_o, rays_d, bound, density_bitfield, C, H, nears, fars,
     return xyzs, dirs, deltas, rays
 
 
+GROUP = 16   # rays per group of the patch-interleaved layout (csrc/raymarch.hip::kGroup)
+
+
+def march_rays_patch(rays_o, rays_d, bound, density_bitfield, C, H, nears, fars, dt_gamma=0, max_steps=1024,
+                     noises=None, counter=None):
+    """Full-frame inference march in the PATCH-INTERLEAVED layout (no upstream counterpart; it
+    replaces the alive-ray loop).  Rays are grouped 16 at a time in the order given; inside a group
+    all k-th samples are adjacent:  slot(r,k) = rays[g0,1] + sum_i min(c_i,k) + #{i<r: c_i>k}.
+
+    -> xyzs [M,3], dirs [M,3], deltas [M,2], rays int32 [N,3] = (ray, offset-of-ray-in-ray-order, count);
+    M is the exact sample count (one 4-byte device->host read).
+    """
+    lib = _lib.load()
+    rays_o, rays_d = _f(rays_o).view(-1, 3), _f(rays_d).view(-1, 3)
+    dev = rays_o.device
+    N = rays_o.shape[0]
+    nears, fars = _f(nears), _f(fars)
+    noises = _f(noises) if noises is not None else None
+    if counter is None:
+        counter = torch.zeros(2, dtype=I32, device=dev)
+    rays = torch.empty(N, 3, dtype=I32, device=dev)
+    ws = torch.empty(lib.inr_march_workspace_bytes(N), dtype=U8, device=dev)
+    args = (ptr(rays_o, F32, "rays_o"), ptr(rays_d, F32, "rays_d"), ptr(density_bitfield, U8, "density_bitfield"),
+            float(bound), float(dt_gamma), int(max_steps), N, int(C), int(H))
+    check(lib.inr_march_rays_train_count(*args, ptr(nears, F32, "nears"), ptr(fars, F32, "fars"),
+                                         ptr(noises, F32, "noises", allow_none=True), ptr(rays),
+                                         ptr(counter, I32, "counter"), ptr(ws), stream_ptr()), "march_rays_train_count")
+    M = int(counter[0].item())
+    xyzs = torch.empty(M, 3, dtype=F32, device=dev)       # every row is written: no memset needed
+    dirs = torch.empty(M, 3, dtype=F32, device=dev)
+    deltas = torch.empty(M, 2, dtype=F32, device=dev)
+    check(lib.inr_march_rays_patch_write(*args, M, ptr(nears), ptr(fars), ptr(noises, F32, "noises", allow_none=True),
+                                         ptr(rays), ptr(xyzs, allow_none=M == 0), ptr(dirs, allow_none=M == 0),
+                                         ptr(deltas, allow_none=M == 0), stream_ptr()), "march_rays_patch_write")
+    return xyzs, dirs, deltas, rays
+
+
+def composite_rays_patch(sigmas, rgbs, deltas, rays, T_thresh=1e-4, extra=None):
+    """Compositing of the patch-interleaved layout (inference only, no autograd).
+    -> weights_sum [N], depth [N], image [N,3] (, extra_out [N,K])."""
+    lib = _lib.load()
+    sigmas, rgbs, deltas = _f(sigmas), _f(rgbs), _f(deltas)
+    dev = rays.device
+    N, M = rays.shape[0], sigmas.shape[0]
+    K = 0 if extra is None else extra.shape[1]
+    ws = torch.empty(N, dtype=F32, device=dev)
+    depth = torch.empty(N, dtype=F32, device=dev)
+    image = torch.empty(N, 3, dtype=F32, device=dev)
+    extra_out = torch.zeros(N, K, dtype=F32, device=dev) if K else None
+    none_ok = M == 0
+    check(lib.inr_composite_rays_patch_forward(
+        ptr(sigmas, F32, "sigmas", allow_none=none_ok), ptr(rgbs, F32, "rgbs", allow_none=none_ok),
+        ptr(deltas, F32, "deltas", allow_none=none_ok), ptr(rays, I32, "rays"), N, M, float(T_thresh),
+        ptr(_f(extra) if extra is not None else None, allow_none=True), K, ptr(ws), ptr(depth), ptr(image),
+        ptr(extra_out, allow_none=True), stream_ptr()), "composite_rays_patch_forward")
+    if K:
+        return ws, depth, image, extra_out
+    return ws, depth, image
+
+
+def patch_slots(rays):
+    """Reference (torch, host-side index maths) of the patch-interleaved slot map: for every ray n and
+    step k < count_n the sample row.  Returns int64 [total] rows in RAY-MAJOR order, i.e.
+    ``xyzs_patch[patch_slots(rays)]`` is the ray-major sample array.  Used by tests and tools."""
+    r = rays.cpu().long()
+    N = r.shape[0]
+    cnt, off = r[:, 2], r[:, 1]
+    pad = (-N) % GROUP
+    c = torch.cat([cnt, torch.zeros(pad, dtype=torch.long)]).view(-1, GROUP)          # [G,16]
+    base = torch.cat([off, torch.zeros(pad, dtype=torch.long)]).view(-1, GROUP)[:, 0]  # offset of the group's first ray
+    out = []
+    for g in range(c.shape[0]):
+        cg = c[g]
+        kmax = int(cg.max())
+        if kmax == 0:
+            continue
+        k = torch.arange(kmax)[:, None]                                               # [k,1]
+        act = cg[None, :] > k                                                          # [k,16]
+        nact = act.sum(1)
+        S = base[g] + torch.cat([torch.zeros(1, dtype=torch.long), nact.cumsum(0)[:-1]])
+        rank = act.long().cumsum(1) - act.long()
+        slot = S[:, None] + rank                                                       # [k,16]
+        for i in range(GROUP):
+            out.append(slot[: int(cg[i]), i])
+    return torch.cat(out) if out else torch.zeros(0, dtype=torch.long)
+
+
 class _CompositeRaysTrain(torch.autograd.Function):
     @staticmethod
     def forward(ctx, sigmas, rgbs, extra, deltas, rays, T_thresh):

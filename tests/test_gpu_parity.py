@@ -364,3 +364,53 @@ def test_occupancy_update_matches_oracle(params_k16, level_table):
     near = np.abs(grid.ravel() - thr) < 1e-3 * thr
     diff = np.unpackbits(net.density_bitfield.cpu().numpy(), bitorder="little") != np.unpackbits(bits, bitorder="little")
     assert not (diff & ~near).any()
+
+
+# ---------------------------------------------------------------------------- patch-interleaved layout
+def test_patch_layout_is_a_permutation_of_ray_major(rm, room, room_bitfield, bits_dev):
+    """The fused-frame writer places sample (ray, k) at slot base + sum_i min(c_i,k) + #{i<r: c_i>k}:
+    un-permuting with the host-side reference map gives the oracle's ray-major samples bit for bit."""
+    from oracle import march, rays
+    ro, rd = scene_rays(room, 1000, seed=61)            # 1000: last group is partial (1000 % 16 = 8)
+    aabb = np.asarray([-1, -1, -1, 1, 1, 1], np.float32)
+    nears, fars = rays.near_far_from_aabb(ro, rd, aabb, 0.05)
+    ref = march.march_rays_train(ro, rd, room_bitfield, 1.0, 1, 128, nears, fars)
+    xyzs, dirs, deltas, rr = rm.march_rays_patch(_t(ro), _t(rd), 1.0, bits_dev, 1, 128, _t(nears), _t(fars))
+    assert (rr.cpu().numpy() == ref["rays"]).all()
+    slots = rm.patch_slots(rr)
+    assert slots.shape[0] == ref["total"] and len(set(slots.tolist())) == ref["total"]
+    assert (xyzs.cpu().numpy()[slots] == ref["xyzs"]).all()
+    assert (deltas.cpu().numpy()[slots] == ref["deltas"]).all()
+    assert (dirs.cpu().numpy()[slots] == ref["dirs"]).all()
+    # every group's k-th samples are adjacent: slots of (ray r, step 0) within a group are consecutive
+    first = slots[torch.as_tensor(ref["rays"][:16, 1].astype(np.int64))[ref["rays"][:16, 2] > 0]]
+    assert (first.sort().values == torch.arange(first.min(), first.min() + len(first))).all()
+
+
+def test_composite_patch_equals_ray_major(rm, room, room_bitfield, bits_dev):
+    from oracle import rays
+    ro, rd = scene_rays(room, 700, seed=62)
+    aabb = np.asarray([-1, -1, -1, 1, 1, 1], np.float32)
+    nears, fars = rays.near_far_from_aabb(ro, rd, aabb, 0.05)
+    xp, dp, dlp, rr = rm.march_rays_patch(_t(ro), _t(rd), 1.0, bits_dev, 1, 128, _t(nears), _t(fars))
+    xr, dr, dlr, rr2 = rm.march_rays_train(_t(ro), _t(rd), 1.0, bits_dev, 1, 128, _t(nears), _t(fars))
+    M = xp.shape[0]
+    gen = torch.Generator().manual_seed(0)
+    sig_r = (torch.rand(M, generator=gen) * 80).to(DEV)
+    rgb_r = torch.rand(M, 3, generator=gen).to(DEV)
+    ext_r = torch.randn(M, 16, generator=gen).to(DEV)
+    slots = rm.patch_slots(rr).to(DEV)
+    sig_p, rgb_p, ext_p = torch.empty_like(sig_r), torch.empty_like(rgb_r), torch.empty_like(ext_r)
+    sig_p[slots], rgb_p[slots], ext_p[slots] = sig_r, rgb_r, ext_r
+    a = rm.composite_rays_train(sig_r, rgb_r, dlr[:M], rr2, 1e-4, extra=ext_r)
+    b = rm.composite_rays_patch(sig_p, rgb_p, dlp, rr, 1e-4, extra=ext_p)
+    for u, v in zip(a, b):
+        assert torch.allclose(u, v, atol=1e-5, rtol=1e-5)
+
+
+def test_get_rays_patch_order_covers_image():
+    from instance_nerf_amd.nerf.utils import get_rays, patch_order
+    inds = patch_order(40, 24, 4, "cpu")
+    assert sorted(inds.tolist()) == list(range(40 * 24))
+    first = inds[:16]
+    assert set((first // 24).tolist()) == {0, 1, 2, 3} and set((first % 24).tolist()) == {0, 1, 2, 3}
