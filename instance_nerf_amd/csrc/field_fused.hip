@@ -35,6 +35,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #ifndef INR_MLP_FP32
 #define INR_MLP_FP32 0
 #endif
+#ifndef INR_MLP_SETPRIO
+#define INR_MLP_SETPRIO 0
+#endif
 
 // Ablation builds for profiling only (tools/build_probe.py): 1 = no table gathers (features are
 // synthesised from x), 2 = no MLP (features are summed into sigma).  The shipped library is
@@ -78,29 +81,48 @@ __device__ __forceinline__ f32x4 relu4(f32x4 v) {
 // in the combining operator, selected per lane with v_cndmask; (cy+1)*pa = cy*pa + pa (mod 2^32).
 // Gathers are buffer loads: one 32-bit byte offset per corner against a wave-uniform descriptor
 // of the whole table (49 MB < 4 GB), so a corner costs ONE address VGPR and is bounds-checked.
-struct LaneLevels {
-  float scale[4];
-  uint32_t base[4];   // byte offset of the level's first row
-  uint32_t pa[4], pb[4], mask[4];
-  bool hashed[4];
-  bool live[4];
+// Per-(q, slot) level constants live in LDS (16 records of 8 words, written once per workgroup) and are
+// re-read per tile right before use - two ds_read_b128 per level - instead of occupying ~24 VGPRs
+// for the whole kernel: the gather phase already holds 64 data + 12 fraction registers per lane and
+// must stay <= 128 VGPRs for 4 waves/SIMD.
+//   word 0 scale (f32)   1 byte offset of the level's first row   2 pa   3 pb   4 mask   5 hashed(0/1)
+// A level beyond num_levels needs no predicate: all its words are 0, so its gathers read row 0 of the
+// table (valid memory, finite) and its two features meet all-zero weight columns (the packer zero-fills
+// inputs >= 2 * num_levels).
+struct LevelRec {
+  uint4 a, b;
 };
+constexpr int kLevelRecBytes = 16 * sizeof(LevelRec);   // 512 B after the weights
 
-__device__ __forceinline__ void load_lane_levels(const GridDesc& G, int q, LaneLevels& L) {
-#pragma unroll
-  for (int li = 0; li < 4; ++li) {
+__device__ __forceinline__ void stage_level_recs(const GridDesc& G, LevelRec* recs) {
+  const int t = threadIdx.x;
+  if (t < 16) {
+    const int q = t >> 2, li = t & 3;
     const int l = (li >> 1) * 8 + 2 * q + (li & 1);
     const bool live = l < G.num_levels;
     const int lc = live ? l : 0;
     const uint32_t m = G.mask[lc], s = G.res1[lc];
-    L.live[li] = live;
-    L.scale[li] = G.scales[lc];
-    L.base[li] = G.offsets[lc] * 8u;
-    L.hashed[li] = m != 0;
-    L.pa[li] = m ? 2654435761u : s;
-    L.pb[li] = m ? 805459861u : s * s;
-    L.mask[li] = m ? m : 0xFFFFFFFFu;
+    LevelRec r;
+    r.a.x = live ? __float_as_uint(G.scales[lc]) : 0u;
+    r.a.y = live ? G.offsets[lc] * 8u : 0u;
+    r.a.z = !live ? 0u : (m ? 2654435761u : s);
+    r.a.w = !live ? 0u : (m ? 805459861u : s * s);
+    r.b.x = !live ? 0u : (m ? m : 0xFFFFFFFFu);
+    r.b.y = (live && m) ? 1u : 0u;
+    r.b.z = 0u; r.b.w = 0u;
+    recs[t] = r;
   }
+}
+
+// wave-uniform (kernel arguments only): slot li is served by hashed, present levels for every q
+__device__ __forceinline__ bool slot_all_hashed(const GridDesc& G, int li) {
+  bool ah = true;
+#pragma unroll
+  for (int qq = 0; qq < 4; ++qq) {
+    const int lq = (li >> 1) * 8 + 2 * qq + (li & 1);
+    ah = ah && (lq < G.num_levels) && (G.mask[lq < G.num_levels ? lq : 0] != 0);
+  }
+  return ah;
 }
 
 typedef unsigned int u32x2 __attribute__((__vector_size__(2 * sizeof(unsigned int))));
@@ -110,33 +132,44 @@ struct Gathered {
   float fx[4], fy[4], fz[4];
 };
 
-__device__ __forceinline__ void issue_gathers(const LaneLevels& L, __amdgpu_buffer_rsrc_t rsrc, float x0, float x1,
-                                              float x2, Gathered& g) {
+__device__ __forceinline__ void issue_gathers(const LevelRec* __restrict__ my_recs, const bool (&all_hashed)[4],
+                                              __amdgpu_buffer_rsrc_t rsrc, float x0, float x1, float x2, Gathered& g) {
 #pragma unroll
   for (int li = 0; li < 4; ++li) {
-    const float s = L.scale[li];
+    const uint4 ra = my_recs[li].a;
+    const float s = __uint_as_float(ra.x);
+    const uint32_t base = ra.y, pa = ra.z, pb = ra.w;
+    const uint32_t mask = my_recs[li].b.x;
     const float px = x0 * s + 0.5f, py = x1 * s + 0.5f, pz = x2 * s + 0.5f;   // mul, add: not fused
     const float flx = floorf(px), fly = floorf(py), flz = floorf(pz);
     g.fx[li] = px - flx; g.fy[li] = py - fly; g.fz[li] = pz - flz;
     const uint32_t cx = (uint32_t)flx, cy = (uint32_t)fly, cz = (uint32_t)flz;
-    const bool h = L.hashed[li];
-    const uint32_t hy0 = cy * L.pa[li], hy1 = hy0 + L.pa[li];
-    const uint32_t hz0 = cz * L.pb[li], hz1 = hz0 + L.pb[li];
-    const uint32_t yz[4] = {h ? (hy0 ^ hz0) : (hy0 + hz0), h ? (hy1 ^ hz0) : (hy1 + hz0),
-                            h ? (hy0 ^ hz1) : (hy0 + hz1), h ? (hy1 ^ hz1) : (hy1 + hz1)};
+    const uint32_t hy0 = cy * pa, hy1 = hy0 + pa;
+    const uint32_t hz0 = cz * pb, hz1 = hz0 + pb;
+    if (all_hashed[li]) {              // wave-uniform: xor-only index maths
+      const uint32_t yz[4] = {hy0 ^ hz0, hy1 ^ hz0, hy0 ^ hz1, hy1 ^ hz1};
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const uint32_t c = cx + (k & 1);
-      const uint32_t idx = (h ? (c ^ yz[k >> 1]) : (c + yz[k >> 1])) & L.mask[li];
-      const uint32_t off = L.live[li] ? L.base[li] + idx * 8u : 0u;
-      g.v[li][k] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)off, 0, 0);
+      for (int k = 0; k < 8; ++k) {
+        const uint32_t idx = ((cx + (k & 1)) ^ yz[k >> 1]) & mask;
+        g.v[li][k] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(base + idx * 8u), 0, 0);
+      }
+    } else {
+      const bool h = my_recs[li].b.y != 0;
+      const uint32_t yz[4] = {h ? (hy0 ^ hz0) : (hy0 + hz0), h ? (hy1 ^ hz0) : (hy1 + hz0),
+                              h ? (hy0 ^ hz1) : (hy0 + hz1), h ? (hy1 ^ hz1) : (hy1 + hz1)};
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const uint32_t c = cx + (k & 1);
+        const uint32_t idx = (h ? (c ^ yz[k >> 1]) : (c + yz[k >> 1])) & mask;
+        g.v[li][k] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(base + idx * 8u), 0, 0);
+      }
     }
   }
 }
 
 // trilinear blend in corner order: weight = (wx*wy)*wz, accumulate with fmaf.
 // out[s], s = 0..7 <-> feature 16*(s>>2) + 4q + (s&3).
-__device__ __forceinline__ void blend(const LaneLevels& L, const Gathered& g, f32x4& lo, f32x4& hi) {
+__device__ __forceinline__ void blend(const Gathered& g, f32x4& lo, f32x4& hi) {
   float f[8];
 #pragma unroll
   for (int li = 0; li < 4; ++li) {
@@ -153,8 +186,8 @@ __device__ __forceinline__ void blend(const LaneLevels& L, const Gathered& g, f3
       ax = fmaf(w, __uint_as_float(bx), ax);
       ay = fmaf(w, __uint_as_float(by), ay);
     }
-    f[2 * li] = L.live[li] ? ax : 0.f;
-    f[2 * li + 1] = L.live[li] ? ay : 0.f;
+    f[2 * li] = ax;
+    f[2 * li + 1] = ay;
   }
   lo[0] = f[0]; lo[1] = f[1]; lo[2] = f[2]; lo[3] = f[3];
   hi[0] = f[4]; hi[1] = f[5]; hi[2] = f[6]; hi[3] = f[7];
@@ -348,6 +381,8 @@ __global__ void __launch_bounds__(kFieldThreads, 4) k_nerf_fwd(const float* __re
   extern __shared__ __attribute__((aligned(16))) float4 wl[];
   constexpr int kStage = (kColor ? kNerfFloats : kCol0) / 4;
   for (int i = threadIdx.x; i < kStage; i += kFieldThreads) wl[i] = packed[i];
+  LevelRec* recs = reinterpret_cast<LevelRec*>(wl + kStage);
+  stage_level_recs(G, recs);
   __syncthreads();
 
   constexpr int kWaves = kFieldThreads / 64;
@@ -359,8 +394,7 @@ __global__ void __launch_bounds__(kFieldThreads, 4) k_nerf_fwd(const float* __re
   int64_t tile_begin, tile_end, tile_step;
   xcd_tile_range(n_tiles, kWaves, tile_begin, tile_end, tile_step);
 
-  LaneLevels L;
-  load_lane_levels(G, q, L);
+  const bool all_hashed[4] = {slot_all_hashed(G, 0), slot_all_hashed(G, 1), slot_all_hashed(G, 2), slot_all_hashed(G, 3)};
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)emb, 0, (int)emb_bytes, 0x00020000);
 
   for (int64_t tile = tile_begin; tile < tile_end; tile += tile_step) {
@@ -376,9 +410,12 @@ __global__ void __launch_bounds__(kFieldThreads, 4) k_nerf_fwd(const float* __re
 #else
     {
       Gathered g;
-      issue_gathers(L, rsrc, me.x0, me.x1, me.x2, g);
+      uint32_t rec_off = (uint32_t)q * 4u * (uint32_t)sizeof(LevelRec);
+      asm volatile("" : "+v"(rec_off));    // opaque per tile: keeps the records in LDS, not hoisted into VGPRs
+      issue_gathers(reinterpret_cast<const LevelRec*>(reinterpret_cast<const char*>(recs) + rec_off), all_hashed, rsrc,
+                    me.x0, me.x1, me.x2, g);
       __builtin_amdgcn_sched_barrier(0);   // all 32 gathers in flight before the first blend waits
-      blend(L, g, enc[0], enc[1]);
+      blend(g, enc[0], enc[1]);
     }
 #endif
 #if INR_PROBE_MODE == 2
@@ -391,6 +428,9 @@ __global__ void __launch_bounds__(kFieldThreads, 4) k_nerf_fwd(const float* __re
     }
 #endif
 
+#if INR_MLP_SETPRIO
+    __builtin_amdgcn_s_setprio(1);     // matrix phase: get through it and back to issuing gathers
+#endif
     f32x4 h1[4];
     mlp_layer<4, 2>(wl + kSig0 / 4, lane, enc, h1);
 #pragma unroll
@@ -430,6 +470,9 @@ __global__ void __launch_bounds__(kFieldThreads, 4) k_nerf_fwd(const float* __re
         rgb[m * 3 + 2] = 1.0f / (1.0f + expf(-o[0][2]));
       }
     }
+#if INR_MLP_SETPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
   }
 }
 
@@ -443,6 +486,8 @@ __global__ void __launch_bounds__(kFieldThreads, 4) k_instance_fwd(const float* 
   constexpr int K = K_MT * 16;
   constexpr int kStage = (kIns2 + K * 64) / 4;
   for (int i = threadIdx.x; i < kStage; i += kFieldThreads) wl[i] = packed[i];
+  LevelRec* recs = reinterpret_cast<LevelRec*>(wl + kStage);
+  stage_level_recs(G, recs);
   __syncthreads();
 
   constexpr int kWaves = kFieldThreads / 64;
@@ -454,8 +499,7 @@ __global__ void __launch_bounds__(kFieldThreads, 4) k_instance_fwd(const float* 
   int64_t tile_begin, tile_end, tile_step;
   xcd_tile_range(n_tiles, kWaves, tile_begin, tile_end, tile_step);
 
-  LaneLevels L;
-  load_lane_levels(G, q, L);
+  const bool all_hashed[4] = {slot_all_hashed(G, 0), slot_all_hashed(G, 1), slot_all_hashed(G, 2), slot_all_hashed(G, 3)};
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)emb, 0, (int)emb_bytes, 0x00020000);
 
   for (int64_t tile = tile_begin; tile < tile_end; tile += tile_step) {
@@ -466,9 +510,12 @@ __global__ void __launch_bounds__(kFieldThreads, 4) k_instance_fwd(const float* 
     f32x4 enc[2];
     {
       Gathered g;
-      issue_gathers(L, rsrc, me.x0, me.x1, me.x2, g);
+      uint32_t rec_off = (uint32_t)q * 4u * (uint32_t)sizeof(LevelRec);
+      asm volatile("" : "+v"(rec_off));    // opaque per tile: keeps the records in LDS, not hoisted into VGPRs
+      issue_gathers(reinterpret_cast<const LevelRec*>(reinterpret_cast<const char*>(recs) + rec_off), all_hashed, rsrc,
+                    me.x0, me.x1, me.x2, g);
       __builtin_amdgcn_sched_barrier(0);   // all 32 gathers in flight before the first blend waits
-      blend(L, g, enc[0], enc[1]);
+      blend(g, enc[0], enc[1]);
     }
     f32x4 h1[4], h2[4], o[K_MT];
     mlp_layer<4, 2>(wl + kIns0 / 4, lane, enc, h1);
@@ -614,12 +661,12 @@ int inr_nerf_forward(const float* x, const float* d, int64_t M, const int32_t* n
   const uint32_t emb_bytes = (uint32_t)emb_bytes64;
   const int64_t n_tiles = (M + 15) / 16;
   if (rgb) {
-    const size_t lds = kNerfFloats * sizeof(float);
+    const size_t lds = kNerfFloats * sizeof(float) + kLevelRecBytes;
     const int grid = grid_for(k_nerf_fwd<true>, lds, n_tiles);
     k_nerf_fwd<true><<<grid, kFieldThreads, lds, as_stream(s)>>>(x, d, M, n_samples_dev, bound, e, emb_bytes, G, p,
                                                       density_scale, sigma, rgb, geo_feat);
   } else {
-    const size_t lds = kCol0 * sizeof(float);
+    const size_t lds = kCol0 * sizeof(float) + kLevelRecBytes;
     const int grid = grid_for(k_nerf_fwd<false>, lds, n_tiles);
     k_nerf_fwd<false><<<grid, kFieldThreads, lds, as_stream(s)>>>(x, d, M, n_samples_dev, bound, e, emb_bytes, G, p,
                                                        density_scale, sigma, nullptr, geo_feat);
@@ -644,7 +691,7 @@ int inr_instance_forward(const float* x, int64_t M, const int32_t* n_samples_dev
   const uint64_t emb_bytes64 = (uint64_t)desc->offsets[desc->num_levels] * 8ull;
   INR_REQUIRE(emb_bytes64 < (1ull << 31), "table larger than 2 GiB is not addressable by the 32-bit gather offsets");
   const uint32_t eb = (uint32_t)emb_bytes64;
-  const size_t lds = (size_t)(kIns2 + K * 64) * sizeof(float);
+  const size_t lds = (size_t)(kIns2 + K * 64) * sizeof(float) + kLevelRecBytes;
   const int64_t n_tiles = (M + 15) / 16;
   hipStream_t st = as_stream(s);
   switch (K / 16) {

@@ -20,15 +20,27 @@ from .. import _lib
 _PATCH_INDS = {}
 
 
-def patch_order(H, W, patch, device):
+SUPER_TILE = int(os.environ.get("INR_SUPER_TILE", "0"))   # pixels; 0 = patches in row-major order
+
+
+def patch_order(H, W, patch, device, super_tile=None):
     """Flat pixel indices of an HxW image enumerated patch by patch (patch x patch pixels, row-major
     inside a patch).  16 consecutive entries = one 4x4 patch = one group of the patch-interleaved
-    sample layout.  Cached per (H, W, patch, device)."""
-    key = (H, W, patch, str(device))
+    sample layout.  With ``super_tile`` (a multiple of ``patch``) the patches themselves are visited
+    super-tile by super-tile, which keeps vertically adjacent patches close in the stream.
+    Cached per (H, W, patch, super_tile, device)."""
+    st = SUPER_TILE if super_tile is None else super_tile
+    key = (H, W, patch, st, str(device))
     if key not in _PATCH_INDS:
         jj, ii = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
         ii, jj = ii.reshape(-1), jj.reshape(-1)
-        k = ((jj // patch) * ((W + patch - 1) // patch) + (ii // patch)) * (patch * patch) + (jj % patch) * patch + (ii % patch)
+        npx = (W + patch - 1) // patch
+        k = ((jj // patch) * npx + (ii // patch))
+        if st:
+            nsx = (W + st - 1) // st
+            pps = st // patch
+            k = ((jj // st) * nsx + (ii // st)) * (pps * pps) + ((jj % st) // patch) * pps + ((ii % st) // patch)
+        k = k * (patch * patch) + (jj % patch) * patch + (ii % patch)
         _PATCH_INDS[key] = torch.argsort(k).to(device)
     return _PATCH_INDS[key]
 

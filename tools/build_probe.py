@@ -9,12 +9,18 @@ from instance_nerf_amd import build as b  # noqa: E402
 
 out = os.path.join(ROOT, "tools", "_probe")
 os.makedirs(out, exist_ok=True)
+# arguments: probe modes ("1", "2") or NAME=-Dflag[,-Dflag] for other compile-time variants
 for mode in sys.argv[1:] or ["1", "2"]:
+    if "=" in mode:
+        name, flags = mode.split("=", 1)
+        defs = flags.split(",")
+    else:
+        name, defs = f"probe{mode}", [f"-DINR_PROBE_MODE={mode}"]
     objs = []
     for src in b.SOURCES:
-        obj = os.path.join(out, f"{src[:-4]}.m{mode}.o")
-        subprocess.check_call(["hipcc", "-x", "hip", "-c", os.path.join(b.CSRC, src), "-o", obj, f"-DINR_PROBE_MODE={mode}"] + b.FLAGS)
+        obj = os.path.join(out, f"{src[:-4]}.{name}.o")
+        subprocess.check_call(["hipcc", "-x", "hip", "-c", os.path.join(b.CSRC, src), "-o", obj] + defs + b.FLAGS)
         objs.append(obj)
-    lib = os.path.join(out, f"libinr_probe{mode}.so")
+    lib = os.path.join(out, f"libinr_{name}.so")
     subprocess.check_call(["hipcc", "-shared", "-o", lib] + objs + ["--offload-arch=gfx950"])
     print(lib)

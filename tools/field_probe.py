@@ -16,11 +16,15 @@ reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 dev = torch.device("cuda", 0)
 net, room = build_network(dev)
 poses, intr, H, W = room.cameras()
-r = get_rays(torch.from_numpy(poses[:1]).to(dev), intr, H, W)
+PATCH = int(os.environ.get("PROBE_PATCH", "4"))
+r = get_rays(torch.from_numpy(poses[:1]).to(dev), intr, H, W, patch=PATCH)
 ro, rd = r["rays_o"].view(-1, 3), r["rays_d"].view(-1, 3)
 nears, fars = raymarching.near_far_from_aabb(ro, rd, net.aabb_infer, net.min_near)
-xyzs, dirs, deltas, rays = raymarching.march_rays_train(ro, rd, 1, net.density_bitfield, 1, 128, nears, fars,
-                                                        force_all_rays=True)
+if os.environ.get("PROBE_RAYMAJOR"):
+    xyzs, dirs, deltas, rays = raymarching.march_rays_train(ro, rd, 1, net.density_bitfield, 1, 128, nears, fars,
+                                                            force_all_rays=True)
+else:
+    xyzs, dirs, deltas, rays = raymarching.march_rays_patch(ro, rd, 1, net.density_bitfield, 1, 128, nears, fars)
 M = xyzs.shape[0]
 with torch.no_grad():
     net(xyzs, dirs)
