@@ -28,6 +28,18 @@ HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BYTES_PER_SAMPLE = 1024         # 16 levels x 8 corners x 2 features x 4 B
 
 
+def measured_traffic_bytes_per_sample(res):
+    """HBM-side bytes per sample of the fused field kernel from the committed PMC profile
+    (profiles/r01_traffic.json: FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc passes, gfx950 x2
+    read correction).  PMC counters cannot be collected from inside this process; None if absent or
+    if the workload is not the profiled one."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    if res != 800 or not os.path.exists(path):
+        return None
+    t = json.load(open(path))
+    return float(t["read_bytes_per_sample"]) + float(t["write_bytes_per_sample"])
+
+
 def build_network(dev, seed=0):
     from instance_nerf_amd.nerf import NeRFNetwork
     from instance_nerf_amd.scene import RoomScene
@@ -38,8 +50,9 @@ def build_network(dev, seed=0):
     return net.eval(), room
 
 
-def cpu_baseline(room, n_rays=2048):
-    """Oracle (kind 'port') on the host cores, bounded sample: n_rays rays of view 0, same field sizes.
+def cpu_baseline(room, chunk=4096, budget_s=12.0, max_chunks=24):
+    """Oracle (kind 'port') on the host cores, bounded sample of the same workload: 4096-ray chunks of
+    view 0 (a strided sub-image per chunk) until ~budget_s seconds of CPU work have been done.
 
     The oracle is numpy + torch-CPU: its many small ops stop scaling (and then regress badly)
     beyond ~16 threads, so it runs on min(cores, 16) threads; ``cores`` reports what was used."""
@@ -50,17 +63,21 @@ def cpu_baseline(room, n_rays=2048):
     p = field.init_params(seed=0, table=table, table_std=1e-4)
     bits = room.density_bitfield(128, 1.0)
     poses, intr, H, W = room.cameras()
-    stride = int(np.sqrt(H * W / n_rays))
-    ii, jj = np.meshgrid(np.arange(0, W, stride), np.arange(0, H, stride))
-    inds = (jj * W + ii).ravel()[:n_rays]
-    r = orays.get_rays(poses[:1], intr, H, W, inds=inds)
-    t0 = time.perf_counter()
-    with torch.no_grad():
-        out = orender.render_train(r["rays_o"][0], r["rays_d"][0], p, table, bits, min_near=0.05)
-    dt = time.perf_counter() - t0
-    return {"value": round(out["total"] / dt / 1e6, 5), "unit": "Msamples/s", "cores": threads, "kind": "port",
-            "sample": f"{len(inds)} rays ({stride}-pixel strided crop of view 0, 800x800 camera), "
-                      f"{out['total']} samples, oracle march+field+composite, {dt:.1f} s"}
+    perm = np.random.default_rng(7).permutation(H * W)
+    total, rays_done, t_used, n = 0, 0, 0.0, 0
+    while t_used < budget_s and n < max_chunks:
+        inds = np.sort(perm[n * chunk:(n + 1) * chunk])
+        r = orays.get_rays(poses[:1], intr, H, W, inds=inds)
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            out = orender.render_train(r["rays_o"][0], r["rays_d"][0], p, table, bits, min_near=0.05)
+        t_used += time.perf_counter() - t0
+        total += out["total"]
+        rays_done += len(inds)
+        n += 1
+    return {"value": round(total / t_used / 1e6, 5), "unit": "Msamples/s", "cores": threads, "kind": "port",
+            "sample": f"{rays_done} random rays of view 0 (800x800 camera) in {n} chunks of {chunk}, {total} samples, "
+                      f"oracle march+field+composite, {t_used:.1f} s"}
 
 
 def main():
@@ -88,7 +105,6 @@ def main():
     net, room = build_network(dev)
     poses, intr, H, W = room.cameras(H=args.res, W=args.res, focal=args.res / 2.0)
     poses_d = torch.from_numpy(poses).to(dev)
-    field_ms, samples = [], []
 
     # events around the dominant kernel (fused field) on the stream it is launched on
     orig_forward = net.forward
@@ -144,6 +160,8 @@ def main():
     if rank == 0:
         avg_kernel_s = kernel_ms / 1e3 / max(n_launch, 1)
         achieved = (n_samples / max(n_launch, 1)) * BYTES_PER_SAMPLE / avg_kernel_s / 1e9
+        tbs = measured_traffic_bytes_per_sample(args.res)
+        traffic = None if tbs is None else round((n_samples / max(n_launch, 1)) * tbs / avg_kernel_s / 1e9, 1)
         line = {
             "metric": "Msamples/sec (train+infer) 3D-FRONT 800x800 at 1/2/4/8 MI355X; PSNR parity",
             "value": round(samples_all / elapsed_all / 1e6, 3),
@@ -157,7 +175,8 @@ def main():
                        "samples_per_step": n_samples // args.steps, "rays_per_step": H * W,
                        "parallelism": f"views sharded over {world} GPU(s), no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "traffic_source": "profiles/r01_traffic.json (rocprofv3 PMC, GB/s at this run's launch time)",
                          "kernel": "k_nerf_fwd<true> (fused hash gather + SH + MLP)",
                          "avg_launch_ms": round(avg_kernel_s * 1e3, 4), "launches": n_launch,
                          "algorithmic_bytes_per_sample": BYTES_PER_SAMPLE},
