@@ -1,0 +1,31 @@
+"""Instance-field training step timing (BASELINE configs[2]: K=64 logits, 4096 rays/batch, NeRF frozen)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from instance_nerf_amd.nerf import NeRFNetwork
+from instance_nerf_amd.nerf.provider import SyntheticRoomDataset
+from instance_nerf_amd.nerf.utils import Trainer
+
+dev = torch.device("cuda", 0)
+torch.manual_seed(0)
+net = NeRFNetwork(cuda_ray=True, bound=1, min_near=0.05, density_thresh=10, num_instances=64).to(dev)
+ds = SyntheticRoomDataset(dev, num_rays=4096, num_instances=64)
+net.density_bitfield.copy_(torch.from_numpy(ds.room.density_bitfield(128, 1.0)).to(dev))
+tr = Trainer("probe", None, net, stage="instance", device=dev, iters=1000, update_extra_interval=10 ** 9)
+tr.global_step = 1          # keep the analytic occupancy grid (no update from the untrained NeRF)
+batches = [ds.batch() for _ in range(8)]
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+losses = []
+for i in range(8):
+    losses.append(float(tr.train_one_step(batches[i % 8])))
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+n0 = 0
+for i in range(steps):
+    l = tr.train_one_step(batches[i % 8])
+    n0 += int(net.step_counter[(net.local_step - 1) % 16, 0])
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / steps
+losses.append(float(l))
+print(f"train step {dt*1e3:.3f} ms, {n0/steps:.0f} samples/step, {n0/steps/dt/1e6:.2f} Msamples/s, loss {losses[0]:.4f} -> {losses[-1]:.4f}")
