@@ -36,29 +36,57 @@ __global__ void __launch_bounds__(256) k_grid_fwd(const float* __restrict__ x, c
   out[m * L + l] = acc;
 }
 
-// Scatter-add of w * dL/dy into the table gradient.  Hardware fp32 atomics
-// (-munsafe-fp-atomics -> global_atomic_add_f32, executed at L2).
+// Scatter-add of w * dL/dy into the table gradient (hardware fp32 atomics: -munsafe-fp-atomics ->
+// global_atomic_add_f32).  Measured on MI355X (tools/micro/atomic_bench.hip): scattered atomics run at
+// 21 G/s, address-adjacent ones at 150 G/s.  So: ONE LEVEL PER WAVE (blockIdx.y), lanes = consecutive
+// samples.  Training samples are ray-major, hence neighbouring lanes sit in the same or the next cell:
+// their rows are equal or adjacent (x is the fastest index for dense AND hashed levels), atomics of one
+// instruction fall into few 128-B lines, and runs of EQUAL rows are first summed inside the wave by a
+// segmented scan so that only the last lane of a run issues the atomic (level 0: ~37 samples per cell).
+__device__ __forceinline__ void run_reduce_atomic(float* __restrict__ gemb, uint32_t row, bool valid, float vx,
+                                                  float vy) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t key = valid ? row : 0xFFFFFFFFu - (uint32_t)lane;     // invalid lanes never join a run
+  const uint32_t prev = __shfl_up(key, 1, 64);
+  const uint32_t next = __shfl_down(key, 1, 64);
+  bool head = (lane == 0) || (prev != key);         // first lane of a run of equal rows
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {                // segmented inclusive scan (head flags stop the carry)
+    const float ux = __shfl_up(vx, d, 64), uy = __shfl_up(vy, d, 64);
+    const bool uh = __shfl_up((int)head, d, 64) != 0;
+    if (lane >= d && !head) {
+      vx += ux;
+      vy += uy;
+      head = uh;
+    }
+  }
+  const bool tail = (lane == 63) || (next != key);
+  if (valid && tail && (vx != 0.0f || vy != 0.0f)) {
+    float* p = gemb + 2 * (size_t)row;
+    atomicAdd(p, vx);
+    atomicAdd(p + 1, vy);
+  }
+}
+
 __global__ void __launch_bounds__(256) k_grid_bwd(const float* __restrict__ x, const float2* __restrict__ gout,
                                                   GridDesc G, int64_t M, float bound, float* __restrict__ gemb) {
-  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int l = blockIdx.y;
   const int L = G.num_levels;
-  const int64_t m = tid / L;
-  const int l = (int)(tid - m * L);
-  if (m >= M) return;
+  const bool valid = m < M;
+  const int64_t mc = valid ? m : M - 1;
   const float rb = 2.0f * bound;
-  const float x0 = (x[m * 3 + 0] + bound) / rb;
-  const float x1 = (x[m * 3 + 1] + bound) / rb;
-  const float x2 = (x[m * 3 + 2] + bound) / rb;
+  const float x0 = (x[mc * 3 + 0] + bound) / rb;
+  const float x1 = (x[mc * 3 + 1] + bound) / rb;
+  const float x2 = (x[mc * 3 + 2] + bound) / rb;
   Cell c;
   locate(G, l, x0, x1, x2, c);
-  const float2 g = gout[m * L + l];
-  if (g.x == 0.0f && g.y == 0.0f) return;
+  const float2 g = valid ? gout[mc * L + l] : make_float2(0.f, 0.f);
+  const uint32_t base = G.offsets[l];
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     const float w = corner_weight(c, k);
-    float* p = gemb + 2 * (size_t)(G.offsets[l] + corner_index(G, l, c, k));
-    atomicAdd(p, w * g.x);
-    atomicAdd(p + 1, w * g.y);
+    run_reduce_atomic(gemb, base + corner_index(G, l, c, k), valid, w * g.x, w * g.y);
   }
 }
 
@@ -178,9 +206,9 @@ int inr_grid_encode_backward(const float* x, const float* grad_out, const inr_gr
   if (rc) return rc;
   INR_REQUIRE(((uintptr_t)grad_out & 7) == 0, "grad_out must be 8-byte aligned");
   if (M == 0) return INR_OK;
-  const int64_t total = M * G.num_levels;
-  k_grid_bwd<<<blocks_for(total, 256), 256, 0, as_stream(s)>>>(x, reinterpret_cast<const float2*>(grad_out), G, M,
-                                                               bound, grad_embeddings);
+  const dim3 grid(blocks_for(M, 256), (unsigned)G.num_levels);
+  k_grid_bwd<<<grid, 256, 0, as_stream(s)>>>(x, reinterpret_cast<const float2*>(grad_out), G, M, bound,
+                                             grad_embeddings);
   return check_launch("grid_encode_backward");
 }
 
