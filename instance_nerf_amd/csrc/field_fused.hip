@@ -193,6 +193,98 @@ __device__ __forceinline__ void blend(const Gathered& g, f32x4& lo, f32x4& hi) {
   hi[0] = f[4]; hi[1] = f[5]; hi[2] = f[6]; hi[3] = f[7];
 }
 
+// ---- x-split gather (default) -------------------------------------------------------------------------
+// The gather phase is bound by L1/TA line look-ups, and the two x-neighbour corners of a cell share a
+// 128-byte line 15 times out of 16 (x is the fastest-varying index in dense AND hashed levels), yet as
+// corner k and k+1 of one lane they are fetched by two different instructions = two look-ups.
+// Here a sample's gathers are split over 8 lanes = (level group q) x (x side xb); a 16-sample tile is
+// gathered in two rounds of 8 samples.  In lane order  lane = 16q + 8xb + j8  the two x-side lanes of a
+// sample sit 8 apart, issue the same instruction and hit the same line -> one look-up.  Each lane blends
+// its 4 (y,z) corners with its own x weight; the halves are added with one DPP row_ror:8 per value; the
+// lane with xb == r keeps round r, which is sample j = 8 xb + j8 = lane & 15: exactly the MFMA B layout.
+#ifndef INR_XSPLIT
+#define INR_XSPLIT 1
+#endif
+#ifndef INR_FIELD_PIPE
+#define INR_FIELD_PIPE 0
+#endif
+
+struct GatheredXS {
+  u32x2 v[2][4][4];               // [round][slot][(y,z) corner]; fractions are recomputed at blend time
+};                                // (24 VGPRs less across the gather wait than keeping them)
+
+__device__ __forceinline__ float ror8_add(float v) {
+  const int o = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128 /*row_ror:8*/, 0xF, 0xF, false);
+  return v + __int_as_float(o);
+}
+
+__device__ __forceinline__ void issue_gathers_xs(const LevelRec* __restrict__ my_recs, const bool (&all_hashed)[4],
+                                                 __amdgpu_buffer_rsrc_t rsrc, uint32_t xb, const float (&xr)[2][3],
+                                                 GatheredXS& g) {
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+#pragma unroll
+    for (int li = 0; li < 4; ++li) {
+      const uint4 ra = my_recs[li].a;
+      const float s = __uint_as_float(ra.x);
+      const uint32_t base = ra.y, pa = ra.z, pb = ra.w;
+      const uint32_t mask = my_recs[li].b.x;
+      const float px = xr[r][0] * s + 0.5f, py = xr[r][1] * s + 0.5f, pz = xr[r][2] * s + 0.5f;   // mul, add
+      const float flx = floorf(px), fly = floorf(py), flz = floorf(pz);
+      const uint32_t cx = (uint32_t)flx + xb, cy = (uint32_t)fly, cz = (uint32_t)flz;
+      const uint32_t hy0 = cy * pa, hy1 = hy0 + pa;
+      const uint32_t hz0 = cz * pb, hz1 = hz0 + pb;
+      if (all_hashed[li]) {
+        const uint32_t yz[4] = {hy0 ^ hz0, hy1 ^ hz0, hy0 ^ hz1, hy1 ^ hz1};
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          g.v[r][li][c] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(base + ((cx ^ yz[c]) & mask) * 8u), 0, 0);
+      } else {
+        const bool h = my_recs[li].b.y != 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const uint32_t hy = (c & 1) ? hy1 : hy0, hz = (c & 2) ? hz1 : hz0;
+          const uint32_t idx = (h ? (cx ^ hy ^ hz) : (cx + hy + hz)) & mask;
+          g.v[r][li][c] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(base + idx * 8u), 0, 0);
+        }
+      }
+    }
+  }
+}
+
+// weight = (wx*wy)*wz as in the oracle; the two x halves are summed after the 4-corner partial blends.
+__device__ __forceinline__ void blend_xs(const LevelRec* __restrict__ my_recs, const GatheredXS& g, uint32_t xb,
+                                         const float (&xr)[2][3], f32x4& lo, f32x4& hi) {
+  float f[2][8];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+#pragma unroll
+    for (int li = 0; li < 4; ++li) {
+      const float s = __uint_as_float(my_recs[li].a.x);
+      const float px = xr[r][0] * s + 0.5f, py = xr[r][1] * s + 0.5f, pz = xr[r][2] * s + 0.5f;   // same ops as at issue
+      const float fx = px - floorf(px), fy = py - floorf(py), fz = pz - floorf(pz);
+      const float wxs = xb ? fx : 1.0f - fx;
+      float ax = 0.f, ay = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float wy = (c & 1) ? fy : 1.0f - fy;
+        const float wz = (c & 2) ? fz : 1.0f - fz;
+        const float w = (wxs * wy) * wz;
+        const unsigned bx = g.v[r][li][c][0], by = g.v[r][li][c][1];
+        ax = fmaf(w, __uint_as_float(bx), ax);
+        ay = fmaf(w, __uint_as_float(by), ay);
+      }
+      f[r][2 * li] = ror8_add(ax);
+      f[r][2 * li + 1] = ror8_add(ay);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    lo[e] = xb ? f[1][e] : f[0][e];
+    hi[e] = xb ? f[1][4 + e] : f[0][4 + e];
+  }
+}
+
 // One MLP layer: out[mt] (N_MT output tiles) = W * in, K = 16 * N_G inputs.  in[g] is the B
 // operand of k-steps 4g..4g+3.  The N_MT accumulator chains are interleaved (independent
 // MFMAs back to back: the 16x16x4 f32 MFMA issues every 32 cycles but has a 40-cycle
@@ -369,10 +461,16 @@ __device__ __forceinline__ void xcd_tile_range(int64_t n_tiles, int waves_per_bl
   }
 }
 
-constexpr int kFieldThreads = 512;   // 8 waves share one 40 KB weight image in LDS; 2 workgroups / CU
+#ifndef INR_FIELD_THREADS
+#define INR_FIELD_THREADS 512
+#endif
+#ifndef INR_FIELD_MIN_WAVES
+#define INR_FIELD_MIN_WAVES 4
+#endif
+constexpr int kFieldThreads = INR_FIELD_THREADS;   // waves of a workgroup share one 40 KB weight image in LDS
 
 template <bool kColor>
-__global__ void __launch_bounds__(kFieldThreads, 4) k_nerf_fwd(const float* __restrict__ x, const float* __restrict__ d,
+__global__ void __launch_bounds__(kFieldThreads, INR_FIELD_MIN_WAVES) k_nerf_fwd(const float* __restrict__ x, const float* __restrict__ d,
                                                                int64_t M, const int32_t* __restrict__ n_dev, float bound,
                                                                const float2* __restrict__ emb, uint32_t emb_bytes, GridDesc G,
                                                                const float4* __restrict__ packed, float density_scale,
@@ -397,6 +495,29 @@ __global__ void __launch_bounds__(kFieldThreads, 4) k_nerf_fwd(const float* __re
   const bool all_hashed[4] = {slot_all_hashed(G, 0), slot_all_hashed(G, 1), slot_all_hashed(G, 2), slot_all_hashed(G, 3)};
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)emb, 0, (int)emb_bytes, 0x00020000);
 
+#if INR_FIELD_PIPE
+  // Software pipeline per wave: blend(t) -> issue the 32 gathers of tile t+1 -> MLP(t) -> stores(t).
+  // With 2 waves/SIMD (256 VGPRs each) the next tile's table reads fly underneath this tile's MFMAs.
+  const uint32_t xb = (uint32_t)(lane >> 3) & 1u;
+  uint32_t rec_off0 = (uint32_t)q * 4u * (uint32_t)sizeof(LevelRec);
+  const LevelRec* my_recs0 = reinterpret_cast<const LevelRec*>(reinterpret_cast<const char*>(recs) + rec_off0);
+  auto load_xr = [&](int64_t t, float (&xr)[2][3]) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int64_t mr = min(t * 16 + r * 8 + (lane & 7), n - 1);
+      xr[r][0] = (x[mr * 3 + 0] + bound) / rb;
+      xr[r][1] = (x[mr * 3 + 1] + bound) / rb;
+      xr[r][2] = (x[mr * 3 + 2] + bound) / rb;
+    }
+  };
+  GatheredXS g;
+  float xr_cur[2][3], xr_nxt[2][3];
+  if (tile_begin < tile_end) {
+    load_xr(tile_begin, xr_cur);
+    issue_gathers_xs(my_recs0, all_hashed, rsrc, xb, xr_cur, g);
+    if (tile_begin + tile_step < tile_end) load_xr(tile_begin + tile_step, xr_nxt);
+  }
+#endif
   for (int64_t tile = tile_begin; tile < tile_end; tile += tile_step) {
     const int64_t m = tile * 16 + j;
     const bool valid = m < n;
@@ -404,7 +525,43 @@ __global__ void __launch_bounds__(kFieldThreads, 4) k_nerf_fwd(const float* __re
     load_tile_in<kColor>(x, d, valid ? m : n - 1, bound, rb, me);
 
     f32x4 enc[2];
-#if INR_PROBE_MODE == 1
+#if INR_FIELD_PIPE
+    {
+      uint32_t rec_off = rec_off0;
+      asm volatile("" : "+v"(rec_off));
+      const LevelRec* my_recs = reinterpret_cast<const LevelRec*>(reinterpret_cast<const char*>(recs) + rec_off);
+      blend_xs(my_recs, g, xb, xr_cur, enc[0], enc[1]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (tile + tile_step < tile_end) {                 // wave-uniform
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+          for (int a = 0; a < 3; ++a) xr_cur[r][a] = xr_nxt[r][a];
+        issue_gathers_xs(my_recs, all_hashed, rsrc, xb, xr_cur, g);
+        if (tile + 2 * tile_step < tile_end) load_xr(tile + 2 * tile_step, xr_nxt);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#elif INR_XSPLIT && INR_PROBE_MODE != 1
+    {
+      const uint32_t xb = (uint32_t)(lane >> 3) & 1u;
+      float xr[2][3];
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int64_t mr = min(tile * 16 + r * 8 + (lane & 7), n - 1);
+        xr[r][0] = (x[mr * 3 + 0] + bound) / rb;
+        xr[r][1] = (x[mr * 3 + 1] + bound) / rb;
+        xr[r][2] = (x[mr * 3 + 2] + bound) / rb;
+      }
+      GatheredXS g;
+      uint32_t rec_off = (uint32_t)q * 4u * (uint32_t)sizeof(LevelRec);
+      asm volatile("" : "+v"(rec_off));    // opaque per tile: keeps the records in LDS, not hoisted into VGPRs
+      issue_gathers_xs(reinterpret_cast<const LevelRec*>(reinterpret_cast<const char*>(recs) + rec_off), all_hashed,
+                       rsrc, xb, xr, g);
+      __builtin_amdgcn_sched_barrier(0);   // all 32 gathers in flight before the first blend waits
+      blend_xs(reinterpret_cast<const LevelRec*>(reinterpret_cast<const char*>(recs) + rec_off), g, xb, xr, enc[0], enc[1]);
+    }
+#elif INR_PROBE_MODE == 1
     enc[0] = f32x4{me.x0, me.x1, me.x2, me.x0 * me.x1};
     enc[1] = f32x4{me.x1 * me.x2, me.x2 * me.x0, me.x0 + me.x1, me.x2 - me.x1};
 #else
@@ -477,7 +634,7 @@ __global__ void __launch_bounds__(kFieldThreads, 4) k_nerf_fwd(const float* __re
 }
 
 template <int K_MT>
-__global__ void __launch_bounds__(kFieldThreads, 4) k_instance_fwd(const float* __restrict__ x, int64_t M,
+__global__ void __launch_bounds__(kFieldThreads, INR_FIELD_MIN_WAVES) k_instance_fwd(const float* __restrict__ x, int64_t M,
                                                                    const int32_t* __restrict__ n_dev, float bound,
                                                                    const float2* __restrict__ emb, uint32_t emb_bytes,
                                                                    GridDesc G, const float4* __restrict__ packed,
@@ -508,6 +665,26 @@ __global__ void __launch_bounds__(kFieldThreads, 4) k_instance_fwd(const float* 
     TileIn me;
     load_tile_in<false>(x, nullptr, valid ? m : n - 1, bound, rb, me);
     f32x4 enc[2];
+#if INR_XSPLIT
+    {
+      const uint32_t xb = (uint32_t)(lane >> 3) & 1u;
+      float xr[2][3];
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int64_t mr = min(tile * 16 + r * 8 + (lane & 7), n - 1);
+        xr[r][0] = (x[mr * 3 + 0] + bound) / rb;
+        xr[r][1] = (x[mr * 3 + 1] + bound) / rb;
+        xr[r][2] = (x[mr * 3 + 2] + bound) / rb;
+      }
+      GatheredXS g;
+      uint32_t rec_off = (uint32_t)q * 4u * (uint32_t)sizeof(LevelRec);
+      asm volatile("" : "+v"(rec_off));
+      issue_gathers_xs(reinterpret_cast<const LevelRec*>(reinterpret_cast<const char*>(recs) + rec_off), all_hashed,
+                       rsrc, xb, xr, g);
+      __builtin_amdgcn_sched_barrier(0);
+      blend_xs(reinterpret_cast<const LevelRec*>(reinterpret_cast<const char*>(recs) + rec_off), g, xb, xr, enc[0], enc[1]);
+    }
+#else
     {
       Gathered g;
       uint32_t rec_off = (uint32_t)q * 4u * (uint32_t)sizeof(LevelRec);
@@ -517,6 +694,7 @@ __global__ void __launch_bounds__(kFieldThreads, 4) k_instance_fwd(const float* 
       __builtin_amdgcn_sched_barrier(0);   // all 32 gathers in flight before the first blend waits
       blend(g, enc[0], enc[1]);
     }
+#endif
     f32x4 h1[4], h2[4], o[K_MT];
     mlp_layer<4, 2>(wl + kIns0 / 4, lane, enc, h1);
 #pragma unroll
@@ -598,16 +776,23 @@ static int kidx_color_in(int ks, int q) {
   return row >= 1 ? 16 + row - 1 : -1;           // row 0 is the raw density: not an input
 }
 
-// Persistent grid: exactly the number of workgroups that are co-resident (CUs x blocks/CU from
-// the occupancy query for THIS kernel), so no second partial round of blocks trails the first.
+// Persistent grid.  MEASURED (tools/field_probe.py, 37 M samples, MI355X): the kernel is fastest with
+// 8-12 waves per CU - 4: 10.3 ms, 6: 8.3, 8: 6.8, 12: 6.8, 16: 7.1-7.2 - because every resident wave adds a
+// tile's worth of table lines to the L1/L2 working set; beyond ~2 waves/SIMD the extra latency hiding is
+// worth less than the cache it costs (a per-wave double-buffered pipeline at 8 waves/CU measures 6.95 ms
+// for the same reason).  So: ONE 512-thread workgroup per CU, all co-resident, no tail round.
+constexpr int kFieldBlocksPerCU = 1;
+
 template <class Kern>
 static int grid_for(Kern kern, size_t lds_bytes, int64_t n_tiles) {
-  int dev = 0, cus = 256, per_cu = 2;
+  int dev = 0, cus = 256, fit = kFieldBlocksPerCU;
   if (hipGetDevice(&dev) == hipSuccess) {
     hipDeviceProp_t p;
     if (hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount;
   }
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kFieldThreads, lds_bytes) != hipSuccess || per_cu < 1) per_cu = 2;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, kern, kFieldThreads, lds_bytes) != hipSuccess || fit < 1) fit = 1;
+  int per_cu = std::min(fit, kFieldBlocksPerCU);
+  if (const char* e = getenv("INR_FIELD_BLOCKS_PER_CU")) per_cu = std::max(1, std::min(fit, atoi(e)));   // profiling knob
   const int64_t want = (n_tiles + kFieldThreads / 64 - 1) / (kFieldThreads / 64);
   return (int)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)cus * per_cu));
 }
