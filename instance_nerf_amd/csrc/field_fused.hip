@@ -205,9 +205,7 @@ __device__ __forceinline__ void blend(const Gathered& g, f32x4& lo, f32x4& hi) {
 #ifndef INR_XSPLIT
 #define INR_XSPLIT 1
 #endif
-#ifndef INR_FIELD_PIPE
-#define INR_FIELD_PIPE 0
-#endif
+
 
 struct GatheredXS {
   u32x2 v[2][4][4];               // [round][slot][(y,z) corner]; fractions are recomputed at blend time
@@ -433,32 +431,47 @@ __device__ __forceinline__ void load_tile_in(const float* __restrict__ x, const 
   }
 }
 
-// Latency hiding is by occupancy, not by a per-wave software pipeline: a tile's 32 gathers per
-// lane are all issued back to back (addresses first, then one wait), the MFMA phase that follows
-// needs far fewer registers than the gather phase, and the kernel is held to <= 128 VGPRs so that
-// 4 waves per SIMD (16 per CU) are resident: while one wave of a SIMD runs its ~160 MFMAs the
-// other three have their table reads in flight.  (A per-wave double-buffered variant was tried
-// first: it needs ~64 more live VGPRs and spilled 239 registers at the 256-register cap.)
+// Latency hiding is by wave-level parallelism, not by a per-wave software pipeline: a tile's 32 gathers
+// per lane are all issued back to back (addresses first, then one wait) and while one wave of a SIMD
+// runs its 60 MFMAs the other has its table reads in flight.  A per-wave double-buffered variant
+// (next tile's gathers issued before this tile's MLP, 168 VGPRs) was built and measured twice: it is
+// not faster (6.95 vs 6.81 ms at 8 waves/CU) because it enlarges the per-CU working set exactly like a
+// higher occupancy does - see grid_for() - so it was removed.
 // XCD-aware persistent schedule.  Workgroup b runs on XCD b % 8 (observed dispatch order; used
 // for speed only - any placement gives the same results).  The sample stream is ray-major and
 // rays are image-ordered, so a contiguous range of tiles is a compact region of space: XCD k takes
 // the k-th eighth of the tiles and its workgroups stride through it, which keeps each XCD's
 // private 4 MB L2 on one part of the hash table's working set instead of all of it.
-__device__ __forceinline__ void xcd_tile_range(int64_t n_tiles, int waves_per_block, int64_t& begin, int64_t& end,
-                                               int64_t& step) {
+#ifndef INR_TILE_RUN
+#define INR_TILE_RUN 1
+#endif
+// Tile schedule of one wave: iteration i -> tile.  Waves of an XCD cover its range in runs of
+// INR_TILE_RUN consecutive tiles (run length 1 = plain striding).
+struct TileSched {
+  int64_t lo, hi;      // tile range of this wave's XCD
+  int64_t first;       // first tile of this wave's first run
+  int64_t stride;      // distance between the starts of consecutive runs of this wave
+  __device__ __forceinline__ int64_t tile(int64_t i) const {
+    return first + (i / INR_TILE_RUN) * stride + (i % INR_TILE_RUN);
+  }
+};
+__device__ __forceinline__ TileSched make_sched(int64_t n_tiles, int waves_per_block) {
   const int nb = gridDim.x, b = blockIdx.x;
   const int w = threadIdx.x >> 6;
+  TileSched s;
   if (nb % 8 == 0) {
     const int xcd = b & 7, local = b >> 3, per = nb >> 3;
-    const int64_t lo = n_tiles * xcd / 8, hi = n_tiles * (xcd + 1) / 8;
-    begin = lo + (int64_t)local * waves_per_block + w;
-    end = hi;
-    step = (int64_t)per * waves_per_block;
+    s.lo = n_tiles * xcd / 8;
+    s.hi = n_tiles * (xcd + 1) / 8;
+    s.first = s.lo + ((int64_t)local * waves_per_block + w) * INR_TILE_RUN;
+    s.stride = (int64_t)per * waves_per_block * INR_TILE_RUN;
   } else {
-    begin = (int64_t)b * waves_per_block + w;
-    end = n_tiles;
-    step = (int64_t)nb * waves_per_block;
+    s.lo = 0;
+    s.hi = n_tiles;
+    s.first = ((int64_t)b * waves_per_block + w) * INR_TILE_RUN;
+    s.stride = (int64_t)nb * waves_per_block * INR_TILE_RUN;
   }
+  return s;
 }
 
 #ifndef INR_FIELD_THREADS
@@ -489,60 +502,19 @@ __global__ void __launch_bounds__(kFieldThreads, INR_FIELD_MIN_WAVES) k_nerf_fwd
   if (n_dev) n = min((int64_t)*n_dev, M);
   const int64_t n_tiles = (n + 15) >> 4;
   const float rb = 2.0f * bound;
-  int64_t tile_begin, tile_end, tile_step;
-  xcd_tile_range(n_tiles, kWaves, tile_begin, tile_end, tile_step);
+  const TileSched sched = make_sched(n_tiles, kWaves);
 
   const bool all_hashed[4] = {slot_all_hashed(G, 0), slot_all_hashed(G, 1), slot_all_hashed(G, 2), slot_all_hashed(G, 3)};
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)emb, 0, (int)emb_bytes, 0x00020000);
 
-#if INR_FIELD_PIPE
-  // Software pipeline per wave: blend(t) -> issue the 32 gathers of tile t+1 -> MLP(t) -> stores(t).
-  // With 2 waves/SIMD (256 VGPRs each) the next tile's table reads fly underneath this tile's MFMAs.
-  const uint32_t xb = (uint32_t)(lane >> 3) & 1u;
-  uint32_t rec_off0 = (uint32_t)q * 4u * (uint32_t)sizeof(LevelRec);
-  const LevelRec* my_recs0 = reinterpret_cast<const LevelRec*>(reinterpret_cast<const char*>(recs) + rec_off0);
-  auto load_xr = [&](int64_t t, float (&xr)[2][3]) {
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      const int64_t mr = min(t * 16 + r * 8 + (lane & 7), n - 1);
-      xr[r][0] = (x[mr * 3 + 0] + bound) / rb;
-      xr[r][1] = (x[mr * 3 + 1] + bound) / rb;
-      xr[r][2] = (x[mr * 3 + 2] + bound) / rb;
-    }
-  };
-  GatheredXS g;
-  float xr_cur[2][3], xr_nxt[2][3];
-  if (tile_begin < tile_end) {
-    load_xr(tile_begin, xr_cur);
-    issue_gathers_xs(my_recs0, all_hashed, rsrc, xb, xr_cur, g);
-    if (tile_begin + tile_step < tile_end) load_xr(tile_begin + tile_step, xr_nxt);
-  }
-#endif
-  for (int64_t tile = tile_begin; tile < tile_end; tile += tile_step) {
+  for (int64_t it = 0, tile = sched.tile(0); tile < sched.hi; tile = sched.tile(++it)) {
     const int64_t m = tile * 16 + j;
     const bool valid = m < n;
     TileIn me;
     load_tile_in<kColor>(x, d, valid ? m : n - 1, bound, rb, me);
 
     f32x4 enc[2];
-#if INR_FIELD_PIPE
-    {
-      uint32_t rec_off = rec_off0;
-      asm volatile("" : "+v"(rec_off));
-      const LevelRec* my_recs = reinterpret_cast<const LevelRec*>(reinterpret_cast<const char*>(recs) + rec_off);
-      blend_xs(my_recs, g, xb, xr_cur, enc[0], enc[1]);
-      __builtin_amdgcn_sched_barrier(0);
-      if (tile + tile_step < tile_end) {                 // wave-uniform
-#pragma unroll
-        for (int r = 0; r < 2; ++r)
-#pragma unroll
-          for (int a = 0; a < 3; ++a) xr_cur[r][a] = xr_nxt[r][a];
-        issue_gathers_xs(my_recs, all_hashed, rsrc, xb, xr_cur, g);
-        if (tile + 2 * tile_step < tile_end) load_xr(tile + 2 * tile_step, xr_nxt);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-#elif INR_XSPLIT && INR_PROBE_MODE != 1
+#if INR_XSPLIT && INR_PROBE_MODE != 1
     {
       const uint32_t xb = (uint32_t)(lane >> 3) & 1u;
       float xr[2][3];
@@ -653,13 +625,12 @@ __global__ void __launch_bounds__(kFieldThreads, INR_FIELD_MIN_WAVES) k_instance
   if (n_dev) n = min((int64_t)*n_dev, M);
   const int64_t n_tiles = (n + 15) >> 4;
   const float rb = 2.0f * bound;
-  int64_t tile_begin, tile_end, tile_step;
-  xcd_tile_range(n_tiles, kWaves, tile_begin, tile_end, tile_step);
+  const TileSched sched = make_sched(n_tiles, kWaves);
 
   const bool all_hashed[4] = {slot_all_hashed(G, 0), slot_all_hashed(G, 1), slot_all_hashed(G, 2), slot_all_hashed(G, 3)};
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)emb, 0, (int)emb_bytes, 0x00020000);
 
-  for (int64_t tile = tile_begin; tile < tile_end; tile += tile_step) {
+  for (int64_t it = 0, tile = sched.tile(0); tile < sched.hi; tile = sched.tile(++it)) {
     const int64_t m = tile * 16 + j;
     const bool valid = m < n;
     TileIn me;
