@@ -10,8 +10,8 @@
  * "replaces" notes below name the upstream extension symbol and the survey
  * row instead of a file:line
  * inside /root/reference.  The one FFI call site that IS in the reference tree,
- * roi_align_3d (/root/reference/nerf_rcnn/model/utils.py:608), belongs to the
- * "next" rows (section 8f) and is not part of this header yet.
+ * roi_align_3d (/root/reference/nerf_rcnn/model/utils.py:608), is a "next" row
+ * (section 8f, f2) and is declared at the end of this header.
  *
  * Conventions (chosen to fix the flaws of the reference's only in-tree
  * extension, /root/reference/nerf_rcnn/model/rotated_iou/cuda_op/):
@@ -179,6 +179,19 @@ int inr_instance_forward(const float* x, int64_t M, const int32_t* n_samples_dev
                          const float* embeddings, const inr_grid_desc* desc /*host*/,
                          const float* packed /*device*/, int32_t K, float* logits /*[M,K]*/,
                          inr_stream_t s);
+
+/* ---- 3-D RoIAlign ("next" row f2; replaces roi_align.roi_align.roi_align_3d, the one FFI call in the
+ * reference tree: /root/reference/nerf_rcnn/model/utils.py:604-609).  torchvision roi_align semantics
+ * (aligned=False, adaptive ceil(roi/out) sampling grid, average) on three axes: x<->W, y<->L, z<->H.
+ * input [N,C,W,L,H], rois [K,6] = (x1,y1,z1,x2,y2,z2) in input-scale units, roi_inds int32 [K],
+ * out [K,C,out_w,out_l,out_h].  backward ACCUMULATES into grad_input (caller zeroes it).          */
+int inr_roi_align_3d_forward(const float* input, const float* rois, const int32_t* roi_inds, int32_t N,
+                             int32_t C, int32_t W, int32_t L, int32_t H, int64_t K, int32_t out_w,
+                             int32_t out_l, int32_t out_h, float spatial_scale, float* out, inr_stream_t s);
+int inr_roi_align_3d_backward(const float* grad_out, const float* rois, const int32_t* roi_inds, int32_t N,
+                              int32_t C, int32_t W, int32_t L, int32_t H, int64_t K, int32_t out_w,
+                              int32_t out_l, int32_t out_h, float spatial_scale, float* grad_input,
+                              inr_stream_t s);
 
 /* ---- optimiser (replaces the Trainer's torch.optim.Adam sweep over the table, a15) ------ */
 int inr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,

@@ -57,6 +57,10 @@ _SIGS = {
     "inr_instance_pack_weights": (c_int32, [P, P, P, c_int32, P]),
     "inr_nerf_forward": (c_int32, [P, P, c_int64, P, c_float, P, POINTER(GridDesc), P, c_float, P, P, P, P]),
     "inr_instance_forward": (c_int32, [P, c_int64, P, c_float, P, POINTER(GridDesc), P, c_int32, P, P]),
+    "inr_roi_align_3d_forward": (c_int32, [P, P, P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int64, c_int32,
+                                           c_int32, c_int32, c_float, P, P]),
+    "inr_roi_align_3d_backward": (c_int32, [P, P, P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int64, c_int32,
+                                            c_int32, c_int32, c_float, P, P]),
     "inr_adam_step": (c_int32, [P, P, P, P, c_int64, c_float, c_float, c_float, c_float, c_int32, c_float, P]),
 }
 EXPORTS = tuple(_SIGS)

@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libinr_hip.so")
-SOURCES = ["raymarch.hip", "encoders.hip", "field_fused.hip"]
+SOURCES = ["raymarch.hip", "encoders.hip", "field_fused.hip", "roialign.hip"]
 HEADERS = ["common.h", "grid_common.h", os.path.join("..", "..", "include", "inr.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function"]

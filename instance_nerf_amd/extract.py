@@ -1,0 +1,92 @@
+"""rgb-sigma grid extraction: the step after the render path that feeds NeRF-RCNN.
+
+The reference's extractor lives in a third repository (a fork of instant-ngp,
+/root/reference/README.md:89) and is not available; what IS in the reference tree is the consumer:
+``SegmentationDataset.load_feature`` (/root/reference/nerf_rcnn/datasets.py:766-792) and
+``ngp_density_to_alpha`` (datasets.py:865-866), plus the metadata keys read by
+/root/reference/nerf_rcnn/scripts/proposals2ngp.py:24-29.  This module writes exactly what they read:
+
+* ``rgbsigma`` float32 ``[W, L, H, 4]`` (or flat ``[H*L*W, 4]``, or uint8), channels (r, g, b, d) with
+  d the RAW pre-activation density (the consumer applies ``1 - exp(-exp(d)/100)``), i.e. log(sigma);
+* ``resolution`` int ``[3] = (W, L, H)``, longest side <= 160 (train_rpn.sh:11, poolers.py:40);
+* ``bbox_min``, ``bbox_max``, ``scale``, ``offset``, ``from_mitsuba``.
+
+Queries go through ``NeRFNetwork.density`` / ``.color`` (the fused HIP field kernel).  Choices made here
+because the reference extractor is unseen: voxel-CENTRE positions; rgb = mean over 4 fixed view
+directions (the tetrahedron (1,1,1), (1,-1,-1), (-1,1,-1), (-1,-1,1), normalised).
+"""
+import numpy as np
+import torch
+
+VIEW_DIRS = np.asarray([[1, 1, 1], [1, -1, -1], [-1, 1, -1], [-1, -1, 1]], dtype=np.float32) / np.sqrt(3.0)
+
+
+def grid_resolution(bbox_min, bbox_max, max_side=160):
+    """Per-axis resolution with the longest side = max_side and (approximately) cubic voxels."""
+    ext = np.asarray(bbox_max, dtype=np.float64) - np.asarray(bbox_min, dtype=np.float64)
+    res = np.maximum(np.round(ext / ext.max() * max_side), 1).astype(np.int64)
+    return res
+
+
+def lattice(bbox_min, bbox_max, res, device):
+    """Voxel-centre positions, float32 [W*L*H, 3], index order (w, l, h) with h fastest."""
+    axes = []
+    for a in range(3):
+        n = int(res[a])
+        t = (torch.arange(n, dtype=torch.float32, device=device) + 0.5) / n
+        axes.append(float(bbox_min[a]) + t * (float(bbox_max[a]) - float(bbox_min[a])))
+    ww, ll, hh = torch.meshgrid(*axes, indexing="ij")
+    return torch.stack([ww.reshape(-1), ll.reshape(-1), hh.reshape(-1)], -1)
+
+
+@torch.no_grad()
+def extract_rgbsigma(model, bbox_min=None, bbox_max=None, max_side=160, res=None, chunk=1 << 22):
+    """-> (rgbsigma float32 [W,L,H,4] on the model's device, res int64[3]).  Channel 3 = log(sigma)."""
+    dev = next(model.parameters()).device
+    b = float(model.bound)
+    bbox_min = np.asarray([-b, -b, -b] if bbox_min is None else bbox_min, dtype=np.float32)
+    bbox_max = np.asarray([b, b, b] if bbox_max is None else bbox_max, dtype=np.float32)
+    res = grid_resolution(bbox_min, bbox_max, max_side) if res is None else np.asarray(res, dtype=np.int64)
+    pts = lattice(bbox_min, bbox_max, res, dev)
+    out = torch.empty(pts.shape[0], 4, dtype=torch.float32, device=dev)
+    dirs = torch.from_numpy(VIEW_DIRS).to(dev)
+    was_training = model.training
+    model.eval()
+    for s in range(0, pts.shape[0], chunk):
+        x = pts[s:s + chunk].clamp(-b, b)
+        den = model.density(x)
+        rgb = torch.zeros(x.shape[0], 3, dtype=torch.float32, device=dev)
+        for v in range(dirs.shape[0]):
+            rgb += model.color(x, dirs[v].expand(x.shape[0], 3).contiguous(), geo_feat=den["geo_feat"])
+        out[s:s + chunk, :3] = rgb / dirs.shape[0]
+        out[s:s + chunk, 3] = torch.log(den["sigma"].clamp_min(1e-30))
+    model.train(was_training)
+    return out.view(int(res[0]), int(res[1]), int(res[2]), 4), res
+
+
+def write_features_npz(path, rgbsigma, bbox_min, bbox_max, scale=1.0, offset=(0.0, 0.0, 0.0), from_mitsuba=False,
+                       flat=False, as_uint8=False):
+    """Writes ``features/<scene>.npz`` in the layout /root/reference/nerf_rcnn/datasets.py:766-792 reads.
+
+    rgbsigma: array-like [W, L, H, 4].  flat=True stores [H*L*W, 4] such that the consumer's
+    ``reshape(res[2], res[1], res[0], -1)`` + ``transpose(3, 2, 1, 0)`` (transpose_yz=False, the shipped
+    setting, run_rcnn.py:250) recovers [C, W, L, H].  as_uint8 quantises every channel from [0, 1] to
+    [0, 255]: the consumer divides by 255 but its density normalisation runs on the raw integer array
+    first, so uint8 files are only meaningful with channel 3 already holding alpha in [0, 1] and the
+    consumer's ``normalize_density=False``.
+    """
+    g = np.asarray(rgbsigma.detach().cpu() if torch.is_tensor(rgbsigma) else rgbsigma)
+    if g.ndim != 4 or g.shape[-1] != 4:
+        raise ValueError("rgbsigma must be [W, L, H, 4]")
+    W, L, H = g.shape[:3]
+    if as_uint8:
+        g = np.clip(np.round(g * 255.0), 0, 255).astype(np.uint8)
+    else:
+        g = g.astype(np.float32)
+    if flat:
+        g = np.ascontiguousarray(np.transpose(g, (2, 1, 0, 3))).reshape(H * L * W, 4)
+    np.savez_compressed(path, rgbsigma=g, resolution=np.asarray([W, L, H], dtype=np.int64),
+                        bbox_min=np.asarray(bbox_min, dtype=np.float32), bbox_max=np.asarray(bbox_max, dtype=np.float32),
+                        scale=np.float32(scale), offset=np.asarray(offset, dtype=np.float32),
+                        from_mitsuba=np.bool_(from_mitsuba))
+    return path

@@ -1,0 +1,49 @@
+"""``roi_align_3d`` with the signature the reference calls
+(/root/reference/nerf_rcnn/model/utils.py:608): differentiable w.r.t. ``input``."""
+import torch
+
+from .. import _lib
+from .._lib import check, ptr, stream_ptr
+
+
+class _RoIAlign3D(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, input, rois, roi_inds, out_w, out_l, out_h, spatial_scale):
+        lib = _lib.load()
+        input = input.contiguous().float()
+        rois = rois.contiguous().float()
+        roi_inds = roi_inds.contiguous().to(torch.int32)
+        if input.dim() != 5 or rois.dim() != 2 or rois.shape[1] != 6 or roi_inds.shape[0] != rois.shape[0]:
+            raise RuntimeError("roi_align_3d: input must be [N,C,W,L,H], rois [K,6], roi_inds [K]")
+        N, C, W, L, H = input.shape
+        K = rois.shape[0]
+        out = torch.empty(K, C, out_w, out_l, out_h, dtype=torch.float32, device=input.device)
+        check(lib.inr_roi_align_3d_forward(ptr(input, torch.float32, "input", allow_none=input.numel() == 0),
+                                           ptr(rois, torch.float32, "rois", allow_none=K == 0),
+                                           ptr(roi_inds, torch.int32, "roi_inds", allow_none=K == 0), N, C, W, L, H, K,
+                                           out_w, out_l, out_h, float(spatial_scale), ptr(out, allow_none=K == 0),
+                                           stream_ptr()), "roi_align_3d_forward")
+        ctx.save_for_backward(rois, roi_inds)
+        ctx.shape = (N, C, W, L, H)
+        ctx.cfg = (out_w, out_l, out_h, float(spatial_scale))
+        ctx.mark_non_differentiable(roi_inds)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        lib = _lib.load()
+        rois, roi_inds = ctx.saved_tensors
+        N, C, W, L, H = ctx.shape
+        ow, ol, oh, scale = ctx.cfg
+        K = rois.shape[0]
+        grad = grad.contiguous().float()
+        gin = torch.zeros(N, C, W, L, H, dtype=torch.float32, device=grad.device)
+        check(lib.inr_roi_align_3d_backward(ptr(grad, allow_none=K == 0), ptr(rois, allow_none=K == 0),
+                                            ptr(roi_inds, allow_none=K == 0), N, C, W, L, H, K, ow, ol, oh, scale,
+                                            ptr(gin, allow_none=gin.numel() == 0), stream_ptr()), "roi_align_3d_backward")
+        return gin, None, None, None, None, None, None
+
+
+def roi_align_3d(input, rois, roi_inds, out_w, out_l, out_h, spatial_scale):
+    """input f32[N,C,W,L,H], rois f32[K,6] (x1,y1,z1,x2,y2,z2), roi_inds int[K] -> f32[K,C,out_w,out_l,out_h]."""
+    return _RoIAlign3D.apply(input, rois, roi_inds, int(out_w), int(out_l), int(out_h), spatial_scale)

@@ -30,4 +30,4 @@ this repository and is documented on the function that makes it:
   in the operation order written in ``march.py``.
 """
 
-from . import rays, occupancy, march, hashgrid, sh, field, composite, render  # noqa: F401
+from . import rays, occupancy, march, hashgrid, sh, field, composite, render, consumers, roialign  # noqa: F401

@@ -1,0 +1,65 @@
+"""f1 (rgb-sigma grid writer): the consumer contract is pinned to the reference's own loader."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import consumers
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_oracle_consumer_matches_reference_golden():
+    """oracle.consumers == what /root/reference/nerf_rcnn/datasets.py returned (golden made by the reference)."""
+    g = np.load(os.path.join(G, "features_consumer.npz"))
+    assert np.allclose(consumers.ngp_density_to_alpha(g["dens_in"]), g["dens_alpha"], atol=1e-7)
+    res = g["resolution"]
+    f = lambda arr, **kw: consumers.load_feature({"rgbsigma": arr, "resolution": res}, **kw)
+    assert np.allclose(f(g["grid"]), g["exp_grid"], atol=1e-7)
+    assert np.allclose(f(g["flat"]), g["exp_flat_noT"], atol=1e-7)
+    assert np.allclose(f(g["flat"], transpose_yz=True), g["exp_flat_T"], atol=1e-7)
+    assert np.allclose(f(g["u8"], normalize_density=False), g["exp_u8"], atol=1e-7)
+
+
+@pytest.mark.parametrize("flat", [False, True])
+def test_writer_roundtrip_through_consumer(tmp_path, flat):
+    from instance_nerf_amd.extract import write_features_npz
+    rng = np.random.default_rng(1)
+    grid = rng.normal(size=(6, 4, 5, 4)).astype(np.float32)
+    p = write_features_npz(str(tmp_path / "scene.npz"), grid, [-1, -1, -1], [1, 1, 1], flat=flat)
+    with np.load(p) as z:
+        assert set(z.files) >= {"rgbsigma", "resolution", "bbox_min", "bbox_max", "scale", "offset", "from_mitsuba"}
+        assert z["resolution"].tolist() == [6, 4, 5]
+        out = consumers.load_feature(z, normalize_density=True, transpose_yz=False)
+    assert out.shape == (4, 6, 4, 5)
+    assert np.allclose(out[:3], np.transpose(grid[..., :3], (3, 0, 1, 2)))
+    assert np.allclose(out[3], consumers.ngp_density_to_alpha(grid[..., 3]), atol=1e-7)
+
+
+def test_grid_resolution_and_lattice():
+    from instance_nerf_amd.extract import grid_resolution, lattice
+    res = grid_resolution([-1, -1, -0.5], [1, 1, 0.5], 160)
+    assert res.tolist() == [160, 160, 80]
+    pts = lattice([-1, -1, -1], [1, 1, 1], [4, 2, 2], "cpu")
+    assert pts.shape == (16, 3)
+    assert torch.allclose(pts[0], torch.tensor([-0.75, -0.5, -0.5])) and torch.allclose(pts[1], torch.tensor([-0.75, -0.5, 0.5]))
+
+
+@pytest.mark.gpu
+def test_extract_matches_oracle_field(level_table, params_k16):
+    """Grid values = oracle density (log) / colour (mean over the 4 fixed directions) at voxel centres."""
+    from instance_nerf_amd.extract import VIEW_DIRS, extract_rgbsigma, lattice
+    from oracle import field
+    from test_gpu_parity import _network
+    net = _network(params_k16, K=0).eval()
+    grid, res = extract_rgbsigma(net, res=[12, 10, 8])
+    assert tuple(grid.shape) == (12, 10, 8, 4)
+    pts = lattice([-1, -1, -1], [1, 1, 1], res, "cpu")
+    with torch.no_grad():
+        den = field.density(pts, params_k16, 1.0, level_table)
+        rgb = sum(field.color(torch.from_numpy(VIEW_DIRS[v]).expand(pts.shape[0], 3), den["geo_feat"], params_k16)
+                  for v in range(4)) / 4
+    got = grid.view(-1, 4).cpu()
+    assert torch.allclose(got[:, 3], den["sigma_raw"], atol=1e-4, rtol=1e-4)
+    assert (got[:, :3] - rgb).abs().max() < 1e-4
