@@ -80,6 +80,37 @@ def cpu_baseline(room, chunk=4096, budget_s=12.0, max_chunks=24):
                       f"oracle march+field+composite, {t_used:.1f} s"}
 
 
+def train_probe(dev, steps=20, warmup=5):
+    """Secondary measurement (not the headline value): instance-field training step, BASELINE configs[2]
+    (K=64 logits, 4096 rays/batch, NeRF frozen): march -> frozen NeRF (fused) -> instance grid encode ->
+    MLP -> K-channel compositing -> CE -> backward (atomic scatter) -> fused Adam."""
+    from instance_nerf_amd.nerf import NeRFNetwork
+    from instance_nerf_amd.nerf.provider import SyntheticRoomDataset
+    from instance_nerf_amd.nerf.utils import Trainer
+    torch.manual_seed(0)
+    net = NeRFNetwork(cuda_ray=True, bound=1, min_near=0.05, density_thresh=10, num_instances=64).to(dev)
+    ds = SyntheticRoomDataset(dev, num_rays=4096, num_instances=64)
+    net.density_bitfield.copy_(torch.from_numpy(ds.room.density_bitfield(128, 1.0)).to(dev))
+    tr = Trainer("bench", None, net, stage="instance", device=dev, iters=1000, update_extra_interval=10 ** 9)
+    tr.global_step = 1                     # keep the analytic occupancy grid
+    batches = [ds.batch() for _ in range(4)]
+    first = last = 0.0
+    for i in range(warmup):
+        l = float(tr.train_one_step(batches[i % 4]))
+        first = l if i == 0 else first
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 0
+    for i in range(steps):
+        last = tr.train_one_step(batches[i % 4])
+        n += int(net.step_counter[(net.local_step - 1) % 16, 0])
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"workload": "instance-field training step, K=64, 4096 rays/batch, NeRF frozen (BASELINE configs[2])",
+            "ms_per_step": round(dt * 1e3, 3), "samples_per_step": n // steps,
+            "msamples_per_s": round(n / steps / dt / 1e6, 2), "loss_first": round(first, 4), "loss_last": round(float(last), 4)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -87,6 +118,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--res", type=int, default=800)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train-probe", action="store_true")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -181,6 +213,8 @@ def main():
                          "avg_launch_ms": round(avg_kernel_s * 1e3, 4), "launches": n_launch,
                          "algorithmic_bytes_per_sample": BYTES_PER_SAMPLE},
         }
+        if world == 1 and not args.no_train_probe:
+            line["train_step"] = train_probe(dev)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(room)
         print(json.dumps(line), flush=True)
