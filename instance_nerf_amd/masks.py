@@ -1,0 +1,131 @@
+"""Mask plumbing either side of the instance-field trainer.
+
+f3  ``load_matched_masks``: reads what /root/reference/Mask2Former_sample/match_seg.py:140 writes -
+    one ``<img>.npy`` per view, int32 [H, W], -1 = ignore / unmatched, 0 = background, > 0 = instance id
+    (match_seg.py:65-91,131-138) - and turns it into per-ray labels for the CE loss (ignore_index -1).
+f4  ``project_3d_masks``: counterpart of the reference's ``scripts/project_3d_masks.py`` (in the
+    un-vendored submodule, /root/reference/README.md:63).  Input: NeRF-RCNN's discrete 3-D masks
+    (/root/reference/nerf_rcnn/run_rcnn.py:652-666: ``masks [k, W, L, H]``); output:
+    ``<proj_dir>/<img>_<inst>.png`` with foreground = channel 0 > 0 and instance ids starting at 1
+    (match_seg.py:55-62,99-102: files ``*_0.png`` are skipped by the consumer).  A pixel belongs to
+    instance i when the NeRF-weighted mask value along its ray, sum_s w_s * mask_i(x_s), exceeds
+    ``thresh``: the K-channel compositing of the render path with mask_i as the extra channel.
+"""
+import os
+import struct
+import zlib
+
+import numpy as np
+import torch
+
+from . import raymarching
+from .nerf.utils import get_rays
+
+
+# ---------------------------------------------------------------------------------------- f3
+def load_matched_masks(seg_dir, names=None):
+    """-> dict {image name: int32 [H, W]} from ``<seg_dir>/<name>.npy``."""
+    files = sorted(f for f in os.listdir(seg_dir) if f.endswith(".npy"))
+    if names is not None:
+        files = [f for f in files if f[:-4] in set(names)]
+    out = {}
+    for f in files:
+        m = np.load(os.path.join(seg_dir, f))
+        if m.ndim != 2:
+            raise ValueError(f"{f}: expected an [H, W] instance-id map, got shape {m.shape}")
+        out[f[:-4]] = m.astype(np.int32)
+    return out
+
+
+def labels_for_rays(mask, inds, num_instances):
+    """mask int32 [H, W], inds int64 [N] flat pixel indices -> int64 [N] CE targets (-1 stays ignore;
+    ids >= num_instances are ignored too, they have no logit)."""
+    m = torch.as_tensor(mask).reshape(-1).long()
+    lab = m[inds.cpu()] if torch.is_tensor(inds) else m[torch.as_tensor(inds)]
+    lab = torch.where(lab >= num_instances, torch.full_like(lab, -1), lab)
+    return lab
+
+
+# ---------------------------------------------------------------------------------------- png
+def save_png_gray(path, img):
+    """Minimal 8-bit grayscale PNG writer (no imaging library in the image); ``cv2.imread`` decodes it to
+    three equal channels, so ``img[:, :, 0] > 0`` (match_seg.py:59) sees the mask."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w = img.shape
+    raw = b"".join(b"\x00" + img[r].tobytes() for r in range(h))
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+    png = (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 0, 0, 0, 0))
+           + chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
+    with open(path, "wb") as f:
+        f.write(png)
+
+
+def read_png_gray(path):
+    """Decoder for files written by ``save_png_gray`` (tests)."""
+    data = open(path, "rb").read()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, w, h = 8, b"", 0, 0
+    while pos < len(data):
+        n, tag = struct.unpack(">I", data[pos:pos + 4])[0], data[pos + 4:pos + 8]
+        body = data[pos + 8:pos + 8 + n]
+        if tag == b"IHDR":
+            w, h = struct.unpack(">II", body[:8])
+        elif tag == b"IDAT":
+            idat += body
+        pos += 12 + n
+    raw = zlib.decompress(idat)
+    return np.frombuffer(raw, np.uint8).reshape(h, w + 1)[:, 1:].copy()
+
+
+# ---------------------------------------------------------------------------------------- f4
+@torch.no_grad()
+def soft_project(model, masks, bbox_min, bbox_max, rays_o, rays_d, T_thresh=1e-4, dt_gamma=0, max_steps=1024):
+    """NeRF-weighted projection of k voxel masks along rays.  masks [k, W, L, H]; rays [N, 3].
+    -> (soft [N, k] = sum_s w_s * mask(x_s), weights_sum [N])."""
+    dev = rays_o.device
+    masks = torch.as_tensor(masks).to(dev).float()
+    k = masks.shape[0]
+    res = torch.tensor(masks.shape[1:], device=dev, dtype=torch.float32)
+    lo = torch.as_tensor(np.asarray(bbox_min, dtype=np.float32)).to(dev)
+    hi = torch.as_tensor(np.asarray(bbox_max, dtype=np.float32)).to(dev)
+    nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, model.aabb_infer, model.min_near)
+    xyzs, dirs, deltas, rays = raymarching.march_rays_patch(rays_o, rays_d, model.bound, model.density_bitfield,
+                                                           model.cascade, model.grid_size, nears, fars, dt_gamma, max_steps)
+    sigmas, rgbs = model(xyzs, dirs)
+    sigmas = sigmas * model.density_scale
+    cell = ((xyzs - lo) / (hi - lo) * res).floor().long()
+    inside = ((cell >= 0) & (cell < res.long())).all(-1)
+    cell = cell.clamp(min=0)
+    cell = torch.minimum(cell, res.long() - 1)
+    vals = masks[:, cell[:, 0], cell[:, 1], cell[:, 2]].t().contiguous() * inside[:, None]     # [M, k]
+    ws, _, _, soft = raymarching.composite_rays_patch(sigmas, rgbs, deltas, rays, T_thresh, extra=vals)
+    return soft, ws
+
+
+@torch.no_grad()
+def project_3d_masks(model, masks, bbox_min, bbox_max, poses, intrinsics, H, W, proj_dir=None, img_names=None,
+                     thresh=0.5):
+    """-> bool array [n_views, k, H, W]; when ``proj_dir`` is given also writes ``<img>_<inst>.png``
+    (inst = mask index + 1) for every non-empty projection."""
+    dev = next(model.parameters()).device
+    poses = torch.as_tensor(poses).to(dev).float()
+    k = len(masks)
+    out = np.zeros((poses.shape[0], k, H, W), dtype=bool)
+    was_training = model.training
+    model.eval()
+    for v in range(poses.shape[0]):
+        r = get_rays(poses[v:v + 1], intrinsics, H, W, patch=4 if (H % 4 == 0 and W % 4 == 0) else 0)
+        soft, _ = soft_project(model, masks, bbox_min, bbox_max, r["rays_o"][0], r["rays_d"][0])
+        flat = torch.zeros(H * W, k, device=dev)
+        flat[r["inds"][0]] = soft
+        out[v] = (flat > thresh).t().reshape(k, H, W).cpu().numpy()
+        if proj_dir is not None:
+            os.makedirs(proj_dir, exist_ok=True)
+            name = img_names[v] if img_names is not None else f"{v:04d}"
+            for i in range(k):
+                if out[v, i].any():
+                    save_png_gray(os.path.join(proj_dir, f"{name}_{i + 1}.png"), out[v, i].astype(np.uint8) * 255)
+    model.train(was_training)
+    return out
