@@ -127,11 +127,19 @@ def main():
     if not torch.cuda.is_available():
         print(json.dumps({"error": "no GPU: bench.py measures the HIP path only (no CPU fallback)"}))
         sys.exit(1)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one process per GPU; the modulo only matters for the single-GPU dry run of the N>1 logic
+    # (INR_DIST_BACKEND=gloo, several ranks sharing cuda:0)
+    local_dev = local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
+    backend = os.environ.get("INR_DIST_BACKEND", "nccl")          # "nccl" == RCCL on ROCm
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+    red_dev = dev if backend == "nccl" else torch.device("cpu")
 
     from instance_nerf_amd.nerf.utils import get_rays
     net, room = build_network(dev)
@@ -182,8 +190,8 @@ def main():
     n_samples = int(sum(int(c[0]) for c in counters))
     kernel_ms = sum(a.elapsed_time(b) for a, b, _ in ev_pairs)
     n_launch = len(ev_pairs)
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    tot = torch.tensor([float(n_samples)], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+    tot = torch.tensor([float(n_samples)], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
