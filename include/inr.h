@@ -193,6 +193,12 @@ int inr_roi_align_3d_backward(const float* grad_out, const float* rois, const in
                               int32_t out_l, int32_t out_h, float spatial_scale, float* grad_input,
                               inr_stream_t s);
 
+/* ---- weight gradient of the tiny bias-free MLP layers (replaces the BLAS call autograd makes for
+ * nn.Linear in NeRFNetwork, a9/a13):  grad_w[o][i] += sum_m grad_y[m][o] * x[m][i],  n_in, n_out <= 64.
+ * x [M, n_in], grad_y [M, n_out], grad_w [n_out, n_in] is ACCUMULATED into (caller zeroes it).      */
+int inr_linear_wgrad(const float* x, const float* grad_y, int64_t M, int32_t n_in, int32_t n_out,
+                     float* grad_w, inr_stream_t s);
+
 /* ---- optimiser (replaces the Trainer's torch.optim.Adam sweep over the table, a15) ------ */
 int inr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                   float lr, float beta1, float beta2, float eps, int32_t step, float grad_scale,

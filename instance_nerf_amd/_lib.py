@@ -61,6 +61,7 @@ _SIGS = {
                                            c_int32, c_int32, c_float, P, P]),
     "inr_roi_align_3d_backward": (c_int32, [P, P, P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int64, c_int32,
                                             c_int32, c_int32, c_float, P, P]),
+    "inr_linear_wgrad": (c_int32, [P, P, c_int64, c_int32, c_int32, P, P]),
     "inr_adam_step": (c_int32, [P, P, P, P, c_int64, c_float, c_float, c_float, c_float, c_int32, c_float, P]),
 }
 EXPORTS = tuple(_SIGS)

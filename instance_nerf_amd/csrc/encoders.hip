@@ -174,6 +174,57 @@ __global__ void k_adam_tail(float* p, const float* g, float* m, float* v, int64_
   p[i] = p[i] - lr_t * mm / (sqrtf(vv) + eps_t);
 }
 
+// ---- weight gradient of a bias-free linear layer: dW[o][i] += sum_m gy[m][o] * x[m][i] -------------------
+// The reduction runs over SAMPLES (m ~ 2e5) while o, i <= 64: a GEMM with a tiny output and a huge K,
+// which the BLAS library runs on 2-4 workgroups (measured 0.43-0.48 ms per layer).  Here every wave
+// takes a slab of samples, keeps the whole [<=64 x <=64] result in 16 MFMA accumulators
+// (v_mfma_f32_16x16x4_f32: exact fp32, k = 4 samples per instruction) and adds it to dW with
+// address-adjacent atomics at the end (split-K over ~1000 waves).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kWgradSlab = 256;   // samples per wave
+
+__global__ void __launch_bounds__(256) k_linear_wgrad(const float* __restrict__ x, const float* __restrict__ gy,
+                                                      int64_t M, int n_in, int n_out, float* __restrict__ gw) {
+  const int lane = threadIdx.x & 63, q = lane >> 4, j = lane & 15;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t m0 = wave * kWgradSlab;
+  if (m0 >= M) return;
+  const int n_ot = (n_out + 15) >> 4, n_it = (n_in + 15) >> 4;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int64_t m_end = min(M, m0 + kWgradSlab);
+  for (int64_t m = m0; m < m_end; m += 4) {
+    const int64_t row = m + q;                       // k-slot q of this step
+    const bool rv = row < m_end;
+    float av[4], bv[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int o = 16 * t + j, i = 16 * t + j;
+      av[t] = (rv && o < n_out) ? gy[row * n_out + o] : 0.f;      // A[i = out][k = sample]
+      bv[t] = (rv && i < n_in) ? x[row * n_in + i] : 0.f;         // B[k = sample][j = in]
+    }
+#pragma unroll
+    for (int ot = 0; ot < 4; ++ot)
+#pragma unroll
+      for (int it = 0; it < 4; ++it)
+        if (ot < n_ot && it < n_it) acc[ot][it] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ot], bv[it], acc[ot][it], 0, 0, 0);
+  }
+#pragma unroll
+  for (int ot = 0; ot < 4; ++ot)
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+      if (ot < n_ot && it < n_it) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int o = 16 * ot + 4 * q + r, i = 16 * it + j;
+          if (o < n_out && i < n_in) atomicAdd(gw + (size_t)o * n_in + i, acc[ot][it][r]);
+        }
+      }
+}
+
 }  // namespace inr
 
 using namespace inr;
@@ -229,6 +280,16 @@ int inr_sh_encode_backward(const float* grad_out, const float* d, int64_t M, int
   INR_REQUIRE(grad_out && d && grad_d, "null pointer");
   k_sh_bwd<<<blocks_for(M, 256), 256, 0, as_stream(s)>>>(grad_out, d, M, degree, grad_d);
   return check_launch("sh_encode_backward");
+}
+
+int inr_linear_wgrad(const float* x, const float* grad_y, int64_t M, int32_t n_in, int32_t n_out, float* grad_w,
+                     inr_stream_t s) {
+  INR_REQUIRE(M >= 0 && n_in > 0 && n_in <= 64 && n_out > 0 && n_out <= 64, "n_in and n_out must be in 1..64");
+  if (M == 0) return INR_OK;
+  INR_REQUIRE(x && grad_y && grad_w, "null pointer");
+  const int64_t waves = (M + kWgradSlab - 1) / kWgradSlab;
+  k_linear_wgrad<<<blocks_for(waves, 4), 256, 0, as_stream(s)>>>(x, grad_y, M, n_in, n_out, grad_w);
+  return check_launch("linear_wgrad");
 }
 
 int inr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,

@@ -27,10 +27,44 @@ from ..encoding import get_encoder
 from .renderer import NeRFRenderer
 
 
+class _LinearFn(torch.autograd.Function):
+    """y = x W^T with the weight gradient on the split-K MFMA kernel (inr_linear_wgrad): the reduction runs
+    over ~2e5 samples with a <= 64x64 result, a shape the BLAS library serialises on a few workgroups."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return F.linear(x, w)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = gy @ w
+        if ctx.needs_input_grad[1]:
+            lib = _lib.load()
+            gyc, xc = gy.contiguous(), x.contiguous()
+            gw = torch.zeros_like(w)
+            check(lib.inr_linear_wgrad(ptr(xc, torch.float32, "x"), ptr(gyc, torch.float32, "grad_y"), xc.shape[0],
+                                       w.shape[1], w.shape[0], ptr(gw), stream_ptr()), "linear_wgrad")
+        return gx, gw
+
+
+class HipLinear(nn.Linear):
+    """nn.Linear(bias=False) whose backward uses the HIP weight-gradient kernel (same parameters/state dict)."""
+
+    def forward(self, x):
+        if (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and self.in_features <= 64
+                and self.out_features <= 64 and torch.is_grad_enabled() and self.weight.requires_grad):
+            return _LinearFn.apply(x, self.weight)
+        return F.linear(x, self.weight)
+
+
 def _mlp(in_dim, hidden, out_dim, num_layers):
     layers = []
     for l in range(num_layers):
-        layers.append(nn.Linear(in_dim if l == 0 else hidden, out_dim if l == num_layers - 1 else hidden, bias=False))
+        layers.append(HipLinear(in_dim if l == 0 else hidden, out_dim if l == num_layers - 1 else hidden, bias=False))
     return nn.ModuleList(layers)
 
 

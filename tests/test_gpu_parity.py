@@ -456,3 +456,16 @@ def test_trainer_matches_oracle_training(room, room_bitfield, level_table):
     assert abs(psnr(hip_losses[-1]) - psnr(ref_losses[-1])) < 0.05
     w = net.sigma_net[0].weight.detach().cpu()
     assert torch.allclose(w, p["sigma_w0"].detach(), atol=2e-3)
+
+
+def test_linear_wgrad_matches_torch():
+    from instance_nerf_amd.nerf.network import HipLinear
+    gen = torch.Generator().manual_seed(0)
+    for M, n_in, n_out in ((1000, 32, 64), (5003, 64, 64), (777, 31, 64), (300, 64, 3), (4, 64, 16)):
+        lin = HipLinear(n_in, n_out, bias=False).to(DEV)
+        x = torch.randn(M, n_in, generator=gen).to(DEV).requires_grad_(True)
+        gy = torch.randn(M, n_out, generator=gen).to(DEV)
+        lin(x).backward(gy)
+        ref_w = gy.t().double() @ x.detach().double()
+        assert torch.allclose(lin.weight.grad.double(), ref_w, atol=1e-3, rtol=1e-4)
+        assert torch.allclose(x.grad, gy @ lin.weight.detach(), atol=1e-5)
