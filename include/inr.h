@@ -150,6 +150,12 @@ int inr_grid_encode_backward(const float* x, const float* grad_out /*[M,L*F]*/,
                              const inr_grid_desc* desc /*host*/, int64_t M, float bound,
                              float* grad_embeddings /*[T,F]*/, inr_stream_t s);
 
+/* same, processing the samples in the order given (int32 permutation of 0..M-1, nullable): the sum is
+ * order-independent up to fp32 rounding; a spatial (Morton) order makes the atomics address-adjacent */
+int inr_grid_encode_backward_ordered(const float* x, const float* grad_out, const int32_t* order,
+                                     const inr_grid_desc* desc /*host*/, int64_t M, float bound,
+                                     float* grad_embeddings /*[T,F]*/, inr_stream_t s);
+
 /* ---- SH (replaces shencoder sh_encode_forward / _backward, a10) ------------------------ */
 int inr_sh_encode_forward(const float* d /*[M,3]*/, int64_t M, int32_t degree, float* out, inr_stream_t s);
 int inr_sh_encode_backward(const float* grad_out, const float* d, int64_t M, int32_t degree,

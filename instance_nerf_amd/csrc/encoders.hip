@@ -68,13 +68,18 @@ __device__ __forceinline__ void run_reduce_atomic(float* __restrict__ gemb, uint
   }
 }
 
+// `order` (nullable): a permutation of the samples; lane m processes sample order[m].  Passing the
+// samples' Morton order makes neighbouring lanes neighbours in SPACE for every level (not only along a
+// ray), which lengthens the equal-row runs and makes the remaining atomics address-adjacent.
 __global__ void __launch_bounds__(256) k_grid_bwd(const float* __restrict__ x, const float2* __restrict__ gout,
-                                                  GridDesc G, int64_t M, float bound, float* __restrict__ gemb) {
+                                                  const int32_t* __restrict__ order, GridDesc G, int64_t M, float bound,
+                                                  float* __restrict__ gemb) {
   const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int l = blockIdx.y;
   const int L = G.num_levels;
   const bool valid = m < M;
-  const int64_t mc = valid ? m : M - 1;
+  const int64_t ms = valid ? m : M - 1;
+  const int64_t mc = order ? (int64_t)order[ms] : ms;
   const float rb = 2.0f * bound;
   const float x0 = (x[mc * 3 + 0] + bound) / rb;
   const float x1 = (x[mc * 3 + 1] + bound) / rb;
@@ -249,6 +254,12 @@ int inr_grid_encode_forward(const float* x, const float* embeddings, const inr_g
 
 int inr_grid_encode_backward(const float* x, const float* grad_out, const inr_grid_desc* desc, int64_t M, float bound,
                              float* grad_embeddings, inr_stream_t s) {
+  return inr_grid_encode_backward_ordered(x, grad_out, nullptr, desc, M, bound, grad_embeddings, s);
+}
+
+int inr_grid_encode_backward_ordered(const float* x, const float* grad_out, const int32_t* order,
+                                     const inr_grid_desc* desc, int64_t M, float bound, float* grad_embeddings,
+                                     inr_stream_t s) {
   INR_REQUIRE(M >= 0 && desc, "bad argument");
   if (M == 0) return INR_OK;
   INR_REQUIRE(x && grad_out && grad_embeddings, "null pointer");
@@ -258,7 +269,7 @@ int inr_grid_encode_backward(const float* x, const float* grad_out, const inr_gr
   INR_REQUIRE(((uintptr_t)grad_out & 7) == 0, "grad_out must be 8-byte aligned");
   if (M == 0) return INR_OK;
   const dim3 grid(blocks_for(M, 256), (unsigned)G.num_levels);
-  k_grid_bwd<<<grid, 256, 0, as_stream(s)>>>(x, reinterpret_cast<const float2*>(grad_out), G, M, bound,
+  k_grid_bwd<<<grid, 256, 0, as_stream(s)>>>(x, reinterpret_cast<const float2*>(grad_out), order, G, M, bound,
                                              grad_embeddings);
   return check_launch("grid_encode_backward");
 }
