@@ -469,3 +469,75 @@ def test_linear_wgrad_matches_torch():
         ref_w = gy.t().double() @ x.detach().double()
         assert torch.allclose(lin.weight.grad.double(), ref_w, atol=1e-3, rtol=1e-4)
         assert torch.allclose(x.grad, gy @ lin.weight.detach(), atol=1e-5)
+
+
+# ---------------------------------------------------------------------------- other configurations / full size
+def test_bound2_two_cascades_bit_exact(rm):
+    """bound = 2 -> 2 cascades, mip level chosen per sample from position and step size; dt_gamma > 0."""
+    from oracle import hashgrid, march, rays
+    rng = np.random.default_rng(5)
+    H, C, bound = 64, 2, 2.0
+    bits = (rng.random(C * H ** 3 // 8) < 0.03).astype(np.uint8) * rng.integers(1, 256, C * H ** 3 // 8).astype(np.uint8)
+    n = 512
+    ro = rng.uniform(-1.5, 1.5, size=(n, 3)).astype(np.float32)
+    rd = rng.normal(size=(n, 3)).astype(np.float32)
+    rd /= np.linalg.norm(rd, axis=1, keepdims=True)
+    aabb = np.asarray([-bound] * 3 + [bound] * 3, np.float32)
+    nears, fars = rays.near_far_from_aabb(ro, rd, aabb, 0.2)
+    noises = rng.random(n).astype(np.float32)
+    for gamma in (0.0, 1.0 / 256):
+        ref = march.march_rays_train(ro, rd, bits, bound, C, H, nears, fars, noises, gamma, 512)
+        x, d, dl, rr = rm.march_rays_train(_t(ro), _t(rd), bound, _t(bits), C, H, _t(nears), _t(fars), dt_gamma=gamma,
+                                           max_steps=512, noises=_t(noises))
+        assert ref["total"] > 1000
+        assert (rr.cpu().numpy() == ref["rays"]).all()
+        assert (x.cpu().numpy()[:ref["total"]] == ref["xyzs"]).all()
+        assert (dl.cpu().numpy()[:ref["total"]] == ref["deltas"]).all()
+    # encoder at bound 2 (desired resolution 4096: different level table)
+    from instance_nerf_amd.gridencoder import GridEncoder
+    enc = GridEncoder(desired_resolution=4096, num_levels=12, log2_hashmap_size=17).to(DEV)
+    tb = hashgrid.level_table(num_levels=12, log2_hashmap_size=17, desired_resolution=4096)
+    emb = (torch.rand(tb["total_rows"], 2, generator=torch.Generator().manual_seed(0)) * 2 - 1)
+    enc.embeddings.data.copy_(emb)
+    xx = torch.tensor(ref["xyzs"][:4000])
+    with torch.no_grad():
+        got = enc(xx.to(DEV), bound=bound).cpu()
+    want = hashgrid.encode(xx, emb, bound, tb)
+    assert (got - want).abs().max() < 1e-5
+
+
+def test_full_frame_properties(params_k16, room, room_bitfield):
+    """800x800 (640 000 rays): the patch-interleaved path and the ray-major path render the same image;
+    offsets are the exclusive scan of the counts; every ray's opacity is in [0, 1]."""
+    from instance_nerf_amd.nerf.utils import get_rays
+    net = _network(params_k16, K=0).eval()
+    net.density_bitfield.copy_(_t(room_bitfield))
+    poses, intr, H, W = room.cameras()
+    r = get_rays(_t(poses[2:3]), intr, H, W, patch=4)
+    with torch.no_grad():
+        a = net.render(r["rays_o"], r["rays_d"], bg_color=1, infer_mode="fused")
+        b = net.render(r["rays_o"], r["rays_d"], bg_color=1, infer_mode="fused_raymajor")
+    assert int(a["num_samples"][0]) == int(b["num_samples"][0]) > 20_000_000
+    assert (a["image"] - b["image"]).abs().max() < 2e-5
+    assert (a["weights_sum"] - b["weights_sum"]).abs().max() < 2e-5
+    assert a["weights_sum"].min() >= 0 and a["weights_sum"].max() <= 1 + 1e-5
+    assert torch.isfinite(a["image"]).all()
+    # scan property on the full ray set
+    from instance_nerf_amd import raymarching as _rm
+    nears, fars = _rm.near_far_from_aabb(r["rays_o"][0], r["rays_d"][0], net.aabb_infer, 0.05)
+    _, _, _, rays = _rm.march_rays_patch(r["rays_o"][0], r["rays_d"][0], 1.0, net.density_bitfield,
+                                                                                 1, 128, nears, fars)
+    cnt = rays[:, 2].long()
+    assert torch.equal(rays[:, 1].long(), torch.cumsum(cnt, 0) - cnt)
+    assert torch.equal(rays[:, 0].long(), torch.arange(H * W, device=DEV))
+
+
+def test_rays_missing_the_volume(rm, bits_dev):
+    ro = np.asarray([[5, 5, 5], [0, 0, 3], [0, 0, 0]], np.float32)
+    rd = np.asarray([[1, 0, 0], [0, 1, 0], [0, 0, 1]], np.float32)
+    aabb = _t(np.asarray([-1, -1, -1, 1, 1, 1], np.float32))
+    nears, fars = rm.near_far_from_aabb(_t(ro), _t(rd), aabb, 0.05)
+    x, d, dl, rays = rm.march_rays_patch(_t(ro), _t(rd), 1.0, bits_dev, 1, 128, nears, fars)
+    assert rays[:2, 2].tolist() == [0, 0] and rays[2, 2] > 0
+    ws, depth, img = rm.composite_rays_patch(torch.zeros(x.shape[0], device=DEV), torch.zeros(x.shape[0], 3, device=DEV), dl, rays)
+    assert ws.tolist() == [0.0, 0.0, 0.0]
