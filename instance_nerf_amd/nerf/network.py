@@ -169,6 +169,12 @@ class NeRFNetwork(NeRFRenderer):
         h = _run_mlp(self.sigma_net, self.encoder(x, bound=self.bound))
         return {"sigma": trunc_exp(h[..., 0]), "geo_feat": h[..., 1:]}
 
+    def density_sigma(self, x):
+        params = [self.encoder.embeddings] + [l.weight for l in self.sigma_net]
+        if self._fusable and not self._needs_grad(params):
+            return self._fused_nerf(x, None, False, False)[0]
+        return self.density(x)["sigma"]
+
     def color(self, x, d, mask=None, geo_feat=None, **kwargs):
         """rgb [M,3]; rows where ``mask`` is False are zero (upstream semantics)."""
         if geo_feat is None:

@@ -60,6 +60,10 @@ class NeRFRenderer(nn.Module):
     def color(self, x, d, mask=None, **kwargs):
         raise NotImplementedError()
 
+    def density_sigma(self, x):
+        """sigma only (the occupancy update needs nothing else); subclasses may skip the geo features."""
+        return self.density(x)["sigma"]
+
     def instance(self, x):
         return None
 
@@ -254,7 +258,7 @@ class NeRFRenderer(nn.Module):
             half = bnd / H
             cas_xyzs = xyzs * (bnd - half)
             cas_xyzs = cas_xyzs + (torch.rand_like(cas_xyzs) * 2 - 1) * half
-            sigmas = self.density(cas_xyzs)["sigma"].reshape(-1).detach() * self.density_scale
+            sigmas = self.density_sigma(cas_xyzs).reshape(-1).detach() * self.density_scale
             tmp_grid[cas, indices] = sigmas
 
     # ----------------------------------------------------------------------------------------

@@ -1,0 +1,34 @@
+"""NeRF-stage training step timing (MSE on rgb, 4096 rays/batch) + occupancy update timing."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from instance_nerf_amd.nerf import NeRFNetwork
+from instance_nerf_amd.nerf.provider import SyntheticRoomDataset
+from instance_nerf_amd.nerf.utils import Trainer
+
+dev = torch.device("cuda", 0)
+torch.manual_seed(0)
+net = NeRFNetwork(cuda_ray=True, bound=1, min_near=0.05, density_thresh=10).to(dev)
+ds = SyntheticRoomDataset(dev, num_rays=4096)
+net.density_bitfield.copy_(torch.from_numpy(ds.room.density_bitfield(128, 1.0)).to(dev))
+tr = Trainer("probe", None, net, stage="nerf", device=dev, iters=1000, update_extra_interval=10 ** 9)
+tr.global_step = 1
+batches = [ds.batch() for _ in range(8)]
+for i in range(8):
+    l0 = float(tr.train_one_step(batches[i % 8])) if i == 0 else l0
+    tr.train_one_step(batches[i % 8])
+torch.cuda.synchronize()
+steps = 40
+t0 = time.perf_counter(); n = 0
+for i in range(steps):
+    l = tr.train_one_step(batches[i % 8]); n += int(net.step_counter[(net.local_step - 1) % 16, 0])
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / steps
+print(f"nerf train step {dt*1e3:.3f} ms, {n/steps:.0f} samples/step, {n/steps/dt/1e6:.2f} Msamples/s, loss {l0:.4f} -> {float(l):.4f}")
+net.density_grid.zero_()
+for i in range(4):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    net.update_extra_state()
+    torch.cuda.synchronize()
+    print(f"update_extra_state #{i} (full 128^3): {(time.perf_counter()-t0)*1e3:.2f} ms  mean_density {net.mean_density:.4f}")
