@@ -43,38 +43,38 @@ __global__ void __launch_bounds__(256) k_grid_fwd(const float* __restrict__ x, c
 // their rows are equal or adjacent (x is the fastest index for dense AND hashed levels), atomics of one
 // instruction fall into few 128-B lines, and runs of EQUAL rows are first summed inside the wave by a
 // segmented scan so that only the last lane of a run issues the atomic (level 0: ~37 samples per cell).
-__device__ __forceinline__ void run_reduce_atomic(float* __restrict__ gemb, uint32_t row, bool valid, float vx,
-                                                  float vy) {
+// Lane layout: 4 lanes per sample = (x side xb) x (feature f); a wave holds 16 consecutive samples of
+// ONE level.  For a (y,z) corner the four lanes of a sample address 2 rows x 2 features; x-neighbour rows
+// are adjacent 15 times out of 16 (x is the fastest index in dense and hashed levels), so the four
+// atomics of one instruction fall into one 16-byte piece of one line instead of four separate
+// instructions each touching its own line.  Equal addresses of consecutive samples (same cell) are
+// first summed inside the wave (segmented scan over lanes 4 apart); only the last lane of a run issues
+// the atomic.
+__device__ __forceinline__ void run_reduce_atomic4(float* __restrict__ gemb, uint32_t addr, bool valid, float v) {
   const int lane = threadIdx.x & 63;
-  const uint32_t key = valid ? row : 0xFFFFFFFFu - (uint32_t)lane;     // invalid lanes never join a run
-  const uint32_t prev = __shfl_up(key, 1, 64);
-  const uint32_t next = __shfl_down(key, 1, 64);
-  bool head = (lane == 0) || (prev != key);         // first lane of a run of equal rows
+  const uint32_t key = valid ? addr : 0xFFFFFFFFu - (uint32_t)lane;     // invalid lanes never join a run
+  const uint32_t prev = __shfl_up(key, 4, 64);
+  const uint32_t next = __shfl_down(key, 4, 64);
+  bool head = (lane < 4) || (prev != key);          // first sample of a run of equal addresses
 #pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {                // segmented inclusive scan (head flags stop the carry)
-    const float ux = __shfl_up(vx, d, 64), uy = __shfl_up(vy, d, 64);
+  for (int d = 4; d < 64; d <<= 1) {                // segmented inclusive scan along lanes 4 apart
+    const float u = __shfl_up(v, d, 64);
     const bool uh = __shfl_up((int)head, d, 64) != 0;
     if (lane >= d && !head) {
-      vx += ux;
-      vy += uy;
+      v += u;
       head = uh;
     }
   }
-  const bool tail = (lane == 63) || (next != key);
-  if (valid && tail && (vx != 0.0f || vy != 0.0f)) {
-    float* p = gemb + 2 * (size_t)row;
-    atomicAdd(p, vx);
-    atomicAdd(p + 1, vy);
-  }
+  const bool tail = (lane >= 60) || (next != key);
+  if (valid && tail && v != 0.0f) atomicAdd(gemb + addr, v);
 }
 
-// `order` (nullable): a permutation of the samples; lane m processes sample order[m].  Passing the
-// samples' Morton order makes neighbouring lanes neighbours in SPACE for every level (not only along a
-// ray), which lengthens the equal-row runs and makes the remaining atomics address-adjacent.
-__global__ void __launch_bounds__(256) k_grid_bwd(const float* __restrict__ x, const float2* __restrict__ gout,
+// `order` (nullable): a permutation of the samples; sample slot m processes sample order[m].
+__global__ void __launch_bounds__(256) k_grid_bwd(const float* __restrict__ x, const float* __restrict__ gout,
                                                   const int32_t* __restrict__ order, GridDesc G, int64_t M, float bound,
                                                   float* __restrict__ gemb) {
-  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t m = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+  const int sub = threadIdx.x & 3, xb = sub >> 1, f = sub & 1;
   const int l = blockIdx.y;
   const int L = G.num_levels;
   const bool valid = m < M;
@@ -86,12 +86,14 @@ __global__ void __launch_bounds__(256) k_grid_bwd(const float* __restrict__ x, c
   const float x2 = (x[mc * 3 + 2] + bound) / rb;
   Cell c;
   locate(G, l, x0, x1, x2, c);
-  const float2 g = valid ? gout[mc * L + l] : make_float2(0.f, 0.f);
+  const float g = valid ? gout[(mc * L + l) * 2 + f] : 0.f;
   const uint32_t base = G.offsets[l];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
+  for (int yz = 0; yz < 4; ++yz) {
+    const int k = xb | (yz << 1);                   // corner: bit 0 = x side, bits 1,2 = y, z sides
     const float w = corner_weight(c, k);
-    run_reduce_atomic(gemb, base + corner_index(G, l, c, k), valid, w * g.x, w * g.y);
+    const uint32_t row = base + corner_index(G, l, c, k);
+    run_reduce_atomic4(gemb, 2u * row + (uint32_t)f, valid, w * g);
   }
 }
 
@@ -268,9 +270,9 @@ int inr_grid_encode_backward_ordered(const float* x, const float* grad_out, cons
   if (rc) return rc;
   INR_REQUIRE(((uintptr_t)grad_out & 7) == 0, "grad_out must be 8-byte aligned");
   if (M == 0) return INR_OK;
-  const dim3 grid(blocks_for(M, 256), (unsigned)G.num_levels);
-  k_grid_bwd<<<grid, 256, 0, as_stream(s)>>>(x, reinterpret_cast<const float2*>(grad_out), order, G, M, bound,
-                                             grad_embeddings);
+  INR_REQUIRE((uint64_t)desc->offsets[desc->num_levels] * 2ull < (1ull << 32), "table too large for 32-bit element offsets");
+  const dim3 grid(blocks_for(M * 4, 256), (unsigned)G.num_levels);
+  k_grid_bwd<<<grid, 256, 0, as_stream(s)>>>(x, grad_out, order, G, M, bound, grad_embeddings);
   return check_launch("grid_encode_backward");
 }
 
