@@ -188,7 +188,7 @@ __global__ void k_adam_tail(float* p, const float* g, float* m, float* v, int64_
 // (v_mfma_f32_16x16x4_f32: exact fp32, k = 4 samples per instruction) and adds it to dW with
 // address-adjacent atomics at the end (split-K over ~1000 waves).
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr int kWgradSlab = 256;   // samples per wave
+constexpr int kWgradSlab = 256;   // samples per wave (the final 64x64 atomics per wave bound how small a slab pays)
 
 __global__ void __launch_bounds__(256) k_linear_wgrad(const float* __restrict__ x, const float* __restrict__ gy,
                                                       int64_t M, int n_in, int n_out, float* __restrict__ gw) {
@@ -203,21 +203,29 @@ __global__ void __launch_bounds__(256) k_linear_wgrad(const float* __restrict__ 
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int64_t m_end = min(M, m0 + kWgradSlab);
-  for (int64_t m = m0; m < m_end; m += 4) {
-    const int64_t row = m + q;                       // k-slot q of this step
-    const bool rv = row < m_end;
-    float av[4], bv[4];
+  // the slab is processed in groups of 4 k-steps (16 samples): all 32 loads of a group are issued
+  // before its 64 MFMAs, so the loop is not a chain of dependent load -> MFMA round trips
+  for (int64_t mg = m0; mg < m_end; mg += 16) {
+    float av[4][4], bv[4][4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int o = 16 * t + j, i = 16 * t + j;
-      av[t] = (rv && o < n_out) ? gy[row * n_out + o] : 0.f;      // A[i = out][k = sample]
-      bv[t] = (rv && i < n_in) ? x[row * n_in + i] : 0.f;         // B[k = sample][j = in]
+    for (int u = 0; u < 4; ++u) {
+      const int64_t row = mg + 4 * u + q;            // k-slot q of k-step u
+      const bool rv = row < m_end;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int c = 16 * t + j;
+        av[u][t] = (rv && c < n_out) ? gy[row * n_out + c] : 0.f;      // A[i = out][k = sample]
+        bv[u][t] = (rv && c < n_in) ? x[row * n_in + c] : 0.f;         // B[k = sample][j = in]
+      }
     }
 #pragma unroll
-    for (int ot = 0; ot < 4; ++ot)
+    for (int u = 0; u < 4; ++u)
 #pragma unroll
-      for (int it = 0; it < 4; ++it)
-        if (ot < n_ot && it < n_it) acc[ot][it] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ot], bv[it], acc[ot][it], 0, 0, 0);
+      for (int ot = 0; ot < 4; ++ot)
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+          if (ot < n_ot && it < n_it)
+            acc[ot][it] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][ot], bv[u][it], acc[ot][it], 0, 0, 0);
   }
 #pragma unroll
   for (int ot = 0; ot < 4; ++ot)
