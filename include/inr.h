@@ -127,17 +127,20 @@ int inr_composite_rays(int64_t n_alive, int32_t n_step, int32_t* rays_alive, flo
 int inr_compact_alive(const int32_t* rays_alive, int64_t n_alive, int32_t* out, int32_t* n_out,
                       inr_stream_t s);
 
-/* ---- compositing for training (replaces raymarching.composite_rays_train fwd/bwd, a12/a13) */
+/* ---- compositing for training (replaces raymarching.composite_rays_train fwd/bwd, a12/a13) ----
+ * weights [M] (nullable unless extra is given): receives the per-sample compositing weight
+ * w = alpha * T (0 behind the termination point); the K-channel forward/backward use it.          */
 int inr_composite_rays_train_forward(const float* sigmas, const float* rgbs, const float* deltas,
                                      const int32_t* rays, int64_t N, float T_thresh,
                                      const float* extra /*[M,K] nullable*/, int32_t K,
                                      float* weights_sum, float* depth, float* image,
-                                     float* extra_out /*[N,K]*/, inr_stream_t s);
+                                     float* extra_out /*[N,K]*/, float* weights /*[M]*/, inr_stream_t s);
 int inr_composite_rays_train_backward(const float* grad_weights_sum, const float* grad_image,
                                       const float* grad_extra_out /*nullable*/, const float* sigmas,
                                       const float* rgbs, const float* extra, const float* deltas,
                                       const int32_t* rays, const float* weights_sum,
-                                      const float* image, int64_t N, float T_thresh, int32_t K,
+                                      const float* image, const float* weights /*[M] from forward*/,
+                                      int64_t N, float T_thresh, int32_t K,
                                       float* grad_sigmas, float* grad_rgbs,
                                       float* grad_extra /*[M,K] nullable*/, inr_stream_t s);
 

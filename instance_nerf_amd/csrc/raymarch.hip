@@ -353,55 +353,106 @@ __global__ void __launch_bounds__(kRayBlock) k_alive_scatter(const int32_t* __re
 }
 
 // ------------------------------------------------------------------------------------------
-// a12: training compositing, one lane per ray (sequential scan along the ray)
+// a12: training compositing.  One WAVE per ray: a training batch has few rays (4096) with ~50-200
+// samples each, so one-lane-per-ray loops are pure latency (100+ us for 0.2 M samples).  Here the 64
+// lanes take 64 consecutive samples (coalesced loads), the transmittance is an inclusive product scan
+// across the wave, sums are wave reductions, and the per-sample weights w = alpha*T (0 behind the
+// termination point) are stored once so that the K-channel kernels and the backward need no scan of
+// their own.  Rounding differs from a sequential loop by ~1 ulp per scan step (tree order).
+__device__ __forceinline__ float wave_incl_prod(float v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const float u = __shfl_up(v, d, 64);
+    if (lane >= d) v *= u;
+  }
+  return v;
+}
+__device__ __forceinline__ float wave_incl_sum(float v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const float u = __shfl_up(v, d, 64);
+    if (lane >= d) v += u;
+  }
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
+
 __global__ void __launch_bounds__(kRayBlock) k_composite_train_fwd(const float* __restrict__ sigmas,
                                                                    const float* __restrict__ rgbs,
                                                                    const float* __restrict__ deltas,
                                                                    const int32_t* __restrict__ rays, int64_t N,
                                                                    float T_thresh, float* __restrict__ weights_sum,
                                                                    float* __restrict__ depth,
-                                                                   float* __restrict__ image) {
-  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N) return;
-  const int32_t rid = rays[n * 3], off = rays[n * 3 + 1], cnt = rays[n * 3 + 2];
-  float T = 1.0f, r = 0, g = 0, b = 0, ws = 0, t = 0, d = 0;
-  for (int s = 0; s < cnt; ++s) {
-    const int64_t i = (int64_t)off + s;
-    const float2 dl = reinterpret_cast<const float2*>(deltas)[i];
-    const float alpha = 1.0f - expf(-sigmas[i] * dl.x);
-    const float w = alpha * T;
-    r += w * rgbs[i * 3]; g += w * rgbs[i * 3 + 1]; b += w * rgbs[i * 3 + 2];
-    t += dl.y;
-    d += w * t;
-    ws += w;
-    T *= 1.0f - alpha;
-    if (T < T_thresh) break;
-  }
-  weights_sum[rid] = ws; depth[rid] = d;
-  image[rid * 3] = r; image[rid * 3 + 1] = g; image[rid * 3 + 2] = b;
-}
-
-// a13: K extra channels (instance logits), one wave per ray, lane = channel (coalesced rows)
-__global__ void __launch_bounds__(kRayBlock) k_composite_train_extra_fwd(const float* __restrict__ sigmas,
-                                                                         const float* __restrict__ deltas,
-                                                                         const float* __restrict__ extra,
-                                                                         const int32_t* __restrict__ rays, int64_t N,
-                                                                         float T_thresh, int K,
-                                                                         float* __restrict__ extra_out) {
+                                                                   float* __restrict__ image,
+                                                                   float* __restrict__ wbuf) {
   const int64_t n = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
   if (n >= N) return;
   const int32_t rid = rays[n * 3], off = rays[n * 3 + 1], cnt = rays[n * 3 + 2];
-  float T = 1.0f, acc = 0.0f;
-  for (int s = 0; s < cnt; ++s) {
-    const int64_t i = (int64_t)off + s;
-    const float alpha = 1.0f - expf(-sigmas[i] * deltas[i * 2]);
-    const float w = alpha * T;
-    if (lane < K) acc += w * extra[i * K + lane];
-    T *= 1.0f - alpha;
-    if (T < T_thresh) break;
+  float T_carry = 1.0f, t_carry = 0.0f, r = 0, g = 0, b = 0, ws = 0, dsum = 0;
+  for (int base = 0; base < cnt; base += 64) {
+    const bool act = base + lane < cnt;
+    const int64_t i = (int64_t)off + base + lane;
+    float alpha = 0.f, dy = 0.f, cr = 0.f, cg = 0.f, cb = 0.f;
+    if (act) {
+      const float2 dl = reinterpret_cast<const float2*>(deltas)[i];
+      alpha = 1.0f - expf(-sigmas[i] * dl.x);
+      dy = dl.y;
+      cr = rgbs[i * 3]; cg = rgbs[i * 3 + 1]; cb = rgbs[i * 3 + 2];
+    }
+    const float P = wave_incl_prod(1.0f - alpha, lane);
+    float Pprev = __shfl_up(P, 1, 64);
+    if (lane == 0) Pprev = 1.0f;
+    const float T = T_carry * Pprev;                 // transmittance before this sample
+    const bool used = act && (T >= T_thresh || (base + lane) == 0);
+    const float w = used ? alpha * T : 0.0f;
+    const float t = t_carry + wave_incl_sum(dy, lane);
+    r += w * cr; g += w * cg; b += w * cb; ws += w; dsum += w * t;
+    if (wbuf && act) wbuf[i] = w;
+    T_carry *= __shfl(P, 63, 64);
+    t_carry = __shfl(t, 63, 64);
+    if (T_carry < T_thresh) {                        // wave-uniform: the rest of the ray is unused
+      if (wbuf)
+        for (int64_t k = (int64_t)base + 64 + lane; k < cnt; k += 64) wbuf[(int64_t)off + k] = 0.0f;
+      break;
+    }
   }
-  if (lane < K) extra_out[(int64_t)rid * K + lane] = acc;
+  r = wave_sum(r); g = wave_sum(g); b = wave_sum(b); ws = wave_sum(ws); dsum = wave_sum(dsum);
+  if (lane == 0) {
+    weights_sum[rid] = ws; depth[rid] = dsum;
+    image[rid * 3] = r; image[rid * 3 + 1] = g; image[rid * 3 + 2] = b;
+  }
+}
+
+// a13: K extra channels (instance logits): out[ray][ch] = sum_i w_i * extra[i][ch]; one wave per ray,
+// lane = channel (coalesced 4K-byte rows), no scan (weights come from k_composite_train_fwd)
+__global__ void __launch_bounds__(kRayBlock) k_composite_train_extra_fwd(const float* __restrict__ wbuf,
+                                                                         const float* __restrict__ extra,
+                                                                         const int32_t* __restrict__ rays, int64_t N,
+                                                                         int K, float* __restrict__ extra_out) {
+  const int64_t n = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (n >= N) return;
+  const int32_t rid = rays[n * 3], off = rays[n * 3 + 1], cnt = rays[n * 3 + 2];
+  float acc = 0.0f;
+  if (lane < K) {
+    int s = 0;
+    for (; s + 4 <= cnt; s += 4) {                   // 4 independent row loads in flight
+      const int64_t i = (int64_t)off + s;
+      const float e0 = extra[i * K + lane], e1 = extra[(i + 1) * K + lane], e2 = extra[(i + 2) * K + lane],
+                  e3 = extra[(i + 3) * K + lane];
+      acc += wbuf[i] * e0;
+      acc += wbuf[i + 1] * e1;
+      acc += wbuf[i + 2] * e2;
+      acc += wbuf[i + 3] * e3;
+    }
+    for (; s < cnt; ++s) acc += wbuf[(int64_t)off + s] * extra[((int64_t)off + s) * K + lane];
+    extra_out[(int64_t)rid * K + lane] = acc;
+  }
 }
 
 __global__ void __launch_bounds__(kRayBlock) k_composite_train_bwd(
@@ -409,55 +460,60 @@ __global__ void __launch_bounds__(kRayBlock) k_composite_train_bwd(
     const float* __restrict__ rgbs, const float* __restrict__ deltas, const int32_t* __restrict__ rays,
     const float* __restrict__ weights_sum, const float* __restrict__ image, int64_t N, float T_thresh,
     float* __restrict__ grad_sigmas, float* __restrict__ grad_rgbs) {
-  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t n = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
   if (n >= N) return;
   const int32_t rid = rays[n * 3], off = rays[n * 3 + 1], cnt = rays[n * 3 + 2];
   const float gr = g_img[rid * 3], gg = g_img[rid * 3 + 1], gb = g_img[rid * 3 + 2];
   const float gw = g_ws ? g_ws[rid] : 0.0f;
   const float rf = image[rid * 3], gf = image[rid * 3 + 1], bf = image[rid * 3 + 2];
   const float wsf = weights_sum[rid];
-  float T = 1.0f, r = 0, g = 0, b = 0;
-  int s = 0;
-  for (; s < cnt; ++s) {
-    const int64_t i = (int64_t)off + s;
-    const float d0 = deltas[i * 2];
-    const float alpha = 1.0f - expf(-sigmas[i] * d0);
-    const float w = alpha * T;
-    const float cr = rgbs[i * 3], cg = rgbs[i * 3 + 1], cb = rgbs[i * 3 + 2];
-    r += w * cr; g += w * cg; b += w * cb;
-    T *= 1.0f - alpha;
-    grad_rgbs[i * 3] = gr * w; grad_rgbs[i * 3 + 1] = gg * w; grad_rgbs[i * 3 + 2] = gb * w;
-    grad_sigmas[i] = d0 * (gr * (T * cr - (rf - r)) + gg * (T * cg - (gf - g)) + gb * (T * cb - (bf - b)) +
-                           gw * (1.0f - wsf));
-    if (T < T_thresh) { ++s; break; }
-  }
-  for (; s < cnt; ++s) {  // samples behind the termination point get zero gradient
-    const int64_t i = (int64_t)off + s;
-    grad_rgbs[i * 3] = 0.f; grad_rgbs[i * 3 + 1] = 0.f; grad_rgbs[i * 3 + 2] = 0.f;
-    grad_sigmas[i] = 0.f;
+  float T_carry = 1.0f, cr_carry = 0.f, cg_carry = 0.f, cb_carry = 0.f;
+  bool dead = false;                                  // wave-uniform: termination point passed
+  for (int base = 0; base < cnt; base += 64) {
+    const bool act = base + lane < cnt;
+    const int64_t i = (int64_t)off + base + lane;
+    if (dead) {
+      if (act) { grad_sigmas[i] = 0.f; grad_rgbs[i * 3] = 0.f; grad_rgbs[i * 3 + 1] = 0.f; grad_rgbs[i * 3 + 2] = 0.f; }
+      continue;
+    }
+    float alpha = 0.f, d0 = 0.f, cr = 0.f, cg = 0.f, cb = 0.f;
+    if (act) {
+      d0 = deltas[i * 2];
+      alpha = 1.0f - expf(-sigmas[i] * d0);
+      cr = rgbs[i * 3]; cg = rgbs[i * 3 + 1]; cb = rgbs[i * 3 + 2];
+    }
+    const float P = wave_incl_prod(1.0f - alpha, lane);
+    float Pprev = __shfl_up(P, 1, 64);
+    if (lane == 0) Pprev = 1.0f;
+    const float T = T_carry * Pprev, Tn = T_carry * P;     // before / after this sample
+    const bool used = act && (T >= T_thresh || (base + lane) == 0);
+    const float w = used ? alpha * T : 0.0f;
+    const float ar = cr_carry + wave_incl_sum(w * cr, lane);   // colour accumulated up to and including i
+    const float ag = cg_carry + wave_incl_sum(w * cg, lane);
+    const float ab = cb_carry + wave_incl_sum(w * cb, lane);
+    if (act) {
+      grad_rgbs[i * 3] = gr * w; grad_rgbs[i * 3 + 1] = gg * w; grad_rgbs[i * 3 + 2] = gb * w;
+      grad_sigmas[i] = used ? d0 * (gr * (Tn * cr - (rf - ar)) + gg * (Tn * cg - (gf - ag)) + gb * (Tn * cb - (bf - ab)) +
+                                    gw * (1.0f - wsf))
+                            : 0.0f;
+    }
+    T_carry *= __shfl(P, 63, 64);
+    cr_carry = __shfl(ar, 63, 64); cg_carry = __shfl(ag, 63, 64); cb_carry = __shfl(ab, 63, 64);
+    if (T_carry < T_thresh) dead = true;
   }
 }
 
 __global__ void __launch_bounds__(kRayBlock) k_composite_train_extra_bwd(
-    const float* __restrict__ g_extra_out, const float* __restrict__ sigmas, const float* __restrict__ deltas,
-    const int32_t* __restrict__ rays, int64_t N, float T_thresh, int K, float* __restrict__ grad_extra) {
+    const float* __restrict__ g_extra_out, const float* __restrict__ wbuf, const int32_t* __restrict__ rays, int64_t N,
+    int K, float* __restrict__ grad_extra) {
   const int64_t n = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
   if (n >= N) return;
   const int32_t rid = rays[n * 3], off = rays[n * 3 + 1], cnt = rays[n * 3 + 2];
-  const float g = lane < K ? g_extra_out[(int64_t)rid * K + lane] : 0.0f;
-  float T = 1.0f;
-  int s = 0;
-  for (; s < cnt; ++s) {
-    const int64_t i = (int64_t)off + s;
-    const float alpha = 1.0f - expf(-sigmas[i] * deltas[i * 2]);
-    const float w = alpha * T;
-    if (lane < K) grad_extra[i * K + lane] = w * g;
-    T *= 1.0f - alpha;
-    if (T < T_thresh) { ++s; break; }
-  }
-  for (; s < cnt; ++s)
-    if (lane < K) grad_extra[((int64_t)off + s) * K + lane] = 0.0f;
+  if (lane >= K) return;
+  const float g = g_extra_out[(int64_t)rid * K + lane];
+  for (int s = 0; s < cnt; ++s) grad_extra[((int64_t)off + s) * K + lane] = wbuf[(int64_t)off + s] * g;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -764,38 +820,39 @@ int inr_compact_alive(const int32_t* rays_alive, int64_t n_alive, int32_t* out, 
 
 int inr_composite_rays_train_forward(const float* sigmas, const float* rgbs, const float* deltas, const int32_t* rays,
                                      int64_t N, float T_thresh, const float* extra, int32_t K, float* weights_sum,
-                                     float* depth, float* image, float* extra_out, inr_stream_t s) {
+                                     float* depth, float* image, float* extra_out, float* weights, inr_stream_t s) {
   INR_REQUIRE(rays && weights_sum && depth && image && N >= 0, "bad argument");
-  INR_REQUIRE(!extra || (extra_out && K > 0 && K <= 64), "extra needs extra_out and 0 < K <= 64");
+  INR_REQUIRE(!extra || (extra_out && weights && K > 0 && K <= 64), "extra needs extra_out, weights and 0 < K <= 64");
   if (N == 0) return INR_OK;
   INR_REQUIRE(sigmas && rgbs && deltas, "null sample arrays");
   INR_REQUIRE(((uintptr_t)deltas & 7) == 0, "deltas must be 8-byte aligned");
   hipStream_t st = as_stream(s);
-  k_composite_train_fwd<<<blocks_for(N, kRayBlock), kRayBlock, 0, st>>>(sigmas, rgbs, deltas, rays, N, T_thresh,
-                                                                        weights_sum, depth, image);
+  k_composite_train_fwd<<<blocks_for(N * 64, kRayBlock), kRayBlock, 0, st>>>(sigmas, rgbs, deltas, rays, N, T_thresh,
+                                                                             weights_sum, depth, image, weights);
   if (extra)
-    k_composite_train_extra_fwd<<<blocks_for(N * 64, kRayBlock), kRayBlock, 0, st>>>(sigmas, deltas, extra, rays, N,
-                                                                                     T_thresh, K, extra_out);
+    k_composite_train_extra_fwd<<<blocks_for(N * 64, kRayBlock), kRayBlock, 0, st>>>(weights, extra, rays, N, K,
+                                                                                     extra_out);
   return check_launch("composite_rays_train_forward");
 }
 
 int inr_composite_rays_train_backward(const float* grad_weights_sum, const float* grad_image,
                                       const float* grad_extra_out, const float* sigmas, const float* rgbs,
                                       const float* extra, const float* deltas, const int32_t* rays,
-                                      const float* weights_sum, const float* image, int64_t N, float T_thresh,
-                                      int32_t K, float* grad_sigmas, float* grad_rgbs, float* grad_extra,
-                                      inr_stream_t s) {
+                                      const float* weights_sum, const float* image, const float* weights, int64_t N,
+                                      float T_thresh, int32_t K, float* grad_sigmas, float* grad_rgbs,
+                                      float* grad_extra, inr_stream_t s) {
   (void)extra;
   INR_REQUIRE(grad_image && rays && weights_sum && image && grad_sigmas && grad_rgbs && N >= 0, "bad argument");
-  INR_REQUIRE(!grad_extra_out || (grad_extra && K > 0 && K <= 64), "grad_extra_out needs grad_extra and 0 < K <= 64");
+  INR_REQUIRE(!grad_extra_out || (grad_extra && weights && K > 0 && K <= 64),
+              "grad_extra_out needs grad_extra, weights and 0 < K <= 64");
   if (N == 0) return INR_OK;
   hipStream_t st = as_stream(s);
-  k_composite_train_bwd<<<blocks_for(N, kRayBlock), kRayBlock, 0, st>>>(grad_weights_sum, grad_image, sigmas, rgbs,
-                                                                        deltas, rays, weights_sum, image, N, T_thresh,
-                                                                        grad_sigmas, grad_rgbs);
+  k_composite_train_bwd<<<blocks_for(N * 64, kRayBlock), kRayBlock, 0, st>>>(grad_weights_sum, grad_image, sigmas,
+                                                                             rgbs, deltas, rays, weights_sum, image, N,
+                                                                             T_thresh, grad_sigmas, grad_rgbs);
   if (grad_extra_out)
-    k_composite_train_extra_bwd<<<blocks_for(N * 64, kRayBlock), kRayBlock, 0, st>>>(grad_extra_out, sigmas, deltas,
-                                                                                     rays, N, T_thresh, K, grad_extra);
+    k_composite_train_extra_bwd<<<blocks_for(N * 64, kRayBlock), kRayBlock, 0, st>>>(grad_extra_out, weights, rays, N,
+                                                                                     K, grad_extra);
   return check_launch("composite_rays_train_backward");
 }
 

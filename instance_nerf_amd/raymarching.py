@@ -217,11 +217,12 @@ class _CompositeRaysTrain(torch.autograd.Function):
         depth = torch.zeros(N, dtype=F32, device=dev)
         image = torch.zeros(N, 3, dtype=F32, device=dev)
         extra_out = torch.zeros(N, K, dtype=F32, device=dev) if K else None
+        wbuf = torch.zeros(sigmas.shape[0], dtype=F32, device=dev) if K else None     # rows of dropped rays stay 0
         check(lib.inr_composite_rays_train_forward(
             ptr(sigmas, F32, "sigmas"), ptr(rgbs, F32, "rgbs"), ptr(deltas, F32, "deltas"), ptr(rays, I32, "rays"),
             N, float(T_thresh), ptr(extra, F32, "extra", allow_none=True), K, ptr(ws), ptr(depth), ptr(image),
-            ptr(extra_out, allow_none=True), stream_ptr()), "composite_rays_train_forward")
-        ctx.save_for_backward(sigmas, rgbs, extra, deltas, rays, ws, image)
+            ptr(extra_out, allow_none=True), ptr(wbuf, allow_none=True), stream_ptr()), "composite_rays_train_forward")
+        ctx.save_for_backward(sigmas, rgbs, extra, deltas, rays, ws, image, wbuf)
         ctx.T_thresh = T_thresh
         ctx.K = K
         ctx.mark_non_differentiable(depth)
@@ -232,7 +233,7 @@ class _CompositeRaysTrain(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_ws, g_depth, g_image, g_extra=None):
         lib = _lib.load()
-        sigmas, rgbs, extra, deltas, rays, ws, image = ctx.saved_tensors
+        sigmas, rgbs, extra, deltas, rays, ws, image, wbuf = ctx.saved_tensors
         N = rays.shape[0]
         K = ctx.K
         dev = sigmas.device
@@ -248,8 +249,9 @@ class _CompositeRaysTrain(torch.autograd.Function):
             g_extra = None
         check(lib.inr_composite_rays_train_backward(
             ptr(g_ws), ptr(g_image), ptr(g_extra, allow_none=True), ptr(sigmas), ptr(rgbs),
-            ptr(extra, allow_none=True), ptr(deltas), ptr(rays), ptr(ws), ptr(image), N, float(ctx.T_thresh), K,
-            ptr(gs), ptr(gc), ptr(ge, allow_none=True), stream_ptr()), "composite_rays_train_backward")
+            ptr(extra, allow_none=True), ptr(deltas), ptr(rays), ptr(ws), ptr(image), ptr(wbuf, allow_none=True), N,
+            float(ctx.T_thresh), K, ptr(gs), ptr(gc), ptr(ge, allow_none=True), stream_ptr()),
+            "composite_rays_train_backward")
         return gs, gc, ge, None, None, None
 
 
