@@ -78,19 +78,23 @@ int inr_packbits(const float* grid, int64_t n_bytes, float thresh, uint8_t* bitf
  * order.  Call inr_march_rays_train_count first (fills counts/offsets and
  * counter[0] = total samples, counter[1] = N), size the outputs (M rows), then
  * inr_march_rays_train_write.  A ray whose offset + count > M is dropped (its
- * rays row is still written).  workspace: inr_march_workspace_bytes(N).        */
-int64_t inr_march_workspace_bytes(int64_t N);
+ * rays row is still written).  workspace: inr_march_workspace_bytes(N, sample_cap), 8-byte aligned.
+ * sample_cap > 0: the count pass records (t, delta) of each ray's first sample_cap samples in the
+ * workspace and the write pass replays them instead of marching again (rays with more samples are
+ * re-marched); pass the SAME workspace and sample_cap to the write call.  Results are identical.      */
+int64_t inr_march_workspace_bytes(int64_t N, int32_t sample_cap);
 int inr_march_rays_train_count(const float* rays_o, const float* rays_d, const uint8_t* bitfield,
                                float bound, float dt_gamma, int32_t max_steps, int64_t N,
                                int32_t cascade, int32_t H, const float* nears, const float* fars,
                                const float* noises /*nullable*/, int32_t* rays /*[N,3]*/,
-                               int32_t* counter /*[2]*/, void* workspace, inr_stream_t s);
+                               int32_t* counter /*[2]*/, void* workspace, int32_t sample_cap, inr_stream_t s);
 int inr_march_rays_train_write(const float* rays_o, const float* rays_d, const uint8_t* bitfield,
                                float bound, float dt_gamma, int32_t max_steps, int64_t N,
                                int32_t cascade, int32_t H, int64_t M, const float* nears,
                                const float* fars, const float* noises /*nullable*/,
                                const int32_t* rays /*[N,3] from _count*/, float* xyzs /*[M,3]*/,
-                               float* dirs /*[M,3]*/, float* deltas /*[M,2]*/, inr_stream_t s);
+                               float* dirs /*[M,3]*/, float* deltas /*[M,2]*/, const void* workspace,
+                               int32_t sample_cap, inr_stream_t s);
 
 /* ---- fused full-frame inference path (replaces the alive-ray loop of NeRFRenderer.run_cuda, a5) ----
  * Same counting pass as training (inr_march_rays_train_count), then samples are written in the
@@ -104,7 +108,8 @@ int inr_march_rays_patch_write(const float* rays_o, const float* rays_d, const u
                                int32_t cascade, int32_t H, int64_t M, const float* nears,
                                const float* fars, const float* noises /*nullable*/,
                                const int32_t* rays /*[N,3] from inr_march_rays_train_count*/,
-                               float* xyzs, float* dirs, float* deltas, inr_stream_t s);
+                               float* xyzs, float* dirs, float* deltas, const void* workspace,
+                               int32_t sample_cap, inr_stream_t s);
 int inr_composite_rays_patch_forward(const float* sigmas, const float* rgbs, const float* deltas,
                                      const int32_t* rays, int64_t N, int64_t M, float T_thresh,
                                      const float* extra /*[M,K] nullable*/, int32_t K,
@@ -123,7 +128,7 @@ int inr_composite_rays(int64_t n_alive, int32_t n_step, int32_t* rays_alive, flo
                        const float* extra /*[n_alive*n_step,K] nullable*/, float* extra_acc /*[N,K]*/,
                        int32_t K, inr_stream_t s);
 /* order-preserving compaction of rays_alive >= 0; n_out (device int32[2]) = {survivors, n_alive};
- * `out` needs room for n_alive + inr_march_workspace_bytes(n_alive)/4 int32 (list first, scratch after) */
+ * `out` needs room for n_alive + inr_march_workspace_bytes(n_alive, 0)/4 int32 (list first, scratch after) */
 int inr_compact_alive(const int32_t* rays_alive, int64_t n_alive, int32_t* out, int32_t* n_out,
                       inr_stream_t s);
 

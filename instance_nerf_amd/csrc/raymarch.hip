@@ -98,7 +98,7 @@ __device__ __forceinline__ float step_dt(const MarchParams& P, float t) {
   return clampf(t * P.dt_gamma, P.dt_min, P.dt_max);
 }
 
-// Marches from t until t >= far or max_emit samples were emitted.  emit(px,py,pz,dt,delta).
+// Marches from t until t >= far or max_emit samples were emitted.  emit(px,py,pz,dt,delta,t).
 template <class Emit>
 __device__ __forceinline__ int march_ray(const MarchParams& P, const Ray& r, float t, float far,
                                          int max_emit, Emit&& emit) {
@@ -122,7 +122,7 @@ __device__ __forceinline__ int march_ray(const MarchParams& P, const Ray& r, flo
     const bool occ = (P.bits[idx >> 3] >> (idx & 7)) & 1;
     if (occ) {
       const float tn = t + dt;
-      emit(px, py, pz, dt, tn - last_t);
+      emit(px, py, pz, dt, tn - last_t, t);
       t = tn;
       last_t = tn;
       ++n;
@@ -153,14 +153,26 @@ __global__ void __launch_bounds__(kRayBlock) k_march_count(MarchParams P, const 
                                                            const float* __restrict__ fars,
                                                            const float* __restrict__ noises,
                                                            int32_t* __restrict__ counts,
-                                                           int32_t* __restrict__ block_sums) {
+                                                           int32_t* __restrict__ block_sums,
+                                                           float2* __restrict__ cap_buf, int cap) {
   __shared__ int32_t wsum[kRayBlock / 64];
   const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   int cnt = 0;
   if (n < N) {
     const Ray r = load_ray(rays_o, rays_d, n);
     const float t0 = start_t(P, nears[n], noises ? noises[n] : 0.0f);
-    cnt = march_ray(P, r, t0, fars[n], max_steps, [](float, float, float, float, float) {});
+    if (cap > 0) {
+      // Record (t, delta) of the first `cap` samples of the ray: the write pass replays them (position and
+      // dt are pure functions of t, evaluated with the same operations) instead of marching a second time.
+      float2* row = cap_buf + n * cap;
+      int k = 0;
+      cnt = march_ray(P, r, t0, fars[n], max_steps, [&](float, float, float, float, float delta, float t) {
+        if (k < cap) row[k] = make_float2(t, delta);
+        ++k;
+      });
+    } else {
+      cnt = march_ray(P, r, t0, fars[n], max_steps, [](float, float, float, float, float, float) {});
+    }
     counts[n] = cnt;
   }
   const int incl = wave_inclusive_scan(cnt);
@@ -220,7 +232,23 @@ __global__ void __launch_bounds__(kRayBlock) k_finalize_offsets(const int32_t* _
   }
 }
 
-// pass 4: re-march and write the samples into their slots
+// Replays the first cnt (<= cap) recorded samples of a ray: emit(px,py,pz,dt,delta,t) with exactly the values
+// the march produced (same clamp(o + t*d) and step_dt(t) operations).
+template <class Emit>
+__device__ __forceinline__ void replay_ray(const MarchParams& P, const Ray& r, const float2* __restrict__ row, int cnt,
+                                           Emit&& emit) {
+  for (int k = 0; k < cnt; ++k) {
+    const float2 td = row[k];
+    const float t = td.x;
+    const float px = clampf(r.ox + t * r.dx, -P.bound, P.bound);
+    const float py = clampf(r.oy + t * r.dy, -P.bound, P.bound);
+    const float pz = clampf(r.oz + t * r.dz, -P.bound, P.bound);
+    emit(px, py, pz, step_dt(P, t), td.y, t);
+  }
+}
+
+// pass 4: write the samples into their slots (replay of the recorded samples, or a second march for rays
+// longer than the capture row)
 __global__ void __launch_bounds__(kRayBlock) k_march_write(MarchParams P, const float* __restrict__ rays_o,
                                                            const float* __restrict__ rays_d, int64_t N,
                                                            int64_t M, const float* __restrict__ nears,
@@ -228,21 +256,27 @@ __global__ void __launch_bounds__(kRayBlock) k_march_write(MarchParams P, const 
                                                            const float* __restrict__ noises,
                                                            const int32_t* __restrict__ rays,
                                                            float* __restrict__ xyzs, float* __restrict__ dirs,
-                                                           float* __restrict__ deltas) {
+                                                           float* __restrict__ deltas,
+                                                           const float2* __restrict__ cap_buf, int cap) {
   const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
   const int off = rays[n * 3 + 1];
   const int cnt = rays[n * 3 + 2];
   if (cnt == 0 || (int64_t)off + cnt > M) return;
   const Ray r = load_ray(rays_o, rays_d, n);
-  const float t0 = start_t(P, nears[n], noises ? noises[n] : 0.0f);
   int64_t i = off;
-  march_ray(P, r, t0, fars[n], cnt, [&](float px, float py, float pz, float dt, float delta) {
+  auto emit = [&](float px, float py, float pz, float dt, float delta, float) {
     xyzs[i * 3 + 0] = px; xyzs[i * 3 + 1] = py; xyzs[i * 3 + 2] = pz;
     dirs[i * 3 + 0] = r.dx; dirs[i * 3 + 1] = r.dy; dirs[i * 3 + 2] = r.dz;
     deltas[i * 2 + 0] = dt; deltas[i * 2 + 1] = delta;
     ++i;
-  });
+  };
+  if (cnt <= cap) {
+    replay_ray(P, r, cap_buf + n * cap, cnt, emit);
+  } else {
+    const float t0 = start_t(P, nears[n], noises ? noises[n] : 0.0f);
+    march_ray(P, r, t0, fars[n], cnt, emit);
+  }
 }
 
 // a5: inference march, up to n_step samples per live ray; buffers pre-zeroed by this kernel
@@ -263,7 +297,7 @@ __global__ void __launch_bounds__(kRayBlock) k_march_rays(MarchParams P, int64_t
     const Ray r = load_ray(rays_o, rays_d, ridx);
     int64_t i = base;
     written = march_ray(P, r, rays_t[ridx], fars[ridx], n_step,
-                        [&](float px, float py, float pz, float dt, float delta) {
+                        [&](float px, float py, float pz, float dt, float delta, float) {
                           xyzs[i * 3 + 0] = px; xyzs[i * 3 + 1] = py; xyzs[i * 3 + 2] = pz;
                           dirs[i * 3 + 0] = r.dx; dirs[i * 3 + 1] = r.dy; dirs[i * 3 + 2] = r.dz;
                           deltas[i * 2 + 0] = dt; deltas[i * 2 + 1] = delta;
@@ -572,7 +606,8 @@ __global__ void __launch_bounds__(kRayBlock) k_march_write_patch(MarchParams P, 
                                                                  const float* __restrict__ noises,
                                                                  const int32_t* __restrict__ rays,
                                                                  float* __restrict__ xyzs, float* __restrict__ dirs,
-                                                                 float* __restrict__ deltas) {
+                                                                 float* __restrict__ deltas,
+                                                                 const float2* __restrict__ cap_buf, int cap) {
   const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int off = n < N ? rays[n * 3 + 1] : 0;
   const int cnt = n < N ? rays[n * 3 + 2] : 0;
@@ -580,13 +615,18 @@ __global__ void __launch_bounds__(kRayBlock) k_march_write_patch(MarchParams P, 
   cur.init(cnt, off);                                   // all 64 lanes take part in the shuffles
   if (cnt == 0 || (int64_t)cur.S + cur.total() > M) return;   // a group that does not fit is dropped whole
   const Ray r = load_ray(rays_o, rays_d, n);
-  const float t0 = start_t(P, nears[n], noises ? noises[n] : 0.0f);
-  march_ray(P, r, t0, fars[n], cnt, [&](float px, float py, float pz, float dt, float delta) {
+  auto emit = [&](float px, float py, float pz, float dt, float delta, float) {
     const int64_t i = cur.next();
     xyzs[i * 3 + 0] = px; xyzs[i * 3 + 1] = py; xyzs[i * 3 + 2] = pz;
     dirs[i * 3 + 0] = r.dx; dirs[i * 3 + 1] = r.dy; dirs[i * 3 + 2] = r.dz;
     deltas[i * 2 + 0] = dt; deltas[i * 2 + 1] = delta;
-  });
+  };
+  if (cnt <= cap) {
+    replay_ray(P, r, cap_buf + n * cap, cnt, emit);
+  } else {
+    const float t0 = start_t(P, nears[n], noises ? noises[n] : 0.0f);
+    march_ray(P, r, t0, fars[n], cnt, emit);
+  }
 }
 
 // one lane per ray; the 16 lanes of a group walk k in lockstep, so slot ranks come from one ballot
@@ -709,24 +749,30 @@ int inr_packbits(const float* grid, int64_t n_bytes, float thresh, uint8_t* bitf
   return check_launch("packbits");
 }
 
-int64_t inr_march_workspace_bytes(int64_t N) {
+static int64_t ws_ints(int64_t N) {
   const int64_t nb = (N + kRayBlock - 1) / kRayBlock;
-  return (N + nb + 64) * (int64_t)sizeof(int32_t);
+  return ((N + nb + 64 + 1) / 2) * 2;     // even: the capture rows that follow are float2
+}
+int64_t inr_march_workspace_bytes(int64_t N, int32_t sample_cap) {
+  return ws_ints(N) * (int64_t)sizeof(int32_t) + N * (int64_t)(sample_cap > 0 ? sample_cap : 0) * (int64_t)sizeof(float2);
 }
 
 int inr_march_rays_train_count(const float* rays_o, const float* rays_d, const uint8_t* bitfield, float bound,
                                float dt_gamma, int32_t max_steps, int64_t N, int32_t cascade, int32_t H,
                                const float* nears, const float* fars, const float* noises, int32_t* rays,
-                               int32_t* counter, void* workspace, inr_stream_t s) {
+                               int32_t* counter, void* workspace, int32_t sample_cap, inr_stream_t s) {
   INR_REQUIRE(rays_o && rays_d && bitfield && nears && fars && rays && counter && workspace, "null pointer");
   INR_REQUIRE(N > 0 && N < (1ll << 31), "N out of range");
   INR_REQUIRE(max_steps > 0 && cascade >= 1 && H >= 8 && H <= 1024, "bad grid parameters");
   const MarchParams P = make_params(bitfield, bound, dt_gamma, max_steps, cascade, H);
   const unsigned nb = blocks_for(N, kRayBlock);
+  INR_REQUIRE(sample_cap >= 0 && ((uintptr_t)workspace & 7) == 0, "workspace must be 8-byte aligned");
   int32_t* counts = reinterpret_cast<int32_t*>(workspace);
   int32_t* block_sums = counts + N;
+  float2* cap_buf = reinterpret_cast<float2*>(counts + ws_ints(N));
   hipStream_t st = as_stream(s);
-  k_march_count<<<nb, kRayBlock, 0, st>>>(P, rays_o, rays_d, N, max_steps, nears, fars, noises, counts, block_sums);
+  k_march_count<<<nb, kRayBlock, 0, st>>>(P, rays_o, rays_d, N, max_steps, nears, fars, noises, counts, block_sums,
+                                          cap_buf, sample_cap);
   k_scan_block_sums<<<1, 1024, 0, st>>>(block_sums, (int)nb, N, counter);
   k_finalize_offsets<<<nb, kRayBlock, 0, st>>>(counts, block_sums, N, rays);
   return check_launch("march_rays_train_count");
@@ -735,28 +781,35 @@ int inr_march_rays_train_count(const float* rays_o, const float* rays_d, const u
 int inr_march_rays_train_write(const float* rays_o, const float* rays_d, const uint8_t* bitfield, float bound,
                                float dt_gamma, int32_t max_steps, int64_t N, int32_t cascade, int32_t H, int64_t M,
                                const float* nears, const float* fars, const float* noises, const int32_t* rays,
-                               float* xyzs, float* dirs, float* deltas, inr_stream_t s) {
+                               float* xyzs, float* dirs, float* deltas, const void* workspace, int32_t sample_cap,
+                               inr_stream_t s) {
   INR_REQUIRE(rays_o && rays_d && bitfield && nears && fars && rays, "null pointer");
   INR_REQUIRE(N > 0 && M >= 0, "bad sizes");
   if (M == 0) return INR_OK;
   INR_REQUIRE(xyzs && dirs && deltas, "null output");
   const MarchParams P = make_params(bitfield, bound, dt_gamma, max_steps, cascade, H);
+  INR_REQUIRE(sample_cap == 0 || workspace, "sample_cap > 0 needs the workspace of the count pass");
+  const float2* cap_buf = sample_cap > 0 ? reinterpret_cast<const float2*>(reinterpret_cast<const int32_t*>(workspace) + ws_ints(N)) : nullptr;
   k_march_write<<<blocks_for(N, kRayBlock), kRayBlock, 0, as_stream(s)>>>(P, rays_o, rays_d, N, M, nears, fars, noises,
-                                                                          rays, xyzs, dirs, deltas);
+                                                                          rays, xyzs, dirs, deltas, cap_buf, sample_cap);
   return check_launch("march_rays_train_write");
 }
 
 int inr_march_rays_patch_write(const float* rays_o, const float* rays_d, const uint8_t* bitfield, float bound,
                                float dt_gamma, int32_t max_steps, int64_t N, int32_t cascade, int32_t H, int64_t M,
                                const float* nears, const float* fars, const float* noises, const int32_t* rays,
-                               float* xyzs, float* dirs, float* deltas, inr_stream_t s) {
+                               float* xyzs, float* dirs, float* deltas, const void* workspace, int32_t sample_cap,
+                               inr_stream_t s) {
   INR_REQUIRE(rays_o && rays_d && bitfield && nears && fars && rays, "null pointer");
   INR_REQUIRE(N > 0 && M >= 0, "bad sizes");
   if (M == 0) return INR_OK;
   INR_REQUIRE(xyzs && dirs && deltas, "null output");
   const MarchParams P = make_params(bitfield, bound, dt_gamma, max_steps, cascade, H);
+  INR_REQUIRE(sample_cap == 0 || workspace, "sample_cap > 0 needs the workspace of the count pass");
+  const float2* cap_buf = sample_cap > 0 ? reinterpret_cast<const float2*>(reinterpret_cast<const int32_t*>(workspace) + ws_ints(N)) : nullptr;
   k_march_write_patch<<<blocks_for(N, kRayBlock), kRayBlock, 0, as_stream(s)>>>(P, rays_o, rays_d, N, M, nears, fars,
-                                                                                noises, rays, xyzs, dirs, deltas);
+                                                                                noises, rays, xyzs, dirs, deltas, cap_buf,
+                                                                                sample_cap);
   return check_launch("march_rays_patch_write");
 }
 
