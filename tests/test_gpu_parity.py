@@ -541,3 +541,26 @@ def test_rays_missing_the_volume(rm, bits_dev):
     assert rays[:2, 2].tolist() == [0, 0] and rays[2, 2] > 0
     ws, depth, img = rm.composite_rays_patch(torch.zeros(x.shape[0], device=DEV), torch.zeros(x.shape[0], 3, device=DEV), dl, rays)
     assert ws.tolist() == [0.0, 0.0, 0.0]
+
+
+@pytest.mark.parametrize("cap", [0, 8, 64, 512])
+def test_capture_replay_is_bit_identical(rm, room, room_bitfield, bits_dev, cap, monkeypatch):
+    """The write pass replaying recorded (t, delta) pairs, re-marching long rays, or marching twice all
+    produce the oracle's samples bit for bit (both writers)."""
+    from oracle import march, rays
+    monkeypatch.setattr(rm, "SAMPLE_CAP", cap)
+    monkeypatch.setattr(rm, "SAMPLE_CAP_TRAIN", cap)
+    ro, rd = scene_rays(room, 777, seed=81)
+    aabb = np.asarray([-1, -1, -1, 1, 1, 1], np.float32)
+    nears, fars = rays.near_far_from_aabb(ro, rd, aabb, 0.05)
+    noises = np.random.default_rng(3).random(777).astype(np.float32)
+    ref = march.march_rays_train(ro, rd, room_bitfield, 1.0, 1, 128, nears, fars, noises, 1.0 / 256, 1024)
+    x, d, dl, rr = rm.march_rays_train(_t(ro), _t(rd), 1.0, bits_dev, 1, 128, _t(nears), _t(fars), dt_gamma=1.0 / 256,
+                                       noises=_t(noises))
+    assert (rr.cpu().numpy() == ref["rays"]).all()
+    assert (x.cpu().numpy()[:ref["total"]] == ref["xyzs"]).all() and (dl.cpu().numpy()[:ref["total"]] == ref["deltas"]).all()
+    xp, dp, dlp, rp = rm.march_rays_patch(_t(ro), _t(rd), 1.0, bits_dev, 1, 128, _t(nears), _t(fars), dt_gamma=1.0 / 256,
+                                          noises=_t(noises))
+    slots = rm.patch_slots(rp)
+    assert (xp.cpu().numpy()[slots] == ref["xyzs"]).all() and (dlp.cpu().numpy()[slots] == ref["deltas"]).all()
+    assert (dp.cpu().numpy()[slots] == ref["dirs"]).all()
