@@ -63,7 +63,12 @@ const char* inr_last_error(void);
 /* Fills props[0..3] = {CU count, wavefront size, LDS bytes per CU, gcn arch number}. */
 int inr_device_info(int32_t device, int64_t* props);
 
-/* ---- rays (replaces raymarching.near_far_from_aabb) ------------------ */
+/* ---- rays: generation (replaces nerf/utils.py::get_rays) and ray/AABB (a2) -------------
+ * poses [B,4,4] camera-to-world row-major; pixel `inds[k]` (flat j*W+i; NULL = 0..n-1) -> rays_o/rays_d [B,n,3]:
+ * dir = ((i+.5-cx)/fx, (j+.5-cy)/fy, 1) normalised and rotated by the pose, origin = translation.     */
+int inr_get_rays(const float* poses, int64_t B, float fx, float fy, float cx, float cy, int32_t W,
+                 const int64_t* inds /*[n] nullable*/, int64_t n, float* rays_o, float* rays_d, inr_stream_t s);
+
 int inr_near_far_from_aabb(const float* rays_o, const float* rays_d, const float* aabb /*[6]*/,
                            int64_t N, float min_near, float* nears, float* fars, inr_stream_t s);
 

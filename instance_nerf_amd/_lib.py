@@ -28,6 +28,7 @@ _SIGS = {
     "inr_abi_version": (c_int32, []),
     "inr_last_error": (c_char_p, []),
     "inr_device_info": (c_int32, [c_int32, POINTER(c_int64)]),
+    "inr_get_rays": (c_int32, [P, c_int64, c_float, c_float, c_float, c_float, c_int32, P, c_int64, P, P, P]),
     "inr_near_far_from_aabb": (c_int32, [P, P, P, c_int64, c_float, P, P, P]),
     "inr_morton3D": (c_int32, [P, c_int64, P, P]),
     "inr_morton3D_invert": (c_int32, [P, c_int64, P, P]),

@@ -48,6 +48,30 @@ __global__ void __launch_bounds__(kRayBlock) k_near_far(const float* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------
+// a1: ray generation (replaces the dozen elementwise ops of nerf/utils.py::get_rays): pixel centre at +0.5,
+// dir = ((i-cx)/fx, (j-cy)/fy, 1) normalised, rotated by the pose; same operation order as oracle/rays.py
+// (no FMA) so rays are bit-identical to the CPU oracle's.
+__global__ void __launch_bounds__(kRayBlock) k_get_rays(const float* __restrict__ poses, int64_t B, float fx, float fy,
+                                                        float cx, float cy, int W, const int64_t* __restrict__ inds,
+                                                        int64_t n, float* __restrict__ rays_o,
+                                                        float* __restrict__ rays_d) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * n) return;
+  const int64_t b = idx / n, k = idx - b * n;
+  const int64_t pix = inds ? inds[k] : k;
+  const float i = (float)(pix % W) + 0.5f, j = (float)(pix / W) + 0.5f;
+  const float xs = (i - cx) / fx, ys = (j - cy) / fy;
+  const float nrm = sqrtf(xs * xs + ys * ys + 1.0f * 1.0f);
+  const float dx = xs / nrm, dy = ys / nrm, dz = 1.0f / nrm;
+  const float* P = poses + b * 16;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    rays_d[idx * 3 + r] = dx * P[r * 4 + 0] + dy * P[r * 4 + 1] + dz * P[r * 4 + 2];
+    rays_o[idx * 3 + r] = P[r * 4 + 3];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // a3: morton / packbits
 __global__ void k_morton3D(const int32_t* __restrict__ coords, int64_t N, int32_t* __restrict__ out) {
   const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -715,6 +739,16 @@ int inr_device_info(int32_t device, int64_t* props) {
   props[2] = (int64_t)p.maxSharedMemoryPerMultiProcessor;
   props[3] = p.gcnArchName[0] ? atoi(p.gcnArchName + 3) : 0;
   return INR_OK;
+}
+
+int inr_get_rays(const float* poses, int64_t B, float fx, float fy, float cx, float cy, int32_t W, const int64_t* inds,
+                 int64_t n, float* rays_o, float* rays_d, inr_stream_t s) {
+  INR_REQUIRE(B >= 0 && n >= 0 && W > 0, "bad sizes");
+  if (B * n == 0) return INR_OK;
+  INR_REQUIRE(poses && rays_o && rays_d, "null pointer");
+  k_get_rays<<<blocks_for(B * n, kRayBlock), kRayBlock, 0, as_stream(s)>>>(poses, B, fx, fy, cx, cy, W, inds, n, rays_o,
+                                                                           rays_d);
+  return check_launch("get_rays");
 }
 
 int inr_near_far_from_aabb(const float* rays_o, const float* rays_d, const float* aabb, int64_t N,

@@ -64,6 +64,19 @@ def get_rays(poses, intrinsics, H, W, N=-1, error_map=None, inds=None, patch=0):
             inds = patch_order(H, W, patch, device)
         else:
             inds = torch.arange(H * W, device=device)
+    inds = inds.contiguous().long()
+    n = inds.shape[0]
+    if poses.is_cuda:
+        lib = _lib.load()
+        poses = poses.contiguous().float()
+        rays_o = torch.empty(B, n, 3, dtype=torch.float32, device=device)
+        rays_d = torch.empty(B, n, 3, dtype=torch.float32, device=device)
+        _lib.check(lib.inr_get_rays(_lib.ptr(poses, torch.float32, "poses"), B, float(fx), float(fy), float(cx), float(cy),
+                                    int(W), _lib.ptr(inds, torch.int64, "inds", allow_none=n == 0), n,
+                                    _lib.ptr(rays_o, allow_none=B * n == 0), _lib.ptr(rays_d, allow_none=B * n == 0),
+                                    _lib.stream_ptr()), "get_rays")
+        return {"rays_o": rays_o, "rays_d": rays_d, "inds": inds[None].expand(B, -1)}
+    # host tensors (dataset preparation on the CPU): same arithmetic with torch ops
     i = (inds % W).float() + 0.5
     j = torch.div(inds, W, rounding_mode="floor").float() + 0.5
     xs = (i - cx) / fx

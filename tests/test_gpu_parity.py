@@ -564,3 +564,18 @@ def test_capture_replay_is_bit_identical(rm, room, room_bitfield, bits_dev, cap,
     slots = rm.patch_slots(rp)
     assert (xp.cpu().numpy()[slots] == ref["xyzs"]).all() and (dlp.cpu().numpy()[slots] == ref["deltas"]).all()
     assert (dp.cpu().numpy()[slots] == ref["dirs"]).all()
+
+
+def test_get_rays_bit_exact(room):
+    from instance_nerf_amd.nerf.utils import get_rays
+    from oracle import rays
+    poses, intr, H, W = room.cameras()
+    inds = np.random.default_rng(0).integers(0, H * W, size=5000)
+    ref = rays.get_rays(poses[:3], intr, H, W, inds=inds)
+    got = get_rays(_t(poses[:3]), intr, H, W, inds=_t(inds))
+    assert (got["rays_d"].cpu().numpy() == ref["rays_d"]).all()
+    assert (got["rays_o"].cpu().numpy() == ref["rays_o"]).all()
+    full = get_rays(_t(poses[:1]), intr, 16, 12)
+    assert full["rays_d"].shape == (1, 192, 3) and torch.allclose(full["rays_d"].norm(dim=-1), torch.ones(1, 192, device=DEV), atol=1e-6)
+    host = get_rays(torch.from_numpy(poses[:3]), intr, H, W, inds=torch.from_numpy(inds))      # CPU branch
+    assert np.allclose(host["rays_d"].numpy(), ref["rays_d"], atol=1e-7)
