@@ -67,3 +67,13 @@ def test_product_never_imports_oracle():
                 if re.search(r"^\s*(from|import)\s+oracle\b", s, flags=re.M):
                     bad.append(f)
     assert not bad
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    """No silent fallback: without libinr_hip.so every op raises (checked on a fresh loader state)."""
+    import pytest
+    from instance_nerf_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libinr_hip.so")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _lib.load()
