@@ -193,7 +193,7 @@ __device__ __forceinline__ void blend(const Gathered& g, f32x4& lo, f32x4& hi) {
   hi[0] = f[4]; hi[1] = f[5]; hi[2] = f[6]; hi[3] = f[7];
 }
 
-// ---- x-split gather (default) -------------------------------------------------------------------------
+// ---- x-split gather (alternative, OFF by default) -----------------------------------------------------
 // The gather phase is bound by L1/TA line look-ups, and the two x-neighbour corners of a cell share a
 // 128-byte line 15 times out of 16 (x is the fastest-varying index in dense AND hashed levels), yet as
 // corner k and k+1 of one lane they are fetched by two different instructions = two look-ups.
@@ -202,8 +202,11 @@ __device__ __forceinline__ void blend(const Gathered& g, f32x4& lo, f32x4& hi) {
 // sample sit 8 apart, issue the same instruction and hit the same line -> one look-up.  Each lane blends
 // its 4 (y,z) corners with its own x weight; the halves are added with one DPP row_ror:8 per value; the
 // lane with xb == r keeps round r, which is sample j = 8 xb + j8 = lane & 15: exactly the MFMA B layout.
+// MEASURED: this halves the L1 line look-ups but not the time at 16 waves/CU (7.156 vs 7.168 ms), and at the
+// final 8 waves/CU - where the VALU is the busiest unit (70 %) - its second cell-locate per level pair and the
+// fraction recompute cost 11 % (6.91 vs 6.21 ms per 37 M samples).  Kept for A/B runs only.
 #ifndef INR_XSPLIT
-#define INR_XSPLIT 1
+#define INR_XSPLIT 0
 #endif
 
 

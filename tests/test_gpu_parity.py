@@ -579,3 +579,49 @@ def test_get_rays_bit_exact(room):
     assert full["rays_d"].shape == (1, 192, 3) and torch.allclose(full["rays_d"].norm(dim=-1), torch.ones(1, 192, device=DEV), atol=1e-6)
     host = get_rays(torch.from_numpy(poses[:3]), intr, H, W, inds=torch.from_numpy(inds))      # CPU branch
     assert np.allclose(host["rays_d"].numpy(), ref["rays_d"], atol=1e-7)
+
+
+def test_instance_training_matches_oracle(room, room_bitfield, level_table):
+    """Instance-field stage (NeRF frozen, CE on rendered logits, ignore -1): HIP Trainer vs oracle from the same
+    parameters and batches - same loss curve, same predicted instance ids (mIoU of the two label maps ~ 1)."""
+    from instance_nerf_amd.nerf.utils import MIoUMeter, Trainer
+    from oracle import field, render
+    K = 16
+    p0 = field.init_params(seed=4, table=level_table, table_std=1e-4, K=K)
+    p0["embeddings"] = (torch.rand(p0["embeddings"].shape, generator=torch.Generator().manual_seed(6)) * 2 - 1)
+    net = _network({k: v.clone() for k, v in p0.items()}, K=K)
+    net.density_bitfield.copy_(_t(room_bitfield))
+    tr = Trainer("i", None, net, stage="instance", device=torch.device(DEV), lr=1e-2, iters=100, update_extra_interval=10 ** 9)
+    tr.global_step = 1
+    orig_render = net.render
+    net.render = lambda *a, **kw: orig_render(*a, **{**kw, "perturb": False, "force_all_rays": True})
+    p = {k: v.clone() for k, v in p0.items()}
+    train_keys = ("inst_embeddings", "inst_w0", "inst_w1", "inst_w2")
+    for k in train_keys:
+        p[k].requires_grad_(True)
+    opt = torch.optim.Adam([p[k] for k in train_keys], lr=1e-2, betas=(0.9, 0.99), eps=1e-15)
+    ro, rd = scene_rays(room, 192, seed=130)
+    _, ids, _ = room.trace(ro, rd)
+    labels = np.where(np.arange(192) % 9 == 0, -1, ids % K)
+    hip, ref = [], []
+    for s in range(6):
+        data = {"rays_o": _t(ro)[None], "rays_d": _t(rd)[None], "masks": _t(labels)[None]}
+        hip.append(float(tr.train_one_step(data)))
+        for g in opt.param_groups:
+            g["lr"] = 1e-2 * 0.1 ** min((s + 2) / 100, 1)
+        out = render.render_train(ro, rd, p, level_table, room_bitfield, min_near=0.05, with_instance=True)
+        loss = render.instance_ce_loss(out["instance"], labels)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        ref.append(float(loss))
+    assert ref[-1] < ref[0]
+    for a, b in zip(hip, ref):
+        assert abs(a - b) < 2e-3 * max(abs(b), 1e-3), (hip, ref)
+    net.eval()
+    with torch.no_grad():
+        pred_hip = orig_render(_t(ro)[None], _t(rd)[None], bg_color=1)["instance"][0].argmax(-1).cpu()
+        pred_ref = render.render_train(ro, rd, p, level_table, room_bitfield, min_near=0.05, with_instance=True)["instance"].argmax(-1)
+    meter = MIoUMeter(K)
+    meter.update(pred_hip, pred_ref)
+    assert meter.measure() > 0.98
