@@ -69,8 +69,21 @@ __device__ __forceinline__ f32x4 mfma4(const float4 a, const f32x4 b, f32x4 c) {
   c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b[3], c, 0, 0, 0);
   return c;
 }
+// ReLU as ONE integer max on the bit pattern (negative floats, -0 and negative NaNs are negative integers);
+// fmaxf() costs two v_max_f32 here because the compiler canonicalises MFMA outputs first.
+#ifndef INR_TRIM_RELU
+#define INR_TRIM_RELU 1
+#endif
+#ifndef INR_TRIM_EXP
+#define INR_TRIM_EXP 1
+#endif
+#if INR_TRIM_RELU
+__device__ __forceinline__ float relu1(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
+#else
+__device__ __forceinline__ float relu1(float x) { return fmaxf(x, 0.f); }
+#endif
 __device__ __forceinline__ f32x4 relu4(f32x4 v) {
-  v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+  v[0] = relu1(v[0]); v[1] = relu1(v[1]); v[2] = relu1(v[2]); v[3] = relu1(v[3]);
   return v;
 }
 
@@ -423,12 +436,17 @@ struct TileIn {
   float d0, d1, d2;
 };
 
+// x01 = (x + bound) / (2 bound): a true IEEE division, as in the oracle.  (Replacing it by a multiplication
+// with the exact reciprocal when 2*bound is a power of two - selected by a wave-uniform flag - measured 7 %
+// SLOWER: the extra control flow in front of the gathers costs more than the ~30 instructions it saves.)
+__device__ __forceinline__ float to_x01(float x, float bound, float rb, float) { return (x + bound) / rb; }
+
 template <bool kDir>
 __device__ __forceinline__ void load_tile_in(const float* __restrict__ x, const float* __restrict__ d, int64_t m,
-                                             float bound, float rb, TileIn& t) {
-  t.x0 = (x[m * 3 + 0] + bound) / rb;
-  t.x1 = (x[m * 3 + 1] + bound) / rb;
-  t.x2 = (x[m * 3 + 2] + bound) / rb;
+                                             float bound, float rb, float rb_inv, TileIn& t) {
+  t.x0 = to_x01(x[m * 3 + 0], bound, rb, rb_inv);
+  t.x1 = to_x01(x[m * 3 + 1], bound, rb, rb_inv);
+  t.x2 = to_x01(x[m * 3 + 2], bound, rb, rb_inv);
   if constexpr (kDir) {
     t.d0 = d[m * 3]; t.d1 = d[m * 3 + 1]; t.d2 = d[m * 3 + 2];
   }
@@ -505,6 +523,7 @@ __global__ void __launch_bounds__(kFieldThreads, INR_FIELD_MIN_WAVES) k_nerf_fwd
   if (n_dev) n = min((int64_t)*n_dev, M);
   const int64_t n_tiles = (n + 15) >> 4;
   const float rb = 2.0f * bound;
+  const float rb_inv = 0.0f;
   const TileSched sched = make_sched(n_tiles, kWaves);
 
   const bool all_hashed[4] = {slot_all_hashed(G, 0), slot_all_hashed(G, 1), slot_all_hashed(G, 2), slot_all_hashed(G, 3)};
@@ -514,7 +533,7 @@ __global__ void __launch_bounds__(kFieldThreads, INR_FIELD_MIN_WAVES) k_nerf_fwd
     const int64_t m = tile * 16 + j;
     const bool valid = m < n;
     TileIn me;
-    load_tile_in<kColor>(x, d, valid ? m : n - 1, bound, rb, me);
+    load_tile_in<kColor>(x, d, valid ? m : n - 1, bound, rb, rb_inv, me);
 
     f32x4 enc[2];
 #if INR_XSPLIT && INR_PROBE_MODE != 1
@@ -524,9 +543,9 @@ __global__ void __launch_bounds__(kFieldThreads, INR_FIELD_MIN_WAVES) k_nerf_fwd
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
         const int64_t mr = min(tile * 16 + r * 8 + (lane & 7), n - 1);
-        xr[r][0] = (x[mr * 3 + 0] + bound) / rb;
-        xr[r][1] = (x[mr * 3 + 1] + bound) / rb;
-        xr[r][2] = (x[mr * 3 + 2] + bound) / rb;
+        xr[r][0] = to_x01(x[mr * 3 + 0], bound, rb, rb_inv);
+        xr[r][1] = to_x01(x[mr * 3 + 1], bound, rb, rb_inv);
+        xr[r][2] = to_x01(x[mr * 3 + 2], bound, rb, rb_inv);
       }
       GatheredXS g;
       uint32_t rec_off = (uint32_t)q * 4u * (uint32_t)sizeof(LevelRec);
@@ -571,7 +590,11 @@ __global__ void __launch_bounds__(kFieldThreads, INR_FIELD_MIN_WAVES) k_nerf_fwd
     mlp_layer<1, 4>(wl + kSig1 / 4, lane, h1, h2);      // row 0 = raw density, rows 1..15 = geo features
 
     if (valid) {
+#if INR_TRIM_EXP
+      if (q == 0) sigma[m] = __expf(h2[0][0]) * density_scale;
+#else
       if (q == 0) sigma[m] = expf(h2[0][0]) * density_scale;
+#endif
       if (geo) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -597,9 +620,15 @@ __global__ void __launch_bounds__(kFieldThreads, INR_FIELD_MIN_WAVES) k_nerf_fwd
       for (int t = 0; t < 4; ++t) c2[t] = relu4(c2[t]);
       mlp_layer<1, 4>(wl + kCol2 / 4, lane, c2, o);
       if (valid && q == 0) {
+#if INR_TRIM_EXP
+        rgb[m * 3 + 0] = __frcp_rn(1.0f + __expf(-o[0][0]));     // v_exp_f32 / v_rcp_f32: ~1e-7 relative
+        rgb[m * 3 + 1] = __frcp_rn(1.0f + __expf(-o[0][1]));
+        rgb[m * 3 + 2] = __frcp_rn(1.0f + __expf(-o[0][2]));
+#else
         rgb[m * 3 + 0] = 1.0f / (1.0f + expf(-o[0][0]));
         rgb[m * 3 + 1] = 1.0f / (1.0f + expf(-o[0][1]));
         rgb[m * 3 + 2] = 1.0f / (1.0f + expf(-o[0][2]));
+#endif
       }
     }
 #if INR_MLP_SETPRIO
@@ -628,6 +657,7 @@ __global__ void __launch_bounds__(kFieldThreads, INR_FIELD_MIN_WAVES) k_instance
   if (n_dev) n = min((int64_t)*n_dev, M);
   const int64_t n_tiles = (n + 15) >> 4;
   const float rb = 2.0f * bound;
+  const float rb_inv = 0.0f;
   const TileSched sched = make_sched(n_tiles, kWaves);
 
   const bool all_hashed[4] = {slot_all_hashed(G, 0), slot_all_hashed(G, 1), slot_all_hashed(G, 2), slot_all_hashed(G, 3)};
@@ -637,7 +667,7 @@ __global__ void __launch_bounds__(kFieldThreads, INR_FIELD_MIN_WAVES) k_instance
     const int64_t m = tile * 16 + j;
     const bool valid = m < n;
     TileIn me;
-    load_tile_in<false>(x, nullptr, valid ? m : n - 1, bound, rb, me);
+    load_tile_in<false>(x, nullptr, valid ? m : n - 1, bound, rb, rb_inv, me);
     f32x4 enc[2];
 #if INR_XSPLIT
     {
@@ -646,9 +676,9 @@ __global__ void __launch_bounds__(kFieldThreads, INR_FIELD_MIN_WAVES) k_instance
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
         const int64_t mr = min(tile * 16 + r * 8 + (lane & 7), n - 1);
-        xr[r][0] = (x[mr * 3 + 0] + bound) / rb;
-        xr[r][1] = (x[mr * 3 + 1] + bound) / rb;
-        xr[r][2] = (x[mr * 3 + 2] + bound) / rb;
+        xr[r][0] = to_x01(x[mr * 3 + 0], bound, rb, rb_inv);
+        xr[r][1] = to_x01(x[mr * 3 + 1], bound, rb, rb_inv);
+        xr[r][2] = to_x01(x[mr * 3 + 2], bound, rb, rb_inv);
       }
       GatheredXS g;
       uint32_t rec_off = (uint32_t)q * 4u * (uint32_t)sizeof(LevelRec);
