@@ -221,6 +221,9 @@ __device__ __forceinline__ void blend(const Gathered& g, f32x4& lo, f32x4& hi) {
 #ifndef INR_XSPLIT
 #define INR_XSPLIT 0
 #endif
+#ifndef INR_RECS_IN_REGS
+#define INR_RECS_IN_REGS 0
+#endif
 
 
 struct GatheredXS {
@@ -527,6 +530,11 @@ __global__ void __launch_bounds__(kFieldThreads, INR_FIELD_MIN_WAVES) k_nerf_fwd
   const TileSched sched = make_sched(n_tiles, kWaves);
 
   const bool all_hashed[4] = {slot_all_hashed(G, 0), slot_all_hashed(G, 1), slot_all_hashed(G, 2), slot_all_hashed(G, 3)};
+#if INR_RECS_IN_REGS
+  LevelRec my_recs_reg[4];
+#pragma unroll
+  for (int li = 0; li < 4; ++li) my_recs_reg[li] = recs[q * 4 + li];
+#endif
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)emb, 0, (int)emb_bytes, 0x00020000);
 
   for (int64_t it = 0, tile = sched.tile(0); tile < sched.hi; tile = sched.tile(++it)) {
@@ -561,10 +569,14 @@ __global__ void __launch_bounds__(kFieldThreads, INR_FIELD_MIN_WAVES) k_nerf_fwd
 #else
     {
       Gathered g;
+#if INR_RECS_IN_REGS
+      issue_gathers(my_recs_reg, all_hashed, rsrc, me.x0, me.x1, me.x2, g);
+#else
       uint32_t rec_off = (uint32_t)q * 4u * (uint32_t)sizeof(LevelRec);
       asm volatile("" : "+v"(rec_off));    // opaque per tile: keeps the records in LDS, not hoisted into VGPRs
       issue_gathers(reinterpret_cast<const LevelRec*>(reinterpret_cast<const char*>(recs) + rec_off), all_hashed, rsrc,
                     me.x0, me.x1, me.x2, g);
+#endif
       __builtin_amdgcn_sched_barrier(0);   // all 32 gathers in flight before the first blend waits
       blend(g, enc[0], enc[1]);
     }
@@ -661,6 +673,11 @@ __global__ void __launch_bounds__(kFieldThreads, INR_FIELD_MIN_WAVES) k_instance
   const TileSched sched = make_sched(n_tiles, kWaves);
 
   const bool all_hashed[4] = {slot_all_hashed(G, 0), slot_all_hashed(G, 1), slot_all_hashed(G, 2), slot_all_hashed(G, 3)};
+#if INR_RECS_IN_REGS
+  LevelRec my_recs_reg[4];
+#pragma unroll
+  for (int li = 0; li < 4; ++li) my_recs_reg[li] = recs[q * 4 + li];
+#endif
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)emb, 0, (int)emb_bytes, 0x00020000);
 
   for (int64_t it = 0, tile = sched.tile(0); tile < sched.hi; tile = sched.tile(++it)) {
@@ -691,10 +708,14 @@ __global__ void __launch_bounds__(kFieldThreads, INR_FIELD_MIN_WAVES) k_instance
 #else
     {
       Gathered g;
+#if INR_RECS_IN_REGS
+      issue_gathers(my_recs_reg, all_hashed, rsrc, me.x0, me.x1, me.x2, g);
+#else
       uint32_t rec_off = (uint32_t)q * 4u * (uint32_t)sizeof(LevelRec);
       asm volatile("" : "+v"(rec_off));    // opaque per tile: keeps the records in LDS, not hoisted into VGPRs
       issue_gathers(reinterpret_cast<const LevelRec*>(reinterpret_cast<const char*>(recs) + rec_off), all_hashed, rsrc,
                     me.x0, me.x1, me.x2, g);
+#endif
       __builtin_amdgcn_sched_barrier(0);   // all 32 gathers in flight before the first blend waits
       blend(g, enc[0], enc[1]);
     }
