@@ -107,7 +107,8 @@ int inr_march_rays_train_write(const float* rays_o, const float* rays_d, const u
  *   slot(r, k) = rays[g0,1] + sum_i min(c_i, k) + #{ i < r : c_i > k }
  * (all k-th samples of a group adjacent).  A group whose slots do not fit in M is dropped whole.
  * inr_composite_rays_patch_forward composites that layout (per ray, in k order, stop at T < T_thresh;
- * same arithmetic as inr_composite_rays_train_forward); extra_out must be zero-initialised.          */
+ * same arithmetic as the sequential training compositing); weights [M] (nullable unless extra is given)
+ * receives the per-sample weight, which the K-channel pass (one wave per ray) then uses.              */
 int inr_march_rays_patch_write(const float* rays_o, const float* rays_d, const uint8_t* bitfield,
                                float bound, float dt_gamma, int32_t max_steps, int64_t N,
                                int32_t cascade, int32_t H, int64_t M, const float* nears,
@@ -119,7 +120,7 @@ int inr_composite_rays_patch_forward(const float* sigmas, const float* rgbs, con
                                      const int32_t* rays, int64_t N, int64_t M, float T_thresh,
                                      const float* extra /*[M,K] nullable*/, int32_t K,
                                      float* weights_sum, float* depth, float* image,
-                                     float* extra_out /*[N,K], zeroed*/, inr_stream_t s);
+                                     float* extra_out /*[N,K]*/, float* weights /*[M]*/, inr_stream_t s);
 
 /* ---- inference march/composite (replace raymarching.march_rays / composite_rays, a5) */
 int inr_march_rays(int64_t n_alive, int32_t n_step, const int32_t* rays_alive, const float* rays_t,

@@ -40,7 +40,7 @@ _SIGS = {
                                              c_int64, P, P, P, P, P, P, P, P, c_int32, P]),
     "inr_march_rays_patch_write": (c_int32, [P, P, P, c_float, c_float, c_int32, c_int64, c_int32, c_int32,
                                              c_int64, P, P, P, P, P, P, P, P, c_int32, P]),
-    "inr_composite_rays_patch_forward": (c_int32, [P, P, P, P, c_int64, c_int64, c_float, P, c_int32, P, P, P, P, P]),
+    "inr_composite_rays_patch_forward": (c_int32, [P, P, P, P, c_int64, c_int64, c_float, P, c_int32, P, P, P, P, P, P]),
     "inr_march_rays": (c_int32, [c_int64, c_int32, P, P, P, P, c_float, c_float, c_int32, c_int32, c_int32,
                                  P, P, P, P, P, P, P]),
     "inr_composite_rays": (c_int32, [c_int64, c_int32, P, P, P, P, P, P, P, P, c_float, P, P, c_int32, P]),

@@ -658,10 +658,9 @@ __global__ void __launch_bounds__(kRayBlock) k_composite_patch_fwd(const float* 
                                                                    const float* __restrict__ rgbs,
                                                                    const float* __restrict__ deltas,
                                                                    const int32_t* __restrict__ rays, int64_t N, int64_t M,
-                                                                   float T_thresh, const float* __restrict__ extra, int K,
+                                                                   float T_thresh, float* __restrict__ wbuf,
                                                                    float* __restrict__ weights_sum,
-                                                                   float* __restrict__ depth, float* __restrict__ image,
-                                                                   float* __restrict__ extra_out) {
+                                                                   float* __restrict__ depth, float* __restrict__ image) {
   const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & 63, g0 = lane & ~(kGroup - 1), rr = lane & (kGroup - 1);
   const int32_t rid = n < N ? rays[n * 3] : 0;
@@ -690,11 +689,11 @@ __global__ void __launch_bounds__(kRayBlock) k_composite_patch_fwd(const float* 
       t += dl.y;
       dsum += w * t;
       ws += w;
-      if (extra) {
-        for (int c = 0; c < K; ++c) extra_out[(int64_t)rid * K + c] += w * extra[i * K + c];
-      }
+      if (wbuf) wbuf[i] = w;
       T *= 1.0f - alpha;
       if (T < T_thresh) done = true;
+    } else if (active && wbuf) {
+      wbuf[(int64_t)S + __popc(field & ((1u << rr) - 1u))] = 0.0f;     // behind the termination point
     }
     S += __popc(field);
   }
@@ -702,6 +701,45 @@ __global__ void __launch_bounds__(kRayBlock) k_composite_patch_fwd(const float* 
     weights_sum[rid] = ws; depth[rid] = dsum;
     image[rid * 3] = r; image[rid * 3 + 1] = g; image[rid * 3 + 2] = b;
   }
+}
+
+// K extra channels of the patch-interleaved layout: out[ray][ch] = sum_k w[slot(r,k)] * extra[slot(r,k)][ch].
+// One wave per ray, lane = channel (coalesced 4K-byte rows); slot(r,k) = base + sum_i min(c_i,k) + #{i<r: c_i>k}
+// is advanced incrementally from the 16 counts of the ray's group (wave-uniform scalar work).
+__global__ void __launch_bounds__(kRayBlock) k_composite_patch_extra(const float* __restrict__ wbuf,
+                                                                     const float* __restrict__ extra,
+                                                                     const int32_t* __restrict__ rays, int64_t N,
+                                                                     int64_t M, int K, float* __restrict__ extra_out) {
+  const int64_t n = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (n >= N) return;
+  const int64_t g0 = n & ~(int64_t)(kGroup - 1);
+  const int r = (int)(n - g0);
+  int c[kGroup];
+  int total = 0;
+#pragma unroll
+  for (int i = 0; i < kGroup; ++i) {
+    c[i] = (g0 + i < N) ? rays[(g0 + i) * 3 + 2] : 0;
+    total += c[i];
+  }
+  const int32_t rid = rays[n * 3];
+  int64_t S = rays[g0 * 3 + 1];
+  const int cnt = (S + total <= M) ? c[r] : 0;          // dropped group
+  float acc = 0.0f;
+  for (int k = 0; k < cnt; ++k) {
+    int nact = 0, rank = 0;
+#pragma unroll
+    for (int i = 0; i < kGroup; ++i) {
+      const int gt = c[i] > k ? 1 : 0;
+      nact += gt;
+      rank += (i < r) ? gt : 0;
+    }
+    const int64_t slot = S + rank;
+    S += nact;
+    const float w = wbuf[slot];
+    if (lane < K && w != 0.0f) acc += w * extra[slot * K + lane];
+  }
+  if (lane < K) extra_out[(int64_t)rid * K + lane] = acc;
 }
 
 static MarchParams make_params(const uint8_t* bits, float bound, float dt_gamma, int max_steps, int C, int H) {
@@ -850,15 +888,19 @@ int inr_march_rays_patch_write(const float* rays_o, const float* rays_d, const u
 int inr_composite_rays_patch_forward(const float* sigmas, const float* rgbs, const float* deltas, const int32_t* rays,
                                      int64_t N, int64_t M, float T_thresh, const float* extra, int32_t K,
                                      float* weights_sum, float* depth, float* image, float* extra_out,
-                                     inr_stream_t s) {
+                                     float* weights, inr_stream_t s) {
   INR_REQUIRE(N >= 0 && M >= 0, "bad sizes");
   if (N == 0) return INR_OK;
   INR_REQUIRE(rays && weights_sum && depth && image, "null pointer");
   INR_REQUIRE(M == 0 || (sigmas && rgbs && deltas), "null sample arrays");
-  INR_REQUIRE(!extra || (extra_out && K > 0), "extra needs extra_out and K > 0 (extra_out must be zeroed)");
+  INR_REQUIRE(!extra || (extra_out && weights && K > 0 && K <= 64), "extra needs extra_out, weights and 0 < K <= 64");
   INR_REQUIRE(((uintptr_t)deltas & 7) == 0, "deltas must be 8-byte aligned");
-  k_composite_patch_fwd<<<blocks_for(N, kRayBlock), kRayBlock, 0, as_stream(s)>>>(
-      sigmas, rgbs, deltas, rays, N, M, T_thresh, extra, K, weights_sum, depth, image, extra_out);
+  hipStream_t st = as_stream(s);
+  k_composite_patch_fwd<<<blocks_for(N, kRayBlock), kRayBlock, 0, st>>>(sigmas, rgbs, deltas, rays, N, M, T_thresh,
+                                                                        weights, weights_sum, depth, image);
+  if (extra)
+    k_composite_patch_extra<<<blocks_for(N * 64, kRayBlock), kRayBlock, 0, st>>>(weights, extra, rays, N, M, K,
+                                                                                 extra_out);
   return check_launch("composite_rays_patch_forward");
 }
 
