@@ -625,3 +625,40 @@ def test_instance_training_matches_oracle(room, room_bitfield, level_table):
     meter = MIoUMeter(K)
     meter.update(pred_hip, pred_ref)
     assert meter.measure() > 0.98
+
+
+def test_trainer_checkpoint_roundtrip(tmp_path, room, room_bitfield, level_table):
+    """save_checkpoint / load_checkpoint restore model, occupancy state and optimiser moments: two trainers
+    continue identically (upstream keys: epoch, global_step, stats, model, optimizer, mean_count, mean_density)."""
+    from instance_nerf_amd.nerf.utils import Trainer
+    from oracle import field
+    p0 = field.init_params(seed=8, table=level_table, table_std=1e-4)
+
+    def make():
+        net = _network({k: v.clone() for k, v in p0.items()}, K=0)
+        net.density_bitfield.copy_(_t(room_bitfield))
+        tr = Trainer("ck", None, net, stage="nerf", device=torch.device(DEV), iters=50, update_extra_interval=10 ** 9,
+                     workspace=str(tmp_path))
+        tr.global_step = 1
+        orig = net.render
+        net.render = lambda *a, **kw: orig(*a, **{**kw, "perturb": False, "force_all_rays": True})
+        return tr
+
+    def batch(s):
+        ro, rd = scene_rays(room, 128, cam=s % 8, seed=300 + s)
+        rgb, _, _ = room.trace(ro, rd)
+        return {"rays_o": _t(ro)[None], "rays_d": _t(rd)[None], "images": _t(rgb)[None]}
+
+    a = make()
+    for s in range(3):
+        a.train_one_step(batch(s))
+    path = a.save_checkpoint()
+    state = torch.load(path, map_location="cpu", weights_only=False)
+    assert {"epoch", "global_step", "stats", "model", "optimizer", "mean_count", "mean_density"} <= set(state)
+    b = make()
+    b.load_checkpoint(path)
+    assert b.global_step == a.global_step
+    la = float(a.train_one_step(batch(3)))
+    lb = float(b.train_one_step(batch(3)))
+    assert abs(la - lb) < 1e-6 * max(1.0, abs(la))
+    assert torch.allclose(a.model.encoder.embeddings, b.model.encoder.embeddings, atol=1e-7)
