@@ -213,6 +213,14 @@ int inr_roi_align_3d_backward(const float* grad_out, const float* rois, const in
                               int32_t out_l, int32_t out_h, float spatial_scale, float* grad_input,
                               inr_stream_t s);
 
+/* Instance logits rendered in place (inference, patch-interleaved layout): extra_out[ray][ch] =
+ * sum_k weights[slot(ray,k)] * logits(xyzs[slot(ray,k)])[ch]; the [M,K] logits never exist in memory.
+ * xyzs/weights [M] in the patch-interleaved layout (inr_march_rays_patch_write / the weights output of
+ * inr_composite_rays_patch_forward), rays [N,3] from the count pass, extra_out [N,K].                   */
+int inr_instance_render(const float* xyzs, const int32_t* rays, const float* weights, int64_t N, int64_t M,
+                        float bound, const float* embeddings, const inr_grid_desc* desc /*host*/,
+                        const float* packed /*device*/, int32_t K, float* extra_out, inr_stream_t s);
+
 /* ---- weight gradient of the tiny bias-free MLP layers (replaces the BLAS call autograd makes for
  * nn.Linear in NeRFNetwork, a9/a13):  grad_w[o][i] += sum_m grad_y[m][o] * x[m][i],  n_in, n_out <= 64.
  * x [M, n_in], grad_y [M, n_out], grad_w [n_out, n_in] is ACCUMULATED into (caller zeroes it).      */

@@ -738,6 +738,89 @@ __global__ void __launch_bounds__(kFieldThreads, INR_FIELD_MIN_WAVES) k_instance
   }
 }
 
+
+// ---- instance logits rendered in place (inference) ---------------------------------------------------------
+// out[ray][ch] = sum_k w(ray,k) * logits(x(ray,k))[ch] without ever writing the [M, K] logits: one wave owns a
+// 16-ray group of the patch-interleaved layout for ALL its steps, MFMA column j is FIXED to ray j (the slot of
+// its k-th sample is re-derived per step from one ballot: base + sum_i min(c_i,k) + #{i<j: c_i>k}), and
+// w * logits accumulates in the MFMA output registers (16 per lane).  Steps where every live ray of the group
+// has w == 0 (behind the termination point) skip the gather and the MLP altogether.
+template <int K_MT>
+__global__ void __launch_bounds__(kFieldThreads, INR_FIELD_MIN_WAVES) k_instance_render(
+    const float* __restrict__ x, const int32_t* __restrict__ rays, const float* __restrict__ wbuf, int64_t N, int64_t M,
+    float bound, const float2* __restrict__ emb, uint32_t emb_bytes, GridDesc G, const float4* __restrict__ packed,
+    float* __restrict__ extra_out) {
+  extern __shared__ __attribute__((aligned(16))) float4 wl[];
+  constexpr int K = K_MT * 16;
+  constexpr int kStage = (kIns2 + K * 64) / 4;
+  for (int i = threadIdx.x; i < kStage; i += kFieldThreads) wl[i] = packed[i];
+  LevelRec* recs = reinterpret_cast<LevelRec*>(wl + kStage);
+  stage_level_recs(G, recs);
+  __syncthreads();
+
+  constexpr int kWaves = kFieldThreads / 64;
+  const int lane = threadIdx.x & 63, q = lane >> 4, j = lane & 15;
+  const float rb = 2.0f * bound;
+  const int64_t n_groups = (N + 15) >> 4;
+  const TileSched sched = make_sched(n_groups, kWaves);
+  const bool all_hashed[4] = {slot_all_hashed(G, 0), slot_all_hashed(G, 1), slot_all_hashed(G, 2), slot_all_hashed(G, 3)};
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)emb, 0, (int)emb_bytes, 0x00020000);
+
+  for (int64_t it = 0, grp = sched.tile(0); grp < sched.hi; grp = sched.tile(++it)) {
+    const int64_t ray = grp * 16 + j;
+    const int cnt = ray < N ? rays[ray * 3 + 2] : 0;
+    int64_t S = rays[grp * 16 * 3 + 1];                    // slot base of the group (offset of its first ray)
+    int gtot = cnt;                                        // group total, to honour a dropped group
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) gtot += __shfl_xor(gtot, d, 64);
+    const bool fits = S + gtot <= M;
+    f32x4 acc[K_MT];
+#pragma unroll
+    for (int mt = 0; mt < K_MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; fits; ++k) {
+      const unsigned field = (unsigned)(__ballot(k < cnt) & 0xFFFFull);      // lanes 0..15 = q 0, column j
+      if (field == 0) break;
+      const bool active = k < cnt;
+      const int64_t slot = S + __popc(field & ((1u << j) - 1u));
+      S += __popc(field);
+      const float w = active ? wbuf[slot] : 0.0f;
+      if (__ballot(w != 0.0f) == 0ull) continue;           // the whole group is past its termination points
+      const int64_t m = active ? slot : 0;
+      const float x0 = (x[m * 3 + 0] + bound) / rb, x1 = (x[m * 3 + 1] + bound) / rb, x2 = (x[m * 3 + 2] + bound) / rb;
+      f32x4 enc[2];
+      {
+        Gathered g;
+        uint32_t rec_off = (uint32_t)q * 4u * (uint32_t)sizeof(LevelRec);
+        asm volatile("" : "+v"(rec_off));
+        issue_gathers(reinterpret_cast<const LevelRec*>(reinterpret_cast<const char*>(recs) + rec_off), all_hashed, rsrc,
+                      x0, x1, x2, g);
+        __builtin_amdgcn_sched_barrier(0);
+        blend(g, enc[0], enc[1]);
+      }
+      f32x4 h1[4], h2[4], o[K_MT];
+      mlp_layer<4, 2>(wl + kIns0 / 4, lane, enc, h1);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) h1[t] = relu4(h1[t]);
+      mlp_layer<4, 4>(wl + kIns1 / 4, lane, h1, h2);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) h2[t] = relu4(h2[t]);
+      mlp_layer<K_MT, 4>(wl + kIns2 / 4, lane, h2, o);
+#pragma unroll
+      for (int mt = 0; mt < K_MT; ++mt) {
+        acc[mt][0] = fmaf(w, o[mt][0], acc[mt][0]); acc[mt][1] = fmaf(w, o[mt][1], acc[mt][1]);
+        acc[mt][2] = fmaf(w, o[mt][2], acc[mt][2]); acc[mt][3] = fmaf(w, o[mt][3], acc[mt][3]);
+      }
+    }
+    if (ray < N) {
+      const int32_t rid = rays[ray * 3];
+#pragma unroll
+      for (int mt = 0; mt < K_MT; ++mt)
+        *reinterpret_cast<float4*>(extra_out + (int64_t)rid * K + 16 * mt + 4 * q) =
+            make_float4(acc[mt][0], acc[mt][1], acc[mt][2], acc[mt][3]);
+    }
+  }
+}
+
 // ---- host-side packing into fragment order ------------------------------------------------------
 // W is [n_out, n_in] row-major.  kidx(ks, q) -> input column (or -1 for a zero slot).
 static inline uint16_t bf16_rne(float x) {
@@ -911,6 +994,36 @@ int inr_instance_forward(const float* x, int64_t M, const int32_t* n_samples_dev
     default: k_instance_fwd<4><<<grid_for(k_instance_fwd<4>, lds, n_tiles), kFieldThreads, lds, st>>>(x, M, n_samples_dev, bound, e, eb, G, p, logits); break;
   }
   return check_launch("instance_forward");
+}
+
+int inr_instance_render(const float* xyzs, const int32_t* rays, const float* weights, int64_t N, int64_t M, float bound,
+                        const float* embeddings, const inr_grid_desc* desc, const float* packed, int32_t K,
+                        float* extra_out, inr_stream_t s) {
+  INR_REQUIRE(N >= 0 && M >= 0 && desc, "bad argument");
+  if (N == 0) return INR_OK;
+  INR_REQUIRE(rays && embeddings && packed && extra_out, "null pointer");
+  INR_REQUIRE(M == 0 || (xyzs && weights), "null sample arrays");
+  INR_REQUIRE(K > 0 && K <= 64 && K % 16 == 0, "K must be 16, 32, 48 or 64");
+  INR_REQUIRE(((uintptr_t)embeddings & 7) == 0 && ((uintptr_t)packed & 15) == 0 && ((uintptr_t)extra_out & 15) == 0,
+              "embeddings/packed/extra_out misaligned");
+  GridDesc G;
+  int rc = make_grid_desc(desc, G);
+  if (rc) return rc;
+  const float2* e = reinterpret_cast<const float2*>(embeddings);
+  const float4* p = reinterpret_cast<const float4*>(packed);
+  const uint64_t emb_bytes64 = (uint64_t)desc->offsets[desc->num_levels] * 8ull;
+  INR_REQUIRE(emb_bytes64 < (1ull << 31), "table larger than 2 GiB is not addressable by the 32-bit gather offsets");
+  const uint32_t eb = (uint32_t)emb_bytes64;
+  const size_t lds = (size_t)(kIns2 + K * 64) * sizeof(float) + kLevelRecBytes;
+  const int64_t n_groups = (N + 15) / 16;
+  hipStream_t st = as_stream(s);
+  switch (K / 16) {
+    case 1: k_instance_render<1><<<grid_for(k_instance_render<1>, lds, n_groups), kFieldThreads, lds, st>>>(xyzs, rays, weights, N, M, bound, e, eb, G, p, extra_out); break;
+    case 2: k_instance_render<2><<<grid_for(k_instance_render<2>, lds, n_groups), kFieldThreads, lds, st>>>(xyzs, rays, weights, N, M, bound, e, eb, G, p, extra_out); break;
+    case 3: k_instance_render<3><<<grid_for(k_instance_render<3>, lds, n_groups), kFieldThreads, lds, st>>>(xyzs, rays, weights, N, M, bound, e, eb, G, p, extra_out); break;
+    default: k_instance_render<4><<<grid_for(k_instance_render<4>, lds, n_groups), kFieldThreads, lds, st>>>(xyzs, rays, weights, N, M, bound, e, eb, G, p, extra_out); break;
+  }
+  return check_launch("instance_render");
 }
 
 }  // extern "C"

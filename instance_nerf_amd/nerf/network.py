@@ -208,6 +208,22 @@ class NeRFNetwork(NeRFRenderer):
             return out
         return _run_mlp(self.instance_net, self.instance_encoder(x, bound=self.bound))
 
+    @torch.no_grad()
+    def instance_render(self, xyzs, rays, weights):
+        """Rendered instance logits [N, K] from the patch-interleaved samples and their compositing weights, with
+        the per-sample logits kept on chip (inference only).  None when the fused kernel does not apply."""
+        if not (self.num_instances and self._fusable_inst):
+            return None
+        lib = _lib.load()
+        N, M = rays.shape[0], xyzs.shape[0]
+        out = torch.empty(N, self.num_instances, dtype=torch.float32, device=rays.device)
+        check(lib.inr_instance_render(ptr(xyzs, torch.float32, "xyzs", allow_none=M == 0), ptr(rays, torch.int32, "rays"),
+                                      ptr(weights, torch.float32, "weights", allow_none=M == 0), N, M, float(self.bound),
+                                      ptr(self.instance_encoder.embeddings.data, torch.float32),
+                                      self.instance_encoder.desc, ptr(self._packed_weights("instance")),
+                                      self.num_instances, ptr(out), stream_ptr()), "instance_render")
+        return out
+
     def get_params(self, lr):
         params = [{"params": self.encoder.parameters(), "lr": lr},
                   {"params": self.sigma_net.parameters(), "lr": lr},

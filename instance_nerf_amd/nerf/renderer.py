@@ -107,11 +107,18 @@ class NeRFRenderer(nn.Module):
             sigmas, rgbs = self(xyzs, dirs)
             if self.density_scale != 1:
                 sigmas = self.density_scale * sigmas
-            extra = self.instance(xyzs) if with_instance else None
-            out = raymarching.composite_rays_patch(sigmas, rgbs, deltas, rays, T_thresh, extra=extra)
-            weights_sum, depth, image = out[0], out[1], out[2]
-            if with_instance:
-                results["instance"] = out[3].view(*prefix, -1)
+            fused_inst = with_instance and getattr(self, "_fusable_inst", False) and hasattr(self, "instance_render")
+            if fused_inst:
+                # weights first, then the instance field accumulates w * logits on chip (no [M, K] round trip)
+                weights_sum, depth, image, wbuf = raymarching.composite_rays_patch(sigmas, rgbs, deltas, rays, T_thresh,
+                                                                                  return_weights=True)
+                results["instance"] = self.instance_render(xyzs, rays, wbuf).view(*prefix, -1)
+            else:
+                extra = self.instance(xyzs) if with_instance else None
+                out = raymarching.composite_rays_patch(sigmas, rgbs, deltas, rays, T_thresh, extra=extra)
+                weights_sum, depth, image = out[0], out[1], out[2]
+                if with_instance:
+                    results["instance"] = out[3].view(*prefix, -1)
             results["num_samples"] = counter
         elif self.training or infer_mode == "fused_raymajor":
             if self.training:

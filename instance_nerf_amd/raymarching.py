@@ -164,9 +164,9 @@ def march_rays_patch(rays_o, rays_d, bound, density_bitfield, C, H, nears, fars,
     return xyzs, dirs, deltas, rays
 
 
-def composite_rays_patch(sigmas, rgbs, deltas, rays, T_thresh=1e-4, extra=None):
+def composite_rays_patch(sigmas, rgbs, deltas, rays, T_thresh=1e-4, extra=None, return_weights=False):
     """Compositing of the patch-interleaved layout (inference only, no autograd).
-    -> weights_sum [N], depth [N], image [N,3] (, extra_out [N,K])."""
+    -> weights_sum [N], depth [N], image [N,3] (, extra_out [N,K]) (, weights [M] when return_weights)."""
     lib = _lib.load()
     sigmas, rgbs, deltas = _f(sigmas), _f(rgbs), _f(deltas)
     dev = rays.device
@@ -176,16 +176,15 @@ def composite_rays_patch(sigmas, rgbs, deltas, rays, T_thresh=1e-4, extra=None):
     depth = torch.empty(N, dtype=F32, device=dev)
     image = torch.empty(N, 3, dtype=F32, device=dev)
     extra_out = torch.empty(N, K, dtype=F32, device=dev) if K else None
-    wbuf = torch.empty(max(M, 1), dtype=F32, device=dev) if K else None
+    wbuf = torch.empty(max(M, 1), dtype=F32, device=dev) if (K or return_weights) else None
     none_ok = M == 0
     check(lib.inr_composite_rays_patch_forward(
         ptr(sigmas, F32, "sigmas", allow_none=none_ok), ptr(rgbs, F32, "rgbs", allow_none=none_ok),
         ptr(deltas, F32, "deltas", allow_none=none_ok), ptr(rays, I32, "rays"), N, M, float(T_thresh),
         ptr(_f(extra) if extra is not None else None, allow_none=True), K, ptr(ws), ptr(depth), ptr(image),
         ptr(extra_out, allow_none=True), ptr(wbuf, allow_none=True), stream_ptr()), "composite_rays_patch_forward")
-    if K:
-        return ws, depth, image, extra_out
-    return ws, depth, image
+    out = (ws, depth, image) + ((extra_out,) if K else ())
+    return out + ((wbuf,) if return_weights else ())
 
 
 def patch_slots(rays):
