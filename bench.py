@@ -198,7 +198,8 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         out = step(args.warmup + i)
-        counters.append(out["num_samples"])
+        # samples the field actually evaluated (the early-terminating mode may evaluate fewer than were marched)
+        counters.append(out["num_evaluated"] if "num_evaluated" in out else out["num_samples"])
     barrier()
     elapsed = time.perf_counter() - t0
 

@@ -213,6 +213,16 @@ int inr_roi_align_3d_backward(const float* grad_out, const float* rois, const in
                               int32_t out_l, int32_t out_h, float spatial_scale, float* grad_input,
                               inr_stream_t s);
 
+/* Whole-ray rendering with early termination (inference, patch-interleaved layout): field evaluation and alpha
+ * compositing in one launch; a 16-ray group stops being evaluated once all its rays are below T_thresh (what the
+ * alive-ray loop of NeRFRenderer.run_cuda achieves, a5, without host round trips).  Same results as
+ * inr_nerf_forward + inr_composite_rays_patch_forward up to fp32 rounding.  weights [M] nullable (w per sample,
+ * 0 when skipped); evaluated (device uint64, nullable) is incremented by the number of samples evaluated.        */
+int inr_nerf_render(const float* xyzs, const float* deltas, const int32_t* rays, const float* rays_d /*[N,3]*/,
+                    int64_t N, int64_t M, float bound, const float* embeddings, const inr_grid_desc* desc /*host*/,
+                    const float* packed /*device*/, float density_scale, float T_thresh, float* weights_sum,
+                    float* depth, float* image, float* weights, uint64_t* evaluated, inr_stream_t s);
+
 /* Instance logits rendered in place (inference, patch-interleaved layout): extra_out[ray][ch] =
  * sum_k weights[slot(ray,k)] * logits(xyzs[slot(ray,k)])[ch]; the [M,K] logits never exist in memory.
  * xyzs/weights [M] in the patch-interleaved layout (inr_march_rays_patch_write / the weights output of

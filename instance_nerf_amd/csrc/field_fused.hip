@@ -821,6 +821,123 @@ __global__ void __launch_bounds__(kFieldThreads, INR_FIELD_MIN_WAVES) k_instance
   }
 }
 
+
+// ---- whole-ray rendering with early termination (inference) --------------------------------------------------
+// Field evaluation AND alpha compositing in one kernel: one wave owns a 16-ray group of the patch-interleaved
+// layout for all its steps, MFMA column j is fixed to ray j, the compositing state (T, colour, opacity, depth)
+// lives in the registers of lane (q = 0, j), sigma / rgb never reach HBM, and - the point - a step whose rays
+// have all dropped below T_thresh is not evaluated at all: the group stops as soon as its last ray is opaque.
+// This is what upstream's alive-ray loop buys on trained (opaque) scenes, without its per-iteration host sync.
+// On a transparent scene it evaluates exactly the samples of the two-kernel path.  weights (nullable) receives
+// w per sample (0 for skipped samples) for k_instance_render; evaluated[0] += samples actually evaluated.
+__global__ void __launch_bounds__(kFieldThreads, INR_FIELD_MIN_WAVES) k_nerf_render(
+    const float* __restrict__ x, const float* __restrict__ deltas, const int32_t* __restrict__ rays,
+    const float* __restrict__ rays_d, int64_t N, int64_t M, float bound, const float2* __restrict__ emb,
+    uint32_t emb_bytes, GridDesc G, const float4* __restrict__ packed, float density_scale, float T_thresh,
+    float* __restrict__ weights_sum, float* __restrict__ depth, float* __restrict__ image, float* __restrict__ wbuf,
+    unsigned long long* __restrict__ evaluated) {
+  extern __shared__ __attribute__((aligned(16))) float4 wl[];
+  constexpr int kStage = kNerfFloats / 4;
+  for (int i = threadIdx.x; i < kStage; i += kFieldThreads) wl[i] = packed[i];
+  LevelRec* recs = reinterpret_cast<LevelRec*>(wl + kStage);
+  stage_level_recs(G, recs);
+  __syncthreads();
+
+  constexpr int kWaves = kFieldThreads / 64;
+  const int lane = threadIdx.x & 63, q = lane >> 4, j = lane & 15;
+  const float rb = 2.0f * bound;
+  const int64_t n_groups = (N + 15) >> 4;
+  const TileSched sched = make_sched(n_groups, kWaves);
+  const bool all_hashed[4] = {slot_all_hashed(G, 0), slot_all_hashed(G, 1), slot_all_hashed(G, 2), slot_all_hashed(G, 3)};
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)emb, 0, (int)emb_bytes, 0x00020000);
+  unsigned long long n_eval = 0;
+
+  for (int64_t it = 0, grp = sched.tile(0); grp < sched.hi; grp = sched.tile(++it)) {
+    const int64_t ray = grp * 16 + j;
+    const bool has_ray = ray < N;
+    const int cnt = has_ray ? rays[ray * 3 + 2] : 0;
+    int64_t S = rays[grp * 16 * 3 + 1];
+    int gtot = cnt;
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) gtot += __shfl_xor(gtot, d, 64);
+    const bool fits = S + gtot <= M;
+    const int64_t rc = has_ray ? ray : N - 1;
+    float sh[16];
+    sh4(rays_d[rc * 3], rays_d[rc * 3 + 1], rays_d[rc * 3 + 2], sh);   // the direction is constant along a ray
+    f32x4 cin0;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) cin0[ks] = select4(q, sh[4 * ks], sh[4 * ks + 1], sh[4 * ks + 2], sh[4 * ks + 3]);
+    float T = 1.0f, cr = 0.f, cg = 0.f, cb = 0.f, ws = 0.f, tt = 0.f, dsum = 0.f;   // meaningful in lanes q == 0
+    bool done = false;
+    for (int k = 0; fits; ++k) {
+      const unsigned long long bal = __ballot(k < cnt);
+      const unsigned field = (unsigned)(bal & 0xFFFFull);
+      if (field == 0) break;
+      const unsigned donef = (unsigned)(__ballot(done) & 0xFFFFull);
+      const unsigned livef = field & ~donef;
+      const bool active = (field >> j) & 1u, live = (livef >> j) & 1u;
+      const int64_t slot = S + __popc(field & ((1u << j) - 1u));
+      S += __popc(field);
+      if (livef == 0) {                                   // every remaining ray of the group is opaque
+        if (wbuf && active && q == 0) wbuf[slot] = 0.0f;
+        continue;
+      }
+      if (lane == 0) n_eval += __popc(livef);
+      const int64_t m = live ? slot : (active ? slot : 0);
+      const float x0 = (x[m * 3 + 0] + bound) / rb, x1 = (x[m * 3 + 1] + bound) / rb, x2 = (x[m * 3 + 2] + bound) / rb;
+      f32x4 enc[2];
+      {
+        Gathered g;
+        uint32_t rec_off = (uint32_t)q * 4u * (uint32_t)sizeof(LevelRec);
+        asm volatile("" : "+v"(rec_off));
+        issue_gathers(reinterpret_cast<const LevelRec*>(reinterpret_cast<const char*>(recs) + rec_off), all_hashed, rsrc,
+                      x0, x1, x2, g);
+        __builtin_amdgcn_sched_barrier(0);
+        blend(g, enc[0], enc[1]);
+      }
+      f32x4 h1[4], h2[1];
+      mlp_layer<4, 2>(wl + kSig0 / 4, lane, enc, h1);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) h1[t] = relu4(h1[t]);
+      mlp_layer<1, 4>(wl + kSig1 / 4, lane, h1, h2);
+      f32x4 cin[2], c1[4], c2[4], o[1];
+      cin[0] = cin0;
+      cin[1] = h2[0];
+      mlp_layer<4, 2>(wl + kCol0 / 4, lane, cin, c1);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) c1[t] = relu4(c1[t]);
+      mlp_layer<4, 4>(wl + kCol1 / 4, lane, c1, c2);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) c2[t] = relu4(c2[t]);
+      mlp_layer<1, 4>(wl + kCol2 / 4, lane, c2, o);
+      if (q == 0 && active) {
+        float w = 0.0f;
+        if (live) {
+          const float2 dl = reinterpret_cast<const float2*>(deltas)[slot];
+          const float sg = __expf(h2[0][0]) * density_scale;
+          const float alpha = 1.0f - expf(-sg * dl.x);
+          w = alpha * T;
+          cr += w * __frcp_rn(1.0f + __expf(-o[0][0]));
+          cg += w * __frcp_rn(1.0f + __expf(-o[0][1]));
+          cb += w * __frcp_rn(1.0f + __expf(-o[0][2]));
+          tt += dl.y;
+          dsum += w * tt;
+          ws += w;
+          T *= 1.0f - alpha;
+          if (T < T_thresh) done = true;
+        }
+        if (wbuf) wbuf[slot] = w;
+      }
+    }
+    if (q == 0 && has_ray) {
+      const int32_t rid = rays[ray * 3];
+      weights_sum[rid] = ws; depth[rid] = dsum;
+      image[rid * 3] = cr; image[rid * 3 + 1] = cg; image[rid * 3 + 2] = cb;
+    }
+  }
+  if (evaluated && lane == 0 && n_eval) atomicAdd(evaluated, n_eval);
+}
+
 // ---- host-side packing into fragment order ------------------------------------------------------
 // W is [n_out, n_in] row-major.  kidx(ks, q) -> input column (or -1 for a zero slot).
 static inline uint16_t bf16_rne(float x) {
@@ -1024,6 +1141,30 @@ int inr_instance_render(const float* xyzs, const int32_t* rays, const float* wei
     default: k_instance_render<4><<<grid_for(k_instance_render<4>, lds, n_groups), kFieldThreads, lds, st>>>(xyzs, rays, weights, N, M, bound, e, eb, G, p, extra_out); break;
   }
   return check_launch("instance_render");
+}
+
+int inr_nerf_render(const float* xyzs, const float* deltas, const int32_t* rays, const float* rays_d, int64_t N,
+                    int64_t M, float bound, const float* embeddings, const inr_grid_desc* desc, const float* packed,
+                    float density_scale, float T_thresh, float* weights_sum, float* depth, float* image, float* weights,
+                    uint64_t* evaluated, inr_stream_t s) {
+  INR_REQUIRE(N >= 0 && M >= 0 && desc, "bad argument");
+  if (N == 0) return INR_OK;
+  INR_REQUIRE(rays && rays_d && embeddings && packed && weights_sum && depth && image, "null pointer");
+  INR_REQUIRE(M == 0 || (xyzs && deltas), "null sample arrays");
+  INR_REQUIRE(((uintptr_t)embeddings & 7) == 0 && ((uintptr_t)packed & 15) == 0 && ((uintptr_t)deltas & 7) == 0,
+              "embeddings/packed/deltas misaligned");
+  GridDesc G;
+  int rc = make_grid_desc(desc, G);
+  if (rc) return rc;
+  const uint64_t emb_bytes64 = (uint64_t)desc->offsets[desc->num_levels] * 8ull;
+  INR_REQUIRE(emb_bytes64 < (1ull << 31), "table larger than 2 GiB is not addressable by the 32-bit gather offsets");
+  const size_t lds = kNerfFloats * sizeof(float) + kLevelRecBytes;
+  const int64_t n_groups = (N + 15) / 16;
+  k_nerf_render<<<grid_for(k_nerf_render, lds, n_groups), kFieldThreads, lds, as_stream(s)>>>(
+      xyzs, deltas, rays, rays_d, N, M, bound, reinterpret_cast<const float2*>(embeddings), (uint32_t)emb_bytes64, G,
+      reinterpret_cast<const float4*>(packed), density_scale, T_thresh, weights_sum, depth, image, weights,
+      reinterpret_cast<unsigned long long*>(evaluated));
+  return check_launch("nerf_render");
 }
 
 }  // extern "C"

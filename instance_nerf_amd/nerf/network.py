@@ -209,6 +209,29 @@ class NeRFNetwork(NeRFRenderer):
         return _run_mlp(self.instance_net, self.instance_encoder(x, bound=self.bound))
 
     @torch.no_grad()
+    def nerf_render(self, xyzs, deltas, rays, rays_d, T_thresh=1e-4, want_weights=False):
+        """Field + compositing with early termination in one launch (inference, patch-interleaved layout).
+        -> (weights_sum [N], depth [N], image [N,3], weights [M] | None, evaluated int64[1]); None if not fusable."""
+        if not self._fusable:
+            return None
+        lib = _lib.load()
+        N, M = rays.shape[0], xyzs.shape[0]
+        dev = rays.device
+        ws = torch.empty(N, dtype=torch.float32, device=dev)
+        depth = torch.empty(N, dtype=torch.float32, device=dev)
+        image = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        wbuf = torch.empty(max(M, 1), dtype=torch.float32, device=dev) if want_weights else None
+        evaluated = torch.zeros(1, dtype=torch.int64, device=dev)
+        check(lib.inr_nerf_render(ptr(xyzs, torch.float32, "xyzs", allow_none=M == 0),
+                                  ptr(deltas, torch.float32, "deltas", allow_none=M == 0), ptr(rays, torch.int32, "rays"),
+                                  ptr(rays_d.contiguous(), torch.float32, "rays_d"), N, M, float(self.bound),
+                                  ptr(self.encoder.embeddings.data, torch.float32), self.encoder.desc,
+                                  ptr(self._packed_weights("nerf")), float(self.density_scale), float(T_thresh),
+                                  ptr(ws), ptr(depth), ptr(image), ptr(wbuf, allow_none=True), ptr(evaluated),
+                                  stream_ptr()), "nerf_render")
+        return ws, depth, image, wbuf, evaluated
+
+    @torch.no_grad()
     def instance_render(self, xyzs, rays, weights):
         """Rendered instance logits [N, K] from the patch-interleaved samples and their compositing weights, with
         the per-sample logits kept on chip (inference only).  None when the fused kernel does not apply."""

@@ -662,3 +662,27 @@ def test_trainer_checkpoint_roundtrip(tmp_path, room, room_bitfield, level_table
     lb = float(b.train_one_step(batch(3)))
     assert abs(la - lb) < 1e-6 * max(1.0, abs(la))
     assert torch.allclose(a.model.encoder.embeddings, b.model.encoder.embeddings, atol=1e-7)
+
+
+@pytest.mark.parametrize("density_scale", [1.0, 300.0])
+def test_fused_terminate_equals_two_kernel_path(params_k16, room, room_bitfield, density_scale):
+    """Field + compositing in one launch with per-group early termination renders the same image and instance
+    logits as the two-kernel path; on an opaque scene it evaluates only a fraction of the marched samples."""
+    from instance_nerf_amd.nerf.utils import get_rays
+    net = _network(params_k16, K=16).eval()
+    net.density_bitfield.copy_(_t(room_bitfield))
+    net.density_scale = density_scale
+    poses, intr, H, W = room.cameras(n=2, H=64, W=64, focal=32.0)
+    r = get_rays(_t(poses[1:2]), intr, 64, 64, patch=4)
+    with torch.no_grad():
+        a = net.render(r["rays_o"], r["rays_d"], bg_color=1, infer_mode="fused")
+        b = net.render(r["rays_o"], r["rays_d"], bg_color=1, infer_mode="fused_terminate")
+    assert (a["image"] - b["image"]).abs().max() < 1e-4
+    assert (a["weights_sum"] - b["weights_sum"]).abs().max() < 1e-4
+    assert (a["instance"] - b["instance"]).abs().max() < 1e-3
+    total, ev = int(b["num_samples"][0]), int(b["num_evaluated"][0])
+    assert 0 < ev <= total
+    if density_scale > 1:
+        assert ev < 0.6 * total          # opaque: most samples behind the first surface are never evaluated
+    else:
+        assert ev > 0.9 * total
