@@ -139,10 +139,12 @@ int inr_compact_alive(const int32_t* rays_alive, int64_t n_alive, int32_t* out, 
                       inr_stream_t s);
 
 /* ---- compositing for training (replaces raymarching.composite_rays_train fwd/bwd, a12/a13) ----
+ * M = rows of the sample arrays: a ray with offset + count > M was dropped by the march writer and
+ * composites to zero (its gradient rows are left untouched - the caller zero-initialises them).
  * weights [M] (nullable unless extra is given): receives the per-sample compositing weight
  * w = alpha * T (0 behind the termination point); the K-channel forward/backward use it.          */
 int inr_composite_rays_train_forward(const float* sigmas, const float* rgbs, const float* deltas,
-                                     const int32_t* rays, int64_t N, float T_thresh,
+                                     const int32_t* rays, int64_t N, int64_t M, float T_thresh,
                                      const float* extra /*[M,K] nullable*/, int32_t K,
                                      float* weights_sum, float* depth, float* image,
                                      float* extra_out /*[N,K]*/, float* weights /*[M]*/, inr_stream_t s);
@@ -151,7 +153,7 @@ int inr_composite_rays_train_backward(const float* grad_weights_sum, const float
                                       const float* rgbs, const float* extra, const float* deltas,
                                       const int32_t* rays, const float* weights_sum,
                                       const float* image, const float* weights /*[M] from forward*/,
-                                      int64_t N, float T_thresh, int32_t K,
+                                      int64_t N, int64_t M, float T_thresh, int32_t K,
                                       float* grad_sigmas, float* grad_rgbs,
                                       float* grad_extra /*[M,K] nullable*/, inr_stream_t s);
 

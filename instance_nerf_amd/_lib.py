@@ -45,8 +45,8 @@ _SIGS = {
                                  P, P, P, P, P, P, P]),
     "inr_composite_rays": (c_int32, [c_int64, c_int32, P, P, P, P, P, P, P, P, c_float, P, P, c_int32, P]),
     "inr_compact_alive": (c_int32, [P, c_int64, P, P, P]),
-    "inr_composite_rays_train_forward": (c_int32, [P, P, P, P, c_int64, c_float, P, c_int32, P, P, P, P, P, P]),
-    "inr_composite_rays_train_backward": (c_int32, [P, P, P, P, P, P, P, P, P, P, P, c_int64, c_float, c_int32,
+    "inr_composite_rays_train_forward": (c_int32, [P, P, P, P, c_int64, c_int64, c_float, P, c_int32, P, P, P, P, P, P]),
+    "inr_composite_rays_train_backward": (c_int32, [P, P, P, P, P, P, P, P, P, P, P, c_int64, c_int64, c_float, c_int32,
                                                     P, P, P, P]),
     "inr_grid_encode_forward": (c_int32, [P, P, POINTER(GridDesc), c_int64, c_float, P, P]),
     "inr_grid_encode_backward": (c_int32, [P, P, POINTER(GridDesc), c_int64, c_float, P, P]),

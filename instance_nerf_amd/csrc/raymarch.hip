@@ -443,14 +443,17 @@ __global__ void __launch_bounds__(kRayBlock) k_composite_train_fwd(const float* 
                                                                    const float* __restrict__ rgbs,
                                                                    const float* __restrict__ deltas,
                                                                    const int32_t* __restrict__ rays, int64_t N,
-                                                                   float T_thresh, float* __restrict__ weights_sum,
+                                                                   int64_t M, float T_thresh,
+                                                                   float* __restrict__ weights_sum,
                                                                    float* __restrict__ depth,
                                                                    float* __restrict__ image,
                                                                    float* __restrict__ wbuf) {
   const int64_t n = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
   if (n >= N) return;
-  const int32_t rid = rays[n * 3], off = rays[n * 3 + 1], cnt = rays[n * 3 + 2];
+  const int32_t rid = rays[n * 3], off = rays[n * 3 + 1];
+  int32_t cnt = rays[n * 3 + 2];
+  if ((int64_t)off + cnt > M) cnt = 0;     // the writer dropped this ray (sample buffer sized from mean_count)
   float T_carry = 1.0f, t_carry = 0.0f, r = 0, g = 0, b = 0, ws = 0, dsum = 0;
   for (int base = 0; base < cnt; base += 64) {
     const bool act = base + lane < cnt;
@@ -491,11 +494,14 @@ __global__ void __launch_bounds__(kRayBlock) k_composite_train_fwd(const float* 
 __global__ void __launch_bounds__(kRayBlock) k_composite_train_extra_fwd(const float* __restrict__ wbuf,
                                                                          const float* __restrict__ extra,
                                                                          const int32_t* __restrict__ rays, int64_t N,
-                                                                         int K, float* __restrict__ extra_out) {
+                                                                         int64_t M, int K,
+                                                                         float* __restrict__ extra_out) {
   const int64_t n = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
   if (n >= N) return;
-  const int32_t rid = rays[n * 3], off = rays[n * 3 + 1], cnt = rays[n * 3 + 2];
+  const int32_t rid = rays[n * 3], off = rays[n * 3 + 1];
+  int32_t cnt = rays[n * 3 + 2];
+  if ((int64_t)off + cnt > M) cnt = 0;
   float acc = 0.0f;
   if (lane < K) {
     int s = 0;
@@ -516,12 +522,14 @@ __global__ void __launch_bounds__(kRayBlock) k_composite_train_extra_fwd(const f
 __global__ void __launch_bounds__(kRayBlock) k_composite_train_bwd(
     const float* __restrict__ g_ws, const float* __restrict__ g_img, const float* __restrict__ sigmas,
     const float* __restrict__ rgbs, const float* __restrict__ deltas, const int32_t* __restrict__ rays,
-    const float* __restrict__ weights_sum, const float* __restrict__ image, int64_t N, float T_thresh,
+    const float* __restrict__ weights_sum, const float* __restrict__ image, int64_t N, int64_t M, float T_thresh,
     float* __restrict__ grad_sigmas, float* __restrict__ grad_rgbs) {
   const int64_t n = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
   if (n >= N) return;
-  const int32_t rid = rays[n * 3], off = rays[n * 3 + 1], cnt = rays[n * 3 + 2];
+  const int32_t rid = rays[n * 3], off = rays[n * 3 + 1];
+  int32_t cnt = rays[n * 3 + 2];
+  if ((int64_t)off + cnt > M) cnt = 0;     // dropped ray: its (zero-initialised) gradient rows stay untouched
   const float gr = g_img[rid * 3], gg = g_img[rid * 3 + 1], gb = g_img[rid * 3 + 2];
   const float gw = g_ws ? g_ws[rid] : 0.0f;
   const float rf = image[rid * 3], gf = image[rid * 3 + 1], bf = image[rid * 3 + 2];
@@ -564,11 +572,13 @@ __global__ void __launch_bounds__(kRayBlock) k_composite_train_bwd(
 
 __global__ void __launch_bounds__(kRayBlock) k_composite_train_extra_bwd(
     const float* __restrict__ g_extra_out, const float* __restrict__ wbuf, const int32_t* __restrict__ rays, int64_t N,
-    int K, float* __restrict__ grad_extra) {
+    int64_t M, int K, float* __restrict__ grad_extra) {
   const int64_t n = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
   if (n >= N) return;
-  const int32_t rid = rays[n * 3], off = rays[n * 3 + 1], cnt = rays[n * 3 + 2];
+  const int32_t rid = rays[n * 3], off = rays[n * 3 + 1];
+  int32_t cnt = rays[n * 3 + 2];
+  if ((int64_t)off + cnt > M) cnt = 0;
   if (lane >= K) return;
   const float g = g_extra_out[(int64_t)rid * K + lane];
   for (int s = 0; s < cnt; ++s) grad_extra[((int64_t)off + s) * K + lane] = wbuf[(int64_t)off + s] * g;
@@ -948,18 +958,19 @@ int inr_compact_alive(const int32_t* rays_alive, int64_t n_alive, int32_t* out, 
 }
 
 int inr_composite_rays_train_forward(const float* sigmas, const float* rgbs, const float* deltas, const int32_t* rays,
-                                     int64_t N, float T_thresh, const float* extra, int32_t K, float* weights_sum,
-                                     float* depth, float* image, float* extra_out, float* weights, inr_stream_t s) {
-  INR_REQUIRE(rays && weights_sum && depth && image && N >= 0, "bad argument");
+                                     int64_t N, int64_t M, float T_thresh, const float* extra, int32_t K,
+                                     float* weights_sum, float* depth, float* image, float* extra_out, float* weights,
+                                     inr_stream_t s) {
+  INR_REQUIRE(rays && weights_sum && depth && image && N >= 0 && M >= 0, "bad argument");
   INR_REQUIRE(!extra || (extra_out && weights && K > 0 && K <= 64), "extra needs extra_out, weights and 0 < K <= 64");
   if (N == 0) return INR_OK;
   INR_REQUIRE(sigmas && rgbs && deltas, "null sample arrays");
   INR_REQUIRE(((uintptr_t)deltas & 7) == 0, "deltas must be 8-byte aligned");
   hipStream_t st = as_stream(s);
-  k_composite_train_fwd<<<blocks_for(N * 64, kRayBlock), kRayBlock, 0, st>>>(sigmas, rgbs, deltas, rays, N, T_thresh,
+  k_composite_train_fwd<<<blocks_for(N * 64, kRayBlock), kRayBlock, 0, st>>>(sigmas, rgbs, deltas, rays, N, M, T_thresh,
                                                                              weights_sum, depth, image, weights);
   if (extra)
-    k_composite_train_extra_fwd<<<blocks_for(N * 64, kRayBlock), kRayBlock, 0, st>>>(weights, extra, rays, N, K,
+    k_composite_train_extra_fwd<<<blocks_for(N * 64, kRayBlock), kRayBlock, 0, st>>>(weights, extra, rays, N, M, K,
                                                                                      extra_out);
   return check_launch("composite_rays_train_forward");
 }
@@ -968,20 +979,20 @@ int inr_composite_rays_train_backward(const float* grad_weights_sum, const float
                                       const float* grad_extra_out, const float* sigmas, const float* rgbs,
                                       const float* extra, const float* deltas, const int32_t* rays,
                                       const float* weights_sum, const float* image, const float* weights, int64_t N,
-                                      float T_thresh, int32_t K, float* grad_sigmas, float* grad_rgbs,
+                                      int64_t M, float T_thresh, int32_t K, float* grad_sigmas, float* grad_rgbs,
                                       float* grad_extra, inr_stream_t s) {
   (void)extra;
-  INR_REQUIRE(grad_image && rays && weights_sum && image && grad_sigmas && grad_rgbs && N >= 0, "bad argument");
+  INR_REQUIRE(grad_image && rays && weights_sum && image && grad_sigmas && grad_rgbs && N >= 0 && M >= 0, "bad argument");
   INR_REQUIRE(!grad_extra_out || (grad_extra && weights && K > 0 && K <= 64),
               "grad_extra_out needs grad_extra, weights and 0 < K <= 64");
   if (N == 0) return INR_OK;
   hipStream_t st = as_stream(s);
   k_composite_train_bwd<<<blocks_for(N * 64, kRayBlock), kRayBlock, 0, st>>>(grad_weights_sum, grad_image, sigmas,
-                                                                             rgbs, deltas, rays, weights_sum, image, N,
+                                                                             rgbs, deltas, rays, weights_sum, image, N, M,
                                                                              T_thresh, grad_sigmas, grad_rgbs);
   if (grad_extra_out)
     k_composite_train_extra_bwd<<<blocks_for(N * 64, kRayBlock), kRayBlock, 0, st>>>(grad_extra_out, weights, rays, N,
-                                                                                     K, grad_extra);
+                                                                                     M, K, grad_extra);
   return check_launch("composite_rays_train_backward");
 }
 

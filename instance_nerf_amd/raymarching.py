@@ -231,7 +231,8 @@ class _CompositeRaysTrain(torch.autograd.Function):
         wbuf = torch.zeros(sigmas.shape[0], dtype=F32, device=dev) if K else None     # rows of dropped rays stay 0
         check(lib.inr_composite_rays_train_forward(
             ptr(sigmas, F32, "sigmas"), ptr(rgbs, F32, "rgbs"), ptr(deltas, F32, "deltas"), ptr(rays, I32, "rays"),
-            N, float(T_thresh), ptr(extra, F32, "extra", allow_none=True), K, ptr(ws), ptr(depth), ptr(image),
+            N, sigmas.shape[0], float(T_thresh), ptr(extra, F32, "extra", allow_none=True), K, ptr(ws), ptr(depth),
+            ptr(image),
             ptr(extra_out, allow_none=True), ptr(wbuf, allow_none=True), stream_ptr()), "composite_rays_train_forward")
         ctx.save_for_backward(sigmas, rgbs, extra, deltas, rays, ws, image, wbuf)
         ctx.T_thresh = T_thresh
@@ -261,7 +262,7 @@ class _CompositeRaysTrain(torch.autograd.Function):
         check(lib.inr_composite_rays_train_backward(
             ptr(g_ws), ptr(g_image), ptr(g_extra, allow_none=True), ptr(sigmas), ptr(rgbs),
             ptr(extra, allow_none=True), ptr(deltas), ptr(rays), ptr(ws), ptr(image), ptr(wbuf, allow_none=True), N,
-            float(ctx.T_thresh), K, ptr(gs), ptr(gc), ptr(ge, allow_none=True), stream_ptr()),
+            sigmas.shape[0], float(ctx.T_thresh), K, ptr(gs), ptr(gc), ptr(ge, allow_none=True), stream_ptr()),
             "composite_rays_train_backward")
         return gs, gc, ge, None, None, None
 

@@ -686,3 +686,28 @@ def test_fused_terminate_equals_two_kernel_path(params_k16, room, room_bitfield,
         assert ev < 0.6 * total          # opaque: most samples behind the first surface are never evaluated
     else:
         assert ev > 0.9 * total
+
+
+def test_composite_train_with_dropped_rays(rm, room, room_bitfield, bits_dev):
+    """Sample buffers sized from mean_count: rays that overflow M are dropped by the writer and must composite to
+    zero (and get zero gradients) - never be read past the end of the buffers (regression: GPU memory fault)."""
+    from oracle import rays
+    ro, rd = scene_rays(room, 600, seed=91)
+    aabb = np.asarray([-1, -1, -1, 1, 1, 1], np.float32)
+    nears, fars = rays.near_far_from_aabb(ro, rd, aabb, 0.05)
+    _, _, _, rr_full = rm.march_rays_train(_t(ro), _t(rd), 1.0, bits_dev, 1, 128, _t(nears), _t(fars))
+    total = int(rr_full[:, 2].sum())
+    M = (total // 2 // 128) * 128
+    x, d, dl, rr = rm.march_rays_train(_t(ro), _t(rd), 1.0, bits_dev, 1, 128, _t(nears), _t(fars), None, M, False, 128)
+    assert x.shape[0] == M
+    kept = ((rr[:, 1] + rr[:, 2]) <= M)
+    gen = torch.Generator().manual_seed(0)
+    sig = (torch.rand(M, generator=gen) * 30).to(DEV).requires_grad_(True)
+    rgb = torch.rand(M, 3, generator=gen).to(DEV).requires_grad_(True)
+    ext = torch.randn(M, 16, generator=gen).to(DEV).requires_grad_(True)
+    ws, depth, img, eo = rm.composite_rays_train(sig, rgb, dl, rr, 1e-4, extra=ext)
+    assert (ws[~kept] == 0).all() and (img[~kept] == 0).all() and (eo[~kept] == 0).all()
+    assert (ws[kept & (rr[:, 2] > 0)] > 0).all()
+    (ws.sum() + img.sum() + eo.sum()).backward()
+    last = int((rr[kept, 1] + rr[kept, 2]).max())
+    assert (sig.grad[last:] == 0).all() and (ext.grad[last:] == 0).all() and torch.isfinite(sig.grad).all()
