@@ -96,3 +96,28 @@ def update_density_grid(density_grid, sigma_fn, H, cascade, bound, decay=0.95,
     mean_density = float(np.clip(grid, 0, None).mean(dtype=np.float64))
     thresh = min(mean_density, density_thresh)
     return grid, packbits(grid.reshape(-1), thresh), mean_density
+
+
+def mark_untrained_cells(poses, intrinsic, H, cascade, bound):
+    """Cells no camera sees (upstream ``NeRFRenderer.mark_untrained_grid``): for every cascade the
+    cell centre x = (2c/(H-1) - 1) * (b - b/H) is moved into each camera frame, cam = R^T (x - t); the cell is
+    seen if z > 0, |x| < cx/fx * z + 2*b/H and |y| < cy/fy * z + 2*b/H.  Returns bool [C, H^3] in Morton order,
+    True = unseen (the renderer stores -1 there)."""
+    fx, fy, cx, cy = intrinsic
+    r = np.arange(H, dtype=np.int32)
+    xx, yy, zz = np.meshgrid(r, r, r, indexing="ij")
+    coords = np.stack([xx.ravel(), yy.ravel(), zz.ravel()], -1)
+    idx = morton3D(coords).astype(np.int64)
+    poses = np.asarray(poses, dtype=np.float32)
+    unseen = np.ones((cascade, H ** 3), dtype=bool)
+    for cas in range(cascade):
+        b = min(2.0 ** cas, bound)
+        half = b / H
+        world = (F32(2.0) * coords.astype(F32) / F32(H - 1) - F32(1.0)) * F32(b - half)
+        seen = np.zeros(coords.shape[0], dtype=bool)
+        for P in poses:
+            cam = (world - P[:3, 3]) @ P[:3, :3]
+            seen |= (cam[:, 2] > 0) & (np.abs(cam[:, 0]) < cx / fx * cam[:, 2] + half * 2) \
+                & (np.abs(cam[:, 1]) < cy / fy * cam[:, 2] + half * 2)
+        unseen[cas, idx] = ~seen
+    return unseen

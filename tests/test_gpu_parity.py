@@ -729,3 +729,19 @@ def test_training_from_scratch_with_mean_count_buffers(room):
     assert all(np.isfinite(losses))
     assert np.mean(losses[-8:]) < np.mean(losses[:8])
     assert 0.0 < float((net.density_bitfield != 0).float().mean()) <= 1.0
+
+
+def test_mark_untrained_grid_matches_oracle(room):
+    from instance_nerf_amd.nerf import NeRFNetwork
+    from oracle import occupancy
+    net = NeRFNetwork(cuda_ray=True, bound=2, min_near=0.05, grid_size=32).to(DEV)     # 2 cascades, small grid
+    poses = np.stack([room.look_at([0.8, 0.1, 0.0], target=(2, 0.2, 0.1)), room.look_at([-0.5, 0.5, 0.3], target=(0, 2, 0))])
+    intr = (40.0, 40.0, 32.0, 32.0)
+    net.mark_untrained_grid(torch.from_numpy(poses), intr)
+    ref = occupancy.mark_untrained_cells(poses, intr, 32, 2, 2.0)
+    got = (net.density_grid.cpu().numpy() == -1)
+    assert 0.05 < ref.mean() < 0.95
+    assert (got != ref).mean() < 1e-3            # float rounding at frustum boundaries only
+    # marked cells never become occupied by an update
+    net.update_extra_state()
+    assert (net.density_grid.cpu().numpy()[got] == -1).all()
