@@ -745,3 +745,36 @@ def test_mark_untrained_grid_matches_oracle(room):
     # marked cells never become occupied by an update
     net.update_extra_state()
     assert (net.density_grid.cpu().numpy()[got] == -1).all()
+
+
+def test_render_bound2_and_staged_chunks(room):
+    """bound = 2 (two cascades, desired resolution 4096) end to end vs the oracle, and staged rendering in
+    max_ray_batch chunks equals the single-batch result."""
+    from instance_nerf_amd.nerf import NeRFNetwork
+    from oracle import field, hashgrid, render
+    bound = 2.0
+    tb = hashgrid.level_table(desired_resolution=4096)
+    p = field.init_params(seed=5, table=tb, table_std=1.0)
+    net = NeRFNetwork(cuda_ray=True, bound=2, min_near=0.2, grid_size=64).to(DEV).eval()
+    assert net.cascade == 2 and (net.encoder.table["scales"] == tb["scales"]).all()
+    net.load_state_dict({"encoder.embeddings": p["embeddings"], "sigma_net.0.weight": p["sigma_w0"],
+                         "sigma_net.1.weight": p["sigma_w1"], "color_net.0.weight": p["color_w0"],
+                         "color_net.1.weight": p["color_w1"], "color_net.2.weight": p["color_w2"]}, strict=False)
+    rng = np.random.default_rng(2)
+    bits = (rng.random(2 * 64 ** 3 // 8) < 0.02).astype(np.uint8) * rng.integers(1, 256, 2 * 64 ** 3 // 8).astype(np.uint8)
+    net.density_bitfield.copy_(_t(bits))
+    n = 300
+    ro = rng.uniform(-1.2, 1.2, size=(n, 3)).astype(np.float32)
+    rd = rng.normal(size=(n, 3)).astype(np.float32)
+    rd /= np.linalg.norm(rd, axis=1, keepdims=True)
+    ref = render.render_train(ro, rd, p, tb, bits, bound=bound, cascade=2, H=64, min_near=0.2, dt_gamma=1 / 128,
+                              max_steps=512)
+    with torch.no_grad():
+        a = net.render(_t(ro)[None], _t(rd)[None], bg_color=1, dt_gamma=1 / 128, max_steps=512, infer_mode="fused")
+        b = net.render(_t(ro)[None], _t(rd)[None], bg_color=1, dt_gamma=1 / 128, max_steps=512, staged=True,
+                       max_ray_batch=64, infer_mode="fused")
+        c = net.render(_t(ro)[None], _t(rd)[None], bg_color=1, dt_gamma=1 / 128, max_steps=512, infer_mode="fused_terminate")
+    assert int(a["num_samples"][0]) == ref["total"] > 500
+    assert np.abs(a["image"][0].cpu().numpy() - ref["image"].detach().numpy()).max() < 1e-4
+    assert (a["image"] - b["image"]).abs().max() < 1e-6 and (a["weights_sum"] - b["weights_sum"]).abs().max() < 1e-6
+    assert (a["image"] - c["image"]).abs().max() < 1e-4
