@@ -114,8 +114,9 @@ int inr_march_rays_patch_write(const float* rays_o, const float* rays_d, const u
                                int32_t cascade, int32_t H, int64_t M, const float* nears,
                                const float* fars, const float* noises /*nullable*/,
                                const int32_t* rays /*[N,3] from inr_march_rays_train_count*/,
-                               float* xyzs, float* dirs, float* deltas, const void* workspace,
-                               int32_t sample_cap, inr_stream_t s);
+                               float* xyzs, float* dirs /*nullable if ray_ids*/, float* deltas,
+                               const void* workspace, int32_t sample_cap, int32_t* ray_ids /*[M] nullable*/,
+                               int32_t normalise /*1: xyzs = (p+bound)/(2 bound)*/, inr_stream_t s);
 int inr_composite_rays_patch_forward(const float* sigmas, const float* rgbs, const float* deltas,
                                      const int32_t* rays, int64_t N, int64_t M, float T_thresh,
                                      const float* extra /*[M,K] nullable*/, int32_t K,
@@ -176,6 +177,8 @@ int inr_grid_encode_backward_ordered(const float* x, const float* grad_out, cons
 int inr_sh_encode_forward(const float* d /*[M,3]*/, int64_t M, int32_t degree, float* out, inr_stream_t s);
 int inr_sh_encode_backward(const float* grad_out, const float* d, int64_t M, int32_t degree,
                            float* grad_d, inr_stream_t s);
+/* degree-4 SH of N ray directions in the lane order of the fused field kernel: out[n][q][ks] = sh[4 ks + q] */
+int inr_sh_table_q(const float* d /*[N,3]*/, int64_t N, float* out /*[N,16], 16-byte aligned*/, inr_stream_t s);
 
 /* ---- fused field evaluation (replaces NeRFNetwork.forward/density + the fork's
  * instance head, a9/a13; the MFMA kernel the north star asks for) ---------------------------
@@ -197,6 +200,13 @@ int inr_nerf_forward(const float* x, const float* d, int64_t M, const int32_t* n
                      float bound, const float* embeddings, const inr_grid_desc* desc /*host*/,
                      const float* packed /*device*/, float density_scale, float* sigma, float* rgb,
                      float* geo_feat, inr_stream_t s);
+/* Fused-frame variant of inr_nerf_forward: x01 [M,3] already normalised by inr_march_rays_patch_write
+ * (normalise = 1), directions given as a per-sample ray id + the per-ray table of inr_sh_table_q
+ * ([N,4,4]: row q holds SH components q, 4+q, 8+q, 12+q).  Same results, ~100 VALU instructions per tile less. */
+int inr_nerf_forward_table(const float* x01, const int32_t* ray_ids, const float* sh_table_q, int64_t M,
+                           float bound, const float* embeddings, const inr_grid_desc* desc /*host*/,
+                           const float* packed /*device*/, float density_scale, float* sigma, float* rgb,
+                           inr_stream_t s);
 int inr_instance_forward(const float* x, int64_t M, const int32_t* n_samples_dev, float bound,
                          const float* embeddings, const inr_grid_desc* desc /*host*/,
                          const float* packed /*device*/, int32_t K, float* logits /*[M,K]*/,

@@ -108,6 +108,18 @@ __global__ void __launch_bounds__(256) k_sh_fwd(const float* __restrict__ d, int
   for (int i = 0; i < C; ++i) out[m * C + i] = v[i];
 }
 
+// per-ray SH table in the lane order of the fused field kernel: out[n][q][ks] = sh[4*ks + q]
+__global__ void __launch_bounds__(256) k_sh_table_q(const float* __restrict__ d, int64_t N, float* __restrict__ out) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float v[16];
+  sh4(d[n * 3], d[n * 3 + 1], d[n * 3 + 2], v);
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) out[n * 16 + q * 4 + ks] = v[4 * ks + q];
+}
+
 __global__ void __launch_bounds__(256) k_sh_bwd(const float* __restrict__ go, const float* __restrict__ d,
                                                 int64_t M, int degree, float* __restrict__ gd) {
   const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -291,6 +303,14 @@ int inr_sh_encode_forward(const float* d, int64_t M, int32_t degree, float* out,
   INR_REQUIRE(d && out, "null pointer");
   k_sh_fwd<<<blocks_for(M, 256), 256, 0, as_stream(s)>>>(d, M, degree, out);
   return check_launch("sh_encode_forward");
+}
+
+int inr_sh_table_q(const float* d, int64_t N, float* out, inr_stream_t s) {
+  INR_REQUIRE(N >= 0, "negative N");
+  if (N == 0) return INR_OK;
+  INR_REQUIRE(d && out && ((uintptr_t)out & 15) == 0, "null or misaligned pointer");
+  k_sh_table_q<<<blocks_for(N, 256), 256, 0, as_stream(s)>>>(d, N, out);
+  return check_launch("sh_table_q");
 }
 
 int inr_sh_encode_backward(const float* grad_out, const float* d, int64_t M, int32_t degree, float* grad_d,

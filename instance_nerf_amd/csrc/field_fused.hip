@@ -506,13 +506,17 @@ __device__ __forceinline__ TileSched make_sched(int64_t n_tiles, int waves_per_b
 #endif
 constexpr int kFieldThreads = INR_FIELD_THREADS;   // waves of a workgroup share one 40 KB weight image in LDS
 
-template <bool kColor>
+// kTable: fused-frame fast path - x is already normalised to [0,1] by the march writer and the direction
+// encoding comes from a per-ray SH table (shq[ray][q] = this lane's four components) via a per-sample ray id:
+// ~100 VALU instructions per tile less than dividing and evaluating 16 polynomials in every lane.
+template <bool kColor, bool kTable = false>
 __global__ void __launch_bounds__(kFieldThreads, INR_FIELD_MIN_WAVES) k_nerf_fwd(const float* __restrict__ x, const float* __restrict__ d,
                                                                int64_t M, const int32_t* __restrict__ n_dev, float bound,
                                                                const float2* __restrict__ emb, uint32_t emb_bytes, GridDesc G,
                                                                const float4* __restrict__ packed, float density_scale,
                                                                float* __restrict__ sigma, float* __restrict__ rgb,
-                                                               float* __restrict__ geo) {
+                                                               float* __restrict__ geo, const int32_t* __restrict__ ray_ids,
+                                                               const float4* __restrict__ shq) {
   extern __shared__ __attribute__((aligned(16))) float4 wl[];
   constexpr int kStage = (kColor ? kNerfFloats : kCol0) / 4;
   for (int i = threadIdx.x; i < kStage; i += kFieldThreads) wl[i] = packed[i];
@@ -541,7 +545,16 @@ __global__ void __launch_bounds__(kFieldThreads, INR_FIELD_MIN_WAVES) k_nerf_fwd
     const int64_t m = tile * 16 + j;
     const bool valid = m < n;
     TileIn me;
-    load_tile_in<kColor>(x, d, valid ? m : n - 1, bound, rb, rb_inv, me);
+    f32x4 sh_in = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (kTable) {
+      static_assert(!(kTable && INR_XSPLIT), "the x-split gather normalises x itself");
+      const int64_t mm = valid ? m : n - 1;
+      me.x0 = x[mm * 3 + 0]; me.x1 = x[mm * 3 + 1]; me.x2 = x[mm * 3 + 2];
+      const float4 t4 = shq[(int64_t)ray_ids[mm] * 4 + q];
+      sh_in = f32x4{t4.x, t4.y, t4.z, t4.w};
+    } else {
+      load_tile_in<kColor>(x, d, valid ? m : n - 1, bound, rb, rb_inv, me);
+    }
 
     f32x4 enc[2];
 #if INR_XSPLIT && INR_PROBE_MODE != 1
@@ -617,11 +630,15 @@ __global__ void __launch_bounds__(kFieldThreads, INR_FIELD_MIN_WAVES) k_nerf_fwd
     }
 
     if constexpr (kColor) {
-      float sh[16];
-      sh4(me.d0, me.d1, me.d2, sh);
       f32x4 cin[2];
+      if constexpr (kTable) {
+        cin[0] = sh_in;
+      } else {
+        float sh[16];
+        sh4(me.d0, me.d1, me.d2, sh);
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) cin[0][ks] = select4(q, sh[4 * ks], sh[4 * ks + 1], sh[4 * ks + 2], sh[4 * ks + 3]);
+        for (int ks = 0; ks < 4; ++ks) cin[0][ks] = select4(q, sh[4 * ks], sh[4 * ks + 1], sh[4 * ks + 2], sh[4 * ks + 3]);
+      }
       cin[1] = h2[0];                                 // k-slot (q, r) = sigma-net row 4q+r (row 0 has zero weight)
       f32x4 c1[4], c2[4], o[1];
       mlp_layer<4, 2>(wl + kCol0 / 4, lane, cin, c1);
@@ -1074,14 +1091,36 @@ int inr_nerf_forward(const float* x, const float* d, int64_t M, const int32_t* n
     const size_t lds = kNerfFloats * sizeof(float) + kLevelRecBytes;
     const int grid = grid_for(k_nerf_fwd<true>, lds, n_tiles);
     k_nerf_fwd<true><<<grid, kFieldThreads, lds, as_stream(s)>>>(x, d, M, n_samples_dev, bound, e, emb_bytes, G, p,
-                                                      density_scale, sigma, rgb, geo_feat);
+                                                      density_scale, sigma, rgb, geo_feat, nullptr, nullptr);
   } else {
     const size_t lds = kCol0 * sizeof(float) + kLevelRecBytes;
     const int grid = grid_for(k_nerf_fwd<false>, lds, n_tiles);
     k_nerf_fwd<false><<<grid, kFieldThreads, lds, as_stream(s)>>>(x, d, M, n_samples_dev, bound, e, emb_bytes, G, p,
-                                                       density_scale, sigma, nullptr, geo_feat);
+                                                       density_scale, sigma, nullptr, geo_feat, nullptr, nullptr);
   }
   return check_launch("nerf_forward");
+}
+
+int inr_nerf_forward_table(const float* x01, const int32_t* ray_ids, const float* sh_table_q, int64_t M, float bound,
+                           const float* embeddings, const inr_grid_desc* desc, const float* packed, float density_scale,
+                           float* sigma, float* rgb, inr_stream_t s) {
+  INR_REQUIRE(M >= 0 && desc, "bad argument");
+  if (M == 0) return INR_OK;
+  INR_REQUIRE(x01 && ray_ids && sh_table_q && embeddings && packed && sigma && rgb, "null pointer");
+  INR_REQUIRE(((uintptr_t)embeddings & 7) == 0 && ((uintptr_t)packed & 15) == 0 && ((uintptr_t)sh_table_q & 15) == 0,
+              "embeddings/packed/sh_table_q misaligned");
+  GridDesc G;
+  int rc = make_grid_desc(desc, G);
+  if (rc) return rc;
+  const uint64_t emb_bytes64 = (uint64_t)desc->offsets[desc->num_levels] * 8ull;
+  INR_REQUIRE(emb_bytes64 < (1ull << 31), "table larger than 2 GiB is not addressable by the 32-bit gather offsets");
+  const size_t lds = kNerfFloats * sizeof(float) + kLevelRecBytes;
+  const int grid = grid_for(k_nerf_fwd<true, true>, lds, (M + 15) / 16);
+  k_nerf_fwd<true, true><<<grid, kFieldThreads, lds, as_stream(s)>>>(
+      x01, nullptr, M, nullptr, bound, reinterpret_cast<const float2*>(embeddings), (uint32_t)emb_bytes64, G,
+      reinterpret_cast<const float4*>(packed), density_scale, sigma, rgb, nullptr, ray_ids,
+      reinterpret_cast<const float4*>(sh_table_q));
+  return check_launch("nerf_forward_table");
 }
 
 int inr_instance_forward(const float* x, int64_t M, const int32_t* n_samples_dev, float bound, const float* embeddings,

@@ -641,7 +641,8 @@ __global__ void __launch_bounds__(kRayBlock) k_march_write_patch(MarchParams P, 
                                                                  const int32_t* __restrict__ rays,
                                                                  float* __restrict__ xyzs, float* __restrict__ dirs,
                                                                  float* __restrict__ deltas,
-                                                                 const float2* __restrict__ cap_buf, int cap) {
+                                                                 const float2* __restrict__ cap_buf, int cap,
+                                                                 int32_t* __restrict__ ray_ids, int normalise) {
   const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int off = n < N ? rays[n * 3 + 1] : 0;
   const int cnt = n < N ? rays[n * 3 + 2] : 0;
@@ -649,10 +650,15 @@ __global__ void __launch_bounds__(kRayBlock) k_march_write_patch(MarchParams P, 
   cur.init(cnt, off);                                   // all 64 lanes take part in the shuffles
   if (cnt == 0 || (int64_t)cur.S + cur.total() > M) return;   // a group that does not fit is dropped whole
   const Ray r = load_ray(rays_o, rays_d, n);
+  const float rb = 2.0f * P.bound;
   auto emit = [&](float px, float py, float pz, float dt, float delta, float) {
     const int64_t i = cur.next();
+    if (normalise) {      // x01 = (p + bound) / (2 bound), the very operation the field kernel would do per lane
+      px = (px + P.bound) / rb; py = (py + P.bound) / rb; pz = (pz + P.bound) / rb;
+    }
     xyzs[i * 3 + 0] = px; xyzs[i * 3 + 1] = py; xyzs[i * 3 + 2] = pz;
-    dirs[i * 3 + 0] = r.dx; dirs[i * 3 + 1] = r.dy; dirs[i * 3 + 2] = r.dz;
+    if (dirs) { dirs[i * 3 + 0] = r.dx; dirs[i * 3 + 1] = r.dy; dirs[i * 3 + 2] = r.dz; }
+    if (ray_ids) ray_ids[i] = (int32_t)n;
     deltas[i * 2 + 0] = dt; deltas[i * 2 + 1] = delta;
   };
   if (cnt <= cap) {
@@ -881,17 +887,17 @@ int inr_march_rays_patch_write(const float* rays_o, const float* rays_d, const u
                                float dt_gamma, int32_t max_steps, int64_t N, int32_t cascade, int32_t H, int64_t M,
                                const float* nears, const float* fars, const float* noises, const int32_t* rays,
                                float* xyzs, float* dirs, float* deltas, const void* workspace, int32_t sample_cap,
-                               inr_stream_t s) {
+                               int32_t* ray_ids, int32_t normalise, inr_stream_t s) {
   INR_REQUIRE(rays_o && rays_d && bitfield && nears && fars && rays, "null pointer");
   INR_REQUIRE(N > 0 && M >= 0, "bad sizes");
   if (M == 0) return INR_OK;
-  INR_REQUIRE(xyzs && dirs && deltas, "null output");
+  INR_REQUIRE(xyzs && deltas && (dirs || ray_ids), "null output");
   const MarchParams P = make_params(bitfield, bound, dt_gamma, max_steps, cascade, H);
   INR_REQUIRE(sample_cap == 0 || workspace, "sample_cap > 0 needs the workspace of the count pass");
   const float2* cap_buf = sample_cap > 0 ? reinterpret_cast<const float2*>(reinterpret_cast<const int32_t*>(workspace) + ws_ints(N)) : nullptr;
   k_march_write_patch<<<blocks_for(N, kRayBlock), kRayBlock, 0, as_stream(s)>>>(P, rays_o, rays_d, N, M, nears, fars,
                                                                                 noises, rays, xyzs, dirs, deltas, cap_buf,
-                                                                                sample_cap);
+                                                                                sample_cap, ray_ids, normalise);
   return check_launch("march_rays_patch_write");
 }
 

@@ -147,6 +147,29 @@ class NeRFNetwork(NeRFRenderer):
               "nerf_forward")
         return sigma, rgb, geo
 
+    @torch.no_grad()
+    def forward_table(self, x01, ray_ids, rays_d):
+        """forward() for the fused frame path: x01 [M,3] normalised samples and ray_ids int32 [M] from
+        ``march_rays_patch(table=True)``, rays_d [N,3].  The direction encoding is evaluated once per RAY into a
+        table; results equal ``forward(x, rays_d[ray_ids])``.  None when the fused kernel does not apply."""
+        if not self._fusable:
+            return None
+        lib = _lib.load()
+        rays_d = rays_d.contiguous().float().view(-1, 3)
+        N, M = rays_d.shape[0], x01.shape[0]
+        dev = x01.device
+        shq = torch.empty(N, 16, dtype=torch.float32, device=dev)
+        check(lib.inr_sh_table_q(ptr(rays_d, torch.float32, "rays_d"), N, ptr(shq), stream_ptr()), "sh_table_q")
+        sigma = torch.empty(M, dtype=torch.float32, device=dev)
+        rgb = torch.empty(M, 3, dtype=torch.float32, device=dev)
+        check(lib.inr_nerf_forward_table(ptr(x01, torch.float32, "x01", allow_none=M == 0),
+                                         ptr(ray_ids, torch.int32, "ray_ids", allow_none=M == 0), ptr(shq), M,
+                                         float(self.bound), ptr(self.encoder.embeddings.data, torch.float32),
+                                         self.encoder.desc, ptr(self._packed_weights("nerf")), 1.0,
+                                         ptr(sigma, allow_none=M == 0), ptr(rgb, allow_none=M == 0), stream_ptr()),
+              "nerf_forward_table")
+        return sigma, rgb
+
     # ---- upstream API -----------------------------------------------------------------------------
     def forward(self, x, d):
         """x [M,3] in [-bound,bound], d [M,3] unit -> sigma [M], color [M,3]."""

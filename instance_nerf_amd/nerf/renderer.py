@@ -128,10 +128,13 @@ class NeRFRenderer(nn.Module):
         elif not self.training and infer_mode in ("fused", "fused_terminate"):
             # full batch in four launches, patch-interleaved sample layout (csrc/raymarch.hip)
             counter = torch.zeros(2, dtype=torch.int32, device=device)
+            # without an instance head the samples are consumed by the NeRF field only: the writer then emits
+            # normalised coordinates + ray ids and the field reads a per-ray direction table (forward_table)
+            table = (not with_instance) and getattr(self, "_fusable", False) and hasattr(self, "forward_table")
             xyzs, dirs, deltas, rays = raymarching.march_rays_patch(
                 rays_o, rays_d, self.bound, self.density_bitfield, self.cascade, self.grid_size, nears, fars,
-                dt_gamma, max_steps, noises=noises if perturb else None, counter=counter)
-            sigmas, rgbs = self(xyzs, dirs)
+                dt_gamma, max_steps, noises=noises if perturb else None, counter=counter, table=table)
+            sigmas, rgbs = self.forward_table(xyzs, dirs, rays_d) if table else self(xyzs, dirs)
             if self.density_scale != 1:
                 sigmas = self.density_scale * sigmas
             if fused_inst:

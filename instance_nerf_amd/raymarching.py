@@ -128,13 +128,16 @@ GROUP = 16   # rays per group of the patch-interleaved layout (csrc/raymarch.hip
 
 
 def march_rays_patch(rays_o, rays_d, bound, density_bitfield, C, H, nears, fars, dt_gamma=0, max_steps=1024,
-                     noises=None, counter=None):
+                     noises=None, counter=None, table=False):
     """Full-frame inference march in the PATCH-INTERLEAVED layout (no upstream counterpart; it
     replaces the alive-ray loop).  Rays are grouped 16 at a time in the order given; inside a group
     all k-th samples are adjacent:  slot(r,k) = rays[g0,1] + sum_i min(c_i,k) + #{i<r: c_i>k}.
 
     -> xyzs [M,3], dirs [M,3], deltas [M,2], rays int32 [N,3] = (ray, offset-of-ray-in-ray-order, count);
     M is the exact sample count (one 4-byte device->host read).
+
+    ``table=True`` is the feed of ``NeRFNetwork.forward_table``: xyzs come back NORMALISED,
+    (p + bound) / (2 bound), and the second result is the int32 ray id of every sample instead of its direction.
     """
     lib = _lib.load()
     rays_o, rays_d = _f(rays_o).view(-1, 3), _f(rays_d).view(-1, 3)
@@ -155,13 +158,15 @@ def march_rays_patch(rays_o, rays_d, bound, density_bitfield, C, H, nears, fars,
           "march_rays_train_count")
     M = int(counter[0].item())
     xyzs = torch.empty(M, 3, dtype=F32, device=dev)       # every row is written: no memset needed
-    dirs = torch.empty(M, 3, dtype=F32, device=dev)
+    dirs = None if table else torch.empty(M, 3, dtype=F32, device=dev)
+    ray_ids = torch.empty(M, dtype=I32, device=dev) if table else None
     deltas = torch.empty(M, 2, dtype=F32, device=dev)
     check(lib.inr_march_rays_patch_write(*args, M, ptr(nears), ptr(fars), ptr(noises, F32, "noises", allow_none=True),
-                                         ptr(rays), ptr(xyzs, allow_none=M == 0), ptr(dirs, allow_none=M == 0),
-                                         ptr(deltas, allow_none=M == 0), ptr(ws), cap, stream_ptr()),
+                                         ptr(rays), ptr(xyzs, allow_none=M == 0), ptr(dirs, allow_none=True),
+                                         ptr(deltas, allow_none=M == 0), ptr(ws), cap,
+                                         ptr(ray_ids, allow_none=True), 1 if table else 0, stream_ptr()),
           "march_rays_patch_write")
-    return xyzs, dirs, deltas, rays
+    return xyzs, (ray_ids if table else dirs), deltas, rays
 
 
 def composite_rays_patch(sigmas, rgbs, deltas, rays, T_thresh=1e-4, extra=None, return_weights=False):

@@ -387,6 +387,29 @@ def test_patch_layout_is_a_permutation_of_ray_major(rm, room, room_bitfield, bit
     assert (first.sort().values == torch.arange(first.min(), first.min() + len(first))).all()
 
 
+def test_table_feed_equals_plain_feed_bit_for_bit(rm, room, room_bitfield, bits_dev, level_table):
+    """march_rays_patch(table=True) -> forward_table(x01, ray ids, per-ray SH table) is the same arithmetic as
+    march_rays_patch() -> forward(x, d): normalised coordinates and outputs must be bit-identical."""
+    from oracle import field, rays
+    ro, rd = scene_rays(room, 1000, seed=63)
+    aabb = np.asarray([-1, -1, -1, 1, 1, 1], np.float32)
+    nears, fars = rays.near_far_from_aabb(ro, rd, aabb, 0.05)
+    a = (_t(ro), _t(rd), 1.0, bits_dev, 1, 128, _t(nears), _t(fars))
+    xyzs, dirs, deltas, rr = rm.march_rays_patch(*a)
+    x01, ids, deltas_t, rr_t = rm.march_rays_patch(*a, table=True)
+    assert (rr == rr_t).all() and (deltas == deltas_t).all()
+    assert ((xyzs + 1.0) / 2.0 == x01).all()
+    assert (_t(rd)[ids.long()] == dirs).all()
+    net = _network(field.init_params(seed=9, table=level_table, table_std=0.3), K=0)
+    with torch.no_grad():
+        s0, c0 = net(xyzs, dirs)
+        s1, c1 = net.forward_table(x01, ids, _t(rd))
+    assert (s0 == s1).all() and (c0 == c1).all()
+    # empty batch
+    e = net.forward_table(x01[:0], ids[:0], _t(rd))
+    assert e[0].shape == (0,) and e[1].shape == (0, 3)
+
+
 def test_composite_patch_equals_ray_major(rm, room, room_bitfield, bits_dev):
     from oracle import rays
     ro, rd = scene_rays(room, 700, seed=62)
