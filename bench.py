@@ -80,35 +80,57 @@ def cpu_baseline(room, chunk=4096, budget_s=12.0, max_chunks=24):
                       f"oracle march+field+composite, {t_used:.1f} s"}
 
 
-def train_probe(dev, steps=20, warmup=5):
+def train_probe(dev, rank=0, world=1, red_dev=None, steps=20, warmup=5):
     """Secondary measurement (not the headline value): instance-field training step, BASELINE configs[2]
-    (K=64 logits, 4096 rays/batch, NeRF frozen): march -> frozen NeRF (fused) -> instance grid encode ->
-    MLP -> K-channel compositing -> CE -> backward (atomic scatter) -> fused Adam."""
+    (K=64 logits, 4096 rays/batch per GPU, NeRF frozen): march -> frozen NeRF (fused) -> instance grid encode ->
+    MLP -> K-channel compositing -> CE -> backward (atomic scatter) -> [gradient all-reduce] -> fused Adam.
+    With world > 1 this is configs[3]: every rank draws its own rays, parameters are replicated and the
+    gradients (49 MB hash table + MLP) are all-reduced over RCCL each step; all ranks must call it."""
+    import torch.distributed as dist
     from instance_nerf_amd.nerf import NeRFNetwork
     from instance_nerf_amd.nerf.provider import SyntheticRoomDataset
     from instance_nerf_amd.nerf.utils import Trainer
-    torch.manual_seed(0)
+    torch.manual_seed(0)                   # replicated initial parameters
     net = NeRFNetwork(cuda_ray=True, bound=1, min_near=0.05, density_thresh=10, num_instances=64).to(dev)
-    ds = SyntheticRoomDataset(dev, num_rays=4096, num_instances=64)
+    ds = SyntheticRoomDataset(dev, num_rays=4096, num_instances=64, rank=rank)
     net.density_bitfield.copy_(torch.from_numpy(ds.room.density_bitfield(128, 1.0)).to(dev))
-    tr = Trainer("bench", None, net, stage="instance", device=dev, iters=1000, update_extra_interval=10 ** 9)
+    tr = Trainer("bench", None, net, stage="instance", device=dev, iters=1000, update_extra_interval=10 ** 9,
+                 local_rank=rank, world_size=world)
     tr.global_step = 1                     # keep the analytic occupancy grid
     batches = [ds.batch() for _ in range(4)]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
     first = last = 0.0
     for i in range(warmup):
         l = float(tr.train_one_step(batches[i % 4]))
         first = l if i == 0 else first
-    torch.cuda.synchronize()
+    barrier()
     t0 = time.perf_counter()
     n = 0
     for i in range(steps):
         last = tr.train_one_step(batches[i % 4])
         n += int(net.step_counter[(net.local_step - 1) % 16, 0])
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
-    return {"workload": "instance-field training step, K=64, 4096 rays/batch, NeRF frozen (BASELINE configs[2])",
-            "ms_per_step": round(dt * 1e3, 3), "samples_per_step": n // steps,
-            "msamples_per_s": round(n / steps / dt / 1e6, 2), "loss_first": round(first, 4), "loss_last": round(float(last), 4)}
+    barrier()
+    elapsed = time.perf_counter() - t0
+    n_all = float(n)
+    if world > 1:
+        t = torch.tensor([elapsed, float(n)], dtype=torch.float64, device=red_dev)
+        tm, ts = t[:1].clone(), t[1:].clone()
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        dist.all_reduce(ts, op=dist.ReduceOp.SUM)
+        elapsed, n_all = float(tm.item()), float(ts.item())
+    dt = elapsed / steps
+    reduced = sum(p.numel() for g in tr.optimizer.param_groups for p in g["params"]) * 4
+    return {"workload": "instance-field training step, K=64, 4096 rays/batch per GPU, NeRF frozen "
+                        f"(BASELINE configs[{2 if world == 1 else 3}])",
+            "n_gpus": world, "ms_per_step": round(dt * 1e3, 3), "samples_per_step": int(n_all) // steps,
+            "msamples_per_s": round(n_all / steps / dt / 1e6, 2),
+            "allreduce_mb_per_step": round(reduced / 1e6, 1) if world > 1 else 0.0,
+            "loss_first": round(first, 4), "loss_last": round(float(last), 4)}
 
 
 def main():
@@ -239,10 +261,14 @@ def main():
                          "avg_launch_ms": round(avg_kernel_s * 1e3, 4), "launches": n_launch,
                          "algorithmic_bytes_per_sample": BYTES_PER_SAMPLE},
         }
-        if world == 1 and not args.no_train_probe:
-            line["train_step"] = train_probe(dev)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(room)
+    if not args.no_train_probe:
+        del net                                       # the probe builds its own (instance-head) network
+        ts = train_probe(dev, rank, world, red_dev)   # collective when world > 1: every rank runs it
+        if rank == 0:
+            line["train_step"] = ts
+    if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
