@@ -105,17 +105,25 @@ def train_probe(dev, rank=0, world=1, red_dev=None, steps=20, warmup=5):
         torch.cuda.synchronize()
 
     first = last = 0.0
+    totals = []
     for i in range(warmup):
         l = float(tr.train_one_step(batches[i % 4]))
+        totals.append(int(net.step_counter[(net.local_step - 1) % 16, 0]))
         first = l if i == 0 else first
+    # Steady state of upstream's loop: after the first 16 steps update_extra_state() sets mean_count (the mean
+    # sample total of the last steps), sample buffers get that fixed size, rays that overflow it are dropped and
+    # the step has no host sync.  The probe keeps the analytic occupancy grid, so it sets mean_count itself.
+    net.mean_count = int(sum(totals) / len(totals))
+    tr.train_one_step(batches[0])
     barrier()
     t0 = time.perf_counter()
-    n = 0
+    marched = torch.zeros((), dtype=torch.int64, device=dev)
     for i in range(steps):
         last = tr.train_one_step(batches[i % 4])
-        n += int(net.step_counter[(net.local_step - 1) % 16, 0])
+        marched += torch.clamp(net.step_counter[(net.local_step - 1) % 16, 0], max=net.mean_count)
     barrier()
     elapsed = time.perf_counter() - t0
+    n = int(marched.item())
     n_all = float(n)
     if world > 1:
         t = torch.tensor([elapsed, float(n)], dtype=torch.float64, device=red_dev)

@@ -303,6 +303,184 @@ __global__ void __launch_bounds__(kRayBlock) k_march_write(MarchParams P, const 
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Wave-per-ray marcher for SMALL batches (training: 4096 rays).  With one thread per ray the march is a chain of
+// ~600 dependent bit tests per ray and 4096 threads leave the machine empty: 0.19 ms per pass, all latency.
+// The candidate sequence c_0 = t, c_{j+1} = c_j + dt(c_j) does not depend on the occupancy grid, so a wave
+// evaluates 64 consecutive candidates at once (position, level, cell, bit test, exit distance of a miss - the
+// very expressions of march_ray) and then resolves which of them the serial walk visits: a hit goes to the next
+// candidate, a miss to the first candidate not below its exit distance.  Same samples, same bits as march_ray.
+// emit(k, px, py, pz, dt, delta, t) runs in the lanes that own a sample; k is its index along the ray.
+template <class Emit>
+__device__ __forceinline__ int march_ray_coop(const MarchParams& P, const Ray& r, float t, float far, int max_emit,
+                                              Emit&& emit) {
+  const int lane = threadIdx.x & 63;
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
+  int n = 0;
+  float last_t = t;
+  while (t < far && n < max_emit) {                       // wave-uniform
+    // candidate of this lane: `lane` sequential additions, exactly the serial accumulation
+    float c = t;
+    for (int j = 0; j < 63; ++j) c = j < lane ? c + step_dt(P, c) : c;
+    const bool in = c < far;
+    const float px = clampf(r.ox + c * r.dx, -P.bound, P.bound);
+    const float py = clampf(r.oy + c * r.dy, -P.bound, P.bound);
+    const float pz = clampf(r.oz + c * r.dz, -P.bound, P.bound);
+    const float dt = step_dt(P, c);
+    const float tn = c + dt;
+    int e0, e1;
+    (void)frexpf(fmaxf(fabsf(px), fmaxf(fabsf(py), fabsf(pz))), &e0);
+    (void)frexpf(dt * (float)P.H * 0.5f, &e1);
+    const int level = max(clampi(e0, 0, P.C - 1), clampi(e1, 0, P.C - 1));
+    const float mb = fminf(ldexpf(1.0f, level), P.bound);
+    const float rmb = 1.0f / mb;
+    const int nx = clampi((int)(((px * rmb + 1.0f) * 0.5f) * (float)P.H), 0, P.H - 1);
+    const int ny = clampi((int)(((py * rmb + 1.0f) * 0.5f) * (float)P.H), 0, P.H - 1);
+    const int nz = clampi((int)(((pz * rmb + 1.0f) * 0.5f) * (float)P.H), 0, P.H - 1);
+    const uint32_t idx = (uint32_t)level * (uint32_t)P.H3 + morton3((uint32_t)nx, (uint32_t)ny, (uint32_t)nz);
+    const bool occ = (P.bits[idx >> 3] >> (idx & 7)) & 1;
+    const float ax = ((float)nx + 0.5f) + 0.5f * r.sx;
+    const float ay = ((float)ny + 0.5f) + 0.5f * r.sy;
+    const float az = ((float)nz + 0.5f) + 0.5f * r.sz;
+    const float cx = (((ax * P.rH) * 2.0f - 1.0f) * mb - px) * r.rdx;
+    const float cy = (((ay * P.rH) * 2.0f - 1.0f) * mb - py) * r.rdy;
+    const float cz = (((az * P.rH) * 2.0f - 1.0f) * mb - pz) * r.rdz;
+    const float tt = c + fmaxf(0.0f, fminf(cx, fminf(cy, cz)));
+    // a miss continues at the first later candidate that is not below tt (do { t += dt } while (t < tt));
+    // candidates increase with the lane, so a binary search over the lanes finds it (64 = beyond this window)
+    int lo = lane + 1, hi = 64;
+#pragma unroll
+    for (int it = 0; it < 7; ++it) {
+      const int mid = (lo + hi) >> 1;
+      const float cm = __shfl(c, min(mid, 63), 64);
+      const bool below = mid < 64 && cm < tt;
+      if (lo < hi) {
+        if (below) lo = mid + 1; else hi = mid;
+      }
+    }
+    const int next = lo;
+    const uint64_t in_mask = __ballot(in);
+    const uint64_t miss_mask = __ballot(in && !occ);
+    const int n_in = __popcll(in_mask);                   // the lanes below `far` are a prefix
+    // serial walk over the window: runs of hits are taken whole, every visited miss jumps
+    uint64_t visited = 0;
+    int v = 0, last_miss = -1;
+    while (v < n_in) {
+      const uint64_t rest = miss_mask >> v;
+      const int m = rest ? v + __builtin_ctzll(rest) : 64;          // next miss at or after v
+      const int stop = min(m, n_in);
+      if (stop > v) visited |= (stop - v >= 64 ? ~0ull : ((1ull << (stop - v)) - 1ull)) << v;
+      if (m >= n_in) { v = stop; last_miss = -1; break; }
+      visited |= 1ull << m;
+      last_miss = m;
+      v = __builtin_amdgcn_readlane(next, m);
+    }
+    uint64_t emit_mask = visited & in_mask & ~miss_mask;
+    int k_new = __popcll(emit_mask);
+    bool full = false;
+    if (n + k_new >= max_emit) {                          // keep the first max_emit - n samples, the ray ends there
+      full = true;
+      const int keep = max_emit - n;
+      uint64_t m2 = emit_mask;
+      for (int i = 0; i < keep; ++i) m2 &= m2 - 1;                  // clear the `keep` lowest set bits
+      emit_mask &= ~m2;
+      k_new = keep;
+    }
+    const uint64_t before = emit_mask & lt_mask;
+    const int prev = before ? 63 - __builtin_clzll(before) : 0;
+    const float prev_tn = __shfl(tn, prev, 64);            // executed by all lanes
+    if ((emit_mask >> lane) & 1ull) {
+      const float last = before ? prev_tn : last_t;
+      emit(n + __popcll(before), px, py, pz, dt, tn - last, c);
+    }
+    if (emit_mask) last_t = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tn),
+                                                                                63 - __builtin_clzll(emit_mask)));
+    n += k_new;
+    if (full) break;
+    if (v < 64) {                                         // reached a candidate at or beyond `far` inside the window
+      t = far;
+    } else {
+      // the walk left the window: continue from c_64, and finish the pending skip of the last visited miss
+      const float c63 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tn), 63));
+      t = c63;                                            // c_63 + dt(c_63)
+      if (last_miss >= 0) {
+        const float tt_m = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tt), last_miss));
+        while (t < tt_m) t = t + step_dt(P, t);
+      }
+    }
+  }
+  return n;
+}
+
+constexpr int kCoopRaysPerBlock = 4;
+
+__global__ void __launch_bounds__(kCoopRaysPerBlock * 64) k_march_count_coop(MarchParams P, const float* __restrict__ rays_o,
+                                                                             const float* __restrict__ rays_d, int64_t N,
+                                                                             int max_steps, const float* __restrict__ nears,
+                                                                             const float* __restrict__ fars,
+                                                                             const float* __restrict__ noises,
+                                                                             int32_t* __restrict__ counts) {
+  const int64_t n = (int64_t)blockIdx.x * kCoopRaysPerBlock + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const Ray r = load_ray(rays_o, rays_d, n);
+  const float t0 = start_t(P, nears[n], noises ? noises[n] : 0.0f);
+  const int cnt = march_ray_coop(P, r, t0, fars[n], max_steps, [](int, float, float, float, float, float, float) {});
+  if ((threadIdx.x & 63) == 0) counts[n] = cnt;
+}
+
+// one workgroup: rays[n] = (n, exclusive scan of counts in ray order, count); counter = {total, N}
+__global__ void __launch_bounds__(1024) k_scan_counts(const int32_t* __restrict__ counts, int64_t N,
+                                                      int32_t* __restrict__ rays, int32_t* __restrict__ counter) {
+  __shared__ int32_t wsum[16];
+  __shared__ int32_t carry_s;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (int64_t base = 0; base < N; base += 1024) {
+    const int64_t i = base + threadIdx.x;
+    const int v = i < N ? counts[i] : 0;
+    const int incl = wave_inclusive_scan(v);
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    int off = carry_s + incl - v;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) off += wsum[w];
+    if (i < N) {
+      rays[i * 3 + 0] = (int32_t)i;
+      rays[i * 3 + 1] = off;
+      rays[i * 3 + 2] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 1023) carry_s = off + v;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    counter[0] = carry_s;
+    counter[1] = (int32_t)N;
+  }
+}
+
+__global__ void __launch_bounds__(kCoopRaysPerBlock * 64) k_march_write_coop(MarchParams P, const float* __restrict__ rays_o,
+                                                                             const float* __restrict__ rays_d, int64_t N,
+                                                                             int64_t M, const float* __restrict__ nears,
+                                                                             const float* __restrict__ fars,
+                                                                             const float* __restrict__ noises,
+                                                                             const int32_t* __restrict__ rays,
+                                                                             float* __restrict__ xyzs, float* __restrict__ dirs,
+                                                                             float* __restrict__ deltas) {
+  const int64_t n = (int64_t)blockIdx.x * kCoopRaysPerBlock + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const int off = rays[n * 3 + 1];
+  const int cnt = rays[n * 3 + 2];
+  if (cnt == 0 || (int64_t)off + cnt > M) return;
+  const Ray r = load_ray(rays_o, rays_d, n);
+  const float t0 = start_t(P, nears[n], noises ? noises[n] : 0.0f);
+  march_ray_coop(P, r, t0, fars[n], cnt, [&](int k, float px, float py, float pz, float dt, float delta, float) {
+    const int64_t i = (int64_t)off + k;
+    xyzs[i * 3 + 0] = px; xyzs[i * 3 + 1] = py; xyzs[i * 3 + 2] = pz;
+    dirs[i * 3 + 0] = r.dx; dirs[i * 3 + 1] = r.dy; dirs[i * 3 + 2] = r.dz;
+    deltas[i * 2 + 0] = dt; deltas[i * 2 + 1] = delta;
+  });
+}
+
 // a5: inference march, up to n_step samples per live ray; buffers pre-zeroed by this kernel
 __global__ void __launch_bounds__(kRayBlock) k_march_rays(MarchParams P, int64_t n_alive, int n_step,
                                                           const int32_t* __restrict__ rays_alive,
@@ -837,6 +1015,15 @@ int inr_packbits(const float* grid, int64_t n_bytes, float thresh, uint8_t* bitf
   return check_launch("packbits");
 }
 
+// Small batches (training) take the wave-per-ray marcher; both marchers produce the same bits.
+// INR_MARCH_COOP=0/1 forces the choice (tests run both).
+static bool use_coop(int64_t N, int32_t sample_cap) {
+  if (sample_cap > 0) return false;
+  const char* e = getenv("INR_MARCH_COOP");
+  if (e && *e) return atoi(e) != 0;
+  return N <= 32768;
+}
+
 static int64_t ws_ints(int64_t N) {
   const int64_t nb = (N + kRayBlock - 1) / kRayBlock;
   return ((N + nb + 64 + 1) / 2) * 2;     // even: the capture rows that follow are float2
@@ -859,6 +1046,12 @@ int inr_march_rays_train_count(const float* rays_o, const float* rays_d, const u
   int32_t* block_sums = counts + N;
   float2* cap_buf = reinterpret_cast<float2*>(counts + ws_ints(N));
   hipStream_t st = as_stream(s);
+  if (use_coop(N, sample_cap)) {
+    k_march_count_coop<<<blocks_for(N, kCoopRaysPerBlock), kCoopRaysPerBlock * 64, 0, st>>>(P, rays_o, rays_d, N, max_steps,
+                                                                                          nears, fars, noises, counts);
+    k_scan_counts<<<1, 1024, 0, st>>>(counts, N, rays, counter);
+    return check_launch("march_rays_train_count");
+  }
   k_march_count<<<nb, kRayBlock, 0, st>>>(P, rays_o, rays_d, N, max_steps, nears, fars, noises, counts, block_sums,
                                           cap_buf, sample_cap);
   k_scan_block_sums<<<1, 1024, 0, st>>>(block_sums, (int)nb, N, counter);
@@ -878,6 +1071,11 @@ int inr_march_rays_train_write(const float* rays_o, const float* rays_d, const u
   const MarchParams P = make_params(bitfield, bound, dt_gamma, max_steps, cascade, H);
   INR_REQUIRE(sample_cap == 0 || workspace, "sample_cap > 0 needs the workspace of the count pass");
   const float2* cap_buf = sample_cap > 0 ? reinterpret_cast<const float2*>(reinterpret_cast<const int32_t*>(workspace) + ws_ints(N)) : nullptr;
+  if (use_coop(N, sample_cap)) {
+    k_march_write_coop<<<blocks_for(N, kCoopRaysPerBlock), kCoopRaysPerBlock * 64, 0, as_stream(s)>>>(
+        P, rays_o, rays_d, N, M, nears, fars, noises, rays, xyzs, dirs, deltas);
+    return check_launch("march_rays_train_write");
+  }
   k_march_write<<<blocks_for(N, kRayBlock), kRayBlock, 0, as_stream(s)>>>(P, rays_o, rays_d, N, M, nears, fars, noises,
                                                                           rays, xyzs, dirs, deltas, cap_buf, sample_cap);
   return check_launch("march_rays_train_write");

@@ -66,8 +66,15 @@ def test_morton_packbits_bit_exact(rm):
     assert rm.morton3D(_t(c[:0])).numel() == 0          # empty input
 
 
+@pytest.fixture(params=["thread_per_ray", "wave_per_ray"])
+def marcher(request, monkeypatch):
+    """Both training marchers (csrc/raymarch.hip: march_ray / march_ray_coop) must produce the same bits."""
+    monkeypatch.setenv("INR_MARCH_COOP", "1" if request.param == "wave_per_ray" else "0")
+    return request.param
+
+
 @pytest.mark.parametrize("tag,gamma", [("g0", 0.0), ("g1", 1.0 / 128)])
-def test_march_train_golden_bit_exact(rm, bits_dev, tag, gamma):
+def test_march_train_golden_bit_exact(rm, bits_dev, tag, gamma, marcher):
     g = np.load(os.path.join(G, "march.npz"))
     xyzs, dirs, deltas, rays = rm.march_rays_train(_t(g["rays_o"]), _t(g["rays_d"]), 1.0, bits_dev, 1, 128,
                                                    _t(g["nears"]), _t(g["fars"]), dt_gamma=gamma, max_steps=1024,
@@ -81,7 +88,7 @@ def test_march_train_golden_bit_exact(rm, bits_dev, tag, gamma):
         assert (d[off:off + cnt] == g["rays_d"][n]).all()
 
 
-def test_march_train_large_vs_oracle(rm, room, room_bitfield, bits_dev):
+def test_march_train_large_vs_oracle(rm, room, room_bitfield, bits_dev, marcher):
     """2048 rays across two cameras: counts, offsets and every sample position bit-exact."""
     from oracle import march, rays
     ro = np.concatenate([scene_rays(room, 1024, cam=c, seed=30 + c)[0] for c in (0, 5)])
@@ -103,6 +110,31 @@ def test_march_train_large_vs_oracle(rm, room, room_bitfield, bits_dev):
     x2, _, _, _ = rm.march_rays_train(_t(ro), _t(rd), 1.0, bits_dev, 1, 128, _t(nears), _t(fars), None, M,
                                       noises=_t(noises))
     assert (x2.cpu().numpy() == cut["xyzs"]).all()
+
+
+def test_march_train_cascades_and_max_steps(rm, marcher):
+    """Two cascades with a growing step (dt_gamma > 0), a random sparse bitfield (long skips that leave a
+    64-candidate window, isolated hits) and a max_steps small enough to cut rays short."""
+    from oracle import march, rays
+    rng = np.random.default_rng(12)
+    bits = (rng.random(2 * 64 ** 3 // 8) < 0.3).astype(np.uint8) * rng.integers(1, 256, 2 * 64 ** 3 // 8).astype(np.uint8)
+    n = 777
+    ro = rng.uniform(-1.5, 1.5, size=(n, 3)).astype(np.float32)
+    rd = rng.normal(size=(n, 3)).astype(np.float32)
+    rd /= np.linalg.norm(rd, axis=1, keepdims=True)
+    rd[:5] = np.asarray([[1, 0, 0], [0, -1, 0], [0, 0, 1], [0.6, 0.8, 0], [0, 0.6, -0.8]], np.float32)   # axis-parallel
+    aabb = np.asarray([-2, -2, -2, 2, 2, 2], np.float32)
+    nears, fars = rays.near_far_from_aabb(ro, rd, aabb, 0.2)
+    noises = rng.random(n).astype(np.float32)
+    for gamma, max_steps in ((1.0 / 128, 1024), (0.0, 1024), (1.0 / 128, 23), (0.0, 64)):
+        ref = march.march_rays_train(ro, rd, bits, 2.0, 2, 64, nears, fars, noises, gamma, max_steps)
+        x, d, dl, rr = rm.march_rays_train(_t(ro), _t(rd), 2.0, _t(bits), 2, 64, _t(nears), _t(fars),
+                                           dt_gamma=gamma, max_steps=max_steps, noises=_t(noises))
+        assert (rr.cpu().numpy() == ref["rays"]).all(), (gamma, max_steps)
+        assert ref["total"] > 2000
+        assert (x.cpu().numpy()[:ref["total"]] == ref["xyzs"]).all()
+        assert (dl.cpu().numpy()[:ref["total"]] == ref["deltas"]).all()
+        assert (d.cpu().numpy()[:ref["total"]] == ref["dirs"]).all()
 
 
 def test_march_infer_step_bit_exact(rm, room, room_bitfield, bits_dev):
