@@ -1,0 +1,19 @@
+#!/bin/bash
+# PMC passes over bench.py's render loop (each counter group in its own run, kernel-trace only, bounded).
+# usage (GPU box, repo root): bash tools/pmc_bench.sh <tag>
+TAG=${1:-pmcb}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+export TMPDIR=/tmp
+cd /tmp
+run() {
+  name=$1; shift
+  timeout 240 rocprofv3 --kernel-trace --output-format csv --pmc "$@" -d $R/gpurun_out/$TAG -o $name -- \
+    python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-train-probe > $R/gpurun_out/$TAG.$name.log 2>&1
+  echo "$name rc=$?"
+}
+run grbm GRBM_GUI_ACTIVE
+run hbm_rd FETCH_SIZE
+run hbm_wr WRITE_SIZE
+run rdreq TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum TCC_HIT_sum TCC_MISS_sum
+run sq SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU
+python3 $R/tools/pmc_summary.py $R/gpurun_out/$TAG k_nerf_fwd
