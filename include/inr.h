@@ -207,6 +207,21 @@ int inr_nerf_forward_table(const float* x01, const int32_t* ray_ids, const float
                            float bound, const float* embeddings, const inr_grid_desc* desc /*host*/,
                            const float* packed /*device*/, float density_scale, float* sigma, float* rgb,
                            inr_stream_t s);
+/* Training path of the instance field (a13): weights are packed ON THE DEVICE every step (forward layout as
+ * inr_instance_pack_weights, plus the transposed sections the input-gradient kernel uses); the forward also
+ * stores the encoder output [M,32] and both hidden activations [M,64]; inr_instance_backward turns
+ * dL/dlogits [M,K] into dL/dz2, dL/dz1 [M,64] (ReLU-masked) and dL/denc [M,32] in one launch.  Weight gradients
+ * are inr_linear_wgrad(h2, dlogits), (h1, dz2), (enc, dz1); the table gradient is inr_grid_encode_backward(denc). */
+int64_t inr_instance_bwd_packed_floats(void);
+int inr_instance_pack_weights_device(const float* w0 /*[64,32]*/, const float* w1 /*[64,64]*/,
+                                     const float* w2 /*[K,64]*/, int32_t K, float* packed_fwd, float* packed_bwd,
+                                     inr_stream_t s);
+int inr_instance_forward_train(const float* x, int64_t M, float bound, const float* embeddings,
+                               const inr_grid_desc* desc /*host*/, const float* packed_fwd, int32_t K,
+                               float* logits, float* enc, float* h1, float* h2, inr_stream_t s);
+int inr_instance_backward(const float* grad_logits, int32_t K, const float* h1, const float* h2, int64_t M,
+                          const float* packed_bwd, float* grad_z2, float* grad_z1, float* grad_enc,
+                          inr_stream_t s);
 int inr_instance_forward(const float* x, int64_t M, const int32_t* n_samples_dev, float bound,
                          const float* embeddings, const inr_grid_desc* desc /*host*/,
                          const float* packed /*device*/, int32_t K, float* logits /*[M,K]*/,

@@ -666,12 +666,15 @@ __global__ void __launch_bounds__(kFieldThreads, INR_FIELD_MIN_WAVES) k_nerf_fwd
   }
 }
 
-template <int K_MT>
+// kSave (training): the encoder output and the two hidden activations are also written, row-major, for the
+// weight gradients and the ReLU masks of k_instance_bwd.
+template <int K_MT, bool kSave = false>
 __global__ void __launch_bounds__(kFieldThreads, INR_FIELD_MIN_WAVES) k_instance_fwd(const float* __restrict__ x, int64_t M,
                                                                    const int32_t* __restrict__ n_dev, float bound,
                                                                    const float2* __restrict__ emb, uint32_t emb_bytes,
                                                                    GridDesc G, const float4* __restrict__ packed,
-                                                                   float* __restrict__ logits) {
+                                                                   float* __restrict__ logits, float* __restrict__ enc_out,
+                                                                   float* __restrict__ h1_out, float* __restrict__ h2_out) {
   extern __shared__ __attribute__((aligned(16))) float4 wl[];
   constexpr int K = K_MT * 16;
   constexpr int kStage = (kIns2 + K * 64) / 4;
@@ -751,7 +754,130 @@ __global__ void __launch_bounds__(kFieldThreads, INR_FIELD_MIN_WAVES) k_instance
         float4 v = make_float4(o[mt][0], o[mt][1], o[mt][2], o[mt][3]);
         *reinterpret_cast<float4*>(logits + m * K + 16 * mt + 4 * q) = v;
       }
+      if constexpr (kSave) {
+        // lane q holds encoder features 4q..4q+3 and 16+4q..16+4q+3, and rows 16t+4q..+3 of every hidden tile
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+          *reinterpret_cast<float4*>(enc_out + m * 32 + 16 * t + 4 * q) = make_float4(enc[t][0], enc[t][1], enc[t][2], enc[t][3]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          *reinterpret_cast<float4*>(h1_out + m * 64 + 16 * t + 4 * q) = make_float4(h1[t][0], h1[t][1], h1[t][2], h1[t][3]);
+          *reinterpret_cast<float4*>(h2_out + m * 64 + 16 * t + 4 * q) = make_float4(h2[t][0], h2[t][1], h2[t][2], h2[t][3]);
+        }
+      }
     }
+  }
+}
+
+// ---- instance MLP input gradients (training) ----------------------------------------------------------------
+// The chain dL/dlogits -> dL/dz2 -> dL/dz1 -> dL/denc is the same transposed formulation with W^T as the A
+// operand: G^T = W^T . dY^T, so every layer's D registers are again the next layer's B operand.  Sections of
+// `packed`: W2^T (64 x 64, inputs beyond K zero), W1^T (64 x 64), W0^T (32 x 64).  ReLU masks come from the saved
+// activations (h > 0), loaded in the D-register layout with one float4 per tile.
+constexpr int kBwd2 = 0;
+constexpr int kBwd1 = kBwd2 + 64 * 64;
+constexpr int kBwd0 = kBwd1 + 64 * 64;
+constexpr int kBwdFloats = kBwd0 + 32 * 64;
+
+__device__ __forceinline__ f32x4 load4(const float* p) {
+  const float4 v = *reinterpret_cast<const float4*>(p);
+  return f32x4{v.x, v.y, v.z, v.w};
+}
+__device__ __forceinline__ void store4(float* p, f32x4 v) {
+  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ f32x4 mask4(f32x4 g, f32x4 h) {
+  return f32x4{h[0] > 0.f ? g[0] : 0.f, h[1] > 0.f ? g[1] : 0.f, h[2] > 0.f ? g[2] : 0.f, h[3] > 0.f ? g[3] : 0.f};
+}
+
+__global__ void __launch_bounds__(kFieldThreads, INR_FIELD_MIN_WAVES) k_instance_bwd(const float* __restrict__ dlogits, int K,
+                                                                   const float* __restrict__ h1, const float* __restrict__ h2,
+                                                                   int64_t M, const float4* __restrict__ packed,
+                                                                   float* __restrict__ dz2, float* __restrict__ dz1,
+                                                                   float* __restrict__ denc) {
+  extern __shared__ __attribute__((aligned(16))) float4 wl[];
+  for (int i = threadIdx.x; i < kBwdFloats / 4; i += kFieldThreads) wl[i] = packed[i];
+  __syncthreads();
+  constexpr int kWaves = kFieldThreads / 64;
+  const int lane = threadIdx.x & 63, q = lane >> 4, j = lane & 15;
+  const int64_t n_tiles = (M + 15) >> 4;
+  const TileSched sched = make_sched(n_tiles, kWaves);
+  for (int64_t it = 0, tile = sched.tile(0); tile < sched.hi; tile = sched.tile(++it)) {
+    const int64_t m = tile * 16 + j;
+    const bool valid = m < M;
+    const int64_t mm = valid ? m : M - 1;
+    f32x4 g[4], hh[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int c = 16 * t + 4 * q;
+      g[t] = (valid && c < K) ? load4(dlogits + mm * K + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+      hh[t] = load4(h2 + mm * 64 + c);
+    }
+    f32x4 a[4], b[4], c0[2];
+    mlp_layer<4, 4>(wl + kBwd2 / 4, lane, g, a);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      a[t] = mask4(a[t], hh[t]);
+      hh[t] = load4(h1 + mm * 64 + 16 * t + 4 * q);
+    }
+    if (valid) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) store4(dz2 + m * 64 + 16 * t + 4 * q, a[t]);
+    }
+    mlp_layer<4, 4>(wl + kBwd1 / 4, lane, a, b);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) b[t] = mask4(b[t], hh[t]);
+    if (valid) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) store4(dz1 + m * 64 + 16 * t + 4 * q, b[t]);
+    }
+    mlp_layer<2, 4>(wl + kBwd0 / 4, lane, b, c0);
+    if (valid) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) store4(denc + m * 32 + 16 * t + 4 * q, c0[t]);
+    }
+  }
+}
+
+// Device-side weight packing for training (the weights change every step; the host packers above would cost a
+// device->host->device round trip per step).  One thread per packed bf16 pair position; same layout and
+// rounding as pack_section_bf16.  transpose: the section holds W^T of the row-major [n_rows_w, n_cols_w] weight.
+struct PackJob {
+  const float* W;
+  int w_rows, w_cols;      // row-major weight as stored by nn.Linear: [out, in]
+  int n_out, n_in;         // logical section size (rows = MFMA output rows, cols = inputs)
+  int n_mt, n_s;
+  int transpose;
+  int dst_off;             // float offset of the section in the packed buffer
+};
+struct PackJobs {
+  PackJob j[6];
+};
+
+__device__ __forceinline__ uint16_t bf16_rne_dev(float x) {
+  uint32_t u = __float_as_uint(x);
+  if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x40u);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
+__global__ void __launch_bounds__(256) k_pack_weights(PackJobs jobs, float* __restrict__ packed_fwd,
+                                                      float* __restrict__ packed_bwd) {
+  const PackJob J = jobs.j[blockIdx.y];
+  const int total = J.n_mt * J.n_s * 64 * 8;
+  float* base = (blockIdx.y < 3 ? packed_fwd : packed_bwd) + J.dst_off;
+  uint16_t* dst = reinterpret_cast<uint16_t*>(base);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int e = i & 7, lane = (i >> 3) & 63, rest = i >> 9;
+    const int st = rest % J.n_s, mt = rest / J.n_s;
+    const int row = 16 * mt + (lane & 15);
+    const int col = 16 * (2 * st + (e >> 2)) + 4 * (lane >> 4) + (e & 3);
+    float v = 0.f;
+    if (row < J.n_out && col < J.n_in) v = J.transpose ? J.W[(size_t)col * J.w_cols + row] : J.W[(size_t)row * J.w_cols + col];
+    const uint16_t hi = bf16_rne_dev(v);
+    const uint16_t lo = bf16_rne_dev(v - __uint_as_float((uint32_t)hi << 16));
+    dst[((((size_t)(mt * J.n_s + st) * 2 + 0) * 64 + lane) * 8) + e] = hi;
+    dst[((((size_t)(mt * J.n_s + st) * 2 + 1) * 64 + lane) * 8) + e] = lo;
   }
 }
 
@@ -1144,12 +1270,81 @@ int inr_instance_forward(const float* x, int64_t M, const int32_t* n_samples_dev
   const int64_t n_tiles = (M + 15) / 16;
   hipStream_t st = as_stream(s);
   switch (K / 16) {
-    case 1: k_instance_fwd<1><<<grid_for(k_instance_fwd<1>, lds, n_tiles), kFieldThreads, lds, st>>>(x, M, n_samples_dev, bound, e, eb, G, p, logits); break;
-    case 2: k_instance_fwd<2><<<grid_for(k_instance_fwd<2>, lds, n_tiles), kFieldThreads, lds, st>>>(x, M, n_samples_dev, bound, e, eb, G, p, logits); break;
-    case 3: k_instance_fwd<3><<<grid_for(k_instance_fwd<3>, lds, n_tiles), kFieldThreads, lds, st>>>(x, M, n_samples_dev, bound, e, eb, G, p, logits); break;
-    default: k_instance_fwd<4><<<grid_for(k_instance_fwd<4>, lds, n_tiles), kFieldThreads, lds, st>>>(x, M, n_samples_dev, bound, e, eb, G, p, logits); break;
+    case 1: k_instance_fwd<1><<<grid_for(k_instance_fwd<1>, lds, n_tiles), kFieldThreads, lds, st>>>(x, M, n_samples_dev, bound, e, eb, G, p, logits, nullptr, nullptr, nullptr); break;
+    case 2: k_instance_fwd<2><<<grid_for(k_instance_fwd<2>, lds, n_tiles), kFieldThreads, lds, st>>>(x, M, n_samples_dev, bound, e, eb, G, p, logits, nullptr, nullptr, nullptr); break;
+    case 3: k_instance_fwd<3><<<grid_for(k_instance_fwd<3>, lds, n_tiles), kFieldThreads, lds, st>>>(x, M, n_samples_dev, bound, e, eb, G, p, logits, nullptr, nullptr, nullptr); break;
+    default: k_instance_fwd<4><<<grid_for(k_instance_fwd<4>, lds, n_tiles), kFieldThreads, lds, st>>>(x, M, n_samples_dev, bound, e, eb, G, p, logits, nullptr, nullptr, nullptr); break;
   }
   return check_launch("instance_forward");
+}
+
+int64_t inr_instance_bwd_packed_floats(void) { return kBwdFloats; }
+
+int inr_instance_pack_weights_device(const float* w0, const float* w1, const float* w2, int32_t K, float* packed_fwd,
+                                     float* packed_bwd, inr_stream_t s) {
+#if INR_MLP_FP32
+  set_error("instance_pack_weights_device: built with INR_MLP_FP32 (no device packer for the fp32 layout)");
+  return INR_EINVAL;
+#else
+  INR_REQUIRE(w0 && w1 && w2 && packed_fwd && packed_bwd, "null pointer");
+  INR_REQUIRE(K > 0 && K <= 64 && K % 16 == 0, "K must be 16, 32, 48 or 64");
+  INR_REQUIRE(((uintptr_t)packed_fwd & 15) == 0 && ((uintptr_t)packed_bwd & 15) == 0, "packed buffers misaligned");
+  PackJobs jobs;
+  //           W   rows cols  n_out n_in  mt      steps T  offset
+  jobs.j[0] = {w0, 64, 32, 64, 32, 4, 1, 0, kIns0};
+  jobs.j[1] = {w1, 64, 64, 64, 64, 4, 2, 0, kIns1};
+  jobs.j[2] = {w2, K, 64, K, 64, K / 16, 2, 0, kIns2};
+  jobs.j[3] = {w2, K, 64, 64, K, 4, 2, 1, kBwd2};
+  jobs.j[4] = {w1, 64, 64, 64, 64, 4, 2, 1, kBwd1};
+  jobs.j[5] = {w0, 64, 32, 32, 64, 2, 2, 1, kBwd0};
+  k_pack_weights<<<dim3(8, 6), 256, 0, as_stream(s)>>>(jobs, packed_fwd, packed_bwd);
+  return check_launch("instance_pack_weights_device");
+#endif
+}
+
+int inr_instance_forward_train(const float* x, int64_t M, float bound, const float* embeddings, const inr_grid_desc* desc,
+                               const float* packed, int32_t K, float* logits, float* enc, float* h1, float* h2,
+                               inr_stream_t s) {
+  INR_REQUIRE(M >= 0 && desc, "bad argument");
+  if (M == 0) return INR_OK;
+  INR_REQUIRE(x && embeddings && packed && logits && enc && h1 && h2, "null pointer");
+  INR_REQUIRE(K > 0 && K <= 64 && K % 16 == 0, "K must be 16, 32, 48 or 64");
+  INR_REQUIRE(((uintptr_t)embeddings & 7) == 0 &&
+                  (((uintptr_t)packed | (uintptr_t)logits | (uintptr_t)enc | (uintptr_t)h1 | (uintptr_t)h2) & 15) == 0,
+              "embeddings/packed/outputs misaligned");
+  GridDesc G;
+  int rc = make_grid_desc(desc, G);
+  if (rc) return rc;
+  const float2* e = reinterpret_cast<const float2*>(embeddings);
+  const float4* p = reinterpret_cast<const float4*>(packed);
+  const uint64_t emb_bytes64 = (uint64_t)desc->offsets[desc->num_levels] * 8ull;
+  INR_REQUIRE(emb_bytes64 < (1ull << 31), "table larger than 2 GiB is not addressable by the 32-bit gather offsets");
+  const uint32_t eb = (uint32_t)emb_bytes64;
+  const size_t lds = (size_t)(kIns2 + K * 64) * sizeof(float) + kLevelRecBytes;
+  const int64_t n_tiles = (M + 15) / 16;
+  hipStream_t st = as_stream(s);
+  switch (K / 16) {
+    case 1: k_instance_fwd<1, true><<<grid_for(k_instance_fwd<1, true>, lds, n_tiles), kFieldThreads, lds, st>>>(x, M, nullptr, bound, e, eb, G, p, logits, enc, h1, h2); break;
+    case 2: k_instance_fwd<2, true><<<grid_for(k_instance_fwd<2, true>, lds, n_tiles), kFieldThreads, lds, st>>>(x, M, nullptr, bound, e, eb, G, p, logits, enc, h1, h2); break;
+    case 3: k_instance_fwd<3, true><<<grid_for(k_instance_fwd<3, true>, lds, n_tiles), kFieldThreads, lds, st>>>(x, M, nullptr, bound, e, eb, G, p, logits, enc, h1, h2); break;
+    default: k_instance_fwd<4, true><<<grid_for(k_instance_fwd<4, true>, lds, n_tiles), kFieldThreads, lds, st>>>(x, M, nullptr, bound, e, eb, G, p, logits, enc, h1, h2); break;
+  }
+  return check_launch("instance_forward_train");
+}
+
+int inr_instance_backward(const float* grad_logits, int32_t K, const float* h1, const float* h2, int64_t M,
+                          const float* packed_bwd, float* grad_z2, float* grad_z1, float* grad_enc, inr_stream_t s) {
+  INR_REQUIRE(M >= 0, "negative M");
+  if (M == 0) return INR_OK;
+  INR_REQUIRE(grad_logits && h1 && h2 && packed_bwd && grad_z2 && grad_z1 && grad_enc, "null pointer");
+  INR_REQUIRE(K > 0 && K <= 64 && K % 16 == 0, "K must be 16, 32, 48 or 64");
+  INR_REQUIRE((((uintptr_t)grad_logits | (uintptr_t)h1 | (uintptr_t)h2 | (uintptr_t)packed_bwd | (uintptr_t)grad_z2 |
+                (uintptr_t)grad_z1 | (uintptr_t)grad_enc) & 15) == 0, "arrays must be 16-byte aligned");
+  const size_t lds = (size_t)kBwdFloats * sizeof(float);
+  const int64_t n_tiles = (M + 15) / 16;
+  k_instance_bwd<<<grid_for(k_instance_bwd, lds, n_tiles), kFieldThreads, lds, as_stream(s)>>>(
+      grad_logits, K, h1, h2, M, reinterpret_cast<const float4*>(packed_bwd), grad_z2, grad_z1, grad_enc);
+  return check_launch("instance_backward");
 }
 
 int inr_instance_render(const float* xyzs, const int32_t* rays, const float* weights, int64_t N, int64_t M, float bound,

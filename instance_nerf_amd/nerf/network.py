@@ -51,6 +51,59 @@ class _LinearFn(torch.autograd.Function):
         return gx, gw
 
 
+class _InstanceFieldFn(torch.autograd.Function):
+    """Instance field x -> logits for TRAINING in two fused launches (csrc/field_fused.hip): the forward gathers,
+    runs the three layers on the matrix cores and keeps enc / h1 / h2 for the backward; the backward runs the
+    whole input-gradient chain (W^T as the MFMA A operand, ReLU masks from the saved activations) in one kernel.
+    Weight gradients stay on the split-K kernel, the table gradient on the atomic scatter."""
+
+    @staticmethod
+    def forward(ctx, x, emb, w0, w1, w2, desc, bound):
+        lib = _lib.load()
+        f32 = torch.float32
+        K, M, dev = w2.shape[0], x.shape[0], x.device
+        pf = torch.empty(lib.inr_instance_packed_floats(K), dtype=f32, device=dev)
+        pb = torch.empty(lib.inr_instance_bwd_packed_floats(), dtype=f32, device=dev)
+        check(lib.inr_instance_pack_weights_device(ptr(w0.detach().contiguous(), f32, "w0"),
+                                                   ptr(w1.detach().contiguous(), f32, "w1"),
+                                                   ptr(w2.detach().contiguous(), f32, "w2"), K, ptr(pf), ptr(pb),
+                                                   stream_ptr()), "instance_pack_weights_device")
+        logits = torch.empty(M, K, dtype=f32, device=dev)
+        act = torch.empty(M, 32 + 64 + 64, dtype=f32, device=dev) if M else torch.empty(0, 160, dtype=f32, device=dev)
+        enc, h1, h2 = act.view(-1)[:M * 32].view(M, 32), act.view(-1)[M * 32:M * 96].view(M, 64), \
+            act.view(-1)[M * 96:].view(M, 64)
+        check(lib.inr_instance_forward_train(ptr(x, f32, "x", allow_none=M == 0), M, float(bound),
+                                             ptr(emb.detach(), f32, "embeddings"), desc, ptr(pf), K,
+                                             ptr(logits, allow_none=M == 0), ptr(enc, allow_none=M == 0),
+                                             ptr(h1, allow_none=M == 0), ptr(h2, allow_none=M == 0), stream_ptr()),
+              "instance_forward_train")
+        ctx.save_for_backward(x, enc, h1, h2, pb, emb)
+        ctx.desc, ctx.bound, ctx.K = desc, bound, K
+        return logits
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        f32 = torch.float32
+        x, enc, h1, h2, pb, emb = ctx.saved_tensors
+        K, M, dev = ctx.K, x.shape[0], x.device
+        g = g.contiguous().float()
+        grads = torch.empty(M, 64 + 64 + 32, dtype=f32, device=dev)
+        dz2, dz1, denc = grads.view(-1)[:M * 64].view(M, 64), grads.view(-1)[M * 64:M * 128].view(M, 64), \
+            grads.view(-1)[M * 128:].view(M, 32)
+        gw = torch.zeros(64 * 32 + 64 * 64 + K * 64, dtype=f32, device=dev)      # one fill for the three weights
+        gw0, gw1, gw2 = gw[:2048].view(64, 32), gw[2048:6144].view(64, 64), gw[6144:].view(K, 64)
+        g_emb = torch.zeros_like(emb)
+        if M:
+            check(lib.inr_instance_backward(ptr(g, f32, "grad_logits"), K, ptr(h1), ptr(h2), M, ptr(pb), ptr(dz2),
+                                            ptr(dz1), ptr(denc), stream_ptr()), "instance_backward")
+            for xin, gy, n_in, n_out, out in ((h2, g, 64, K, gw2), (h1, dz2, 64, 64, gw1), (enc, dz1, 32, 64, gw0)):
+                check(lib.inr_linear_wgrad(ptr(xin), ptr(gy), M, n_in, n_out, ptr(out), stream_ptr()), "linear_wgrad")
+            check(lib.inr_grid_encode_backward_ordered(ptr(x), ptr(denc), None, ctx.desc, M, float(ctx.bound),
+                                                       ptr(g_emb), stream_ptr()), "grid_encode_backward")
+        return None, g_emb, gw0, gw1, gw2, None, None
+
+
 class HipLinear(nn.Linear):
     """nn.Linear(bias=False) whose backward uses the HIP weight-gradient kernel (same parameters/state dict)."""
 
@@ -98,6 +151,7 @@ class NeRFNetwork(NeRFRenderer):
         self._fusable_inst = (self.num_instances in (16, 32, 48, 64) and num_layers_instance == 3
                               and hidden_dim_instance == 64)
         self._packed = {}
+        self.fused_instance_train = True     # False: HIP encoder + rocBLAS layers (the composable path)
 
     # ---- packed MFMA weights (cached until a weight tensor changes) ------------------------------
     def _packed_weights(self, which):
@@ -229,6 +283,11 @@ class NeRFNetwork(NeRFRenderer):
                                            self.instance_encoder.desc, ptr(self._packed_weights("instance")),
                                            self.num_instances, ptr(out), stream_ptr()), "instance_forward")
             return out
+        if (self._fusable_inst and self.fused_instance_train and x.is_cuda and all(p.requires_grad for p in params)
+                and torch.is_grad_enabled() and not x.requires_grad):
+            return _InstanceFieldFn.apply(x.contiguous().float(), self.instance_encoder.embeddings,
+                                          self.instance_net[0].weight, self.instance_net[1].weight,
+                                          self.instance_net[2].weight, self.instance_encoder.desc, self.bound)
         return _run_mlp(self.instance_net, self.instance_encoder(x, bound=self.bound))
 
     @torch.no_grad()

@@ -833,3 +833,79 @@ def test_render_bound2_and_staged_chunks(room):
     assert np.abs(a["image"][0].cpu().numpy() - ref["image"].detach().numpy()).max() < 1e-4
     assert (a["image"] - b["image"]).abs().max() < 1e-6 and (a["weights_sum"] - b["weights_sum"]).abs().max() < 1e-6
     assert (a["image"] - c["image"]).abs().max() < 1e-4
+
+
+@pytest.mark.parametrize("K", [16, 48, 64])
+def test_instance_field_fused_training_kernels(level_table, K):
+    """C ABI of the fused instance-field training path: device-packed weights, forward with saved activations and
+    the one-launch input-gradient chain, each against fp32 torch on the same inputs (ReLU masks taken from the
+    kernel's own activations: a pre-activation within 1e-5 of zero may legitimately fall on either side)."""
+    from instance_nerf_amd import _lib
+    from instance_nerf_amd._lib import check, ptr, stream_ptr
+    from oracle import field, hashgrid
+    lib = _lib.load()
+    p = field.init_params(seed=21, table=level_table, table_std=0.5, K=K)
+    net = _network(p, K=K)
+    gen = torch.Generator().manual_seed(4)
+    M = 5000 + 7                                        # last tile is partial
+    x = (torch.rand(M, 3, generator=gen) * 2 - 1).to(DEV)
+    g = torch.randn(M, K, generator=gen).to(DEV)
+    w0, w1, w2 = [l.weight.detach() for l in net.instance_net]
+    emb = net.instance_encoder.embeddings.data
+    pf = torch.empty(lib.inr_instance_packed_floats(K), device=DEV)
+    pb = torch.empty(lib.inr_instance_bwd_packed_floats(), device=DEV)
+    check(lib.inr_instance_pack_weights_device(ptr(w0), ptr(w1), ptr(w2), K, ptr(pf), ptr(pb), stream_ptr()), "pack")
+    assert (pf.cpu() == net._packed_weights("instance").cpu()).all()      # same bits as the host packer
+    logits, enc = torch.empty(M, K, device=DEV), torch.empty(M, 32, device=DEV)
+    h1, h2 = torch.empty(M, 64, device=DEV), torch.empty(M, 64, device=DEV)
+    check(lib.inr_instance_forward_train(ptr(x), M, 1.0, ptr(emb), net.instance_encoder.desc, ptr(pf), K, ptr(logits),
+                                         ptr(enc), ptr(h1), ptr(h2), stream_ptr()), "forward_train")
+    rel = lambda a, b: float((a - b).abs().max() / b.abs().max())
+    with torch.no_grad():
+        enc_r = hashgrid.encode(x.cpu(), p["inst_embeddings"], 1.0, level_table).to(DEV)
+        h1_r = torch.relu(enc_r @ w0.t())
+        h2_r = torch.relu(h1_r @ w1.t())
+        lg_r = h2_r @ w2.t()
+    assert rel(enc, enc_r) < 1e-5 and rel(h1, h1_r) < 1e-4 and rel(h2, h2_r) < 1e-4 and rel(logits, lg_r) < 1e-4
+    with torch.no_grad():
+        assert (net.eval().instance(x) == logits).all()                   # inference kernel: identical logits
+    dz2, dz1, denc = torch.empty(M, 64, device=DEV), torch.empty(M, 64, device=DEV), torch.empty(M, 32, device=DEV)
+    check(lib.inr_instance_backward(ptr(g), K, ptr(h1), ptr(h2), M, ptr(pb), ptr(dz2), ptr(dz1), ptr(denc),
+                                    stream_ptr()), "backward")
+    dz2_r = (g @ w2) * (h2 > 0)
+    dz1_r = (dz2_r @ w1) * (h1 > 0)
+    denc_r = dz1_r @ w0
+    assert rel(dz2, dz2_r) < 1e-4 and rel(dz1, dz1_r) < 1e-4 and rel(denc, denc_r) < 1e-4
+    # empty batch
+    assert lib.inr_instance_backward(None, K, None, None, 0, None, None, None, None, stream_ptr()) == 0
+
+
+def test_instance_field_fused_training_autograd(level_table):
+    """End to end through autograd: the fused path and the composable path (HIP encoder + rocBLAS layers) give the
+    same logits and gradients, up to the handful of samples whose ReLU pre-activation is within rounding of zero
+    (those contribute to one path and not the other)."""
+    from oracle import field
+    K = 64
+    p = field.init_params(seed=22, table=level_table, table_std=0.5, K=K)
+    net = _network(p, K=K).train()
+    gen = torch.Generator().manual_seed(5)
+    M = 6000
+    x = (torch.rand(M, 3, generator=gen) * 2 - 1).to(DEV)
+    gy = torch.randn(M, K, generator=gen).to(DEV)
+    params = [net.instance_encoder.embeddings] + [l.weight for l in net.instance_net]
+    res = {}
+    for fused in (True, False):
+        net.fused_instance_train = fused
+        for q in params:
+            q.grad = None
+        out = net.instance(x)
+        assert out.requires_grad
+        out.backward(gy)
+        res[fused] = (out.detach().clone(), [q.grad.detach().clone() for q in params])
+    assert (res[True][0] - res[False][0]).abs().max() < 1e-4 * res[False][0].abs().max()
+    for a, b in zip(res[True][1], res[False][1]):
+        assert a.shape == b.shape
+        assert torch.linalg.norm(a - b) < 2e-2 * torch.linalg.norm(b)
+        if a.shape[0] > 64:          # the table: a flipped sample only touches its own 16 x 8 rows
+            bad = ((a - b).abs() > 1e-3 * b.abs().max()).sum().item()
+            assert bad <= 0.002 * int((b != 0).sum()), bad
