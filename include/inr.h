@@ -155,7 +155,7 @@ int inr_composite_rays_train_backward(const float* grad_weights_sum, const float
                                       const int32_t* rays, const float* weights_sum,
                                       const float* image, const float* weights /*[M] from forward*/,
                                       int64_t N, int64_t M, float T_thresh, int32_t K,
-                                      float* grad_sigmas, float* grad_rgbs,
+                                      float* grad_sigmas, float* grad_rgbs /*both nullable: frozen NeRF*/,
                                       float* grad_extra /*[M,K] nullable*/, inr_stream_t s);
 
 /* ---- hash grid (replaces gridencoder grid_encode_forward / _backward, a7/a8) -------- */
@@ -268,6 +268,16 @@ int inr_linear_wgrad(const float* x, const float* grad_y, int64_t M, int32_t n_i
 int inr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                   float lr, float beta1, float beta2, float eps, int32_t step, float grad_scale,
                   inr_stream_t s);
+/* The same update for up to 16 tensors in one launch; host arrays of device pointers / sizes / learning rates. */
+int inr_adam_step_multi(int32_t n_tensors, float* const* params, const float* const* grads, float* const* exp_avgs,
+                        float* const* exp_avg_sqs, const int64_t* numels, const float* lrs, float beta1, float beta2,
+                        float eps, int32_t step, float grad_scale, inr_stream_t s);
+/* Tail of NeRFRenderer.run_cuda (a14): image_out = image + (1 - weights_sum) * bg;
+ * depth_out = clamp(depth - near, 0) / (far - near); outputs may alias the inputs.  No autograd: callers that
+ * need gradients through the image use torch ops. */
+int inr_finish_rays(const float* image /*[N,3]*/, const float* depth /*[N]*/, const float* weights_sum,
+                    const float* nears, const float* fars, float bg_r, float bg_g, float bg_b, int64_t N,
+                    float* image_out, float* depth_out, inr_stream_t s);
 
 #ifdef __cplusplus
 }

@@ -193,6 +193,51 @@ __global__ void k_adam_tail(float* p, const float* g, float* m, float* v, int64_
   p[i] = p[i] - lr_t * mm / (sqrtf(vv) + eps_t);
 }
 
+// all tensors of an optimiser step in ONE launch (blockIdx.y = tensor): a training step has 4-9 parameter
+// tensors, most of them a few KB, and a launch per tensor costs more than their arithmetic
+constexpr int kAdamMaxTensors = 16;
+struct AdamJobs {
+  float* p[kAdamMaxTensors];
+  const float* g[kAdamMaxTensors];
+  float* m[kAdamMaxTensors];
+  float* v[kAdamMaxTensors];
+  int64_t n[kAdamMaxTensors];
+  float lr_t[kAdamMaxTensors];
+};
+__global__ void __launch_bounds__(256) k_adam_multi(AdamJobs J, float b1, float b2, float eps_t, float gscale) {
+  const int t = blockIdx.y;
+  float* __restrict__ p = J.p[t];
+  const float* __restrict__ g = J.g[t];
+  float* __restrict__ m = J.m[t];
+  float* __restrict__ v = J.v[t];
+  const int64_t n = J.n[t];
+  const float lr_t = J.lr_t[t];
+  const bool aligned = (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0;
+  const int64_t n4 = aligned ? n / 4 : 0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x, tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (int64_t i = tid; i < n4; i += stride) {
+    float4 pp = reinterpret_cast<float4*>(p)[i], gg = reinterpret_cast<const float4*>(g)[i],
+           mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+#define INR_ADAM1(c)                                   \
+  {                                                    \
+    const float gr = gg.c * gscale;                    \
+    mm.c = b1 * mm.c + (1.0f - b1) * gr;               \
+    vv.c = b2 * vv.c + (1.0f - b2) * gr * gr;          \
+    pp.c = pp.c - lr_t * mm.c / (sqrtf(vv.c) + eps_t); \
+  }
+    INR_ADAM1(x) INR_ADAM1(y) INR_ADAM1(z) INR_ADAM1(w)
+#undef INR_ADAM1
+    reinterpret_cast<float4*>(p)[i] = pp; reinterpret_cast<float4*>(m)[i] = mm; reinterpret_cast<float4*>(v)[i] = vv;
+  }
+  for (int64_t i = n4 * 4 + tid; i < n; i += stride) {
+    const float gr = g[i] * gscale;
+    const float mm = b1 * m[i] + (1.0f - b1) * gr;
+    const float vv = b2 * v[i] + (1.0f - b2) * gr * gr;
+    m[i] = mm; v[i] = vv;
+    p[i] = p[i] - lr_t * mm / (sqrtf(vv) + eps_t);
+  }
+}
+
 // ---- weight gradient of a bias-free linear layer: dW[o][i] += sum_m gy[m][o] * x[m][i] -------------------
 // The reduction runs over SAMPLES (m ~ 2e5) while o, i <= 64: a GEMM with a tiny output and a huge K,
 // which the BLAS library runs on 2-4 workgroups (measured 0.43-0.48 ms per layer).  Here every wave
@@ -331,6 +376,28 @@ int inr_linear_wgrad(const float* x, const float* grad_y, int64_t M, int32_t n_i
   const int64_t waves = (M + kWgradSlab - 1) / kWgradSlab;
   k_linear_wgrad<<<blocks_for(waves, 4), 256, 0, as_stream(s)>>>(x, grad_y, M, n_in, n_out, grad_w);
   return check_launch("linear_wgrad");
+}
+
+int inr_adam_step_multi(int32_t n_tensors, float* const* params, const float* const* grads, float* const* exp_avgs,
+                        float* const* exp_avg_sqs, const int64_t* numels, const float* lrs, float beta1, float beta2,
+                        float eps, int32_t step, float grad_scale, inr_stream_t s) {
+  INR_REQUIRE(n_tensors >= 0 && n_tensors <= kAdamMaxTensors && step >= 1, "bad argument (at most 16 tensors per call)");
+  if (n_tensors == 0) return INR_OK;
+  INR_REQUIRE(params && grads && exp_avgs && exp_avg_sqs && numels && lrs, "null pointer");
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  AdamJobs J;
+  int64_t n_max = 0;
+  for (int t = 0; t < n_tensors; ++t) {
+    INR_REQUIRE(numels[t] >= 0 && (numels[t] == 0 || (params[t] && grads[t] && exp_avgs[t] && exp_avg_sqs[t])),
+                "null tensor pointer");
+    J.p[t] = params[t]; J.g[t] = grads[t]; J.m[t] = exp_avgs[t]; J.v[t] = exp_avg_sqs[t]; J.n[t] = numels[t];
+    J.lr_t[t] = (float)(lrs[t] * sqrt(bc2) / bc1);      // same folding as inr_adam_step
+    n_max = std::max(n_max, numels[t]);
+  }
+  if (n_max == 0) return INR_OK;
+  const unsigned nb = (unsigned)std::min<int64_t>((n_max / 4 + 255) / 256 + 1, 256 * 16);
+  k_adam_multi<<<dim3(nb, n_tensors), 256, 0, as_stream(s)>>>(J, beta1, beta2, (float)(eps * sqrt(bc2)), grad_scale);
+  return check_launch("adam_step_multi");
 }
 
 int inr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,

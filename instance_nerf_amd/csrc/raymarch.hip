@@ -481,6 +481,22 @@ __global__ void __launch_bounds__(kCoopRaysPerBlock * 64) k_march_write_coop(Mar
   });
 }
 
+// tail of run_cuda (a14): image += (1 - weights_sum) * bg, depth = clamp(depth - near, 0) / (far - near); one launch
+// instead of seven elementwise ones (no-grad use only)
+__global__ void __launch_bounds__(256) k_finish_rays(const float* image, const float* depth,
+                                                     const float* __restrict__ weights_sum,
+                                                     const float* __restrict__ nears, const float* __restrict__ fars,
+                                                     float bg_r, float bg_g, float bg_b, int64_t N, float* image_out,
+                                                     float* depth_out) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const float a = 1.0f - weights_sum[n];
+  image_out[n * 3 + 0] = image[n * 3 + 0] + a * bg_r;
+  image_out[n * 3 + 1] = image[n * 3 + 1] + a * bg_g;
+  image_out[n * 3 + 2] = image[n * 3 + 2] + a * bg_b;
+  depth_out[n] = fmaxf(depth[n] - nears[n], 0.0f) / (fars[n] - nears[n]);
+}
+
 // a5: inference march, up to n_step samples per live ray; buffers pre-zeroed by this kernel
 __global__ void __launch_bounds__(kRayBlock) k_march_rays(MarchParams P, int64_t n_alive, int n_step,
                                                           const int32_t* __restrict__ rays_alive,
@@ -1161,6 +1177,17 @@ int inr_compact_alive(const int32_t* rays_alive, int64_t n_alive, int32_t* out, 
   return check_launch("compact_alive");
 }
 
+int inr_finish_rays(const float* image, const float* depth, const float* weights_sum, const float* nears,
+                    const float* fars, float bg_r, float bg_g, float bg_b, int64_t N, float* image_out, float* depth_out,
+                    inr_stream_t s) {
+  INR_REQUIRE(N >= 0, "negative N");
+  if (N == 0) return INR_OK;
+  INR_REQUIRE(image && depth && weights_sum && nears && fars && image_out && depth_out, "null pointer");
+  k_finish_rays<<<blocks_for(N, 256), 256, 0, as_stream(s)>>>(image, depth, weights_sum, nears, fars, bg_r, bg_g, bg_b, N,
+                                                              image_out, depth_out);
+  return check_launch("finish_rays");
+}
+
 int inr_composite_rays_train_forward(const float* sigmas, const float* rgbs, const float* deltas, const int32_t* rays,
                                      int64_t N, int64_t M, float T_thresh, const float* extra, int32_t K,
                                      float* weights_sum, float* depth, float* image, float* extra_out, float* weights,
@@ -1186,14 +1213,17 @@ int inr_composite_rays_train_backward(const float* grad_weights_sum, const float
                                       int64_t M, float T_thresh, int32_t K, float* grad_sigmas, float* grad_rgbs,
                                       float* grad_extra, inr_stream_t s) {
   (void)extra;
-  INR_REQUIRE(grad_image && rays && weights_sum && image && grad_sigmas && grad_rgbs && N >= 0 && M >= 0, "bad argument");
+  INR_REQUIRE(rays && N >= 0 && M >= 0, "bad argument");
+  INR_REQUIRE((grad_sigmas != nullptr) == (grad_rgbs != nullptr), "grad_sigmas and grad_rgbs go together");
+  INR_REQUIRE(!grad_sigmas || (grad_image && weights_sum && image && sigmas && rgbs && deltas), "null pointer");
   INR_REQUIRE(!grad_extra_out || (grad_extra && weights && K > 0 && K <= 64),
               "grad_extra_out needs grad_extra, weights and 0 < K <= 64");
   if (N == 0) return INR_OK;
   hipStream_t st = as_stream(s);
-  k_composite_train_bwd<<<blocks_for(N * 64, kRayBlock), kRayBlock, 0, st>>>(grad_weights_sum, grad_image, sigmas,
-                                                                             rgbs, deltas, rays, weights_sum, image, N, M,
-                                                                             T_thresh, grad_sigmas, grad_rgbs);
+  if (grad_sigmas)   // null: the density/colour field is frozen (instance stage) - only the K channels flow back
+    k_composite_train_bwd<<<blocks_for(N * 64, kRayBlock), kRayBlock, 0, st>>>(grad_weights_sum, grad_image, sigmas,
+                                                                               rgbs, deltas, rays, weights_sum, image, N, M,
+                                                                               T_thresh, grad_sigmas, grad_rgbs);
   if (grad_extra_out)
     k_composite_train_extra_bwd<<<blocks_for(N * 64, kRayBlock), kRayBlock, 0, st>>>(grad_extra_out, weights, rays, N,
                                                                                      M, K, grad_extra);

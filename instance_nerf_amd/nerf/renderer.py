@@ -21,7 +21,8 @@ import math
 import torch
 import torch.nn as nn
 
-from .. import raymarching
+from .. import _lib, raymarching
+from .._lib import check, ptr, stream_ptr
 
 
 class NeRFRenderer(nn.Module):
@@ -163,7 +164,8 @@ class NeRFRenderer(nn.Module):
                 rays_o, rays_d, self.bound, self.density_bitfield, self.cascade, self.grid_size, nears, fars,
                 counter, mean_count, perturb, 128, force_all_rays, dt_gamma, max_steps, noises=noises)
             sigmas, rgbs = self(xyzs, dirs)
-            sigmas = self.density_scale * sigmas
+            if self.density_scale != 1:
+                sigmas = self.density_scale * sigmas
             extra = self.instance(xyzs) if with_instance else None
             out = raymarching.composite_rays_train(sigmas, rgbs, deltas, rays, T_thresh, extra=extra)
             weights_sum, depth, image = out[0], out[1], out[2]
@@ -203,12 +205,35 @@ class NeRFRenderer(nn.Module):
 
         if not self.training:
             self._last_opacity = weights_sum.mean()
-        image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
-        depth = torch.clamp(depth - nears, min=0) / (fars - nears)
+        bg3 = self._bg_triplet(bg_color)
+        if bg3 is not None and not (torch.is_grad_enabled() and (image.requires_grad or weights_sum.requires_grad)):
+            # no gradient flows through the shaded image (inference, or the instance stage on a frozen NeRF):
+            # background blend + depth normalisation in one launch, in place on this call's own buffers
+            lib = _lib.load()
+            src_i, src_d = image.detach().contiguous(), depth.detach().contiguous()
+            # the training path keeps the compositing outputs for its backward: write to fresh buffers there
+            image = torch.empty_like(src_i) if self.training else src_i
+            depth = torch.empty_like(src_d) if self.training else src_d
+            check(lib.inr_finish_rays(ptr(src_i, torch.float32, "image"), ptr(src_d, torch.float32, "depth"),
+                                      ptr(weights_sum.detach().contiguous(), torch.float32, "weights_sum"),
+                                      ptr(nears, torch.float32, "nears"), ptr(fars, torch.float32, "fars"),
+                                      bg3[0], bg3[1], bg3[2], N, ptr(image), ptr(depth), stream_ptr()), "finish_rays")
+        else:
+            image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
+            depth = torch.clamp(depth - nears, min=0) / (fars - nears)
         results["image"] = image.view(*prefix, 3)
         results["depth"] = depth.view(*prefix)
         results["weights_sum"] = weights_sum.view(*prefix)
         return results
+
+    @staticmethod
+    def _bg_triplet(bg_color):
+        """(r, g, b) floats when the background is one colour for all rays (a number or a host-side triple)."""
+        if isinstance(bg_color, (int, float)):
+            return (float(bg_color),) * 3
+        if isinstance(bg_color, (list, tuple)) and len(bg_color) == 3 and all(isinstance(c, (int, float)) for c in bg_color):
+            return tuple(float(c) for c in bg_color)
+        return None
 
     # ----------------------------------------------------------------------------------------
     @torch.no_grad()

@@ -169,8 +169,11 @@ class FusedAdam:
 
     @torch.no_grad()
     def step(self, grad_scale=1.0):
+        """One launch for all tensors of the step (inr_adam_step_multi, 16 tensors per call)."""
+        import ctypes
         lib = _lib.load()
         self.step_count += 1
+        jobs = []
         for g in self.param_groups:
             for p in g["params"]:
                 if p.grad is None or not p.requires_grad:
@@ -178,14 +181,23 @@ class FusedAdam:
                 st = self.state.get(p)
                 if st is None:
                     st = self.state[p] = (torch.zeros_like(p.data), torch.zeros_like(p.data))
-                grad = p.grad.contiguous()
-                _lib.check(lib.inr_adam_step(_lib.ptr(p.data, torch.float32, "param"), _lib.ptr(grad, torch.float32, "grad"),
-                                             _lib.ptr(st[0]), _lib.ptr(st[1]), p.numel(), float(g["lr"]),
-                                             self.betas[0], self.betas[1], self.eps, self.step_count,
-                                             float(grad_scale), _lib.stream_ptr()), "adam_step")
-                # the C ABI wrote p in place behind autograd's back: bump the version counter so
-                # cached MFMA-packed weights (NeRFNetwork._packed_weights) are refreshed
-                torch.autograd.graph.increment_version(p)
+                grad = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                for t, name in ((p.data, "param"), (grad, "grad"), (st[0], "exp_avg"), (st[1], "exp_avg_sq")):
+                    _lib.ptr(t, torch.float32, name)         # device / dtype / contiguity checks
+                jobs.append((p, grad, st[0], st[1], float(g["lr"])))
+        for i in range(0, len(jobs), 16):
+            chunk = jobs[i:i + 16]
+            n = len(chunk)
+            arr = lambda k: (ctypes.c_void_p * n)(*[j[k].data_ptr() for j in chunk])
+            numels = (ctypes.c_int64 * n)(*[j[0].numel() for j in chunk])
+            lrs = (ctypes.c_float * n)(*[j[4] for j in chunk])
+            _lib.check(lib.inr_adam_step_multi(n, arr(0), arr(1), arr(2), arr(3), numels, lrs, self.betas[0],
+                                               self.betas[1], self.eps, self.step_count, float(grad_scale),
+                                               _lib.stream_ptr()), "adam_step_multi")
+        for p, *_ in jobs:
+            # the C ABI wrote p in place behind autograd's back: bump the version counter so
+            # cached MFMA-packed weights (NeRFNetwork._packed_weights) are refreshed
+            torch.autograd.graph.increment_version(p)
 
     def state_dict(self):
         flat = [p for g in self.param_groups for p in g["params"]]

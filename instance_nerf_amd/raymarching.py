@@ -115,9 +115,8 @@ def march_rays_train(rays_o, rays_d, bound, density_bitfield, C, H, nears, fars,
         M = int(mean_count)
     if align > 0:
         M += align - M % align if M % align else 0
-    xyzs = torch.zeros(M, 3, dtype=F32, device=dev)
-    dirs = torch.zeros(M, 3, dtype=F32, device=dev)
-    deltas = torch.zeros(M, 2, dtype=F32, device=dev)
+    buf = torch.zeros(M * 8, dtype=F32, device=dev)      # one fill: rows no ray owns (padding, dropped rays) are zero
+    xyzs, dirs, deltas = buf[:M * 3].view(M, 3), buf[M * 3:M * 6].view(M, 3), buf[M * 6:].view(M, 2)
     check(lib.inr_march_rays_train_write(*args, M, ptr(nears), ptr(fars), ptr(noises, F32, "noises", allow_none=True),
                                          ptr(rays), ptr(xyzs), ptr(dirs), ptr(deltas), ptr(ws), cap, stream_ptr()),
           "march_rays_train_write")
@@ -229,11 +228,13 @@ class _CompositeRaysTrain(torch.autograd.Function):
         K = 0 if extra is None else extra.shape[1]
         if extra is not None:
             extra = _f(extra)
-        ws = torch.zeros(N, dtype=F32, device=dev)
-        depth = torch.zeros(N, dtype=F32, device=dev)
-        image = torch.zeros(N, 3, dtype=F32, device=dev)
-        extra_out = torch.zeros(N, K, dtype=F32, device=dev) if K else None
-        wbuf = torch.zeros(sigmas.shape[0], dtype=F32, device=dev) if K else None     # rows of dropped rays stay 0
+        # every ray's outputs are written by the kernels (zeros for dropped rays); weight rows no ray owns are
+        # never read - so nothing needs a fill
+        ws = torch.empty(N, dtype=F32, device=dev)
+        depth = torch.empty(N, dtype=F32, device=dev)
+        image = torch.empty(N, 3, dtype=F32, device=dev)
+        extra_out = torch.empty(N, K, dtype=F32, device=dev) if K else None
+        wbuf = torch.empty(sigmas.shape[0], dtype=F32, device=dev) if K else None
         check(lib.inr_composite_rays_train_forward(
             ptr(sigmas, F32, "sigmas"), ptr(rgbs, F32, "rgbs"), ptr(deltas, F32, "deltas"), ptr(rays, I32, "rays"),
             N, sigmas.shape[0], float(T_thresh), ptr(extra, F32, "extra", allow_none=True), K, ptr(ws), ptr(depth),
@@ -254,21 +255,26 @@ class _CompositeRaysTrain(torch.autograd.Function):
         N = rays.shape[0]
         K = ctx.K
         dev = sigmas.device
-        g_ws = _f(g_ws) if g_ws is not None else torch.zeros(N, dtype=F32, device=dev)
-        g_image = _f(g_image) if g_image is not None else torch.zeros(N, 3, dtype=F32, device=dev)
-        gs = torch.zeros_like(sigmas)
-        gc = torch.zeros_like(rgbs)
+        need_field = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        gs = gc = None
+        if need_field:
+            g_ws = _f(g_ws) if g_ws is not None else None
+            g_image = _f(g_image) if g_image is not None else torch.zeros(N, 3, dtype=F32, device=dev)
+            gs = torch.zeros_like(sigmas)
+            gc = torch.zeros_like(rgbs)
         ge = None
         if K and g_extra is not None and ctx.needs_input_grad[2]:
             g_extra = _f(g_extra)
-            ge = torch.zeros_like(extra)
+            ge = torch.zeros_like(extra)        # rows no ray owns must stay zero: they flow into the field backward
         else:
             g_extra = None
-        check(lib.inr_composite_rays_train_backward(
-            ptr(g_ws), ptr(g_image), ptr(g_extra, allow_none=True), ptr(sigmas), ptr(rgbs),
-            ptr(extra, allow_none=True), ptr(deltas), ptr(rays), ptr(ws), ptr(image), ptr(wbuf, allow_none=True), N,
-            sigmas.shape[0], float(ctx.T_thresh), K, ptr(gs), ptr(gc), ptr(ge, allow_none=True), stream_ptr()),
-            "composite_rays_train_backward")
+        if need_field or ge is not None:
+            check(lib.inr_composite_rays_train_backward(
+                ptr(g_ws, allow_none=True) if need_field else None, ptr(g_image) if need_field else None,
+                ptr(g_extra, allow_none=True), ptr(sigmas), ptr(rgbs),
+                ptr(extra, allow_none=True), ptr(deltas), ptr(rays), ptr(ws), ptr(image), ptr(wbuf, allow_none=True), N,
+                sigmas.shape[0], float(ctx.T_thresh), K, ptr(gs, allow_none=True), ptr(gc, allow_none=True),
+                ptr(ge, allow_none=True), stream_ptr()), "composite_rays_train_backward")
         return gs, gc, ge, None, None, None
 
 
