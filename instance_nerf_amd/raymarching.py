@@ -243,7 +243,11 @@ class _CompositeRaysTrain(torch.autograd.Function):
         ctx.save_for_backward(sigmas, rgbs, extra, deltas, rays, ws, image, wbuf)
         ctx.T_thresh = T_thresh
         ctx.K = K
-        ctx.mark_non_differentiable(depth)
+        ctx.set_materialize_grads(False)          # unused outputs reach backward as None, not as zero fills
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            ctx.mark_non_differentiable(depth)
+        else:                                      # frozen density/colour field: only the K channels carry gradient
+            ctx.mark_non_differentiable(depth, ws, image)
         if K:
             return ws, depth, image, extra_out
         return ws, depth, image
