@@ -260,9 +260,12 @@ int inr_instance_render(const float* xyzs, const int32_t* rays, const float* wei
 
 /* ---- weight gradient of the tiny bias-free MLP layers (replaces the BLAS call autograd makes for
  * nn.Linear in NeRFNetwork, a9/a13):  grad_w[o][i] += sum_m grad_y[m][o] * x[m][i],  n_in, n_out <= 64.
- * x [M, n_in], grad_y [M, n_out], grad_w [n_out, n_in] is ACCUMULATED into (caller zeroes it).      */
+ * x [M, n_in], grad_y [M, n_out], grad_w [n_out, n_in] is ACCUMULATED into (caller zeroes it).
+ * workspace: inr_linear_wgrad_workspace_bytes() bytes of scratch (per-workgroup partial sums; two passes, no
+ * atomics - same-address float atomics from hundreds of workgroups were the slowest part of this op).  */
+int64_t inr_linear_wgrad_workspace_bytes(void);
 int inr_linear_wgrad(const float* x, const float* grad_y, int64_t M, int32_t n_in, int32_t n_out,
-                     float* grad_w, inr_stream_t s);
+                     float* grad_w, void* workspace, inr_stream_t s);
 
 /* ---- optimiser (replaces the Trainer's torch.optim.Adam sweep over the table, a15) ------ */
 int inr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,

@@ -70,4 +70,17 @@ __device__ __forceinline__ int wave_inclusive_scan(int v) {
   return v;
 }
 
+// Compute units of the current device, queried once per device: hipGetDeviceProperties fills a multi-KB struct
+// and costs tens of microseconds - too much for a call that precedes every launch of a 50 us kernel.
+inline int cu_count() {
+  static int cached[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (cached[dev] == 0) {
+    int n = 0;
+    cached[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+  }
+  return cached[dev];
+}
+
 }  // namespace inr

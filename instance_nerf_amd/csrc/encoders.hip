@@ -241,65 +241,145 @@ __global__ void __launch_bounds__(256) k_adam_multi(AdamJobs J, float b1, float 
 // ---- weight gradient of a bias-free linear layer: dW[o][i] += sum_m gy[m][o] * x[m][i] -------------------
 // The reduction runs over SAMPLES (m ~ 2e5) while o, i <= 64: a GEMM with a tiny output and a huge K,
 // which the BLAS library runs on 2-4 workgroups (measured 0.43-0.48 ms per layer).  Here every wave
-// takes a slab of samples, keeps the whole [<=64 x <=64] result in 16 MFMA accumulators
-// (v_mfma_f32_16x16x4_f32: exact fp32, k = 4 samples per instruction) and adds it to dW with
-// address-adjacent atomics at the end (split-K over ~1000 waves).
+// takes 16-sample units, keeps the whole [<=64 x <=64] result in 16 MFMA accumulators
+// (v_mfma_f32_16x16x4_f32: exact fp32, k = 4 samples per instruction); the waves of a workgroup sum their
+// results in LDS and the workgroup adds one set to dW with address-adjacent atomics (split-K over the CUs).
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr int kWgradSlab = 256;   // samples per wave (the final 64x64 atomics per wave bound how small a slab pays)
 
-__global__ void __launch_bounds__(256) k_linear_wgrad(const float* __restrict__ x, const float* __restrict__ gy,
-                                                      int64_t M, int n_in, int n_out, float* __restrict__ gw) {
-  const int lane = threadIdx.x & 63, q = lane >> 4, j = lane & 15;
-  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int64_t m0 = wave * kWgradSlab;
-  if (m0 >= M) return;
-  const int n_ot = (n_out + 15) >> 4, n_it = (n_in + 15) >> 4;
-  f32x4 acc[4][4];
+// Feature f of the 16*N-wide operand sits in MFMA block f % N, row/column f / N: lane j then owns the N
+// CONTIGUOUS features N*j .. N*j+N-1 of a sample row - one 16-byte load when N = 4 - and any such relabelling
+// is legal as long as the write-out uses it too.
+template <int N>
+__device__ __forceinline__ void wgrad_load(const float* __restrict__ row, int n, int j, bool valid, float* v) {
+  if (n == 16 * N) {                   // wave-uniform: full width, vector load
+    if constexpr (N == 4) {
+      const float4 t = valid ? *reinterpret_cast<const float4*>(row + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+      return;
+    } else if constexpr (N == 2) {
+      const float2 t = valid ? *reinterpret_cast<const float2*>(row + 2 * j) : make_float2(0.f, 0.f);
+      v[0] = t.x; v[1] = t.y;
+      return;
+    }
+  }
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int e = 0; e < N; ++e) v[e] = (valid && N * j + e < n) ? row[N * j + e] : 0.f;
+}
+
+// Pass 1: units of 16 samples are dealt round-robin to all waves of the grid (8 waves per workgroup, two
+// workgroups per CU).  The 8 partial results of a workgroup are summed by a 3-round tree through LDS (plain
+// 16-byte stores and loads - ds_add_f32 and same-address global atomics were both measured far slower) and the
+// workgroup's [N_OT x N_IT x 256] fragment-ordered partial goes to `partial[blockIdx.x]` with plain stores.
+constexpr int kWgradWaves = 8;       // tree buffer = 4 waves x 16 KB = 64 KB; two workgroups per CU
+constexpr int kWgradGroupsPerCU = 2;
+template <int N_OT, int N_IT>
+__global__ void __launch_bounds__(kWgradWaves * 64) k_linear_wgrad(const float* __restrict__ x, const float* __restrict__ gy,
+                                                                  int64_t M, int n_in, int n_out,
+                                                                  float4* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) float4 tree[];     // [kWgradWaves/2][N_OT*N_IT][64 lanes]
+  constexpr int kBlk = N_OT * N_IT;
+  const int lane = threadIdx.x & 63, q = lane >> 4, j = lane & 15, w = threadIdx.x >> 6;
+  const int64_t n_waves = (int64_t)gridDim.x * kWgradWaves;
+  const int64_t wave = (int64_t)w * gridDim.x + blockIdx.x;          // neighbouring units -> different CUs
+  const int64_t n_units = (M + 15) >> 4;
+  f32x4 acc[N_OT][N_IT];
 #pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int64_t m_end = min(M, m0 + kWgradSlab);
-  // the slab is processed in groups of 4 k-steps (16 samples): all 32 loads of a group are issued
-  // before its 64 MFMAs, so the loop is not a chain of dependent load -> MFMA round trips
-  for (int64_t mg = m0; mg < m_end; mg += 16) {
-    float av[4][4], bv[4][4];
+  for (int a = 0; a < N_OT; ++a)
+#pragma unroll
+    for (int b = 0; b < N_IT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // 16 samples per iteration: the 8 row loads (4 k-steps x 2 operands) are issued before the MFMAs
+  for (int64_t unit = wave; unit < n_units; unit += n_waves) {
+    const int64_t mg = unit * 16;
+    float av[4][N_OT], bv[4][N_IT];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int64_t row = mg + 4 * u + q;            // k-slot q of k-step u
-      const bool rv = row < m_end;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int c = 16 * t + j;
-        av[u][t] = (rv && c < n_out) ? gy[row * n_out + c] : 0.f;      // A[i = out][k = sample]
-        bv[u][t] = (rv && c < n_in) ? x[row * n_in + c] : 0.f;         // B[k = sample][j = in]
-      }
+      const bool rv = row < M;
+      wgrad_load<N_OT>(gy + row * n_out, n_out, j, rv, av[u]);      // A[i = out][k = sample]
+      wgrad_load<N_IT>(x + row * n_in, n_in, j, rv, bv[u]);         // B[k = sample][j = in]
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
-      for (int ot = 0; ot < 4; ++ot)
+      for (int ot = 0; ot < N_OT; ++ot)
 #pragma unroll
-        for (int it = 0; it < 4; ++it)
-          if (ot < n_ot && it < n_it)
-            acc[ot][it] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][ot], bv[u][it], acc[ot][it], 0, 0, 0);
+        for (int it = 0; it < N_IT; ++it)
+          acc[ot][it] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][ot], bv[u][it], acc[ot][it], 0, 0, 0);
   }
 #pragma unroll
-  for (int ot = 0; ot < 4; ++ot)
+  for (int half = kWgradWaves / 2; half >= 1; half >>= 1) {
+    if (w >= half && w < 2 * half) {
 #pragma unroll
-    for (int it = 0; it < 4; ++it)
-      if (ot < n_ot && it < n_it) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int o = 16 * ot + 4 * q + r, i = 16 * it + j;
-          if (o < n_out && i < n_in) atomicAdd(gw + (size_t)o * n_in + i, acc[ot][it][r]);
-        }
+      for (int b = 0; b < kBlk; ++b) {
+        const f32x4 v = acc[b / N_IT][b % N_IT];
+        tree[((w - half) * kBlk + b) * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
       }
+    }
+    __syncthreads();
+    if (w < half) {
+#pragma unroll
+      for (int b = 0; b < kBlk; ++b) {
+        const float4 v = tree[(w * kBlk + b) * 64 + lane];
+        acc[b / N_IT][b % N_IT] += f32x4{v.x, v.y, v.z, v.w};
+      }
+    }
+    __syncthreads();
+  }
+  if (w == 0) {
+#pragma unroll
+    for (int b = 0; b < kBlk; ++b) {
+      const f32x4 v = acc[b / N_IT][b % N_IT];
+      partial[((size_t)blockIdx.x * kBlk + b) * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  }
+}
+
+// Pass 2: gw[o][i] += sum over workgroups; fragment (ot, it) lane (q, j) register r holds output feature
+// N_OT*(4q+r)+ot, input feature N_IT*j+it (see wgrad_load).
+__global__ void __launch_bounds__(1024) k_wgrad_reduce(const float* __restrict__ partial, int n_groups, int n_ot, int n_it,
+                                                       int n_in, int n_out, float* __restrict__ gw) {
+  // 64 consecutive elements per block, the groups split over 16 waves with 8 loads in flight each
+  __shared__ float red[16][64];
+  const int e = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  const int idx = blockIdx.x * 64 + e;
+  const int per = n_ot * n_it * 256;
+  float s = 0.f;
+  int g = slice;
+  for (; g + 7 * 16 < n_groups; g += 8 * 16) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)(g + 16 * u) * per + idx];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; g < n_groups; g += 16) s += partial[(size_t)g * per + idx];
+  red[slice][e] = s;
+  __syncthreads();
+  if (slice == 0) {
+#pragma unroll
+    for (int k = 1; k < 16; ++k) s += red[k][e];
+    const int b = idx >> 8, lane = (idx >> 2) & 63, r = idx & 3;
+    const int o = n_ot * (4 * (lane >> 4) + r) + b / n_it, i = n_it * (lane & 15) + b % n_it;
+    if (o < n_out && i < n_in) gw[(size_t)o * n_in + i] += s;
+  }
 }
 
 }  // namespace inr
 
 using namespace inr;
+
+template <int N_OT>
+static void wgrad_launch(unsigned nb, hipStream_t st, const float* x, const float* gy, int64_t M, int n_in, int n_out,
+                         float4* partial) {
+  const int n_it = (n_in + 15) / 16;
+  const size_t lds = (size_t)(kWgradWaves / 2) * N_OT * n_it * 64 * sizeof(float4);
+  switch (n_it) {
+    case 1: k_linear_wgrad<N_OT, 1><<<nb, kWgradWaves * 64, lds, st>>>(x, gy, M, n_in, n_out, partial); break;
+    case 2: k_linear_wgrad<N_OT, 2><<<nb, kWgradWaves * 64, lds, st>>>(x, gy, M, n_in, n_out, partial); break;
+    case 3: k_linear_wgrad<N_OT, 3><<<nb, kWgradWaves * 64, lds, st>>>(x, gy, M, n_in, n_out, partial); break;
+    default: k_linear_wgrad<N_OT, 4><<<nb, kWgradWaves * 64, lds, st>>>(x, gy, M, n_in, n_out, partial); break;
+  }
+}
 
 extern "C" {
 
@@ -368,13 +448,31 @@ int inr_sh_encode_backward(const float* grad_out, const float* d, int64_t M, int
   return check_launch("sh_encode_backward");
 }
 
+int64_t inr_linear_wgrad_workspace_bytes(void) {
+  return (int64_t)cu_count() * kWgradGroupsPerCU * 64 * 64 * (int64_t)sizeof(float);
+}
+
 int inr_linear_wgrad(const float* x, const float* grad_y, int64_t M, int32_t n_in, int32_t n_out, float* grad_w,
-                     inr_stream_t s) {
+                     void* workspace, inr_stream_t s) {
   INR_REQUIRE(M >= 0 && n_in > 0 && n_in <= 64 && n_out > 0 && n_out <= 64, "n_in and n_out must be in 1..64");
   if (M == 0) return INR_OK;
-  INR_REQUIRE(x && grad_y && grad_w, "null pointer");
-  const int64_t waves = (M + kWgradSlab - 1) / kWgradSlab;
-  k_linear_wgrad<<<blocks_for(waves, 4), 256, 0, as_stream(s)>>>(x, grad_y, M, n_in, n_out, grad_w);
+  INR_REQUIRE(x && grad_y && grad_w && workspace, "null pointer");
+  // full-width rows are read with 16/8-byte loads
+  INR_REQUIRE((n_in % 16 != 0 || ((uintptr_t)x & 15) == 0) && (n_out % 16 != 0 || ((uintptr_t)grad_y & 15) == 0) &&
+                  ((uintptr_t)workspace & 15) == 0, "x / grad_y / workspace must be 16-byte aligned");
+  const int64_t units = (M + 15) / 16;
+  const unsigned nb = (unsigned)std::max<int64_t>(1, std::min<int64_t>((units + kWgradWaves - 1) / kWgradWaves, (int64_t)cu_count() * kWgradGroupsPerCU));
+  hipStream_t st = as_stream(s);
+  float4* partial = reinterpret_cast<float4*>(workspace);
+  const int n_ot = (n_out + 15) / 16, n_it = (n_in + 15) / 16;
+  switch (n_ot) {
+    case 1: wgrad_launch<1>(nb, st, x, grad_y, M, n_in, n_out, partial); break;
+    case 2: wgrad_launch<2>(nb, st, x, grad_y, M, n_in, n_out, partial); break;
+    case 3: wgrad_launch<3>(nb, st, x, grad_y, M, n_in, n_out, partial); break;
+    default: wgrad_launch<4>(nb, st, x, grad_y, M, n_in, n_out, partial); break;
+  }
+  k_wgrad_reduce<<<n_ot * n_it * 4, 1024, 0, st>>>(reinterpret_cast<const float*>(workspace), (int)nb, n_ot, n_it, n_in, n_out,
+                                              grad_w);
   return check_launch("linear_wgrad");
 }
 

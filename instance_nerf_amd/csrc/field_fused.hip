@@ -1153,12 +1153,19 @@ constexpr int kFieldBlocksPerCU = 1;
 
 template <class Kern>
 static int grid_for(Kern kern, size_t lds_bytes, int64_t n_tiles) {
-  int dev = 0, cus = 256, fit = kFieldBlocksPerCU;
-  if (hipGetDevice(&dev) == hipSuccess) {
-    hipDeviceProp_t p;
-    if (hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount;
+  // occupancy of (kernel, LDS size) is a constant of the build: ask the runtime once per pair
+  struct Entry { const void* kern; size_t lds; int fit; };
+  static Entry cache[64];
+  static int n_cached = 0;
+  const int cus = cu_count();
+  int fit = 0;
+  for (int i = 0; i < n_cached; ++i)
+    if (cache[i].kern == (const void*)kern && cache[i].lds == lds_bytes) fit = cache[i].fit;
+  if (fit < 1) {
+    fit = kFieldBlocksPerCU;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, kern, kFieldThreads, lds_bytes) != hipSuccess || fit < 1) fit = 1;
+    if (n_cached < 64) cache[n_cached++] = Entry{(const void*)kern, lds_bytes, fit};
   }
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, kern, kFieldThreads, lds_bytes) != hipSuccess || fit < 1) fit = 1;
   int per_cu = std::min(fit, kFieldBlocksPerCU);
   if (const char* e = getenv("INR_FIELD_BLOCKS_PER_CU")) per_cu = std::max(1, std::min(fit, atoi(e)));   // profiling knob
   const int64_t want = (n_tiles + kFieldThreads / 64 - 1) / (kFieldThreads / 64);

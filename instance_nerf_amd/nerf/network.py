@@ -46,8 +46,9 @@ class _LinearFn(torch.autograd.Function):
             lib = _lib.load()
             gyc, xc = gy.contiguous(), x.contiguous()
             gw = torch.zeros_like(w)
+            ws = torch.empty(lib.inr_linear_wgrad_workspace_bytes() // 4, dtype=torch.float32, device=w.device)
             check(lib.inr_linear_wgrad(ptr(xc, torch.float32, "x"), ptr(gyc, torch.float32, "grad_y"), xc.shape[0],
-                                       w.shape[1], w.shape[0], ptr(gw), stream_ptr()), "linear_wgrad")
+                                       w.shape[1], w.shape[0], ptr(gw), ptr(ws), stream_ptr()), "linear_wgrad")
         return gx, gw
 
 
@@ -97,8 +98,10 @@ class _InstanceFieldFn(torch.autograd.Function):
         if M:
             check(lib.inr_instance_backward(ptr(g, f32, "grad_logits"), K, ptr(h1), ptr(h2), M, ptr(pb), ptr(dz2),
                                             ptr(dz1), ptr(denc), stream_ptr()), "instance_backward")
+            ws = torch.empty(lib.inr_linear_wgrad_workspace_bytes() // 4, dtype=f32, device=dev)   # reused in stream order
             for xin, gy, n_in, n_out, out in ((h2, g, 64, K, gw2), (h1, dz2, 64, 64, gw1), (enc, dz1, 32, 64, gw0)):
-                check(lib.inr_linear_wgrad(ptr(xin), ptr(gy), M, n_in, n_out, ptr(out), stream_ptr()), "linear_wgrad")
+                check(lib.inr_linear_wgrad(ptr(xin), ptr(gy), M, n_in, n_out, ptr(out), ptr(ws), stream_ptr()),
+                      "linear_wgrad")
             check(lib.inr_grid_encode_backward_ordered(ptr(x), ptr(denc), None, ctx.desc, M, float(ctx.bound),
                                                        ptr(g_emb), stream_ptr()), "grid_encode_backward")
         return None, g_emb, gw0, gw1, gw2, None, None
