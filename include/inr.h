@@ -207,6 +207,24 @@ int inr_nerf_forward_table(const float* x01, const int32_t* ray_ids, const float
                            float bound, const float* embeddings, const inr_grid_desc* desc /*host*/,
                            const float* packed /*device*/, float density_scale, float* sigma, float* rgb,
                            inr_stream_t s);
+/* Training path of the NeRF field (a9 under autograd): device-packed weights (forward layout of
+ * inr_nerf_pack_weights + the transposed sections of the backward), a forward that also stores the activations
+ * (enc [M,32], h1 [M,64], so [M,16] = raw sigma-net output, cin [M,32] = colour-net input with a zero pad column,
+ * c1, c2 [M,64]) and ONE backward launch from (dL/dsigma [M], dL/drgb [M,3]) to
+ * grad_o [M,4] (rgb logits, 3 live), grad_zc2, grad_zc1 [M,64], grad_so [M,16], grad_zh1 [M,64], grad_enc [M,32].
+ * sigma here is exp(so[:,0]) (no density_scale); pass the scale the caller applies afterwards as density_scale = 1.
+ * Weight gradients: inr_linear_wgrad(c2, grad_o), (c1, grad_zc2), (cin, grad_zc1), (h1, grad_so), (enc, grad_zh1). */
+int64_t inr_nerf_bwd_packed_floats(void);
+int inr_nerf_pack_weights_device(const float* sigma_w0, const float* sigma_w1, const float* color_w0,
+                                 const float* color_w1, const float* color_w2, float* packed_fwd,
+                                 float* packed_bwd, inr_stream_t s);
+int inr_nerf_forward_train(const float* x, const float* d, int64_t M, float bound, const float* embeddings,
+                           const inr_grid_desc* desc /*host*/, const float* packed_fwd, float* sigma, float* rgb,
+                           float* enc, float* h1, float* so, float* cin, float* c1, float* c2, inr_stream_t s);
+int inr_nerf_backward(const float* grad_sigma, const float* grad_rgb, const float* rgb, const float* so,
+                      const float* h1, const float* c1, const float* c2, int64_t M, float density_scale,
+                      const float* packed_bwd, float* grad_o, float* grad_zc2, float* grad_zc1, float* grad_so,
+                      float* grad_zh1, float* grad_enc, inr_stream_t s);
 /* Training path of the instance field (a13): weights are packed ON THE DEVICE every step (forward layout as
  * inr_instance_pack_weights, plus the transposed sections the input-gradient kernel uses); the forward also
  * stores the encoder output [M,32] and both hidden activations [M,64]; inr_instance_backward turns

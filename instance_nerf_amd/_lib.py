@@ -40,6 +40,10 @@ _SIGS = {
                                              c_int64, P, P, P, P, P, P, P, P, c_int32, P]),
     "inr_march_rays_patch_write": (c_int32, [P, P, P, c_float, c_float, c_int32, c_int64, c_int32, c_int32,
                                              c_int64, P, P, P, P, P, P, P, P, c_int32, P, c_int32, P]),
+    "inr_nerf_bwd_packed_floats": (c_int64, []),
+    "inr_nerf_pack_weights_device": (c_int32, [P, P, P, P, P, P, P, P]),
+    "inr_nerf_forward_train": (c_int32, [P, P, c_int64, c_float, P, POINTER(GridDesc), P, P, P, P, P, P, P, P, P, P]),
+    "inr_nerf_backward": (c_int32, [P, P, P, P, P, P, P, c_int64, c_float, P, P, P, P, P, P, P, P]),
     "inr_instance_bwd_packed_floats": (c_int64, []),
     "inr_instance_pack_weights_device": (c_int32, [P, P, P, c_int32, P, P, P]),
     "inr_instance_forward_train": (c_int32, [P, c_int64, c_float, P, POINTER(GridDesc), P, c_int32, P, P, P, P, P]),

@@ -72,10 +72,10 @@ __device__ __forceinline__ void run_reduce_atomic4(float* __restrict__ gemb, uin
 // `order` (nullable): a permutation of the samples; sample slot m processes sample order[m].
 __global__ void __launch_bounds__(256) k_grid_bwd(const float* __restrict__ x, const float* __restrict__ gout,
                                                   const int32_t* __restrict__ order, GridDesc G, int64_t M, float bound,
-                                                  float* __restrict__ gemb) {
+                                                  float* __restrict__ gemb, int level0) {
   const int64_t m = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
   const int sub = threadIdx.x & 3, xb = sub >> 1, f = sub & 1;
-  const int l = blockIdx.y;
+  const int l = level0 + blockIdx.y;
   const int L = G.num_levels;
   const bool valid = m < M;
   const int64_t ms = valid ? m : M - 1;
@@ -416,8 +416,12 @@ int inr_grid_encode_backward_ordered(const float* x, const float* grad_out, cons
   INR_REQUIRE(((uintptr_t)grad_out & 7) == 0, "grad_out must be 8-byte aligned");
   if (M == 0) return INR_OK;
   INR_REQUIRE((uint64_t)desc->offsets[desc->num_levels] * 2ull < (1ull << 32), "table too large for 32-bit element offsets");
-  const dim3 grid(blocks_for(M * 4, 256), (unsigned)G.num_levels);
-  k_grid_bwd<<<grid, 256, 0, as_stream(s)>>>(x, grad_out, order, G, M, bound, grad_embeddings);
+  int l0 = 0, l1 = G.num_levels;
+  if (const char* e = getenv("INR_GRID_BWD_LEVELS")) {      // profiling knob "lo:hi": only levels lo..hi-1
+    if (sscanf(e, "%d:%d", &l0, &l1) != 2 || l0 < 0 || l1 > G.num_levels || l0 >= l1) { l0 = 0; l1 = G.num_levels; }
+  }
+  const dim3 grid(blocks_for(M * 4, 256), (unsigned)(l1 - l0));
+  k_grid_bwd<<<grid, 256, 0, as_stream(s)>>>(x, grad_out, order, G, M, bound, grad_embeddings, l0);
   return check_launch("grid_encode_backward");
 }
 

@@ -509,14 +509,32 @@ constexpr int kFieldThreads = INR_FIELD_THREADS;   // waves of a workgroup share
 // kTable: fused-frame fast path - x is already normalised to [0,1] by the march writer and the direction
 // encoding comes from a per-ray SH table (shq[ray][q] = this lane's four components) via a per-sample ray id:
 // ~100 VALU instructions per tile less than dividing and evaluating 16 polynomials in every lane.
-template <bool kColor, bool kTable = false>
+__device__ __forceinline__ f32x4 load4(const float* p) {
+  const float4 v = *reinterpret_cast<const float4*>(p);
+  return f32x4{v.x, v.y, v.z, v.w};
+}
+__device__ __forceinline__ void store4(float* p, f32x4 v) {
+  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ f32x4 mask4(f32x4 g, f32x4 h) {
+  return f32x4{h[0] > 0.f ? g[0] : 0.f, h[1] > 0.f ? g[1] : 0.f, h[2] > 0.f ? g[2] : 0.f, h[3] > 0.f ? g[3] : 0.f};
+}
+
+// kSave (training): activations the backward needs, row-major - enc [M,32], h1 [M,64], so [M,16] (raw sigma-net
+// output: density logit + 15 geo features), cin [M,32] (colour-net input in weight-column order: 16 SH, 15 geo, 0),
+// c1, c2 [M,64].
+struct NerfSave {
+  float *enc, *h1, *so, *cin, *c1, *c2;
+};
+
+template <bool kColor, bool kTable = false, bool kSave = false>
 __global__ void __launch_bounds__(kFieldThreads, INR_FIELD_MIN_WAVES) k_nerf_fwd(const float* __restrict__ x, const float* __restrict__ d,
                                                                int64_t M, const int32_t* __restrict__ n_dev, float bound,
                                                                const float2* __restrict__ emb, uint32_t emb_bytes, GridDesc G,
                                                                const float4* __restrict__ packed, float density_scale,
                                                                float* __restrict__ sigma, float* __restrict__ rgb,
                                                                float* __restrict__ geo, const int32_t* __restrict__ ray_ids,
-                                                               const float4* __restrict__ shq) {
+                                                               const float4* __restrict__ shq, NerfSave sv) {
   extern __shared__ __attribute__((aligned(16))) float4 wl[];
   constexpr int kStage = (kColor ? kNerfFloats : kCol0) / 4;
   for (int i = threadIdx.x; i < kStage; i += kFieldThreads) wl[i] = packed[i];
@@ -648,6 +666,26 @@ __global__ void __launch_bounds__(kFieldThreads, INR_FIELD_MIN_WAVES) k_nerf_fwd
 #pragma unroll
       for (int t = 0; t < 4; ++t) c2[t] = relu4(c2[t]);
       mlp_layer<1, 4>(wl + kCol2 / 4, lane, c2, o);
+      if constexpr (kSave) {
+        if (valid) {
+#pragma unroll
+          for (int t = 0; t < 2; ++t) store4(sv.enc + m * 32 + 16 * t + 4 * q, enc[t]);
+          store4(sv.so + m * 16 + 4 * q, h2[0]);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            store4(sv.h1 + m * 64 + 16 * t + 4 * q, h1[t]);
+            store4(sv.c1 + m * 64 + 16 * t + 4 * q, c1[t]);
+            store4(sv.c2 + m * 64 + 16 * t + 4 * q, c2[t]);
+          }
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) sv.cin[m * 32 + 4 * ks + q] = cin[0][ks];      // SH component 4ks+q
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = 4 * q + r;                                                   // sigma-net output row
+            sv.cin[m * 32 + (row >= 1 ? 15 + row : 31)] = row >= 1 ? h2[0][r] : 0.f;       // geo row-1 | pad column
+          }
+        }
+      }
       if (valid && q == 0) {
 #if INR_TRIM_EXP
         rgb[m * 3 + 0] = __frcp_rn(1.0f + __expf(-o[0][0]));     // v_exp_f32 / v_rcp_f32: ~1e-7 relative
@@ -779,17 +817,6 @@ constexpr int kBwd1 = kBwd2 + 64 * 64;
 constexpr int kBwd0 = kBwd1 + 64 * 64;
 constexpr int kBwdFloats = kBwd0 + 32 * 64;
 
-__device__ __forceinline__ f32x4 load4(const float* p) {
-  const float4 v = *reinterpret_cast<const float4*>(p);
-  return f32x4{v.x, v.y, v.z, v.w};
-}
-__device__ __forceinline__ void store4(float* p, f32x4 v) {
-  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
-}
-__device__ __forceinline__ f32x4 mask4(f32x4 g, f32x4 h) {
-  return f32x4{h[0] > 0.f ? g[0] : 0.f, h[1] > 0.f ? g[1] : 0.f, h[2] > 0.f ? g[2] : 0.f, h[3] > 0.f ? g[3] : 0.f};
-}
-
 __global__ void __launch_bounds__(kFieldThreads, INR_FIELD_MIN_WAVES) k_instance_bwd(const float* __restrict__ dlogits, int K,
                                                                    const float* __restrict__ h1, const float* __restrict__ h2,
                                                                    int64_t M, const float4* __restrict__ packed,
@@ -839,6 +866,93 @@ __global__ void __launch_bounds__(kFieldThreads, INR_FIELD_MIN_WAVES) k_instance
   }
 }
 
+// ---- NeRF field input gradients (training) -------------------------------------------------------------------
+// (g_sigma, g_rgb) -> colour net -> geo features + density logit -> sigma net -> dL/denc, one launch, same
+// transposed formulation as k_instance_bwd.  Sections of `packed` (W^T as the A operand, zero-padded):
+//   C2T 64 x 32 (3 live inputs)   C1T 64 x 64   C0T 16 x 64 (row i = sigma-net output row i: row 0 zero, row i >= 1
+//   is colour-net input column 15 + i)   S1T 64 x 32 (16 live inputs)   S0T 32 x 64.
+constexpr int kNbC2 = 0;
+constexpr int kNbC1 = kNbC2 + 64 * 32;
+constexpr int kNbC0 = kNbC1 + 64 * 64;
+constexpr int kNbS1 = kNbC0 + 16 * 64;
+constexpr int kNbS0 = kNbS1 + 64 * 32;
+constexpr int kNerfBwdFloats = kNbS0 + 32 * 64;      // 11264 floats = 44 KB
+
+struct NerfBwdIO {
+  const float *g_sigma, *g_rgb, *rgb, *so, *h1, *c1, *c2;     // inputs
+  float *d_o, *dz_c2, *dz_c1, *d_so, *dz_h1, *d_enc;           // outputs: [M,4] [M,64] [M,64] [M,16] [M,64] [M,32]
+};
+
+__global__ void __launch_bounds__(kFieldThreads, INR_FIELD_MIN_WAVES) k_nerf_bwd(NerfBwdIO io, int64_t M, float density_scale,
+                                                               const float4* __restrict__ packed) {
+  extern __shared__ __attribute__((aligned(16))) float4 wl[];
+  for (int i = threadIdx.x; i < kNerfBwdFloats / 4; i += kFieldThreads) wl[i] = packed[i];
+  __syncthreads();
+  constexpr int kWaves = kFieldThreads / 64;
+  const int lane = threadIdx.x & 63, q = lane >> 4, j = lane & 15;
+  const int64_t n_tiles = (M + 15) >> 4;
+  const TileSched sched = make_sched(n_tiles, kWaves);
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  for (int64_t it = 0, tile = sched.tile(0); tile < sched.hi; tile = sched.tile(++it)) {
+    const int64_t m = tile * 16 + j;
+    const bool valid = m < M;
+    const int64_t mm = valid ? m : M - 1;
+    // d(rgb logits): rows 0..2 of a 16-row tile live in lane q == 0
+    f32x4 g[2] = {zero4, zero4};
+    if (valid && q == 0) {
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const float c = io.rgb[mm * 3 + r];
+        g[0][r] = io.g_rgb[mm * 3 + r] * c * (1.0f - c);
+      }
+    }
+    if (valid && q == 0) store4(io.d_o + m * 4, g[0]);
+    f32x4 hh[4], a[4], b[4], ds[2], e0[2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) hh[t] = load4(io.c2 + mm * 64 + 16 * t + 4 * q);
+    mlp_layer<4, 2>(wl + kNbC2 / 4, lane, g, a);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      a[t] = mask4(a[t], hh[t]);
+      hh[t] = load4(io.c1 + mm * 64 + 16 * t + 4 * q);
+    }
+    if (valid) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) store4(io.dz_c2 + m * 64 + 16 * t + 4 * q, a[t]);
+    }
+    mlp_layer<4, 4>(wl + kNbC1 / 4, lane, a, b);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      b[t] = mask4(b[t], hh[t]);
+      hh[t] = load4(io.h1 + mm * 64 + 16 * t + 4 * q);
+    }
+    if (valid) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) store4(io.dz_c1 + m * 64 + 16 * t + 4 * q, b[t]);
+    }
+    mlp_layer<1, 4>(wl + kNbC0 / 4, lane, b, ds);      // rows 1..15: d(geo); row 0: 0
+    ds[1] = zero4;
+    if (q == 0) {
+      // density: sigma = density_scale * exp(so0), trunc_exp backward = g * exp(clamp(so0, -15, 15))
+      const float so0 = io.so[mm * 16];
+      ds[0][0] = valid ? io.g_sigma[mm] * density_scale * __expf(fminf(fmaxf(so0, -15.0f), 15.0f)) : 0.f;
+    }
+    if (valid) store4(io.d_so + m * 16 + 4 * q, ds[0]);
+    mlp_layer<4, 2>(wl + kNbS1 / 4, lane, ds, a);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) a[t] = mask4(a[t], hh[t]);
+    if (valid) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) store4(io.dz_h1 + m * 64 + 16 * t + 4 * q, a[t]);
+    }
+    mlp_layer<2, 4>(wl + kNbS0 / 4, lane, a, e0);
+    if (valid) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) store4(io.d_enc + m * 32 + 16 * t + 4 * q, e0[t]);
+    }
+  }
+}
+
 // Device-side weight packing for training (the weights change every step; the host packers above would cost a
 // device->host->device round trip per step).  One thread per packed bf16 pair position; same layout and
 // rounding as pack_section_bf16.  transpose: the section holds W^T of the row-major [n_rows_w, n_cols_w] weight.
@@ -849,9 +963,12 @@ struct PackJob {
   int n_mt, n_s;
   int transpose;
   int dst_off;             // float offset of the section in the packed buffer
+  int kmode;               // 0: k-slot = feature 16*(ks>>2)+4q+(ks&3); 1: colour-net input (kidx_color_in)
+  int row_min, row_shift;  // transpose only: rows below row_min are zero, row i reads source column i + row_shift
+  int bwd;                 // which output buffer
 };
 struct PackJobs {
-  PackJob j[6];
+  PackJob j[10];
 };
 
 __device__ __forceinline__ uint16_t bf16_rne_dev(float x) {
@@ -865,15 +982,23 @@ __global__ void __launch_bounds__(256) k_pack_weights(PackJobs jobs, float* __re
                                                       float* __restrict__ packed_bwd) {
   const PackJob J = jobs.j[blockIdx.y];
   const int total = J.n_mt * J.n_s * 64 * 8;
-  float* base = (blockIdx.y < 3 ? packed_fwd : packed_bwd) + J.dst_off;
+  float* base = (J.bwd ? packed_bwd : packed_fwd) + J.dst_off;
   uint16_t* dst = reinterpret_cast<uint16_t*>(base);
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
     const int e = i & 7, lane = (i >> 3) & 63, rest = i >> 9;
     const int st = rest % J.n_s, mt = rest / J.n_s;
     const int row = 16 * mt + (lane & 15);
-    const int col = 16 * (2 * st + (e >> 2)) + 4 * (lane >> 4) + (e & 3);
+    const int qq = lane >> 4;
+    int col = 16 * (2 * st + (e >> 2)) + 4 * qq + (e & 3);
+    if (J.kmode == 1) {                                  // colour-net input: 4 SH slots, then sigma-net rows (row 0 unused)
+      const int r = 4 * qq + (e & 3);
+      col = (e >> 2) == 0 ? 4 * (e & 3) + qq : (r >= 1 ? 15 + r : -1);
+    }
     float v = 0.f;
-    if (row < J.n_out && col < J.n_in) v = J.transpose ? J.W[(size_t)col * J.w_cols + row] : J.W[(size_t)row * J.w_cols + col];
+    if (row < J.n_out && col >= 0 && col < J.n_in) {
+      if (!J.transpose) v = J.W[(size_t)row * J.w_cols + col];
+      else if (row >= J.row_min) v = J.W[(size_t)col * J.w_cols + row + J.row_shift];
+    }
     const uint16_t hi = bf16_rne_dev(v);
     const uint16_t lo = bf16_rne_dev(v - __uint_as_float((uint32_t)hi << 16));
     dst[((((size_t)(mt * J.n_s + st) * 2 + 0) * 64 + lane) * 8) + e] = hi;
@@ -1224,12 +1349,12 @@ int inr_nerf_forward(const float* x, const float* d, int64_t M, const int32_t* n
     const size_t lds = kNerfFloats * sizeof(float) + kLevelRecBytes;
     const int grid = grid_for(k_nerf_fwd<true>, lds, n_tiles);
     k_nerf_fwd<true><<<grid, kFieldThreads, lds, as_stream(s)>>>(x, d, M, n_samples_dev, bound, e, emb_bytes, G, p,
-                                                      density_scale, sigma, rgb, geo_feat, nullptr, nullptr);
+                                                      density_scale, sigma, rgb, geo_feat, nullptr, nullptr, NerfSave{});
   } else {
     const size_t lds = kCol0 * sizeof(float) + kLevelRecBytes;
     const int grid = grid_for(k_nerf_fwd<false>, lds, n_tiles);
     k_nerf_fwd<false><<<grid, kFieldThreads, lds, as_stream(s)>>>(x, d, M, n_samples_dev, bound, e, emb_bytes, G, p,
-                                                       density_scale, sigma, nullptr, geo_feat, nullptr, nullptr);
+                                                       density_scale, sigma, nullptr, geo_feat, nullptr, nullptr, NerfSave{});
   }
   return check_launch("nerf_forward");
 }
@@ -1252,7 +1377,7 @@ int inr_nerf_forward_table(const float* x01, const int32_t* ray_ids, const float
   k_nerf_fwd<true, true><<<grid, kFieldThreads, lds, as_stream(s)>>>(
       x01, nullptr, M, nullptr, bound, reinterpret_cast<const float2*>(embeddings), (uint32_t)emb_bytes64, G,
       reinterpret_cast<const float4*>(packed), density_scale, sigma, rgb, nullptr, ray_ids,
-      reinterpret_cast<const float4*>(sh_table_q));
+      reinterpret_cast<const float4*>(sh_table_q), NerfSave{});
   return check_launch("nerf_forward_table");
 }
 
@@ -1298,12 +1423,12 @@ int inr_instance_pack_weights_device(const float* w0, const float* w1, const flo
   INR_REQUIRE(((uintptr_t)packed_fwd & 15) == 0 && ((uintptr_t)packed_bwd & 15) == 0, "packed buffers misaligned");
   PackJobs jobs;
   //           W   rows cols  n_out n_in  mt      steps T  offset
-  jobs.j[0] = {w0, 64, 32, 64, 32, 4, 1, 0, kIns0};
-  jobs.j[1] = {w1, 64, 64, 64, 64, 4, 2, 0, kIns1};
-  jobs.j[2] = {w2, K, 64, K, 64, K / 16, 2, 0, kIns2};
-  jobs.j[3] = {w2, K, 64, 64, K, 4, 2, 1, kBwd2};
-  jobs.j[4] = {w1, 64, 64, 64, 64, 4, 2, 1, kBwd1};
-  jobs.j[5] = {w0, 64, 32, 32, 64, 2, 2, 1, kBwd0};
+  jobs.j[0] = {w0, 64, 32, 64, 32, 4, 1, 0, kIns0, 0, 0, 0, 0};
+  jobs.j[1] = {w1, 64, 64, 64, 64, 4, 2, 0, kIns1, 0, 0, 0, 0};
+  jobs.j[2] = {w2, K, 64, K, 64, K / 16, 2, 0, kIns2, 0, 0, 0, 0};
+  jobs.j[3] = {w2, K, 64, 64, K, 4, 2, 1, kBwd2, 0, 0, 0, 1};
+  jobs.j[4] = {w1, 64, 64, 64, 64, 4, 2, 1, kBwd1, 0, 0, 0, 1};
+  jobs.j[5] = {w0, 64, 32, 32, 64, 2, 2, 1, kBwd0, 0, 0, 0, 1};
   k_pack_weights<<<dim3(8, 6), 256, 0, as_stream(s)>>>(jobs, packed_fwd, packed_bwd);
   return check_launch("instance_pack_weights_device");
 #endif
@@ -1352,6 +1477,75 @@ int inr_instance_backward(const float* grad_logits, int32_t K, const float* h1, 
   k_instance_bwd<<<grid_for(k_instance_bwd, lds, n_tiles), kFieldThreads, lds, as_stream(s)>>>(
       grad_logits, K, h1, h2, M, reinterpret_cast<const float4*>(packed_bwd), grad_z2, grad_z1, grad_enc);
   return check_launch("instance_backward");
+}
+
+int64_t inr_nerf_bwd_packed_floats(void) { return kNerfBwdFloats; }
+
+int inr_nerf_pack_weights_device(const float* sigma_w0, const float* sigma_w1, const float* color_w0,
+                                 const float* color_w1, const float* color_w2, float* packed_fwd, float* packed_bwd,
+                                 inr_stream_t s) {
+#if INR_MLP_FP32
+  set_error("nerf_pack_weights_device: built with INR_MLP_FP32 (no device packer for the fp32 layout)");
+  return INR_EINVAL;
+#else
+  INR_REQUIRE(sigma_w0 && sigma_w1 && color_w0 && color_w1 && color_w2 && packed_fwd && packed_bwd, "null pointer");
+  INR_REQUIRE(((uintptr_t)packed_fwd & 15) == 0 && ((uintptr_t)packed_bwd & 15) == 0, "packed buffers misaligned");
+  PackJobs jobs;
+  //           W         rows cols n_out n_in mt steps T  offset kmode row_min shift bwd
+  jobs.j[0] = {sigma_w0, 64, 32, 64, 32, 4, 1, 0, kSig0, 0, 0, 0, 0};
+  jobs.j[1] = {sigma_w1, 16, 64, 16, 64, 1, 2, 0, kSig1, 0, 0, 0, 0};
+  jobs.j[2] = {color_w0, 64, 31, 64, 31, 4, 1, 0, kCol0, 1, 0, 0, 0};
+  jobs.j[3] = {color_w1, 64, 64, 64, 64, 4, 2, 0, kCol1, 0, 0, 0, 0};
+  jobs.j[4] = {color_w2, 3, 64, 3, 64, 1, 2, 0, kCol2, 0, 0, 0, 0};
+  jobs.j[5] = {color_w2, 3, 64, 64, 3, 4, 1, 1, kNbC2, 0, 0, 0, 1};
+  jobs.j[6] = {color_w1, 64, 64, 64, 64, 4, 2, 1, kNbC1, 0, 0, 0, 1};
+  jobs.j[7] = {color_w0, 64, 31, 16, 64, 1, 2, 1, kNbC0, 0, 1, 15, 1};      // row i >= 1 <- input column 15 + i
+  jobs.j[8] = {sigma_w1, 16, 64, 64, 16, 4, 1, 1, kNbS1, 0, 0, 0, 1};
+  jobs.j[9] = {sigma_w0, 64, 32, 32, 64, 2, 2, 1, kNbS0, 0, 0, 0, 1};
+  k_pack_weights<<<dim3(8, 10), 256, 0, as_stream(s)>>>(jobs, packed_fwd, packed_bwd);
+  return check_launch("nerf_pack_weights_device");
+#endif
+}
+
+int inr_nerf_forward_train(const float* x, const float* d, int64_t M, float bound, const float* embeddings,
+                           const inr_grid_desc* desc, const float* packed, float* sigma, float* rgb, float* enc,
+                           float* h1, float* so, float* cin, float* c1, float* c2, inr_stream_t s) {
+  INR_REQUIRE(M >= 0 && desc, "bad argument");
+  if (M == 0) return INR_OK;
+  INR_REQUIRE(x && d && embeddings && packed && sigma && rgb && enc && h1 && so && cin && c1 && c2, "null pointer");
+  INR_REQUIRE(((uintptr_t)embeddings & 7) == 0 &&
+                  (((uintptr_t)packed | (uintptr_t)enc | (uintptr_t)h1 | (uintptr_t)so | (uintptr_t)cin | (uintptr_t)c1 |
+                    (uintptr_t)c2) & 15) == 0, "embeddings/packed/activation arrays misaligned");
+  GridDesc G;
+  int rc = make_grid_desc(desc, G);
+  if (rc) return rc;
+  const uint64_t emb_bytes64 = (uint64_t)desc->offsets[desc->num_levels] * 8ull;
+  INR_REQUIRE(emb_bytes64 < (1ull << 31), "table larger than 2 GiB is not addressable by the 32-bit gather offsets");
+  const size_t lds = kNerfFloats * sizeof(float) + kLevelRecBytes;
+  const int grid = grid_for(k_nerf_fwd<true, false, true>, lds, (M + 15) / 16);
+  k_nerf_fwd<true, false, true><<<grid, kFieldThreads, lds, as_stream(s)>>>(
+      x, d, M, nullptr, bound, reinterpret_cast<const float2*>(embeddings), (uint32_t)emb_bytes64, G,
+      reinterpret_cast<const float4*>(packed), 1.0f, sigma, rgb, nullptr, nullptr, nullptr,
+      NerfSave{enc, h1, so, cin, c1, c2});
+  return check_launch("nerf_forward_train");
+}
+
+int inr_nerf_backward(const float* grad_sigma, const float* grad_rgb, const float* rgb, const float* so, const float* h1,
+                      const float* c1, const float* c2, int64_t M, float density_scale, const float* packed_bwd,
+                      float* grad_o, float* grad_zc2, float* grad_zc1, float* grad_so, float* grad_zh1, float* grad_enc,
+                      inr_stream_t s) {
+  INR_REQUIRE(M >= 0, "negative M");
+  if (M == 0) return INR_OK;
+  INR_REQUIRE(grad_sigma && grad_rgb && rgb && so && h1 && c1 && c2 && packed_bwd && grad_o && grad_zc2 && grad_zc1 &&
+                  grad_so && grad_zh1 && grad_enc, "null pointer");
+  INR_REQUIRE((((uintptr_t)so | (uintptr_t)h1 | (uintptr_t)c1 | (uintptr_t)c2 | (uintptr_t)packed_bwd | (uintptr_t)grad_o |
+                (uintptr_t)grad_zc2 | (uintptr_t)grad_zc1 | (uintptr_t)grad_so | (uintptr_t)grad_zh1 |
+                (uintptr_t)grad_enc) & 15) == 0, "arrays must be 16-byte aligned");
+  const size_t lds = (size_t)kNerfBwdFloats * sizeof(float);
+  NerfBwdIO io{grad_sigma, grad_rgb, rgb, so, h1, c1, c2, grad_o, grad_zc2, grad_zc1, grad_so, grad_zh1, grad_enc};
+  k_nerf_bwd<<<grid_for(k_nerf_bwd, lds, (M + 15) / 16), kFieldThreads, lds, as_stream(s)>>>(
+      io, M, density_scale, reinterpret_cast<const float4*>(packed_bwd));
+  return check_launch("nerf_backward");
 }
 
 int inr_instance_render(const float* xyzs, const int32_t* rays, const float* weights, int64_t N, int64_t M, float bound,

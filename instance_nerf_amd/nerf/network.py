@@ -107,6 +107,75 @@ class _InstanceFieldFn(torch.autograd.Function):
         return None, g_emb, gw0, gw1, gw2, None, None
 
 
+class _NerfFieldFn(torch.autograd.Function):
+    """(x, d) -> (sigma, rgb) of the NeRF field for TRAINING: one fused forward that keeps the activations and one
+    fused backward for the whole input-gradient chain (colour net -> geo features / density logit -> sigma net ->
+    encoder), csrc/field_fused.hip::k_nerf_fwd<.., kSave> / k_nerf_bwd.  Weight gradients: the two-pass MFMA kernel;
+    table gradient: the atomic scatter.  sigma is returned WITHOUT density_scale (the renderer applies it)."""
+
+    @staticmethod
+    def forward(ctx, x, d, emb, ws0, ws1, wc0, wc1, wc2, desc, bound):
+        lib = _lib.load()
+        f32 = torch.float32
+        M, dev = x.shape[0], x.device
+        pf = torch.empty(lib.inr_nerf_packed_floats(), dtype=f32, device=dev)
+        pb = torch.empty(lib.inr_nerf_bwd_packed_floats(), dtype=f32, device=dev)
+        ws = [w.detach().contiguous() for w in (ws0, ws1, wc0, wc1, wc2)]
+        check(lib.inr_nerf_pack_weights_device(*[ptr(w, f32, "weight") for w in ws], ptr(pf), ptr(pb), stream_ptr()),
+              "nerf_pack_weights_device")
+        sigma = torch.empty(M, dtype=f32, device=dev)
+        rgb = torch.empty(M, 3, dtype=f32, device=dev)
+        widths = (32, 64, 16, 32, 64, 64)                       # enc, h1, so, cin, c1, c2
+        act = torch.empty(M * sum(widths), dtype=f32, device=dev)
+        parts, off = [], 0
+        for wdt in widths:
+            parts.append(act[off:off + M * wdt].view(M, wdt))
+            off += M * wdt
+        enc, h1, so, cin, c1, c2 = parts
+        if M:
+            check(lib.inr_nerf_forward_train(ptr(x, f32, "x"), ptr(d, f32, "d"), M, float(bound),
+                                             ptr(emb.detach(), f32, "embeddings"), desc, ptr(pf), ptr(sigma), ptr(rgb),
+                                             ptr(enc), ptr(h1), ptr(so), ptr(cin), ptr(c1), ptr(c2), stream_ptr()),
+                  "nerf_forward_train")
+        ctx.save_for_backward(x, rgb, enc, h1, so, cin, c1, c2, pb, emb)
+        ctx.desc, ctx.bound = desc, bound
+        ctx.set_materialize_grads(False)
+        return sigma, rgb
+
+    @staticmethod
+    def backward(ctx, g_sigma, g_rgb):
+        lib = _lib.load()
+        f32 = torch.float32
+        x, rgb, enc, h1, so, cin, c1, c2, pb, emb = ctx.saved_tensors
+        M, dev = x.shape[0], x.device
+        g_sigma = torch.zeros(M, dtype=f32, device=dev) if g_sigma is None else g_sigma.contiguous().float()
+        g_rgb = torch.zeros(M, 3, dtype=f32, device=dev) if g_rgb is None else g_rgb.contiguous().float()
+        widths = (4, 64, 64, 16, 64, 32)                        # d_o, dz_c2, dz_c1, d_so, dz_h1, d_enc
+        buf = torch.empty(M * sum(widths), dtype=f32, device=dev)
+        parts, off = [], 0
+        for wdt in widths:
+            parts.append(buf[off:off + M * wdt].view(M, wdt))
+            off += M * wdt
+        d_o, dz_c2, dz_c1, d_so, dz_h1, d_enc = parts
+        sizes = (4 * 64, 64 * 64, 64 * 32, 16 * 64, 64 * 32)    # wc2 (4 rows, 3 live), wc1, wc0 (32 cols, 31 live), ws1, ws0
+        gw = torch.zeros(sum(sizes), dtype=f32, device=dev)
+        gwc2, gwc1, gwc0, gws1, gws0 = [g.view(*shape) for g, shape in zip(
+            gw.split(sizes), ((4, 64), (64, 64), (64, 32), (16, 64), (64, 32)))]
+        g_emb = torch.zeros_like(emb)
+        if M:
+            check(lib.inr_nerf_backward(ptr(g_sigma), ptr(g_rgb), ptr(rgb), ptr(so), ptr(h1), ptr(c1), ptr(c2), M, 1.0,
+                                        ptr(pb), ptr(d_o), ptr(dz_c2), ptr(dz_c1), ptr(d_so), ptr(dz_h1), ptr(d_enc),
+                                        stream_ptr()), "nerf_backward")
+            wsp = torch.empty(lib.inr_linear_wgrad_workspace_bytes() // 4, dtype=f32, device=dev)
+            for xin, gy, n_in, n_out, out in ((c2, d_o, 64, 4, gwc2), (c1, dz_c2, 64, 64, gwc1), (cin, dz_c1, 32, 64, gwc0),
+                                              (h1, d_so, 64, 16, gws1), (enc, dz_h1, 32, 64, gws0)):
+                check(lib.inr_linear_wgrad(ptr(xin), ptr(gy), M, n_in, n_out, ptr(out), ptr(wsp), stream_ptr()),
+                      "linear_wgrad")
+            check(lib.inr_grid_encode_backward_ordered(ptr(x), ptr(d_enc), None, ctx.desc, M, float(ctx.bound),
+                                                       ptr(g_emb), stream_ptr()), "grid_encode_backward")
+        return None, None, g_emb, gws0, gws1, gwc0[:, :31], gwc1, gwc2[:3], None, None
+
+
 class HipLinear(nn.Linear):
     """nn.Linear(bias=False) whose backward uses the HIP weight-gradient kernel (same parameters/state dict)."""
 
@@ -155,6 +224,7 @@ class NeRFNetwork(NeRFRenderer):
                               and hidden_dim_instance == 64)
         self._packed = {}
         self.fused_instance_train = True     # False: HIP encoder + rocBLAS layers (the composable path)
+        self.fused_nerf_train = True
 
     # ---- packed MFMA weights (cached until a weight tensor changes) ------------------------------
     def _packed_weights(self, which):
@@ -233,6 +303,11 @@ class NeRFNetwork(NeRFRenderer):
         if self._fusable and not self._needs_grad(self._nerf_params()):
             sigma, rgb, _ = self._fused_nerf(x, d, True, False)
             return sigma, rgb
+        if (self._fusable and self.fused_nerf_train and x.is_cuda and torch.is_grad_enabled()
+                and all(p.requires_grad for p in self._nerf_params()) and not (x.requires_grad or d.requires_grad)):
+            return _NerfFieldFn.apply(x.contiguous().float(), d.contiguous().float(), self.encoder.embeddings,
+                                      self.sigma_net[0].weight, self.sigma_net[1].weight, self.color_net[0].weight,
+                                      self.color_net[1].weight, self.color_net[2].weight, self.encoder.desc, self.bound)
         h = _run_mlp(self.sigma_net, self.encoder(x, bound=self.bound))
         sigma = trunc_exp(h[..., 0])
         geo_feat = h[..., 1:]

@@ -909,3 +909,92 @@ def test_instance_field_fused_training_autograd(level_table):
         if a.shape[0] > 64:          # the table: a flipped sample only touches its own 16 x 8 rows
             bad = ((a - b).abs() > 1e-3 * b.abs().max()).sum().item()
             assert bad <= 0.002 * int((b != 0).sum()), bad
+
+
+def test_nerf_field_fused_training_kernels(level_table):
+    """C ABI of the fused NeRF-field training path against fp32 torch: device-packed weights (same bits as the host
+    packer), forward with saved activations, and the one-launch input-gradient chain (ReLU masks from the kernel's own
+    activations)."""
+    from instance_nerf_amd import _lib
+    from instance_nerf_amd._lib import check, ptr, stream_ptr
+    from oracle import field, hashgrid, sh
+    lib = _lib.load()
+    p = field.init_params(seed=31, table=level_table, table_std=0.5)
+    net = _network(p, K=0)
+    gen = torch.Generator().manual_seed(6)
+    M = 4000 + 5
+    x = (torch.rand(M, 3, generator=gen) * 2 - 1).to(DEV)
+    d = torch.randn(M, 3, generator=gen)
+    d = (d / d.norm(dim=1, keepdim=True)).to(DEV)
+    ws0, ws1 = [l.weight.detach() for l in net.sigma_net]
+    wc0, wc1, wc2 = [l.weight.detach() for l in net.color_net]
+    emb = net.encoder.embeddings.data
+    pf = torch.empty(lib.inr_nerf_packed_floats(), device=DEV)
+    pb = torch.empty(lib.inr_nerf_bwd_packed_floats(), device=DEV)
+    check(lib.inr_nerf_pack_weights_device(ptr(ws0), ptr(ws1), ptr(wc0), ptr(wc1), ptr(wc2), ptr(pf), ptr(pb),
+                                           stream_ptr()), "pack")
+    assert (pf.cpu() == net._packed_weights("nerf").cpu()).all()
+    E = lambda w: torch.empty(M, w, device=DEV)
+    sigma, rgb = torch.empty(M, device=DEV), E(3)
+    enc, h1, so, cin, c1, c2 = E(32), E(64), E(16), E(32), E(64), E(64)
+    check(lib.inr_nerf_forward_train(ptr(x), ptr(d), M, 1.0, ptr(emb), net.encoder.desc, ptr(pf), ptr(sigma), ptr(rgb),
+                                     ptr(enc), ptr(h1), ptr(so), ptr(cin), ptr(c1), ptr(c2), stream_ptr()), "fwd")
+    rel = lambda a, b: float((a - b).abs().max() / b.abs().max())
+    with torch.no_grad():
+        enc_r = hashgrid.encode(x.cpu(), p["embeddings"], 1.0, level_table).to(DEV)
+        h1_r = torch.relu(enc_r @ ws0.t())
+        so_r = h1_r @ ws1.t()
+        sh_r = sh.sh_encode(d.cpu()).to(DEV) if hasattr(sh, "sh_encode") else net.encoder_dir(d)
+        cin_r = torch.cat([sh_r, so_r[:, 1:]], -1)
+        c1_r = torch.relu(cin_r @ wc0.t())
+        c2_r = torch.relu(c1_r @ wc1.t())
+        rgb_r = torch.sigmoid(c2_r @ wc2.t())
+        s0, r0 = net(x, d)                              # inference kernel
+    assert rel(enc, enc_r) < 1e-5 and rel(h1, h1_r) < 1e-4 and rel(so, so_r) < 1e-4
+    assert rel(cin[:, :31], cin_r) < 1e-4 and (cin[:, 31] == 0).all()
+    assert rel(c1, c1_r) < 1e-4 and rel(c2, c2_r) < 1e-4 and rel(rgb, rgb_r) < 1e-4
+    assert rel(sigma, torch.exp(so_r[:, 0])) < 1e-4
+    assert (sigma == s0).all() and (rgb == r0).all()
+    g_sigma = torch.randn(M, generator=gen).to(DEV)
+    g_rgb = torch.randn(M, 3, generator=gen).to(DEV)
+    d_o, dz_c2, dz_c1, d_so, dz_h1, d_enc = E(4), E(64), E(64), E(16), E(64), E(32)
+    check(lib.inr_nerf_backward(ptr(g_sigma), ptr(g_rgb), ptr(rgb), ptr(so), ptr(h1), ptr(c1), ptr(c2), M, 1.0, ptr(pb),
+                                ptr(d_o), ptr(dz_c2), ptr(dz_c1), ptr(d_so), ptr(dz_h1), ptr(d_enc), stream_ptr()), "bwd")
+    do_r = g_rgb * rgb * (1 - rgb)
+    dzc2_r = (do_r @ wc2) * (c2 > 0)
+    dzc1_r = (dzc2_r @ wc1) * (c1 > 0)
+    dcin_r = dzc1_r @ wc0
+    dso_r = torch.cat([(g_sigma * torch.exp(so[:, 0].clamp(-15, 15)))[:, None], dcin_r[:, 16:]], -1)
+    dzh1_r = (dso_r @ ws1) * (h1 > 0)
+    denc_r = dzh1_r @ ws0
+    assert rel(d_o[:, :3], do_r) < 1e-5 and (d_o[:, 3] == 0).all()
+    assert rel(dz_c2, dzc2_r) < 1e-4 and rel(dz_c1, dzc1_r) < 1e-4 and rel(d_so, dso_r) < 1e-4
+    assert rel(dz_h1, dzh1_r) < 1e-4 and rel(d_enc, denc_r) < 1e-4
+
+
+def test_nerf_field_fused_training_autograd(level_table):
+    """End to end through autograd: fused vs composable NeRF-field training path (see the instance-field twin)."""
+    from oracle import field
+    p = field.init_params(seed=32, table=level_table, table_std=0.5)
+    net = _network(p, K=0).train()
+    gen = torch.Generator().manual_seed(7)
+    M = 6000
+    x = (torch.rand(M, 3, generator=gen) * 2 - 1).to(DEV)
+    d = torch.randn(M, 3, generator=gen)
+    d = (d / d.norm(dim=1, keepdim=True)).to(DEV)
+    gs, gc = torch.randn(M, generator=gen).to(DEV), torch.randn(M, 3, generator=gen).to(DEV)
+    params = net._nerf_params()
+    res = {}
+    for fused in (True, False):
+        net.fused_nerf_train = fused
+        for q in params:
+            q.grad = None
+        sigma, rgb = net(x, d)
+        assert sigma.requires_grad and rgb.requires_grad
+        ((sigma * gs).sum() + (rgb * gc).sum()).backward()
+        res[fused] = (sigma.detach().clone(), rgb.detach().clone(), [q.grad.detach().clone() for q in params])
+    assert (res[True][0] - res[False][0]).abs().max() < 1e-4 * res[False][0].abs().max()
+    assert (res[True][1] - res[False][1]).abs().max() < 1e-5
+    for a, b in zip(res[True][2], res[False][2]):
+        assert a.shape == b.shape
+        assert torch.linalg.norm(a - b) < 2e-2 * torch.linalg.norm(b)
