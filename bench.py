@@ -80,21 +80,23 @@ def cpu_baseline(room, chunk=4096, budget_s=12.0, max_chunks=24):
                       f"oracle march+field+composite, {t_used:.1f} s"}
 
 
-def train_probe(dev, rank=0, world=1, red_dev=None, steps=20, warmup=5):
+def train_probe(dev, rank=0, world=1, red_dev=None, steps=20, warmup=5, stage="instance"):
     """Secondary measurement (not the headline value): instance-field training step, BASELINE configs[2]
     (K=64 logits, 4096 rays/batch per GPU, NeRF frozen): march -> frozen NeRF (fused) -> instance grid encode ->
     MLP -> K-channel compositing -> CE -> backward (atomic scatter) -> [gradient all-reduce] -> fused Adam.
     With world > 1 this is configs[3]: every rank draws its own rays, parameters are replicated and the
-    gradients (49 MB hash table + MLP) are all-reduced over RCCL each step; all ranks must call it."""
+    gradients (49 MB hash table + MLP) are all-reduced over RCCL each step; all ranks must call it.
+    stage="nerf": the same loop for the NeRF itself (MSE on rgb; table + sigma/colour nets trained)."""
     import torch.distributed as dist
     from instance_nerf_amd.nerf import NeRFNetwork
     from instance_nerf_amd.nerf.provider import SyntheticRoomDataset
     from instance_nerf_amd.nerf.utils import Trainer
     torch.manual_seed(0)                   # replicated initial parameters
-    net = NeRFNetwork(cuda_ray=True, bound=1, min_near=0.05, density_thresh=10, num_instances=64).to(dev)
+    net = NeRFNetwork(cuda_ray=True, bound=1, min_near=0.05, density_thresh=10,
+                      num_instances=64 if stage == "instance" else 0).to(dev)
     ds = SyntheticRoomDataset(dev, num_rays=4096, num_instances=64, rank=rank)
     net.density_bitfield.copy_(torch.from_numpy(ds.room.density_bitfield(128, 1.0)).to(dev))
-    tr = Trainer("bench", None, net, stage="instance", device=dev, iters=1000, update_extra_interval=10 ** 9,
+    tr = Trainer("bench", None, net, stage=stage, device=dev, iters=1000, update_extra_interval=10 ** 9,
                  local_rank=rank, world_size=world)
     tr.global_step = 1                     # keep the analytic occupancy grid
     batches = [ds.batch() for _ in range(4)]
@@ -136,8 +138,10 @@ def train_probe(dev, rank=0, world=1, red_dev=None, steps=20, warmup=5):
         elapsed, n_all = float(tm.item()), float(ts.item())
     dt = elapsed / steps
     reduced = sum(p.numel() for g in tr.optimizer.param_groups for p in g["params"]) * 4
-    return {"workload": "instance-field training step, K=64, 4096 rays/batch per GPU, NeRF frozen "
-                        f"(BASELINE configs[{2 if world == 1 else 3}])",
+    what = ("instance-field training step, K=64, 4096 rays/batch per GPU, NeRF frozen "
+            f"(BASELINE configs[{2 if world == 1 else 3}])") if stage == "instance" else \
+        "NeRF training step (MSE on rgb: hash table + sigma/colour nets), 4096 rays/batch per GPU"
+    return {"workload": what,
             "n_gpus": world, "ms_per_step": round(dt * 1e3, 3), "samples_per_step": int(n_all) // steps,
             "msamples_per_s": round(n_all / steps / dt / 1e6, 2),
             "allreduce_mb_per_step": round(reduced / 1e6, 1) if world > 1 else 0.0,
@@ -277,8 +281,10 @@ def main():
     if not args.no_train_probe:
         del net                                       # the probe builds its own (instance-head) network
         ts = train_probe(dev, rank, world, red_dev)   # collective when world > 1: every rank runs it
+        tn = train_probe(dev, rank, world, red_dev, stage="nerf")
         if rank == 0:
             line["train_step"] = ts
+            line["train_step_nerf"] = tn
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:
