@@ -8,13 +8,17 @@ The instance head (``instance_encoder``, ``instance_net``, ``num_instances``) is
 this repository's reading of the fork's addition [U-fork]: a position-only
 hash-grid + MLP producing K raw logits.
 
-Two execution paths, both HIP:
+Execution paths, all HIP:
 * no-grad (render / occupancy update / frozen NeRF under instance training):
-  ONE fused kernel per call - gather + SH + MLPs on fp32 MFMA
+  ONE fused kernel per call - gather + SH + MLPs on the matrix cores
   (csrc/field_fused.hip);
-* grad: hand-written HIP encoders (forward gather, backward atomic scatter) with
-  the tiny MLP GEMMs left to rocBLAS through ``nn.Linear`` - upstream's default
-  configuration (its ``--ff`` fused MLP is optional there too).
+* grad, standard architecture (``_NerfFieldFn`` / ``_InstanceFieldFn``): a fused
+  forward that keeps the activations, ONE fused backward for the whole
+  input-gradient chain, the two-pass MFMA weight-gradient kernel and the atomic
+  table scatter;
+* grad, any other layer shape (or ``fused_*_train = False``): hand-written HIP
+  encoders with the tiny MLP GEMMs left to rocBLAS through ``nn.Linear`` -
+  upstream's default configuration (its ``--ff`` fused MLP is optional there too).
 """
 import torch
 import torch.nn as nn
