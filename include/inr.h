@@ -84,9 +84,11 @@ int inr_packbits(const float* grid, int64_t n_bytes, float thresh, uint8_t* bitf
  * counter[0] = total samples, counter[1] = N), size the outputs (M rows), then
  * inr_march_rays_train_write.  A ray whose offset + count > M is dropped (its
  * rays row is still written).  workspace: inr_march_workspace_bytes(N, sample_cap), 8-byte aligned.
- * sample_cap > 0: the count pass records (t, delta) of each ray's first sample_cap samples in the
- * workspace and the write pass replays them instead of marching again (rays with more samples are
- * re-marched); pass the SAME workspace and sample_cap to the write call.  Results are identical.      */
+ * sample_cap > 0: the count pass records, one bit per step candidate (the sequence t_{i+1} = t_i + dt(t_i) is
+ * independent of the grid), which of each ray's first sample_cap candidates were emitted; the write pass
+ * regenerates the sequence and emits at the set bits instead of walking the occupancy grid again (rays that
+ * need more candidates are re-marched); pass the SAME workspace and sample_cap to the write call.  Results
+ * are identical.                                                                                        */
 int64_t inr_march_workspace_bytes(int64_t N, int32_t sample_cap);
 int inr_march_rays_train_count(const float* rays_o, const float* rays_d, const uint8_t* bitfield,
                                float bound, float dt_gamma, int32_t max_steps, int64_t N,

@@ -122,10 +122,12 @@ __device__ __forceinline__ float step_dt(const MarchParams& P, float t) {
   return clampf(t * P.dt_gamma, P.dt_min, P.dt_max);
 }
 
-// Marches from t until t >= far or max_emit samples were emitted.  emit(px,py,pz,dt,delta,t).
-template <class Emit>
+// Marches from t until t >= far or max_emit samples were emitted.  emit(px,py,pz,dt,delta,t); advance() is called
+// every time t moves on by one step, i.e. once per step CANDIDATE (the sequence t_0 = t, t_{i+1} = t_i + dt(t_i)
+// does not depend on the grid - only which candidates are visited and emitted does).
+template <class Emit, class Advance>
 __device__ __forceinline__ int march_ray(const MarchParams& P, const Ray& r, float t, float far,
-                                         int max_emit, Emit&& emit) {
+                                         int max_emit, Emit&& emit, Advance&& advance) {
   int n = 0;
   float last_t = t;
   while (t < far && n < max_emit) {
@@ -148,6 +150,7 @@ __device__ __forceinline__ int march_ray(const MarchParams& P, const Ray& r, flo
       const float tn = t + dt;
       emit(px, py, pz, dt, tn - last_t, t);
       t = tn;
+      advance();
       last_t = tn;
       ++n;
     } else {
@@ -160,10 +163,16 @@ __device__ __forceinline__ int march_ray(const MarchParams& P, const Ray& r, flo
       const float tt = t + fmaxf(0.0f, fminf(cx, fminf(cy, cz)));
       do {
         t = t + step_dt(P, t);
+        advance();
       } while (t < tt);
     }
   }
   return n;
+}
+template <class Emit>
+__device__ __forceinline__ int march_ray(const MarchParams& P, const Ray& r, float t, float far,
+                                         int max_emit, Emit&& emit) {
+  return march_ray(P, r, t, far, max_emit, emit, [] {});
 }
 
 __device__ __forceinline__ float start_t(const MarchParams& P, float near, float noise) {
@@ -178,22 +187,37 @@ __global__ void __launch_bounds__(kRayBlock) k_march_count(MarchParams P, const 
                                                            const float* __restrict__ noises,
                                                            int32_t* __restrict__ counts,
                                                            int32_t* __restrict__ block_sums,
-                                                           float2* __restrict__ cap_buf, int cap) {
+                                                           uint32_t* __restrict__ mask, int cap_words) {
   __shared__ int32_t wsum[kRayBlock / 64];
   const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   int cnt = 0;
   if (n < N) {
     const Ray r = load_ray(rays_o, rays_d, n);
     const float t0 = start_t(P, nears[n], noises ? noises[n] : 0.0f);
-    if (cap > 0) {
-      // Record (t, delta) of the first `cap` samples of the ray: the write pass replays them (position and
-      // dt are pure functions of t, evaluated with the same operations) instead of marching a second time.
-      float2* row = cap_buf + n * cap;
-      int k = 0;
-      cnt = march_ray(P, r, t0, fars[n], max_steps, [&](float, float, float, float, float delta, float t) {
-        if (k < cap) row[k] = make_float2(t, delta);
-        ++k;
-      });
+    if (cap_words > 0) {
+      // Record WHICH step candidates were emitted, one bit per candidate, words laid out [word][ray]: the write
+      // pass regenerates the candidate sequence with the same additions and emits at the set bits - no second
+      // walk through the occupancy grid.  A ray that runs past the last word is flagged and marched again.
+      uint32_t word = 0;
+      int widx = 0, cand = 0;
+      bool ok = true;
+      cnt = march_ray(P, r, t0, fars[n], max_steps,
+                      [&](float, float, float, float, float, float) {
+                        const int w = cand >> 5;
+                        if (w < cap_words) {
+                          while (widx < w) {
+                            mask[(int64_t)widx * N + n] = word;
+                            word = 0;
+                            ++widx;
+                          }
+                          word |= 1u << (cand & 31);
+                        } else {
+                          ok = false;
+                        }
+                      },
+                      [&] { ++cand; });
+      if (widx < cap_words) mask[(int64_t)widx * N + n] = word;
+      mask[(int64_t)cap_words * N + n] = ok ? 1u : 0u;
     } else {
       cnt = march_ray(P, r, t0, fars[n], max_steps, [](float, float, float, float, float, float) {});
     }
@@ -256,18 +280,28 @@ __global__ void __launch_bounds__(kRayBlock) k_finalize_offsets(const int32_t* _
   }
 }
 
-// Replays the first cnt (<= cap) recorded samples of a ray: emit(px,py,pz,dt,delta,t) with exactly the values
-// the march produced (same clamp(o + t*d) and step_dt(t) operations).
+// Replays a ray from its candidate bit mask: emit(px,py,pz,dt,delta,t) with exactly the values the march produced
+// (same t accumulation, same clamp(o + t*d) and step_dt(t) operations).
 template <class Emit>
-__device__ __forceinline__ void replay_ray(const MarchParams& P, const Ray& r, const float2* __restrict__ row, int cnt,
-                                           Emit&& emit) {
-  for (int k = 0; k < cnt; ++k) {
-    const float2 td = row[k];
-    const float t = td.x;
-    const float px = clampf(r.ox + t * r.dx, -P.bound, P.bound);
-    const float py = clampf(r.oy + t * r.dy, -P.bound, P.bound);
-    const float pz = clampf(r.oz + t * r.dz, -P.bound, P.bound);
-    emit(px, py, pz, step_dt(P, t), td.y, t);
+__device__ __forceinline__ void replay_ray(const MarchParams& P, const Ray& r, const uint32_t* __restrict__ mask, int64_t N,
+                                           int64_t n, float t, int cnt, Emit&& emit) {
+  float last_t = t;
+  int emitted = 0;
+  for (int w = 0; emitted < cnt; ++w) {
+    const uint32_t bits = mask[(int64_t)w * N + n];
+    for (int b = 0; b < 32 && emitted < cnt; ++b) {
+      const float dt = step_dt(P, t);
+      const float tn = t + dt;
+      if ((bits >> b) & 1u) {
+        const float px = clampf(r.ox + t * r.dx, -P.bound, P.bound);
+        const float py = clampf(r.oy + t * r.dy, -P.bound, P.bound);
+        const float pz = clampf(r.oz + t * r.dz, -P.bound, P.bound);
+        emit(px, py, pz, dt, tn - last_t, t);
+        last_t = tn;
+        ++emitted;
+      }
+      t = tn;
+    }
   }
 }
 
@@ -281,7 +315,7 @@ __global__ void __launch_bounds__(kRayBlock) k_march_write(MarchParams P, const 
                                                            const int32_t* __restrict__ rays,
                                                            float* __restrict__ xyzs, float* __restrict__ dirs,
                                                            float* __restrict__ deltas,
-                                                           const float2* __restrict__ cap_buf, int cap) {
+                                                           const uint32_t* __restrict__ mask, int cap_words) {
   const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
   const int off = rays[n * 3 + 1];
@@ -295,10 +329,10 @@ __global__ void __launch_bounds__(kRayBlock) k_march_write(MarchParams P, const 
     deltas[i * 2 + 0] = dt; deltas[i * 2 + 1] = delta;
     ++i;
   };
-  if (cnt <= cap) {
-    replay_ray(P, r, cap_buf + n * cap, cnt, emit);
+  const float t0 = start_t(P, nears[n], noises ? noises[n] : 0.0f);
+  if (cap_words > 0 && mask[(int64_t)cap_words * N + n]) {
+    replay_ray(P, r, mask, N, n, t0, cnt, emit);
   } else {
-    const float t0 = start_t(P, nears[n], noises ? noises[n] : 0.0f);
     march_ray(P, r, t0, fars[n], cnt, emit);
   }
 }
@@ -835,7 +869,7 @@ __global__ void __launch_bounds__(kRayBlock) k_march_write_patch(MarchParams P, 
                                                                  const int32_t* __restrict__ rays,
                                                                  float* __restrict__ xyzs, float* __restrict__ dirs,
                                                                  float* __restrict__ deltas,
-                                                                 const float2* __restrict__ cap_buf, int cap,
+                                                                 const uint32_t* __restrict__ mask, int cap_words,
                                                                  int32_t* __restrict__ ray_ids, int normalise) {
   const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int off = n < N ? rays[n * 3 + 1] : 0;
@@ -855,10 +889,10 @@ __global__ void __launch_bounds__(kRayBlock) k_march_write_patch(MarchParams P, 
     if (ray_ids) ray_ids[i] = (int32_t)n;
     deltas[i * 2 + 0] = dt; deltas[i * 2 + 1] = delta;
   };
-  if (cnt <= cap) {
-    replay_ray(P, r, cap_buf + n * cap, cnt, emit);
+  const float t0 = start_t(P, nears[n], noises ? noises[n] : 0.0f);
+  if (cap_words > 0 && mask[(int64_t)cap_words * N + n]) {
+    replay_ray(P, r, mask, N, n, t0, cnt, emit);
   } else {
-    const float t0 = start_t(P, nears[n], noises ? noises[n] : 0.0f);
     march_ray(P, r, t0, fars[n], cnt, emit);
   }
 }
@@ -1044,8 +1078,11 @@ static int64_t ws_ints(int64_t N) {
   const int64_t nb = (N + kRayBlock - 1) / kRayBlock;
   return ((N + nb + 64 + 1) / 2) * 2;     // even: the capture rows that follow are float2
 }
+// sample_cap: number of step candidates per ray the count pass records as a bit mask (rounded up to 32; 0 = none)
+static int cap_words_of(int32_t sample_cap) { return sample_cap > 0 ? (sample_cap + 31) / 32 : 0; }
 int64_t inr_march_workspace_bytes(int64_t N, int32_t sample_cap) {
-  return ws_ints(N) * (int64_t)sizeof(int32_t) + N * (int64_t)(sample_cap > 0 ? sample_cap : 0) * (int64_t)sizeof(float2);
+  const int w = cap_words_of(sample_cap);
+  return ws_ints(N) * (int64_t)sizeof(int32_t) + (w ? N * (int64_t)(w + 1) * (int64_t)sizeof(uint32_t) : 0);
 }
 
 int inr_march_rays_train_count(const float* rays_o, const float* rays_d, const uint8_t* bitfield, float bound,
@@ -1060,7 +1097,7 @@ int inr_march_rays_train_count(const float* rays_o, const float* rays_d, const u
   INR_REQUIRE(sample_cap >= 0 && ((uintptr_t)workspace & 7) == 0, "workspace must be 8-byte aligned");
   int32_t* counts = reinterpret_cast<int32_t*>(workspace);
   int32_t* block_sums = counts + N;
-  float2* cap_buf = reinterpret_cast<float2*>(counts + ws_ints(N));
+  uint32_t* mask = reinterpret_cast<uint32_t*>(counts + ws_ints(N));
   hipStream_t st = as_stream(s);
   if (use_coop(N, sample_cap)) {
     k_march_count_coop<<<blocks_for(N, kCoopRaysPerBlock), kCoopRaysPerBlock * 64, 0, st>>>(P, rays_o, rays_d, N, max_steps,
@@ -1069,7 +1106,7 @@ int inr_march_rays_train_count(const float* rays_o, const float* rays_d, const u
     return check_launch("march_rays_train_count");
   }
   k_march_count<<<nb, kRayBlock, 0, st>>>(P, rays_o, rays_d, N, max_steps, nears, fars, noises, counts, block_sums,
-                                          cap_buf, sample_cap);
+                                          mask, cap_words_of(sample_cap));
   k_scan_block_sums<<<1, 1024, 0, st>>>(block_sums, (int)nb, N, counter);
   k_finalize_offsets<<<nb, kRayBlock, 0, st>>>(counts, block_sums, N, rays);
   return check_launch("march_rays_train_count");
@@ -1086,14 +1123,14 @@ int inr_march_rays_train_write(const float* rays_o, const float* rays_d, const u
   INR_REQUIRE(xyzs && dirs && deltas, "null output");
   const MarchParams P = make_params(bitfield, bound, dt_gamma, max_steps, cascade, H);
   INR_REQUIRE(sample_cap == 0 || workspace, "sample_cap > 0 needs the workspace of the count pass");
-  const float2* cap_buf = sample_cap > 0 ? reinterpret_cast<const float2*>(reinterpret_cast<const int32_t*>(workspace) + ws_ints(N)) : nullptr;
+  const uint32_t* mask = sample_cap > 0 ? reinterpret_cast<const uint32_t*>(reinterpret_cast<const int32_t*>(workspace) + ws_ints(N)) : nullptr;
   if (use_coop(N, sample_cap)) {
     k_march_write_coop<<<blocks_for(N, kCoopRaysPerBlock), kCoopRaysPerBlock * 64, 0, as_stream(s)>>>(
         P, rays_o, rays_d, N, M, nears, fars, noises, rays, xyzs, dirs, deltas);
     return check_launch("march_rays_train_write");
   }
   k_march_write<<<blocks_for(N, kRayBlock), kRayBlock, 0, as_stream(s)>>>(P, rays_o, rays_d, N, M, nears, fars, noises,
-                                                                          rays, xyzs, dirs, deltas, cap_buf, sample_cap);
+                                                                          rays, xyzs, dirs, deltas, mask, cap_words_of(sample_cap));
   return check_launch("march_rays_train_write");
 }
 
@@ -1108,10 +1145,10 @@ int inr_march_rays_patch_write(const float* rays_o, const float* rays_d, const u
   INR_REQUIRE(xyzs && deltas && (dirs || ray_ids), "null output");
   const MarchParams P = make_params(bitfield, bound, dt_gamma, max_steps, cascade, H);
   INR_REQUIRE(sample_cap == 0 || workspace, "sample_cap > 0 needs the workspace of the count pass");
-  const float2* cap_buf = sample_cap > 0 ? reinterpret_cast<const float2*>(reinterpret_cast<const int32_t*>(workspace) + ws_ints(N)) : nullptr;
+  const uint32_t* mask = sample_cap > 0 ? reinterpret_cast<const uint32_t*>(reinterpret_cast<const int32_t*>(workspace) + ws_ints(N)) : nullptr;
   k_march_write_patch<<<blocks_for(N, kRayBlock), kRayBlock, 0, as_stream(s)>>>(P, rays_o, rays_d, N, M, nears, fars,
-                                                                                noises, rays, xyzs, dirs, deltas, cap_buf,
-                                                                                sample_cap, ray_ids, normalise);
+                                                                                noises, rays, xyzs, dirs, deltas, mask,
+                                                                                cap_words_of(sample_cap), ray_ids, normalise);
   return check_launch("march_rays_patch_write");
 }
 

@@ -21,11 +21,12 @@ from ._lib import check, ptr, stream_ptr
 
 F32, I32, U8 = torch.float32, torch.int32, torch.uint8
 
-# Samples per ray the count pass records for the write pass to replay (0 = march twice); rays with more
-# samples are re-marched; 8 bytes of scratch per ray and slot.  Measured on MI355X: full 800x800 frames gain
-# ~1 % with 128 (4164 -> 4217 Msamples/s); the 4096-ray training batches LOSE 7 % (1.94 -> 2.08 ms/step: the
-# stores slow the latency-bound count pass and long rays march twice anyway), so training keeps 0.
-SAMPLE_CAP = int(__import__("os").environ.get("INR_SAMPLE_CAP", "128"))
+# Step candidates per ray whose hit/miss pattern the count pass records as a bit mask (0 = march twice): the
+# write pass then regenerates the candidate sequence t_{i+1} = t_i + dt(t_i) and emits at the set bits instead
+# of walking the occupancy grid again; rays needing more candidates are re-marched.  1024 covers every ray of a
+# bound-1 scene (far - near <= 2 sqrt(3), dt >= 2 sqrt(3) / 1024); 4 bytes of scratch per ray and 32 candidates.
+# Training batches of <= 32768 rays use the wave-per-ray marcher and never capture.
+SAMPLE_CAP = int(__import__("os").environ.get("INR_SAMPLE_CAP", "1024"))
 SAMPLE_CAP_TRAIN = int(__import__("os").environ.get("INR_SAMPLE_CAP_TRAIN", "0"))
 
 

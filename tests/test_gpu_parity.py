@@ -598,10 +598,11 @@ def test_rays_missing_the_volume(rm, bits_dev):
     assert ws.tolist() == [0.0, 0.0, 0.0]
 
 
-@pytest.mark.parametrize("cap", [0, 8, 64, 512])
+@pytest.mark.parametrize("cap", [0, 40, 256, 1024])
 def test_capture_replay_is_bit_identical(rm, room, room_bitfield, bits_dev, cap, monkeypatch):
-    """The write pass replaying recorded (t, delta) pairs, re-marching long rays, or marching twice all
-    produce the oracle's samples bit for bit (both writers)."""
+    """The write pass replaying the recorded candidate bit mask, re-marching rays that outrun the mask, or
+    marching twice all produce the oracle's samples bit for bit (both writers, thread-per-ray marcher)."""
+    monkeypatch.setenv("INR_MARCH_COOP", "0")
     from oracle import march, rays
     monkeypatch.setattr(rm, "SAMPLE_CAP", cap)
     monkeypatch.setattr(rm, "SAMPLE_CAP_TRAIN", cap)
