@@ -125,22 +125,29 @@ __device__ __forceinline__ float step_dt(const MarchParams& P, float t) {
 // Marches from t until t >= far or max_emit samples were emitted.  emit(px,py,pz,dt,delta,t); advance() is called
 // every time t moves on by one step, i.e. once per step CANDIDATE (the sequence t_0 = t, t_{i+1} = t_i + dt(t_i)
 // does not depend on the grid - only which candidates are visited and emitted does).
-template <class Emit, class Advance>
+// kSingle: one cascade (bound <= 1) - the mip level is 0 for every sample, so the two frexp, the level clamp and
+// the per-iteration 1/mb are loop invariants (same values, a quarter fewer instructions per iteration).
+template <bool kSingle = false, class Emit, class Advance>
 __device__ __forceinline__ int march_ray(const MarchParams& P, const Ray& r, float t, float far,
                                          int max_emit, Emit&& emit, Advance&& advance) {
   int n = 0;
   float last_t = t;
+  const float mb1 = fminf(ldexpf(1.0f, 0), P.bound), rmb1 = 1.0f / mb1;
   while (t < far && n < max_emit) {
     const float px = clampf(r.ox + t * r.dx, -P.bound, P.bound);
     const float py = clampf(r.oy + t * r.dy, -P.bound, P.bound);
     const float pz = clampf(r.oz + t * r.dz, -P.bound, P.bound);
     const float dt = step_dt(P, t);
-    int e0, e1;
-    (void)frexpf(fmaxf(fabsf(px), fmaxf(fabsf(py), fabsf(pz))), &e0);
-    (void)frexpf(dt * (float)P.H * 0.5f, &e1);
-    const int level = max(clampi(e0, 0, P.C - 1), clampi(e1, 0, P.C - 1));
-    const float mb = fminf(ldexpf(1.0f, level), P.bound);
-    const float rmb = 1.0f / mb;
+    int level = 0;
+    float mb = mb1, rmb = rmb1;
+    if constexpr (!kSingle) {
+      int e0, e1;
+      (void)frexpf(fmaxf(fabsf(px), fmaxf(fabsf(py), fabsf(pz))), &e0);
+      (void)frexpf(dt * (float)P.H * 0.5f, &e1);
+      level = max(clampi(e0, 0, P.C - 1), clampi(e1, 0, P.C - 1));
+      mb = fminf(ldexpf(1.0f, level), P.bound);
+      rmb = 1.0f / mb;
+    }
     const int nx = clampi((int)(((px * rmb + 1.0f) * 0.5f) * (float)P.H), 0, P.H - 1);
     const int ny = clampi((int)(((py * rmb + 1.0f) * 0.5f) * (float)P.H), 0, P.H - 1);
     const int nz = clampi((int)(((pz * rmb + 1.0f) * 0.5f) * (float)P.H), 0, P.H - 1);
@@ -172,7 +179,14 @@ __device__ __forceinline__ int march_ray(const MarchParams& P, const Ray& r, flo
 template <class Emit>
 __device__ __forceinline__ int march_ray(const MarchParams& P, const Ray& r, float t, float far,
                                          int max_emit, Emit&& emit) {
-  return march_ray(P, r, t, far, max_emit, emit, [] {});
+  return march_ray<false>(P, r, t, far, max_emit, emit, [] {});
+}
+// run-time dispatch on the cascade count (wave-uniform)
+template <class Emit, class Advance>
+__device__ __forceinline__ int march_ray_any(const MarchParams& P, const Ray& r, float t, float far,
+                                             int max_emit, Emit&& emit, Advance&& advance) {
+  return P.C == 1 ? march_ray<true>(P, r, t, far, max_emit, emit, advance)
+                  : march_ray<false>(P, r, t, far, max_emit, emit, advance);
 }
 
 __device__ __forceinline__ float start_t(const MarchParams& P, float near, float noise) {
@@ -201,7 +215,7 @@ __global__ void __launch_bounds__(kRayBlock) k_march_count(MarchParams P, const 
       uint32_t word = 0;
       int widx = 0, cand = 0;
       bool ok = true;
-      cnt = march_ray(P, r, t0, fars[n], max_steps,
+      cnt = march_ray_any(P, r, t0, fars[n], max_steps,
                       [&](float, float, float, float, float, float) {
                         const int w = cand >> 5;
                         if (w < cap_words) {
@@ -219,7 +233,7 @@ __global__ void __launch_bounds__(kRayBlock) k_march_count(MarchParams P, const 
       if (widx < cap_words) mask[(int64_t)widx * N + n] = word;
       mask[(int64_t)cap_words * N + n] = ok ? 1u : 0u;
     } else {
-      cnt = march_ray(P, r, t0, fars[n], max_steps, [](float, float, float, float, float, float) {});
+      cnt = march_ray_any(P, r, t0, fars[n], max_steps, [](float, float, float, float, float, float) {}, [] {});
     }
     counts[n] = cnt;
   }
@@ -345,9 +359,10 @@ __global__ void __launch_bounds__(kRayBlock) k_march_write(MarchParams P, const 
 // very expressions of march_ray) and then resolves which of them the serial walk visits: a hit goes to the next
 // candidate, a miss to the first candidate not below its exit distance.  Same samples, same bits as march_ray.
 // emit(k, px, py, pz, dt, delta, t) runs in the lanes that own a sample; k is its index along the ray.
-template <class Emit>
+template <bool kSingle = false, class Emit>
 __device__ __forceinline__ int march_ray_coop(const MarchParams& P, const Ray& r, float t, float far, int max_emit,
                                               Emit&& emit) {
+  const float mb1 = fminf(ldexpf(1.0f, 0), P.bound), rmb1 = 1.0f / mb1;      // kSingle: see march_ray
   const int lane = threadIdx.x & 63;
   const uint64_t lt_mask = (1ull << lane) - 1ull;
   int n = 0;
@@ -362,12 +377,16 @@ __device__ __forceinline__ int march_ray_coop(const MarchParams& P, const Ray& r
     const float pz = clampf(r.oz + c * r.dz, -P.bound, P.bound);
     const float dt = step_dt(P, c);
     const float tn = c + dt;
-    int e0, e1;
-    (void)frexpf(fmaxf(fabsf(px), fmaxf(fabsf(py), fabsf(pz))), &e0);
-    (void)frexpf(dt * (float)P.H * 0.5f, &e1);
-    const int level = max(clampi(e0, 0, P.C - 1), clampi(e1, 0, P.C - 1));
-    const float mb = fminf(ldexpf(1.0f, level), P.bound);
-    const float rmb = 1.0f / mb;
+    int level = 0;
+    float mb = mb1, rmb = rmb1;
+    if constexpr (!kSingle) {
+      int e0, e1;
+      (void)frexpf(fmaxf(fabsf(px), fmaxf(fabsf(py), fabsf(pz))), &e0);
+      (void)frexpf(dt * (float)P.H * 0.5f, &e1);
+      level = max(clampi(e0, 0, P.C - 1), clampi(e1, 0, P.C - 1));
+      mb = fminf(ldexpf(1.0f, level), P.bound);
+      rmb = 1.0f / mb;
+    }
     const int nx = clampi((int)(((px * rmb + 1.0f) * 0.5f) * (float)P.H), 0, P.H - 1);
     const int ny = clampi((int)(((py * rmb + 1.0f) * 0.5f) * (float)P.H), 0, P.H - 1);
     const int nz = clampi((int)(((pz * rmb + 1.0f) * 0.5f) * (float)P.H), 0, P.H - 1);
@@ -458,7 +477,9 @@ __global__ void __launch_bounds__(kCoopRaysPerBlock * 64) k_march_count_coop(Mar
   if (n >= N) return;
   const Ray r = load_ray(rays_o, rays_d, n);
   const float t0 = start_t(P, nears[n], noises ? noises[n] : 0.0f);
-  const int cnt = march_ray_coop(P, r, t0, fars[n], max_steps, [](int, float, float, float, float, float, float) {});
+  auto none = [](int, float, float, float, float, float, float) {};
+  const int cnt = P.C == 1 ? march_ray_coop<true>(P, r, t0, fars[n], max_steps, none)
+                           : march_ray_coop<false>(P, r, t0, fars[n], max_steps, none);
   if ((threadIdx.x & 63) == 0) counts[n] = cnt;
 }
 
@@ -507,12 +528,14 @@ __global__ void __launch_bounds__(kCoopRaysPerBlock * 64) k_march_write_coop(Mar
   if (cnt == 0 || (int64_t)off + cnt > M) return;
   const Ray r = load_ray(rays_o, rays_d, n);
   const float t0 = start_t(P, nears[n], noises ? noises[n] : 0.0f);
-  march_ray_coop(P, r, t0, fars[n], cnt, [&](int k, float px, float py, float pz, float dt, float delta, float) {
+  auto put = [&](int k, float px, float py, float pz, float dt, float delta, float) {
     const int64_t i = (int64_t)off + k;
     xyzs[i * 3 + 0] = px; xyzs[i * 3 + 1] = py; xyzs[i * 3 + 2] = pz;
     dirs[i * 3 + 0] = r.dx; dirs[i * 3 + 1] = r.dy; dirs[i * 3 + 2] = r.dz;
     deltas[i * 2 + 0] = dt; deltas[i * 2 + 1] = delta;
-  });
+  };
+  if (P.C == 1) march_ray_coop<true>(P, r, t0, fars[n], cnt, put);
+  else march_ray_coop<false>(P, r, t0, fars[n], cnt, put);
 }
 
 // tail of run_cuda (a14): image += (1 - weights_sum) * bg, depth = clamp(depth - near, 0) / (far - near); one launch
