@@ -50,13 +50,26 @@ def get_rays(poses, intrinsics, H, W, N=-1, error_map=None, inds=None, patch=0):
     """poses [B,4,4] (camera-to-world), intrinsics (fx,fy,cx,cy) -> dict(rays_o, rays_d [B,N,3], inds [B,N]).
 
     Pixel centres at +0.5; dir = ((i-cx)/fx, (j-cy)/fy, 1) normalised, rotated by R; N>0 draws N
-    random pixels (shared across the batch).  ``patch=4`` (full images only) enumerates the pixels
+    random pixels (shared across the batch; with ``error_map`` [B, 128*128] they are drawn per batch element
+    in proportion to the map, as upstream).  ``patch=4`` (full images only) enumerates the pixels
     4x4-patch by patch instead of row-major - same rays, an order the renderer's patch-interleaved
     layout turns into compact tiles; scatter results back with ``image.view(-1,3)[inds] = pred``.
     """
     device = poses.device
     B = poses.shape[0]
     fx, fy, cx, cy = intrinsics
+    if inds is None and N > 0 and error_map is not None:
+        # upstream's importance sampling: draw coarse cells of the [B, 128*128] error map without replacement,
+        # then a uniform pixel inside each cell; every batch element gets its own pixels
+        inds_coarse = torch.multinomial(error_map.to(device), N, replacement=False)          # [B, N]
+        cx_, cy_ = torch.div(inds_coarse, 128, rounding_mode="floor"), inds_coarse % 128
+        sx, sy = H / 128, W / 128
+        px = (cx_ * sx + torch.rand(B, N, device=device) * sx).long().clamp(max=H - 1)
+        py = (cy_ * sy + torch.rand(B, N, device=device) * sy).long().clamp(max=W - 1)
+        per_batch = px * W + py
+        parts = [get_rays(poses[b:b + 1], intrinsics, H, W, inds=per_batch[b]) for b in range(B)]
+        return {"rays_o": torch.cat([p["rays_o"] for p in parts]), "rays_d": torch.cat([p["rays_d"] for p in parts]),
+                "inds": per_batch, "inds_coarse": inds_coarse}
     if inds is None:
         if N > 0:
             inds = torch.randint(0, H * W, size=[N], device=device)
@@ -240,6 +253,47 @@ def allreduce_gradients(params, world_size, bucket_bytes=64 << 20):
         g.div_(world_size)
 
 
+class ParamEMA:
+    """Exponential moving average of the trained parameters, the subset of ``torch_ema.ExponentialMovingAverage``
+    upstream's Trainer uses (``update`` after every optimiser step, ``store``/``copy_to``/``restore`` around
+    evaluation, ``state_dict``): shadow += (1 - d) * (param - shadow), d = min(decay, (1 + n) / (10 + n))."""
+
+    def __init__(self, params, decay):
+        self.params = [p for p in params if p.requires_grad]
+        self.decay, self.num_updates = float(decay), 0
+        self.shadow = [p.detach().clone() for p in self.params]
+        self.backup = None
+
+    @torch.no_grad()
+    def update(self):
+        self.num_updates += 1
+        d = min(self.decay, (1 + self.num_updates) / (10 + self.num_updates))
+        torch._foreach_lerp_(self.shadow, [p.detach() for p in self.params], 1.0 - d)
+
+    @torch.no_grad()
+    def store(self):
+        self.backup = [p.detach().clone() for p in self.params]
+
+    @torch.no_grad()
+    def copy_to(self):
+        for p, s in zip(self.params, self.shadow):
+            p.copy_(s)                       # through torch: bumps the version counter (packed-weight caches refresh)
+
+    @torch.no_grad()
+    def restore(self):
+        for p, b in zip(self.params, self.backup):
+            p.copy_(b)
+        self.backup = None
+
+    def state_dict(self):
+        return {"decay": self.decay, "num_updates": self.num_updates, "shadow_params": self.shadow}
+
+    def load_state_dict(self, sd):
+        self.decay, self.num_updates = sd["decay"], sd["num_updates"]
+        for s, v in zip(self.shadow, sd["shadow_params"]):
+            s.copy_(v.to(s.device))
+
+
 class Trainer:
     """Minimal counterpart of upstream's ``Trainer`` for the two stages the reference runs
     (SURVEY.md section 3.1): NeRF training (MSE on rgb) and instance-field training (NeRF frozen,
@@ -253,7 +307,7 @@ class Trainer:
 
     def __init__(self, name, opt, model, criterion=None, optimizer=None, lr=1e-2, iters=30000,
                  local_rank=0, world_size=1, device=None, workspace="workspace", fused_adam=True,
-                 stage="nerf", update_extra_interval=16):
+                 stage="nerf", update_extra_interval=16, ema_decay=None):
         self.name, self.opt, self.model = name, opt, model
         self.world_size, self.local_rank = world_size, local_rank
         self.device = device or (torch.device("cuda", local_rank) if torch.cuda.is_available() else torch.device("cpu"))
@@ -273,6 +327,10 @@ class Trainer:
         else:
             self.optimizer = torch.optim.Adam(groups, lr=lr, betas=(0.9, 0.99), eps=1e-15)
         self.iters = iters
+        # upstream: ema_decay=0.95 from its main scripts; evaluation then runs on the averaged parameters.
+        # (Its GradScaler / fp16 autocast has no counterpart: this path computes in fp32.)
+        self.ema = ParamEMA([p for g in self.optimizer.param_groups for p in g["params"]], ema_decay) \
+            if ema_decay is not None else None
         self.base_lrs = [g["lr"] for g in self.optimizer.param_groups]
         self.global_step = 0
         self.epoch = 0
@@ -329,6 +387,8 @@ class Trainer:
         allreduce_gradients(params, self.world_size)
         self._lr_step()
         self.optimizer.step()
+        if self.ema is not None:
+            self.ema.update()
         return loss.detach()
 
     def train(self, train_loader, valid_loader=None, max_epochs=1):
@@ -346,9 +406,14 @@ class Trainer:
     def evaluate(self, loader):
         self.model.eval()
         meter = PSNRMeter() if self.stage == "nerf" else MIoUMeter(self.model.num_instances)
+        if self.ema is not None:
+            self.ema.store()
+            self.ema.copy_to()
         for data in loader:
             pred, _, truth, _ = self.eval_step(data)
             meter.update(pred, truth)
+        if self.ema is not None:
+            self.ema.restore()
         result = meter.measure()
         if self.world_size > 1:
             t = torch.tensor([result], dtype=torch.float64, device=self.device)
@@ -366,6 +431,8 @@ class Trainer:
         if self.model.cuda_ray:
             state["mean_count"] = self.model.mean_count
             state["mean_density"] = self.model.mean_density
+        if self.ema is not None:
+            state["ema"] = self.ema.state_dict()
         if self.local_rank == 0:
             torch.save(state, path)
         return path
@@ -380,3 +447,5 @@ class Trainer:
             return
         self.epoch, self.global_step, self.stats = state["epoch"], state["global_step"], state["stats"]
         self.optimizer.load_state_dict(state["optimizer"])
+        if self.ema is not None and "ema" in state:
+            self.ema.load_state_dict(state["ema"])

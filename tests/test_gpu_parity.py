@@ -694,7 +694,7 @@ def test_trainer_checkpoint_roundtrip(tmp_path, room, room_bitfield, level_table
         net = _network({k: v.clone() for k, v in p0.items()}, K=0)
         net.density_bitfield.copy_(_t(room_bitfield))
         tr = Trainer("ck", None, net, stage="nerf", device=torch.device(DEV), iters=50, update_extra_interval=10 ** 9,
-                     workspace=str(tmp_path))
+                     workspace=str(tmp_path), ema_decay=0.95)
         tr.global_step = 1
         orig = net.render
         net.render = lambda *a, **kw: orig(*a, **{**kw, "perturb": False, "force_all_rays": True})
@@ -718,6 +718,20 @@ def test_trainer_checkpoint_roundtrip(tmp_path, room, room_bitfield, level_table
     lb = float(b.train_one_step(batch(3)))
     assert abs(la - lb) < 1e-6 * max(1.0, abs(la))
     assert torch.allclose(a.model.encoder.embeddings, b.model.encoder.embeddings, atol=1e-7)
+    # parameter EMA (upstream ema_decay=0.95): follows torch_ema's recurrence, travels with the checkpoint, and
+    # evaluation runs on the averaged parameters and puts the live ones back
+    assert "ema" in state and a.ema.num_updates == 4 == b.ema.num_updates
+    for sa, sb in zip(a.ema.shadow, b.ema.shadow):
+        assert torch.allclose(sa, sb, atol=1e-7)
+    w = a.model.sigma_net[0].weight
+    live = w.detach().clone()
+    shadow = a.ema.shadow[[id(q) for q in a.ema.params].index(id(w))]
+    assert not torch.equal(live, shadow)
+    seen = {}
+    orig_eval = a.eval_step
+    a.eval_step = lambda data: (seen.setdefault("w", w.detach().clone()), orig_eval(data))[1]
+    a.evaluate([batch(5)])
+    assert torch.equal(seen["w"], shadow) and torch.equal(w.detach(), live)
 
 
 @pytest.mark.parametrize("density_scale", [1.0, 300.0])

@@ -152,3 +152,22 @@ def test_instance_training_reduces_loss(room, room_bitfield, level_table):
         opt.step()
         losses.append(loss.item())
     assert losses[-1] < losses[0]
+
+
+def test_get_rays_error_map_sampling():
+    """error_map importance sampling (upstream get_rays): pixels come from the coarse cells with non-zero error."""
+    import torch
+    from instance_nerf_amd.nerf.utils import get_rays
+    poses = torch.eye(4)[None].repeat(2, 1, 1)
+    err = torch.zeros(2, 128 * 128)
+    err[0, 5 * 128 + 7] = 1.0                     # one hot cell per image...
+    err[0, 9 * 128 + 1] = 1.0
+    err[1, 100 * 128 + 50:100 * 128 + 60] = 1.0   # ...and a run of ten cells
+    H = W = 256
+    out = get_rays(poses, (200.0, 200.0, 128.0, 128.0), H, W, N=2, error_map=err)
+    assert out["rays_d"].shape == (2, 2, 3) and out["inds"].shape == (2, 2) and out["inds_coarse"].shape == (2, 2)
+    rows, cols = out["inds"] // W, out["inds"] % W
+    assert set((rows[0] // 2).tolist()) == {5, 9} and set((cols[0] // 2).tolist()) <= {7, 1}
+    assert (rows[1] // 2 == 100).all() and ((cols[1] // 2 >= 50) & (cols[1] // 2 < 60)).all()
+    ref = get_rays(poses[:1], (200.0, 200.0, 128.0, 128.0), H, W, inds=out["inds"][0])
+    assert torch.equal(ref["rays_d"][0], out["rays_d"][0])
