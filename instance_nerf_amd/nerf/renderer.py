@@ -108,9 +108,7 @@ class NeRFRenderer(nn.Module):
         results = {}
         with_instance = getattr(self, "num_instances", 0) > 0
         if not self.training and infer_mode == "auto":
-            last = getattr(self, "_last_opacity", None)
-            # the previous call has completed (every call reads its sample count back), so .item() does not stall
-            infer_mode = "fused_terminate" if (last is not None and float(last.item()) > 0.5) else "fused"
+            infer_mode = "fused_terminate" if self._recent_opacity() > 0.5 else "fused"
 
         fused_inst = with_instance and getattr(self, "_fusable_inst", False) and hasattr(self, "instance_render")
         if (not self.training and infer_mode == "fused_terminate" and getattr(self, "_fusable", False)
@@ -204,7 +202,7 @@ class NeRFRenderer(nn.Module):
             raise ValueError(f"unknown infer_mode {infer_mode!r}")
 
         if not self.training:
-            self._last_opacity = weights_sum.mean()
+            self._note_opacity(weights_sum)
         bg3 = self._bg_triplet(bg_color)
         if bg3 is not None and not (torch.is_grad_enabled() and (image.requires_grad or weights_sum.requires_grad)):
             # no gradient flows through the shaded image (inference, or the instance stage on a frozen NeRF):
@@ -225,6 +223,34 @@ class NeRFRenderer(nn.Module):
         results["depth"] = depth.view(*prefix)
         results["weights_sum"] = weights_sum.view(*prefix)
         return results
+
+    # Mean opacity of recent eval calls, for infer_mode="auto".  The value travels to the host through a pinned
+    # buffer + event and is only read once its copy has completed: no call ever waits for a previous frame.
+    def _note_opacity(self, weights_sum):
+        if not weights_sum.is_cuda:
+            self._opacity_value = float(weights_sum.mean())
+            return
+        d = self.__dict__
+        if "_opacity_free" not in d:               # four pinned scalars, allocated once
+            d["_opacity_free"] = [torch.empty((), dtype=torch.float32, pin_memory=True) for _ in range(4)]
+            d["_opacity_pending"] = []
+        self._recent_opacity()                     # recycles the slots whose copies have landed
+        if not d["_opacity_free"]:
+            return                                 # four samples still in flight: skip this one
+        host = d["_opacity_free"].pop()
+        host.copy_(weights_sum.mean(), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        d["_opacity_pending"].append((ev, host))
+
+    def _recent_opacity(self):
+        d = self.__dict__
+        pending = d.get("_opacity_pending", [])
+        while pending and pending[0][0].query():
+            _, host = pending.pop(0)
+            d["_opacity_value"] = float(host)
+            d["_opacity_free"].append(host)
+        return d.get("_opacity_value", 0.0)
 
     @staticmethod
     def _bg_triplet(bg_color):

@@ -758,6 +758,32 @@ def test_fused_terminate_equals_two_kernel_path(params_k16, room, room_bitfield,
         assert ev > 0.9 * total
 
 
+def test_auto_mode_follows_recent_opacity(params_k16, room, room_bitfield):
+    """infer_mode="auto": the mean opacity of earlier calls (read through a pinned buffer once its copy has landed -
+    no call waits for a previous frame) selects the early-terminating kernel for opaque scenes only."""
+    from instance_nerf_amd.nerf.utils import get_rays
+    poses, intr, H, W = room.cameras(n=2, H=64, W=64, focal=32.0)
+    r = get_rays(_t(poses[1:2]), intr, 64, 64, patch=4)
+    for density_scale, opaque in ((300.0, True), (1e-3, False)):
+        net = _network(params_k16, K=16).eval()
+        net.density_bitfield.copy_(_t(room_bitfield))
+        net.density_scale = density_scale
+        with torch.no_grad():
+            first = net.render(r["rays_o"], r["rays_d"], bg_color=1)            # nothing known yet: two-kernel path
+            assert "num_evaluated" not in first
+            torch.cuda.synchronize()
+            assert (net._recent_opacity() > 0.5) == opaque
+            second = net.render(r["rays_o"], r["rays_d"], bg_color=1)
+        assert ("num_evaluated" in second) == opaque
+        assert (first["image"] - second["image"]).abs().max() < 1e-4
+        for _ in range(8):                                                         # slots are recycled, never exhausted
+            with torch.no_grad():
+                net.render(r["rays_o"], r["rays_d"], bg_color=1)
+        torch.cuda.synchronize()
+        net._recent_opacity()
+        assert len(net._opacity_free) == 4 and not net._opacity_pending
+
+
 def test_composite_train_with_dropped_rays(rm, room, room_bitfield, bits_dev):
     """Sample buffers sized from mean_count: rays that overflow M are dropped by the writer and must composite to
     zero (and get zero gradients) - never be read past the end of the buffers (regression: GPU memory fault)."""
