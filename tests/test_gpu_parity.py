@@ -561,7 +561,7 @@ def test_bound2_two_cascades_bit_exact(rm):
     assert (got - want).abs().max() < 1e-5
 
 
-def test_full_frame_properties(params_k16, room, room_bitfield):
+def test_full_frame_properties(params_k16, room, room_bitfield, level_table):
     """800x800 (640 000 rays): the patch-interleaved path and the ray-major path render the same image;
     offsets are the exclusive scan of the counts; every ray's opacity is in [0, 1]."""
     from instance_nerf_amd.nerf.utils import get_rays
@@ -585,6 +585,15 @@ def test_full_frame_properties(params_k16, room, room_bitfield):
     cnt = rays[:, 2].long()
     assert torch.equal(rays[:, 1].long(), torch.cumsum(cnt, 0) - cnt)
     assert torch.equal(rays[:, 0].long(), torch.arange(H * W, device=DEV))
+    # a random subset of the full frame against the oracle run on exactly those rays (pixels of the full-size job
+    # are independent, so this ties the 640 000-ray launch to the oracle at a size it finishes in seconds)
+    from oracle import render
+    pick = torch.from_numpy(np.random.default_rng(17).choice(H * W, size=1200, replace=False)).to(DEV)
+    ro, rd = r["rays_o"][0][pick].cpu().numpy(), r["rays_d"][0][pick].cpu().numpy()
+    with torch.no_grad():
+        ref = render.render_train(ro, rd, params_k16, level_table, room_bitfield, min_near=0.05)
+    assert np.abs(a["image"][0][pick].cpu().numpy() - ref["image"].numpy()).max() < 1e-4
+    assert (cnt[pick].cpu().numpy() == ref["rays"][:, 2]).all()
 
 
 def test_rays_missing_the_volume(rm, bits_dev):
