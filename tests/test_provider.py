@@ -1,0 +1,73 @@
+"""NeRFDataset: the on-disk format of the reference's NeRF-stage data (transforms*.json + images [+ matched masks])."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+
+def _write_scene(root, n=4, H=12, W=16, with_alpha=True):
+    from PIL import Image
+    os.makedirs(os.path.join(root, "images"), exist_ok=True)
+    os.makedirs(os.path.join(root, "masks"), exist_ok=True)
+    rng = np.random.default_rng(0)
+    frames, imgs, masks = [], [], []
+    for i in range(n):
+        a = rng.integers(0, 256, size=(H, W, 4 if with_alpha else 3), dtype=np.uint8)
+        Image.fromarray(a).save(os.path.join(root, "images", f"{i:04d}.png"))
+        m = rng.integers(-1, 7, size=(H, W)).astype(np.int32)
+        np.save(os.path.join(root, "masks", f"{i:04d}.npy"), m)
+        T = np.eye(4)
+        T[:3, :3] = np.linalg.qr(rng.normal(size=(3, 3)))[0]
+        T[:3, 3] = rng.normal(size=3)
+        frames.append({"file_path": f"images/{i:04d}", "transform_matrix": T.tolist()})
+        imgs.append(a); masks.append(m)
+    meta = {"camera_angle_x": 0.6911, "frames": frames[::-1]}          # unsorted on purpose
+    with open(os.path.join(root, "transforms_train.json"), "w") as f:
+        json.dump(meta, f)
+    return imgs, masks, frames
+
+
+def test_nerf_dataset_reads_transforms_images_and_masks(tmp_path):
+    from instance_nerf_amd.nerf.provider import NeRFDataset, nerf_matrix_to_ngp
+    from instance_nerf_amd.nerf.utils import get_rays
+    imgs, masks, frames = _write_scene(str(tmp_path))
+    ds = NeRFDataset(str(tmp_path), type="train", num_rays=50, mask_dir=str(tmp_path / "masks"), num_instances=5)
+    assert len(ds) == 4 and ds.names == ["0000", "0001", "0002", "0003"] and (ds.H, ds.W) == (12, 16)
+    fx, fy, cx, cy = ds.intrinsics
+    assert abs(fx - 16 / (2 * np.tan(0.6911 / 2))) < 1e-4 and fx == fy and (cx, cy) == (8.0, 6.0)
+    # pose convention: axes (y, z, x), camera y/z flipped, translation * 0.33
+    T = np.asarray(frames[2]["transform_matrix"], np.float32)
+    P = nerf_matrix_to_ngp(T)
+    assert np.allclose(ds.poses[2].numpy(), P)
+    assert np.allclose(P[:3, 3], T[[1, 2, 0], 3] * 0.33) and np.allclose(P[:3, 0], T[[1, 2, 0], 0])
+    assert np.allclose(P[:3, 1], -T[[1, 2, 0], 1]) and abs(np.linalg.det(P[:3, :3]) - 1) < 1e-5
+    b = ds[1]
+    assert b["rays_o"].shape == (1, 50, 3) and b["images"].shape == (1, 50, 3) and b["masks"].shape == (1, 50)
+    # alpha composited on white, labels gathered at the same pixels, ids without a logit become ignore
+    a = imgs[1].astype(np.float32) / 255
+    want = (a[..., :3] * a[..., 3:] + 1 - a[..., 3:]).reshape(-1, 3)
+    torch.manual_seed(3)
+    b = ds[1]
+    torch.manual_seed(3)
+    inds = get_rays(ds.poses[1:2], ds.intrinsics, 12, 16, 50)["inds"][0]
+    assert np.allclose(b["images"][0].numpy(), want[inds.numpy()], atol=1e-6)
+    lab = masks[1].reshape(-1)[inds.numpy()]
+    assert (b["masks"][0].numpy() == np.where(lab >= 5, -1, lab)).all()
+    # evaluation split: whole images, row-major
+    ev = NeRFDataset(str(tmp_path), type="train", num_rays=50)
+    ev.training, ev.num_rays = False, -1
+    full = ev[0]
+    assert full["rays_d"].shape == (1, 12 * 16, 3) and full["images"].shape == (1, 12, 16, 3)
+    assert len(list(iter(ds))) == 4
+
+
+def test_nerf_dataset_errors(tmp_path):
+    from instance_nerf_amd.nerf.provider import NeRFDataset
+    with pytest.raises(FileNotFoundError):
+        NeRFDataset(str(tmp_path), type="train")
+    _write_scene(str(tmp_path), n=2)
+    os.remove(tmp_path / "masks" / "0001.npy")
+    with pytest.raises(FileNotFoundError):
+        NeRFDataset(str(tmp_path), type="train", mask_dir=str(tmp_path / "masks"))
