@@ -1048,3 +1048,43 @@ def test_nerf_field_fused_training_autograd(level_table):
     for a, b in zip(res[True][2], res[False][2]):
         assert a.shape == b.shape
         assert torch.linalg.norm(a - b) < 2e-2 * torch.linalg.norm(b)
+
+
+def test_trainer_runs_on_a_transforms_json_scene(tmp_path, room):
+    """Data on disk in the reference's NeRF-stage format -> NeRFDataset -> both Trainer stages (a few steps each):
+    the loader, the HIP ray generator and the fused training kernels fit together; losses are finite and fall."""
+    import json
+    from PIL import Image
+    from instance_nerf_amd.nerf import NeRFNetwork
+    from instance_nerf_amd.nerf.provider import NeRFDataset
+    from instance_nerf_amd.nerf.utils import Trainer
+    from oracle import rays as orays
+    H = W = 48
+    poses, intr, _, _ = room.cameras(n=4, H=H, W=W, focal=W / 2.0)
+    os.makedirs(tmp_path / "images"), os.makedirs(tmp_path / "masks")
+    frames = []
+    for i, P in enumerate(poses):
+        r = orays.get_rays(P[None], intr, H, W)
+        rgb, ids, _ = room.trace(r["rays_o"][0], r["rays_d"][0])
+        Image.fromarray((rgb.reshape(H, W, 3) * 255).astype(np.uint8)).save(tmp_path / "images" / f"v{i}.png")
+        np.save(tmp_path / "masks" / f"v{i}.npy", (ids % 8).reshape(H, W).astype(np.int32))
+        # invert nerf_matrix_to_ngp (scale 1, no offset): the file stores the Blender-convention matrix
+        T = np.eye(4, dtype=np.float32)
+        T[[1, 2, 0], 0], T[[1, 2, 0], 1], T[[1, 2, 0], 2], T[[1, 2, 0], 3] = P[:3, 0], -P[:3, 1], -P[:3, 2], P[:3, 3]
+        frames.append({"file_path": f"images/v{i}.png", "transform_matrix": T.tolist()})
+    with open(tmp_path / "transforms_train.json", "w") as f:
+        json.dump({"fl_x": W / 2.0, "fl_y": W / 2.0, "cx": W / 2.0, "cy": H / 2.0, "w": W, "h": H, "frames": frames}, f)
+    ds = NeRFDataset(str(tmp_path), type="train", device=DEV, scale=1.0, num_rays=1024, mask_dir=str(tmp_path / "masks"),
+                     num_instances=16)
+    assert torch.allclose(ds.poses.cpu(), torch.from_numpy(poses), atol=1e-6)
+    torch.manual_seed(0)
+    net = NeRFNetwork(cuda_ray=True, bound=1, min_near=0.05, num_instances=16).to(DEV)
+    net.density_bitfield.copy_(_t(room.density_bitfield(128, 1.0)))
+    tr = Trainer("json", None, net, stage="nerf", device=torch.device(DEV), iters=200, update_extra_interval=10 ** 9)
+    tr.global_step = 1
+    losses = [float(tr.train_one_step(ds[i % len(ds)])) for i in range(30)]
+    assert np.isfinite(losses).all() and np.mean(losses[-5:]) < 0.7 * np.mean(losses[:5])
+    ti = Trainer("json", None, net, stage="instance", device=torch.device(DEV), iters=200, update_extra_interval=10 ** 9)
+    ti.global_step = 1
+    ce = [float(ti.train_one_step(ds[i % len(ds)])) for i in range(30)]
+    assert np.isfinite(ce).all() and np.mean(ce[-5:]) < np.mean(ce[:5])
