@@ -253,6 +253,53 @@ def allreduce_gradients(params, world_size, bucket_bytes=64 << 20):
         g.div_(world_size)
 
 
+def shard_range(n_rays, rank, world_size, align=16):
+    """Contiguous ray range [lo, hi) of this rank; boundaries are multiples of ``align`` (the 16-ray groups of the
+    patch-interleaved sample layout must not straddle two GPUs)."""
+    groups = (n_rays + align - 1) // align
+    lo = min(n_rays, (groups * rank // world_size) * align)
+    hi = min(n_rays, (groups * (rank + 1) // world_size) * align)
+    return lo, hi
+
+
+@torch.no_grad()
+def render_sharded(model, rays_o, rays_d, rank=0, world_size=1, keys=("image", "depth", "weights_sum", "instance"),
+                   **kwargs):
+    """One frame split over the GPUs of a node (render row): rays are independent, parameters and the
+    occupancy bitfield are replicated, every rank renders a contiguous range and the results are all-gathered
+    (RCCL; 16 + 4K bytes per ray, nothing on the critical path of the kernels).  rays_o, rays_d [B,N,3] -> dict of
+    full [B,N,...] tensors on every rank."""
+    B, N = rays_o.shape[:2]
+    bounds = [shard_range(N, r, world_size) for r in range(world_size)]
+    if any(b <= a for a, b in bounds):
+        raise ValueError(f"{N} rays cannot be split over {world_size} ranks in whole 16-ray groups")
+    lo, hi = bounds[rank]
+    out = model.render(rays_o[:, lo:hi].contiguous(), rays_d[:, lo:hi].contiguous(), **kwargs)
+    if world_size == 1:
+        return out
+    result = {}
+    for k in keys:
+        if k not in out:
+            continue
+        tail = out[k].shape[2:]
+        parts = [torch.empty(B, b - a, *tail, dtype=out[k].dtype, device=rays_o.device) for a, b in bounds]
+        mine = out[k].contiguous()
+        if len({b - a for a, b in bounds}) == 1:
+            dist.all_gather(parts, mine)
+        else:
+            _all_gather_uneven(parts, mine, rank)
+        result[k] = torch.cat(parts, 1)
+    return result
+
+
+def _all_gather_uneven(parts, mine, rank):
+    """all_gather for shards of different length: one broadcast per rank (world_size <= 8 on a node)."""
+    for r, buf in enumerate(parts):
+        if r == rank:
+            buf.copy_(mine)
+        dist.broadcast(buf, src=r)
+
+
 class ParamEMA:
     """Exponential moving average of the trained parameters, the subset of ``torch_ema.ExponentialMovingAverage``
     upstream's Trainer uses (``update`` after every optimiser step, ``store``/``copy_to``/``restore`` around

@@ -57,3 +57,48 @@ def test_views_are_sharded_without_overlap():
     for i in range(6):
         views = [(i * world + r) % n for r in range(world)]
         assert len(set(views)) == world
+
+
+def test_shard_range_covers_rays_in_whole_groups():
+    from instance_nerf_amd.nerf.utils import shard_range
+    for n in (640000, 4096, 1000, 17, 5):
+        for world in (1, 2, 3, 8):
+            b = [shard_range(n, r, world) for r in range(world)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+            assert all(lo % 16 == 0 for lo, _ in b)
+
+
+class _FakeModel:
+    """render() stand-in with per-ray results that depend on the ray only (the sharding logic is host-side)."""
+    def render(self, rays_o, rays_d, **kw):
+        s = rays_o.sum(-1) + 2 * rays_d.sum(-1)
+        return {"image": torch.stack([s, 2 * s, 3 * s], -1), "depth": s + 1, "weights_sum": s * 0 + 0.5,
+                "num_samples": torch.zeros(2)}
+
+
+def _render_worker(rank, world, port, q, n):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from instance_nerf_amd.nerf.utils import render_sharded
+    g = torch.Generator().manual_seed(1)
+    ro, rd = torch.randn(1, n, 3, generator=g), torch.randn(1, n, 3, generator=g)
+    full = _FakeModel().render(ro, rd)
+    got = render_sharded(_FakeModel(), ro, rd, rank, world)
+    ok = all(torch.equal(got[k], full[k]) for k in ("image", "depth", "weights_sum")) and "num_samples" not in got
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [64, 1000])          # even shards (all_gather) and uneven ones (broadcasts)
+def test_render_sharded_world2(n):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_render_worker, args=(r, 2, port, q, n)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(60)
+    assert all(ok for _, ok in res)
