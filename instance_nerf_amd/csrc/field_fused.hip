@@ -35,9 +35,6 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #ifndef INR_MLP_FP32
 #define INR_MLP_FP32 0
 #endif
-#ifndef INR_MLP_SETPRIO
-#define INR_MLP_SETPRIO 0
-#endif
 
 // Ablation builds for profiling only (tools/build_probe.py): 1 = no table gathers (features are
 // synthesised from x), 2 = no MLP (features are summed into sigma).  The shipped library is
@@ -206,101 +203,10 @@ __device__ __forceinline__ void blend(const Gathered& g, f32x4& lo, f32x4& hi) {
   hi[0] = f[4]; hi[1] = f[5]; hi[2] = f[6]; hi[3] = f[7];
 }
 
-// ---- x-split gather (alternative, OFF by default) -----------------------------------------------------
-// The gather phase is bound by L1/TA line look-ups, and the two x-neighbour corners of a cell share a
-// 128-byte line 15 times out of 16 (x is the fastest-varying index in dense AND hashed levels), yet as
-// corner k and k+1 of one lane they are fetched by two different instructions = two look-ups.
-// Here a sample's gathers are split over 8 lanes = (level group q) x (x side xb); a 16-sample tile is
-// gathered in two rounds of 8 samples.  In lane order  lane = 16q + 8xb + j8  the two x-side lanes of a
-// sample sit 8 apart, issue the same instruction and hit the same line -> one look-up.  Each lane blends
-// its 4 (y,z) corners with its own x weight; the halves are added with one DPP row_ror:8 per value; the
-// lane with xb == r keeps round r, which is sample j = 8 xb + j8 = lane & 15: exactly the MFMA B layout.
-// MEASURED: this halves the L1 line look-ups but not the time at 16 waves/CU (7.156 vs 7.168 ms), and at the
-// final 8 waves/CU - where the VALU is the busiest unit (70 %) - its second cell-locate per level pair and the
-// fraction recompute cost 11 % (6.91 vs 6.21 ms per 37 M samples).  Kept for A/B runs only.
-#ifndef INR_XSPLIT
-#define INR_XSPLIT 0
-#endif
-#ifndef INR_RECS_IN_REGS
-#define INR_RECS_IN_REGS 0
-#endif
-
-
-struct GatheredXS {
-  u32x2 v[2][4][4];               // [round][slot][(y,z) corner]; fractions are recomputed at blend time
-};                                // (24 VGPRs less across the gather wait than keeping them)
-
-__device__ __forceinline__ float ror8_add(float v) {
-  const int o = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128 /*row_ror:8*/, 0xF, 0xF, false);
-  return v + __int_as_float(o);
-}
-
-__device__ __forceinline__ void issue_gathers_xs(const LevelRec* __restrict__ my_recs, const bool (&all_hashed)[4],
-                                                 __amdgpu_buffer_rsrc_t rsrc, uint32_t xb, const float (&xr)[2][3],
-                                                 GatheredXS& g) {
-#pragma unroll
-  for (int r = 0; r < 2; ++r) {
-#pragma unroll
-    for (int li = 0; li < 4; ++li) {
-      const uint4 ra = my_recs[li].a;
-      const float s = __uint_as_float(ra.x);
-      const uint32_t base = ra.y, pa = ra.z, pb = ra.w;
-      const uint32_t mask = my_recs[li].b.x;
-      const float px = xr[r][0] * s + 0.5f, py = xr[r][1] * s + 0.5f, pz = xr[r][2] * s + 0.5f;   // mul, add
-      const float flx = floorf(px), fly = floorf(py), flz = floorf(pz);
-      const uint32_t cx = (uint32_t)flx + xb, cy = (uint32_t)fly, cz = (uint32_t)flz;
-      const uint32_t hy0 = cy * pa, hy1 = hy0 + pa;
-      const uint32_t hz0 = cz * pb, hz1 = hz0 + pb;
-      if (all_hashed[li]) {
-        const uint32_t yz[4] = {hy0 ^ hz0, hy1 ^ hz0, hy0 ^ hz1, hy1 ^ hz1};
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-          g.v[r][li][c] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(base + ((cx ^ yz[c]) & mask) * 8u), 0, 0);
-      } else {
-        const bool h = my_recs[li].b.y != 0;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const uint32_t hy = (c & 1) ? hy1 : hy0, hz = (c & 2) ? hz1 : hz0;
-          const uint32_t idx = (h ? (cx ^ hy ^ hz) : (cx + hy + hz)) & mask;
-          g.v[r][li][c] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(base + idx * 8u), 0, 0);
-        }
-      }
-    }
-  }
-}
-
-// weight = (wx*wy)*wz as in the oracle; the two x halves are summed after the 4-corner partial blends.
-__device__ __forceinline__ void blend_xs(const LevelRec* __restrict__ my_recs, const GatheredXS& g, uint32_t xb,
-                                         const float (&xr)[2][3], f32x4& lo, f32x4& hi) {
-  float f[2][8];
-#pragma unroll
-  for (int r = 0; r < 2; ++r) {
-#pragma unroll
-    for (int li = 0; li < 4; ++li) {
-      const float s = __uint_as_float(my_recs[li].a.x);
-      const float px = xr[r][0] * s + 0.5f, py = xr[r][1] * s + 0.5f, pz = xr[r][2] * s + 0.5f;   // same ops as at issue
-      const float fx = px - floorf(px), fy = py - floorf(py), fz = pz - floorf(pz);
-      const float wxs = xb ? fx : 1.0f - fx;
-      float ax = 0.f, ay = 0.f;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const float wy = (c & 1) ? fy : 1.0f - fy;
-        const float wz = (c & 2) ? fz : 1.0f - fz;
-        const float w = (wxs * wy) * wz;
-        const unsigned bx = g.v[r][li][c][0], by = g.v[r][li][c][1];
-        ax = fmaf(w, __uint_as_float(bx), ax);
-        ay = fmaf(w, __uint_as_float(by), ay);
-      }
-      f[r][2 * li] = ror8_add(ax);
-      f[r][2 * li + 1] = ror8_add(ay);
-    }
-  }
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    lo[e] = xb ? f[1][e] : f[0][e];
-    hi[e] = xb ? f[1][4 + e] : f[0][4 + e];
-  }
-}
+// (An x-split gather - 8 lanes per sample so that the two x-neighbour corners of a cell are fetched by one
+// instruction and share one L1 look-up - was built and measured: it halves the look-ups but not the time at 16
+// waves/CU, and costs 11 % in the final 8 waves/CU regime where the VALU is the busiest unit.  Removed; see
+// DESIGN.md section 3 and the git history.)
 
 // One MLP layer: out[mt] (N_MT output tiles) = W * in, K = 16 * N_G inputs.  in[g] is the B
 // operand of k-steps 4g..4g+3.  The N_MT accumulator chains are interleaved (independent
@@ -552,11 +458,6 @@ __global__ void __launch_bounds__(kFieldThreads, INR_FIELD_MIN_WAVES) k_nerf_fwd
   const TileSched sched = make_sched(n_tiles, kWaves);
 
   const bool all_hashed[4] = {slot_all_hashed(G, 0), slot_all_hashed(G, 1), slot_all_hashed(G, 2), slot_all_hashed(G, 3)};
-#if INR_RECS_IN_REGS
-  LevelRec my_recs_reg[4];
-#pragma unroll
-  for (int li = 0; li < 4; ++li) my_recs_reg[li] = recs[q * 4 + li];
-#endif
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)emb, 0, (int)emb_bytes, 0x00020000);
 
   for (int64_t it = 0, tile = sched.tile(0); tile < sched.hi; tile = sched.tile(++it)) {
@@ -565,7 +466,6 @@ __global__ void __launch_bounds__(kFieldThreads, INR_FIELD_MIN_WAVES) k_nerf_fwd
     TileIn me;
     f32x4 sh_in = {0.f, 0.f, 0.f, 0.f};
     if constexpr (kTable) {
-      static_assert(!(kTable && INR_XSPLIT), "the x-split gather normalises x itself");
       const int64_t mm = valid ? m : n - 1;
       me.x0 = x[mm * 3 + 0]; me.x1 = x[mm * 3 + 1]; me.x2 = x[mm * 3 + 2];
       const float4 t4 = shq[(int64_t)ray_ids[mm] * 4 + q];
@@ -575,43 +475,15 @@ __global__ void __launch_bounds__(kFieldThreads, INR_FIELD_MIN_WAVES) k_nerf_fwd
     }
 
     f32x4 enc[2];
-#if INR_XSPLIT && INR_PROBE_MODE != 1
-    {
-      const uint32_t xb = (uint32_t)(lane >> 3) & 1u;
-      float xr[2][3];
-#pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        const int64_t mr = min(tile * 16 + r * 8 + (lane & 7), n - 1);
-        xr[r][0] = to_x01(x[mr * 3 + 0], bound, rb, rb_inv);
-        xr[r][1] = to_x01(x[mr * 3 + 1], bound, rb, rb_inv);
-        xr[r][2] = to_x01(x[mr * 3 + 2], bound, rb, rb_inv);
-      }
-      GatheredXS g;
-      uint32_t rec_off = (uint32_t)q * 4u * (uint32_t)sizeof(LevelRec);
-      asm volatile("" : "+v"(rec_off));    // opaque per tile: keeps the records in LDS, not hoisted into VGPRs
-      issue_gathers_xs(reinterpret_cast<const LevelRec*>(reinterpret_cast<const char*>(recs) + rec_off), all_hashed,
-                       rsrc, xb, xr, g);
-      __builtin_amdgcn_sched_barrier(0);   // all 32 gathers in flight before the first blend waits
-      blend_xs(reinterpret_cast<const LevelRec*>(reinterpret_cast<const char*>(recs) + rec_off), g, xb, xr, enc[0], enc[1]);
-    }
-#elif INR_PROBE_MODE == 1
-    enc[0] = f32x4{me.x0, me.x1, me.x2, me.x0 * me.x1};
-    enc[1] = f32x4{me.x1 * me.x2, me.x2 * me.x0, me.x0 + me.x1, me.x2 - me.x1};
-#else
     {
       Gathered g;
-#if INR_RECS_IN_REGS
-      issue_gathers(my_recs_reg, all_hashed, rsrc, me.x0, me.x1, me.x2, g);
-#else
       uint32_t rec_off = (uint32_t)q * 4u * (uint32_t)sizeof(LevelRec);
       asm volatile("" : "+v"(rec_off));    // opaque per tile: keeps the records in LDS, not hoisted into VGPRs
       issue_gathers(reinterpret_cast<const LevelRec*>(reinterpret_cast<const char*>(recs) + rec_off), all_hashed, rsrc,
                     me.x0, me.x1, me.x2, g);
-#endif
       __builtin_amdgcn_sched_barrier(0);   // all 32 gathers in flight before the first blend waits
       blend(g, enc[0], enc[1]);
     }
-#endif
 #if INR_PROBE_MODE == 2
     {
       float acc = 0.f;
@@ -622,9 +494,6 @@ __global__ void __launch_bounds__(kFieldThreads, INR_FIELD_MIN_WAVES) k_nerf_fwd
     }
 #endif
 
-#if INR_MLP_SETPRIO
-    __builtin_amdgcn_s_setprio(1);     // matrix phase: get through it and back to issuing gathers
-#endif
     f32x4 h1[4];
     mlp_layer<4, 2>(wl + kSig0 / 4, lane, enc, h1);
 #pragma unroll
@@ -698,9 +567,6 @@ __global__ void __launch_bounds__(kFieldThreads, INR_FIELD_MIN_WAVES) k_nerf_fwd
 #endif
       }
     }
-#if INR_MLP_SETPRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
   }
 }
 
@@ -731,11 +597,6 @@ __global__ void __launch_bounds__(kFieldThreads, INR_FIELD_MIN_WAVES) k_instance
   const TileSched sched = make_sched(n_tiles, kWaves);
 
   const bool all_hashed[4] = {slot_all_hashed(G, 0), slot_all_hashed(G, 1), slot_all_hashed(G, 2), slot_all_hashed(G, 3)};
-#if INR_RECS_IN_REGS
-  LevelRec my_recs_reg[4];
-#pragma unroll
-  for (int li = 0; li < 4; ++li) my_recs_reg[li] = recs[q * 4 + li];
-#endif
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)emb, 0, (int)emb_bytes, 0x00020000);
 
   for (int64_t it = 0, tile = sched.tile(0); tile < sched.hi; tile = sched.tile(++it)) {
@@ -744,40 +605,15 @@ __global__ void __launch_bounds__(kFieldThreads, INR_FIELD_MIN_WAVES) k_instance
     TileIn me;
     load_tile_in<false>(x, nullptr, valid ? m : n - 1, bound, rb, rb_inv, me);
     f32x4 enc[2];
-#if INR_XSPLIT
-    {
-      const uint32_t xb = (uint32_t)(lane >> 3) & 1u;
-      float xr[2][3];
-#pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        const int64_t mr = min(tile * 16 + r * 8 + (lane & 7), n - 1);
-        xr[r][0] = to_x01(x[mr * 3 + 0], bound, rb, rb_inv);
-        xr[r][1] = to_x01(x[mr * 3 + 1], bound, rb, rb_inv);
-        xr[r][2] = to_x01(x[mr * 3 + 2], bound, rb, rb_inv);
-      }
-      GatheredXS g;
-      uint32_t rec_off = (uint32_t)q * 4u * (uint32_t)sizeof(LevelRec);
-      asm volatile("" : "+v"(rec_off));
-      issue_gathers_xs(reinterpret_cast<const LevelRec*>(reinterpret_cast<const char*>(recs) + rec_off), all_hashed,
-                       rsrc, xb, xr, g);
-      __builtin_amdgcn_sched_barrier(0);
-      blend_xs(reinterpret_cast<const LevelRec*>(reinterpret_cast<const char*>(recs) + rec_off), g, xb, xr, enc[0], enc[1]);
-    }
-#else
     {
       Gathered g;
-#if INR_RECS_IN_REGS
-      issue_gathers(my_recs_reg, all_hashed, rsrc, me.x0, me.x1, me.x2, g);
-#else
       uint32_t rec_off = (uint32_t)q * 4u * (uint32_t)sizeof(LevelRec);
       asm volatile("" : "+v"(rec_off));    // opaque per tile: keeps the records in LDS, not hoisted into VGPRs
       issue_gathers(reinterpret_cast<const LevelRec*>(reinterpret_cast<const char*>(recs) + rec_off), all_hashed, rsrc,
                     me.x0, me.x1, me.x2, g);
-#endif
       __builtin_amdgcn_sched_barrier(0);   // all 32 gathers in flight before the first blend waits
       blend(g, enc[0], enc[1]);
     }
-#endif
     f32x4 h1[4], h2[4], o[K_MT];
     mlp_layer<4, 2>(wl + kIns0 / 4, lane, enc, h1);
 #pragma unroll
