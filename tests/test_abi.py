@@ -18,6 +18,44 @@ def test_header_and_binding_agree():
     assert sorted(_lib.EXPORTS) == _declared()
 
 
+def _prototypes():
+    """name -> list of parameter type strings, parsed from the header."""
+    src = open(os.path.join(ROOT, "include", "inr.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"//[^\n]*", "", src)
+    out = {}
+    for m in re.finditer(r"\b(?:int|int64_t|const char\*)\s+(inr_[a-zA-Z0-9_]+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
+        args = " ".join(m.group(2).split())
+        params = [] if args in ("", "void") else [a.strip() for a in args.split(",")]
+        out[m.group(1)] = params
+    return out
+
+
+def test_ctypes_signatures_match_the_header():
+    """Every argtypes list of the binding has the arity of its prototype, and pointer / float / 64-bit / 32-bit
+    parameters sit where the header puts them (a wrong ctypes width corrupts arguments silently)."""
+    import ctypes
+    from instance_nerf_amd import _lib
+    protos = _prototypes()
+    assert sorted(protos) == _declared()
+    ptr_like = (ctypes.c_void_p, ctypes.c_char_p)
+    for name, params in protos.items():
+        restype, argtypes = _lib._SIGS[name]
+        assert len(argtypes) == len(params), (name, len(argtypes), params)
+        for t, decl in zip(argtypes, params):
+            is_ptr = "*" in decl or decl.split()[0] == "inr_stream_t"
+            if is_ptr:
+                assert t in ptr_like or hasattr(t, "contents") or t is _lib.P, (name, decl, t)
+            elif decl.startswith("float"):
+                assert t is ctypes.c_float, (name, decl, t)
+            elif decl.startswith("int64_t"):
+                assert t is ctypes.c_int64, (name, decl, t)
+            elif decl.startswith(("int32_t", "int ")):
+                assert t is ctypes.c_int32, (name, decl, t)
+            else:
+                raise AssertionError(f"{name}: unhandled parameter type {decl!r}")
+
+
 def test_library_loads_and_exports_all_symbols():
     from instance_nerf_amd import _lib
     if not os.path.exists(_lib.LIB_PATH):
