@@ -295,6 +295,14 @@ int inr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
 int inr_adam_step_multi(int32_t n_tensors, float* const* params, const float* const* grads, float* const* exp_avgs,
                         float* const* exp_avg_sqs, const int64_t* numels, const float* lrs, float beta1, float beta2,
                         float eps, int32_t step, float grad_scale, inr_stream_t s);
+/* The same with the step-dependent scalars in DEVICE memory (hyper_dev = [eps_t, lr_t[0..15]], written by
+ * inr_adam_set_hyper on the stream - the values travel as kernel arguments, no host buffer has to stay alive): a
+ * captured hipGraph of a training step can then be replayed with a new learning rate and bias correction. */
+int inr_adam_set_hyper(const float* lrs /*host*/, int32_t n_tensors, float beta1, float beta2, float eps,
+                       int32_t step, float* hyper_dev /*[17]*/, inr_stream_t s);
+int inr_adam_step_multi_dev(int32_t n_tensors, float* const* params, const float* const* grads,
+                            float* const* exp_avgs, float* const* exp_avg_sqs, const int64_t* numels,
+                            const float* hyper_dev, float beta1, float beta2, float grad_scale, inr_stream_t s);
 /* Tail of NeRFRenderer.run_cuda (a14): image_out = image + (1 - weights_sum) * bg;
  * depth_out = clamp(depth - near, 0) / (far - near); outputs may alias the inputs.  No autograd: callers that
  * need gradients through the image use torch ops. */

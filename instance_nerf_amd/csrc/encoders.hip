@@ -204,8 +204,22 @@ struct AdamJobs {
   int64_t n[kAdamMaxTensors];
   float lr_t[kAdamMaxTensors];
 };
-__global__ void __launch_bounds__(256) k_adam_multi(AdamJobs J, float b1, float b2, float eps_t, float gscale) {
+struct AdamHyper {
+  float v[1 + kAdamMaxTensors];
+};
+__global__ void k_adam_set_hyper(AdamHyper h, float* __restrict__ hyper) {
+  if (threadIdx.x < 1 + kAdamMaxTensors) hyper[threadIdx.x] = h.v[threadIdx.x];
+}
+
+// hyper (nullable, device): [eps_t, lr_t[0..15]] - the step-dependent scalars live in memory so that a captured
+// hipGraph of the training step can be replayed with a new learning rate / bias correction
+__global__ void __launch_bounds__(256) k_adam_multi(AdamJobs J, float b1, float b2, float eps_t, float gscale,
+                                                    const float* __restrict__ hyper) {
   const int t = blockIdx.y;
+  if (hyper) {
+    eps_t = hyper[0];
+    J.lr_t[t] = hyper[1 + t];
+  }
   float* __restrict__ p = J.p[t];
   const float* __restrict__ g = J.g[t];
   float* __restrict__ m = J.m[t];
@@ -498,8 +512,42 @@ int inr_adam_step_multi(int32_t n_tensors, float* const* params, const float* co
   }
   if (n_max == 0) return INR_OK;
   const unsigned nb = (unsigned)std::min<int64_t>((n_max / 4 + 255) / 256 + 1, 256 * 16);
-  k_adam_multi<<<dim3(nb, n_tensors), 256, 0, as_stream(s)>>>(J, beta1, beta2, (float)(eps * sqrt(bc2)), grad_scale);
+  k_adam_multi<<<dim3(nb, n_tensors), 256, 0, as_stream(s)>>>(J, beta1, beta2, (float)(eps * sqrt(bc2)), grad_scale,
+                                                              nullptr);
   return check_launch("adam_step_multi");
+}
+
+int inr_adam_set_hyper(const float* lrs, int32_t n_tensors, float beta1, float beta2, float eps, int32_t step,
+                       float* hyper_dev, inr_stream_t s) {
+  INR_REQUIRE(lrs && hyper_dev && n_tensors >= 0 && n_tensors <= kAdamMaxTensors && step >= 1, "bad argument");
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  AdamHyper h;
+  h.v[0] = (float)(eps * sqrt(bc2));
+  for (int t = 0; t < kAdamMaxTensors; ++t) h.v[1 + t] = t < n_tensors ? (float)(lrs[t] * sqrt(bc2) / bc1) : 0.f;
+  // the values travel as kernel arguments (copied at launch), so the caller's buffers may change right away
+  k_adam_set_hyper<<<1, 32, 0, as_stream(s)>>>(h, hyper_dev);
+  return check_launch("adam_set_hyper");
+}
+
+int inr_adam_step_multi_dev(int32_t n_tensors, float* const* params, const float* const* grads, float* const* exp_avgs,
+                            float* const* exp_avg_sqs, const int64_t* numels, const float* hyper_dev, float beta1,
+                            float beta2, float grad_scale, inr_stream_t s) {
+  INR_REQUIRE(n_tensors >= 0 && n_tensors <= kAdamMaxTensors, "bad argument (at most 16 tensors per call)");
+  if (n_tensors == 0) return INR_OK;
+  INR_REQUIRE(params && grads && exp_avgs && exp_avg_sqs && numels && hyper_dev, "null pointer");
+  AdamJobs J;
+  int64_t n_max = 0;
+  for (int t = 0; t < n_tensors; ++t) {
+    INR_REQUIRE(numels[t] >= 0 && (numels[t] == 0 || (params[t] && grads[t] && exp_avgs[t] && exp_avg_sqs[t])),
+                "null tensor pointer");
+    J.p[t] = params[t]; J.g[t] = grads[t]; J.m[t] = exp_avgs[t]; J.v[t] = exp_avg_sqs[t]; J.n[t] = numels[t];
+    J.lr_t[t] = 0.f;
+    n_max = std::max(n_max, numels[t]);
+  }
+  if (n_max == 0) return INR_OK;
+  const unsigned nb = (unsigned)std::min<int64_t>((n_max / 4 + 255) / 256 + 1, 256 * 16);
+  k_adam_multi<<<dim3(nb, n_tensors), 256, 0, as_stream(s)>>>(J, beta1, beta2, 0.f, grad_scale, hyper_dev);
+  return check_launch("adam_step_multi_dev");
 }
 
 int inr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,

@@ -212,6 +212,56 @@ class FusedAdam:
             # cached MFMA-packed weights (NeRFNetwork._packed_weights) are refreshed
             torch.autograd.graph.increment_version(p)
 
+    # -- hipGraph support: the step-dependent scalars live in a device tensor --------------------------------
+    def _jobs(self):
+        jobs = []
+        for g in self.param_groups:
+            for p in g["params"]:
+                if p.grad is None or not p.requires_grad:
+                    continue
+                st = self.state.get(p)
+                if st is None:
+                    st = self.state[p] = (torch.zeros_like(p.data), torch.zeros_like(p.data))
+                jobs.append((p, p.grad, st[0], st[1], g))
+        return jobs
+
+    def refresh_hyper(self):
+        """Advance the step counter and write [eps_t, lr_t...] for the NEXT launch of ``step_captured`` (a tiny
+        kernel on the stream whose arguments carry the values: call it right before the launch / graph replay)."""
+        import ctypes
+        lib = _lib.load()
+        self.step_count += 1
+        lrs = [float(j[4]["lr"]) for j in self._hyper_jobs]
+        _lib.check(lib.inr_adam_set_hyper((ctypes.c_float * len(lrs))(*lrs), len(lrs), self.betas[0], self.betas[1],
+                                          self.eps, self.step_count, _lib.ptr(self._hyper_dev), _lib.stream_ptr()),
+                   "adam_set_hyper")
+
+    @torch.no_grad()
+    def step_captured(self):
+        """``step()`` for use inside a captured graph: identical arithmetic, learning rate and bias correction read
+        from device memory (``refresh_hyper``).  At most 16 tensors."""
+        import ctypes
+        lib = _lib.load()
+        jobs = self._jobs()
+        if len(jobs) > 16:
+            raise RuntimeError("step_captured handles at most 16 parameter tensors")
+        if getattr(self, "_hyper_dev", None) is None:
+            dev = jobs[0][0].device
+            self._hyper_dev = torch.zeros(17, dtype=torch.float32, device=dev)
+        self._hyper_jobs = jobs
+        n = len(jobs)
+        for j in jobs:
+            for t, name in ((j[0].data, "param"), (j[1], "grad"), (j[2], "exp_avg"), (j[3], "exp_avg_sq")):
+                _lib.ptr(t, torch.float32, name)
+        arr = lambda k: (ctypes.c_void_p * n)(*[j[k].data_ptr() for j in jobs])
+        numels = (ctypes.c_int64 * n)(*[j[0].numel() for j in jobs])
+        _lib.check(lib.inr_adam_step_multi_dev(n, arr(0), arr(1), arr(2), arr(3), numels, _lib.ptr(self._hyper_dev),
+                                               self.betas[0], self.betas[1], 1.0, _lib.stream_ptr()), "adam_step_multi_dev")
+
+    def bump_versions(self):
+        for j in getattr(self, "_hyper_jobs", []):
+            torch.autograd.graph.increment_version(j[0])
+
     def state_dict(self):
         flat = [p for g in self.param_groups for p in g["params"]]
         return {"step": self.step_count, "lrs": [g["lr"] for g in self.param_groups],
@@ -354,7 +404,7 @@ class Trainer:
 
     def __init__(self, name, opt, model, criterion=None, optimizer=None, lr=1e-2, iters=30000,
                  local_rank=0, world_size=1, device=None, workspace="workspace", fused_adam=True,
-                 stage="nerf", update_extra_interval=16, ema_decay=None):
+                 stage="nerf", update_extra_interval=16, ema_decay=None, use_graph=False):
         self.name, self.opt, self.model = name, opt, model
         self.world_size, self.local_rank = world_size, local_rank
         self.device = device or (torch.device("cuda", local_rank) if torch.cuda.is_available() else torch.device("cpu"))
@@ -379,6 +429,11 @@ class Trainer:
         self.ema = ParamEMA([p for g in self.optimizer.param_groups for p in g["params"]], ema_decay) \
             if ema_decay is not None else None
         self.base_lrs = [g["lr"] for g in self.optimizer.param_groups]
+        # use_graph: in the steady state (sample buffers sized by mean_count, no host read-back) the whole step -
+        # march, fields, compositing, loss, backward, Adam - is captured once per buffer size as a hipGraph and
+        # replayed; one process, FusedAdam only.  Falls back to the eager step whenever the conditions do not hold.
+        self.use_graph = bool(use_graph) and world_size == 1 and isinstance(self.optimizer, FusedAdam)
+        self._graph = None
         self.global_step = 0
         self.epoch = 0
         self.stats = {"loss": [], "results": []}
@@ -422,11 +477,64 @@ class Trainer:
         return outputs["image"], outputs["depth"], outputs.get("instance")
 
     # -- loops -------------------------------------------------------------------------------
+    # -- captured step ----------------------------------------------------------------------
+    GRAPH_ALIGN = 16384        # buffer sizes are rounded up to this many samples so that a graph survives the
+                               # small changes of mean_count at every occupancy update
+
+    def _graph_key(self, data):
+        return (self.model.mean_count, self.stage) + tuple((k, tuple(v.shape)) for k, v in sorted(data.items())
+                                                            if torch.is_tensor(v))
+
+    def _capture(self, data):
+        m = self.model
+        static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in data.items()}
+        slot = m.local_step % 16
+        opt = self.optimizer
+        for g in opt.param_groups:              # moments and the hyper-parameter tensor must exist BEFORE the capture
+            for p in g["params"]:               # (an allocation + zero fill inside it would be replayed every step)
+                if p.requires_grad and p not in opt.state:
+                    opt.state[p] = (torch.zeros_like(p.data), torch.zeros_like(p.data))
+        if getattr(opt, "_hyper_dev", None) is None:
+            opt._hyper_dev = torch.zeros(17, dtype=torch.float32, device=self.device)
+        self.optimizer.zero_grad()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            _, _, loss = self.train_step(static)
+            loss.backward()
+            self.optimizer.step_captured()
+        m.local_step -= 1                       # the capture pass launched nothing; undo its bookkeeping
+        self._graph = {"graph": g, "static": static, "loss": loss, "slot": slot, "key": self._graph_key(data)}
+
+    def _replay(self, data):
+        G, m = self._graph, self.model
+        for k, v in data.items():
+            if torch.is_tensor(v):
+                G["static"][k].copy_(v, non_blocking=True)
+        self._lr_step()
+        self.optimizer.refresh_hyper()
+        G["graph"].replay()
+        cur = m.local_step % 16
+        if cur != G["slot"]:                    # the graph always writes the slot it was captured with
+            m.step_counter[cur].copy_(m.step_counter[G["slot"]])
+        m.local_step += 1
+        self.optimizer.bump_versions()
+        if self.ema is not None:
+            self.ema.update()
+        return G["loss"].detach()
+
     def train_one_step(self, data):
         self.model.train()
         if self.model.cuda_ray and self.global_step % self.update_extra_interval == 0:
             self.model.update_extra_state()
+            if self.use_graph and self.model.mean_count > 0:
+                a = self.GRAPH_ALIGN
+                self.model.mean_count = (self.model.mean_count + a - 1) // a * a
         self.global_step += 1
+        if self.use_graph and self.model.cuda_ray and self.model.mean_count > 0:
+            if self._graph is None or self._graph["key"] != self._graph_key(data):
+                self._capture(data)
+            return self._replay(data)
         self.optimizer.zero_grad()
         _, _, loss = self.train_step(data)
         loss.backward()

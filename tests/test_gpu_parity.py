@@ -1088,3 +1088,40 @@ def test_trainer_runs_on_a_transforms_json_scene(tmp_path, room):
     ti.global_step = 1
     ce = [float(ti.train_one_step(ds[i % len(ds)])) for i in range(30)]
     assert np.isfinite(ce).all() and np.mean(ce[-5:]) < np.mean(ce[:5])
+
+
+@pytest.mark.parametrize("stage", ["nerf", "instance"])
+def test_captured_training_step_equals_eager(stage):
+    """Trainer(use_graph=True): the steady-state step captured once as a hipGraph (march, fields, compositing, loss,
+    backward, Adam with its step-dependent scalars in device memory) and replayed follows the eager trainer step for
+    step - same ray jitter, same learning-rate schedule, same bias correction - and survives an occupancy update."""
+    from instance_nerf_amd.nerf import NeRFNetwork
+    from instance_nerf_amd.nerf.provider import SyntheticRoomDataset
+    from instance_nerf_amd.nerf.utils import Trainer
+    dev = torch.device(DEV)
+    runs = {}
+    for use_graph in (False, True):
+        torch.manual_seed(0)
+        net = NeRFNetwork(cuda_ray=True, bound=1, min_near=0.05, num_instances=16 if stage == "instance" else 0).to(dev)
+        ds = SyntheticRoomDataset(dev, num_rays=1024, num_instances=16, seed=5)
+        net.density_bitfield.copy_(_t(ds.room.density_bitfield(128, 1.0)))
+        tr = Trainer("g", None, net, stage=stage, device=dev, iters=200, update_extra_interval=10 ** 9, use_graph=use_graph,
+                     ema_decay=0.95)
+        tr.global_step = 1
+        batches = [ds.batch() for _ in range(3)]
+        losses = [float(tr.train_one_step(batches[i % 3])) for i in range(3)]          # eager: exact sample totals
+        net.mean_count = 65536                                                        # steady state from here on
+        losses += [float(tr.train_one_step(batches[i % 3])) for i in range(6)]
+        assert (tr._graph is not None) == use_graph
+        net.mean_count = 81920                                                        # buffer size changes: re-capture
+        losses += [float(tr.train_one_step(batches[i % 3])) for i in range(4)]
+        runs[use_graph] = (losses, [p.detach().clone() for g in tr.optimizer.param_groups for p in g["params"]],
+                           tr.optimizer.step_count, [s.clone() for s in tr.ema.shadow], net.local_step)
+    a, b = runs[False], runs[True]
+    assert a[2] == b[2] == 13 and a[4] == b[4]
+    assert np.allclose(a[0], b[0], rtol=2e-3), (a[0], b[0])
+    assert a[0][-1] < a[0][0]
+    for p, q in zip(a[1], b[1]):
+        assert torch.linalg.norm(p - q) < 1e-2 * torch.linalg.norm(p)
+    for p, q in zip(a[3], b[3]):
+        assert torch.linalg.norm(p - q) < 1e-2 * torch.linalg.norm(p)
