@@ -288,8 +288,12 @@ def main():
             line["cpu_baseline"] = cpu_baseline(room)
     if not args.no_train_probe:
         del net                                       # the probe builds its own (instance-head) network
-        ts = train_probe(dev, rank, world, red_dev)   # collective when world > 1: every rank runs it
-        tn = train_probe(dev, rank, world, red_dev, stage="nerf")
+        # secondary measurements must never cost the headline line: report a failure instead of dying with it
+        try:
+            ts = train_probe(dev, rank, world, red_dev)   # collective when world > 1: every rank runs it
+            tn = train_probe(dev, rank, world, red_dev, stage="nerf")
+        except Exception as e:                            # noqa: BLE001
+            ts = tn = {"error": f"{type(e).__name__}: {e}"[:300]}
         if rank == 0:
             line["train_step"] = ts
             line["train_step_nerf"] = tn
