@@ -4,7 +4,7 @@
 One step = one full 800x800 render of the synthetic 3D-FRONT-like room (BASELINE.json
 configs[1]: hash-grid NeRF L=16,F=2, sigma+colour, SURVEY.md section 8d scene and cameras):
 ray generation -> ray/AABB -> occupancy march (count, scan, write) -> fused hash-gather + SH +
-MLP (fp32 MFMA) -> alpha compositing, everything on the GPU with parameters, bitfield and
+MLP (bf16x3-split MFMA, fp32 accumulate) -> alpha compositing, everything on the GPU with parameters, bitfield and
 poses resident in HBM before the timed region.  Samples = live (occupied) samples the field
 evaluated.  N > 1 ranks (torchrun, one process per GPU): every rank renders its own views -
 no data-path collective - and value = all samples / max-over-ranks time ("weak" scaling).
@@ -163,7 +163,21 @@ def main():
     ap.add_argument("--streams", type=int, default=1, help="HIP streams frames alternate on (1 = no overlap)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start N fresh ranks (one per GPU) as CHILD processes -
+        # nothing in this process has touched the GPU yet, and it is never replaced by exec - and pass their
+        # exit code on.  The driver's own `python -m torch.distributed.run ... bench.py --gpus N` skips this.
+        import subprocess
+        port = os.environ.get("MASTER_PORT", str(29500 + os.getpid() % 2000))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.run(cmd).returncode)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        print(json.dumps({"error": f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                                   f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus})"}))
+        sys.exit(2)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
@@ -272,7 +286,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed_all / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            # gathers, interpolation, SH, marching and compositing are IEEE fp32; the MLP GEMMs run on
+            # v_mfma_f32_16x16x32_bf16 with a 3-term bf16 split of both operands (~2^-16 relative, fp32 accumulate)
+            "dtype": "f32 (MLP GEMMs: bf16x3-split MFMA, fp32 accumulate)", "data": "synthetic",
             "config": {"workload": f"render {args.res}x{args.res} synthetic 3D-FRONT-like room, hash-grid NeRF "
                                    "L=16 F=2 T=6119864 sigma+rgb (BASELINE configs[1]), one view per step per GPU",
                        "samples_per_step": n_samples // args.steps, "rays_per_step": H * W,
@@ -288,12 +304,23 @@ def main():
             line["cpu_baseline"] = cpu_baseline(room)
     if not args.no_train_probe:
         del net                                       # the probe builds its own (instance-head) network
-        # secondary measurements must never cost the headline line: report a failure instead of dying with it
-        try:
-            ts = train_probe(dev, rank, world, red_dev)   # collective when world > 1: every rank runs it
+        if world == 1:
+            # secondary measurements must never cost the headline line: report a failure instead of dying with it
+            try:
+                ts = train_probe(dev, rank, world, red_dev)
+                tn = train_probe(dev, rank, world, red_dev, stage="nerf")
+            except Exception as e:                        # noqa: BLE001
+                ts = tn = {"error": f"{type(e).__name__}: {e}"[:300]}
+        else:
+            # the probe contains collectives: a rank that swallowed an exception would leave the others waiting in
+            # all_reduce, so exceptions propagate (non-zero exit, the launcher tears the job down).  The headline
+            # line is kept in a side file first so a failing probe cannot lose the measurement.
+            if rank == 0:
+                os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+                with open(os.path.join(ROOT, "gpurun_out", f"bench_headline_n{world}.json"), "w") as f:
+                    f.write(json.dumps(line) + "\n")
+            ts = train_probe(dev, rank, world, red_dev)   # every rank runs it
             tn = train_probe(dev, rank, world, red_dev, stage="nerf")
-        except Exception as e:                            # noqa: BLE001
-            ts = tn = {"error": f"{type(e).__name__}: {e}"[:300]}
         if rank == 0:
             line["train_step"] = ts
             line["train_step_nerf"] = tn

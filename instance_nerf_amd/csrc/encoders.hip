@@ -23,6 +23,10 @@ __global__ void __launch_bounds__(256) k_grid_fwd(const float* __restrict__ x, c
   const float x0 = (x[m * 3 + 0] + bound) / rb;
   const float x1 = (x[m * 3 + 1] + bound) / rb;
   const float x2 = (x[m * 3 + 2] + bound) / rb;
+  if (oob01(x0, x1, x2)) {             // outside the grid: zero features (upstream's flag_oob)
+    out[m * L + l] = make_float2(0.f, 0.f);
+    return;
+  }
   Cell c;
   locate(G, l, x0, x1, x2, c);
   float2 acc = make_float2(0.f, 0.f);
@@ -77,13 +81,17 @@ __global__ void __launch_bounds__(256) k_grid_bwd(const float* __restrict__ x, c
   const int sub = threadIdx.x & 3, xb = sub >> 1, f = sub & 1;
   const int l = level0 + blockIdx.y;
   const int L = G.num_levels;
-  const bool valid = m < M;
+  bool valid = m < M;
   const int64_t ms = valid ? m : M - 1;
   const int64_t mc = order ? (int64_t)order[ms] : ms;
   const float rb = 2.0f * bound;
-  const float x0 = (x[mc * 3 + 0] + bound) / rb;
-  const float x1 = (x[mc * 3 + 1] + bound) / rb;
-  const float x2 = (x[mc * 3 + 2] + bound) / rb;
+  float x0 = (x[mc * 3 + 0] + bound) / rb;
+  float x1 = (x[mc * 3 + 1] + bound) / rb;
+  float x2 = (x[mc * 3 + 2] + bound) / rb;
+  if (oob01(x0, x1, x2)) {             // outside the grid: no gradient (upstream's flag_oob); all lanes stay in
+    valid = false;                     // the wave for the segmented scan
+    x0 = x1 = x2 = 0.0f;
+  }
   Cell c;
   locate(G, l, x0, x1, x2, c);
   const float g = valid ? gout[(mc * L + l) * 2 + f] : 0.f;

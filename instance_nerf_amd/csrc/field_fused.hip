@@ -343,6 +343,7 @@ __device__ __forceinline__ float select4(int q, float a, float b, float c, float
 struct TileIn {
   float x0, x1, x2;   // x01
   float d0, d1, d2;
+  bool oob;           // x01 left [0,1]: features are zero (upstream's flag_oob); x01 is then replaced by 0
 };
 
 // x01 = (x + bound) / (2 bound): a true IEEE division, as in the oracle.  (Replacing it by a multiplication
@@ -356,6 +357,8 @@ __device__ __forceinline__ void load_tile_in(const float* __restrict__ x, const 
   t.x0 = to_x01(x[m * 3 + 0], bound, rb, rb_inv);
   t.x1 = to_x01(x[m * 3 + 1], bound, rb, rb_inv);
   t.x2 = to_x01(x[m * 3 + 2], bound, rb, rb_inv);
+  t.oob = oob01(t.x0, t.x1, t.x2);
+  if (t.oob) t.x0 = t.x1 = t.x2 = 0.0f;
   if constexpr (kDir) {
     t.d0 = d[m * 3]; t.d1 = d[m * 3 + 1]; t.d2 = d[m * 3 + 2];
   }
@@ -483,6 +486,9 @@ __global__ void __launch_bounds__(kFieldThreads, INR_FIELD_MIN_WAVES) k_nerf_fwd
                     me.x0, me.x1, me.x2, g);
       __builtin_amdgcn_sched_barrier(0);   // all 32 gathers in flight before the first blend waits
       blend(g, enc[0], enc[1]);
+    }
+    if constexpr (!kTable) {               // the table feed comes from the marcher, which clamps to the volume
+      if (me.oob) enc[0] = enc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 #if INR_PROBE_MODE == 2
     {
@@ -614,6 +620,7 @@ __global__ void __launch_bounds__(kFieldThreads, INR_FIELD_MIN_WAVES) k_instance
       __builtin_amdgcn_sched_barrier(0);   // all 32 gathers in flight before the first blend waits
       blend(g, enc[0], enc[1]);
     }
+    if (me.oob) enc[0] = enc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 h1[4], h2[4], o[K_MT];
     mlp_layer<4, 2>(wl + kIns0 / 4, lane, enc, h1);
 #pragma unroll

@@ -43,6 +43,12 @@ inline int make_grid_desc(const inr_grid_desc* d, GridDesc& G) {
   return INR_OK;
 }
 
+// Upstream's gridencoder flags a sample whose normalised coordinate leaves [0,1] on any axis (flag_oob): its
+// features are zero and it adds nothing to the table gradient.  NaN counts as outside.
+__device__ __forceinline__ bool oob01(float x0, float x1, float x2) {
+  return !(x0 >= 0.0f && x0 <= 1.0f && x1 >= 0.0f && x1 <= 1.0f && x2 >= 0.0f && x2 <= 1.0f);
+}
+
 struct Cell {
   uint32_t gx, gy, gz;   // lower corner
   float fx, fy, fz;      // fractional position inside the cell

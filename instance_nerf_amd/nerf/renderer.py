@@ -26,6 +26,8 @@ from .._lib import check, ptr, stream_ptr
 
 
 class NeRFRenderer(nn.Module):
+    min_staged_batch = 1 << 20
+
     def __init__(self, bound=1, cuda_ray=False, density_scale=1, min_near=0.2, density_thresh=0.01,
                  bg_radius=-1, grid_size=128):
         super().__init__()
@@ -355,19 +357,29 @@ class NeRFRenderer(nn.Module):
         """rays_o, rays_d [B,N,3] -> dict of [B,N,...] tensors (upstream signature)."""
         _run = self.run_cuda if self.cuda_ray else self.run
         B, N = rays_o.shape[:2]
+        # upstream chunks staged renders to fit a 24 GB card; a 640 000-ray frame needs ~2 GB of the 288 GB here, and
+        # rays are independent (chunking never changes a result), so chunks are at least `min_staged_batch` rays.
+        # Set model.min_staged_batch = 0 for upstream's exact chunk size.
+        max_ray_batch = max(int(max_ray_batch), int(self.min_staged_batch))
         if staged and not self.cuda_ray:
             raise NotImplementedError("staged rendering is only meaningful on the cuda_ray path here")
         if staged and N > max_ray_batch:
-            keys = None
+            if not self.training and kwargs.get("infer_mode", "auto") == "auto":
+                # one mode per frame: every chunk of a staged render takes the same kernel path
+                kwargs = dict(kwargs, infer_mode="fused_terminate" if self._recent_opacity() > 0.5 else "fused")
             chunks = {}
             for b in range(B):
                 head = 0
                 while head < N:
                     tail = min(head + max_ray_batch, N)
                     r = _run(rays_o[b:b + 1, head:tail], rays_d[b:b + 1, head:tail], **kwargs)
-                    keys = keys or [k for k in r if k != "num_samples"]
-                    for k in keys:
-                        chunks.setdefault((k, b), []).append(r[k])
+                    for k, v in r.items():
+                        # per-ray results only ([1, n, ...]); the sample counters of a chunk are not concatenated
+                        if torch.is_tensor(v) and v.dim() >= 2 and v.shape[:2] == (1, tail - head):
+                            chunks.setdefault((k, b), []).append(v)
                     head += max_ray_batch
+            keys = sorted({k for k, _ in chunks})
+            n_chunks = (N + max_ray_batch - 1) // max_ray_batch
+            keys = [k for k in keys if all(len(chunks.get((k, b), ())) == n_chunks for b in range(B))]
             return {k: torch.cat([torch.cat(chunks[(k, b)], 1) for b in range(B)], 0) for k in keys}
         return _run(rays_o, rays_d, **kwargs)

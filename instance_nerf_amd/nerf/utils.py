@@ -263,12 +263,44 @@ class FusedAdam:
             torch.autograd.graph.increment_version(j[0])
 
     def state_dict(self):
-        flat = [p for g in self.param_groups for p in g["params"]]
-        return {"step": self.step_count, "lrs": [g["lr"] for g in self.param_groups],
-                "state": {i: self.state[p] for i, p in enumerate(flat) if p in self.state}}
+        """``torch.optim.Adam.state_dict()`` layout (what upstream's checkpoints hold under 'optimizer'): per-parameter
+        ``step`` / ``exp_avg`` / ``exp_avg_sq`` keyed by the running parameter index, and the param groups."""
+        state, groups, i = {}, [], 0
+        for g in self.param_groups:
+            ids = []
+            for p in g["params"]:
+                if p in self.state:
+                    m, v = self.state[p]
+                    state[i] = {"step": torch.tensor(float(self.step_count)), "exp_avg": m, "exp_avg_sq": v}
+                ids.append(i)
+                i += 1
+            groups.append({"lr": g["lr"], "initial_lr": g.get("initial_lr", g["lr"]), "betas": tuple(self.betas),
+                           "eps": self.eps, "weight_decay": 0, "amsgrad": False, "params": ids})
+        return {"state": state, "param_groups": groups}
 
     def load_state_dict(self, sd):
+        """Accepts the torch.optim layout (this class's own and upstream's Adam checkpoints) and round 1's private
+        layout ({'step', 'lrs', 'state': {i: (m, v)}})."""
         flat = [p for g in self.param_groups for p in g["params"]]
+        if "param_groups" in sd:
+            if sum(len(g["params"]) for g in sd["param_groups"]) != len(flat):
+                raise ValueError("optimizer state has a different number of parameters")
+            for g, saved in zip(self.param_groups, sd["param_groups"]):
+                g["lr"] = saved["lr"]
+                g["initial_lr"] = saved.get("initial_lr", g.get("initial_lr", saved["lr"]))
+            if sd["param_groups"]:
+                self.betas = tuple(sd["param_groups"][0].get("betas", self.betas))
+                self.eps = sd["param_groups"][0].get("eps", self.eps)
+            steps = []
+            for i, st in sd["state"].items():
+                p = flat[int(i)]
+                if st["exp_avg"].shape != p.shape:
+                    raise ValueError(f"optimizer state {i}: shape {tuple(st['exp_avg'].shape)} != {tuple(p.shape)}")
+                self.state[p] = (st["exp_avg"].to(p.device, torch.float32).contiguous().clone(),
+                                 st["exp_avg_sq"].to(p.device, torch.float32).contiguous().clone())
+                steps.append(int(float(st["step"])))
+            self.step_count = max(steps) if steps else 0
+            return
         self.step_count = sd["step"]
         for g, lr in zip(self.param_groups, sd["lrs"]):
             g["lr"] = lr
@@ -593,14 +625,32 @@ class Trainer:
         return path
 
     def load_checkpoint(self, path, model_only=False):
+        """Upstream semantics: a checkpoint without a 'model' key is a bare model state dict; missing / unexpected
+        keys are reported, not fatal; a failing optimizer or EMA restore only warns (e.g. an Adam state saved for
+        a different set of trained parameters)."""
+        import warnings
         state = torch.load(path, map_location=self.device, weights_only=False)
-        self.model.load_state_dict(state["model"], strict=False)
+        if "model" not in state:
+            self.model.load_state_dict(state, strict=False)
+            return
+        missing, unexpected = self.model.load_state_dict(state["model"], strict=False)
+        if missing or unexpected:
+            warnings.warn(f"load_checkpoint: missing keys {list(missing)}, unexpected keys {list(unexpected)}")
         if self.model.cuda_ray:
             self.model.mean_count = state.get("mean_count", 0)
             self.model.mean_density = state.get("mean_density", 0)
         if model_only:
             return
-        self.epoch, self.global_step, self.stats = state["epoch"], state["global_step"], state["stats"]
-        self.optimizer.load_state_dict(state["optimizer"])
+        self.epoch = state.get("epoch", self.epoch)
+        self.global_step = state.get("global_step", self.global_step)
+        self.stats = state.get("stats", self.stats)
+        if "optimizer" in state:
+            try:
+                self.optimizer.load_state_dict(state["optimizer"])
+            except Exception as e:                                    # noqa: BLE001 - upstream warns and goes on
+                warnings.warn(f"load_checkpoint: optimizer state not restored ({type(e).__name__}: {e})")
         if self.ema is not None and "ema" in state:
-            self.ema.load_state_dict(state["ema"])
+            try:
+                self.ema.load_state_dict(state["ema"])
+            except Exception as e:                                    # noqa: BLE001
+                warnings.warn(f"load_checkpoint: EMA state not restored ({type(e).__name__}: {e})")

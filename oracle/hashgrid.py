@@ -57,12 +57,19 @@ def corner_indices_weights(x, bound, table):
 
     torch implementation (fp32 arithmetic, int64 index maths masked to uint32
     where the hash needs wraparound).
+
+    Out of range (upstream's ``flag_oob``, SURVEY Appendix A.1 "Later upstream versions zero the output
+    for inputs outside [0,1]"): a sample whose normalised coordinate leaves [0,1] on any axis (NaN
+    included) gets weight 0 on every corner of every level - zero features, no table gradient; its
+    indices are those of x01 = 0 (any valid row would do).
     """
     x = torch.as_tensor(x, dtype=torch.float32)
     M = x.shape[0]
     L = table["num_levels"]
     b = torch.tensor(float(bound), dtype=torch.float32)
     x01 = (x + b) / (2 * b)
+    oob = ~((x01 >= 0) & (x01 <= 1)).all(-1)
+    x01 = torch.where(oob[:, None], torch.zeros_like(x01), x01)
     idx_all = torch.empty((M, L, 8), dtype=torch.int64)
     w_all = torch.empty((M, L, 8), dtype=torch.float32)
     for l in range(L):
@@ -90,6 +97,7 @@ def corner_indices_weights(x, bound, table):
                 i = (cx + cy * s + cz * s * s) % rows
             idx_all[:, l, c] = i + off
             w_all[:, l, c] = (wx * wy) * wz
+    w_all[oob] = 0.0
     return idx_all, w_all
 
 

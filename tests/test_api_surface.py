@@ -73,6 +73,66 @@ def test_trainer_surface():
     assert opt.betas == (0.9, 0.99) and opt.eps == 1e-15 and opt.param_groups[0]["lr"] == 1e-2
 
 
+def test_fused_adam_state_dict_is_the_torch_adam_layout():
+    """Regression (round-1 advisor): upstream checkpoints hold a torch.optim.Adam state dict under 'optimizer'.
+    FusedAdam emits and accepts that layout (and still reads round 1's private one)."""
+    from instance_nerf_amd.nerf.utils import FusedAdam
+    gen = torch.Generator().manual_seed(0)
+    ps = [torch.nn.Parameter(torch.randn(5, 2, generator=gen)), torch.nn.Parameter(torch.randn(7, generator=gen))]
+    ref = torch.optim.Adam([{"params": [ps[0]], "lr": 1e-2}, {"params": [ps[1]], "lr": 3e-3}], betas=(0.9, 0.99), eps=1e-15)
+    for _ in range(3):
+        for p in ps:
+            p.grad = torch.randn(p.shape, generator=gen)
+        ref.step()
+    sd = ref.state_dict()
+    mine = FusedAdam([{"params": [ps[0]], "lr": 1.0}, {"params": [ps[1]], "lr": 1.0}])
+    mine.load_state_dict(sd)
+    assert mine.step_count == 3 and [g["lr"] for g in mine.param_groups] == [1e-2, 3e-3]
+    for i, p in enumerate(ps):
+        assert torch.equal(mine.state[p][0], sd["state"][i]["exp_avg"]) and torch.equal(mine.state[p][1], sd["state"][i]["exp_avg_sq"])
+    out = mine.state_dict()
+    assert set(out) == {"state", "param_groups"} and set(out["state"][0]) == {"step", "exp_avg", "exp_avg_sq"}
+    back = torch.optim.Adam([{"params": [ps[0]]}, {"params": [ps[1]]}])
+    back.load_state_dict(out)                                     # torch accepts what FusedAdam emits
+    assert float(back.state[ps[1]]["step"]) == 3 and back.param_groups[1]["lr"] == 3e-3
+    assert torch.equal(back.state[ps[0]]["exp_avg_sq"], sd["state"][0]["exp_avg_sq"])
+    old = FusedAdam([{"params": ps}])
+    old.load_state_dict({"step": 9, "lrs": [5e-3], "state": {1: (torch.ones(7), torch.full((7,), 2.0))}})
+    assert old.step_count == 9 and old.param_groups[0]["lr"] == 5e-3 and float(old.state[ps[1]][1][0]) == 2.0
+    import pytest
+    with pytest.raises(ValueError):
+        FusedAdam([{"params": ps[:1]}]).load_state_dict(sd)      # different parameter set: caller decides (Trainer warns)
+
+
+def test_load_checkpoint_accepts_upstream_shapes(tmp_path):
+    """A bare model state dict, and a full checkpoint whose optimizer state does not fit (warning, as upstream)."""
+    import warnings
+    from instance_nerf_amd.nerf import NeRFNetwork
+    from instance_nerf_amd.nerf.utils import FusedAdam, Trainer
+    kw = dict(cuda_ray=True, bound=1, num_instances=16)
+    src = NeRFNetwork(**kw)
+    with torch.no_grad():
+        src.sigma_net[0].weight.fill_(0.25)
+        src.density_grid.fill_(3.0)
+    bare, full = str(tmp_path / "bare.pth"), str(tmp_path / "full.pth")
+    torch.save(src.state_dict(), bare)
+    torch.save({"epoch": 7, "global_step": 1234, "stats": {"loss": [1.0], "results": []}, "model": src.state_dict(),
+                "mean_count": 4321, "mean_density": 0.5,
+                "optimizer": torch.optim.Adam([torch.nn.Parameter(torch.zeros(2))]).state_dict()}, full)
+    make = lambda: Trainer("t", None, NeRFNetwork(**kw), stage="instance", device=torch.device("cpu"),
+                           optimizer=lambda groups: FusedAdam(groups))
+    a = make()
+    a.load_checkpoint(bare)
+    assert float(a.model.sigma_net[0].weight[0, 0]) == 0.25 and float(a.model.density_grid[0, 0]) == 3.0
+    b = make()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        b.load_checkpoint(full)
+    assert any("optimizer state not restored" in str(x.message) for x in w)
+    assert (b.epoch, b.global_step, b.model.mean_count, b.model.mean_density) == (7, 1234, 4321, 0.5)
+    assert float(b.model.sigma_net[0].weight[0, 0]) == 0.25
+
+
 def test_hip_path_refuses_cpu_tensors():
     """No CPU fallback behind the extension-level API: host tensors raise before any launch."""
     import pytest

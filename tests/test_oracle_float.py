@@ -26,6 +26,26 @@ def test_hash_indices_in_range_and_weights_sum_to_one(level_table):
     assert (w >= 0).all()
 
 
+def test_points_outside_the_grid_encode_to_zero_and_get_no_gradient(level_table):
+    """Upstream's flag_oob: a normalised coordinate outside [0,1] on any axis (or NaN) -> zero features, no table
+    gradient; points exactly on the faces are inside."""
+    x = torch.tensor([[0.2, -0.3, 0.9], [1.0, -1.0, 1.0], [1.000001, 0, 0], [0, -1.5, 0], [0, 0, 7.0],
+                      [float("nan"), 0, 0], [-1e30, 0, 0], [0.5, 0.5, 0.5]])
+    inside = torch.tensor([True, True, False, False, False, False, False, True])
+    idx, w = hashgrid.corner_indices_weights(x, 1.0, level_table)
+    off = level_table["offsets"].astype(np.int64)
+    for l in range(16):
+        assert (idx[:, l] >= off[l]).all() and (idx[:, l] < off[l + 1]).all()       # always addressable rows
+    assert torch.allclose(w[inside].sum(-1), torch.ones(3, 16), atol=1e-5)
+    assert (w[~inside] == 0).all()
+    emb = torch.rand(level_table["total_rows"], 2, generator=torch.Generator().manual_seed(1)).requires_grad_(True)
+    out = hashgrid.encode(x, emb, 1.0, level_table)
+    assert (out[~inside] == 0).all() and (out[inside].abs().sum(-1) > 0).all()
+    out.sum().backward()
+    only_inside = hashgrid.encode_backward_table(x[inside], torch.ones(3, 32), 1.0, level_table)
+    assert torch.allclose(emb.grad, only_inside, atol=1e-6)
+
+
 def test_dense_levels_are_collision_free(level_table):
     """On a dense level distinct lattice corners map to distinct rows."""
     res = int(level_table["resolutions"][0])
