@@ -50,34 +50,33 @@ def build_network(dev, seed=0):
     return net.eval(), room
 
 
-def cpu_baseline(room, chunk=4096, budget_s=12.0, max_chunks=24):
-    """Oracle (kind 'port') on the host cores, bounded sample of the same workload: 4096-ray chunks of
-    view 0 (a strided sub-image per chunk) until ~budget_s seconds of CPU work have been done.
-
-    The oracle is numpy + torch-CPU: its many small ops stop scaling (and then regress badly)
-    beyond ~16 threads, so it runs on min(cores, 16) threads; ``cores`` reports what was used."""
-    from oracle import field, hashgrid, render as orender, rays as orays
-    threads = min(os.cpu_count() or 1, 16)
-    torch.set_num_threads(threads)
+def cpu_baseline(room, chunk=16384, budget_s=12.0, max_chunks=40):
+    """The C restatement of the whole path (oracle/c/inr_oracle.c through oracle/c_port.py, kind 'port': slab test ->
+    occupancy march -> hash-grid gather + SH + MLPs -> compositing, one ray at a time, OpenMP over rays on every
+    host core) on a bounded sample of the same workload: chunks of random pixels of view 0 until ~budget_s seconds
+    of wall time have been used.  Same table, weights, bitfield and camera as the GPU measurement."""
+    from oracle import c_port, field, hashgrid, rays as orays
     table = hashgrid.level_table()
     p = field.init_params(seed=0, table=table, table_std=1e-4)
     bits = room.density_bitfield(128, 1.0)
     poses, intr, H, W = room.cameras()
     perm = np.random.default_rng(7).permutation(H * W)
+    threads = c_port.num_threads()
+    c_port.render(*[orays.get_rays(poses[:1], intr, H, W, inds=perm[:256])[k][0] for k in ("rays_o", "rays_d")],
+                  p, table, bits, min_near=0.05)                               # page the table in, untimed
     total, rays_done, t_used, n = 0, 0, 0.0, 0
     while t_used < budget_s and n < max_chunks:
         inds = np.sort(perm[n * chunk:(n + 1) * chunk])
         r = orays.get_rays(poses[:1], intr, H, W, inds=inds)
         t0 = time.perf_counter()
-        with torch.no_grad():
-            out = orender.render_train(r["rays_o"][0], r["rays_d"][0], p, table, bits, min_near=0.05)
+        out = c_port.render(r["rays_o"][0], r["rays_d"][0], p, table, bits, min_near=0.05)
         t_used += time.perf_counter() - t0
         total += out["total"]
         rays_done += len(inds)
         n += 1
     return {"value": round(total / t_used / 1e6, 5), "unit": "Msamples/s", "cores": threads, "kind": "port",
             "sample": f"{rays_done} random rays of view 0 (800x800 camera) in {n} chunks of {chunk}, {total} samples, "
-                      f"oracle march+field+composite, {t_used:.1f} s"}
+                      f"C oracle (gcc -O2, OpenMP x{threads}) march+field+composite, {t_used:.1f} s"}
 
 
 def train_probe(dev, rank=0, world=1, red_dev=None, steps=20, warmup=5, stage="instance"):

@@ -142,6 +142,20 @@ struct Gathered {
   float fx[4], fy[4], fz[4];
 };
 
+// Cache-policy bits of the gather loads (raw_buffer_load aux: 1 = sc0, 2 = nt, 16 = sc1), separately for the slots
+// that hold levels 0..7 (reused lines) and 8..15 (one 8-byte row used per 128-byte line).  Profiling knobs; see
+// DESIGN.md for the measured matrix.
+#ifndef INR_AUX_COARSE
+#define INR_AUX_COARSE 0
+#endif
+#ifndef INR_AUX_FINE
+#define INR_AUX_FINE 0
+#endif
+template <int kAux>
+__device__ __forceinline__ u32x2 gather_row(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off) {
+  return __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)byte_off, 0, kAux);
+}
+
 __device__ __forceinline__ void issue_gathers(const LevelRec* __restrict__ my_recs, const bool (&all_hashed)[4],
                                               __amdgpu_buffer_rsrc_t rsrc, float x0, float x1, float x2, Gathered& g) {
 #pragma unroll
@@ -161,7 +175,7 @@ __device__ __forceinline__ void issue_gathers(const LevelRec* __restrict__ my_re
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const uint32_t idx = ((cx + (k & 1)) ^ yz[k >> 1]) & mask;
-        g.v[li][k] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(base + idx * 8u), 0, 0);
+        g.v[li][k] = li < 2 ? gather_row<INR_AUX_COARSE>(rsrc, base + idx * 8u) : gather_row<INR_AUX_FINE>(rsrc, base + idx * 8u);
       }
     } else {
       const bool h = my_recs[li].b.y != 0;
@@ -171,7 +185,7 @@ __device__ __forceinline__ void issue_gathers(const LevelRec* __restrict__ my_re
       for (int k = 0; k < 8; ++k) {
         const uint32_t c = cx + (k & 1);
         const uint32_t idx = (h ? (c ^ yz[k >> 1]) : (c + yz[k >> 1])) & mask;
-        g.v[li][k] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(base + idx * 8u), 0, 0);
+        g.v[li][k] = li < 2 ? gather_row<INR_AUX_COARSE>(rsrc, base + idx * 8u) : gather_row<INR_AUX_FINE>(rsrc, base + idx * 8u);
       }
     }
   }

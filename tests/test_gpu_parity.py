@@ -648,6 +648,39 @@ def test_full_frame_properties(params_k16, room, room_bitfield, level_table):
     assert (cnt[pick].cpu().numpy() == ref["rays"][:, 2]).all()
 
 
+def test_full_size_frame_against_the_c_oracle(rm, params_k16, room, room_bitfield, bits_dev, level_table):
+    """BASELINE-size job (800x800 = 640 000 rays) against the scalar C restatement (oracle/c): EVERY ray's sample
+    count and offset bit-exact (the march is cheap on the CPU), every sample position of the first 20 000 rays
+    bit-exact, and a whole 200x200 frame (40 000 rays, all pixels) rendered by both within 1e-4."""
+    from instance_nerf_amd.nerf.utils import get_rays
+    from oracle import c_port
+    poses, intr, H, W = room.cameras()
+    r = get_rays(_t(poses[2:3]), intr, H, W)
+    ro, rd = r["rays_o"][0], r["rays_d"][0]
+    nears, fars = rm.near_far_from_aabb(ro, rd, _t(np.asarray([-1, -1, -1, 1, 1, 1], np.float32)), 0.05)
+    xyzs, dirs, deltas, rays = rm.march_rays_train(ro, rd, 1.0, bits_dev, 1, 128, nears, fars, force_all_rays=True)
+    cn, cf = c_port.near_far_from_aabb(ro.cpu().numpy(), rd.cpu().numpy(), [-1, -1, -1, 1, 1, 1], 0.05)
+    assert (cn == nears.cpu().numpy()).all() and (cf == fars.cpu().numpy()).all()
+    ref = c_port.march_rays_train(ro.cpu().numpy(), rd.cpu().numpy(), room_bitfield, 1.0, 1, 128, cn, cf)
+    assert ref["total"] > 20_000_000
+    assert (rays.cpu().numpy() == ref["rays"]).all()
+    m = int(ref["rays"][20000, 1])
+    assert (xyzs[:m].cpu().numpy() == ref["xyzs"][:m]).all() and (deltas[:m].cpu().numpy() == ref["deltas"][:m]).all()
+    del xyzs, dirs, deltas, ref
+    net = _network(params_k16, K=0).eval()
+    net.density_bitfield.copy_(bits_dev)
+    poses, intr, h, w = room.cameras(H=200, W=200, focal=100.0)
+    r = get_rays(_t(poses[4:5]), intr, h, w, patch=4)
+    with torch.no_grad():
+        out = net.render(r["rays_o"], r["rays_d"], bg_color=1, infer_mode="fused")
+    c = c_port.render(r["rays_o"][0].cpu().numpy(), r["rays_d"][0].cpu().numpy(), params_k16, level_table, room_bitfield,
+                      min_near=0.05)
+    assert int(out["num_samples"][0]) == c["total"] > 1_000_000
+    assert np.abs(out["image"][0].cpu().numpy() - c["image"]).max() < 1e-4
+    assert np.abs(out["weights_sum"][0].cpu().numpy() - c["weights_sum"]).max() < 1e-4
+    assert np.abs(out["depth"][0].cpu().numpy() - c["depth"]).max() < 1e-4
+
+
 def test_rays_missing_the_volume(rm, bits_dev):
     ro = np.asarray([[5, 5, 5], [0, 0, 3], [0, 0, 0]], np.float32)
     rd = np.asarray([[1, 0, 0], [0, 1, 0], [0, 0, 1]], np.float32)

@@ -1,0 +1,114 @@
+"""The C restatement of the hot path (oracle/c/inr_oracle.c) against the numpy/torch oracle and the committed
+golden vectors (CPU).  Two independent restatements of SURVEY.md Appendix A - one vectorised, one scalar - that
+agree bit for bit on the integer / sample-position work and to fp32 rounding on the field.  Parity unpinned: neither
+is the reference (oracle/__init__)."""
+import os
+
+import numpy as np
+import torch
+
+from conftest import scene_rays
+from oracle import c_port, composite, field, hashgrid, march, occupancy, rays as orays, render
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_c_library_builds_and_reports_threads():
+    assert os.path.exists(c_port.build())
+    assert c_port.num_threads() >= 1
+
+
+def test_morton_packbits_near_far_bit_exact(room):
+    rng = np.random.default_rng(0)
+    c = rng.integers(0, 1024, size=(5000, 3)).astype(np.int32)
+    m = c_port.morton3D(c)
+    assert (m == occupancy.morton3D(c)).all() and (c_port.morton3D_invert(m) == c).all()
+    g = rng.normal(size=4096).astype(np.float32)
+    assert (c_port.packbits(g, 0.1) == occupancy.packbits(g, 0.1)).all()
+    ro, rd = scene_rays(room, n=2048, seed=3)
+    ro[:8] = [[0, 0, 0], [0, 0, -3], [0, 5, 0], [.5, .5, .5], [2, 2, 2], [0, 0, 0.99], [-3, 0, 0], [0, 0, 0]]
+    rd[:8] = [[0, 0, 1], [0, 0, 1], [1, 0, 0], [-1, 0, 0], [-.6, -.6, -.52915], [0, 1, 0], [1, 0, 0], [0, 1, 0]]
+    aabb = np.asarray([-1, -1, -1, 1, 1, 1], np.float32)
+    with np.errstate(all="ignore"):
+        n0, f0 = orays.near_far_from_aabb(ro, rd, aabb, 0.05)
+    n1, f1 = c_port.near_far_from_aabb(ro, rd, aabb, 0.05)
+    assert (n0 == n1).all() and (f0 == f1).all()
+
+
+def test_march_golden_and_numpy_oracle_bit_exact(room, room_bitfield):
+    g = np.load(os.path.join(G, "march.npz"))
+    for tag, gam in (("g0", 0.0), ("g1", 1.0 / 128)):
+        m = c_port.march_rays_train(g["rays_o"], g["rays_d"], room_bitfield, 1.0, 1, 128, g["nears"], g["fars"],
+                                    g["noises"], gam, 1024)
+        assert (m["rays"] == g[f"{tag}_rays"]).all()
+        assert (m["xyzs"] == g[f"{tag}_xyzs"]).all() and (m["deltas"] == g[f"{tag}_deltas"]).all()
+    # a larger batch across two cameras, jittered starts, and the overflow rule (rays past M are dropped)
+    ro = np.concatenate([scene_rays(room, 700, cam=c, seed=30 + c)[0] for c in (0, 5)])
+    rd = np.concatenate([scene_rays(room, 700, cam=c, seed=30 + c)[1] for c in (0, 5)])
+    aabb = np.asarray([-1, -1, -1, 1, 1, 1], np.float32)
+    nears, fars = orays.near_far_from_aabb(ro, rd, aabb, 0.05)
+    noises = np.random.default_rng(9).random(1400).astype(np.float32)
+    for M in (None, 30000):
+        a = march.march_rays_train(ro, rd, room_bitfield, 1.0, 1, 128, nears, fars, noises, 0.0, 1024, M=M)
+        b = c_port.march_rays_train(ro, rd, room_bitfield, 1.0, 1, 128, nears, fars, noises, 0.0, 1024, M=M)
+        assert a["total"] == b["total"] > 30000
+        for k in ("rays", "xyzs", "dirs", "deltas"):
+            assert (a[k] == b[k]).all(), k
+
+
+def test_march_two_cascades_growing_step_and_max_steps():
+    rng = np.random.default_rng(12)
+    bits = (rng.random(2 * 64 ** 3 // 8) < 0.3).astype(np.uint8) * rng.integers(1, 256, 2 * 64 ** 3 // 8).astype(np.uint8)
+    ro = rng.uniform(-1.5, 1.5, size=(400, 3)).astype(np.float32)
+    rd = rng.normal(size=(400, 3)).astype(np.float32)
+    rd /= np.linalg.norm(rd, axis=1, keepdims=True)
+    rd[:3] = [[0, 0, 1], [1, 0, 0], [0, -1, 0]]                     # zero components: infinite reciprocals
+    aabb = np.asarray([-2, -2, -2, 2, 2, 2], np.float32)
+    with np.errstate(all="ignore"):
+        nears, fars = orays.near_far_from_aabb(ro, rd, aabb, 0.2)
+        a = march.march_rays_train(ro, rd, bits, 2.0, 2, 64, nears, fars, None, 1 / 128, 8)
+    b = c_port.march_rays_train(ro, rd, bits, 2.0, 2, 64, nears, fars, None, 1 / 128, 8)
+    assert a["total"] == b["total"] > 800 and (a["rays"][:, 2] == 8).any()
+    for k in ("rays", "xyzs", "deltas"):
+        assert (a[k] == b[k]).all(), k
+
+
+def test_field_golden_and_out_of_range(level_table, params_k16):
+    g = np.load(os.path.join(G, "field.npz"))
+    p = params_k16
+    assert np.abs(c_port.grid_encode(g["x"], p["embeddings"], 1.0, level_table) - g["enc"]).max() < 1e-6
+    assert np.abs(c_port.sh_encode(g["d"]) - g["sh"]).max() < 1e-6
+    sigma, rgb, geo = c_port.nerf_forward(g["x"], g["d"], p, 1.0, level_table, want_geo=True)
+    assert np.allclose(sigma, g["sigma"], rtol=2e-5, atol=1e-6)
+    assert np.abs(rgb - g["rgb"]).max() < 2e-6 and np.abs(geo - g["geo"]).max() < 2e-5
+    assert np.abs(c_port.instance_logits(g["x"], p, 1.0, level_table) - g["logits"]).max() < 2e-5
+    x = np.asarray([[0.2, -0.3, 0.9], [1.0, -1.0, 1.0], [1.000001, 0, 0], [0, -1.5, 0], [np.nan, 0, 0], [0.5, 0.5, 0.5]],
+                   np.float32)
+    enc = c_port.grid_encode(x, p["embeddings"], 1.0, level_table)
+    ref = hashgrid.encode(torch.from_numpy(x), p["embeddings"], 1.0, level_table).numpy()
+    assert (enc[[2, 3, 4]] == 0).all() and np.abs(enc - ref).max() < 1e-6
+
+
+def test_composite_golden():
+    g = np.load(os.path.join(G, "composite.npz"))
+    o = c_port.composite_rays_train(g["sigmas"], g["rgbs"], g["deltas"], g["rays"], 1e-4, extra=g["extra"])
+    assert np.abs(o["weights_sum"] - g["weights_sum"]).max() < 1e-6 and np.abs(o["image"] - g["image"]).max() < 1e-6
+    assert np.abs(o["depth"] - g["depth"]).max() < 2e-6 and np.abs(o["extra"] - g["extra_out"]).max() < 1e-5
+    ref = composite.composite_rays_train(g["sigmas"], g["rgbs"], g["deltas"], g["rays"], 1e-4)
+    assert np.abs(o["weights"] - ref["weights"].numpy()).max() < 1e-6
+
+
+def test_whole_path_render_golden_and_numpy_oracle(room, room_bitfield, level_table, params_k16):
+    g = np.load(os.path.join(G, "render.npz"))
+    a = c_port.render(g["rays_o"], g["rays_d"], params_k16, level_table, room_bitfield, min_near=0.05, with_instance=True)
+    assert a["total"] == int(g["train_total"])
+    assert np.abs(a["image"] - g["train_image"]).max() < 1e-5 and np.abs(a["weights_sum"] - g["train_ws"]).max() < 1e-5
+    assert np.abs(a["depth"] - g["train_depth"]).max() < 1e-5 and np.abs(a["instance"] - g["train_instance"]).max() < 1e-4
+    # an opaque variant (termination inside the rays) against the numpy/torch oracle
+    ro, rd = scene_rays(room, 96, cam=3, seed=77)
+    with torch.no_grad():
+        ref = render.render_train(ro, rd, params_k16, level_table, room_bitfield, min_near=0.05, density_scale=300.0)
+    b = c_port.render(ro, rd, params_k16, level_table, room_bitfield, min_near=0.05, density_scale=300.0)
+    assert b["total"] == ref["total"] and (b["counts"] == ref["rays"][:, 2]).all()
+    assert np.abs(b["image"] - ref["image"].numpy()).max() < 2e-5
+    assert np.abs(b["weights_sum"] - ref["weights_sum"].numpy()).max() < 2e-5 and ref["weights_sum"].numpy().max() > 0.99
