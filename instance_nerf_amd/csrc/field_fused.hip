@@ -137,11 +137,6 @@ __device__ __forceinline__ bool slot_all_hashed(const GridDesc& G, int li) {
 
 typedef unsigned int u32x2 __attribute__((__vector_size__(2 * sizeof(unsigned int))));
 
-struct Gathered {
-  u32x2 v[4][8];      // raw table rows (float2 bits), [level][corner]
-  float fx[4], fy[4], fz[4];
-};
-
 // Cache-policy bits of the gather loads (raw_buffer_load aux: 1 = sc0, 2 = nt, 16 = sc1), separately for the slots
 // that hold levels 0..7 (reused lines) and 8..15 (one 8-byte row used per 128-byte line).  Profiling knobs; see
 // DESIGN.md for the measured matrix.
@@ -155,6 +150,161 @@ template <int kAux>
 __device__ __forceinline__ u32x2 gather_row(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off) {
   return __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)byte_off, 0, kAux);
 }
+
+#ifndef INR_XPAIR
+#define INR_XPAIR 1
+#endif
+
+#if INR_XPAIR
+// Lane-paired gather for the FINE slots (levels 8..15).  Measured on MI355X (tools/micro/gather_bench.hip): the vector
+// memory path prices a gather instruction by the number of DISTINCT 128-byte lines its 64 lanes touch - any two lanes
+// of the wave that hit the same line share one look-up (1.6 distinct lines per clock per CU out of the L1, 0.45 out of
+// the L2, 0.10 out of the Infinity Cache) - while the same line touched by two different instructions is looked up
+// twice.  The two x-neighbour corners of a cell sit in one line 15 times out of 16 (x is the fastest index in dense
+// and hashed levels), and on the fine levels neighbouring samples share nothing, so there every corner is its own
+// look-up.  Hence: lanes q and q^1 of a sample (one "pair") together own the four fine levels {8+4p .. 11+4p},
+// p = q>>1; each fetches ITS x side (q&1) of all four - 16 loads per lane as before - so that the x-neighbour rows are
+// requested by two lanes of ONE instruction and share a look-up.  Each lane blends its side's four corners per level;
+// the two halves meet through v_permlane16_swap_b32 (lanes 16 apart exchange registers): 4 swaps + 4 adds per tile,
+// after which lane q holds the complete features of its own two fine levels exactly where the MLP expects them.
+// The coarse slots (levels 0..7) keep the one-lane-per-level scheme: there neighbouring samples already share lines.
+//
+// Instruction diet (the kernel is co-limited by VALU issue: 775 VALU instructions per tile before):
+//  * cell = (uint)pos and fraction = v_fract_f32(pos) instead of floor / subtract / convert: pos >= 0.5, so truncation
+//    IS the floor, and pos - floor(pos) is exact in binary32, so v_fract returns the same bits;
+//  * weights and blending on the packed-fp32 pipe: the two features of a row arrive as a register pair and take the
+//    same weight (v_pk_fma_f32 with a broadcast operand), x-neighbour weights are formed two at a time (v_pk_mul_f32);
+//    every component is the same IEEE operation as before - (wx*wy)*wz, then fma in corner order - so nothing changes
+//    numerically.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+struct Gathered {
+  u32x2 c[2][8];      // coarse slots: raw rows [level][corner]
+  u32x2 f[4][4];      // fine slots: this lane's x side, [level of the pair][yz corner]
+  float cfx[2], cfy[2], cfz[2];
+  float fwx[4], ffy[4], ffz[4];   // fine: weight of this lane's x side, y / z fractions
+};
+
+__device__ __forceinline__ void issue_gathers(const LevelRec* __restrict__ my_recs, const bool (&all_hashed)[4],
+                                              __amdgpu_buffer_rsrc_t rsrc, float x0, float x1, float x2, Gathered& g) {
+  const int q = (threadIdx.x >> 4) & 3;
+  const uint32_t side = (uint32_t)(q & 1);
+  const LevelRec* pair_recs = my_recs - 4 * (q & 1);     // records of the even lane of this pair
+#pragma unroll
+  for (int li = 0; li < 2; ++li) {
+    const uint4 ra = my_recs[li].a;
+    const float s = __uint_as_float(ra.x);
+    const uint32_t base = ra.y, pa = ra.z, pb = ra.w;
+    const uint32_t mask = my_recs[li].b.x;
+    const float px = x0 * s + 0.5f, py = x1 * s + 0.5f, pz = x2 * s + 0.5f;   // mul, add: not fused
+    g.cfx[li] = __builtin_amdgcn_fractf(px); g.cfy[li] = __builtin_amdgcn_fractf(py); g.cfz[li] = __builtin_amdgcn_fractf(pz);
+    const uint32_t cx = (uint32_t)px, cy = (uint32_t)py, cz = (uint32_t)pz;
+    const uint32_t hy0 = cy * pa, hy1 = hy0 + pa;
+    const uint32_t hz0 = cz * pb, hz1 = hz0 + pb;
+    if (all_hashed[li]) {              // wave-uniform: xor-only index maths
+      const uint32_t yz[4] = {hy0 ^ hz0, hy1 ^ hz0, hy0 ^ hz1, hy1 ^ hz1};
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const uint32_t idx = ((cx + (k & 1)) ^ yz[k >> 1]) & mask;
+        g.c[li][k] = gather_row<INR_AUX_COARSE>(rsrc, base + idx * 8u);
+      }
+    } else {
+      const bool h = my_recs[li].b.y != 0;
+      const uint32_t yz[4] = {h ? (hy0 ^ hz0) : (hy0 + hz0), h ? (hy1 ^ hz0) : (hy1 + hz0),
+                              h ? (hy0 ^ hz1) : (hy0 + hz1), h ? (hy1 ^ hz1) : (hy1 + hz1)};
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const uint32_t c = cx + (k & 1);
+        const uint32_t idx = (h ? (c ^ yz[k >> 1]) : (c + yz[k >> 1])) & mask;
+        g.c[li][k] = gather_row<INR_AUX_COARSE>(rsrc, base + idx * 8u);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const LevelRec* rec = pair_recs + (i >> 1) * 4 + 2 + (i & 1);    // level 8 + 4p + i
+    const uint4 ra = rec->a;
+    const float s = __uint_as_float(ra.x);
+    const uint32_t base = ra.y, pa = ra.z, pb = ra.w;
+    const uint32_t mask = rec->b.x;
+    const float px = x0 * s + 0.5f, py = x1 * s + 0.5f, pz = x2 * s + 0.5f;
+    const float fx = __builtin_amdgcn_fractf(px);
+    g.fwx[i] = side ? fx : 1.0f - fx;
+    g.ffy[i] = __builtin_amdgcn_fractf(py); g.ffz[i] = __builtin_amdgcn_fractf(pz);
+    const uint32_t c = (uint32_t)px + side, cy = (uint32_t)py, cz = (uint32_t)pz;
+    const uint32_t hy0 = cy * pa, hy1 = hy0 + pa;
+    const uint32_t hz0 = cz * pb, hz1 = hz0 + pb;
+    if (all_hashed[2 + (i & 1)]) {     // wave-uniform (both pairs' levels of this step are hashed)
+      g.f[i][0] = gather_row<INR_AUX_FINE>(rsrc, base + ((c ^ (hy0 ^ hz0)) & mask) * 8u);
+      g.f[i][1] = gather_row<INR_AUX_FINE>(rsrc, base + ((c ^ (hy1 ^ hz0)) & mask) * 8u);
+      g.f[i][2] = gather_row<INR_AUX_FINE>(rsrc, base + ((c ^ (hy0 ^ hz1)) & mask) * 8u);
+      g.f[i][3] = gather_row<INR_AUX_FINE>(rsrc, base + ((c ^ (hy1 ^ hz1)) & mask) * 8u);
+    } else {
+      const bool h = rec->b.y != 0;
+      const uint32_t yz[4] = {h ? (hy0 ^ hz0) : (hy0 + hz0), h ? (hy1 ^ hz0) : (hy1 + hz0),
+                              h ? (hy0 ^ hz1) : (hy0 + hz1), h ? (hy1 ^ hz1) : (hy1 + hz1)};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t idx = (h ? (c ^ yz[k]) : (c + yz[k])) & mask;
+        g.f[i][k] = gather_row<INR_AUX_FINE>(rsrc, base + idx * 8u);
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ f32x2 row2(const u32x2 v) {
+  const unsigned bx = v[0], by = v[1];     // (scalars first: see the note on __builtin_bit_cast below)
+  return f32x2{__uint_as_float(bx), __uint_as_float(by)};
+}
+
+// trilinear blend: weight = (wx*wy)*wz, accumulated with fma - coarse levels in corner order 0..7, fine levels as
+// (this side's corners in yz order) and then x side 0 + x side 1.
+// out[s], s = 0..7 <-> feature 16*(s>>2) + 4q + (s&3).
+__device__ __forceinline__ void blend(const Gathered& g, f32x4& lo, f32x4& hi) {
+#pragma unroll
+  for (int li = 0; li < 2; ++li) {
+    const f32x2 wx = {1.0f - g.cfx[li], g.cfx[li]};
+    const float wy0 = 1.0f - g.cfy[li], wz0 = 1.0f - g.cfz[li];
+    const f32x2 a = wx * wy0, b = wx * g.cfy[li];                     // (wx*wy) for y side 0 / 1, both x sides
+    const f32x2 w[4] = {a * wz0, b * wz0, a * g.cfz[li], b * g.cfz[li]};   // corners (0,1) (2,3) (4,5) (6,7)
+    f32x2 acc = {0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const f32x2 wk = (k & 1) ? w[k >> 1].yy : w[k >> 1].xx;
+      acc = __builtin_elementwise_fma(wk, row2(g.c[li][k]), acc);
+    }
+    lo[2 * li] = acc.x;
+    lo[2 * li + 1] = acc.y;
+  }
+  f32x2 part[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const f32x2 wy = {1.0f - g.ffy[i], g.ffy[i]};
+    const f32x2 xy = wy * g.fwx[i];                                    // (wx*wy): y side 0 / 1 (product commutes)
+    const f32x2 w0 = xy * (1.0f - g.ffz[i]), w1 = xy * g.ffz[i];       // corners (y0z0, y1z0), (y0z1, y1z1)
+    f32x2 acc = {0.f, 0.f};
+    acc = __builtin_elementwise_fma(w0.xx, row2(g.f[i][0]), acc);
+    acc = __builtin_elementwise_fma(w0.yy, row2(g.f[i][1]), acc);
+    acc = __builtin_elementwise_fma(w1.xx, row2(g.f[i][2]), acc);
+    acc = __builtin_elementwise_fma(w1.yy, row2(g.f[i][3]), acc);
+    part[i] = acc;
+  }
+  // v_permlane16_swap_b32 vdst, src: the odd 16-lane rows of vdst trade places with the even rows of src.  With
+  // vdst = the partial of an even-lane level and src = the partial of an odd-lane level, afterwards BOTH registers of
+  // every lane belong to that lane's own level: one is its own half, the other the partner's.
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int lv = t >> 1, ft = t & 1;
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(part[lv][ft]), __float_as_uint(part[2 + lv][ft]), false, false);
+    const unsigned r0 = r[0], r1 = r[1];
+    hi[t] = __uint_as_float(r0) + __uint_as_float(r1);      // = x side 0 + x side 1 in both lanes
+  }
+}
+#else
+struct Gathered {
+  u32x2 v[4][8];      // raw table rows (float2 bits), [level][corner]
+  float fx[4], fy[4], fz[4];
+};
 
 __device__ __forceinline__ void issue_gathers(const LevelRec* __restrict__ my_recs, const bool (&all_hashed)[4],
                                               __amdgpu_buffer_rsrc_t rsrc, float x0, float x1, float x2, Gathered& g) {
@@ -216,6 +366,8 @@ __device__ __forceinline__ void blend(const Gathered& g, f32x4& lo, f32x4& hi) {
   lo[0] = f[0]; lo[1] = f[1]; lo[2] = f[2]; lo[3] = f[3];
   hi[0] = f[4]; hi[1] = f[5]; hi[2] = f[6]; hi[3] = f[7];
 }
+
+#endif
 
 // (An x-split gather - 8 lanes per sample so that the two x-neighbour corners of a cell are fetched by one
 // instruction and share one L1 look-up - was built and measured: it halves the look-ups but not the time at 16
@@ -425,7 +577,7 @@ __device__ __forceinline__ TileSched make_sched(int64_t n_tiles, int waves_per_b
 #define INR_FIELD_THREADS 512
 #endif
 #ifndef INR_FIELD_MIN_WAVES
-#define INR_FIELD_MIN_WAVES 4
+#define INR_FIELD_MIN_WAVES 2
 #endif
 constexpr int kFieldThreads = INR_FIELD_THREADS;   // waves of a workgroup share one 40 KB weight image in LDS
 

@@ -650,8 +650,9 @@ def test_full_frame_properties(params_k16, room, room_bitfield, level_table):
 
 def test_full_size_frame_against_the_c_oracle(rm, params_k16, room, room_bitfield, bits_dev, level_table):
     """BASELINE-size job (800x800 = 640 000 rays) against the scalar C restatement (oracle/c): EVERY ray's sample
-    count and offset bit-exact (the march is cheap on the CPU), every sample position of the first 20 000 rays
-    bit-exact, and a whole 200x200 frame (40 000 rays, all pixels) rendered by both within 1e-4."""
+    count and offset bit-exact, every sample position of the first 20 000 rays bit-exact, and the WHOLE rendered
+    frame - all 640 000 pixels, ~26 M samples, table U(-1,1) so outputs are O(1) - within 1e-4 (the C oracle does it
+    in ~10 s on the box's 16 usable cores)."""
     from instance_nerf_amd.nerf.utils import get_rays
     from oracle import c_port
     poses, intr, H, W = room.cameras()
@@ -669,13 +670,12 @@ def test_full_size_frame_against_the_c_oracle(rm, params_k16, room, room_bitfiel
     del xyzs, dirs, deltas, ref
     net = _network(params_k16, K=0).eval()
     net.density_bitfield.copy_(bits_dev)
-    poses, intr, h, w = room.cameras(H=200, W=200, focal=100.0)
-    r = get_rays(_t(poses[4:5]), intr, h, w, patch=4)
+    r = get_rays(_t(poses[2:3]), intr, H, W, patch=4)
     with torch.no_grad():
         out = net.render(r["rays_o"], r["rays_d"], bg_color=1, infer_mode="fused")
     c = c_port.render(r["rays_o"][0].cpu().numpy(), r["rays_d"][0].cpu().numpy(), params_k16, level_table, room_bitfield,
                       min_near=0.05)
-    assert int(out["num_samples"][0]) == c["total"] > 1_000_000
+    assert int(out["num_samples"][0]) == c["total"] > 20_000_000
     assert np.abs(out["image"][0].cpu().numpy() - c["image"]).max() < 1e-4
     assert np.abs(out["weights_sum"][0].cpu().numpy() - c["weights_sum"]).max() < 1e-4
     assert np.abs(out["depth"][0].cpu().numpy() - c["depth"]).max() < 1e-4

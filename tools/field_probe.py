@@ -15,6 +15,12 @@ from instance_nerf_amd.nerf.utils import get_rays  # noqa: E402
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 dev = torch.device("cuda", 0)
 net, room = build_network(dev)
+if os.environ.get("PROBE_LOG2_T"):        # smaller hash tables: where does the time go when every level fits the L2?
+    from instance_nerf_amd.encoding import get_encoder
+    net.encoder, _ = get_encoder("hashgrid", desired_resolution=2048, log2_hashmap_size=int(os.environ["PROBE_LOG2_T"]))
+    net.encoder.to(dev)
+    net._packed = {}
+    print("table rows", net.encoder.table["total_rows"], "MB", net.encoder.table["total_rows"] * 8 / 1e6)
 poses, intr, H, W = room.cameras()
 PATCH = int(os.environ.get("PROBE_PATCH", "4"))
 r = get_rays(torch.from_numpy(poses[:1]).to(dev), intr, H, W, patch=PATCH)
