@@ -95,9 +95,23 @@ def train_probe(dev, rank=0, world=1, red_dev=None, steps=20, warmup=5, stage="i
                       num_instances=64 if stage == "instance" else 0).to(dev)
     ds = SyntheticRoomDataset(dev, num_rays=4096, num_instances=64, rank=rank)
     net.density_bitfield.copy_(torch.from_numpy(ds.room.density_bitfield(128, 1.0)).to(dev))
-    tr = Trainer("bench", None, net, stage=stage, device=dev, iters=1000, update_extra_interval=10 ** 9,
+    tr = Trainer("bench", None, net, stage=stage, device=dev, iters=1000, update_extra_interval=16,
                  local_rank=rank, world_size=world)
-    tr.global_step = 1                     # keep the analytic occupancy grid
+    # Upstream's loop, occupancy update included: every 16 steps update_extra_state() queries the density of 128^3
+    # (later 128^3 / 2) cells, refreshes the grid / bitfield and sets mean_count, which sizes the sample buffers of
+    # the next 16 steps (no host sync inside a step).  The field is untrained here, so the grid it produces says
+    # nothing about the scene: the update runs - and is timed - in full, then the analytic bitfield of the synthetic
+    # room is put back (a 256 KB device copy).
+    analytic = net.density_bitfield.clone()
+    real_update = net.update_extra_state
+    n_updates = [0]
+
+    def update_and_restore(*a, **kw):
+        real_update(*a, **kw)
+        net.density_bitfield.copy_(analytic)
+        n_updates[0] += 1
+    net.update_extra_state = update_and_restore
+    tr.global_step = 1                     # the first update comes after 15 steps, like every later one
     batches = [ds.batch() for _ in range(4)]
 
     def barrier():
@@ -106,20 +120,17 @@ def train_probe(dev, rank=0, world=1, red_dev=None, steps=20, warmup=5, stage="i
         torch.cuda.synchronize()
 
     first = last = 0.0
-    totals = []
-    for i in range(warmup):
+    for i in range(max(warmup, 4) + 16):   # >= one occupancy update: mean_count is set, the steady state begins
         l = float(tr.train_one_step(batches[i % 4]))
-        totals.append(int(net.step_counter[(net.local_step - 1) % 16, 0]))
         first = l if i == 0 else first
-    # Steady state of upstream's loop: after the first 16 steps update_extra_state() sets mean_count (the mean
-    # sample total of the last steps), sample buffers get that fixed size, rays that overflow it are dropped and
-    # the step has no host sync.  The probe keeps the analytic occupancy grid, so it sets mean_count itself.
-    net.mean_count = int(sum(totals) / len(totals))
+    while tr.global_step % 16 != 1:        # start the timed region right after an update: K timed steps then
+        tr.train_one_step(batches[0])      # contain floor(K / 16) updates (1 for the default K = 20)
+    assert net.mean_count > 0
     marched = torch.zeros((), dtype=torch.int64, device=dev)
-    for i in range(4):                     # also loads the code objects of the counting ops below, untimed
-        tr.train_one_step(batches[i])
+    for i in range(2):                     # loads the code objects of the counting ops below, untimed
         marched += torch.clamp(net.step_counter[(net.local_step - 1) % 16, 0], max=net.mean_count)
     marched.zero_()
+    n_updates[0] = 0
     import gc
     gc.collect()                           # the render network of the headline measurement dies here, not mid-loop
     gc.disable()
@@ -148,6 +159,7 @@ def train_probe(dev, rank=0, world=1, red_dev=None, steps=20, warmup=5, stage="i
             "n_gpus": world, "ms_per_step": round(dt * 1e3, 3), "samples_per_step": int(n_all) // steps,
             "msamples_per_s": round(n_all / steps / dt / 1e6, 2),
             "allreduce_mb_per_step": round(reduced / 1e6, 1) if world > 1 else 0.0,
+            "occupancy_updates_in_timed_steps": n_updates[0],
             "loss_first": round(first, 4), "loss_last": round(float(last), 4)}
 
 

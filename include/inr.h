@@ -78,6 +78,22 @@ int inr_morton3D_invert(const int32_t* indices, int64_t N, int32_t* coords /*[N,
 /* bitfield[k] bit i = grid[8k+i] > thresh; n_bytes = cells / 8 */
 int inr_packbits(const float* grid, int64_t n_bytes, float thresh, uint8_t* bitfield, inr_stream_t s);
 
+/* ---- occupancy-grid update (replaces the tensor-op body of NeRFRenderer.update_extra_state, a3) -------------------
+ * One cascade at a time; the grid is in Morton order.  inr_occ_cell_positions: query position of cell morton_idx[i]
+ * (NULL = cell i) - centre (2c/(H-1) - 1) * (b - b/H) plus (2 noise - 1) * b/H, noise [n,3] in [0,1) or NULL.
+ * inr_occ_update: grid = max(grid * decay, sigma * density_scale) where both >= 0 (cells at -1 stay out), for all
+ * cells (morton_idx NULL, m == n_cells, sigma in Morton order) or the listed ones (tmp = scratch [n_cells]);
+ * *mean_sum (double, caller zeroes it once per update) accumulates sum(max(grid, 0)).
+ * inr_packbits_mean: packbits with thresh = min(*mean_sum / n_cells, density_thresh) formed on the device (no host
+ * round trip between the update and the bitfield); mean_out (nullable) receives the mean.                       */
+int inr_occ_cell_positions(const int32_t* morton_idx, const float* noise, int64_t n, int32_t H, float cascade_bound,
+                           float* xyz /*[n,3]*/, inr_stream_t s);
+int inr_occ_update(float* grid /*[n_cells]*/, const float* sigma /*[m]*/, const int32_t* morton_idx /*[m] or NULL*/,
+                   int64_t n_cells, int64_t m, float decay, float density_scale, float* tmp, double* mean_sum,
+                   inr_stream_t s);
+int inr_packbits_mean(const float* grid, int64_t n_cells /*all cascades*/, const double* mean_sum, float density_thresh,
+                      uint8_t* bitfield, float* mean_out, inr_stream_t s);
+
 /* ---- training march (replaces raymarching.march_rays_train, a4) ----------------------
  * Deterministic: sample slots are an exclusive scan of the per-ray counts in ray
  * order.  Call inr_march_rays_train_count first (fills counts/offsets and

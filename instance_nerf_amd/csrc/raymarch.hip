@@ -97,6 +97,66 @@ __global__ void k_packbits(const float* __restrict__ grid, int64_t n_bytes, floa
   bits[n] = (uint8_t)v;
 }
 
+// ---- occupancy-grid update (upstream NeRFRenderer.update_extra_state) ---------------------------------
+// Query position of cell `m` (a Morton index; nullable list = identity) of one cascade: the cell centre
+// x = 2c/(H-1) - 1 scaled to the cascade's half extent minus half a cell, plus a jitter of +-half a cell.  Operation
+// order is oracle/occupancy.py::cell_centers (this file is built with -ffp-contract=off).
+__global__ void k_occ_positions(const int32_t* __restrict__ morton, const float* __restrict__ noise, int64_t n, float Hm1,
+                                float ext, float half, float* __restrict__ xyz) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t m = morton ? (uint32_t)morton[i] : (uint32_t)i;
+  const uint32_t c[3] = {compact_bits10(m), compact_bits10(m >> 1), compact_bits10(m >> 2)};
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    float v = (2.0f * (float)c[a] / Hm1 - 1.0f) * ext;
+    if (noise) v = v + (noise[i * 3 + a] * 2.0f - 1.0f) * half;
+    xyz[i * 3 + a] = v;
+  }
+}
+// tmp[morton[i]] = sigma[i] * density_scale (cells visited twice keep one of the values, as upstream's index_put)
+__global__ void k_occ_scatter(const float* __restrict__ sigma, const int32_t* __restrict__ morton, int64_t m,
+                              float density_scale, float* __restrict__ tmp) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < m) tmp[morton[i]] = sigma[i] * density_scale;
+}
+// grid = max(grid * decay, tmp) where both are >= 0 (cells marked -1 stay out; tmp -1 = not visited);
+// mean_sum += sum(max(grid, 0)) in double (one atomic per workgroup).  `scale` multiplies tmp (1 after k_occ_scatter).
+__global__ void __launch_bounds__(256) k_occ_update(float* __restrict__ grid, const float* __restrict__ tmp, int64_t n,
+                                                    float decay, float scale, double* __restrict__ mean_sum) {
+  __shared__ double red[4];
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float g = grid[i];
+    const float t = tmp[i] * scale;
+    if (g >= 0.0f && t >= 0.0f) {
+      g = fmaxf(g * decay, t);
+      grid[i] = g;
+    }
+    acc += (double)fmaxf(g, 0.0f);
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(mean_sum, red[0] + red[1] + red[2] + red[3]);
+}
+// packbits with the threshold formed on the device: thresh = min(mean, density_thresh), mean = mean_sum / n_cells
+__global__ void k_packbits_mean(const float* __restrict__ grid, int64_t n_bytes, const double* __restrict__ mean_sum,
+                                double inv_cells, float density_thresh, uint8_t* __restrict__ bits,
+                                float* __restrict__ mean_out) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const float mean = (float)(*mean_sum * inv_cells);
+  if (n == 0 && mean_out) *mean_out = mean;
+  if (n >= n_bytes) return;
+  const float thresh = fminf(mean, density_thresh);
+  const float4 a = reinterpret_cast<const float4*>(grid)[n * 2];
+  const float4 b = reinterpret_cast<const float4*>(grid)[n * 2 + 1];
+  uint32_t v = (a.x > thresh) | ((a.y > thresh) << 1) | ((a.z > thresh) << 2) | ((a.w > thresh) << 3) |
+               ((b.x > thresh) << 4) | ((b.y > thresh) << 5) | ((b.z > thresh) << 6) | ((b.w > thresh) << 7);
+  bits[n] = (uint8_t)v;
+}
+
 // ------------------------------------------------------------------------------------------
 // The marcher.  Operation order is the contract written at the top of oracle/march.py.
 struct MarchParams {
@@ -1107,6 +1167,47 @@ int inr_packbits(const float* grid, int64_t n_bytes, float thresh, uint8_t* bitf
   INR_REQUIRE(((uintptr_t)grid & 15) == 0, "grid must be 16-byte aligned");
   k_packbits<<<blocks_for(n_bytes, 256), 256, 0, as_stream(s)>>>(grid, n_bytes, thresh, bitfield);
   return check_launch("packbits");
+}
+
+int inr_occ_cell_positions(const int32_t* morton_idx, const float* noise, int64_t n, int32_t H, float cascade_bound,
+                           float* xyz, inr_stream_t s) {
+  INR_REQUIRE(n >= 0 && H >= 2 && H <= 1024, "bad argument");
+  if (n == 0) return INR_OK;
+  INR_REQUIRE(xyz, "null pointer");
+  const float half = cascade_bound / (float)H;
+  k_occ_positions<<<blocks_for(n, 256), 256, 0, as_stream(s)>>>(morton_idx, noise, n, (float)(H - 1), cascade_bound - half,
+                                                                half, xyz);
+  return check_launch("occ_cell_positions");
+}
+
+int inr_occ_update(float* grid, const float* sigma, const int32_t* morton_idx, int64_t n_cells, int64_t m, float decay,
+                   float density_scale, float* tmp, double* mean_sum, inr_stream_t s) {
+  INR_REQUIRE(n_cells > 0 && m >= 0 && grid && mean_sum, "bad argument");
+  INR_REQUIRE(m == 0 || sigma, "null sigma");
+  hipStream_t st = as_stream(s);
+  const unsigned nb = (unsigned)std::min<int64_t>((n_cells + 255) / 256, (int64_t)cu_count() * 8);
+  if (morton_idx) {
+    INR_REQUIRE(tmp, "a listed update needs the scratch grid");
+    if (hipMemsetAsync(tmp, 0xBF, (size_t)n_cells * sizeof(float), st) != hipSuccess) {   // 0xBFBFBFBF = -1.498: not visited
+      set_error("occ_update: memset failed");
+      return INR_ELAUNCH;
+    }
+    if (m) k_occ_scatter<<<blocks_for(m, 256), 256, 0, st>>>(sigma, morton_idx, m, density_scale, tmp);
+    k_occ_update<<<nb, 256, 0, st>>>(grid, tmp, n_cells, decay, 1.0f, mean_sum);
+  } else {
+    INR_REQUIRE(m == n_cells, "a full sweep needs one sigma per cell (Morton order)");
+    k_occ_update<<<nb, 256, 0, st>>>(grid, sigma, n_cells, decay, density_scale, mean_sum);
+  }
+  return check_launch("occ_update");
+}
+
+int inr_packbits_mean(const float* grid, int64_t n_cells, const double* mean_sum, float density_thresh, uint8_t* bitfield,
+                      float* mean_out, inr_stream_t s) {
+  INR_REQUIRE(n_cells > 0 && n_cells % 8 == 0 && grid && mean_sum && bitfield, "bad argument");
+  INR_REQUIRE(((uintptr_t)grid & 15) == 0, "grid must be 16-byte aligned");
+  k_packbits_mean<<<blocks_for(n_cells / 8, 256), 256, 0, as_stream(s)>>>(grid, n_cells / 8, mean_sum, 1.0 / (double)n_cells,
+                                                                           density_thresh, bitfield, mean_out);
+  return check_launch("packbits_mean");
 }
 
 // Small batches (training) take the wave-per-ray marcher; both marchers produce the same bits.

@@ -303,54 +303,67 @@ class NeRFRenderer(nn.Module):
 
     @torch.no_grad()
     def update_extra_state(self, decay=0.95, S=128):
-        """EMA-max occupancy update + bitfield rebuild (SURVEY a3, Appendix A.1 "Occupancy update")."""
+        """EMA-max occupancy update + bitfield rebuild (SURVEY a3, Appendix A.1 "Occupancy update"; upstream
+        ``NeRFRenderer.update_extra_state``).  First 16 calls: every cell of every cascade; afterwards H^3/4 uniformly
+        random cells plus H^3/4 random occupied cells per cascade.  All on the device: query positions
+        (inr_occ_cell_positions, Morton order), sigma through the fused field kernel, EMA-max + mean
+        (inr_occ_update) and the bitfield with its threshold min(mean, density_thresh) formed on the device
+        (inr_packbits_mean); ONE host read-back per call (mean density and the sample counters that size the next
+        16 steps' buffers together).  ``S`` is accepted for upstream's signature; nothing is chunked here."""
         if not self.cuda_ray:
             return
+        lib = _lib.load()
         dev = self.density_bitfield.device
-        H = self.grid_size
-        tmp_grid = -torch.ones_like(self.density_grid)
-        if self.iter_density < 16:
-            r = torch.arange(H, dtype=torch.int32, device=dev)
-            for xs in r.split(S):
-                for ys in r.split(S):
-                    for zs in r.split(S):
-                        xx, yy, zz = torch.meshgrid(xs, ys, zs, indexing="ij")
-                        coords = torch.stack([xx.reshape(-1), yy.reshape(-1), zz.reshape(-1)], -1)
-                        self._query_cells(coords, tmp_grid)
-        else:
-            n = H ** 3 // 4
-            for cas in range(self.cascade):
+        H, C = self.grid_size, self.cascade
+        n_cells = H ** 3
+        st = stream_ptr()
+        mean_sum = torch.zeros(1, dtype=torch.float64, device=dev)
+        grid = self.density_grid
+        full = self.iter_density < 16
+        for cas in range(C):
+            bnd = float(min(2 ** cas, self.bound))
+            if full:
+                idx, m = None, n_cells
+            else:
+                n = n_cells // 4
                 coords = torch.randint(0, H, (n, 3), device=dev, dtype=torch.int32)
-                occ = torch.nonzero(self.density_grid[cas] > 0).squeeze(-1)
-                if occ.numel() > 0:
-                    pick = occ[torch.randint(0, occ.shape[0], (n,), device=dev)]
-                    occ_coords = raymarching.morton3D_invert(pick.int())
-                    coords = torch.cat([coords, occ_coords], 0)
-                self._query_cells(coords, tmp_grid, only_cascade=cas)
-        valid = (self.density_grid >= 0) & (tmp_grid >= 0)
-        self.density_grid[valid] = torch.maximum(self.density_grid[valid] * decay, tmp_grid[valid])
-        self.mean_density = torch.mean(self.density_grid.clamp(min=0)).item()
+                idx = raymarching.morton3D(coords)
+                # random occupied cells without a host round trip (upstream: torch.nonzero -> sync): stable
+                # compaction through a prefix sum into occ_list[0 .. n_occ), picks = floor(rand * n_occ) with n_occ
+                # read on the device.  No occupied cell at all: the picks fall on cell 0 (one more visit of a cell
+                # that may be visited anyway; upstream skips the occupied half in that case).
+                occ = grid[cas] > 0
+                pos = torch.cumsum(occ, 0)
+                n_occ = pos[-1:]
+                occ_list = torch.zeros(n_cells + 1, dtype=torch.int32, device=dev)
+                cells = torch.arange(n_cells, dtype=torch.int32, device=dev)
+                occ_list.scatter_(0, torch.where(occ, pos - 1, n_cells), cells)
+                pick = torch.minimum((torch.rand(n, device=dev) * n_occ).long(), (n_occ - 1).clamp(min=0))
+                idx = torch.cat([idx, occ_list[pick]]).contiguous()
+                m = idx.shape[0]
+            xyz = torch.empty(m, 3, dtype=torch.float32, device=dev)
+            noise = torch.rand_like(xyz)
+            check(lib.inr_occ_cell_positions(ptr(idx, torch.int32, "morton_idx", allow_none=True),
+                                             ptr(noise, torch.float32, "noise"), m, H, bnd, ptr(xyz), st),
+                  "occ_cell_positions")
+            sigma = self.density_sigma(xyz).reshape(-1).detach().float().contiguous()
+            tmp = None if full else torch.empty(n_cells, dtype=torch.float32, device=dev)
+            check(lib.inr_occ_update(ptr(grid[cas], torch.float32, "density_grid"), ptr(sigma, torch.float32, "sigma"),
+                                     ptr(idx, torch.int32, "morton_idx", allow_none=True), n_cells, m, float(decay),
+                                     float(self.density_scale), ptr(tmp, allow_none=True), ptr(mean_sum), st),
+                  "occ_update")
+        mean_out = torch.empty(1, dtype=torch.float32, device=dev)
+        check(lib.inr_packbits_mean(ptr(grid, torch.float32, "density_grid"), C * n_cells, ptr(mean_sum),
+                                    float(self.density_thresh), ptr(self.density_bitfield, torch.uint8, "density_bitfield"),
+                                    ptr(mean_out), st), "packbits_mean")
         self.iter_density += 1
-        density_thresh = min(self.mean_density, self.density_thresh)
-        raymarching.packbits(self.density_grid, density_thresh, self.density_bitfield)
         total_step = min(16, self.local_step)
+        # one read-back: [mean density, sum of the sample totals of the last steps]
+        host = torch.cat([mean_out.double(), self.step_counter[:max(total_step, 1), 0].sum().double().view(1)]).cpu()
+        self.mean_density = float(host[0])
         if total_step > 0:
-            self.mean_count = int(self.step_counter[:total_step, 0].sum().item() / total_step)
+            self.mean_count = int(float(host[1]) / total_step)
         self.local_step = 0
-
-    def _query_cells(self, coords, tmp_grid, only_cascade=None):
-        H = self.grid_size
-        indices = raymarching.morton3D(coords).long()
-        xyzs = 2 * coords.float() / (H - 1) - 1
-        for cas in range(self.cascade):
-            if only_cascade is not None and cas != only_cascade:
-                continue
-            bnd = min(2 ** cas, self.bound)
-            half = bnd / H
-            cas_xyzs = xyzs * (bnd - half)
-            cas_xyzs = cas_xyzs + (torch.rand_like(cas_xyzs) * 2 - 1) * half
-            sigmas = self.density_sigma(cas_xyzs).reshape(-1).detach() * self.density_scale
-            tmp_grid[cas, indices] = sigmas
 
     # ----------------------------------------------------------------------------------------
     def render(self, rays_o, rays_d, staged=False, max_ray_batch=4096, **kwargs):

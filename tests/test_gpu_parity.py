@@ -450,6 +450,49 @@ def test_occupancy_update_matches_oracle(params_k16, level_table):
     assert not (diff & ~near).any()
 
 
+def test_occupancy_update_steady_state_sweep(params_k16, level_table):
+    """After the first 16 updates only H^3/4 random cells + H^3/4 random OCCUPIED cells are refreshed per call
+    (device-side compaction of the occupied set, no host round trip).  Every cell either keeps its value or becomes
+    max(old * decay, sigma(cell centre)); cells marked -1 stay out; most occupied cells are among the refreshed;
+    the bitfield is packbits(grid, min(mean, density_thresh)) of the resulting grid, threshold formed on the device."""
+    from oracle import occupancy
+    net = _network(params_k16, K=0).eval()
+    H = net.grid_size
+    gen = torch.Generator().manual_seed(3)
+    old = torch.rand(1, H ** 3, generator=gen) * 40.0 * (torch.rand(1, H ** 3, generator=gen) < 0.05)
+    old[0, ::97] = -1.0                                                      # unseen cells
+    net.density_grid.copy_(old.to(DEV))
+    net.iter_density = 16
+    net.density_thresh = 5.0
+    orig = torch.rand_like
+    try:
+        torch.rand_like = lambda t: torch.full_like(t, 0.5)                  # no jitter: sigma at the cell centres
+        net.update_extra_state(decay=0.9)
+    finally:
+        torch.rand_like = orig
+    new = net.density_grid.cpu()
+    assert net.iter_density == 17
+    cells = torch.arange(H ** 3, dtype=torch.int32, device=DEV)
+    from instance_nerf_amd import raymarching
+    coords = raymarching.morton3D_invert(cells).float()
+    centres = (2 * coords / (H - 1) - 1) * (1.0 - 1.0 / H)
+    with torch.no_grad():
+        sig = net.density(centres)["sigma"].cpu()
+    cand = torch.maximum(old[0] * 0.9, sig)
+    changed = new[0] != old[0]
+    assert (new[0][old[0] < 0] == -1).all()
+    rel = ((new[0] - cand).abs() / cand.abs().clamp(min=1e-6))[changed]
+    assert rel.max() < 1e-4, (rel.max(), (rel > 1e-5).sum(), changed.sum())
+    frac_changed = changed.float().mean().item()
+    assert 0.2 < frac_changed < 0.5                                          # <= H^3/2 distinct cells refreshed
+    occupied = old[0] > 0
+    assert changed[occupied].float().mean() > 0.9                            # the occupied half really targets occupied cells
+    mean = new.clamp(min=0).double().mean().item()
+    assert abs(net.mean_density - mean) < 1e-5 * mean
+    thr = min(np.float32(net.mean_density), np.float32(5.0))
+    assert (net.density_bitfield.cpu().numpy() == occupancy.packbits(new.numpy().ravel(), thr)).all()
+
+
 # ---------------------------------------------------------------------------- patch-interleaved layout
 def test_patch_layout_is_a_permutation_of_ray_major(rm, room, room_bitfield, bits_dev):
     """The fused-frame writer places sample (ray, k) at slot base + sum_i min(c_i,k) + #{i<r: c_i>k}:
