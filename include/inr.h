@@ -190,6 +190,12 @@ int inr_grid_encode_backward(const float* x, const float* grad_out /*[M,L*F]*/,
 int inr_grid_encode_backward_ordered(const float* x, const float* grad_out, const int32_t* order,
                                      const inr_grid_desc* desc /*host*/, int64_t M, float bound,
                                      float* grad_embeddings /*[T,F]*/, inr_stream_t s);
+/* The same scatter restricted to levels [level_lo, level_hi): a caller that all-reduces the table gradient over
+ * several GPUs launches it in two or three level ranges and starts the collective on each row range
+ * [offsets[level_lo], offsets[level_hi]) as soon as its launch is queued (nerf/network.py::_table_backward).      */
+int inr_grid_encode_backward_levels(const float* x, const float* grad_out, const int32_t* order,
+                                    const inr_grid_desc* desc, int64_t M, float bound, float* grad_embeddings,
+                                    int32_t level_lo, int32_t level_hi, inr_stream_t s);
 
 /* ---- SH (replaces shencoder sh_encode_forward / _backward, a10) ------------------------ */
 int inr_sh_encode_forward(const float* d /*[M,3]*/, int64_t M, int32_t degree, float* out, inr_stream_t s);

@@ -429,7 +429,14 @@ int inr_grid_encode_backward(const float* x, const float* grad_out, const inr_gr
 int inr_grid_encode_backward_ordered(const float* x, const float* grad_out, const int32_t* order,
                                      const inr_grid_desc* desc, int64_t M, float bound, float* grad_embeddings,
                                      inr_stream_t s) {
+  return inr_grid_encode_backward_levels(x, grad_out, order, desc, M, bound, grad_embeddings, 0, desc ? desc->num_levels : 0, s);
+}
+
+int inr_grid_encode_backward_levels(const float* x, const float* grad_out, const int32_t* order,
+                                    const inr_grid_desc* desc, int64_t M, float bound, float* grad_embeddings,
+                                    int32_t level_lo, int32_t level_hi, inr_stream_t s) {
   INR_REQUIRE(M >= 0 && desc, "bad argument");
+  INR_REQUIRE(level_lo >= 0 && level_lo < level_hi && level_hi <= desc->num_levels, "bad level range");
   if (M == 0) return INR_OK;
   INR_REQUIRE(x && grad_out && grad_embeddings, "null pointer");
   GridDesc G;
@@ -438,9 +445,9 @@ int inr_grid_encode_backward_ordered(const float* x, const float* grad_out, cons
   INR_REQUIRE(((uintptr_t)grad_out & 7) == 0, "grad_out must be 8-byte aligned");
   if (M == 0) return INR_OK;
   INR_REQUIRE((uint64_t)desc->offsets[desc->num_levels] * 2ull < (1ull << 32), "table too large for 32-bit element offsets");
-  int l0 = 0, l1 = G.num_levels;
+  int l0 = level_lo, l1 = level_hi;
   if (const char* e = getenv("INR_GRID_BWD_LEVELS")) {      // profiling knob "lo:hi": only levels lo..hi-1
-    if (sscanf(e, "%d:%d", &l0, &l1) != 2 || l0 < 0 || l1 > G.num_levels || l0 >= l1) { l0 = 0; l1 = G.num_levels; }
+    if (sscanf(e, "%d:%d", &l0, &l1) != 2 || l0 < 0 || l1 > G.num_levels || l0 >= l1) { l0 = level_lo; l1 = level_hi; }
   }
   const dim3 grid(blocks_for(M * 4, 256), (unsigned)(l1 - l0));
   k_grid_bwd<<<grid, 256, 0, as_stream(s)>>>(x, grad_out, order, G, M, bound, grad_embeddings, l0);

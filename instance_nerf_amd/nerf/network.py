@@ -56,6 +56,30 @@ class _LinearFn(torch.autograd.Function):
         return gx, gw
 
 
+def _table_backward(lib, x, denc, desc, M, bound, g_emb, emb):
+    """Table-gradient scatter; returns the gradient to hand back to autograd (None when it was installed directly).
+
+    One process: one launch over all levels.  Several ranks: two level ranges, fine levels first, each handed to the
+    gradient all-reduce as soon as its launch is queued (nerf/utils.py::grad_sync), so the collective of the first
+    range runs under the scatter of the second and under the weight-gradient kernels.  In that case the buffer
+    becomes ``emb.grad`` right here and autograd gets None: autograd would otherwise COPY the returned tensor into
+    ``.grad`` (it adopts it only while no one else references it - the in-flight collective does) at a moment when
+    the buffer is half reduced (tests/test_gpu_ddp.py caught exactly that: one run in three diverged)."""
+    from .utils import grad_sync
+    L = int(desc.num_levels)
+    overlap = grad_sync.active() and L > 8 and emb.grad is None
+    for lo, hi in (((8, L), (0, 8)) if overlap else ((0, L),)):
+        check(lib.inr_grid_encode_backward_levels(ptr(x), ptr(denc), None, desc, M, float(bound), ptr(g_emb), lo, hi,
+                                                  stream_ptr()), "grid_encode_backward")
+        if overlap:
+            grad_sync.reduce_async(g_emb[int(desc.offsets[lo]):int(desc.offsets[hi])])
+    if overlap:
+        emb.grad = g_emb
+        grad_sync.mark(emb, g_emb)
+        return None
+    return g_emb
+
+
 class _InstanceFieldFn(torch.autograd.Function):
     """Instance field x -> logits for TRAINING in two fused launches (csrc/field_fused.hip): the forward gathers,
     runs the three layers on the matrix cores and keeps enc / h1 / h2 for the backward; the backward runs the
@@ -102,12 +126,11 @@ class _InstanceFieldFn(torch.autograd.Function):
         if M:
             check(lib.inr_instance_backward(ptr(g, f32, "grad_logits"), K, ptr(h1), ptr(h2), M, ptr(pb), ptr(dz2),
                                             ptr(dz1), ptr(denc), stream_ptr()), "instance_backward")
+            g_emb = _table_backward(lib, x, denc, ctx.desc, M, ctx.bound, g_emb, emb)      # first: its all-reduce can start
             ws = torch.empty(lib.inr_linear_wgrad_workspace_bytes() // 4, dtype=f32, device=dev)   # reused in stream order
             for xin, gy, n_in, n_out, out in ((h2, g, 64, K, gw2), (h1, dz2, 64, 64, gw1), (enc, dz1, 32, 64, gw0)):
                 check(lib.inr_linear_wgrad(ptr(xin), ptr(gy), M, n_in, n_out, ptr(out), ptr(ws), stream_ptr()),
                       "linear_wgrad")
-            check(lib.inr_grid_encode_backward_ordered(ptr(x), ptr(denc), None, ctx.desc, M, float(ctx.bound),
-                                                       ptr(g_emb), stream_ptr()), "grid_encode_backward")
         return None, g_emb, gw0, gw1, gw2, None, None
 
 
@@ -170,13 +193,12 @@ class _NerfFieldFn(torch.autograd.Function):
             check(lib.inr_nerf_backward(ptr(g_sigma), ptr(g_rgb), ptr(rgb), ptr(so), ptr(h1), ptr(c1), ptr(c2), M, 1.0,
                                         ptr(pb), ptr(d_o), ptr(dz_c2), ptr(dz_c1), ptr(d_so), ptr(dz_h1), ptr(d_enc),
                                         stream_ptr()), "nerf_backward")
+            g_emb = _table_backward(lib, x, d_enc, ctx.desc, M, ctx.bound, g_emb, emb)
             wsp = torch.empty(lib.inr_linear_wgrad_workspace_bytes() // 4, dtype=f32, device=dev)
             for xin, gy, n_in, n_out, out in ((c2, d_o, 64, 4, gwc2), (c1, dz_c2, 64, 64, gwc1), (cin, dz_c1, 32, 64, gwc0),
                                               (h1, d_so, 64, 16, gws1), (enc, dz_h1, 32, 64, gws0)):
                 check(lib.inr_linear_wgrad(ptr(xin), ptr(gy), M, n_in, n_out, ptr(out), ptr(wsp), stream_ptr()),
                       "linear_wgrad")
-            check(lib.inr_grid_encode_backward_ordered(ptr(x), ptr(d_enc), None, ctx.desc, M, float(ctx.bound),
-                                                       ptr(g_emb), stream_ptr()), "grid_encode_backward")
         return None, None, g_emb, gws0, gws1, gwc0[:, :31], gwc1, gwc2[:3], None, None
 
 

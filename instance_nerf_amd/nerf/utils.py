@@ -308,16 +308,62 @@ class FusedAdam:
             self.state[flat[i]] = (m.to(flat[i].device), v.to(flat[i].device))
 
 
+class _GradSync:
+    """Early, overlapped all-reduce of the hash-table gradient (training row).  The table gradient is the
+    LAST thing a backward produces and by far the largest message (49 MB per trained grid), so waiting for the whole
+    backward before starting the collective leaves the links idle for the entire step.  With more than one rank the
+    fused backward functions (nerf/network.py::_table_backward) run the scatter in two level ranges - fine levels
+    first - and hand each finished row range to ``reduce_async``: RCCL moves levels 8..15 over xGMI while the CUs
+    scatter levels 0..7 and reduce the weight gradients.  ``allreduce_gradients`` then only has to wait."""
+
+    def __init__(self):
+        self.world_size = 1
+        self.enabled = os.environ.get("INR_GRAD_OVERLAP", "1") != "0"
+        self.handles = []
+        self.early = {}                 # parameter data_ptr -> (data_ptr, numel) of the gradient whose slices are in flight
+
+    def active(self):
+        return self.enabled and self.world_size > 1 and dist.is_available() and dist.is_initialized()
+
+    def reduce_async(self, view):
+        self.handles.append(dist.all_reduce(view, async_op=True))
+
+    def mark(self, param, grad):
+        self.early[param.data_ptr()] = (grad.data_ptr(), grad.numel())
+
+    def finish(self):
+        for h in self.handles:
+            h.wait()
+        self.handles = []
+
+    def reset(self):
+        self.finish()
+        self.early = {}
+
+
+grad_sync = _GradSync()
+
+
 def allreduce_gradients(params, world_size, bucket_bytes=64 << 20):
     """Gradient all-reduce for ray-batch data parallelism: dense fp32 buckets over
-    RCCL (backend 'nccl' on ROCm) or gloo.  The hash-table gradient (49 MB) goes as ONE message;
-    small MLP gradients are flattened into one bucket."""
+    RCCL (backend 'nccl' on ROCm) or gloo.  The hash-table gradient (49 MB) goes as ONE message - or is already in
+    flight, started from inside the backward in two level ranges (``grad_sync``); small MLP gradients are flattened
+    into one bucket."""
     if world_size <= 1:
         return
     grads = [p.grad for p in params if p.grad is not None]
-    small, cur = [], 0
+    small = []
     handles = []
-    for g in grads:
+    for p in params:
+        g = p.grad
+        if g is None:
+            continue
+        e = grad_sync.early.get(p.data_ptr())
+        if e is not None:
+            if e != (g.data_ptr(), g.numel()):
+                raise RuntimeError("the table gradient was replaced while its all-reduce was in flight "
+                                   "(INR_GRAD_OVERLAP=0 turns the early all-reduce off)")
+            continue                    # its row ranges were handed to the collective during the backward
         if g.numel() * 4 >= bucket_bytes // 4:
             handles.append(dist.all_reduce(g, async_op=True))
         else:
@@ -331,6 +377,7 @@ def allreduce_gradients(params, world_size, bucket_bytes=64 << 20):
             off += g.numel()
     for h in handles:
         h.wait()
+    grad_sync.reset()
     for g in grads:
         g.div_(world_size)
 
@@ -439,6 +486,7 @@ class Trainer:
                  stage="nerf", update_extra_interval=16, ema_decay=None, use_graph=False):
         self.name, self.opt, self.model = name, opt, model
         self.world_size, self.local_rank = world_size, local_rank
+        grad_sync.world_size = world_size
         self.device = device or (torch.device("cuda", local_rank) if torch.cuda.is_available() else torch.device("cpu"))
         self.stage = stage
         self.workspace = workspace
