@@ -30,10 +30,10 @@ BYTES_PER_SAMPLE = 1024         # 16 levels x 8 corners x 2 features x 4 B (SURV
 
 def measured_traffic_bytes_per_sample(res):
     """HBM-side bytes per sample of the fused field kernel from the committed PMC profile
-    (profiles/r01_traffic.json: FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc passes, gfx950 x2
+    (profiles/r02_traffic.json: FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc passes, gfx950 x2
     read correction).  PMC counters cannot be collected from inside this process; None if absent or
     if the workload is not the profiled one."""
-    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r02_traffic.json")
     if res != 800 or not os.path.exists(path):
         return None
     t = json.load(open(path))
@@ -306,7 +306,7 @@ def main():
                        "parallelism": f"views sharded over {world} GPU(s), no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "traffic_source": "profiles/r01_traffic.json (rocprofv3 PMC, GB/s at this run's launch time)",
+                         "traffic_source": "profiles/r02_traffic.json (rocprofv3 PMC, GB/s at this run's launch time)",
                          "kernel": "k_nerf_fwd<true,true> (fused hash gather + SH table + MLP)",
                          "avg_launch_ms": round(avg_kernel_s * 1e3, 4), "launches": n_launch,
                          "algorithmic_bytes_per_sample": BYTES_PER_SAMPLE},
