@@ -5,9 +5,10 @@ Keeps torch-ngp's public surface (``render``, ``run_cuda``, ``update_extra_state
 ``density_grid``/``density_bitfield``/``step_counter``/``mean_count``/...) so the
 reference's instance-field trainer and grid extractor call it unchanged
 (upstream ``nerf/renderer.py`` of the un-vendored submodule,
-/root/reference/.gitmodules:4-6, README.md:27,59).  Only the ``cuda_ray=True``
-path is implemented: it is the hot path; the generic PyTorch sampler of
-upstream's ``run()`` is out of scope.
+/root/reference/.gitmodules:4-6, README.md:27,59).  ``cuda_ray=True`` is the
+hot path (``run_cuda``, all HIP); upstream's default sampler without an occupancy
+grid (``run``: uniform + importance samples) is kept as tensor-op glue around the
+HIP ray/box test and field kernels.
 
 MI355X-first differences (results identical up to fp32 rounding):
 * inference renders a whole ray batch in four launches - count/scan, write,
@@ -23,6 +24,30 @@ import torch.nn as nn
 
 from .. import _lib, raymarching
 from .._lib import check, ptr, stream_ptr
+
+
+def sample_pdf(bins, weights, n_samples, det=False):
+    """Inverse-CDF sampling of ``n_samples`` depths per ray from the piecewise-constant density ``weights`` over
+    ``bins`` (NeRF's hierarchical sampling, as upstream ``nerf/renderer.py::sample_pdf``).  bins [N, T+1],
+    weights [N, T] -> [N, n_samples]."""
+    weights = weights + 1e-5
+    pdf = weights / torch.sum(weights, -1, keepdim=True)
+    cdf = torch.cat([torch.zeros_like(pdf[..., :1]), torch.cumsum(pdf, -1)], -1)
+    if det:
+        u = torch.linspace(0.5 / n_samples, 1 - 0.5 / n_samples, steps=n_samples, device=weights.device)
+        u = u.expand(list(cdf.shape[:-1]) + [n_samples])
+    else:
+        u = torch.rand(list(cdf.shape[:-1]) + [n_samples], device=weights.device)
+    u = u.contiguous()
+    inds = torch.searchsorted(cdf, u, right=True)
+    below = torch.max(torch.zeros_like(inds - 1), inds - 1)
+    above = torch.min((cdf.shape[-1] - 1) * torch.ones_like(inds), inds)
+    cdf_g = torch.stack([torch.gather(cdf, 1, below), torch.gather(cdf, 1, above)], -1)
+    bins_g = torch.stack([torch.gather(bins, 1, below), torch.gather(bins, 1, above)], -1)
+    denom = cdf_g[..., 1] - cdf_g[..., 0]
+    denom = torch.where(denom < 1e-5, torch.ones_like(denom), denom)
+    t = (u - cdf_g[..., 0]) / denom
+    return bins_g[..., 0] + t * (bins_g[..., 1] - bins_g[..., 0])
 
 
 class NeRFRenderer(nn.Module):
@@ -81,10 +106,71 @@ class NeRFRenderer(nn.Module):
         self.local_step = 0
 
     # ----------------------------------------------------------------------------------------
-    def run(self, *args, **kwargs):
-        raise NotImplementedError(
-            "only the cuda_ray=True render path is implemented (the MI355X hot path); "
-            "construct the network with cuda_ray=True")
+    def run(self, rays_o, rays_d, num_steps=128, upsample_steps=128, bg_color=None, perturb=False, **kwargs):
+        """The sampler upstream uses when the network is built WITHOUT ``cuda_ray`` (its default): ``num_steps``
+        uniform depths between the ray's entry and exit of the box, ``upsample_steps`` more drawn from the coarse
+        weights (inverse-CDF sampling, as in NeRF), every sample evaluated by ``density`` / ``color`` (the HIP field
+        kernels), colours only where the weight exceeds 1e-4.  No occupancy grid is involved.  Tensor-op glue around
+        the HIP ray/box test and field kernels - this is upstream's slow path, kept for callers that never enabled
+        ``cuda_ray``; the hot path is ``run_cuda``.  rays_o, rays_d [B,N,3] -> dict(image, depth, weights_sum
+        (, instance))."""
+        prefix = rays_o.shape[:-1]
+        rays_o = rays_o.contiguous().view(-1, 3).float()
+        rays_d = rays_d.contiguous().view(-1, 3).float()
+        N, device = rays_o.shape[0], rays_o.device
+        aabb = self.aabb_train if self.training else self.aabb_infer
+        nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, aabb, self.min_near)
+        hit = (fars > nears) & (fars < 3.0e38)            # rays that miss the box keep near = far = FLT_MAX
+        nears = torch.where(hit, nears, torch.zeros_like(nears)).unsqueeze(-1)
+        fars = torch.where(hit, fars, torch.ones_like(fars)).unsqueeze(-1)
+
+        z_vals = torch.linspace(0.0, 1.0, num_steps, device=device).unsqueeze(0)
+        z_vals = nears + (fars - nears) * z_vals                                      # [N, T]
+        sample_dist = (fars - nears) / num_steps
+        if perturb:
+            z_vals = z_vals + (torch.rand(z_vals.shape, device=device) - 0.5) * sample_dist
+
+        def positions(z):
+            x = rays_o.unsqueeze(-2) + rays_d.unsqueeze(-2) * z.unsqueeze(-1)
+            return torch.min(torch.max(x, aabb[:3]), aabb[3:])
+
+        def weights_of(z, sigma):
+            deltas = torch.cat([z[..., 1:] - z[..., :-1], sample_dist * torch.ones_like(z[..., :1])], dim=-1)
+            alphas = 1 - torch.exp(-deltas * self.density_scale * sigma)
+            shifted = torch.cat([torch.ones_like(alphas[..., :1]), 1 - alphas + 1e-15], dim=-1)
+            return alphas * torch.cumprod(shifted, dim=-1)[..., :-1], deltas
+
+        xyzs = positions(z_vals)
+        den = {k: v.view(N, num_steps, -1) for k, v in self.density(xyzs.reshape(-1, 3)).items()}
+        if upsample_steps > 0:
+            with torch.no_grad():
+                weights, deltas = weights_of(z_vals, den["sigma"].squeeze(-1))
+                z_mid = z_vals[..., :-1] + 0.5 * deltas[..., :-1]
+                new_z = sample_pdf(z_mid, weights[:, 1:-1], upsample_steps, det=not self.training).detach()
+                new_xyzs = positions(new_z)
+            new_den = {k: v.view(N, upsample_steps, -1) for k, v in self.density(new_xyzs.reshape(-1, 3)).items()}
+            z_vals, order = torch.sort(torch.cat([z_vals, new_z], dim=1), dim=1)
+            xyzs = torch.gather(torch.cat([xyzs, new_xyzs], dim=1), 1, order.unsqueeze(-1).expand(-1, -1, 3))
+            den = {k: torch.gather(torch.cat([den[k], new_den[k]], dim=1), 1,
+                                   order.unsqueeze(-1).expand(-1, -1, den[k].shape[-1])) for k in den}
+        weights, _ = weights_of(z_vals, den["sigma"].squeeze(-1))
+        weights = weights * hit.unsqueeze(-1)
+        T = z_vals.shape[1]
+        dirs = rays_d.unsqueeze(-2).expand(-1, T, -1)
+        mask = (weights > 1e-4).reshape(-1)
+        rgbs = self.color(xyzs.reshape(-1, 3), dirs.reshape(-1, 3), mask=mask,
+                          geo_feat=den["geo_feat"].reshape(-1, den["geo_feat"].shape[-1])).view(N, T, 3)
+        weights_sum = weights.sum(dim=-1)
+        depth = torch.sum(weights * ((z_vals - nears) / (fars - nears)).clamp(0, 1), dim=-1)
+        image = torch.sum(weights.unsqueeze(-1) * rgbs, dim=-2)
+        if bg_color is None:
+            bg_color = 1
+        image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
+        results = {"image": image.view(*prefix, 3), "depth": depth.view(*prefix), "weights_sum": weights_sum.view(*prefix)}
+        if getattr(self, "num_instances", 0) > 0:
+            logits = self.instance(xyzs.reshape(-1, 3)).view(N, T, -1)
+            results["instance"] = torch.sum(weights.detach().unsqueeze(-1) * logits, dim=-2).view(*prefix, -1)
+        return results
 
     def run_cuda(self, rays_o, rays_d, dt_gamma=0, bg_color=None, perturb=False, force_all_rays=False,
                  max_steps=1024, T_thresh=1e-4, infer_mode="auto", noises=None, **kwargs):
@@ -373,9 +459,8 @@ class NeRFRenderer(nn.Module):
         # upstream chunks staged renders to fit a 24 GB card; a 640 000-ray frame needs ~2 GB of the 288 GB here, and
         # rays are independent (chunking never changes a result), so chunks are at least `min_staged_batch` rays.
         # Set model.min_staged_batch = 0 for upstream's exact chunk size.
-        max_ray_batch = max(int(max_ray_batch), int(self.min_staged_batch))
-        if staged and not self.cuda_ray:
-            raise NotImplementedError("staged rendering is only meaningful on the cuda_ray path here")
+        if self.cuda_ray:
+            max_ray_batch = max(int(max_ray_batch), int(self.min_staged_batch))
         if staged and N > max_ray_batch:
             if not self.training and kwargs.get("infer_mode", "auto") == "auto":
                 # one mode per frame: every chunk of a staged render takes the same kernel path

@@ -82,6 +82,67 @@ def render_infer(rays_o, rays_d, p, table, bitfield, bound=1.0, cascade=1, H=128
                 raw_depth=depth)
 
 
+@torch.no_grad()
+def render_generic(rays_o, rays_d, p, table, bound=1.0, min_near=0.2, num_steps=128, upsample_steps=128,
+                   density_scale=1.0, bg_color=1.0):
+    """Upstream's sampler WITHOUT an occupancy grid (``NeRFRenderer.run``; Appendix A does not spell
+    it out - this is NeRF's coarse + importance sampling as torch-ngp runs it in evaluation mode: no jitter,
+    deterministic inverse-CDF samples).  Written ray by ray with numpy searchsorted, independently of the
+    product's vectorised version.  -> dict(image [N,3], depth [N], weights_sum [N])."""
+    ro, rd = np.asarray(rays_o, F32), np.asarray(rays_d, F32)
+    N = ro.shape[0]
+    nears, fars = near_far_from_aabb(ro, rd, aabb_of(bound), min_near)
+    image, depth, wsum = np.zeros((N, 3), F32), np.zeros(N, F32), np.zeros(N, F32)
+    lo, hi = -F32(bound), F32(bound)
+
+    def field_at(z, o, d):
+        x = np.clip(o[None, :] + d[None, :] * z[:, None], lo, hi).astype(F32)
+        den = field.density(torch.from_numpy(x), p, bound, table)
+        return x, den["sigma"].numpy() * F32(density_scale), den["geo_feat"]
+
+    def weights_of(z, sigma, dist):
+        deltas = np.append(z[1:] - z[:-1], dist).astype(F32)
+        alphas = 1 - np.exp(-deltas * sigma)
+        T = np.cumprod(np.append(1.0, 1 - alphas + 1e-15))[:-1]
+        return (alphas * T).astype(F32), deltas
+
+    for n in range(N):
+        if not (fars[n] > nears[n] and fars[n] < 3.0e38):
+            image[n] = bg_color
+            continue
+        near, far = nears[n], fars[n]
+        z = (near + (far - near) * np.linspace(0.0, 1.0, num_steps, dtype=F32)).astype(F32)
+        dist = F32((far - near) / num_steps)
+        x, sigma, geo = field_at(z, ro[n], rd[n])
+        if upsample_steps > 0:
+            w, deltas = weights_of(z, sigma, dist)
+            mid = z[:-1] + 0.5 * deltas[:-1]                       # bin edges: T - 1 of them, T - 2 bins
+            pdf = w[1:-1] + 1e-5
+            pdf = pdf / pdf.sum()
+            cdf = np.append(0.0, np.cumsum(pdf)).astype(F32)
+            u = np.linspace(0.5 / upsample_steps, 1 - 0.5 / upsample_steps, upsample_steps, dtype=F32)
+            idx = np.searchsorted(cdf, u, side="right")
+            below, above = np.maximum(idx - 1, 0), np.minimum(idx, len(cdf) - 1)
+            den = cdf[above] - cdf[below]
+            den = np.where(den < 1e-5, 1.0, den)
+            t = (u - cdf[below]) / den
+            z_new = (mid[below] + t * (mid[above] - mid[below])).astype(F32)
+            x2, s2, g2 = field_at(z_new, ro[n], rd[n])
+            order = np.argsort(np.append(z, z_new), kind="stable")
+            z = np.append(z, z_new)[order]
+            x = np.concatenate([x, x2])[order]
+            sigma = np.append(sigma, s2)[order]
+            geo = torch.cat([geo, g2])[torch.from_numpy(order)]
+        w, _ = weights_of(z, sigma, dist)
+        d = torch.from_numpy(np.repeat(rd[n][None], len(z), 0))
+        rgb = field.color(d, geo, p).numpy()
+        rgb = np.where((w > 1e-4)[:, None], rgb, 0.0)
+        wsum[n] = w.sum()
+        depth[n] = (w * np.clip((z - near) / (far - near), 0, 1)).sum()
+        image[n] = (w[:, None] * rgb).sum(0) + (1 - wsum[n]) * bg_color
+    return dict(image=image, depth=depth, weights_sum=wsum)
+
+
 def instance_ce_loss(logits, labels):
     """Cross entropy over rendered logits, ignore_index = -1, mean over kept rays."""
     labels = torch.as_tensor(labels, dtype=torch.int64)

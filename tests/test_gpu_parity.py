@@ -724,6 +724,37 @@ def test_full_size_frame_against_the_c_oracle(rm, params_k16, room, room_bitfiel
     assert np.abs(out["depth"][0].cpu().numpy() - c["depth"]).max() < 1e-4
 
 
+def test_generic_sampler_without_cuda_ray(params_k16, room, level_table):
+    """NeRFNetwork(cuda_ray=False).render(): upstream's default sampler (128 uniform + 128 importance samples, no
+    occupancy grid) as tensor-op glue around the HIP ray/box test and field kernels, against the oracle's ray-by-ray
+    restatement; staged chunks equal the single batch; training mode back-propagates into table and weights."""
+    from instance_nerf_amd.nerf import NeRFNetwork
+    from oracle import render
+    net = NeRFNetwork(cuda_ray=False, num_instances=0, min_near=0.05).to(DEV).eval()
+    net.load_state_dict({"encoder.embeddings": params_k16["embeddings"], "sigma_net.0.weight": params_k16["sigma_w0"],
+                         "sigma_net.1.weight": params_k16["sigma_w1"], "color_net.0.weight": params_k16["color_w0"],
+                         "color_net.1.weight": params_k16["color_w1"], "color_net.2.weight": params_k16["color_w2"]},
+                        strict=False)
+    net.density_scale = 0.3                                        # table U(-1,1): keep the rays semi-transparent
+    ro, rd = scene_rays(room, 40, seed=5)
+    ro[0], rd[0] = [5, 5, 5], [1, 0, 0]                            # misses the box: background only
+    with torch.no_grad():
+        a = net.render(_t(ro)[None], _t(rd)[None], bg_color=1, num_steps=64, upsample_steps=64)
+        b = net.render(_t(ro)[None], _t(rd)[None], bg_color=1, num_steps=64, upsample_steps=64, staged=True, max_ray_batch=16)
+    ref = render.render_generic(ro, rd, params_k16, level_table, min_near=0.05, num_steps=64, upsample_steps=64,
+                                density_scale=0.3)
+    assert a["image"].shape == (1, 40, 3) and (a["image"][0, 0] == 1).all() and a["weights_sum"][0, 0] == 0
+    assert 0.05 < ref["weights_sum"][1:].mean() < 0.999
+    assert np.abs(a["image"][0].cpu().numpy() - ref["image"]).max() < 2e-3
+    assert np.abs(a["weights_sum"][0].cpu().numpy() - ref["weights_sum"]).max() < 2e-3
+    assert np.abs(a["depth"][0].cpu().numpy() - ref["depth"]).max() < 2e-3
+    assert (a["image"] - b["image"]).abs().max() < 1e-6
+    net.train()
+    out = net.render(_t(ro)[None], _t(rd)[None], bg_color=1, num_steps=32, upsample_steps=32, perturb=True)
+    out["image"].sum().backward()
+    assert net.encoder.embeddings.grad.abs().sum() > 0 and net.color_net[2].weight.grad.abs().sum() > 0
+
+
 def test_rays_missing_the_volume(rm, bits_dev):
     ro = np.asarray([[5, 5, 5], [0, 0, 3], [0, 0, 0]], np.float32)
     rd = np.asarray([[1, 0, 0], [0, 1, 0], [0, 0, 1]], np.float32)
