@@ -137,6 +137,53 @@ def test_march_train_cascades_and_max_steps(rm, marcher):
         assert (d.cpu().numpy()[:ref["total"]] == ref["dirs"]).all()
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_march_fuzz_against_the_c_oracle(rm, seed):
+    """Random configurations - cascades 1..3 (bound 1, 2, 4), grid 32..128, occupancy 0.5 %..60 %, constant and growing
+    steps, max_steps 16..1024, rays from inside and outside the volume, axis-aligned directions (infinite
+    reciprocals), jittered starts - all three marchers (lane-per-ray, wave-per-ray, patch writer) against the scalar C
+    restatement: counts, offsets, positions and deltas bit for bit."""
+    from oracle import c_port
+    rng = np.random.default_rng(1000 + seed)
+    C = int(rng.integers(1, 4))
+    bound = float(2 ** (C - 1))
+    H = int(rng.choice([32, 64, 128]))
+    fill = float(rng.choice([0.005, 0.05, 0.3, 0.6]))
+    bits = (rng.random(C * H ** 3 // 8) < fill).astype(np.uint8) * rng.integers(1, 256, C * H ** 3 // 8).astype(np.uint8)
+    dt_gamma = float(rng.choice([0.0, 1.0 / 256, 1.0 / 128, 1.0 / 32]))
+    max_steps = int(rng.choice([16, 100, 512, 1024]))
+    n = int(rng.choice([1, 15, 16, 17, 333, 1500]))
+    ro = rng.uniform(-1.3 * bound, 1.3 * bound, size=(n, 3)).astype(np.float32)
+    rd = rng.normal(size=(n, 3)).astype(np.float32)
+    rd /= np.linalg.norm(rd, axis=1, keepdims=True)
+    rd[: min(n, 3)] = np.eye(3, dtype=np.float32)[: min(n, 3)] * np.float32(rng.choice([-1.0, 1.0]))
+    aabb = np.asarray([-bound] * 3 + [bound] * 3, np.float32)
+    nears, fars = c_port.near_far_from_aabb(ro, rd, aabb, 0.2)
+    noises = rng.random(n).astype(np.float32)
+    ref = c_port.march_rays_train(ro, rd, bits, bound, C, H, nears, fars, noises, dt_gamma, max_steps)
+    gn, gf = rm.near_far_from_aabb(_t(ro), _t(rd), _t(aabb), 0.2)
+    assert (gn.cpu().numpy() == nears).all() and (gf.cpu().numpy() == fars).all()
+    for coop in ("0", "1"):
+        os.environ["INR_MARCH_COOP"] = coop
+        try:
+            xyzs, dirs, deltas, rays = rm.march_rays_train(_t(ro), _t(rd), bound, _t(bits), C, H, gn, gf, dt_gamma=dt_gamma,
+                                                           max_steps=max_steps, noises=_t(noises), force_all_rays=True)
+        finally:
+            os.environ.pop("INR_MARCH_COOP", None)
+        M = ref["total"]
+        assert (rays.cpu().numpy() == ref["rays"]).all(), (coop, C, H, fill, dt_gamma, max_steps, n)
+        assert (xyzs.cpu().numpy()[:M] == ref["xyzs"]).all() and (deltas.cpu().numpy()[:M] == ref["deltas"]).all()
+        assert (dirs.cpu().numpy()[:M] == ref["dirs"]).all()
+    # the frame writer: same samples in the patch-interleaved order (a permutation inside every 16-ray group)
+    ref0 = c_port.march_rays_train(ro, rd, bits, bound, C, H, nears, fars, None, dt_gamma, max_steps)
+    xp, dp, dlp, rp = rm.march_rays_patch(_t(ro), _t(rd), bound, _t(bits), C, H, gn, gf, dt_gamma, max_steps)
+    assert (rp[:, 2].cpu().numpy() == ref0["rays"][:, 2]).all()
+    got = xp.cpu().numpy()[: ref0["total"]]
+    assert got.shape[0] == ref0["total"]
+    key = lambda a: a[np.lexsort(a.T[::-1])]
+    assert (key(got) == key(ref0["xyzs"])).all()
+
+
 def test_march_infer_step_bit_exact(rm, room, room_bitfield, bits_dev):
     from oracle import march, rays
     ro, rd = scene_rays(room, 300, seed=41)
@@ -194,6 +241,38 @@ def test_grid_indices_bit_exact(level_table):
         assert torch.allclose(got, ref, rtol=1e-6, atol=0.5)
         # nearest-row check: blending weight of the other corners is < 3%, rows differ by >= 1
         assert ((got - want).abs() / want.clamp(min=1) < 0.2).float().mean() > 0.9
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_grid_encoder_fuzz_against_the_c_oracle(seed):
+    """Random grid shapes - 2..16 levels, base resolution 4..32, 2^8..2^19 rows per hashed level, finest resolution
+    64..4096, bound 1..4 (dense-only, mixed and hashed-only tables) - stand-alone encoder forward and table gradient
+    against the scalar C / numpy restatements, points on the faces and outside the volume included."""
+    from instance_nerf_amd.gridencoder import GridEncoder
+    from oracle import c_port, hashgrid
+    rng = np.random.default_rng(500 + seed)
+    L = int(rng.choice([2, 5, 8, 13, 16]))
+    base = int(rng.choice([4, 16, 32]))
+    log2_t = int(rng.choice([8, 12, 15, 19]))
+    res = int(rng.choice([64, 512, 2048, 4096]))
+    bound = float(rng.choice([1.0, 2.0, 4.0]))
+    enc = GridEncoder(num_levels=L, base_resolution=base, log2_hashmap_size=log2_t, desired_resolution=res).to(DEV)
+    tb = hashgrid.level_table(num_levels=L, base_resolution=base, log2_hashmap_size=log2_t, desired_resolution=res)
+    for k in ("offsets", "scales", "resolutions", "hashed"):
+        assert (enc.table[k] == tb[k]).all(), k
+    gen = torch.Generator().manual_seed(seed)
+    emb = torch.rand(tb["total_rows"], 2, generator=gen) * 2 - 1
+    enc.embeddings.data.copy_(emb)
+    x = (torch.rand(3000, 3, generator=gen) * 2.2 - 1.1) * bound
+    x[:4] = torch.tensor([[1.0, 1, 1], [-1.0, -1, -1], [1.0, -1, 0.3], [0.0, 0, 0]]) * bound
+    out = enc(x.to(DEV), bound=bound)
+    ref = c_port.grid_encode(x.numpy(), emb.numpy(), bound, tb)
+    assert out.shape == (3000, 2 * L)
+    assert np.abs(out.detach().cpu().numpy() - ref).max() < 2e-6, (L, base, log2_t, res, bound)
+    go = torch.randn(3000, 2 * L, generator=gen)
+    out.backward(go.to(DEV))
+    g_ref = hashgrid.encode_backward_table(x, go, bound, tb)
+    assert torch.allclose(enc.embeddings.grad.cpu(), g_ref, atol=5e-5, rtol=1e-4)
 
 
 def test_grid_encode_forward_golden(level_table, params_k16):
