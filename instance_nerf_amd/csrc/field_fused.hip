@@ -185,8 +185,31 @@ struct Gathered {
   float fwx[4], ffy[4], ffz[4];   // fine: weight of this lane's x side, y / z fractions
 };
 
-__device__ __forceinline__ void issue_gathers(const LevelRec* __restrict__ my_recs, const bool (&all_hashed)[4],
-                                              __amdgpu_buffer_rsrc_t rsrc, float x0, float x1, float x2, Gathered& g) {
+// ONE wave-uniform branch around the whole gather sequence, none inside it.  Round 1 chose between the xor-only and
+// the general index maths per level: every such diamond is a control-flow merge at which the compiler's wait-count
+// pass must assume that the loads of the side NOT taken are still outstanding into the registers the other side
+// writes, so it put `s_waitcnt vmcnt(2)` in front of every level's block - the 32 gathers of a tile went out in five
+// batches, each waiting for the previous one, instead of all at once (found in the ISA in round 2).
+// Staging of the 32 gathers of a tile (measured, profiles/r02_NOTES.txt section 9): all 32 in flight at once is NOT
+// the fastest - on the table feed 5.71 ms against 5.50 ms when the fine levels' loads go out only after all but 8
+// of the 16 coarse loads have landed and each later fine level waits until at most 4 loads are outstanding.  The
+// kernel is throughput-bound (look-ups, VALU issue), not latency-bound, and fewer lines in flight per wave leave
+// more of the 32 KB L1 to the other seven waves of the CU.  (-1 = no wait.)
+#ifndef INR_WAIT_AFTER_COARSE
+#define INR_WAIT_AFTER_COARSE 8
+#endif
+#ifndef INR_WAIT_BETWEEN_FINE
+#define INR_WAIT_BETWEEN_FINE 4
+#endif
+// s_waitcnt vmcnt(N) only (gfx9 encoding: vmcnt[3:0] | expcnt 7 << 4 | lgkmcnt 15 << 8 | vmcnt[5:4] << 14)
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  if constexpr (N >= 0) __builtin_amdgcn_s_waitcnt((N & 0xF) | (0x7 << 4) | (0xF << 8) | ((N >> 4) << 14));
+}
+
+template <bool kFineHashed>
+__device__ __forceinline__ void issue_gathers_impl(const LevelRec* __restrict__ my_recs, __amdgpu_buffer_rsrc_t rsrc,
+                                                   float x0, float x1, float x2, Gathered& g) {
   const int q = (threadIdx.x >> 4) & 3;
   const uint32_t side = (uint32_t)(q & 1);
   const LevelRec* pair_recs = my_recs - 4 * (q & 1);     // records of the even lane of this pair
@@ -201,23 +224,14 @@ __device__ __forceinline__ void issue_gathers(const LevelRec* __restrict__ my_re
     const uint32_t cx = (uint32_t)px, cy = (uint32_t)py, cz = (uint32_t)pz;
     const uint32_t hy0 = cy * pa, hy1 = hy0 + pa;
     const uint32_t hz0 = cz * pb, hz1 = hz0 + pb;
-    if (all_hashed[li]) {              // wave-uniform: xor-only index maths
-      const uint32_t yz[4] = {hy0 ^ hz0, hy1 ^ hz0, hy0 ^ hz1, hy1 ^ hz1};
+    const bool h = my_recs[li].b.y != 0;                 // per lane: the four q of a coarse slot mix dense and hashed
+    const uint32_t yz[4] = {h ? (hy0 ^ hz0) : (hy0 + hz0), h ? (hy1 ^ hz0) : (hy1 + hz0),
+                            h ? (hy0 ^ hz1) : (hy0 + hz1), h ? (hy1 ^ hz1) : (hy1 + hz1)};
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const uint32_t idx = ((cx + (k & 1)) ^ yz[k >> 1]) & mask;
-        g.c[li][k] = gather_row<INR_AUX_COARSE>(rsrc, base + idx * 8u);
-      }
-    } else {
-      const bool h = my_recs[li].b.y != 0;
-      const uint32_t yz[4] = {h ? (hy0 ^ hz0) : (hy0 + hz0), h ? (hy1 ^ hz0) : (hy1 + hz0),
-                              h ? (hy0 ^ hz1) : (hy0 + hz1), h ? (hy1 ^ hz1) : (hy1 + hz1)};
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const uint32_t c = cx + (k & 1);
-        const uint32_t idx = (h ? (c ^ yz[k >> 1]) : (c + yz[k >> 1])) & mask;
-        g.c[li][k] = gather_row<INR_AUX_COARSE>(rsrc, base + idx * 8u);
-      }
+    for (int k = 0; k < 8; ++k) {
+      const uint32_t c = cx + (k & 1);
+      const uint32_t idx = (h ? (c ^ yz[k >> 1]) : (c + yz[k >> 1])) & mask;
+      g.c[li][k] = gather_row<INR_AUX_COARSE>(rsrc, base + idx * 8u);
     }
   }
 #pragma unroll
@@ -234,7 +248,9 @@ __device__ __forceinline__ void issue_gathers(const LevelRec* __restrict__ my_re
     const uint32_t c = (uint32_t)px + side, cy = (uint32_t)py, cz = (uint32_t)pz;
     const uint32_t hy0 = cy * pa, hy1 = hy0 + pa;
     const uint32_t hz0 = cz * pb, hz1 = hz0 + pb;
-    if (all_hashed[2 + (i & 1)]) {     // wave-uniform (both pairs' levels of this step are hashed)
+    if (i == 0) wait_vmcnt<INR_WAIT_AFTER_COARSE>();
+    else wait_vmcnt<INR_WAIT_BETWEEN_FINE>();
+    if constexpr (kFineHashed) {       // every fine level of both pairs is hashed: xor-only index maths
       g.f[i][0] = gather_row<INR_AUX_FINE>(rsrc, base + ((c ^ (hy0 ^ hz0)) & mask) * 8u);
       g.f[i][1] = gather_row<INR_AUX_FINE>(rsrc, base + ((c ^ (hy1 ^ hz0)) & mask) * 8u);
       g.f[i][2] = gather_row<INR_AUX_FINE>(rsrc, base + ((c ^ (hy0 ^ hz1)) & mask) * 8u);
@@ -250,6 +266,12 @@ __device__ __forceinline__ void issue_gathers(const LevelRec* __restrict__ my_re
       }
     }
   }
+}
+
+__device__ __forceinline__ void issue_gathers(const LevelRec* __restrict__ my_recs, const bool (&all_hashed)[4],
+                                              __amdgpu_buffer_rsrc_t rsrc, float x0, float x1, float x2, Gathered& g) {
+  if (all_hashed[2] && all_hashed[3]) issue_gathers_impl<true>(my_recs, rsrc, x0, x1, x2, g);
+  else issue_gathers_impl<false>(my_recs, rsrc, x0, x1, x2, g);
 }
 
 __device__ __forceinline__ f32x2 row2(const u32x2 v) {

@@ -30,14 +30,16 @@ if os.environ.get("PROBE_RAYMAJOR"):
     xyzs, dirs, deltas, rays = raymarching.march_rays_train(ro, rd, 1, net.density_bitfield, 1, 128, nears, fars,
                                                             force_all_rays=True)
 else:
-    xyzs, dirs, deltas, rays = raymarching.march_rays_patch(ro, rd, 1, net.density_bitfield, 1, 128, nears, fars)
+    xyzs, dirs, deltas, rays = raymarching.march_rays_patch(ro, rd, 1, net.density_bitfield, 1, 128, nears, fars,
+                                                            table=bool(os.environ.get("PROBE_TABLE")))
 M = xyzs.shape[0]
+run = (lambda: net.forward_table(xyzs, dirs, rd)) if os.environ.get("PROBE_TABLE") else (lambda: net(xyzs, dirs))
 with torch.no_grad():
-    net(xyzs, dirs)
+    run()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(reps):
-        net(xyzs, dirs)
+        run()
     torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / reps
 print(f"M={M} field {dt*1e3:.3f} ms  {M/dt/1e9:.3f} Gsamples/s  {M*1024/dt/1e9:.1f} GB/s algorithmic")
