@@ -12,7 +12,7 @@ from instance_nerf_amd.nerf.utils import MIoUMeter, PSNRMeter, Trainer, get_rays
 nerf_steps = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
 inst_steps = int(sys.argv[2]) if len(sys.argv) > 2 else 600
 dev = torch.device("cuda", 0)
-torch.manual_seed(0)
+torch.manual_seed(int(os.environ.get("DEMO_SEED", "0")))
 K = 16
 net = NeRFNetwork(cuda_ray=True, bound=1, min_near=0.05, density_thresh=10, num_instances=K).to(dev)
 ds = SyntheticRoomDataset(dev, H=400, W=400, n_views=24, num_rays=4096, num_instances=K, ignore_frac=0.1)
