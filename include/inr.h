@@ -139,7 +139,10 @@ int inr_composite_rays_patch_forward(const float* sigmas, const float* rgbs, con
                                      const int32_t* rays, int64_t N, int64_t M, float T_thresh,
                                      const float* extra /*[M,K] nullable*/, int32_t K,
                                      float* weights_sum, float* depth, float* image,
-                                     float* extra_out /*[N,K]*/, float* weights /*[M]*/, inr_stream_t s);
+                                     float* extra_out /*[N,K]*/, float* weights /*[M]*/,
+                                     uint64_t* skippable /*device, nullable: += samples of steps at which a whole
+                                     16-ray group is already below T_thresh - what inr_nerf_render would skip*/,
+                                     inr_stream_t s);
 
 /* ---- inference march/composite (replace raymarching.march_rays / composite_rays, a5) */
 int inr_march_rays(int64_t n_alive, int32_t n_step, const int32_t* rays_alive, const float* rays_t,

@@ -1008,7 +1008,8 @@ __global__ void __launch_bounds__(kRayBlock) k_composite_patch_fwd(const float* 
                                                                    const int32_t* __restrict__ rays, int64_t N, int64_t M,
                                                                    float T_thresh, float* __restrict__ wbuf,
                                                                    float* __restrict__ weights_sum,
-                                                                   float* __restrict__ depth, float* __restrict__ image) {
+                                                                   float* __restrict__ depth, float* __restrict__ image,
+                                                                   unsigned long long* __restrict__ skippable) {
   const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & 63, g0 = lane & ~(kGroup - 1), rr = lane & (kGroup - 1);
   const int32_t rid = n < N ? rays[n * 3] : 0;
@@ -1024,10 +1025,15 @@ __global__ void __launch_bounds__(kRayBlock) k_composite_patch_fwd(const float* 
   for (int d = 1; d < 64; d <<= 1) maxc = max(maxc, __shfl_xor(maxc, d, 64));
   float T = 1.0f, r = 0, g = 0, b = 0, ws = 0, t = 0, dsum = 0;
   bool done = false;
+  unsigned n_skip = 0;            // samples of steps at which every ray of the group is already below T_thresh
   for (int k = 0; k < maxc; ++k) {
     const bool active = k < cnt;
     const unsigned long long m = __ballot(active);
     const unsigned field = (unsigned)(m >> g0) & 0xFFFFu;
+    if (skippable) {              // (wave-uniform) what the early-terminating kernel would not have evaluated
+      const unsigned live = (unsigned)(__ballot(active && !done) >> g0) & 0xFFFFu;
+      if (rr == 0 && field != 0 && live == 0) n_skip += __popc(field);
+    }
     if (active && !done) {
       const int64_t i = (int64_t)S + __popc(field & ((1u << rr) - 1u));
       const float2 dl = reinterpret_cast<const float2*>(deltas)[i];
@@ -1048,6 +1054,11 @@ __global__ void __launch_bounds__(kRayBlock) k_composite_patch_fwd(const float* 
   if (n < N) {
     weights_sum[rid] = ws; depth[rid] = dsum;
     image[rid * 3] = r; image[rid * 3 + 1] = g; image[rid * 3 + 2] = b;
+  }
+  if (skippable) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) n_skip += __shfl_xor(n_skip, d, 64);
+    if (lane == 0 && n_skip) atomicAdd(skippable, (unsigned long long)n_skip);
   }
 }
 
@@ -1300,7 +1311,7 @@ int inr_march_rays_patch_write(const float* rays_o, const float* rays_d, const u
 int inr_composite_rays_patch_forward(const float* sigmas, const float* rgbs, const float* deltas, const int32_t* rays,
                                      int64_t N, int64_t M, float T_thresh, const float* extra, int32_t K,
                                      float* weights_sum, float* depth, float* image, float* extra_out,
-                                     float* weights, inr_stream_t s) {
+                                     float* weights, uint64_t* skippable, inr_stream_t s) {
   INR_REQUIRE(N >= 0 && M >= 0, "bad sizes");
   if (N == 0) return INR_OK;
   INR_REQUIRE(rays && weights_sum && depth && image, "null pointer");
@@ -1309,7 +1320,8 @@ int inr_composite_rays_patch_forward(const float* sigmas, const float* rgbs, con
   INR_REQUIRE(((uintptr_t)deltas & 7) == 0, "deltas must be 8-byte aligned");
   hipStream_t st = as_stream(s);
   k_composite_patch_fwd<<<blocks_for(N, kRayBlock), kRayBlock, 0, st>>>(sigmas, rgbs, deltas, rays, N, M, T_thresh,
-                                                                        weights, weights_sum, depth, image);
+                                                                        weights, weights_sum, depth, image,
+                                                                        reinterpret_cast<unsigned long long*>(skippable));
   if (extra)
     k_composite_patch_extra<<<blocks_for(N * 64, kRayBlock), kRayBlock, 0, st>>>(weights, extra, rays, N, M, K,
                                                                                  extra_out);

@@ -181,7 +181,8 @@ class NeRFRenderer(nn.Module):
           "fused_terminate"  march -> ONE kernel for field + compositing that stops a 16-ray group once all its rays
                              are opaque (measured 4x faster than "fused" on an opaque scene, 1.4x slower on a
                              transparent one)
-          "auto" (default)   picks between the two from the mean opacity of the previous inference call
+          "auto" (default)   picks between the two from the fraction of samples the early-terminating kernel skips /
+                             would skip, as counted by the previous inference calls (> terminate_above = 0.4)
           "fused_raymajor" / "wavefront"   reference paths kept for parity tests (ray-major layout / upstream's loop)
         """
         prefix = rays_o.shape[:-1]
@@ -194,9 +195,10 @@ class NeRFRenderer(nn.Module):
         if bg_color is None:
             bg_color = 1
         results = {}
+        skipped_frac = None
         with_instance = getattr(self, "num_instances", 0) > 0
         if not self.training and infer_mode == "auto":
-            infer_mode = "fused_terminate" if self._recent_opacity() > 0.5 else "fused"
+            infer_mode = "fused_terminate" if self._recent_skippable() > self.terminate_above else "fused"
 
         fused_inst = with_instance and getattr(self, "_fusable_inst", False) and hasattr(self, "instance_render")
         if (not self.training and infer_mode == "fused_terminate" and getattr(self, "_fusable", False)
@@ -212,6 +214,7 @@ class NeRFRenderer(nn.Module):
                 results["instance"] = self.instance_render(xyzs, rays, wbuf).view(*prefix, -1)
             results["num_samples"] = counter
             results["num_evaluated"] = evaluated
+            skipped_frac = 1.0 - evaluated[0].float() / counter[0].float().clamp(min=1)
         elif not self.training and infer_mode in ("fused", "fused_terminate"):
             # full batch in four launches, patch-interleaved sample layout (csrc/raymarch.hip)
             counter = torch.zeros(2, dtype=torch.int32, device=device)
@@ -224,18 +227,21 @@ class NeRFRenderer(nn.Module):
             sigmas, rgbs = self.forward_table(xyzs, dirs, rays_d) if table else self(xyzs, dirs)
             if self.density_scale != 1:
                 sigmas = self.density_scale * sigmas
+            skippable = torch.zeros(1, dtype=torch.int64, device=device)
             if fused_inst:
                 # weights first, then the instance field accumulates w * logits on chip (no [M, K] round trip)
                 weights_sum, depth, image, wbuf = raymarching.composite_rays_patch(sigmas, rgbs, deltas, rays, T_thresh,
-                                                                                  return_weights=True)
+                                                                                  return_weights=True, skippable=skippable)
                 results["instance"] = self.instance_render(xyzs, rays, wbuf).view(*prefix, -1)
             else:
                 extra = self.instance(xyzs) if with_instance else None
-                out = raymarching.composite_rays_patch(sigmas, rgbs, deltas, rays, T_thresh, extra=extra)
+                out = raymarching.composite_rays_patch(sigmas, rgbs, deltas, rays, T_thresh, extra=extra,
+                                                       skippable=skippable)
                 weights_sum, depth, image = out[0], out[1], out[2]
                 if with_instance:
                     results["instance"] = out[3].view(*prefix, -1)
             results["num_samples"] = counter
+            skipped_frac = skippable[0].float() / counter[0].float().clamp(min=1)
         elif self.training or infer_mode == "fused_raymajor":
             if self.training:
                 counter = self.step_counter[self.local_step % 16]
@@ -289,8 +295,8 @@ class NeRFRenderer(nn.Module):
         else:
             raise ValueError(f"unknown infer_mode {infer_mode!r}")
 
-        if not self.training:
-            self._note_opacity(weights_sum)
+        if not self.training and skipped_frac is not None:
+            self._note_skippable(skipped_frac)
         bg3 = self._bg_triplet(bg_color)
         if bg3 is not None and not (torch.is_grad_enabled() and (image.requires_grad or weights_sum.requires_grad)):
             # no gradient flows through the shaded image (inference, or the instance stage on a frozen NeRF):
@@ -312,33 +318,40 @@ class NeRFRenderer(nn.Module):
         results["weights_sum"] = weights_sum.view(*prefix)
         return results
 
-    # Mean opacity of recent eval calls, for infer_mode="auto".  The value travels to the host through a pinned
-    # buffer + event and is only read once its copy has completed: no call ever waits for a previous frame.
-    def _note_opacity(self, weights_sum):
-        if not weights_sum.is_cuda:
-            self._opacity_value = float(weights_sum.mean())
+    # infer_mode="auto": which kernel path pays?  The early-terminating kernel costs ~1.4x per EVALUATED sample (a
+    # wave owns a 16-ray group for all its steps) and skips every step at which the whole group is below T_thresh, so
+    # it wins when it skips more than ~30 % of the marched samples; 40 % is used (hysteresis against flapping).  The
+    # two-kernel path counts that fraction in its compositing kernel, the terminating kernel reports what it really
+    # evaluated.  (Round 1 switched on mean opacity > 0.5: a half-trained scene - opacity 0.88, only 9 % skippable -
+    # then rendered in 20.5 ms instead of 14.4, profiles/r02_NOTES.txt section 11.)  The value travels to the host
+    # through a pinned buffer + event and is only read once its copy has completed: no call waits for a previous frame.
+    terminate_above = 0.4
+
+    def _note_skippable(self, frac):
+        if not frac.is_cuda:
+            self._skippable_value = float(frac)
             return
         d = self.__dict__
-        if "_opacity_free" not in d:               # four pinned scalars, allocated once
-            d["_opacity_free"] = [torch.empty((), dtype=torch.float32, pin_memory=True) for _ in range(4)]
-            d["_opacity_pending"] = []
-        self._recent_opacity()                     # recycles the slots whose copies have landed
-        if not d["_opacity_free"]:
+        if "_skippable_free" not in d:             # four pinned scalars, allocated once
+            d["_skippable_free"] = [torch.empty((), dtype=torch.float32, pin_memory=True) for _ in range(4)]
+            d["_skippable_pending"] = []
+        self._recent_skippable()                   # recycles the slots whose copies have landed
+        if not d["_skippable_free"]:
             return                                 # four samples still in flight: skip this one
-        host = d["_opacity_free"].pop()
-        host.copy_(weights_sum.mean(), non_blocking=True)
+        host = d["_skippable_free"].pop()
+        host.copy_(frac.reshape(()), non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        d["_opacity_pending"].append((ev, host))
+        d["_skippable_pending"].append((ev, host))
 
-    def _recent_opacity(self):
+    def _recent_skippable(self):
         d = self.__dict__
-        pending = d.get("_opacity_pending", [])
+        pending = d.get("_skippable_pending", [])
         while pending and pending[0][0].query():
             _, host = pending.pop(0)
-            d["_opacity_value"] = float(host)
-            d["_opacity_free"].append(host)
-        return d.get("_opacity_value", 0.0)
+            d["_skippable_value"] = float(host)
+            d["_skippable_free"].append(host)
+        return d.get("_skippable_value", 0.0)
 
     @staticmethod
     def _bg_triplet(bg_color):
@@ -464,7 +477,7 @@ class NeRFRenderer(nn.Module):
         if staged and N > max_ray_batch:
             if not self.training and kwargs.get("infer_mode", "auto") == "auto":
                 # one mode per frame: every chunk of a staged render takes the same kernel path
-                kwargs = dict(kwargs, infer_mode="fused_terminate" if self._recent_opacity() > 0.5 else "fused")
+                kwargs = dict(kwargs, infer_mode="fused_terminate" if self._recent_skippable() > self.terminate_above else "fused")
             chunks = {}
             for b in range(B):
                 head = 0

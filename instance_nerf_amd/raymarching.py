@@ -169,9 +169,11 @@ def march_rays_patch(rays_o, rays_d, bound, density_bitfield, C, H, nears, fars,
     return xyzs, (ray_ids if table else dirs), deltas, rays
 
 
-def composite_rays_patch(sigmas, rgbs, deltas, rays, T_thresh=1e-4, extra=None, return_weights=False):
+def composite_rays_patch(sigmas, rgbs, deltas, rays, T_thresh=1e-4, extra=None, return_weights=False, skippable=None):
     """Compositing of the patch-interleaved layout (inference only, no autograd).
-    -> weights_sum [N], depth [N], image [N,3] (, extra_out [N,K]) (, weights [M] when return_weights)."""
+    -> weights_sum [N], depth [N], image [N,3] (, extra_out [N,K]) (, weights [M] when return_weights).
+    ``skippable`` (int64 [1] on the device, optional) is incremented by the number of samples that lie behind the
+    point where their whole 16-ray group has terminated - what the early-terminating kernel would not evaluate."""
     lib = _lib.load()
     sigmas, rgbs, deltas = _f(sigmas), _f(rgbs), _f(deltas)
     dev = rays.device
@@ -187,7 +189,8 @@ def composite_rays_patch(sigmas, rgbs, deltas, rays, T_thresh=1e-4, extra=None, 
         ptr(sigmas, F32, "sigmas", allow_none=none_ok), ptr(rgbs, F32, "rgbs", allow_none=none_ok),
         ptr(deltas, F32, "deltas", allow_none=none_ok), ptr(rays, I32, "rays"), N, M, float(T_thresh),
         ptr(_f(extra) if extra is not None else None, allow_none=True), K, ptr(ws), ptr(depth), ptr(image),
-        ptr(extra_out, allow_none=True), ptr(wbuf, allow_none=True), stream_ptr()), "composite_rays_patch_forward")
+        ptr(extra_out, allow_none=True), ptr(wbuf, allow_none=True), ptr(skippable, torch.int64, "skippable", allow_none=True),
+        stream_ptr()), "composite_rays_patch_forward")
     out = (ws, depth, image) + ((extra_out,) if K else ())
     return out + ((wbuf,) if return_weights else ())
 

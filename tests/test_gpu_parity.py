@@ -1005,9 +1005,12 @@ def test_fused_terminate_equals_two_kernel_path(params_k16, room, room_bitfield,
         assert ev > 0.9 * total
 
 
-def test_auto_mode_follows_recent_opacity(params_k16, room, room_bitfield):
-    """infer_mode="auto": the mean opacity of earlier calls (read through a pinned buffer once its copy has landed -
-    no call waits for a previous frame) selects the early-terminating kernel for opaque scenes only."""
+def test_auto_mode_follows_the_skippable_fraction(params_k16, room, room_bitfield):
+    """infer_mode="auto": the fraction of marched samples that lie behind the point where their whole 16-ray group
+    has terminated - counted by the compositing kernel of the two-kernel path, reported by the terminating kernel
+    itself - selects the early-terminating kernel only where it skips enough (read through a pinned buffer once its
+    copy has landed: no call waits for a previous frame).  Opacity alone is not the criterion: a scene can be opaque
+    and still need nearly every sample."""
     from instance_nerf_amd.nerf.utils import get_rays
     poses, intr, H, W = room.cameras(n=2, H=64, W=64, focal=32.0)
     r = get_rays(_t(poses[1:2]), intr, 64, 64, patch=4)
@@ -1019,7 +1022,7 @@ def test_auto_mode_follows_recent_opacity(params_k16, room, room_bitfield):
             first = net.render(r["rays_o"], r["rays_d"], bg_color=1)            # nothing known yet: two-kernel path
             assert "num_evaluated" not in first
             torch.cuda.synchronize()
-            assert (net._recent_opacity() > 0.5) == opaque
+            assert (net._recent_skippable() > net.terminate_above) == opaque
             second = net.render(r["rays_o"], r["rays_d"], bg_color=1)
         assert ("num_evaluated" in second) == opaque
         assert (first["image"] - second["image"]).abs().max() < 1e-4
@@ -1027,8 +1030,17 @@ def test_auto_mode_follows_recent_opacity(params_k16, room, room_bitfield):
             with torch.no_grad():
                 net.render(r["rays_o"], r["rays_d"], bg_color=1)
         torch.cuda.synchronize()
-        net._recent_opacity()
-        assert len(net._opacity_free) == 4 and not net._opacity_pending
+        net._recent_skippable()
+        assert len(net._skippable_free) == 4 and not net._skippable_pending
+        if opaque:        # the counter of the two-kernel path predicts what the terminating kernel really skips
+            with torch.no_grad():
+                t = net.render(r["rays_o"], r["rays_d"], bg_color=1, infer_mode="fused_terminate")
+            real = 1.0 - int(t["num_evaluated"][0]) / int(t["num_samples"][0])
+            net.__dict__.pop("_skippable_value", None)
+            with torch.no_grad():
+                net.render(r["rays_o"], r["rays_d"], bg_color=1, infer_mode="fused")
+            torch.cuda.synchronize()
+            assert abs(net._recent_skippable() - real) < 0.02, (net._recent_skippable(), real)
 
 
 @pytest.mark.parametrize("mode", ["auto", "fused_terminate", "fused"])
@@ -1059,7 +1071,7 @@ def test_staged_render_on_an_opaque_scene_two_frames(params_k16, room, room_bitf
         assert (out["weights_sum"][:1] - whole["weights_sum"]).abs().max() < 1e-4
         assert (out["instance"][:1] - whole["instance"]).abs().max() < 1e-3
     if mode == "auto":
-        assert net._recent_opacity() > 0.5                                      # the second frame took the other branch
+        assert net._recent_skippable() > net.terminate_above                    # the second frame took the other branch
     # the trainer's evaluation calls (default mode, staged) on the same opaque scene, twice
     tr = Trainer("t", None, net, stage="instance", device=torch.device(DEV))
     data = {"rays_o": r["rays_o"], "rays_d": r["rays_d"], "masks": torch.zeros(2, 4096, dtype=torch.int64, device=DEV)}
