@@ -323,15 +323,36 @@ def main():
             except Exception as e:                        # noqa: BLE001
                 ts = tn = {"error": f"{type(e).__name__}: {e}"[:300]}
         else:
-            # the probe contains collectives: a rank that swallowed an exception would leave the others waiting in
-            # all_reduce, so exceptions propagate (non-zero exit, the launcher tears the job down).  The headline
-            # line is kept in a side file first so a failing probe cannot lose the measurement.
+            # The probe contains collectives: a rank that swallowed an exception would leave the others waiting in
+            # all_reduce, so exceptions propagate (non-zero exit, the launcher tears the job down).  Two guards keep
+            # the headline measurement when that happens: the line is put in a side file first, and a watchdog THREAD
+            # on rank 0 (a blocked collective holds the main thread inside C++, where no signal handler runs) prints
+            # the line without the probe's numbers and exits if the probe has not finished after 5 minutes.
+            watchdog = None
             if rank == 0:
                 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
                 with open(os.path.join(ROOT, "gpurun_out", f"bench_headline_n{world}.json"), "w") as f:
                     f.write(json.dumps(line) + "\n")
-            ts = train_probe(dev, rank, world, red_dev)   # every rank runs it
-            tn = train_probe(dev, rank, world, red_dev, stage="nerf")
+                import threading
+
+                def bail():
+                    line["train_step"] = line["train_step_nerf"] = {"error": "training probe did not finish in 300 s"}
+                    print(json.dumps(line), flush=True)
+                    os._exit(0)
+                watchdog = threading.Timer(300.0, bail)
+                watchdog.daemon = True
+                watchdog.start()
+            try:
+                ts = train_probe(dev, rank, world, red_dev)   # every rank runs it
+                tn = train_probe(dev, rank, world, red_dev, stage="nerf")
+            except Exception as e:                            # noqa: BLE001
+                if rank == 0:
+                    line["train_step"] = line["train_step_nerf"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+                    print(json.dumps(line), flush=True)
+                raise
+            finally:
+                if watchdog is not None:
+                    watchdog.cancel()
         if rank == 0:
             line["train_step"] = ts
             line["train_step_nerf"] = tn
