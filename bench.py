@@ -163,6 +163,39 @@ def train_probe(dev, rank=0, world=1, red_dev=None, steps=20, warmup=5, stage="i
             "loss_first": round(first, 4), "loss_last": round(float(last), 4)}
 
 
+def config5_probe(dev):
+    """Secondary measurement, BASELINE configs[4]: rgb-sigma lattice extraction at 160^3 (one fused launch per chunk:
+    gather + sigma net once per voxel, colour net for 4 fixed view directions) + 3-D RoIAlign of 256 boxes to 10^3 bins
+    on a [1,256,40,40,40] feature volume.  Replicas only: one scene per GPU, no collective."""
+    from instance_nerf_amd.extract import extract_rgbsigma
+    from instance_nerf_amd.roi_align.roi_align import roi_align_3d
+    net, _ = build_network(dev)
+    extract_rgbsigma(net, max_side=160)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        _, res = extract_rgbsigma(net, max_side=160)
+    torch.cuda.synchronize()
+    t_ext = (time.perf_counter() - t0) / 5
+    feat = torch.randn(1, 256, 40, 40, 40, device=dev)
+    gen = torch.Generator(device=dev).manual_seed(0)
+    lo = torch.rand(256, 3, device=dev, generator=gen) * 100
+    rois = torch.cat([lo, lo + 10 + torch.rand(256, 3, device=dev, generator=gen) * 50], 1)
+    inds = torch.zeros(256, dtype=torch.int32, device=dev)
+    roi_align_3d(feat, rois, inds, 10, 10, 10, 0.25)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        roi_align_3d(feat, rois, inds, 10, 10, 10, 0.25)
+    torch.cuda.synchronize()
+    t_roi = (time.perf_counter() - t0) / 10
+    n = int(res.prod())
+    return {"workload": "rgb-sigma extraction 160^3 (4 view directions) + RoIAlign-3D 256 boxes -> 10^3 x 256 ch on "
+                        "[1,256,40,40,40] (BASELINE configs[4]), per GPU",
+            "extract_ms": round(t_ext * 1e3, 3), "extract_mvoxels_per_s": round(n / t_ext / 1e6, 1),
+            "roi_align_forward_ms": round(t_roi * 1e3, 3)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -356,6 +389,10 @@ def main():
         if rank == 0:
             line["train_step"] = ts
             line["train_step_nerf"] = tn
+            try:                                              # no collective inside: rank 0 alone
+                line["extract_roialign"] = config5_probe(dev)
+            except Exception as e:                            # noqa: BLE001
+                line["extract_roialign"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -267,6 +267,12 @@ int inr_instance_forward_train(const float* x, int64_t M, float bound, const flo
 int inr_instance_backward(const float* grad_logits, int32_t K, const float* h1, const float* h2, int64_t M,
                           const float* packed_bwd, float* grad_z2, float* grad_z1, float* grad_enc,
                           inr_stream_t s);
+/* rgb-sigma lattice extraction (the step after the path that feeds NeRF-RCNN: /root/reference/nerf_rcnn/datasets.py:766-792
+ * reads the result): out[m] = (mean over n_dirs fixed view directions of rgb(x_m, dir), raw density logit of x_m) -
+ * one gather + one sigma-net pass per point, the colour net once per direction.  sh_dirs [n_dirs,16] = degree-4 SH rows
+ * of the directions (inr_sh_encode_forward), n_dirs <= 8; out float [M,4], 16-byte aligned.                            */
+int inr_nerf_forward_dirs(const float* x, int64_t M, float bound, const float* embeddings, const inr_grid_desc* desc /*host*/,
+                          const float* packed /*device*/, const float* sh_dirs, int32_t n_dirs, float* out, inr_stream_t s);
 int inr_instance_forward(const float* x, int64_t M, const int32_t* n_samples_dev, float bound,
                          const float* embeddings, const inr_grid_desc* desc /*host*/,
                          const float* packed /*device*/, int32_t K, float* logits /*[M,K]*/,

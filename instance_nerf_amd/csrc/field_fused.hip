@@ -767,6 +767,75 @@ __global__ void __launch_bounds__(kFieldThreads, INR_FIELD_MIN_WAVES) k_nerf_fwd
   }
 }
 
+// ---- rgb-sigma lattice extraction (BASELINE configs[4]) ---------------------------------------
+// out[m] = (mean over D fixed view directions of rgb(x_m, dir), raw density logit h0(x_m)): ONE gather and ONE
+// sigma-net pass per point, then the colour net once per direction with the direction's SH row as a wave-uniform
+// operand (staged in LDS).  Replaces density() + D x color() through the unfused encoder / BLAS path.
+constexpr int kMaxExtractDirs = 8;
+__global__ void __launch_bounds__(kFieldThreads, INR_FIELD_MIN_WAVES) k_nerf_fwd_dirs(
+    const float* __restrict__ x, int64_t M, float bound, const float2* __restrict__ emb, uint32_t emb_bytes, GridDesc G,
+    const float4* __restrict__ packed, const float* __restrict__ sh_dirs /*[D,16]*/, int D, float4* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float4 wl[];
+  constexpr int kStage = kNerfFloats / 4;
+  for (int i = threadIdx.x; i < kStage; i += kFieldThreads) wl[i] = packed[i];
+  LevelRec* recs = reinterpret_cast<LevelRec*>(wl + kStage);
+  stage_level_recs(G, recs);
+  float* shl = reinterpret_cast<float*>(recs + 16);                   // [D][q][ks]: lane q's four components per direction
+  for (int i = threadIdx.x; i < D * 16; i += kFieldThreads) {
+    const int d = i >> 4, qq = (i >> 2) & 3, ks = i & 3;
+    shl[i] = sh_dirs[d * 16 + 4 * ks + qq];
+  }
+  __syncthreads();
+  constexpr int kWaves = kFieldThreads / 64;
+  const int lane = threadIdx.x & 63, q = lane >> 4, j = lane & 15;
+  const int64_t n_tiles = (M + 15) >> 4;
+  const float rb = 2.0f * bound;
+  const TileSched sched = make_sched(n_tiles, kWaves);
+  const bool all_hashed[4] = {slot_all_hashed(G, 0), slot_all_hashed(G, 1), slot_all_hashed(G, 2), slot_all_hashed(G, 3)};
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)emb, 0, (int)emb_bytes, 0x00020000);
+  const float inv_d = 1.0f / (float)D;
+  for (int64_t it = 0, tile = sched.tile(0); tile < sched.hi; tile = sched.tile(++it)) {
+    const int64_t m = tile * 16 + j;
+    const bool valid = m < M;
+    TileIn me;
+    load_tile_in<false>(x, nullptr, valid ? m : M - 1, bound, rb, 0.0f, me);
+    f32x4 enc[2];
+    {
+      Gathered g;
+      uint32_t rec_off = (uint32_t)q * 4u * (uint32_t)sizeof(LevelRec);
+      asm volatile("" : "+v"(rec_off));
+      issue_gathers(reinterpret_cast<const LevelRec*>(reinterpret_cast<const char*>(recs) + rec_off), all_hashed, rsrc,
+                    me.x0, me.x1, me.x2, g);
+      __builtin_amdgcn_sched_barrier(0);
+      blend(g, enc[0], enc[1]);
+    }
+    if (me.oob) enc[0] = enc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 h1[4], h2[1];
+    mlp_layer<4, 2>(wl + kSig0 / 4, lane, enc, h1);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) h1[t] = relu4(h1[t]);
+    mlp_layer<1, 4>(wl + kSig1 / 4, lane, h1, h2);
+    float r = 0.f, g = 0.f, b = 0.f;
+    for (int d = 0; d < D; ++d) {                                       // wave-uniform trip count
+      f32x4 cin[2], c1[4], c2[4], o[1];
+      const float4 s4 = *reinterpret_cast<const float4*>(shl + d * 16 + q * 4);
+      cin[0] = f32x4{s4.x, s4.y, s4.z, s4.w};
+      cin[1] = h2[0];
+      mlp_layer<4, 2>(wl + kCol0 / 4, lane, cin, c1);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) c1[t] = relu4(c1[t]);
+      mlp_layer<4, 4>(wl + kCol1 / 4, lane, c1, c2);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) c2[t] = relu4(c2[t]);
+      mlp_layer<1, 4>(wl + kCol2 / 4, lane, c2, o);
+      r += __frcp_rn(1.0f + __expf(-o[0][0]));
+      g += __frcp_rn(1.0f + __expf(-o[0][1]));
+      b += __frcp_rn(1.0f + __expf(-o[0][2]));
+    }
+    if (valid && q == 0) out[m] = make_float4(r * inv_d, g * inv_d, b * inv_d, h2[0][0]);
+  }
+}
+
 // kSave (training): the encoder output and the two hidden activations are also written, row-major, for the
 // weight gradients and the ReLU masks of k_instance_bwd.
 template <int K_MT, bool kSave = false>
@@ -1413,6 +1482,27 @@ int inr_nerf_forward_table(const float* x01, const int32_t* ray_ids, const float
       reinterpret_cast<const float4*>(packed), density_scale, sigma, rgb, nullptr, ray_ids,
       reinterpret_cast<const float4*>(sh_table_q), NerfSave{});
   return check_launch("nerf_forward_table");
+}
+
+int inr_nerf_forward_dirs(const float* x, int64_t M, float bound, const float* embeddings, const inr_grid_desc* desc,
+                          const float* packed, const float* sh_dirs, int32_t n_dirs, float* out, inr_stream_t s) {
+  INR_REQUIRE(M >= 0 && desc, "bad argument");
+  if (M == 0) return INR_OK;
+  INR_REQUIRE(x && embeddings && packed && sh_dirs && out, "null pointer");
+  INR_REQUIRE(n_dirs >= 1 && n_dirs <= kMaxExtractDirs, "1..8 view directions");
+  INR_REQUIRE(((uintptr_t)embeddings & 7) == 0 && ((uintptr_t)packed & 15) == 0 && ((uintptr_t)out & 15) == 0,
+              "embeddings/packed/out misaligned");
+  GridDesc G;
+  int rc = make_grid_desc(desc, G);
+  if (rc) return rc;
+  const uint64_t emb_bytes64 = (uint64_t)desc->offsets[desc->num_levels] * 8ull;
+  INR_REQUIRE(emb_bytes64 < (1ull << 31), "table larger than 2 GiB is not addressable by the 32-bit gather offsets");
+  const size_t lds = kNerfFloats * sizeof(float) + kLevelRecBytes + kMaxExtractDirs * 16 * sizeof(float);
+  const int grid = grid_for(k_nerf_fwd_dirs, lds, (M + 15) / 16);
+  k_nerf_fwd_dirs<<<grid, kFieldThreads, lds, as_stream(s)>>>(x, M, bound, reinterpret_cast<const float2*>(embeddings),
+                                                              (uint32_t)emb_bytes64, G, reinterpret_cast<const float4*>(packed),
+                                                              sh_dirs, n_dirs, reinterpret_cast<float4*>(out));
+  return check_launch("nerf_forward_dirs");
 }
 
 int inr_instance_forward(const float* x, int64_t M, const int32_t* n_samples_dev, float bound, const float* embeddings,

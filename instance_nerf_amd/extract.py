@@ -11,7 +11,8 @@ The reference's extractor lives in a third repository (a fork of instant-ngp,
 * ``resolution`` int ``[3] = (W, L, H)``, longest side <= 160 (train_rpn.sh:11, poolers.py:40);
 * ``bbox_min``, ``bbox_max``, ``scale``, ``offset``, ``from_mitsuba``.
 
-Queries go through ``NeRFNetwork.density`` / ``.color`` (the fused HIP field kernel).  Choices made here
+Queries go through ``NeRFNetwork.forward_dirs`` (one fused HIP launch per chunk: gather + sigma net once per
+point, colour net once per view direction; ``density`` / ``color`` for non-standard architectures).  Choices made here
 because the reference extractor is unseen: voxel-CENTRE positions; rgb = mean over 4 fixed view
 directions (the tetrahedron (1,1,1), (1,-1,-1), (-1,1,-1), (-1,-1,1), normalised).
 """
@@ -54,6 +55,11 @@ def extract_rgbsigma(model, bbox_min=None, bbox_max=None, max_side=160, res=None
     model.eval()
     for s in range(0, pts.shape[0], chunk):
         x = pts[s:s + chunk].clamp(-b, b)
+        fused = model.forward_dirs(x, dirs) if hasattr(model, "forward_dirs") else None
+        if fused is not None:                  # one launch: gather + sigma net once, colour net per direction
+            out[s:s + chunk] = fused
+            out[s:s + chunk, 3].clamp_(min=float(np.log(1e-30)))
+            continue
         den = model.density(x)
         rgb = torch.zeros(x.shape[0], 3, dtype=torch.float32, device=dev)
         for v in range(dirs.shape[0]):

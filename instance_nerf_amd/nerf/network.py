@@ -323,6 +323,25 @@ class NeRFNetwork(NeRFRenderer):
               "nerf_forward_table")
         return sigma, rgb
 
+    @torch.no_grad()
+    def forward_dirs(self, x, dirs):
+        """x [M,3], dirs [D,3] unit (D <= 8) -> float [M,4] = (rgb averaged over the D view directions, raw density
+        logit = log sigma): one gather and one sigma-net pass per point, the colour net once per direction, in one
+        launch (the rgb-sigma lattice extraction, ``instance_nerf_amd/extract.py``).  None when the fused kernel does
+        not apply."""
+        if not self._fusable:
+            return None
+        lib = _lib.load()
+        x = x.contiguous().float()
+        M, D = x.shape[0], dirs.shape[0]
+        sh = self.encoder_dir(dirs.to(x.device).contiguous().float()).contiguous()          # [D,16] (HIP SH kernel)
+        out = torch.empty(M, 4, dtype=torch.float32, device=x.device)
+        check(lib.inr_nerf_forward_dirs(ptr(x, torch.float32, "x", allow_none=M == 0), M, float(self.bound),
+                                        ptr(self.encoder.embeddings.data, torch.float32), self.encoder.desc,
+                                        ptr(self._packed_weights("nerf")), ptr(sh, torch.float32, "sh_dirs"), D,
+                                        ptr(out, allow_none=M == 0), stream_ptr()), "nerf_forward_dirs")
+        return out
+
     # ---- upstream API -----------------------------------------------------------------------------
     def forward(self, x, d):
         """x [M,3] in [-bound,bound], d [M,3] unit -> sigma [M], color [M,3]."""

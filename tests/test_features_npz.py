@@ -63,3 +63,15 @@ def test_extract_matches_oracle_field(level_table, params_k16):
     got = grid.view(-1, 4).cpu()
     assert torch.allclose(got[:, 3], den["sigma_raw"], atol=1e-4, rtol=1e-4)
     assert (got[:, :3] - rgb).abs().max() < 1e-4
+    # the one-launch path (forward_dirs) and the density() + 4 x color() path agree; ragged size, points on the faces
+    net.forward_dirs, fused = (lambda x, d: None), net.forward_dirs
+    slow, _ = extract_rgbsigma(net, res=[12, 10, 8])
+    net.forward_dirs = fused
+    assert (slow - grid).abs().max() < 1e-4
+    x = torch.rand(1003, 3, device=grid.device) * 2 - 1
+    x[:3] = torch.tensor([[1.0, 1, 1], [-1.0, -1, -1], [1.0, -1, 0.25]], device=grid.device)
+    out = net.forward_dirs(x, torch.from_numpy(VIEW_DIRS[:3]))
+    with torch.no_grad():
+        d3 = field.density(x.cpu(), params_k16, 1.0, level_table)
+        rgb3 = sum(field.color(torch.from_numpy(VIEW_DIRS[v]).expand(1003, 3), d3["geo_feat"], params_k16) for v in range(3)) / 3
+    assert (out[:, :3].cpu() - rgb3).abs().max() < 1e-4 and torch.allclose(out[:, 3].cpu(), d3["sigma_raw"], atol=1e-4, rtol=1e-4)
