@@ -151,11 +151,6 @@ __device__ __forceinline__ u32x2 gather_row(__amdgpu_buffer_rsrc_t rsrc, uint32_
   return __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)byte_off, 0, kAux);
 }
 
-#ifndef INR_XPAIR
-#define INR_XPAIR 1
-#endif
-
-#if INR_XPAIR
 // Lane-paired gather for the FINE slots (levels 8..15).  Measured on MI355X (tools/micro/gather_bench.hip): the vector
 // memory path prices a gather instruction by the number of DISTINCT 128-byte lines its 64 lanes touch - any two lanes
 // of the wave that hit the same line share one look-up (1.6 distinct lines per clock per CU out of the L1, 0.45 out of
@@ -322,79 +317,10 @@ __device__ __forceinline__ void blend(const Gathered& g, f32x4& lo, f32x4& hi) {
     hi[t] = __uint_as_float(r0) + __uint_as_float(r1);      // = x side 0 + x side 1 in both lanes
   }
 }
-#else
-struct Gathered {
-  u32x2 v[4][8];      // raw table rows (float2 bits), [level][corner]
-  float fx[4], fy[4], fz[4];
-};
 
-__device__ __forceinline__ void issue_gathers(const LevelRec* __restrict__ my_recs, const bool (&all_hashed)[4],
-                                              __amdgpu_buffer_rsrc_t rsrc, float x0, float x1, float x2, Gathered& g) {
-#pragma unroll
-  for (int li = 0; li < 4; ++li) {
-    const uint4 ra = my_recs[li].a;
-    const float s = __uint_as_float(ra.x);
-    const uint32_t base = ra.y, pa = ra.z, pb = ra.w;
-    const uint32_t mask = my_recs[li].b.x;
-    const float px = x0 * s + 0.5f, py = x1 * s + 0.5f, pz = x2 * s + 0.5f;   // mul, add: not fused
-    const float flx = floorf(px), fly = floorf(py), flz = floorf(pz);
-    g.fx[li] = px - flx; g.fy[li] = py - fly; g.fz[li] = pz - flz;
-    const uint32_t cx = (uint32_t)flx, cy = (uint32_t)fly, cz = (uint32_t)flz;
-    const uint32_t hy0 = cy * pa, hy1 = hy0 + pa;
-    const uint32_t hz0 = cz * pb, hz1 = hz0 + pb;
-    if (all_hashed[li]) {              // wave-uniform: xor-only index maths
-      const uint32_t yz[4] = {hy0 ^ hz0, hy1 ^ hz0, hy0 ^ hz1, hy1 ^ hz1};
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const uint32_t idx = ((cx + (k & 1)) ^ yz[k >> 1]) & mask;
-        g.v[li][k] = li < 2 ? gather_row<INR_AUX_COARSE>(rsrc, base + idx * 8u) : gather_row<INR_AUX_FINE>(rsrc, base + idx * 8u);
-      }
-    } else {
-      const bool h = my_recs[li].b.y != 0;
-      const uint32_t yz[4] = {h ? (hy0 ^ hz0) : (hy0 + hz0), h ? (hy1 ^ hz0) : (hy1 + hz0),
-                              h ? (hy0 ^ hz1) : (hy0 + hz1), h ? (hy1 ^ hz1) : (hy1 + hz1)};
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const uint32_t c = cx + (k & 1);
-        const uint32_t idx = (h ? (c ^ yz[k >> 1]) : (c + yz[k >> 1])) & mask;
-        g.v[li][k] = li < 2 ? gather_row<INR_AUX_COARSE>(rsrc, base + idx * 8u) : gather_row<INR_AUX_FINE>(rsrc, base + idx * 8u);
-      }
-    }
-  }
-}
-
-// trilinear blend in corner order: weight = (wx*wy)*wz, accumulate with fmaf.
-// out[s], s = 0..7 <-> feature 16*(s>>2) + 4q + (s&3).
-__device__ __forceinline__ void blend(const Gathered& g, f32x4& lo, f32x4& hi) {
-  float f[8];
-#pragma unroll
-  for (int li = 0; li < 4; ++li) {
-    float ax = 0.f, ay = 0.f;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const float wx = (k & 1) ? g.fx[li] : 1.0f - g.fx[li];
-      const float wy = (k & 2) ? g.fy[li] : 1.0f - g.fy[li];
-      const float wz = (k & 4) ? g.fz[li] : 1.0f - g.fz[li];
-      const float w = (wx * wy) * wz;
-      // (extract to scalars first: __builtin_bit_cast on a vector-element expression reads
-      //  element 0 for every index with this clang)
-      const unsigned bx = g.v[li][k][0], by = g.v[li][k][1];
-      ax = fmaf(w, __uint_as_float(bx), ax);
-      ay = fmaf(w, __uint_as_float(by), ay);
-    }
-    f[2 * li] = ax;
-    f[2 * li + 1] = ay;
-  }
-  lo[0] = f[0]; lo[1] = f[1]; lo[2] = f[2]; lo[3] = f[3];
-  hi[0] = f[4]; hi[1] = f[5]; hi[2] = f[6]; hi[3] = f[7];
-}
-
-#endif
-
-// (An x-split gather - 8 lanes per sample so that the two x-neighbour corners of a cell are fetched by one
-// instruction and share one L1 look-up - was built and measured: it halves the look-ups but not the time at 16
-// waves/CU, and costs 11 % in the final 8 waves/CU regime where the VALU is the busiest unit.  Removed; see
-// DESIGN.md section 3 and the git history.)
+// (Round 1 had tried an x-split with EIGHT lanes per sample - twice the index maths per sample - and lost 11 % in
+// the VALU-bound regime.  The pairing above keeps four lanes per sample and 32 loads per lane; only the fine levels'
+// cell location is duplicated.)
 
 // One MLP layer: out[mt] (N_MT output tiles) = W * in, K = 16 * N_G inputs.  in[g] is the B
 // operand of k-steps 4g..4g+3.  The N_MT accumulator chains are interleaved (independent
