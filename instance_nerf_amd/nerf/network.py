@@ -67,6 +67,11 @@ def _table_backward(lib, x, denc, desc, M, bound, g_emb, emb):
     the buffer is half reduced (tests/test_gpu_ddp.py caught exactly that: one run in three diverged)."""
     from .utils import grad_sync
     L = int(desc.num_levels)
+    if grad_sync.active() and emb.data_ptr() in grad_sync.early:
+        # a second backward before allreduce_gradients(): the first gradient is already being summed over the ranks,
+        # adding an unreduced one to it cannot be reduced correctly afterwards
+        raise RuntimeError("gradient accumulation over several backward passes is not supported together with the "
+                           "overlapped table-gradient all-reduce; set INR_GRAD_OVERLAP=0")
     overlap = grad_sync.active() and L > 8 and emb.grad is None
     for lo, hi in (((8, L), (0, 8)) if overlap else ((0, L),)):
         check(lib.inr_grid_encode_backward_levels(ptr(x), ptr(denc), None, desc, M, float(bound), ptr(g_emb), lo, hi,
