@@ -623,6 +623,58 @@ __global__ void __launch_bounds__(kCoopRaysPerBlock * 64) k_march_write_coop(Mar
   else march_ray_coop<false>(P, r, t0, fars[n], cnt, put);
 }
 
+// ---- mask-supervised loss of the instance stage: cross entropy of the rendered logits against the
+// matched-mask ids, ignore_index rows skipped, mean over the kept rows - forward value AND d loss / d logits in two
+// launches (torch needs log_softmax, nll_loss and their two backward kernels plus fills).  One wave per row
+// (K <= 64 classes, lane = class), at most kCeBlocks workgroups; every workgroup leaves (sum of its row losses, its
+// kept rows) in part[block] - NO atomics: a first version added every wave's sum to one address and took 96 us for
+// 4096 rows, same-address float atomics from different CUs serialise at ~12 ns each.
+constexpr int kCeBlocks = 64;
+__global__ void __launch_bounds__(256) k_ce_rows(const float* __restrict__ logits, const int64_t* __restrict__ labels,
+                                                 int64_t N, int K, int64_t ignore_index, float* __restrict__ dlogits,
+                                                 float2* __restrict__ part) {
+  __shared__ float2 red[4];
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  float loss_sum = 0.f, kept = 0.f;
+  for (int64_t r = wave; r < N; r += n_waves) {
+    const int64_t y = labels[r];
+    const bool keep = y != ignore_index && y >= 0 && y < K;
+    const float x = lane < K ? logits[r * K + lane] : -INFINITY;
+    float m = x;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
+    const float e = lane < K ? expf(x - m) : 0.f;
+    float ssum = e;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) ssum += __shfl_xor(ssum, d, 64);
+    const float xy = __shfl(x, keep ? (int)y : 0, 64);
+    if (keep) {
+      loss_sum += (m + logf(ssum)) - xy;
+      kept += 1.f;
+    }
+    if (lane < K) dlogits[r * K + lane] = keep ? e / ssum - (lane == (int)y ? 1.f : 0.f) : 0.f;
+  }
+  if (lane == 0) red[threadIdx.x >> 6] = make_float2(loss_sum, kept);
+  __syncthreads();
+  if (threadIdx.x == 0)
+    part[blockIdx.x] = make_float2(red[0].x + red[1].x + red[2].x + red[3].x, red[0].y + red[1].y + red[2].y + red[3].y);
+}
+// dlogits *= 1 / kept; loss = sum / kept (NaN when nothing is kept, as torch's mean over an empty set)
+__global__ void __launch_bounds__(256) k_ce_scale(float* __restrict__ dlogits, int64_t n, const float2* __restrict__ part,
+                                                  int n_part, float* __restrict__ loss) {
+  float sum = 0.f, kept = 0.f;
+  for (int i = 0; i < n_part; ++i) {               // <= 64 pairs, the same order in every thread
+    const float2 p = part[i];
+    sum += p.x;
+    kept += p.y;
+  }
+  const float inv = kept > 0.f ? 1.0f / kept : 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dlogits[i] *= inv;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *loss = sum / kept;
+}
+
 // tail of run_cuda (a14): image += (1 - weights_sum) * bg, depth = clamp(depth - near, 0) / (far - near); one launch
 // instead of seven elementwise ones (no-grad use only)
 __global__ void __launch_bounds__(256) k_finish_rays(const float* image, const float* depth,
@@ -1381,6 +1433,22 @@ int inr_compact_alive(const int32_t* rays_alive, int64_t n_alive, int32_t* out, 
   k_scan_block_sums<<<1, 1024, 0, st>>>(block_sums, (int)nb, n_alive, n_out);
   k_alive_scatter<<<nb, kRayBlock, 0, st>>>(rays_alive, n_alive, block_sums, out);
   return check_launch("compact_alive");
+}
+
+int inr_cross_entropy(const float* logits, const int64_t* labels, int64_t N, int32_t K, int64_t ignore_index,
+                      float* grad_logits, float* acc, float* loss, inr_stream_t s) {
+  INR_REQUIRE(N >= 0 && K > 0 && K <= 64, "K must be in 1..64");
+  INR_REQUIRE(acc && loss && ((uintptr_t)acc & 7) == 0, "null or misaligned pointer");
+  hipStream_t st = as_stream(s);
+  int nb = 0;
+  if (N > 0) {
+    INR_REQUIRE(logits && labels && grad_logits, "null pointer");
+    nb = (int)std::min<int64_t>((N + 3) / 4, kCeBlocks);
+    k_ce_rows<<<nb, 256, 0, st>>>(logits, labels, N, K, ignore_index, grad_logits, reinterpret_cast<float2*>(acc));
+  }
+  const unsigned nb2 = (unsigned)std::max<int64_t>(1, std::min<int64_t>((N * K + 255) / 256, (int64_t)cu_count() * 4));
+  k_ce_scale<<<nb2, 256, 0, st>>>(grad_logits, N * K, reinterpret_cast<const float2*>(acc), nb, loss);
+  return check_launch("cross_entropy");
 }
 
 int inr_finish_rays(const float* image, const float* depth, const float* weights_sum, const float* nears,

@@ -535,7 +535,11 @@ class Trainer:
             return pred, data["images"], loss
         logits = outputs["instance"]
         K = logits.shape[-1]
-        loss = torch.nn.functional.cross_entropy(logits.reshape(-1, K), data["masks"].reshape(-1).long(), ignore_index=-1)
+        if logits.is_cuda and K <= 64 and logits.dtype == torch.float32:
+            from .. import raymarching
+            loss = raymarching.cross_entropy(logits.reshape(-1, K), data["masks"].reshape(-1), ignore_index=-1)
+        else:
+            loss = torch.nn.functional.cross_entropy(logits.reshape(-1, K), data["masks"].reshape(-1).long(), ignore_index=-1)
         return logits, data["masks"], loss
 
     @torch.no_grad()

@@ -340,3 +340,32 @@ def compact_alive(rays_alive, n_alive):
           "compact_alive")
     n = int(n_out[0].item())
     return out[:n], n
+
+
+class _CrossEntropy(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels, ignore_index):
+        lib = _lib.load()
+        logits = _f(logits)
+        labels = labels.contiguous().long()
+        N, K = logits.shape
+        grad = torch.empty_like(logits)
+        acc = torch.empty(128, dtype=F32, device=logits.device)
+        loss = torch.empty((), dtype=F32, device=logits.device)
+        check(lib.inr_cross_entropy(ptr(logits, F32, "logits", allow_none=N == 0),
+                                    ptr(labels, torch.int64, "labels", allow_none=N == 0), N, K, int(ignore_index),
+                                    ptr(grad, allow_none=N == 0), ptr(acc), ptr(loss), stream_ptr()), "cross_entropy")
+        ctx.save_for_backward(grad)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None, None
+
+
+def cross_entropy(logits, labels, ignore_index=-1):
+    """Mean cross entropy of logits [N,K] (K <= 64) against int64 labels [N], rows with ``ignore_index`` skipped - the
+    mask-supervised loss of the instance stage - value and gradient in two HIP launches instead of
+    torch's log_softmax / nll_loss pairs.  Same semantics as ``F.cross_entropy(logits, labels, ignore_index=...)``."""
+    return _CrossEntropy.apply(logits, labels, ignore_index)

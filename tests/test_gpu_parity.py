@@ -484,6 +484,32 @@ def test_render_train_golden_and_gradients(params_k16, room, room_bitfield, leve
     assert net.encoder.embeddings.grad is None            # NeRF stayed frozen
 
 
+@pytest.mark.parametrize("K,N", [(64, 4096), (16, 777), (37, 5), (64, 0)])
+def test_cross_entropy_matches_torch(K, N):
+    """The instance stage's loss (mean CE, ignore_index -1) - value and gradient - against F.cross_entropy: ragged
+    sizes, K not a power of two, every row ignored (NaN, as torch), an upstream gradient other than 1."""
+    from instance_nerf_amd import raymarching
+    gen = torch.Generator().manual_seed(K + N)
+    logits = (torch.randn(N, K, generator=gen) * 4).to(DEV)
+    labels = torch.randint(0, K, (N,), generator=gen)
+    labels[torch.rand(N, generator=gen) < 0.2] = -1
+    labels = labels.to(DEV)
+    a = logits.clone().requires_grad_(True)
+    b = logits.clone().requires_grad_(True)
+    la = raymarching.cross_entropy(a, labels, ignore_index=-1)
+    lb = torch.nn.functional.cross_entropy(b, labels, ignore_index=-1)
+    if N == 0 or (labels >= 0).sum() == 0:
+        assert torch.isnan(la) and torch.isnan(lb)
+        return
+    assert abs(float(la) - float(lb)) < 1e-5 * max(1.0, abs(float(lb)))
+    (la * 2.5).backward()
+    (lb * 2.5).backward()
+    assert (a.grad - b.grad).abs().max() < 1e-6
+    assert (a.grad[labels < 0] == 0).all()
+    la2 = raymarching.cross_entropy(logits, torch.full_like(labels, -1))
+    assert torch.isnan(la2)
+
+
 def test_adam_matches_torch():
     import ctypes
     from instance_nerf_amd import _lib
