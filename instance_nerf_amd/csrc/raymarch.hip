@@ -1340,7 +1340,7 @@ int inr_march_rays_train_write(const float* rays_o, const float* rays_d, const u
   INR_REQUIRE(rays_o && rays_d && bitfield && nears && fars && rays, "null pointer");
   INR_REQUIRE(N > 0 && M >= 0, "bad sizes");
   if (M == 0) return INR_OK;
-  INR_REQUIRE(xyzs && dirs && deltas, "null output");
+  INR_REQUIRE(M == 0 || (xyzs && dirs && deltas), "null output");
   const MarchParams P = make_params(bitfield, bound, dt_gamma, max_steps, cascade, H);
   INR_REQUIRE(sample_cap == 0 || workspace, "sample_cap > 0 needs the workspace of the count pass");
   const uint32_t* mask = sample_cap > 0 ? reinterpret_cast<const uint32_t*>(reinterpret_cast<const int32_t*>(workspace) + ws_ints(N)) : nullptr;
@@ -1362,7 +1362,7 @@ int inr_march_rays_patch_write(const float* rays_o, const float* rays_d, const u
   INR_REQUIRE(rays_o && rays_d && bitfield && nears && fars && rays, "null pointer");
   INR_REQUIRE(N > 0 && M >= 0, "bad sizes");
   if (M == 0) return INR_OK;
-  INR_REQUIRE(xyzs && deltas && (dirs || ray_ids), "null output");
+  INR_REQUIRE(M == 0 || (xyzs && deltas && (dirs || ray_ids)), "null output");
   const MarchParams P = make_params(bitfield, bound, dt_gamma, max_steps, cascade, H);
   INR_REQUIRE(sample_cap == 0 || workspace, "sample_cap > 0 needs the workspace of the count pass");
   const uint32_t* mask = sample_cap > 0 ? reinterpret_cast<const uint32_t*>(reinterpret_cast<const int32_t*>(workspace) + ws_ints(N)) : nullptr;
@@ -1386,7 +1386,7 @@ int inr_composite_rays_patch_forward(const float* sigmas, const float* rgbs, con
   k_composite_patch_fwd<<<blocks_for(N, kRayBlock), kRayBlock, 0, st>>>(sigmas, rgbs, deltas, rays, N, M, T_thresh,
                                                                         weights, weights_sum, depth, image,
                                                                         reinterpret_cast<unsigned long long*>(skippable));
-  if (extra)
+  if (extra_out && K > 0)     // also with no sample at all (M == 0, extra null): the rows of extra_out must be zeroed
     k_composite_patch_extra<<<blocks_for(N * 64, kRayBlock), kRayBlock, 0, st>>>(weights, extra, rays, N, M, K,
                                                                                  extra_out);
   return check_launch("composite_rays_patch_forward");
@@ -1468,13 +1468,14 @@ int inr_composite_rays_train_forward(const float* sigmas, const float* rgbs, con
                                      inr_stream_t s) {
   INR_REQUIRE(rays && weights_sum && depth && image && N >= 0 && M >= 0, "bad argument");
   INR_REQUIRE(!extra || (extra_out && weights && K > 0 && K <= 64), "extra needs extra_out, weights and 0 < K <= 64");
+  INR_REQUIRE(!extra_out || M == 0 || (extra && weights), "extra_out needs extra and weights");
   if (N == 0) return INR_OK;
-  INR_REQUIRE(sigmas && rgbs && deltas, "null sample arrays");
+  INR_REQUIRE(M == 0 || (sigmas && rgbs && deltas), "null sample arrays");   // M == 0: every ray is dropped
   INR_REQUIRE(((uintptr_t)deltas & 7) == 0, "deltas must be 8-byte aligned");
   hipStream_t st = as_stream(s);
   k_composite_train_fwd<<<blocks_for(N * 64, kRayBlock), kRayBlock, 0, st>>>(sigmas, rgbs, deltas, rays, N, M, T_thresh,
                                                                              weights_sum, depth, image, weights);
-  if (extra)
+  if (extra_out && K > 0)     // also with no sample at all (M == 0, extra null): the rows of extra_out must be zeroed
     k_composite_train_extra_fwd<<<blocks_for(N * 64, kRayBlock), kRayBlock, 0, st>>>(weights, extra, rays, N, M, K,
                                                                                      extra_out);
   return check_launch("composite_rays_train_forward");
@@ -1489,10 +1490,10 @@ int inr_composite_rays_train_backward(const float* grad_weights_sum, const float
   (void)extra;
   INR_REQUIRE(rays && N >= 0 && M >= 0, "bad argument");
   INR_REQUIRE((grad_sigmas != nullptr) == (grad_rgbs != nullptr), "grad_sigmas and grad_rgbs go together");
-  INR_REQUIRE(!grad_sigmas || (grad_image && weights_sum && image && sigmas && rgbs && deltas), "null pointer");
-  INR_REQUIRE(!grad_extra_out || (grad_extra && weights && K > 0 && K <= 64),
+  INR_REQUIRE(!grad_sigmas || (grad_image && weights_sum && image && (M == 0 || (sigmas && rgbs && deltas))), "null pointer");
+  INR_REQUIRE(!grad_extra_out || M == 0 || (grad_extra && weights && K > 0 && K <= 64),
               "grad_extra_out needs grad_extra, weights and 0 < K <= 64");
-  if (N == 0) return INR_OK;
+  if (N == 0 || M == 0) return INR_OK;       // no sample: nothing to write (every ray is dropped)
   hipStream_t st = as_stream(s);
   if (grad_sigmas)   // null: the density/colour field is frozen (instance stage) - only the K channels flow back
     k_composite_train_bwd<<<blocks_for(N * 64, kRayBlock), kRayBlock, 0, st>>>(grad_weights_sum, grad_image, sigmas,

@@ -860,6 +860,60 @@ def test_generic_sampler_without_cuda_ray(params_k16, room, level_table):
     assert net.encoder.embeddings.grad.abs().sum() > 0 and net.color_net[2].weight.grad.abs().sum() > 0
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_composite_fuzz_against_the_c_oracle(rm, seed):
+    """Random ray sets - empty rays, single-sample rays, rays that terminate early (large sigma), K = 0 / 16 / 64 extra
+    channels, sample buffers smaller than the total (dropped rays) - training compositing forward against the scalar
+    C restatement, and the patch-interleaved inference compositing against the same numbers."""
+    from oracle import c_port
+    rng = np.random.default_rng(700 + seed)
+    N = int(rng.choice([1, 16, 33, 500]))
+    cnt = rng.integers(0, 90, size=N).astype(np.int32)
+    cnt[rng.random(N) < 0.15] = 0
+    off = np.concatenate([[0], np.cumsum(cnt)[:-1]]).astype(np.int32)
+    total = int(cnt.sum())
+    rays = np.stack([rng.permutation(N).astype(np.int32), off, cnt], -1)
+    M = total if seed % 2 == 0 else max(total - int(cnt[-1]) - 1, 0)          # odd seeds: the last ray does not fit
+    sig = (rng.random(max(total, 1)) ** 3 * float(rng.choice([1.0, 40.0, 2000.0]))).astype(np.float32)
+    rgb = rng.random((max(total, 1), 3)).astype(np.float32)
+    dl = np.stack([np.full(max(total, 1), 3.4e-3, np.float32), rng.random(max(total, 1)).astype(np.float32) * 0.05], -1)
+    K = int(rng.choice([0, 16, 64]))
+    ex = rng.normal(size=(max(total, 1), K)).astype(np.float32) if K else None
+    ref = c_port.composite_rays_train(sig[:M], rgb[:M], dl[:M], rays, 1e-4, extra=None if ex is None else ex[:M])
+    out = rm.composite_rays_train(_t(sig[:M]), _t(rgb[:M]), _t(dl[:M]), _t(rays), 1e-4, extra=None if ex is None else _t(ex[:M]))
+    assert np.abs(out[0].cpu().numpy() - ref["weights_sum"]).max() < 2e-6
+    assert np.abs(out[1].cpu().numpy() - ref["depth"]).max() < 1e-5
+    assert np.abs(out[2].cpu().numpy() - ref["image"]).max() < 2e-6
+    if K:
+        assert np.abs(out[3].cpu().numpy() - ref["extra"]).max() < 2e-5
+    if seed % 2 == 1 and cnt[-1] > 0:
+        assert float(out[0][int(rays[-1, 0])]) == 0.0                          # the dropped ray composites to nothing
+
+
+def test_training_batch_that_misses_the_volume(params_k16, room_bitfield):
+    """Every ray of a training batch misses the box (no samples at all): the render is the background, the loss is
+    finite, backward and the optimiser step run (zero table gradient) - found by the compositing fuzz test: the C ABI
+    refused the empty sample arrays."""
+    from instance_nerf_amd.nerf.utils import Trainer
+    net = _network({k: v.clone() for k, v in params_k16.items()}, K=16)
+    net.density_bitfield.copy_(_t(room_bitfield))
+    ro = torch.full((1, 64, 3), 5.0, device=DEV)
+    rd = torch.tensor([1.0, 0.0, 0.0], device=DEV).expand(1, 64, 3).contiguous()
+    for stage, extra in (("nerf", {"images": torch.rand(1, 64, 3, device=DEV)}),
+                         ("instance", {"masks": torch.randint(0, 16, (1, 64), device=DEV)})):
+        tr = Trainer("m", None, net, stage=stage, device=torch.device(DEV), update_extra_interval=10 ** 9)
+        tr.global_step = 1
+        before = net.encoder.embeddings.detach().clone()
+        loss = tr.train_one_step({"rays_o": ro, "rays_d": rd, **extra})
+        assert torch.isfinite(loss)
+        if stage == "nerf":
+            assert torch.equal(net.encoder.embeddings.detach(), before)        # nothing was sampled: nothing moves
+    net.eval()
+    with torch.no_grad():
+        out = net.render(ro, rd, bg_color=1)
+    assert (out["image"] == 1).all() and (out["weights_sum"] == 0).all() and (out["instance"] == 0).all()
+
+
 def test_rays_missing_the_volume(rm, bits_dev):
     ro = np.asarray([[5, 5, 5], [0, 0, 3], [0, 0, 0]], np.float32)
     rd = np.asarray([[1, 0, 0], [0, 1, 0], [0, 0, 1]], np.float32)
