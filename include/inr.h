@@ -341,11 +341,14 @@ int inr_adam_step_multi_dev(int32_t n_tensors, float* const* params, const float
 int inr_cross_entropy(const float* logits /*[N,K]*/, const int64_t* labels /*[N]*/, int64_t N, int32_t K,
                       int64_t ignore_index, float* grad_logits, float* acc, float* loss, inr_stream_t s);
 /* Tail of NeRFRenderer.run_cuda (a14): image_out = image + (1 - weights_sum) * bg;
- * depth_out = clamp(depth - near, 0) / (far - near); outputs may alias the inputs.  No autograd: callers that
- * need gradients through the image use torch ops. */
+ * depth_out = clamp(depth [+ t0 * weights_sum] - near, 0) / (far - near); outputs may alias the inputs.  t0 (nullable)
+ * = start parameter of every ray: upstream's inference compositing accumulates depth over the ABSOLUTE ray parameter
+ * (composite_rays: t = rays_t), its training compositing over t counted from the first step (composite_rays_train:
+ * t = 0); the one-pass inference kernels here count like the latter, so inference passes t0 (= nears without jitter).
+ * No autograd: callers that need gradients through the image use torch ops. */
 int inr_finish_rays(const float* image /*[N,3]*/, const float* depth /*[N]*/, const float* weights_sum,
-                    const float* nears, const float* fars, float bg_r, float bg_g, float bg_b, int64_t N,
-                    float* image_out, float* depth_out, inr_stream_t s);
+                    const float* nears, const float* fars, const float* t0 /*[N] nullable*/, float bg_r, float bg_g,
+                    float bg_b, int64_t N, float* image_out, float* depth_out, inr_stream_t s);
 
 #ifdef __cplusplus
 }

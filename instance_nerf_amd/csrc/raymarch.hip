@@ -676,19 +676,26 @@ __global__ void __launch_bounds__(256) k_ce_scale(float* __restrict__ dlogits, i
 }
 
 // tail of run_cuda (a14): image += (1 - weights_sum) * bg, depth = clamp(depth - near, 0) / (far - near); one launch
-// instead of seven elementwise ones (no-grad use only)
+// instead of seven elementwise ones (no-grad use only).  t0 (nullable): start parameter of every ray.  Upstream's
+// TRAINING compositing accumulates depth over t counted from the ray's first step (composite_rays_train: t = 0,
+// t += delta), its INFERENCE compositing over the absolute ray parameter (composite_rays: t = rays_t, t += delta);
+// the one-pass inference kernels here count like the training kernel, so inference passes t0 and the depth becomes
+// sum w * (t0 + t_rel) = depth + t0 * weights_sum - upstream's inference value.
 __global__ void __launch_bounds__(256) k_finish_rays(const float* image, const float* depth,
                                                      const float* __restrict__ weights_sum,
                                                      const float* __restrict__ nears, const float* __restrict__ fars,
-                                                     float bg_r, float bg_g, float bg_b, int64_t N, float* image_out,
-                                                     float* depth_out) {
+                                                     const float* __restrict__ t0, float bg_r, float bg_g, float bg_b,
+                                                     int64_t N, float* image_out, float* depth_out) {
   const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
-  const float a = 1.0f - weights_sum[n];
+  const float ws = weights_sum[n];
+  const float a = 1.0f - ws;
   image_out[n * 3 + 0] = image[n * 3 + 0] + a * bg_r;
   image_out[n * 3 + 1] = image[n * 3 + 1] + a * bg_g;
   image_out[n * 3 + 2] = image[n * 3 + 2] + a * bg_b;
-  depth_out[n] = fmaxf(depth[n] - nears[n], 0.0f) / (fars[n] - nears[n]);
+  float d = depth[n];
+  if (t0) d = d + t0[n] * ws;
+  depth_out[n] = fmaxf(d - nears[n], 0.0f) / (fars[n] - nears[n]);
 }
 
 // a5: inference march, up to n_step samples per live ray; buffers pre-zeroed by this kernel
@@ -1452,13 +1459,13 @@ int inr_cross_entropy(const float* logits, const int64_t* labels, int64_t N, int
 }
 
 int inr_finish_rays(const float* image, const float* depth, const float* weights_sum, const float* nears,
-                    const float* fars, float bg_r, float bg_g, float bg_b, int64_t N, float* image_out, float* depth_out,
-                    inr_stream_t s) {
+                    const float* fars, const float* t0, float bg_r, float bg_g, float bg_b, int64_t N, float* image_out,
+                    float* depth_out, inr_stream_t s) {
   INR_REQUIRE(N >= 0, "negative N");
   if (N == 0) return INR_OK;
   INR_REQUIRE(image && depth && weights_sum && nears && fars && image_out && depth_out, "null pointer");
-  k_finish_rays<<<blocks_for(N, 256), 256, 0, as_stream(s)>>>(image, depth, weights_sum, nears, fars, bg_r, bg_g, bg_b, N,
-                                                              image_out, depth_out);
+  k_finish_rays<<<blocks_for(N, 256), 256, 0, as_stream(s)>>>(image, depth, weights_sum, nears, fars, t0, bg_r, bg_g, bg_b,
+                                                              N, image_out, depth_out);
   return check_launch("finish_rays");
 }
 

@@ -297,6 +297,17 @@ class NeRFRenderer(nn.Module):
 
         if not self.training and skipped_frac is not None:
             self._note_skippable(skipped_frac)
+        # Depth.  Upstream's training compositing counts t from the ray's first step, its inference compositing uses
+        # the absolute ray parameter (SURVEY Appendix A.1 "Inference loop").  The one-pass inference modes composite
+        # like the training kernel, so they add the start parameter back: sum w (t0 + t_rel) = depth + t0 * sum w.
+        # (The wavefront mode runs upstream's loop and is absolute already.)
+        t_start = None
+        if not self.training and infer_mode in ("fused", "fused_terminate", "fused_raymajor"):
+            t_start = nears
+            if perturb and noises is not None:
+                dt_min = 2 * math.sqrt(3) / max_steps
+                dt_max = 2 * math.sqrt(3) * 2 ** (self.cascade - 1) / self.grid_size
+                t_start = nears + torch.clamp(nears * dt_gamma, dt_min, dt_max) * noises.to(nears)
         bg3 = self._bg_triplet(bg_color)
         if bg3 is not None and not (torch.is_grad_enabled() and (image.requires_grad or weights_sum.requires_grad)):
             # no gradient flows through the shaded image (inference, or the instance stage on a frozen NeRF):
@@ -309,9 +320,12 @@ class NeRFRenderer(nn.Module):
             check(lib.inr_finish_rays(ptr(src_i, torch.float32, "image"), ptr(src_d, torch.float32, "depth"),
                                       ptr(weights_sum.detach().contiguous(), torch.float32, "weights_sum"),
                                       ptr(nears, torch.float32, "nears"), ptr(fars, torch.float32, "fars"),
+                                      ptr(t_start, torch.float32, "t0", allow_none=True),
                                       bg3[0], bg3[1], bg3[2], N, ptr(image), ptr(depth), stream_ptr()), "finish_rays")
         else:
             image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
+            if t_start is not None:
+                depth = depth + t_start * weights_sum.detach()
             depth = torch.clamp(depth - nears, min=0) / (fars - nears)
         results["image"] = image.view(*prefix, 3)
         results["depth"] = depth.view(*prefix)

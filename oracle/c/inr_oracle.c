@@ -7,7 +7,7 @@
  * (/root/reference/.gitmodules:4-6 -> zymk9/torch-ngp, pinned in prose at /root/reference/README.md:27,59);
  * /root/reference/instance_nerf is empty and the reference ships no tests or golden vectors.  This file is a
  * second, independent restatement (scalar C, one ray / one sample at a time) of the algorithm spec recorded in
- * SURVEY.md Appendix A - the first is the vectorised numpy/torch one in oracle/*.py - and the two are checked
+ * SURVEY.md Appendix A - the first is the vectorised numpy/torch one in the .py modules of oracle/ - and the two are checked
  * against each other and against the tests/golden vectors by tests/test_oracle_c.py.
  *
  * Arithmetic contract: every marching operation is one IEEE binary32 operation in the order written (build
@@ -428,8 +428,8 @@ void orc_composite_train(const float* sigmas, const float* rgbs, const float* de
  * the march produced (every one of them is evaluated, as on the training path). */
 int64_t orc_render(const float* o, const float* d, int64_t N, const uint8_t* bits, float bound, int32_t cascade, int32_t H,
                    float min_near, float dt_gamma, int32_t max_steps, float T_thresh, float bg, float density_scale,
-                   const orc_grid* G, const orc_nerf* P, const orc_inst* I, float* image, float* depth,
-                   float* weights_sum, float* instance, int32_t* counts) {
+                   int32_t absolute_depth, const orc_grid* G, const orc_nerf* P, const orc_inst* I, float* image,
+                   float* depth, float* weights_sum, float* instance, int32_t* counts) {
   march_cfg c;
   make_cfg(&c, bits, bound, cascade, H, dt_gamma, max_steps);
   const float aabb[6] = {-bound, -bound, -bound, bound, bound, bound};
@@ -448,7 +448,9 @@ int64_t orc_render(const float* o, const float* d, int64_t N, const uint8_t* bit
       total += cnt;
       if (counts) counts[r] = cnt;
       sh4(d + 3 * r, sh);
-      float T = 1.0f, t = 0.0f, ws = 0.0f, dp = 0.0f, col[3] = {0.0f, 0.0f, 0.0f};
+      /* depth: upstream's training compositing counts t from the first step (composite_rays_train: t = 0), its
+       * inference compositing from the ray's current parameter (composite_rays: t = rays_t = near) */
+      float T = 1.0f, t = absolute_depth ? near : 0.0f, ws = 0.0f, dp = 0.0f, col[3] = {0.0f, 0.0f, 0.0f};
       if (instance) memset(instance + (size_t)r * I->K, 0, sizeof(float) * (size_t)I->K);
       for (int k = 0; k < cnt; ++k) {
         /* every marched sample is evaluated (training semantics); only its weight stops counting */

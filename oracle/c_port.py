@@ -195,9 +195,11 @@ def composite_rays_train(sigmas, rgbs, deltas, rays, T_thresh=1e-4, extra=None):
 
 
 def render(rays_o, rays_d, p, table, bitfield, bound=1.0, cascade=1, H=128, min_near=0.2, dt_gamma=0.0,
-           max_steps=1024, T_thresh=1e-4, bg_color=1.0, with_instance=False, density_scale=1.0):
+           max_steps=1024, T_thresh=1e-4, bg_color=1.0, with_instance=False, density_scale=1.0, absolute_depth=False):
     """The whole path, one ray at a time (OpenMP over rays): what oracle.render.render_train computes with
-    perturb off.  -> dict(image, depth, weights_sum, instance | None, counts, total)."""
+    perturb off; ``absolute_depth=True`` accumulates the depth over the absolute ray parameter as upstream's
+    INFERENCE compositing does (oracle.render.render_infer), False over t counted from the first step as its
+    training compositing does.  -> dict(image, depth, weights_sum, instance | None, counts, total)."""
     o, d, bits, g = _a(rays_o, F32), _a(rays_d, F32), _a(bitfield, U8), _grid(table)
     P, keep = _nerf(p)
     I, keep2 = _inst(p) if with_instance else (None, None)
@@ -208,6 +210,7 @@ def render(rays_o, rays_d, p, table, bitfield, bound=1.0, cascade=1, H=128, min_
     total = load().orc_render(_p(o), _p(d), ctypes.c_int64(N), _p(bits), ctypes.c_float(bound), ctypes.c_int32(cascade),
                               ctypes.c_int32(H), ctypes.c_float(min_near), ctypes.c_float(dt_gamma),
                               ctypes.c_int32(max_steps), ctypes.c_float(T_thresh), ctypes.c_float(bg_color),
-                              ctypes.c_float(density_scale), ctypes.byref(g), ctypes.byref(P),
+                              ctypes.c_float(density_scale), ctypes.c_int32(1 if absolute_depth else 0), ctypes.byref(g),
+                              ctypes.byref(P),
                               ctypes.byref(I) if with_instance else None, _p(img), _p(dp), _p(ws), _p(inst), _p(counts))
     return dict(image=img, depth=dp, weights_sum=ws, instance=inst, counts=counts, total=int(total))

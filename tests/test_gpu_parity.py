@@ -450,6 +450,10 @@ def test_render_infer_golden(params_k16, room_bitfield, mode):
     assert np.abs(out["image"][0].cpu().numpy() - g["infer_image"]).max() < 1e-4
     assert np.abs(out["weights_sum"][0].cpu().numpy() - g["infer_ws"]).max() < 1e-4
     assert np.abs(out["instance"][0].cpu().numpy() - g["infer_instance"]).max() < 1e-3
+    # depth over the ABSOLUTE ray parameter, as upstream's inference compositing (and the oracle's restatement of its
+    # loop) accumulates it - the one-pass modes add the start parameter back (round 2: they used to return the
+    # training-style value)
+    assert np.abs(out["depth"][0].cpu().numpy() - g["infer_depth"]).max() < 1e-4
     if mode == "fused":
         assert int(out["num_samples"][0]) == int(g["train_total"])
 
@@ -822,7 +826,7 @@ def test_full_size_frame_against_the_c_oracle(rm, params_k16, room, room_bitfiel
     with torch.no_grad():
         out = net.render(r["rays_o"], r["rays_d"], bg_color=1, infer_mode="fused")
     c = c_port.render(r["rays_o"][0].cpu().numpy(), r["rays_d"][0].cpu().numpy(), params_k16, level_table, room_bitfield,
-                      min_near=0.05)
+                      min_near=0.05, absolute_depth=True)                      # inference: depth over the absolute t
     assert int(out["num_samples"][0]) == c["total"] > 20_000_000
     assert np.abs(out["image"][0].cpu().numpy() - c["image"]).max() < 1e-4
     assert np.abs(out["weights_sum"][0].cpu().numpy() - c["weights_sum"]).max() < 1e-4
@@ -888,6 +892,66 @@ def test_composite_fuzz_against_the_c_oracle(rm, seed):
         assert np.abs(out[3].cpu().numpy() - ref["extra"]).max() < 2e-5
     if seed % 2 == 1 and cnt[-1] > 0:
         assert float(out[0][int(rays[-1, 0])]) == 0.0                          # the dropped ray composites to nothing
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_render_fuzz_against_the_c_oracle(level_table, seed):
+    """Whole renders on random set-ups - occupancy from empty to full, 1..700 rays (ragged 16-ray groups), K = 0 / 16 /
+    48 / 64 instance logits, opaque and transparent densities, constant and growing steps, every inference mode and
+    the training-mode path - against the scalar C restatement: sample totals exact, image / opacity / depth / rendered
+    logits within 1e-4 / 1e-3."""
+    from oracle import c_port, field
+    rng = np.random.default_rng(4000 + seed)
+    K = int(rng.choice([0, 16, 48, 64]))
+    p = field.init_params(seed=seed, table=level_table, table_std=1.0, K=K)
+    fill = float(rng.choice([0.0, 0.002, 0.05, 0.5, 1.0]))
+    bits = (rng.random(128 ** 3 // 8) < fill).astype(np.uint8) * rng.integers(1, 256, 128 ** 3 // 8).astype(np.uint8)
+    if fill == 1.0:
+        bits[:] = 255
+    n = int(rng.choice([1, 7, 16, 100, 700]))
+    ro = rng.uniform(-0.9, 0.9, size=(n, 3)).astype(np.float32)
+    rd = rng.normal(size=(n, 3)).astype(np.float32)
+    rd /= np.linalg.norm(rd, axis=1, keepdims=True)
+    if n > 2:
+        ro[0], rd[0] = [4, 4, 4], [1, 0, 0]                        # misses the box
+    scale = float(rng.choice([1.0, 30.0, 1000.0])) if fill < 0.5 else float(rng.choice([0.05, 1.0]))
+    gamma = float(rng.choice([0.0, 1.0 / 128]))
+    steps = int(rng.choice([64, 1024])) if fill < 0.5 else 64
+    net = _network(p, K=K).eval()
+    net.density_bitfield.copy_(_t(bits))
+    net.density_scale = scale
+    ref = c_port.render(ro, rd, p, level_table, bits, min_near=0.05, dt_gamma=gamma, max_steps=steps,
+                        with_instance=K > 0, density_scale=scale, absolute_depth=True)       # inference semantics
+    ref_train = c_port.render(ro, rd, p, level_table, bits, min_near=0.05, dt_gamma=gamma, max_steps=steps,
+                              with_instance=K > 0, density_scale=scale)
+    modes = ["fused", "fused_terminate", "fused_raymajor", "auto"] + (["wavefront"] if n <= 100 and steps == 64 else [])
+    for mode in modes:
+        with torch.no_grad():
+            out = net.render(_t(ro)[None], _t(rd)[None], bg_color=1, dt_gamma=gamma, max_steps=steps, infer_mode=mode)
+        tag = (mode, K, fill, n, scale, gamma, steps)
+        if "num_samples" in out:
+            assert int(out["num_samples"][0]) == ref["total"], tag
+        # upstream's alive-ray loop advances `step` by n_step = clamp(N // n_alive, 1, 8) per iteration, so a ray that
+        # is still alive when the budget runs out gets up to 7 samples MORE than max_steps, how many depends on the
+        # other rays; the one-pass modes stop at exactly max_steps like the training marcher (DESIGN section 2).
+        # Rays that hit the cap are therefore only compared in the one-pass modes.
+        ok = np.ones(n, bool) if mode != "wavefront" else ref["counts"] < steps
+        assert np.abs(out["image"][0].cpu().numpy() - ref["image"])[ok].max(initial=0) < 2e-4, tag
+        assert np.abs(out["weights_sum"][0].cpu().numpy() - ref["weights_sum"])[ok].max(initial=0) < 2e-4, tag
+        hit = np.isfinite(ref["depth"]) & ok                # rays that miss the box: 0 / 0 on both sides
+        assert np.abs(out["depth"][0].cpu().numpy() - ref["depth"])[hit].max(initial=0) < 2e-4, tag
+        if K:
+            lim = 2e-3 * max(1.0, float(np.abs(ref["instance"]).max()))
+            assert np.abs(out["instance"][0].cpu().numpy() - ref["instance"])[ok].max(initial=0) < lim, tag
+    net.train()
+    with torch.no_grad():
+        out = net.render(_t(ro)[None], _t(rd)[None], bg_color=1, dt_gamma=gamma, max_steps=steps, perturb=False,
+                         force_all_rays=True)
+    assert np.abs(out["image"][0].cpu().numpy() - ref["image"]).max() < 2e-4
+    hit = np.isfinite(ref_train["depth"])
+    assert np.abs(out["depth"][0].cpu().numpy() - ref_train["depth"])[hit].max(initial=0) < 2e-4   # training: t from the first step
+    if K:
+        assert np.abs(out["instance"][0].cpu().numpy() - ref["instance"]).max() < 2e-3 * max(1.0, float(np.abs(ref["instance"]).max()))
 
 
 def test_training_batch_that_misses_the_volume(params_k16, room_bitfield):

@@ -104,6 +104,11 @@ def test_whole_path_render_golden_and_numpy_oracle(room, room_bitfield, level_ta
     assert a["total"] == int(g["train_total"])
     assert np.abs(a["image"] - g["train_image"]).max() < 1e-5 and np.abs(a["weights_sum"] - g["train_ws"]).max() < 1e-5
     assert np.abs(a["depth"] - g["train_depth"]).max() < 1e-5 and np.abs(a["instance"] - g["train_instance"]).max() < 1e-4
+    # inference semantics: depth over the absolute ray parameter (the golden vector comes from the numpy restatement of
+    # upstream's alive-ray loop, oracle.render.render_infer)
+    e = c_port.render(g["rays_o"], g["rays_d"], params_k16, level_table, room_bitfield, min_near=0.05, with_instance=True,
+                      absolute_depth=True)
+    assert np.abs(e["depth"] - g["infer_depth"]).max() < 1e-5 and np.abs(e["image"] - g["infer_image"]).max() < 1e-5
     # an opaque variant (termination inside the rays) against the numpy/torch oracle
     ro, rd = scene_rays(room, 96, cam=3, seed=77)
     with torch.no_grad():
