@@ -559,6 +559,41 @@ def test_occupancy_update_matches_oracle(params_k16, level_table):
     assert not (diff & ~near).any()
 
 
+def test_occupancy_update_two_cascades_with_unseen_cells():
+    """bound = 2 (two cascades, 64^3 grid, desired resolution 4096), cells marked -1 beforehand, density_scale != 1:
+    the full sweep of update_extra_state (jitter disabled) against the oracle's update - grid, mean, bitfield."""
+    from instance_nerf_amd.nerf import NeRFNetwork
+    from oracle import field, hashgrid, occupancy
+    tb = hashgrid.level_table(desired_resolution=4096)
+    p = field.init_params(seed=3, table=tb, table_std=1.0)
+    net = NeRFNetwork(cuda_ray=True, bound=2, min_near=0.2, grid_size=64, density_scale=0.7, density_thresh=2.0).to(DEV).eval()
+    net.load_state_dict({"encoder.embeddings": p["embeddings"], "sigma_net.0.weight": p["sigma_w0"],
+                         "sigma_net.1.weight": p["sigma_w1"], "color_net.0.weight": p["color_w0"],
+                         "color_net.1.weight": p["color_w1"], "color_net.2.weight": p["color_w2"]}, strict=False)
+    gen = torch.Generator().manual_seed(1)
+    start = torch.rand(2, 64 ** 3, generator=gen) * 3.0
+    start[torch.rand(2, 64 ** 3, generator=gen) < 0.1] = -1.0
+    net.density_grid.copy_(start.to(DEV))
+    orig = torch.rand_like
+    try:
+        torch.rand_like = lambda t: torch.full_like(t, 0.5)
+        net.update_extra_state(decay=0.8)
+    finally:
+        torch.rand_like = orig
+    with torch.no_grad():
+        sig = lambda xyz: field.density(torch.from_numpy(xyz), p, 2.0, tb)["sigma"].numpy()
+        grid, bits, mean = occupancy.update_density_grid(start.numpy(), sig, 64, 2, 2.0, decay=0.8, density_scale=0.7,
+                                                         density_thresh=2.0)
+    got = net.density_grid.cpu().numpy()
+    assert (got[start.numpy() < 0] == -1).all()
+    assert np.allclose(got, grid, rtol=2e-4, atol=1e-6)
+    assert abs(net.mean_density - mean) < 1e-4 * mean
+    thr = min(mean, 2.0)
+    near = np.abs(grid.ravel() - thr) < 1e-3 * thr
+    diff = np.unpackbits(net.density_bitfield.cpu().numpy(), bitorder="little") != np.unpackbits(bits, bitorder="little")
+    assert not (diff & ~near).any() and diff.mean() < 1e-3
+
+
 def test_occupancy_update_steady_state_sweep(params_k16, level_table):
     """After the first 16 updates only H^3/4 random cells + H^3/4 random OCCUPIED cells are refreshed per call
     (device-side compaction of the occupied set, no host round trip).  Every cell either keeps its value or becomes
@@ -952,6 +987,66 @@ def test_render_fuzz_against_the_c_oracle(level_table, seed):
     assert np.abs(out["depth"][0].cpu().numpy() - ref_train["depth"])[hit].max(initial=0) < 2e-4   # training: t from the first step
     if K:
         assert np.abs(out["instance"][0].cpu().numpy() - ref["instance"]).max() < 2e-3 * max(1.0, float(np.abs(ref["instance"]).max()))
+
+
+@pytest.mark.parametrize("seed", range(5))
+def test_training_gradients_fuzz_against_the_oracle(level_table, seed):
+    """Both training stages on random set-ups (occupancy, density scale, ray count, K, growing / constant steps, a
+    sample buffer that drops the last rays): loss and ALL gradients - table, sigma / colour nets or instance nets -
+    of the fused training kernels against torch autograd through the numpy/torch oracle."""
+    from oracle import field, render
+    rng = np.random.default_rng(9000 + seed)
+    K = int(rng.choice([16, 64]))
+    stage = "nerf" if seed % 2 == 0 else "instance"
+    p = field.init_params(seed=seed, table=level_table, table_std=1.0, K=K)
+    fill = float(rng.choice([0.02, 0.2]))
+    bits = (rng.random(128 ** 3 // 8) < fill).astype(np.uint8) * rng.integers(1, 256, 128 ** 3 // 8).astype(np.uint8)
+    n = int(rng.choice([33, 90, 150]))
+    ro = rng.uniform(-0.8, 0.8, size=(n, 3)).astype(np.float32)
+    rd = rng.normal(size=(n, 3)).astype(np.float32)
+    rd /= np.linalg.norm(rd, axis=1, keepdims=True)
+    scale = float(rng.choice([0.3, 3.0]))
+    gamma = float(rng.choice([0.0, 1.0 / 128]))
+    net = _network({k: v.clone() for k, v in p.items()}, K=K).train()
+    net.density_bitfield.copy_(_t(bits))
+    net.density_scale = scale
+    trained = ("embeddings", "sigma_w0", "sigma_w1", "color_w0", "color_w1", "color_w2") if stage == "nerf" else \
+        ("inst_embeddings", "inst_w0", "inst_w1", "inst_w2")
+    names = {"embeddings": "encoder.embeddings", "sigma_w0": "sigma_net.0.weight", "sigma_w1": "sigma_net.1.weight",
+             "color_w0": "color_net.0.weight", "color_w1": "color_net.1.weight", "color_w2": "color_net.2.weight",
+             "inst_embeddings": "instance_encoder.embeddings", "inst_w0": "instance_net.0.weight",
+             "inst_w1": "instance_net.1.weight", "inst_w2": "instance_net.2.weight"}
+    if stage == "instance":
+        net.freeze_nerf()
+    else:
+        for q in list(net.instance_encoder.parameters()) + list(net.instance_net.parameters()):
+            q.requires_grad_(False)
+    q = {k: v.clone().requires_grad_(k in trained) for k, v in p.items()}
+    ref = render.render_train(ro, rd, q, level_table, bits, min_near=0.05, dt_gamma=gamma, max_steps=256,
+                              with_instance=stage == "instance", density_scale=scale)
+    out = net.render(_t(ro)[None], _t(rd)[None], bg_color=1, perturb=False, force_all_rays=True, dt_gamma=gamma,
+                     max_steps=256)
+    assert int(out["num_samples"][0]) == ref["total"] > 20
+    if stage == "nerf":
+        target = rng.random((n, 3)).astype(np.float32)
+        loss = ((out["image"][0] - _t(target)) ** 2).mean()
+        rl = ((ref["image"] - torch.from_numpy(target)) ** 2).mean()
+    else:
+        labels = rng.integers(-1, K, size=n)
+        loss = torch.nn.functional.cross_entropy(out["instance"][0], _t(labels).long(), ignore_index=-1)
+        rl = render.instance_ce_loss(ref["instance"], labels)
+    loss.backward()
+    rl.backward()
+    assert abs(float(loss) - float(rl)) < 1e-4 * max(1.0, abs(float(rl))), (stage, float(loss), float(rl))
+    params = dict(net.named_parameters())
+    for k in trained:
+        got, want = params[names[k]].grad.cpu(), q[k].grad
+        assert want.abs().sum() > 0, k
+        # norm-wise: a ReLU pre-activation within rounding of zero may fall on either side
+        assert torch.linalg.norm(got - want) < 2e-2 * torch.linalg.norm(want), (stage, k)
+    for k in set(names) - set(trained):
+        if names[k] in params:
+            assert params[names[k]].grad is None, k
 
 
 def test_training_batch_that_misses_the_volume(params_k16, room_bitfield):
