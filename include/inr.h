@@ -86,6 +86,11 @@ int inr_packbits(const float* grid, int64_t n_bytes, float thresh, uint8_t* bitf
  * *mean_sum (double, caller zeroes it once per update) accumulates sum(max(grid, 0)).
  * inr_packbits_mean: packbits with thresh = min(*mean_sum / n_cells, density_thresh) formed on the device (no host
  * round trip between the update and the bitfield); mean_out (nullable) receives the mean.                       */
+/* mark_untrained_grid (a3): grid[cas][cell] = -1 for every cell (Morton order) that none of the B training cameras
+ * sees - poses [B,4,4] camera-to-world row-major, pinhole (fx, fy, cx, cy): the cell centre x in camera frame
+ * cam = R^T (x - t) is seen if z > 0, |x| < cx/fx z + 2 half, |y| < cy/fy z + 2 half (half = half a cell).        */
+int inr_mark_untrained_grid(const float* poses, int32_t B, float fx, float fy, float cx, float cy, int32_t H,
+                            int32_t cascade, float bound, float* grid /*[cascade, H^3]*/, inr_stream_t s);
 int inr_occ_cell_positions(const int32_t* morton_idx, const float* noise, int64_t n, int32_t H, float cascade_bound,
                            float* xyz /*[n,3]*/, inr_stream_t s);
 int inr_occ_update(float* grid /*[n_cells]*/, const float* sigma /*[m]*/, const int32_t* morton_idx /*[m] or NULL*/,

@@ -33,6 +33,7 @@ _SIGS = {
     "inr_morton3D": (c_int32, [P, c_int64, P, P]),
     "inr_morton3D_invert": (c_int32, [P, c_int64, P, P]),
     "inr_packbits": (c_int32, [P, c_int64, c_float, P, P]),
+    "inr_mark_untrained_grid": (c_int32, [P, c_int32, c_float, c_float, c_float, c_float, c_int32, c_int32, c_float, P, P]),
     "inr_occ_cell_positions": (c_int32, [P, P, c_int64, c_int32, c_float, P, P]),
     "inr_occ_update": (c_int32, [P, P, P, c_int64, c_int64, c_float, c_float, P, P, P]),
     "inr_packbits_mean": (c_int32, [P, c_int64, P, c_float, P, P, P]),

@@ -114,6 +114,32 @@ __global__ void k_occ_positions(const int32_t* __restrict__ morton, const float*
     xyz[i * 3 + a] = v;
   }
 }
+// mark_untrained_grid: a cell no training camera sees gets -1 and never becomes occupied.  One lane per
+// (cascade, cell in Morton order); the cell centre goes into every camera frame, cam = R^T (x - t); seen if z > 0,
+// |x| < cx/fx * z + 2 * half and |y| < cy/fy * z + 2 * half (half = half a cell of the cascade).
+__global__ void __launch_bounds__(256) k_mark_untrained(const float* __restrict__ poses, int B, float kx, float ky, int H,
+                                                        int C, float bound, float* __restrict__ grid) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t H3 = (int64_t)H * H * H;
+  if (i >= (int64_t)C * H3) return;
+  const int cas = (int)(i / H3);
+  const uint32_t m = (uint32_t)(i - (int64_t)cas * H3);
+  const float bnd = fminf(ldexpf(1.0f, cas), bound), half = bnd / (float)H, ext = bnd - half;
+  const float wx = (2.0f * (float)compact_bits10(m) / (float)(H - 1) - 1.0f) * ext;
+  const float wy = (2.0f * (float)compact_bits10(m >> 1) / (float)(H - 1) - 1.0f) * ext;
+  const float wz = (2.0f * (float)compact_bits10(m >> 2) / (float)(H - 1) - 1.0f) * ext;
+  bool seen = false;
+  for (int b = 0; b < B && !seen; ++b) {
+    const float* P = poses + (int64_t)b * 16;                       // row-major 4x4 camera-to-world
+    const float dx = wx - P[3], dy = wy - P[7], dz = wz - P[11];
+    const float cx = dx * P[0] + dy * P[4] + dz * P[8];
+    const float cy = dx * P[1] + dy * P[5] + dz * P[9];
+    const float cz = dx * P[2] + dy * P[6] + dz * P[10];
+    seen = cz > 0.0f && fabsf(cx) < kx * cz + half * 2.0f && fabsf(cy) < ky * cz + half * 2.0f;
+  }
+  if (!seen) grid[i] = -1.0f;
+}
+
 // tmp[morton[i]] = sigma[i] * density_scale (cells visited twice keep one of the values, as upstream's index_put)
 __global__ void k_occ_scatter(const float* __restrict__ sigma, const int32_t* __restrict__ morton, int64_t m,
                               float density_scale, float* __restrict__ tmp) {
@@ -1249,6 +1275,16 @@ int inr_packbits(const float* grid, int64_t n_bytes, float thresh, uint8_t* bitf
   INR_REQUIRE(((uintptr_t)grid & 15) == 0, "grid must be 16-byte aligned");
   k_packbits<<<blocks_for(n_bytes, 256), 256, 0, as_stream(s)>>>(grid, n_bytes, thresh, bitfield);
   return check_launch("packbits");
+}
+
+int inr_mark_untrained_grid(const float* poses, int32_t B, float fx, float fy, float cx, float cy, int32_t H, int32_t cascade,
+                            float bound, float* grid, inr_stream_t s) {
+  INR_REQUIRE(B >= 0 && H >= 2 && H <= 1024 && cascade >= 1 && grid, "bad argument");
+  INR_REQUIRE(B == 0 || poses, "null poses");
+  INR_REQUIRE(fx != 0.0f && fy != 0.0f, "zero focal length");
+  const int64_t n = (int64_t)cascade * H * H * H;
+  k_mark_untrained<<<blocks_for(n, 256), 256, 0, as_stream(s)>>>(poses, B, cx / fx, cy / fy, H, cascade, bound, grid);
+  return check_launch("mark_untrained_grid");
 }
 
 int inr_occ_cell_positions(const int32_t* morton_idx, const float* noise, int64_t n, int32_t H, float cascade_bound,

@@ -379,40 +379,20 @@ class NeRFRenderer(nn.Module):
     # ----------------------------------------------------------------------------------------
     @torch.no_grad()
     def mark_untrained_grid(self, poses, intrinsic, S=64):
-        """Marks cells no training camera sees with -1 (they never become occupied)."""
+        """Marks cells no training camera sees with -1 (they never become occupied); upstream
+        ``NeRFRenderer.mark_untrained_grid``.  One launch over all cascades and cells (inr_mark_untrained_grid);
+        ``S`` (upstream's chunk size) is accepted and unused."""
         if not self.cuda_ray:
             return
         if not torch.is_tensor(poses):
             poses = torch.as_tensor(poses)
-        B = poses.shape[0]
-        fx, fy, cx, cy = intrinsic
-        dev = self.density_bitfield.device
-        H = self.grid_size
-        r = torch.arange(H, dtype=torch.int32, device=dev)
-        count = torch.zeros_like(self.density_grid)
-        poses = poses.to(dev).float()
-        for xs in r.split(S):
-            for ys in r.split(S):
-                for zs in r.split(S):
-                    xx, yy, zz = torch.meshgrid(xs, ys, zs, indexing="ij")
-                    coords = torch.stack([xx.reshape(-1), yy.reshape(-1), zz.reshape(-1)], -1)
-                    indices = raymarching.morton3D(coords).long()
-                    world = (2 * coords.float() / (H - 1) - 1).unsqueeze(0)          # [1,n,3]
-                    for cas in range(self.cascade):
-                        bnd = min(2 ** cas, self.bound)
-                        half = bnd / H
-                        cas_world = world * (bnd - half)
-                        head = 0
-                        while head < B:
-                            tail = min(head + S, B)
-                            cam = cas_world - poses[head:tail, :3, 3].unsqueeze(1)
-                            cam = cam @ poses[head:tail, :3, :3]                    # world -> camera
-                            mask_z = cam[:, :, 2] > 0
-                            mask_x = torch.abs(cam[:, :, 0]) < cx / fx * cam[:, :, 2] + half * 2
-                            mask_y = torch.abs(cam[:, :, 1]) < cy / fy * cam[:, :, 2] + half * 2
-                            count[cas, indices] += (mask_z & mask_x & mask_y).sum(0).float()
-                            head += S
-        self.density_grid[count == 0] = -1
+        dev = self.density_grid.device
+        poses = poses.to(dev).float().contiguous().view(-1, 16)
+        fx, fy, cx, cy = [float(v) for v in intrinsic]
+        check(_lib.load().inr_mark_untrained_grid(ptr(poses, torch.float32, "poses", allow_none=poses.shape[0] == 0),
+                                                  poses.shape[0], fx, fy, cx, cy, self.grid_size, self.cascade,
+                                                  float(self.bound), ptr(self.density_grid, torch.float32, "density_grid"),
+                                                  stream_ptr()), "mark_untrained_grid")
 
     @torch.no_grad()
     def update_extra_state(self, decay=0.95, S=128):
