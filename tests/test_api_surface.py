@@ -133,6 +133,25 @@ def test_load_checkpoint_accepts_upstream_shapes(tmp_path):
     assert float(b.model.sigma_net[0].weight[0, 0]) == 0.25
 
 
+def test_install_aliases_makes_the_references_imports_resolve_here():
+    """`import raymarching`, `from nerf.network import NeRFNetwork`, `import roi_align` - the imports of the reference's
+    submodule and of /root/reference/nerf_rcnn/model/utils.py:18 - resolve to this package after install_aliases()."""
+    import importlib
+    import subprocess
+    import sys
+    code = ("import instance_nerf_amd as ina; s = ina.install_aliases(); assert s == [], s\n"
+            "import raymarching, gridencoder, shencoder, activation, encoding, roi_align\n"
+            "from nerf.network import NeRFNetwork; from nerf.utils import Trainer, get_rays; from nerf.provider import NeRFDataset\n"
+            "from roi_align.roi_align import roi_align_3d\n"
+            "from gridencoder import GridEncoder; from encoding import get_encoder\n"
+            "assert raymarching.__name__ == 'instance_nerf_amd.raymarching' and NeRFNetwork.__module__ == 'instance_nerf_amd.nerf.network'\n"
+            "print('ok')")
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
+
+
 def test_hip_path_refuses_cpu_tensors():
     """No CPU fallback behind the extension-level API: host tensors raise before any launch."""
     import pytest
