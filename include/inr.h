@@ -198,6 +198,12 @@ int inr_grid_encode_backward(const float* x, const float* grad_out /*[M,L*F]*/,
 int inr_grid_encode_backward_ordered(const float* x, const float* grad_out, const int32_t* order,
                                      const inr_grid_desc* desc /*host*/, int64_t M, float bound,
                                      float* grad_embeddings /*[T,F]*/, inr_stream_t s);
+/* Gradient with respect to the input coordinates (upstream's dy_dx path of gridencoder, taken when the positions
+ * require grad): grad_x [M,3] = sum over levels and corners of grad_out . row * d(weight)/dx * scale_l / (2 bound);
+ * zero for out-of-range points.  A.e. derivative of the trilinear interpolation (cells are piecewise linear).     */
+int inr_grid_encode_backward_input(const float* x, const float* grad_out /*[M,L*F]*/, const float* embeddings,
+                                   const inr_grid_desc* desc /*host*/, int64_t M, float bound, float* grad_x,
+                                   inr_stream_t s);
 /* The same scatter restricted to levels [level_lo, level_hi): a caller that all-reduces the table gradient over
  * several GPUs launches it in two or three level ranges and starts the collective on each row range
  * [offsets[level_lo], offsets[level_hi]) as soon as its launch is queued (nerf/network.py::_table_backward).      */

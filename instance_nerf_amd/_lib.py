@@ -70,6 +70,7 @@ _SIGS = {
     "inr_grid_encode_forward": (c_int32, [P, P, POINTER(GridDesc), c_int64, c_float, P, P]),
     "inr_grid_encode_backward": (c_int32, [P, P, POINTER(GridDesc), c_int64, c_float, P, P]),
     "inr_grid_encode_backward_ordered": (c_int32, [P, P, P, POINTER(GridDesc), c_int64, c_float, P, P]),
+    "inr_grid_encode_backward_input": (c_int32, [P, P, P, POINTER(GridDesc), c_int64, c_float, P, P]),
     "inr_grid_encode_backward_levels": (c_int32, [P, P, P, POINTER(GridDesc), c_int64, c_float, P, c_int32, c_int32, P]),
     "inr_sh_encode_forward": (c_int32, [P, c_int64, c_int32, P, P]),
     "inr_sh_encode_backward": (c_int32, [P, P, c_int64, c_int32, P, P]),

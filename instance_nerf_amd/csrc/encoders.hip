@@ -105,6 +105,43 @@ __global__ void __launch_bounds__(256) k_grid_bwd(const float* __restrict__ x, c
   }
 }
 
+// Gradient with respect to the INPUT coordinates (upstream's dy_dx path, used when the positions require grad):
+// feature_l,f = sum_k w_k(fx,fy,fz) v_k  =>  d/dx = scale_l / (2 bound) * sum_k (dw_k/dfx) v_k, dw/dfx = +-(wy*wz).
+// One lane per (sample, level); the 16 levels of a sample sit in 16 adjacent lanes and meet in a butterfly.
+__global__ void __launch_bounds__(256) k_grid_bwd_input(const float* __restrict__ x, const float2* __restrict__ gout,
+                                                        const float2* __restrict__ emb, GridDesc G, int64_t M, float bound,
+                                                        float* __restrict__ gx) {
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t m = tid >> 4;
+  const int l = (int)(tid & 15);
+  float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+  if (m < M && l < G.num_levels) {
+    const float rb = 2.0f * bound;
+    const float x0 = (x[m * 3 + 0] + bound) / rb, x1 = (x[m * 3 + 1] + bound) / rb, x2 = (x[m * 3 + 2] + bound) / rb;
+    if (!oob01(x0, x1, x2)) {
+      Cell c;
+      locate(G, l, x0, x1, x2, c);
+      const float2 go = gout[m * G.num_levels + l];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float2 v = emb[G.offsets[l] + corner_index(G, l, c, k)];
+        const float d = go.x * v.x + go.y * v.y;
+        const float wx = (k & 1) ? c.fx : 1.0f - c.fx, wy = (k & 2) ? c.fy : 1.0f - c.fy, wz = (k & 4) ? c.fz : 1.0f - c.fz;
+        g0 += ((k & 1) ? 1.0f : -1.0f) * wy * wz * d;
+        g1 += ((k & 2) ? 1.0f : -1.0f) * wx * wz * d;
+        g2 += ((k & 4) ? 1.0f : -1.0f) * wx * wy * d;
+      }
+      const float sc = G.scales[l] / rb;
+      g0 *= sc; g1 *= sc; g2 *= sc;
+    }
+  }
+#pragma unroll
+  for (int d = 1; d < 16; d <<= 1) {
+    g0 += __shfl_xor(g0, d, 64); g1 += __shfl_xor(g1, d, 64); g2 += __shfl_xor(g2, d, 64);
+  }
+  if (l == 0 && m < M) { gx[m * 3 + 0] = g0; gx[m * 3 + 1] = g1; gx[m * 3 + 2] = g2; }
+}
+
 // ---- SH ------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_sh_fwd(const float* __restrict__ d, int64_t M, int degree,
                                                 float* __restrict__ out) {
@@ -452,6 +489,21 @@ int inr_grid_encode_backward_levels(const float* x, const float* grad_out, const
   const dim3 grid(blocks_for(M * 4, 256), (unsigned)(l1 - l0));
   k_grid_bwd<<<grid, 256, 0, as_stream(s)>>>(x, grad_out, order, G, M, bound, grad_embeddings, l0);
   return check_launch("grid_encode_backward");
+}
+
+int inr_grid_encode_backward_input(const float* x, const float* grad_out, const float* embeddings,
+                                   const inr_grid_desc* desc, int64_t M, float bound, float* grad_x, inr_stream_t s) {
+  INR_REQUIRE(M >= 0 && desc, "bad argument");
+  if (M == 0) return INR_OK;
+  INR_REQUIRE(x && grad_out && embeddings && grad_x, "null pointer");
+  GridDesc G;
+  int rc = make_grid_desc(desc, G);
+  if (rc) return rc;
+  INR_REQUIRE(((uintptr_t)embeddings & 7) == 0 && ((uintptr_t)grad_out & 7) == 0, "embeddings/grad_out must be 8-byte aligned");
+  k_grid_bwd_input<<<blocks_for(M * 16, 256), 256, 0, as_stream(s)>>>(x, reinterpret_cast<const float2*>(grad_out),
+                                                                      reinterpret_cast<const float2*>(embeddings), G, M,
+                                                                      bound, grad_x);
+  return check_launch("grid_encode_backward_input");
 }
 
 int inr_sh_encode_forward(const float* d, int64_t M, int32_t degree, float* out, inr_stream_t s) {

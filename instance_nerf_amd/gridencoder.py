@@ -66,8 +66,16 @@ class _GridEncode(torch.autograd.Function):
         lib = _lib.load()
         inputs, embeddings = ctx.saved_tensors
         grad = grad.contiguous().float()
-        g_emb = torch.zeros_like(embeddings)
         M = inputs.shape[0]
+        g_in = None
+        if ctx.needs_input_grad[0]:              # upstream's dy_dx path: positions that require grad
+            g_in = torch.empty_like(inputs)
+            check(lib.inr_grid_encode_backward_input(ptr(inputs), ptr(grad, torch.float32, "grad"),
+                                                     ptr(embeddings.detach(), torch.float32, "embeddings"), ctx.desc, M,
+                                                     float(ctx.bound), ptr(g_in), stream_ptr()), "grid_encode_backward_input")
+        if not ctx.needs_input_grad[1]:
+            return g_in, None, None, None, None
+        g_emb = torch.zeros_like(embeddings)
         order = None
         if M >= SORT_MIN_SAMPLES:
             # Morton order of the sample positions (10 bits per axis): neighbouring lanes become neighbours
@@ -77,7 +85,7 @@ class _GridEncode(torch.autograd.Function):
         check(lib.inr_grid_encode_backward_ordered(ptr(inputs), ptr(grad, torch.float32, "grad"),
                                                    ptr(order, torch.int32, "order", allow_none=True), ctx.desc, M,
                                                    float(ctx.bound), ptr(g_emb), stream_ptr()), "grid_encode_backward")
-        return None, g_emb, None, None, None
+        return g_in, g_emb, None, None, None
 
 
 class GridEncoder(nn.Module):

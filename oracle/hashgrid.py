@@ -126,3 +126,28 @@ def encode_backward_table(x, grad_out, bound, table):
     grad = torch.zeros((table["total_rows"], F), dtype=torch.float32)
     grad.index_add_(0, idx.reshape(-1), contrib)
     return grad
+
+
+def encode_input_grad(x, grad_out, embeddings, bound, table):
+    """d(sum(encode(x) * grad_out)) / dx, f32[M,3]: the a.e. derivative of the trilinear interpolation (upstream's
+    ``dy_dx`` path of gridencoder, taken when the positions require grad).  Indices come from the detached positions,
+    the weights are rebuilt from the fractional parts with autograd on."""
+    x = torch.as_tensor(x, dtype=torch.float32).clone().requires_grad_(True)
+    idx, _ = corner_indices_weights(x.detach(), bound, table)
+    b = torch.tensor(float(bound), dtype=torch.float32)
+    x01 = (x + b) / (2 * b)
+    oob = ~((x01 >= 0) & (x01 <= 1)).all(-1)
+    M, L = x.shape[0], table["num_levels"]
+    F = embeddings.shape[1]
+    out = torch.zeros((M, L, F), dtype=torch.float32)
+    for l in range(L):
+        pos = x01 * float(table["scales"][l]) + 0.5
+        fr = pos - torch.floor(pos).detach()
+        for c in range(8):
+            wx = fr[:, 0] if c & 1 else 1 - fr[:, 0]
+            wy = fr[:, 1] if c & 2 else 1 - fr[:, 1]
+            wz = fr[:, 2] if c & 4 else 1 - fr[:, 2]
+            w = torch.where(oob, torch.zeros(()), (wx * wy) * wz)
+            out[:, l] = out[:, l] + w[:, None] * embeddings.detach()[idx[:, l, c]]
+    (out.reshape(M, L * F) * torch.as_tensor(grad_out, dtype=torch.float32)).sum().backward()
+    return x.grad

@@ -275,6 +275,25 @@ def test_grid_encoder_fuzz_against_the_c_oracle(seed):
     assert torch.allclose(enc.embeddings.grad.cpu(), g_ref, atol=5e-5, rtol=1e-4)
 
 
+def test_grid_encode_input_gradient(level_table, params_k16):
+    """Positions that require grad (upstream's dy_dx path): d encode / dx against the oracle's autograd through the
+    interpolation weights; out-of-range points get zero; the table gradient of the same backward is unchanged."""
+    from oracle import hashgrid
+    enc = _encoder(level_table)
+    enc.embeddings.data.copy_(params_k16["embeddings"])
+    gen = torch.Generator().manual_seed(8)
+    x = torch.rand(2000, 3, generator=gen) * 2.1 - 1.05
+    go = torch.randn(2000, 32, generator=gen)
+    xd = x.to(DEV).requires_grad_(True)
+    enc(xd).backward(go.to(DEV))
+    ref = hashgrid.encode_input_grad(x, go, params_k16["embeddings"], 1.0, level_table)
+    inside = ((x >= -1) & (x <= 1)).all(-1)
+    assert (xd.grad.cpu()[~inside] == 0).all() and inside.float().mean() > 0.7
+    scale = ref.abs().max()
+    assert (xd.grad.cpu() - ref).abs().max() < 1e-4 * scale, ((xd.grad.cpu() - ref).abs().max(), scale)
+    assert torch.allclose(enc.embeddings.grad.cpu(), hashgrid.encode_backward_table(x, go, 1.0, level_table), atol=2e-5, rtol=1e-4)
+
+
 def test_grid_encode_forward_golden(level_table, params_k16):
     g = np.load(os.path.join(G, "field.npz"))
     enc = _encoder(level_table)
