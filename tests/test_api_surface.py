@@ -133,6 +133,21 @@ def test_load_checkpoint_accepts_upstream_shapes(tmp_path):
     assert float(b.model.sigma_net[0].weight[0, 0]) == 0.25
 
 
+def test_ffmlp_surface_and_cpu_forward():
+    """upstream's FFMLP(input_dim, output_dim, hidden_dim, num_layers): one flat `weights` parameter, bias-free ReLU
+    layers; equals the explicit chain of matmuls (CPU; the GPU path shares HipLinear's kernels)."""
+    from instance_nerf_amd.ffmlp import FFMLP
+    m = FFMLP(32, 16, 64, 3)
+    assert m.weights.shape == (64 * 32 + 64 * 64 + 16 * 64,) and [tuple(w.shape) for w in m.layer_weights()] == [(64, 32), (64, 64), (16, 64)]
+    x = torch.randn(7, 5, 32)
+    w0, w1, w2 = m.layer_weights()
+    ref = torch.relu(torch.relu(x @ w0.t()) @ w1.t()) @ w2.t()
+    out = m(x)
+    assert out.shape == (7, 5, 16) and torch.allclose(out, ref, atol=1e-5)
+    out.sum().backward()
+    assert m.weights.grad is not None and m.weights.grad.abs().sum() > 0
+
+
 def test_install_aliases_makes_the_references_imports_resolve_here():
     """`import raymarching`, `from nerf.network import NeRFNetwork`, `import roi_align` - the imports of the reference's
     submodule and of /root/reference/nerf_rcnn/model/utils.py:18 - resolve to this package after install_aliases()."""
@@ -140,7 +155,7 @@ def test_install_aliases_makes_the_references_imports_resolve_here():
     import subprocess
     import sys
     code = ("import instance_nerf_amd as ina; s = ina.install_aliases(); assert s == [], s\n"
-            "import raymarching, gridencoder, shencoder, activation, encoding, roi_align\n"
+            "import raymarching, gridencoder, shencoder, activation, encoding, roi_align, ffmlp\n"
             "from nerf.network import NeRFNetwork; from nerf.utils import Trainer, get_rays; from nerf.provider import NeRFDataset\n"
             "from roi_align.roi_align import roi_align_3d\n"
             "from gridencoder import GridEncoder; from encoding import get_encoder\n"
