@@ -14,6 +14,8 @@ Differences from upstream, all deliberate:
 * ``composite_rays_train`` optionally composites K extra channels (the fork's
   instance logits) with the weights detached.
 """
+import math
+
 import torch
 
 from . import _lib
@@ -44,6 +46,22 @@ def near_far_from_aabb(rays_o, rays_d, aabb, min_near=0.2):
     check(lib.inr_near_far_from_aabb(ptr(rays_o, F32, "rays_o"), ptr(rays_d, F32, "rays_d"), ptr(aabb, F32, "aabb"),
                                      N, float(min_near), ptr(nears), ptr(fars), stream_ptr()), "near_far_from_aabb")
     return nears, fars
+
+
+def sph_from_ray(rays_o, rays_d, radius):
+    """rays_o, rays_d [N,3], radius -> coords [N,2] in [-1,1]: where each ray leaves the sphere of that radius, as
+    (2 theta / pi - 1, phi / pi) with y the up axis - upstream's ``raymarching.sph_from_ray`` [U], the input of its
+    background model (``bg_radius > 0``).  The background model itself is outside the hot path, so this
+    helper is plain tensor ops; it exists because callers written against upstream import the name."""
+    o, d = rays_o.float(), rays_d.float()
+    A = (d * d).sum(-1)
+    B = (o * d).sum(-1)                                   # in fact B / 2
+    C = (o * o).sum(-1) - float(radius) ** 2
+    t = (-B + torch.sqrt(B * B - A * C)) / A              # the larger root: the exit point
+    p = o + t.unsqueeze(-1) * d
+    theta = torch.atan2(torch.sqrt(p[..., 0] ** 2 + p[..., 2] ** 2), p[..., 1])
+    phi = torch.atan2(p[..., 2], p[..., 0])
+    return torch.stack([2 * theta / math.pi - 1, phi / math.pi], -1)
 
 
 def morton3D(coords):

@@ -1,6 +1,7 @@
 """The drop-in surface SURVEY.md section 8b asks for: module / function / argument / parameter names of the
 reference's (absent) torch-ngp submodule, checked by introspection on the CPU (no kernels run)."""
 import inspect
+import math
 
 import torch
 
@@ -131,6 +132,19 @@ def test_load_checkpoint_accepts_upstream_shapes(tmp_path):
     assert any("optimizer state not restored" in str(x.message) for x in w)
     assert (b.epoch, b.global_step, b.model.mean_count, b.model.mean_density) == (7, 1234, 4321, 0.5)
     assert float(b.model.sigma_net[0].weight[0, 0]) == 0.25
+
+
+def test_sph_from_ray_lands_on_the_sphere():
+    from instance_nerf_amd import raymarching
+    g = torch.Generator().manual_seed(0)
+    o = torch.rand(100, 3, generator=g) - 0.5
+    d = torch.nn.functional.normalize(torch.randn(100, 3, generator=g), dim=-1)
+    c = raymarching.sph_from_ray(o, d, 3.0)
+    assert c.shape == (100, 2) and (c.abs() <= 1 + 1e-6).all()
+    theta, phi = (c[:, 0] + 1) * math.pi / 2, c[:, 1] * math.pi
+    p = 3.0 * torch.stack([torch.sin(theta) * torch.cos(phi), torch.cos(theta), torch.sin(theta) * torch.sin(phi)], -1)
+    t = ((p - o) * d).sum(-1, keepdim=True)
+    assert (t > 0).all() and torch.allclose(o + t * d, p, atol=1e-4)          # on the ray, in front of the origin
 
 
 def test_ffmlp_surface_and_cpu_forward():
