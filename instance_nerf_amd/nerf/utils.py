@@ -151,53 +151,81 @@ class MIoUMeter:
         return f"mIoU = {self.measure():.6f}"
 
 
-class FusedAdam:
-    """Adam(betas, eps) with one fused HIP sweep per tensor (reads p,g,m,v; writes p,m,v once).
+class FusedAdam(torch.optim.Optimizer):
+    """Adam(betas, eps) with one fused HIP sweep for all tensors of a step (reads p,g,m,v; writes p,m,v once).
 
-    Drop-in for ``torch.optim.Adam`` on the subset of its interface the Trainer uses
-    (``param_groups``, ``step``, ``zero_grad``, ``state_dict``/``load_state_dict``).
+    A ``torch.optim.Optimizer``: ``param_groups``, ``zero_grad``, ``state_dict`` / ``load_state_dict`` are the base
+    class's, the per-parameter state is torch.optim.Adam's (``step``, ``exp_avg``, ``exp_avg_sq``) - so upstream's
+    checkpoints (a torch Adam state dict under 'optimizer') load, what this class saves loads into torch's Adam, and
+    upstream's ``lr_scheduler(optimizer)`` (a ``LambdaLR``) accepts it.  Parameters without a gradient (frozen NeRF in
+    the instance stage) are skipped.
     """
 
     def __init__(self, params, lr=1e-2, betas=(0.9, 0.99), eps=1e-15):
-        groups = params if isinstance(params, (list, tuple)) and params and isinstance(params[0], dict) \
-            else [{"params": list(params)}]
-        self.param_groups = []
-        for g in groups:
-            g = dict(g)
-            g["params"] = [p for p in g["params"]]
-            g.setdefault("lr", lr)
-            g["initial_lr"] = g["lr"]
-            self.param_groups.append(g)
-        self.betas, self.eps = betas, eps
-        self.state = {}
+        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps))
         self.step_count = 0
 
-    def zero_grad(self, set_to_none=True):
-        for g in self.param_groups:
-            for p in g["params"]:
-                if set_to_none:
-                    p.grad = None
-                elif p.grad is not None:
-                    p.grad.zero_()
+    # betas / eps: one value for the whole optimiser (the kernel takes them once per launch)
+    @property
+    def betas(self):
+        return tuple(self.param_groups[0]["betas"])
 
-    @torch.no_grad()
-    def step(self, grad_scale=1.0):
-        """One launch for all tensors of the step (inr_adam_step_multi, 16 tensors per call)."""
-        import ctypes
-        lib = _lib.load()
-        self.step_count += 1
+    @property
+    def eps(self):
+        return self.param_groups[0]["eps"]
+
+    def _moments(self, p):
+        st = self.state[p]
+        if "exp_avg" not in st:
+            st["step"] = torch.tensor(float(self.step_count))
+            st["exp_avg"] = torch.zeros_like(p.data)
+            st["exp_avg_sq"] = torch.zeros_like(p.data)
+        return st
+
+    def load_state_dict(self, sd):
+        """torch.optim layout (own checkpoints and upstream's Adam checkpoints); round 1's private layout
+        ({'step', 'lrs', 'state': {i: (m, v)}}) is converted first."""
+        if "param_groups" not in sd:
+            flat = [p for g in self.param_groups for p in g["params"]]
+            for g, lr in zip(self.param_groups, sd["lrs"]):
+                g["lr"] = lr
+            for i, (m, v) in sd["state"].items():
+                p = flat[int(i)]
+                self.state[p] = {"step": torch.tensor(float(sd["step"])), "exp_avg": m.to(p.device), "exp_avg_sq": v.to(p.device)}
+            self.step_count = int(sd["step"])
+            return
+        super().load_state_dict(sd)
+        steps = [int(float(st["step"])) for st in self.state.values() if "step" in st]
+        self.step_count = max(steps) if steps else 0
+        for p, st in self.state.items():                     # the kernel wants contiguous fp32 moments
+            for k in ("exp_avg", "exp_avg_sq"):
+                if k in st:
+                    st[k] = st[k].to(p.device, torch.float32).contiguous()
+
+    def _jobs(self):
         jobs = []
         for g in self.param_groups:
             for p in g["params"]:
                 if p.grad is None or not p.requires_grad:
                     continue
-                st = self.state.get(p)
-                if st is None:
-                    st = self.state[p] = (torch.zeros_like(p.data), torch.zeros_like(p.data))
-                grad = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                for t, name in ((p.data, "param"), (grad, "grad"), (st[0], "exp_avg"), (st[1], "exp_avg_sq")):
-                    _lib.ptr(t, torch.float32, name)         # device / dtype / contiguity checks
-                jobs.append((p, grad, st[0], st[1], float(g["lr"])))
+                st = self._moments(p)
+                jobs.append((p, p.grad, st["exp_avg"], st["exp_avg_sq"], g))
+        return jobs
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_scale=1.0):
+        """One launch for all tensors of the step (inr_adam_step_multi, 16 tensors per call)."""
+        import ctypes
+        loss = closure() if closure is not None else None
+        lib = _lib.load()
+        self.step_count += 1
+        jobs = []
+        for p, grad, m, v, g in self._jobs():
+            grad = grad if grad.is_contiguous() else grad.contiguous()
+            for t, name in ((p.data, "param"), (grad, "grad"), (m, "exp_avg"), (v, "exp_avg_sq")):
+                _lib.ptr(t, torch.float32, name)         # device / dtype / contiguity checks
+            jobs.append((p, grad, m, v, float(g["lr"])))
+            self.state[p]["step"] = torch.tensor(float(self.step_count))
         for i in range(0, len(jobs), 16):
             chunk = jobs[i:i + 16]
             n = len(chunk)
@@ -211,20 +239,9 @@ class FusedAdam:
             # the C ABI wrote p in place behind autograd's back: bump the version counter so
             # cached MFMA-packed weights (NeRFNetwork._packed_weights) are refreshed
             torch.autograd.graph.increment_version(p)
+        return loss
 
     # -- hipGraph support: the step-dependent scalars live in a device tensor --------------------------------
-    def _jobs(self):
-        jobs = []
-        for g in self.param_groups:
-            for p in g["params"]:
-                if p.grad is None or not p.requires_grad:
-                    continue
-                st = self.state.get(p)
-                if st is None:
-                    st = self.state[p] = (torch.zeros_like(p.data), torch.zeros_like(p.data))
-                jobs.append((p, p.grad, st[0], st[1], g))
-        return jobs
-
     def refresh_hyper(self):
         """Advance the step counter and write [eps_t, lr_t...] for the NEXT launch of ``step_captured`` (a tiny
         kernel on the stream whose arguments carry the values: call it right before the launch / graph replay)."""
@@ -232,6 +249,8 @@ class FusedAdam:
         lib = _lib.load()
         self.step_count += 1
         lrs = [float(j[4]["lr"]) for j in self._hyper_jobs]
+        for j in self._hyper_jobs:
+            self.state[j[0]]["step"] = torch.tensor(float(self.step_count))
         _lib.check(lib.inr_adam_set_hyper((ctypes.c_float * len(lrs))(*lrs), len(lrs), self.betas[0], self.betas[1],
                                           self.eps, self.step_count, _lib.ptr(self._hyper_dev), _lib.stream_ptr()),
                    "adam_set_hyper")
@@ -261,51 +280,6 @@ class FusedAdam:
     def bump_versions(self):
         for j in getattr(self, "_hyper_jobs", []):
             torch.autograd.graph.increment_version(j[0])
-
-    def state_dict(self):
-        """``torch.optim.Adam.state_dict()`` layout (what upstream's checkpoints hold under 'optimizer'): per-parameter
-        ``step`` / ``exp_avg`` / ``exp_avg_sq`` keyed by the running parameter index, and the param groups."""
-        state, groups, i = {}, [], 0
-        for g in self.param_groups:
-            ids = []
-            for p in g["params"]:
-                if p in self.state:
-                    m, v = self.state[p]
-                    state[i] = {"step": torch.tensor(float(self.step_count)), "exp_avg": m, "exp_avg_sq": v}
-                ids.append(i)
-                i += 1
-            groups.append({"lr": g["lr"], "initial_lr": g.get("initial_lr", g["lr"]), "betas": tuple(self.betas),
-                           "eps": self.eps, "weight_decay": 0, "amsgrad": False, "params": ids})
-        return {"state": state, "param_groups": groups}
-
-    def load_state_dict(self, sd):
-        """Accepts the torch.optim layout (this class's own and upstream's Adam checkpoints) and round 1's private
-        layout ({'step', 'lrs', 'state': {i: (m, v)}})."""
-        flat = [p for g in self.param_groups for p in g["params"]]
-        if "param_groups" in sd:
-            if sum(len(g["params"]) for g in sd["param_groups"]) != len(flat):
-                raise ValueError("optimizer state has a different number of parameters")
-            for g, saved in zip(self.param_groups, sd["param_groups"]):
-                g["lr"] = saved["lr"]
-                g["initial_lr"] = saved.get("initial_lr", g.get("initial_lr", saved["lr"]))
-            if sd["param_groups"]:
-                self.betas = tuple(sd["param_groups"][0].get("betas", self.betas))
-                self.eps = sd["param_groups"][0].get("eps", self.eps)
-            steps = []
-            for i, st in sd["state"].items():
-                p = flat[int(i)]
-                if st["exp_avg"].shape != p.shape:
-                    raise ValueError(f"optimizer state {i}: shape {tuple(st['exp_avg'].shape)} != {tuple(p.shape)}")
-                self.state[p] = (st["exp_avg"].to(p.device, torch.float32).contiguous().clone(),
-                                 st["exp_avg_sq"].to(p.device, torch.float32).contiguous().clone())
-                steps.append(int(float(st["step"])))
-            self.step_count = max(steps) if steps else 0
-            return
-        self.step_count = sd["step"]
-        for g, lr in zip(self.param_groups, sd["lrs"]):
-            g["lr"] = lr
-        for i, (m, v) in sd["state"].items():
-            self.state[flat[i]] = (m.to(flat[i].device), v.to(flat[i].device))
 
 
 class _GradSync:
@@ -471,68 +445,124 @@ class ParamEMA:
 
 
 class Trainer:
-    """Minimal counterpart of upstream's ``Trainer`` for the two stages the reference runs
-    (SURVEY.md section 3.1): NeRF training (MSE on rgb) and instance-field training (NeRF frozen,
+    """Counterpart of upstream's ``Trainer`` (``nerf/utils.py`` of the un-vendored submodule) for the two stages the
+    reference runs: NeRF training (MSE on rgb) and instance-field training (NeRF frozen,
     cross entropy of rendered logits vs. matched-mask ids, ignore -1).
 
-    Same method names and step semantics as upstream (``train_step`` / ``eval_step`` / ``test_step``
-    / ``train`` / ``evaluate`` / ``save_checkpoint`` / ``load_checkpoint``); Adam(betas .9/.99,
-    eps 1e-15), LambdaLR 0.1^(step/iters), occupancy update every 16 steps.  One process per GPU;
-    with world_size > 1 each rank draws its own rays and gradients are all-reduced (RCCL).
+    The constructor takes upstream's arguments in upstream's order and meaning - ``optimizer`` is called with the model,
+    ``lr_scheduler`` with the optimizer, ``metrics`` are meters with ``update / measure / report / clear``,
+    ``use_checkpoint`` in {"latest", "latest_model", "best", "scratch", <path>} - so the construction in upstream's
+    ``main_nerf.py`` works unchanged; ``fp16`` is accepted and ignored (this path computes in fp32: no autocast, no
+    GradScaler), as is ``use_tensorboardX``.  Same methods and step semantics (``train_step`` / ``eval_step`` /
+    ``test_step`` / ``train`` / ``evaluate`` / ``test`` / ``save_checkpoint`` / ``load_checkpoint``).  Defaults when the
+    caller passes neither optimizer nor scheduler are upstream's main-script values: Adam(betas .9/.99, eps 1e-15) as
+    ``FusedAdam``, lr * 0.1^(step/iters), occupancy update every ``opt.update_extra_interval`` (16) steps.
+
+    Keyword-only extensions: ``stage`` ("nerf" | "instance"), ``lr``, ``iters``, ``fused_adam``,
+    ``update_extra_interval``, ``use_graph``.  One process per GPU; with world_size > 1 each rank draws its own rays and
+    gradients are all-reduced (RCCL), the table gradient from inside the backward (``grad_sync``).
     """
 
-    def __init__(self, name, opt, model, criterion=None, optimizer=None, lr=1e-2, iters=30000,
-                 local_rank=0, world_size=1, device=None, workspace="workspace", fused_adam=True,
-                 stage="nerf", update_extra_interval=16, ema_decay=None, use_graph=False):
+    def __init__(self, name, opt, model, criterion=None, optimizer=None, ema_decay=None, lr_scheduler=None, metrics=None,
+                 local_rank=0, world_size=1, device=None, mute=False, fp16=False, eval_interval=1, max_keep_ckpt=2,
+                 workspace="workspace", best_mode="min", use_loss_as_metric=True, report_metric_at_train=False,
+                 use_checkpoint="scratch", use_tensorboardX=False, scheduler_update_every_step=True, *,
+                 lr=1e-2, iters=30000, fused_adam=True, stage="nerf", update_extra_interval=None, use_graph=False):
         self.name, self.opt, self.model = name, opt, model
         self.world_size, self.local_rank = world_size, local_rank
         grad_sync.world_size = world_size
         self.device = device or (torch.device("cuda", local_rank) if torch.cuda.is_available() else torch.device("cpu"))
         self.stage = stage
         self.workspace = workspace
+        self.mute, self.fp16 = mute, False                     # fp32 path; upstream's -O flag is accepted, not applied
+        self.metrics = list(metrics) if metrics else []
+        self.eval_interval, self.max_keep_ckpt = eval_interval, max_keep_ckpt
+        self.best_mode, self.use_loss_as_metric = best_mode, use_loss_as_metric
+        self.report_metric_at_train = report_metric_at_train
+        self.scheduler_update_every_step = scheduler_update_every_step
+        if update_extra_interval is None:
+            update_extra_interval = getattr(opt, "update_extra_interval", 16) if opt is not None else 16
         self.update_extra_interval = update_extra_interval
         self.criterion = criterion or (torch.nn.MSELoss(reduction="none") if stage == "nerf" else None)
         model.to(self.device)
         if stage == "instance":
             model.freeze_nerf()
-        groups = [{"params": [p for p in g["params"] if p.requires_grad], "lr": g["lr"]} for g in model.get_params(lr)]
-        groups = [g for g in groups if g["params"]]
         if optimizer is not None:
-            self.optimizer = optimizer(groups)
-        elif fused_adam and self.device.type == "cuda":
-            self.optimizer = FusedAdam(groups, lr=lr, betas=(0.9, 0.99), eps=1e-15)
+            self.optimizer = optimizer(self.model)             # upstream: lambda model: Adam(model.get_params(lr), ...)
         else:
-            self.optimizer = torch.optim.Adam(groups, lr=lr, betas=(0.9, 0.99), eps=1e-15)
+            groups = [{"params": [p for p in g["params"] if p.requires_grad], "lr": g["lr"]} for g in model.get_params(lr)]
+            groups = [g for g in groups if g["params"]]
+            if fused_adam and self.device.type == "cuda":
+                self.optimizer = FusedAdam(groups, lr=lr, betas=(0.9, 0.99), eps=1e-15)
+            else:
+                self.optimizer = torch.optim.Adam(groups, lr=lr, betas=(0.9, 0.99), eps=1e-15)
         self.iters = iters
-        # upstream: ema_decay=0.95 from its main scripts; evaluation then runs on the averaged parameters.
-        # (Its GradScaler / fp16 autocast has no counterpart: this path computes in fp32.)
-        self.ema = ParamEMA([p for g in self.optimizer.param_groups for p in g["params"]], ema_decay) \
-            if ema_decay is not None else None
+        # upstream: lr_scheduler = lambda optimizer: LambdaLR(optimizer, lambda it: 0.1 ** min(it / opt.iters, 1)),
+        # stepped after every optimiser step; without one, exactly that rule is applied to the param groups
+        self.lr_scheduler = lr_scheduler(self.optimizer) if lr_scheduler is not None else None
+        # upstream: ema_decay=0.95 from its main scripts; evaluation then runs on the averaged parameters
+        trained = [p for g in self.optimizer.param_groups for p in g["params"] if p.requires_grad]
+        self.ema = ParamEMA(trained, ema_decay) if ema_decay is not None else None
         self.base_lrs = [g["lr"] for g in self.optimizer.param_groups]
         # use_graph: in the steady state (sample buffers sized by mean_count, no host read-back) the whole step -
         # march, fields, compositing, loss, backward, Adam - is captured once per buffer size as a hipGraph and
-        # replayed; one process, FusedAdam only.  Falls back to the eager step whenever the conditions do not hold.
-        self.use_graph = bool(use_graph) and world_size == 1 and isinstance(self.optimizer, FusedAdam)
+        # replayed; one process, FusedAdam only, built-in learning-rate rule.  Falls back to the eager step otherwise.
+        self.use_graph = (bool(use_graph) and world_size == 1 and isinstance(self.optimizer, FusedAdam)
+                          and self.lr_scheduler is None)
         self._graph = None
         self.global_step = 0
+        self.local_step = 0
         self.epoch = 0
-        self.stats = {"loss": [], "results": []}
+        self.stats = {"loss": [], "valid_loss": [], "results": [], "checkpoints": [], "best_result": None}
         self.bg_color = 1
+        self.log_ptr = None
+        self.ckpt_path = self.best_path = None
+        if self.workspace is not None:
+            self.ckpt_path = os.path.join(self.workspace, "checkpoints")
+            self.best_path = os.path.join(self.ckpt_path, f"{self.name}.pth")
+        if self.workspace is not None and use_checkpoint != "scratch":
+            if use_checkpoint in ("latest", "latest_model"):
+                self.load_checkpoint(model_only=use_checkpoint == "latest_model")
+            elif use_checkpoint == "best":
+                if self.best_path and os.path.exists(self.best_path):
+                    self.load_checkpoint(self.best_path)
+                else:
+                    self.load_checkpoint()
+            else:
+                self.load_checkpoint(use_checkpoint)
+
+    def log(self, *args, **kwargs):
+        if self.local_rank == 0 and not self.mute:
+            print(*args, **kwargs)
 
     # -- steps -------------------------------------------------------------------------------
     def _lr_step(self):
+        if self.lr_scheduler is not None:      # upstream's scheduler object: stepped AFTER the optimiser (see below)
+            return
         f = 0.1 ** min(self.global_step / self.iters, 1)
         for g, b in zip(self.optimizer.param_groups, self.base_lrs):
             g["lr"] = b * f
 
+    def _render_kwargs(self):
+        return vars(self.opt) if self.opt is not None else {}
+
     def train_step(self, data):
-        """data: rays_o, rays_d [B,N,3] and images [B,N,3] (stage 'nerf') or masks int64 [B,N] (stage 'instance')."""
-        outputs = self.model.render(data["rays_o"], data["rays_d"], staged=False, bg_color=self.bg_color, perturb=True,
-                                    force_all_rays=False, **vars(self.opt) if self.opt is not None else {})
+        """data: rays_o, rays_d [B,N,3] and images [B,N,3|4] (stage 'nerf') or masks int64 [B,N] (stage 'instance').
+        RGBA images are blended over a random per-ray background that the render receives too (upstream)."""
+        bg_color = self.bg_color
+        gt = None
+        if self.stage == "nerf":
+            images = data["images"]
+            gt = images
+            if images.shape[-1] == 4:
+                bg_color = torch.rand_like(images[..., :3])
+                gt = images[..., :3] * images[..., 3:] + bg_color * (1 - images[..., 3:])
+        outputs = self.model.render(data["rays_o"], data["rays_d"], staged=False, bg_color=bg_color, perturb=True,
+                                    force_all_rays=False, **self._render_kwargs())
         if self.stage == "nerf":
             pred = outputs["image"]
-            loss = self.criterion(pred, data["images"]).mean()
-            return pred, data["images"], loss
+            loss = self.criterion(pred, gt).mean()
+            return pred, gt, loss
         logits = outputs["instance"]
         K = logits.shape[-1]
         if logits.is_cuda and K <= 64 and logits.dtype == torch.float32:
@@ -542,23 +572,42 @@ class Trainer:
             loss = torch.nn.functional.cross_entropy(logits.reshape(-1, K), data["masks"].reshape(-1).long(), ignore_index=-1)
         return logits, data["masks"], loss
 
+    @staticmethod
+    def _as_image(t, data, channels=None):
+        """[B, H*W(, C)] -> [B, H, W(, C)] when the batch carries the image size (upstream's evaluation loaders)."""
+        if "H" in data and "W" in data and t.dim() >= 2 and t.shape[1] == int(data["H"]) * int(data["W"]):
+            tail = t.shape[2:]
+            return t.reshape(t.shape[0], int(data["H"]), int(data["W"]), *tail)
+        return t
+
     @torch.no_grad()
     def eval_step(self, data):
-        outputs = self.model.render(data["rays_o"], data["rays_d"], staged=True, bg_color=self.bg_color, perturb=False,
-                                    **vars(self.opt) if self.opt is not None else {})
+        """-> (prediction, depth, truth, loss); images may come as [B,N,C] or [B,H,W,C] (upstream), C = 3 or 4."""
+        rays_o, rays_d = data["rays_o"], data["rays_d"]
+        outputs = self.model.render(rays_o, rays_d, staged=True, bg_color=self.bg_color, perturb=False,
+                                    **self._render_kwargs())
         if self.stage == "nerf":
-            loss = self.criterion(outputs["image"], data["images"]).mean()
-            return outputs["image"], outputs["depth"], data["images"], loss
+            images = data["images"]
+            flat = images.reshape(images.shape[0], -1, images.shape[-1])
+            gt = flat[..., :3] * flat[..., 3:] + self.bg_color * (1 - flat[..., 3:]) if flat.shape[-1] == 4 else flat
+            loss = self.criterion(outputs["image"], gt).mean()
+            return (self._as_image(outputs["image"], data), self._as_image(outputs["depth"], data),
+                    self._as_image(gt, data), loss)
         logits = outputs["instance"]
         K = logits.shape[-1]
-        loss = torch.nn.functional.cross_entropy(logits.reshape(-1, K), data["masks"].reshape(-1).long(), ignore_index=-1)
-        return logits.argmax(-1), outputs["depth"], data["masks"], loss
+        masks = data["masks"].reshape(logits.shape[0], -1)
+        loss = torch.nn.functional.cross_entropy(logits.reshape(-1, K), masks.reshape(-1).long(), ignore_index=-1)
+        return (self._as_image(logits.argmax(-1), data), self._as_image(outputs["depth"], data),
+                self._as_image(masks, data), loss)
 
     @torch.no_grad()
     def test_step(self, data, bg_color=None, perturb=False):
-        outputs = self.model.render(data["rays_o"], data["rays_d"], staged=True, bg_color=bg_color or self.bg_color,
-                                    perturb=perturb, **vars(self.opt) if self.opt is not None else {})
-        return outputs["image"], outputs["depth"], outputs.get("instance")
+        outputs = self.model.render(data["rays_o"], data["rays_d"], staged=True,
+                                    bg_color=self.bg_color if bg_color is None else bg_color,
+                                    perturb=perturb, **self._render_kwargs())
+        inst = outputs.get("instance")
+        return (self._as_image(outputs["image"], data), self._as_image(outputs["depth"], data),
+                None if inst is None else self._as_image(inst, data))
 
     # -- loops -------------------------------------------------------------------------------
     # -- captured step ----------------------------------------------------------------------
@@ -576,8 +625,8 @@ class Trainer:
         opt = self.optimizer
         for g in opt.param_groups:              # moments and the hyper-parameter tensor must exist BEFORE the capture
             for p in g["params"]:               # (an allocation + zero fill inside it would be replayed every step)
-                if p.requires_grad and p not in opt.state:
-                    opt.state[p] = (torch.zeros_like(p.data), torch.zeros_like(p.data))
+                if p.requires_grad:
+                    opt._moments(p)
         if getattr(opt, "_hyper_dev", None) is None:
             opt._hyper_dev = torch.zeros(17, dtype=torch.float32, device=self.device)
         self.optimizer.zero_grad()
@@ -626,62 +675,170 @@ class Trainer:
         allreduce_gradients(params, self.world_size)
         self._lr_step()
         self.optimizer.step()
+        if self.lr_scheduler is not None and self.scheduler_update_every_step:
+            self.lr_scheduler.step()
         if self.ema is not None:
             self.ema.update()
         return loss.detach()
 
     def train(self, train_loader, valid_loader=None, max_epochs=1):
-        for epoch in range(max_epochs):
+        """Upstream's epoch loop: cells no training camera sees are marked once (loaders that expose ``_data.poses`` /
+        ``_data.intrinsics``), every epoch is checkpointed (``max_keep_ckpt`` rotating files), every ``eval_interval``
+        epochs the validation loader is evaluated and the best result kept."""
+        if self.model.cuda_ray and self.epoch == 0:
+            d = getattr(train_loader, "_data", None)
+            if d is not None and hasattr(d, "poses") and hasattr(d, "intrinsics"):
+                self.model.mark_untrained_grid(d.poses, d.intrinsics)
+        for _ in range(self.epoch + 1, self.epoch + max_epochs + 1):
             self.epoch += 1
-            total, n = 0.0, 0
-            for data in train_loader:
-                total += float(self.train_one_step(data))
-                n += 1
-            self.stats["loss"].append(total / max(n, 1))
-            if valid_loader is not None:
-                self.evaluate(valid_loader)
+            self.train_one_epoch(train_loader)
+            if self.workspace is not None and self.local_rank == 0:
+                self.save_checkpoint(full=True, best=False)
+            if valid_loader is not None and self.epoch % max(self.eval_interval, 1) == 0:
+                self.evaluate_one_epoch(valid_loader)
+                if self.workspace is not None and self.local_rank == 0:
+                    self.save_checkpoint(full=False, best=True)
+
+    def train_one_epoch(self, loader):
+        total, n = 0.0, 0
+        for m in self.metrics:
+            m.clear()
+        for data in loader:
+            total += float(self.train_one_step(data))
+            n += 1
+        if self.lr_scheduler is not None and not self.scheduler_update_every_step:
+            self.lr_scheduler.step()
+        self.stats["loss"].append(total / max(n, 1))
+        self.log(f"==> epoch {self.epoch}: loss {self.stats['loss'][-1]:.6f}, lr {self.optimizer.param_groups[0]['lr']:.6f}")
+
+    def evaluate(self, loader, name=None):
+        return self.evaluate_one_epoch(loader, name)
 
     @torch.no_grad()
-    def evaluate(self, loader):
+    def evaluate_one_epoch(self, loader, name=None):
+        """Runs the metrics (the caller's, else PSNR for the NeRF stage / mIoU for the instance stage) on the averaged
+        parameters when an EMA is kept; appends to ``stats['results']`` (first metric, or the loss when
+        ``use_loss_as_metric`` and no metric is given) and ``stats['valid_loss']``."""
         self.model.eval()
-        meter = PSNRMeter() if self.stage == "nerf" else MIoUMeter(self.model.num_instances)
+        meters = self.metrics or [PSNRMeter() if self.stage == "nerf" else MIoUMeter(self.model.num_instances)]
+        for m in meters:
+            m.clear()
         if self.ema is not None:
             self.ema.store()
             self.ema.copy_to()
+        total, n = 0.0, 0
         for data in loader:
-            pred, _, truth, _ = self.eval_step(data)
-            meter.update(pred, truth)
+            pred, _, truth, loss = self.eval_step(data)
+            for m in meters:
+                m.update(pred, truth)
+            total += float(loss)
+            n += 1
         if self.ema is not None:
             self.ema.restore()
-        result = meter.measure()
+        self.model.train()
+        # upstream: the validation loss is the result unless use_loss_as_metric=False (then the first metric).  Without
+        # caller-supplied metrics the stage's own meter (PSNR / mIoU, higher is better) is the result.
+        as_loss = bool(self.metrics) and self.use_loss_as_metric
+        self._result_mode = self.best_mode if self.metrics else "max"
+        result = total / max(n, 1) if as_loss else meters[0].measure()
         if self.world_size > 1:
             t = torch.tensor([result], dtype=torch.float64, device=self.device)
             dist.all_reduce(t)
             result = float(t.item()) / self.world_size
+        self.stats["valid_loss"].append(total / max(n, 1))
         self.stats["results"].append(result)
+        for m in meters:
+            self.log(m.report())
         return result
 
-    # -- checkpoint (upstream keys: epoch, global_step, stats, model, optimizer, mean_count, mean_density) ----
-    def save_checkpoint(self, path=None):
-        path = path or os.path.join(self.workspace, "checkpoints", f"{self.name}_ep{self.epoch:04d}.pth")
-        os.makedirs(os.path.dirname(path), exist_ok=True)
-        state = {"epoch": self.epoch, "global_step": self.global_step, "stats": self.stats,
-                 "model": self.model.state_dict(), "optimizer": self.optimizer.state_dict()}
+    @torch.no_grad()
+    def test(self, loader, save_path=None, name=None, write_video=False):
+        """Renders every view of ``loader`` and writes ``<name>_<i>_rgb.png`` / ``_depth.png`` (instance stage: also
+        ``_instance.png`` with the arg-max ids) into ``save_path`` (default ``<workspace>/results``).  Upstream also
+        assembles a video with imageio, which this image does not have: ``write_video`` is accepted and ignored."""
+        from PIL import Image
+        save_path = save_path or os.path.join(self.workspace or ".", "results")
+        name = name or f"{self.name}_ep{self.epoch:04d}"
+        os.makedirs(save_path, exist_ok=True)
+        self.model.eval()
+        written = []
+        for i, data in enumerate(loader):
+            rgb, depth, inst = self.test_step(data)
+            if rgb.dim() != 4:
+                raise ValueError("test() needs batches that carry the image size ('H', 'W')")
+            img = (rgb[0].clamp(0, 1) * 255).byte().cpu().numpy()
+            dep = (depth[0].clamp(0, 1) * 255).byte().cpu().numpy()
+            Image.fromarray(img).save(os.path.join(save_path, f"{name}_{i:04d}_rgb.png"))
+            Image.fromarray(dep).save(os.path.join(save_path, f"{name}_{i:04d}_depth.png"))
+            written.append(os.path.join(save_path, f"{name}_{i:04d}_rgb.png"))
+            if inst is not None:
+                ids = inst[0].argmax(-1).clamp(0, 255).byte().cpu().numpy()
+                Image.fromarray(ids).save(os.path.join(save_path, f"{name}_{i:04d}_instance.png"))
+        self.model.train()
+        return written
+
+    # -- checkpoint (upstream keys: epoch, global_step, stats, model, optimizer, lr_scheduler, ema, mean_count, mean_density)
+    def save_checkpoint(self, name=None, full=False, best=False, remove_old=True, path=None):
+        """``full``: with optimizer / scheduler / EMA state (to resume training); ``best``: written to
+        ``<workspace>/checkpoints/<name>.pth`` only when the last result improves on ``stats['best_result']``
+        (``best_mode``); otherwise a rotating ``<name>_ep####.pth`` (``max_keep_ckpt`` files kept)."""
+        state = {"epoch": self.epoch, "global_step": self.global_step, "stats": self.stats}
         if self.model.cuda_ray:
             state["mean_count"] = self.model.mean_count
             state["mean_density"] = self.model.mean_density
-        if self.ema is not None:
-            state["ema"] = self.ema.state_dict()
+        if full or path is not None:
+            state["optimizer"] = self.optimizer.state_dict()
+            if self.lr_scheduler is not None:
+                state["lr_scheduler"] = self.lr_scheduler.state_dict()
+            if self.ema is not None:
+                state["ema"] = self.ema.state_dict()
+        if path is None and best:
+            results = self.stats["results"]
+            if not results:
+                return None
+            cur, prev = results[-1], self.stats["best_result"]
+            mode = getattr(self, "_result_mode", self.best_mode)
+            better = prev is None or (cur < prev if mode == "min" else cur > prev)
+            if not better:
+                return None
+            self.stats["best_result"] = cur
+            if self.ema is not None:                       # the best checkpoint holds the averaged parameters
+                self.ema.store()
+                self.ema.copy_to()
+            state["model"] = self.model.state_dict()
+            if self.ema is not None:
+                self.ema.restore()
+            path = self.best_path
+        else:
+            state["model"] = self.model.state_dict()
+            if path is None:
+                name = name or f"{self.name}_ep{self.epoch:04d}"
+                path = os.path.join(self.ckpt_path or os.path.join(self.workspace or ".", "checkpoints"), f"{name}.pth")
+                if remove_old:
+                    self.stats["checkpoints"].append(path)
+                    while len(self.stats["checkpoints"]) > self.max_keep_ckpt:
+                        old = self.stats["checkpoints"].pop(0)
+                        if os.path.exists(old) and self.local_rank == 0:
+                            os.remove(old)
+        os.makedirs(os.path.dirname(path), exist_ok=True)
         if self.local_rank == 0:
             torch.save(state, path)
         return path
 
-    def load_checkpoint(self, path, model_only=False):
-        """Upstream semantics: a checkpoint without a 'model' key is a bare model state dict; missing / unexpected
-        keys are reported, not fatal; a failing optimizer or EMA restore only warns (e.g. an Adam state saved for
-        a different set of trained parameters)."""
+    def load_checkpoint(self, checkpoint=None, model_only=False):
+        """``checkpoint`` None: the newest ``<name>_ep*.pth`` of the workspace (nothing happens when there is none).
+        Upstream semantics: a file without a 'model' key is a bare model state dict; missing / unexpected keys are
+        reported, not fatal; a failing optimizer / scheduler / EMA restore only warns (e.g. an Adam state saved for a
+        different set of trained parameters)."""
+        import glob
         import warnings
-        state = torch.load(path, map_location=self.device, weights_only=False)
+        if checkpoint is None:
+            found = sorted(glob.glob(os.path.join(self.ckpt_path or "", f"{self.name}_ep*.pth")))
+            if not found:
+                self.log("[INFO] no checkpoint found, model randomly initialized")
+                return
+            checkpoint = found[-1]
+        state = torch.load(checkpoint, map_location=self.device, weights_only=False)
         if "model" not in state:
             self.model.load_state_dict(state, strict=False)
             return
@@ -695,14 +852,10 @@ class Trainer:
             return
         self.epoch = state.get("epoch", self.epoch)
         self.global_step = state.get("global_step", self.global_step)
-        self.stats = state.get("stats", self.stats)
-        if "optimizer" in state:
-            try:
-                self.optimizer.load_state_dict(state["optimizer"])
-            except Exception as e:                                    # noqa: BLE001 - upstream warns and goes on
-                warnings.warn(f"load_checkpoint: optimizer state not restored ({type(e).__name__}: {e})")
-        if self.ema is not None and "ema" in state:
-            try:
-                self.ema.load_state_dict(state["ema"])
-            except Exception as e:                                    # noqa: BLE001
-                warnings.warn(f"load_checkpoint: EMA state not restored ({type(e).__name__}: {e})")
+        self.stats = {**self.stats, **state.get("stats", {})}
+        for key, obj in (("optimizer", self.optimizer), ("lr_scheduler", self.lr_scheduler), ("ema", self.ema)):
+            if obj is not None and key in state:
+                try:
+                    obj.load_state_dict(state[key])
+                except Exception as e:                                # noqa: BLE001 - upstream warns and goes on
+                    warnings.warn(f"load_checkpoint: {key} state not restored ({type(e).__name__}: {e})")

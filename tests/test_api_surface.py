@@ -69,6 +69,13 @@ def test_trainer_surface():
     p = inspect.signature(Trainer.__init__).parameters
     assert {"name", "opt", "model", "criterion", "optimizer", "ema_decay", "lr", "local_rank", "world_size", "device",
             "workspace"} <= set(p)
+    # upstream's constructor, in upstream's order (main_nerf.py builds the Trainer with these)
+    assert list(p)[1:23] == ["name", "opt", "model", "criterion", "optimizer", "ema_decay", "lr_scheduler", "metrics",
+                             "local_rank", "world_size", "device", "mute", "fp16", "eval_interval", "max_keep_ckpt",
+                             "workspace", "best_mode", "use_loss_as_metric", "report_metric_at_train", "use_checkpoint",
+                             "use_tensorboardX", "scheduler_update_every_step"]
+    for m in ("train_one_epoch", "evaluate_one_epoch", "test", "log"):
+        assert callable(getattr(Trainer, m)), m
     assert list(inspect.signature(get_rays).parameters)[:6] == ["poses", "intrinsics", "H", "W", "N", "error_map"]
     opt = FusedAdam([torch.nn.Parameter(torch.zeros(3))], lr=1e-2)
     assert opt.betas == (0.9, 0.99) and opt.eps == 1e-15 and opt.param_groups[0]["lr"] == 1e-2
@@ -90,7 +97,10 @@ def test_fused_adam_state_dict_is_the_torch_adam_layout():
     mine.load_state_dict(sd)
     assert mine.step_count == 3 and [g["lr"] for g in mine.param_groups] == [1e-2, 3e-3]
     for i, p in enumerate(ps):
-        assert torch.equal(mine.state[p][0], sd["state"][i]["exp_avg"]) and torch.equal(mine.state[p][1], sd["state"][i]["exp_avg_sq"])
+        assert torch.equal(mine.state[p]["exp_avg"], sd["state"][i]["exp_avg"]) and torch.equal(mine.state[p]["exp_avg_sq"], sd["state"][i]["exp_avg_sq"])
+    assert isinstance(mine, torch.optim.Optimizer)
+    sched = torch.optim.lr_scheduler.LambdaLR(mine, lambda it: 0.1 ** min(it / 100, 1))     # upstream's scheduler accepts it
+    assert sched.get_last_lr() == [1e-2, 3e-3]
     out = mine.state_dict()
     assert set(out) == {"state", "param_groups"} and set(out["state"][0]) == {"step", "exp_avg", "exp_avg_sq"}
     back = torch.optim.Adam([{"params": [ps[0]]}, {"params": [ps[1]]}])
@@ -99,7 +109,7 @@ def test_fused_adam_state_dict_is_the_torch_adam_layout():
     assert torch.equal(back.state[ps[0]]["exp_avg_sq"], sd["state"][0]["exp_avg_sq"])
     old = FusedAdam([{"params": ps}])
     old.load_state_dict({"step": 9, "lrs": [5e-3], "state": {1: (torch.ones(7), torch.full((7,), 2.0))}})
-    assert old.step_count == 9 and old.param_groups[0]["lr"] == 5e-3 and float(old.state[ps[1]][1][0]) == 2.0
+    assert old.step_count == 9 and old.param_groups[0]["lr"] == 5e-3 and float(old.state[ps[1]]["exp_avg_sq"][0]) == 2.0
     import pytest
     with pytest.raises(ValueError):
         FusedAdam([{"params": ps[:1]}]).load_state_dict(sd)      # different parameter set: caller decides (Trainer warns)
@@ -121,7 +131,7 @@ def test_load_checkpoint_accepts_upstream_shapes(tmp_path):
                 "mean_count": 4321, "mean_density": 0.5,
                 "optimizer": torch.optim.Adam([torch.nn.Parameter(torch.zeros(2))]).state_dict()}, full)
     make = lambda: Trainer("t", None, NeRFNetwork(**kw), stage="instance", device=torch.device("cpu"),
-                           optimizer=lambda groups: FusedAdam(groups))
+                           optimizer=lambda model: FusedAdam(model.get_params(1e-2)), workspace=None)   # upstream: optimizer(model)
     a = make()
     a.load_checkpoint(bare)
     assert float(a.model.sigma_net[0].weight[0, 0]) == 0.25 and float(a.model.density_grid[0, 0]) == 3.0

@@ -1213,7 +1213,7 @@ def test_trainer_checkpoint_roundtrip(tmp_path, room, room_bitfield, level_table
     a = make()
     for s in range(3):
         a.train_one_step(batch(s))
-    path = a.save_checkpoint()
+    path = a.save_checkpoint(full=True)          # upstream: full = with optimizer / scheduler / EMA state
     state = torch.load(path, map_location="cpu", weights_only=False)
     assert {"epoch", "global_step", "stats", "model", "optimizer", "mean_count", "mean_density"} <= set(state)
     b = make()
@@ -1596,6 +1596,66 @@ def test_nerf_field_fused_training_autograd(level_table):
     for a, b in zip(res[True][2], res[False][2]):
         assert a.shape == b.shape
         assert torch.linalg.norm(a - b) < 2e-2 * torch.linalg.norm(b)
+
+
+@pytest.mark.parametrize("opt_kind", ["torch_adam", "fused_adam"])
+def test_trainer_built_the_way_upstreams_main_script_builds_it(tmp_path, room, opt_kind):
+    """The construction of upstream's main_nerf.py, verbatim in shape: optimizer = lambda model: Adam(model.get_params(lr)),
+    lr_scheduler = lambda optimizer: LambdaLR(...), metrics=[PSNRMeter()], fp16=True (accepted, fp32 is computed),
+    use_checkpoint='latest', then train(train_loader, valid_loader, max_epochs) and test(loader): epochs are
+    checkpointed with rotation, the validation loss is the result, the best checkpoint is kept, a second Trainer on
+    the same workspace resumes from the newest checkpoint, test() writes the frames."""
+    from argparse import Namespace
+    from instance_nerf_amd.nerf import NeRFNetwork
+    from instance_nerf_amd.nerf.utils import FusedAdam, PSNRMeter, Trainer, get_rays
+    opt = Namespace(lr=1e-2, iters=64, update_extra_interval=4, dt_gamma=0, max_steps=256, cuda_ray=True, fp16=True,
+                    workspace=str(tmp_path), seed=0, num_rays=256, some_cli_flag_the_renderer_ignores=True)
+    poses, intr, H, W = room.cameras(n=4, H=32, W=32, focal=16.0)
+
+    def view(i, n=None):
+        r = get_rays(_t(poses[i:i + 1]), intr, H, W, N=n if n else -1)
+        rgb, _, _ = room.trace(r["rays_o"][0].cpu().numpy(), r["rays_d"][0].cpu().numpy())
+        d = {"rays_o": r["rays_o"], "rays_d": r["rays_d"], "H": H, "W": W}
+        d["images"] = _t(rgb)[None] if n else _t(rgb).view(1, H, W, 3)
+        return d
+    train_loader = [view(i % 3, 256) for i in range(6)]
+    valid_loader = [view(3)]
+
+    def build():
+        torch.manual_seed(0)
+        model = NeRFNetwork(encoding="hashgrid", bound=1, cuda_ray=True, density_scale=1, min_near=0.05, density_thresh=10,
+                            bg_radius=-1)
+        criterion = torch.nn.MSELoss(reduction="none")
+        if opt_kind == "torch_adam":
+            optimizer = lambda model: torch.optim.Adam(model.get_params(opt.lr), betas=(0.9, 0.99), eps=1e-15)
+        else:
+            optimizer = lambda model: FusedAdam(model.get_params(opt.lr), betas=(0.9, 0.99), eps=1e-15)
+        scheduler = lambda optimizer: torch.optim.lr_scheduler.LambdaLR(optimizer, lambda it: 0.1 ** min(it / opt.iters, 1))
+        return Trainer("ngp", opt, model, device=torch.device(DEV), workspace=opt.workspace, optimizer=optimizer,
+                       criterion=criterion, ema_decay=0.95, fp16=opt.fp16, lr_scheduler=scheduler,
+                       scheduler_update_every_step=True, metrics=[PSNRMeter()], use_checkpoint="latest", eval_interval=1,
+                       mute=True)
+    tr = build()
+    assert tr.update_extra_interval == 4 and tr.epoch == 0
+    tr.train(train_loader, valid_loader, 3)
+    assert tr.epoch == 3 and tr.global_step == 18 and len(tr.stats["loss"]) == 3 and len(tr.stats["valid_loss"]) == 3
+    assert tr.stats["results"] == tr.stats["valid_loss"]                       # use_loss_as_metric (upstream's default)
+    assert abs(tr.optimizer.param_groups[0]["lr"] - 1e-2 * 0.1 ** (18 / 64)) < 1e-9
+    ck = sorted(os.listdir(tmp_path / "checkpoints"))
+    assert ck == ["ngp.pth", "ngp_ep0002.pth", "ngp_ep0003.pth"]              # two rotating files + the best one
+    assert tr.stats["best_result"] == min(tr.stats["results"])
+    assert tr.model.mean_count > 0 and tr.stats["loss"][-1] < tr.stats["loss"][0]
+    again = build()                                                            # 'latest': resumes where the first stopped
+    assert again.epoch == 3 and again.global_step == 18
+    assert torch.equal(again.model.encoder.embeddings, tr.model.encoder.embeddings)
+    assert abs(again.optimizer.param_groups[0]["lr"] - tr.optimizer.param_groups[0]["lr"]) < 1e-12
+    torch.manual_seed(5)                                                       # the step jitters its ray starts
+    la = float(tr.train_one_step(train_loader[0]))
+    torch.manual_seed(5)
+    lb = float(again.train_one_step(train_loader[0]))
+    assert abs(la - lb) < 1e-6 * max(1.0, abs(la))
+    files = again.test([view(3)], save_path=str(tmp_path / "results"))
+    assert len(files) == 1 and os.path.exists(files[0]) and os.path.exists(files[0].replace("_rgb", "_depth"))
 
 
 def test_trainer_runs_on_a_transforms_json_scene(tmp_path, room):
