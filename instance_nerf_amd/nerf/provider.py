@@ -76,9 +76,26 @@ class NeRFDataset:
     """
 
     def __init__(self, path, type="train", device="cpu", downscale=1, scale=0.33, offset=(0, 0, 0), num_rays=4096,
-                 mask_dir=None, num_instances=0, preload=True, seed=0):
+                 mask_dir=None, num_instances=0, preload=True, seed=0, n_test=10):
         import json
         import os
+        if hasattr(path, "path"):
+            # upstream's call: NeRFDataset(opt, device=device, type='train', downscale=1, n_test=10) - the second
+            # positional argument is the device there; path / scale / offset / num_rays / preload come from ``opt``
+            opt = path
+
+            def is_device(v):
+                return isinstance(v, torch.device) or (isinstance(v, str) and v.split(":")[0] in ("cpu", "cuda"))
+            if is_device(type) and not is_device(device):
+                type, device = device, type                    # upstream's positional order: (opt, device, type)
+            elif is_device(type):
+                type, device = "train", type                   # NeRFDataset(opt, device)
+            path = opt.path
+            scale, offset = getattr(opt, "scale", scale), getattr(opt, "offset", offset)
+            num_rays, preload = getattr(opt, "num_rays", num_rays), getattr(opt, "preload", preload)
+            mask_dir = getattr(opt, "mask_dir", mask_dir)
+            num_instances = getattr(opt, "num_instances", num_instances)
+            self.opt = opt
         self.root, self.type, self.device = path, type, torch.device(device)
         self.training = type in ("train", "all", "trainval")
         self.num_rays = num_rays if self.training else -1
@@ -173,6 +190,9 @@ class NeRFDataset:
             yield self[i]
 
     def dataloader(self):
-        """Upstream returns a ``DataLoader(list(range(n)), batch_size=1, collate_fn=self.collate)``; iterating this
-        object yields the same batches in the same way."""
+        """Upstream returns a ``DataLoader(list(range(n)), batch_size=1, collate_fn=self.collate)`` that carries the
+        dataset as ``_data`` (the Trainer reads ``_data.poses`` / ``_data.intrinsics`` for ``mark_untrained_grid``) and
+        a ``has_gt`` flag; iterating this object yields the same batches in the same way."""
+        self._data = self
+        self.has_gt = self.images is not None
         return self

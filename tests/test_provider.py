@@ -63,6 +63,25 @@ def test_nerf_dataset_reads_transforms_images_and_masks(tmp_path):
     assert len(list(iter(ds))) == 4
 
 
+def test_nerf_dataset_upstream_call_convention(tmp_path):
+    """NeRFDataset(opt, device=device, type='train').dataloader() - upstream's main script - reads path / scale /
+    num_rays from the namespace; the loader carries the dataset as ``_data`` (poses, intrinsics for the Trainer)."""
+    from argparse import Namespace
+    from instance_nerf_amd.nerf.provider import NeRFDataset
+    _write_scene(str(tmp_path))
+    opt = Namespace(path=str(tmp_path), scale=0.5, offset=[0, 0, 0], bound=1, num_rays=33, preload=False, fp16=False)
+    a = NeRFDataset(opt, device=torch.device("cpu"), type="train")
+    b = NeRFDataset(opt, torch.device("cpu"), "train")                        # positional, upstream's order
+    c = NeRFDataset(opt, "cpu")
+    for ds in (a, b, c):
+        assert ds.type == "train" and ds.device == torch.device("cpu") and ds.num_rays == 33 and len(ds) == 4
+    ref = NeRFDataset(str(tmp_path), type="train", scale=0.5, num_rays=33)
+    assert torch.equal(a.poses, ref.poses)
+    loader = a.dataloader()
+    assert loader._data is a and loader.has_gt and loader._data.intrinsics == ref.intrinsics
+    assert next(iter(loader))["rays_o"].shape == (1, 33, 3)
+
+
 def test_nerf_dataset_errors(tmp_path):
     from instance_nerf_amd.nerf.provider import NeRFDataset
     with pytest.raises(FileNotFoundError):
