@@ -182,6 +182,14 @@ class FusedAdam(torch.optim.Optimizer):
             st["exp_avg_sq"] = torch.zeros_like(p.data)
         return st
 
+    def state_dict(self):
+        # torch keeps one 'step' tensor per parameter; here all trained tensors step together, so the per-parameter
+        # entries are only materialised when a state dict is asked for (not 4-9 host tensors per training step)
+        for st in self.state.values():
+            if "exp_avg" in st:
+                st["step"] = torch.tensor(float(self.step_count))
+        return super().state_dict()
+
     def load_state_dict(self, sd):
         """torch.optim layout (own checkpoints and upstream's Adam checkpoints); round 1's private layout
         ({'step', 'lrs', 'state': {i: (m, v)}}) is converted first."""
@@ -225,7 +233,6 @@ class FusedAdam(torch.optim.Optimizer):
             for t, name in ((p.data, "param"), (grad, "grad"), (m, "exp_avg"), (v, "exp_avg_sq")):
                 _lib.ptr(t, torch.float32, name)         # device / dtype / contiguity checks
             jobs.append((p, grad, m, v, float(g["lr"])))
-            self.state[p]["step"] = torch.tensor(float(self.step_count))
         for i in range(0, len(jobs), 16):
             chunk = jobs[i:i + 16]
             n = len(chunk)
@@ -249,8 +256,6 @@ class FusedAdam(torch.optim.Optimizer):
         lib = _lib.load()
         self.step_count += 1
         lrs = [float(j[4]["lr"]) for j in self._hyper_jobs]
-        for j in self._hyper_jobs:
-            self.state[j[0]]["step"] = torch.tensor(float(self.step_count))
         _lib.check(lib.inr_adam_set_hyper((ctypes.c_float * len(lrs))(*lrs), len(lrs), self.betas[0], self.betas[1],
                                           self.eps, self.step_count, _lib.ptr(self._hyper_dev), _lib.stream_ptr()),
                    "adam_set_hyper")
