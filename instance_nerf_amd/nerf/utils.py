@@ -104,6 +104,27 @@ def get_rays(poses, intrinsics, H, W, N=-1, error_map=None, inds=None, patch=0):
     return {"rays_o": rays_o, "rays_d": rays_d.contiguous(), "inds": inds[None].expand(B, -1)}
 
 
+def seed_everything(seed):
+    """upstream ``nerf/utils.py::seed_everything``: python, numpy and torch (host + device) generators."""
+    import random
+    random.seed(seed)
+    os.environ["PYTHONHASHSEED"] = str(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed(seed)
+
+
+def linear_to_srgb(x):
+    """upstream ``nerf/utils.py::linear_to_srgb``."""
+    return torch.where(x < 0.0031308, 12.92 * x, 1.055 * x.clamp(min=0.0031308) ** 0.41666 - 0.055)
+
+
+def srgb_to_linear(x):
+    """upstream ``nerf/utils.py::srgb_to_linear``."""
+    return torch.where(x < 0.04045, x / 12.92, ((x.clamp(min=0.04045) + 0.055) / 1.055) ** 2.4)
+
+
 class PSNRMeter:
     def __init__(self):
         self.V, self.N = 0.0, 0

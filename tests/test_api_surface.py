@@ -79,6 +79,16 @@ def test_trainer_surface():
     assert list(inspect.signature(get_rays).parameters)[:6] == ["poses", "intrinsics", "H", "W", "N", "error_map"]
     opt = FusedAdam([torch.nn.Parameter(torch.zeros(3))], lr=1e-2)
     assert opt.betas == (0.9, 0.99) and opt.eps == 1e-15 and opt.param_groups[0]["lr"] == 1e-2
+    from instance_nerf_amd.nerf import utils
+    utils.seed_everything(3)
+    a = torch.rand(2)
+    utils.seed_everything(3)
+    assert torch.equal(a, torch.rand(2))
+    x = torch.linspace(0, 1, 50)
+    assert torch.allclose(utils.srgb_to_linear(utils.linear_to_srgb(x)), x, atol=1e-4)
+    m = utils.PSNRMeter()
+    m.update(torch.zeros(4, 3), torch.full((4, 3), 0.1))
+    assert abs(m.measure() - 20.0) < 1e-4 and "PSNR" in m.report()
 
 
 def test_fused_adam_state_dict_is_the_torch_adam_layout():
