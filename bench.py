@@ -204,7 +204,9 @@ def main():
     ap.add_argument("--res", type=int, default=800)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train-probe", action="store_true")
-    ap.add_argument("--streams", type=int, default=1, help="HIP streams frames alternate on (1 = no overlap)")
+    ap.add_argument("--no-pipeline-probe", action="store_true", help="skip the secondary two-stream measurement")
+    ap.add_argument("--pipeline", type=int, default=0,
+                    help="1: headline loop through FramePipeline (views alternate on two streams)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -246,44 +248,55 @@ def main():
     poses, intr, H, W = room.cameras(H=args.res, W=args.res, focal=args.res / 2.0)
     poses_d = torch.from_numpy(poses).to(dev)
 
-    # Frames can alternate between several HIP streams (--streams N) so that the marching / compositing
-    # launches of frame i+1 run underneath the field kernel of frame i (field kernels stay serialised
-    # through an event).  MEASURED SLOWER on MI355X - 2 streams: 2700 vs 4190 Msamples/s, the field kernel
-    # goes from 5.9 to 11.6 ms when 640k marching threads share its CUs and caches - so the default is 1.
-    # The same wrapper carries the timing events around the dominant kernel, on the stream it is launched on.
-    n_streams = max(1, args.streams)
-    streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
+    # The headline loop renders one view at a time on one stream.  The wrapper carries the timing events around the
+    # dominant kernel, on the stream it is launched on.  (Two alternating streams - FramePipeline, the "pipelined"
+    # object of the line - hide the march and the compositing under the field kernel but slow that kernel down:
+    # profiles/r02_NOTES.txt section 18.)
     ev_pairs = []
-    gate = {"done": None}
 
     def timed(fn):
         def wrapper(x, *rest):
             st = torch.cuda.current_stream()
-            if gate["done"] is not None:
-                st.wait_event(gate["done"])
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(st)
             out = fn(x, *rest)
             e1.record(st)
-            gate["done"] = e1
             ev_pairs.append((e0, e1, x.shape[0]))
             return out
         return wrapper
     net.forward = timed(net.forward)
     net.forward_table = timed(net.forward_table)      # the entry the fused frame path uses
 
-    def step(i):
+    pipe = None
+    if args.pipeline:
+        from instance_nerf_amd.nerf.renderer import FramePipeline
+        pipe = FramePipeline(net, dev)
+
+    def step_pipelined(i):
         view = (i * world + rank) % poses_d.shape[0]
-        st = streams[i % n_streams]
-        st.wait_stream(torch.cuda.current_stream())
+        st = pipe.next_stream()
         with torch.cuda.stream(st):
-            r = get_rays(poses_d[view:view + 1], intr, H, W, patch=4)       # same rays, 4x4-patch order
-            with torch.no_grad():
-                out = net.render(r["rays_o"], r["rays_d"], staged=False, bg_color=1, perturb=False, dt_gamma=0,
-                                 max_steps=1024, T_thresh=1e-4)
-                frame = torch.empty(H * W, 3, device=dev)
-                frame[r["inds"][0]] = out["image"][0]                       # back to row-major pixels
-            out["frame"] = frame.view(H, W, 3)
+            r = get_rays(poses_d[view:view + 1], intr, H, W, patch=4)
+        with torch.no_grad():
+            out = pipe.render(r["rays_o"], r["rays_d"], stream=st, bg_color=1, perturb=False, dt_gamma=0,
+                              max_steps=1024, T_thresh=1e-4)
+        with torch.cuda.stream(st):
+            frame = torch.empty(H * W, 3, device=dev)
+            frame[r["inds"][0]] = out["image"][0]
+        out["frame"] = frame.view(H, W, 3)
+        return out
+
+    def step(i):
+        if args.pipeline:
+            return step_pipelined(i)
+        view = (i * world + rank) % poses_d.shape[0]
+        r = get_rays(poses_d[view:view + 1], intr, H, W, patch=4)           # same rays, 4x4-patch order
+        with torch.no_grad():
+            out = net.render(r["rays_o"], r["rays_d"], staged=False, bg_color=1, perturb=False, dt_gamma=0,
+                             max_steps=1024, T_thresh=1e-4)
+            frame = torch.empty(H * W, 3, device=dev)
+            frame[r["inds"][0]] = out["image"][0]                           # back to row-major pixels
+        out["frame"] = frame.view(H, W, 3)
         return out
 
     def barrier():
@@ -344,6 +357,35 @@ def main():
                          "avg_launch_ms": round(avg_kernel_s * 1e3, 4), "launches": n_launch,
                          "algorithmic_bytes_per_sample": BYTES_PER_SAMPLE},
         }
+        if not args.pipeline and not args.no_pipeline_probe:
+            # the same frames with the march of view i+1 under the field kernel of view i (FramePipeline): reported
+            # beside the headline, which stays the one-stream loop the roofline figure is measured in
+            try:
+                from instance_nerf_amd.nerf.renderer import FramePipeline
+                pipe = FramePipeline(net, dev)
+                n_pipe = min(args.steps, 60)
+                for i in range(5):
+                    step_pipelined(i)
+                torch.cuda.synchronize()
+                ev_pairs.clear()
+                cs = []
+                t0 = time.perf_counter()
+                for i in range(n_pipe):
+                    o = step_pipelined(5 + i)
+                    cs.append(o["num_evaluated"] if "num_evaluated" in o else o["num_samples"])
+                torch.cuda.synchronize()
+                el = time.perf_counter() - t0
+                pipe.close()
+                ns = int(sum(int(c[0]) for c in cs))
+                kms = sum(a.elapsed_time(b) for a, b, _ in ev_pairs) / max(len(ev_pairs), 1)
+                line["pipelined"] = {"value": round(ns / el / 1e6, 3), "unit": "Msamples/s", "steps": n_pipe,
+                                     "ms_per_step": round(el / n_pipe * 1e3, 3), "field_kernel_ms": round(kms, 4),
+                                     "field_frac_of_hbm_peak": round(ns / n_pipe * BYTES_PER_SAMPLE / (kms / 1e3) / 1e9
+                                                                     / HBM_PEAK_GBS, 4),
+                                     "what": "FramePipeline: views alternate on two streams, field kernels serialised; "
+                                             "march of view i+1 and compositing of view i-1 run under field kernel i"}
+            except Exception as e:                            # noqa: BLE001
+                line["pipelined"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(room)
     if not args.no_train_probe:

@@ -62,6 +62,12 @@ int inr_abi_version(void);
 const char* inr_last_error(void);
 /* Fills props[0..3] = {CU count, wavefront size, LDS bytes per CU, gcn arch number}. */
 int inr_device_info(int32_t device, int64_t* props);
+/* No upstream counterpart.  For a caller that renders view after view with the march of view i+1 on one stream and
+ * the field kernel of view i on another (NeRFRenderer.run_cuda(shade_stream=...)): on != 0 makes the eval field
+ * launch (inr_nerf_forward_table) and the march launches (inr_march_rays_train_count, inr_march_rays_patch_write)
+ * request extra LDS per workgroup, which is how a launch tells the dispatcher to keep one field workgroup and a
+ * bounded number of march workgroups per CU.  Results do not change; process-wide; off by default.                */
+int inr_set_overlap_placement(int32_t on);
 
 /* ---- rays: generation (replaces nerf/utils.py::get_rays) and ray/AABB (a2) -------------
  * poses [B,4,4] camera-to-world row-major; pixel `inds[k]` (flat j*W+i; NULL = 0..n-1) -> rays_o/rays_d [B,n,3]:

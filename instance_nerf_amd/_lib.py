@@ -27,6 +27,7 @@ P = c_void_p
 _SIGS = {
     "inr_abi_version": (c_int32, []),
     "inr_last_error": (c_char_p, []),
+    "inr_set_overlap_placement": (c_int32, [c_int32]),
     "inr_device_info": (c_int32, [c_int32, POINTER(c_int64)]),
     "inr_get_rays": (c_int32, [P, c_int64, c_float, c_float, c_float, c_float, c_int32, P, c_int64, P, P, P]),
     "inr_near_far_from_aabb": (c_int32, [P, P, P, c_int64, c_float, P, P, P]),

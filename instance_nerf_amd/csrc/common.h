@@ -83,4 +83,9 @@ inline int cu_count() {
   return cached[dev];
 }
 
+// Overlap placement (inr_set_overlap_placement, raymarch.hip): minimum dynamic LDS of the eval field launch and extra
+// dynamic LDS of the march launches; both 0 unless a caller overlaps the two on separate streams.
+extern int g_field_lds_min;
+extern int g_march_lds_pad;
+
 }  // namespace inr

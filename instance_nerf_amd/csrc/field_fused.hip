@@ -1401,7 +1401,7 @@ int inr_nerf_forward_table(const float* x01, const int32_t* ray_ids, const float
   if (rc) return rc;
   const uint64_t emb_bytes64 = (uint64_t)desc->offsets[desc->num_levels] * 8ull;
   INR_REQUIRE(emb_bytes64 < (1ull << 31), "table larger than 2 GiB is not addressable by the 32-bit gather offsets");
-  const size_t lds = kNerfFloats * sizeof(float) + kLevelRecBytes;
+  const size_t lds = std::max(kNerfFloats * sizeof(float) + kLevelRecBytes, (size_t)g_field_lds_min);
   const int grid = grid_for(k_nerf_fwd<true, true>, lds, (M + 15) / 16);
   k_nerf_fwd<true, true><<<grid, kFieldThreads, lds, as_stream(s)>>>(
       x01, nullptr, M, nullptr, bound, reinterpret_cast<const float2*>(embeddings), (uint32_t)emb_bytes64, G,

@@ -9,6 +9,8 @@
 namespace inr {
 
 static thread_local char g_err[512] = "";
+int g_field_lds_min = 0;
+int g_march_lds_pad = 0;
 void set_error(const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
@@ -1221,6 +1223,16 @@ extern "C" {
 int inr_abi_version(void) { return INR_ABI_VERSION; }
 const char* inr_last_error(void) { return inr::g_err; }
 
+int inr_set_overlap_placement(int32_t on) {
+  // LDS is the one per-CU resource a launch can ask for without changing the kernel: 160 KB per CU.  The field
+  // workgroup asks for > 80 KB (so two never share a CU, also not while the next view's march holds registers on some
+  // CUs and the dispatcher looks for room elsewhere), a march workgroup for 48 KB on top of its own, which bounds the
+  // marchers that can sit beside a field workgroup.  Measured in profiles/r02_NOTES.txt section 18.
+  inr::g_field_lds_min = on ? 84 * 1024 : 0;
+  inr::g_march_lds_pad = on ? 48 * 1024 : 0;
+  return INR_OK;
+}
+
 int inr_device_info(int32_t device, int64_t* props) {
   INR_REQUIRE(props, "props is null");
   hipDeviceProp_t p;
@@ -1348,6 +1360,9 @@ int64_t inr_march_workspace_bytes(int64_t N, int32_t sample_cap) {
   return ws_ints(N) * (int64_t)sizeof(int32_t) + (w ? N * (int64_t)(w + 1) * (int64_t)sizeof(uint32_t) : 0);
 }
 
+// extra dynamic LDS per march workgroup while overlap placement is on (inr_set_overlap_placement)
+static size_t march_lds_pad() { return (size_t)inr::g_march_lds_pad; }
+
 int inr_march_rays_train_count(const float* rays_o, const float* rays_d, const uint8_t* bitfield, float bound,
                                float dt_gamma, int32_t max_steps, int64_t N, int32_t cascade, int32_t H,
                                const float* nears, const float* fars, const float* noises, int32_t* rays,
@@ -1368,7 +1383,7 @@ int inr_march_rays_train_count(const float* rays_o, const float* rays_d, const u
     k_scan_counts<<<1, 1024, 0, st>>>(counts, N, rays, counter);
     return check_launch("march_rays_train_count");
   }
-  k_march_count<<<nb, kRayBlock, 0, st>>>(P, rays_o, rays_d, N, max_steps, nears, fars, noises, counts, block_sums,
+  k_march_count<<<nb, kRayBlock, march_lds_pad(), st>>>(P, rays_o, rays_d, N, max_steps, nears, fars, noises, counts, block_sums,
                                           mask, cap_words_of(sample_cap));
   k_scan_block_sums<<<1, 1024, 0, st>>>(block_sums, (int)nb, N, counter);
   k_finalize_offsets<<<nb, kRayBlock, 0, st>>>(counts, block_sums, N, rays);
@@ -1409,7 +1424,7 @@ int inr_march_rays_patch_write(const float* rays_o, const float* rays_d, const u
   const MarchParams P = make_params(bitfield, bound, dt_gamma, max_steps, cascade, H);
   INR_REQUIRE(sample_cap == 0 || workspace, "sample_cap > 0 needs the workspace of the count pass");
   const uint32_t* mask = sample_cap > 0 ? reinterpret_cast<const uint32_t*>(reinterpret_cast<const int32_t*>(workspace) + ws_ints(N)) : nullptr;
-  k_march_write_patch<<<blocks_for(N, kRayBlock), kRayBlock, 0, as_stream(s)>>>(P, rays_o, rays_d, N, M, nears, fars,
+  k_march_write_patch<<<blocks_for(N, kRayBlock), kRayBlock, march_lds_pad(), as_stream(s)>>>(P, rays_o, rays_d, N, M, nears, fars,
                                                                                 noises, rays, xyzs, dirs, deltas, mask,
                                                                                 cap_words_of(sample_cap), ray_ids, normalise);
   return check_launch("march_rays_patch_write");

@@ -173,7 +173,7 @@ class NeRFRenderer(nn.Module):
         return results
 
     def run_cuda(self, rays_o, rays_d, dt_gamma=0, bg_color=None, perturb=False, force_all_rays=False,
-                 max_steps=1024, T_thresh=1e-4, infer_mode="auto", noises=None, **kwargs):
+                 max_steps=1024, T_thresh=1e-4, infer_mode="auto", noises=None, field_gate=None, **kwargs):
         """rays_o, rays_d [B,N,3] -> dict(image [B,N,3], depth [B,N], weights_sum [B,N] (, instance [B,N,K])).
 
         infer_mode (eval only; all modes render the same image):
@@ -184,6 +184,10 @@ class NeRFRenderer(nn.Module):
           "auto" (default)   picks between the two from the fraction of samples the early-terminating kernel skips /
                              would skip, as counted by the previous inference calls (> terminate_above = 0.4)
           "fused_raymajor" / "wavefront"   reference paths kept for parity tests (ray-major layout / upstream's loop)
+
+        field_gate (eval, one-pass modes): an object with ``acquire()`` / ``release()`` called on the current stream
+        right before and after the field evaluation.  FramePipeline uses it to keep the field kernels of views that
+        are rendered on different streams one after the other while everything else overlaps.
         """
         prefix = rays_o.shape[:-1]
         rays_o = rays_o.contiguous().view(-1, 3).float()
@@ -208,8 +212,12 @@ class NeRFRenderer(nn.Module):
             xyzs, dirs, deltas, rays = raymarching.march_rays_patch(
                 rays_o, rays_d, self.bound, self.density_bitfield, self.cascade, self.grid_size, nears, fars,
                 dt_gamma, max_steps, noises=noises if perturb else None, counter=counter)
+            if field_gate is not None:
+                field_gate.acquire()
             weights_sum, depth, image, wbuf, evaluated = self.nerf_render(xyzs, deltas, rays, rays_d, T_thresh,
                                                                           want_weights=with_instance)
+            if field_gate is not None:
+                field_gate.release()
             if with_instance:
                 results["instance"] = self.instance_render(xyzs, rays, wbuf).view(*prefix, -1)
             results["num_samples"] = counter
@@ -224,7 +232,11 @@ class NeRFRenderer(nn.Module):
             xyzs, dirs, deltas, rays = raymarching.march_rays_patch(
                 rays_o, rays_d, self.bound, self.density_bitfield, self.cascade, self.grid_size, nears, fars,
                 dt_gamma, max_steps, noises=noises if perturb else None, counter=counter, table=table)
+            if field_gate is not None:
+                field_gate.acquire()
             sigmas, rgbs = self.forward_table(xyzs, dirs, rays_d) if table else self(xyzs, dirs)
+            if field_gate is not None:
+                field_gate.release()
             if self.density_scale != 1:
                 sigmas = self.density_scale * sigmas
             skippable = torch.zeros(1, dtype=torch.int64, device=device)
@@ -488,3 +500,59 @@ class NeRFRenderer(nn.Module):
             keys = [k for k in keys if all(len(chunks.get((k, b), ())) == n_chunks for b in range(B))]
             return {k: torch.cat([torch.cat(chunks[(k, b)], 1) for b in range(B)], 0) for k in keys}
         return _run(rays_o, rays_d, **kwargs)
+
+
+class FramePipeline:
+    """View-after-view rendering on two alternating streams: while the field kernel of view i runs, the compositing of
+    view i-1 and the ray/box test + march of view i+1 (VALU work with a host read-back of the sample count in the
+    middle) run beside it.  The field kernels themselves stay one after the other (``field_gate``): two of them at once
+    only halve each other's cache.  In-stream order bounds the look-ahead to one view.
+
+    ``render`` returns when its view is queued; the results live on the stream returned with them
+    (``out["stream"]``): use them there, or ``synchronize()`` first.  Overlap placement (include/inr.h,
+    inr_set_overlap_placement) is on while the pipeline is open.  Upstream has no counterpart (its loop renders one view
+    at a time on the default stream); images are bit identical to ``net.render``."""
+
+    def __init__(self, net, device=None):
+        self.net = net
+        self.streams = [torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)]
+        self._turn = 0
+        self._field_done = None
+        raymarching.set_overlap_placement(True)
+
+    # field_gate protocol of NeRFRenderer.run_cuda
+    def acquire(self):
+        if self._field_done is not None:
+            torch.cuda.current_stream().wait_event(self._field_done)
+
+    def release(self):
+        self._field_done = torch.cuda.Event()
+        self._field_done.record(torch.cuda.current_stream())
+
+    def next_stream(self):
+        st = self.streams[self._turn]
+        self._turn ^= 1
+        return st
+
+    def render(self, rays_o, rays_d, stream=None, **kwargs):
+        """``stream``: the pipeline stream the rays were produced on (from ``next_stream()``), or None when they come
+        from the current stream."""
+        if kwargs.pop("staged", False):
+            raise RuntimeError("FramePipeline renders a whole view per call (staged=False)")
+        if stream is None:
+            stream = self.next_stream()
+            stream.wait_stream(torch.cuda.current_stream())
+            rays_o.record_stream(stream)
+            rays_d.record_stream(stream)
+        with torch.cuda.stream(stream):
+            out = self.net.render(rays_o, rays_d, staged=False, field_gate=self, **kwargs)
+        out["stream"] = stream
+        return out
+
+    def synchronize(self):
+        for st in self.streams:
+            st.synchronize()
+
+    def close(self):
+        self.synchronize()
+        raymarching.set_overlap_placement(False)

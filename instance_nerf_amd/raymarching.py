@@ -36,6 +36,12 @@ def _f(t):
     return t.contiguous().float() if (t.dtype != F32 or not t.is_contiguous()) else t
 
 
+def set_overlap_placement(on):
+    """Placement of the eval field kernel and the march kernels when they run on two streams at once (FramePipeline):
+    see inr_set_overlap_placement in include/inr.h.  Process-wide; results do not change."""
+    check(_lib.load().inr_set_overlap_placement(1 if on else 0), "set_overlap_placement")
+
+
 def near_far_from_aabb(rays_o, rays_d, aabb, min_near=0.2):
     """rays_o, rays_d [N,3]; aabb [6] -> nears, fars [N]."""
     lib = _lib.load()

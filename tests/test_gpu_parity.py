@@ -1263,6 +1263,32 @@ def test_fused_terminate_equals_two_kernel_path(params_k16, room, room_bitfield,
         assert ev > 0.9 * total
 
 
+@pytest.mark.parametrize("mode,K", [("fused", 0), ("fused", 16), ("fused_terminate", 16)])
+def test_frame_pipeline_is_bit_identical(params_k16, room, room_bitfield, mode, K):
+    """FramePipeline (views alternate on two streams, field kernels serialised, overlap placement on): same bits as
+    net.render for view after view, buffers of finished views being reused while the next view is in flight."""
+    from instance_nerf_amd.nerf.renderer import FramePipeline
+    from instance_nerf_amd.nerf.utils import get_rays
+    net = _network(params_k16, K=K).eval()
+    net.density_bitfield.copy_(_t(room_bitfield))
+    poses, intr, H, W = room.cameras(n=3, H=96, W=96, focal=48.0)
+    rays = [get_rays(_t(poses[v:v + 1]), intr, 96, 96, patch=4) for v in range(3)]
+    keys = ("image", "depth", "weights_sum") + (("instance",) if K else ())
+    with torch.no_grad():
+        ref = [net.render(r["rays_o"], r["rays_d"], bg_color=1, infer_mode=mode) for r in rays]
+    torch.cuda.synchronize()
+    pipe = FramePipeline(net)
+    with torch.no_grad():
+        outs = [pipe.render(rays[k % 3]["rays_o"], rays[k % 3]["rays_d"], bg_color=1, infer_mode=mode) for k in range(9)]
+    assert [o["stream"] for o in outs[:4]] == [pipe.streams[0], pipe.streams[1]] * 2
+    pipe.close()
+    for k, o in enumerate(outs):
+        for key in keys:
+            assert torch.equal(o[key], ref[k % 3][key]), (k, key)
+    with pytest.raises(RuntimeError):
+        pipe.render(rays[0]["rays_o"], rays[0]["rays_d"], staged=True)
+
+
 def test_auto_mode_follows_the_skippable_fraction(params_k16, room, room_bitfield):
     """infer_mode="auto": the fraction of marched samples that lie behind the point where their whole 16-ray group
     has terminated - counted by the compositing kernel of the two-kernel path, reported by the terminating kernel
