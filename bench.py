@@ -204,7 +204,9 @@ def main():
     ap.add_argument("--res", type=int, default=800)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train-probe", action="store_true")
-    ap.add_argument("--no-pipeline-probe", action="store_true", help="skip the secondary two-stream measurement")
+    ap.add_argument("--pipeline-probe", action="store_true",
+                    help="also measure the same frames through FramePipeline (two streams) and report them as \"pipelined\"; "
+                         "off by default so that a kernel trace of the default command holds one-stream launches only")
     ap.add_argument("--pipeline", type=int, default=0,
                     help="1: headline loop through FramePipeline (views alternate on two streams)")
     args = ap.parse_args()
@@ -357,7 +359,7 @@ def main():
                          "avg_launch_ms": round(avg_kernel_s * 1e3, 4), "launches": n_launch,
                          "algorithmic_bytes_per_sample": BYTES_PER_SAMPLE},
         }
-        if not args.pipeline and not args.no_pipeline_probe:
+        if args.pipeline_probe and not args.pipeline:
             # the same frames with the march of view i+1 under the field kernel of view i (FramePipeline): reported
             # beside the headline, which stays the one-stream loop the roofline figure is measured in
             try:

@@ -321,10 +321,11 @@ int inr_nerf_render(const float* xyzs, const float* deltas, const int32_t* rays,
 /* Instance logits rendered in place (inference, patch-interleaved layout): extra_out[ray][ch] =
  * sum_k weights[slot(ray,k)] * logits(xyzs[slot(ray,k)])[ch]; the [M,K] logits never exist in memory.
  * xyzs/weights [M] in the patch-interleaved layout (inr_march_rays_patch_write / the weights output of
- * inr_composite_rays_patch_forward), rays [N,3] from the count pass, extra_out [N,K].                   */
+ * inr_composite_rays_patch_forward), rays [N,3] from the count pass, extra_out [N,K].  x_is_01 != 0: xyzs holds
+ * the normalised coordinates (x + bound) / (2 bound) the patch writer emits with normalise = 1.          */
 int inr_instance_render(const float* xyzs, const int32_t* rays, const float* weights, int64_t N, int64_t M,
                         float bound, const float* embeddings, const inr_grid_desc* desc /*host*/,
-                        const float* packed /*device*/, int32_t K, float* extra_out, inr_stream_t s);
+                        const float* packed /*device*/, int32_t K, float* extra_out, int32_t x_is_01, inr_stream_t s);
 
 /* ---- weight gradient of the tiny bias-free MLP layers (replaces the BLAS call autograd makes for
  * nn.Linear in NeRFNetwork, a9/a13):  grad_w[o][i] += sum_m grad_y[m][o] * x[m][i],  n_in, n_out <= 64.

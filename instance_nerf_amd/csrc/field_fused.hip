@@ -521,6 +521,47 @@ __device__ __forceinline__ TileSched make_sched(int64_t n_tiles, int waves_per_b
   return s;
 }
 
+// Schedule over 16-ray GROUPS (kernels in which a wave or a workgroup owns a group for all its steps).  An eighth of
+// the groups is not an eighth of the work - the top rows of a frame see the ceiling, the middle rows the whole room -
+// so an XCD's contiguous range holds an eighth of the SAMPLES: range ends by binary search on the groups' slot bases
+// (rays[.][1] is the prefix sum of the counts).  units_per_block: waves (wave-owned groups) or 1 (workgroup-owned).
+#ifndef INR_RENDER_SCHED
+#define INR_RENDER_SCHED 2      // 0: eighth of the groups per XCD, 1: plain striding, 2: eighth of the samples per XCD
+#endif
+__device__ __forceinline__ TileSched make_group_sched(const int32_t* __restrict__ rays, int64_t N, int units_per_block,
+                                                      int unit) {
+  const int64_t n_groups = (N + 15) >> 4;
+  const int nb = gridDim.x, b = blockIdx.x;
+  TileSched s;
+  if (nb % 8 == 0 && INR_RENDER_SCHED != 1) {
+    const int xcd = b & 7, local = b >> 3, per = nb >> 3;
+    if (INR_RENDER_SCHED == 0) {
+      s.lo = n_groups * xcd / 8;
+      s.hi = n_groups * (xcd + 1) / 8;
+    } else {
+      const int64_t total = (int64_t)rays[(N - 1) * 3 + 1] + rays[(N - 1) * 3 + 2];
+      auto first_group_at = [&](int64_t target) {          // first group whose slot base is >= target
+        int64_t lo = 0, hi = n_groups;
+        while (lo < hi) {
+          const int64_t mid = (lo + hi) >> 1;
+          if ((int64_t)rays[mid * 16 * 3 + 1] < target) lo = mid + 1; else hi = mid;
+        }
+        return lo;
+      };
+      s.lo = xcd == 0 ? 0 : first_group_at(total * xcd / 8);
+      s.hi = xcd == 7 ? n_groups : first_group_at(total * (xcd + 1) / 8);
+    }
+    s.first = s.lo + (int64_t)local * units_per_block + unit;
+    s.stride = (int64_t)per * units_per_block;
+  } else {
+    s.lo = 0;
+    s.hi = n_groups;
+    s.first = (int64_t)b * units_per_block + unit;
+    s.stride = (int64_t)nb * units_per_block;
+  }
+  return s;
+}
+
 #ifndef INR_FIELD_THREADS
 #define INR_FIELD_THREADS 512
 #endif
@@ -1037,83 +1078,116 @@ __global__ void __launch_bounds__(256) k_pack_weights(PackJobs jobs, float* __re
 
 
 // ---- instance logits rendered in place (inference) ---------------------------------------------------------
-// out[ray][ch] = sum_k w(ray,k) * logits(x(ray,k))[ch] without ever writing the [M, K] logits: one wave owns a
-// 16-ray group of the patch-interleaved layout for ALL its steps, MFMA column j is FIXED to ray j (the slot of
-// its k-th sample is re-derived per step from one ballot: base + sum_i min(c_i,k) + #{i<j: c_i>k}), and
-// w * logits accumulates in the MFMA output registers (16 per lane).  Steps where every live ray of the group
-// has w == 0 (behind the termination point) skip the gather and the MLP altogether.
+// out[ray][ch] = sum_k w(ray,k) * logits(x(ray,k))[ch] without ever writing the [M, K] logits.  A WORKGROUP owns a
+// 16-ray group of the patch-interleaved layout; its eight waves take the group's steps round robin (wave w: steps w,
+// w + 8, ...), so that at any time the CU works on eight consecutive depths of one 4x4 patch - the access pattern the
+// plain field kernel owes its L1 hit rate to (round 1 / early round 2 gave each wave a group of its own: eight
+// unrelated patches per CU, 7.8 ms for 37 M samples).  MFMA column j is FIXED to ray j (the slot of its k-th sample is
+// base + sum_i min(c_i, k) + #{i < j: c_i > k}), w * logits accumulates in the MFMA output registers (16 per lane), and
+// the eight partial sums meet in LDS when the group is done: one barrier per group, two LDS buffers by group parity
+// (waves 0..3 add up and store group g while waves 4..7 already run group g + 1).  Steps where every live ray of the
+// group has w == 0 (behind the termination point) skip the gather and the MLP.  x_is_01: the march writer already
+// normalised the coordinates (table feed).
 template <int K_MT>
 __global__ void __launch_bounds__(kFieldThreads, INR_FIELD_MIN_WAVES) k_instance_render(
     const float* __restrict__ x, const int32_t* __restrict__ rays, const float* __restrict__ wbuf, int64_t N, int64_t M,
     float bound, const float2* __restrict__ emb, uint32_t emb_bytes, GridDesc G, const float4* __restrict__ packed,
-    float* __restrict__ extra_out) {
+    float* __restrict__ extra_out, int x_is_01) {
   extern __shared__ __attribute__((aligned(16))) float4 wl[];
   constexpr int K = K_MT * 16;
   constexpr int kStage = (kIns2 + K * 64) / 4;
+  constexpr int kWaves = kFieldThreads / 64;
   for (int i = threadIdx.x; i < kStage; i += kFieldThreads) wl[i] = packed[i];
   LevelRec* recs = reinterpret_cast<LevelRec*>(wl + kStage);
+  float4* red = wl + kStage + kLevelRecBytes / 16;        // [2][kWaves][K_MT][64] float4
   stage_level_recs(G, recs);
   __syncthreads();
 
-  constexpr int kWaves = kFieldThreads / 64;
-  const int lane = threadIdx.x & 63, q = lane >> 4, j = lane & 15;
+  const int lane = threadIdx.x & 63, q = lane >> 4, j = lane & 15, wave = threadIdx.x >> 6;
   const float rb = 2.0f * bound;
-  const int64_t n_groups = (N + 15) >> 4;
-  const TileSched sched = make_sched(n_groups, kWaves);
+  const float x_add = x_is_01 ? 0.0f : bound, x_div = x_is_01 ? 1.0f : rb;
+  // a WORKGROUP per group; the XCD's workgroups sweep its range side by side (neighbouring patches share the L2)
+  const TileSched sched = make_group_sched(rays, N, 1, 0);
+  const int64_t g_first = sched.first, g_hi = sched.hi, g_stride = sched.stride;
   const bool all_hashed[4] = {slot_all_hashed(G, 0), slot_all_hashed(G, 1), slot_all_hashed(G, 2), slot_all_hashed(G, 3)};
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)emb, 0, (int)emb_bytes, 0x00020000);
 
-  for (int64_t it = 0, grp = sched.tile(0); grp < sched.hi; grp = sched.tile(++it)) {
+  int parity = 0;
+  for (int64_t grp = g_first; grp < g_hi; grp += g_stride, parity ^= 1) {
     const int64_t ray = grp * 16 + j;
     const int cnt = ray < N ? rays[ray * 3 + 2] : 0;
-    int64_t S = rays[grp * 16 * 3 + 1];                    // slot base of the group (offset of its first ray)
-    int gtot = cnt;                                        // group total, to honour a dropped group
+    const int64_t S0 = rays[grp * 16 * 3 + 1];             // slot base of the group (offset of its first ray)
+    int gtot = cnt, kmax = cnt;                            // group total (to honour a dropped group), longest ray
 #pragma unroll
-    for (int d = 1; d < 16; d <<= 1) gtot += __shfl_xor(gtot, d, 64);
-    const bool fits = S + gtot <= M;
+    for (int d = 1; d < 16; d <<= 1) {
+      gtot += __shfl_xor(gtot, d, 64);
+      kmax = max(kmax, __shfl_xor(kmax, d, 64));
+    }
+    if (S0 + gtot > M) kmax = 0;
     f32x4 acc[K_MT];
 #pragma unroll
     for (int mt = 0; mt < K_MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int k = 0; fits; ++k) {
-      const unsigned field = (unsigned)(__ballot(k < cnt) & 0xFFFFull);      // lanes 0..15 = q 0, column j
-      if (field == 0) break;
+
+    // the sample of (ray j, step k): requested one step of this wave ahead of its use
+    auto request = [&](int k, float& w, float& x0, float& x1, float& x2) {
+      int below = min(cnt, k);                             // samples of ray i before step k, summed over the group
+#pragma unroll
+      for (int d = 1; d < 16; d <<= 1) below += __shfl_xor(below, d, 64);
+      const unsigned field = (unsigned)(__ballot(k < cnt) & 0xFFFFull);
       const bool active = k < cnt;
-      const int64_t slot = S + __popc(field & ((1u << j) - 1u));
-      S += __popc(field);
-      const float w = active ? wbuf[slot] : 0.0f;
-      if (__ballot(w != 0.0f) == 0ull) continue;           // the whole group is past its termination points
-      const int64_t m = active ? slot : 0;
-      const float x0 = (x[m * 3 + 0] + bound) / rb, x1 = (x[m * 3 + 1] + bound) / rb, x2 = (x[m * 3 + 2] + bound) / rb;
-      f32x4 enc[2];
-      {
-        Gathered g;
-        uint32_t rec_off = (uint32_t)q * 4u * (uint32_t)sizeof(LevelRec);
-        asm volatile("" : "+v"(rec_off));
-        issue_gathers(reinterpret_cast<const LevelRec*>(reinterpret_cast<const char*>(recs) + rec_off), all_hashed, rsrc,
-                      x0, x1, x2, g);
-        __builtin_amdgcn_sched_barrier(0);
-        blend(g, enc[0], enc[1]);
+      const int64_t slot = active ? S0 + below + __popc(field & ((1u << j) - 1u)) : 0;
+      w = active ? wbuf[slot] : 0.0f;
+      x0 = x[slot * 3 + 0]; x1 = x[slot * 3 + 1]; x2 = x[slot * 3 + 2];
+    };
+    float w = 0.f, x0 = 0.f, x1 = 0.f, x2 = 0.f;
+    if (wave < kmax) request(wave, w, x0, x1, x2);
+    for (int k = wave; k < kmax; k += kWaves) {
+      float wn = 0.f, xn0 = 0.f, xn1 = 0.f, xn2 = 0.f;
+      if (k + kWaves < kmax) request(k + kWaves, wn, xn0, xn1, xn2);
+      if (__ballot(w != 0.0f) != 0ull) {                   // else: the whole group is past its termination points
+        const float p0 = (x0 + x_add) / x_div, p1 = (x1 + x_add) / x_div, p2 = (x2 + x_add) / x_div;
+        f32x4 enc[2];
+        {
+          Gathered g;
+          uint32_t rec_off = (uint32_t)q * 4u * (uint32_t)sizeof(LevelRec);
+          asm volatile("" : "+v"(rec_off));
+          issue_gathers(reinterpret_cast<const LevelRec*>(reinterpret_cast<const char*>(recs) + rec_off), all_hashed, rsrc,
+                        p0, p1, p2, g);
+          __builtin_amdgcn_sched_barrier(0);
+          blend(g, enc[0], enc[1]);
+        }
+        f32x4 h1[4], h2[4], o[K_MT];
+        mlp_layer<4, 2>(wl + kIns0 / 4, lane, enc, h1);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) h1[t] = relu4(h1[t]);
+        mlp_layer<4, 4>(wl + kIns1 / 4, lane, h1, h2);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) h2[t] = relu4(h2[t]);
+        mlp_layer<K_MT, 4>(wl + kIns2 / 4, lane, h2, o);
+#pragma unroll
+        for (int mt = 0; mt < K_MT; ++mt) {
+          acc[mt][0] = fmaf(w, o[mt][0], acc[mt][0]); acc[mt][1] = fmaf(w, o[mt][1], acc[mt][1]);
+          acc[mt][2] = fmaf(w, o[mt][2], acc[mt][2]); acc[mt][3] = fmaf(w, o[mt][3], acc[mt][3]);
+        }
       }
-      f32x4 h1[4], h2[4], o[K_MT];
-      mlp_layer<4, 2>(wl + kIns0 / 4, lane, enc, h1);
-#pragma unroll
-      for (int t = 0; t < 4; ++t) h1[t] = relu4(h1[t]);
-      mlp_layer<4, 4>(wl + kIns1 / 4, lane, h1, h2);
-#pragma unroll
-      for (int t = 0; t < 4; ++t) h2[t] = relu4(h2[t]);
-      mlp_layer<K_MT, 4>(wl + kIns2 / 4, lane, h2, o);
-#pragma unroll
-      for (int mt = 0; mt < K_MT; ++mt) {
-        acc[mt][0] = fmaf(w, o[mt][0], acc[mt][0]); acc[mt][1] = fmaf(w, o[mt][1], acc[mt][1]);
-        acc[mt][2] = fmaf(w, o[mt][2], acc[mt][2]); acc[mt][3] = fmaf(w, o[mt][3], acc[mt][3]);
-      }
+      w = wn; x0 = xn0; x1 = xn1; x2 = xn2;
     }
-    if (ray < N) {
-      const int32_t rid = rays[ray * 3];
+    float4* mine = red + ((size_t)(parity * kWaves + wave) * K_MT) * 64;
 #pragma unroll
-      for (int mt = 0; mt < K_MT; ++mt)
-        *reinterpret_cast<float4*>(extra_out + (int64_t)rid * K + 16 * mt + 4 * q) =
-            make_float4(acc[mt][0], acc[mt][1], acc[mt][2], acc[mt][3]);
+    for (int mt = 0; mt < K_MT; ++mt) mine[mt * 64 + lane] = make_float4(acc[mt][0], acc[mt][1], acc[mt][2], acc[mt][3]);
+#ifndef INR_EXPERIMENT_NO_GROUP_BARRIER
+    __syncthreads();
+#endif
+    if (threadIdx.x < K_MT * 64 && ray < N) {              // thread t: tile row block t >> 6, lane position t & 63
+      const float4* part = red + (size_t)parity * kWaves * K_MT * 64 + threadIdx.x;
+      float4 sum = part[0];
+#pragma unroll
+      for (int wv = 1; wv < kWaves; ++wv) {
+        const float4 v = part[(size_t)wv * K_MT * 64];
+        sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+      }
+      const int32_t rid = rays[ray * 3];
+      *reinterpret_cast<float4*>(extra_out + (int64_t)rid * K + 16 * (threadIdx.x >> 6) + 4 * q) = sum;
     }
   }
 }
@@ -1143,8 +1217,7 @@ __global__ void __launch_bounds__(kFieldThreads, INR_FIELD_MIN_WAVES) k_nerf_ren
   constexpr int kWaves = kFieldThreads / 64;
   const int lane = threadIdx.x & 63, q = lane >> 4, j = lane & 15;
   const float rb = 2.0f * bound;
-  const int64_t n_groups = (N + 15) >> 4;
-  const TileSched sched = make_sched(n_groups, kWaves);
+  const TileSched sched = make_group_sched(rays, N, kWaves, threadIdx.x >> 6);
   const bool all_hashed[4] = {slot_all_hashed(G, 0), slot_all_hashed(G, 1), slot_all_hashed(G, 2), slot_all_hashed(G, 3)};
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)emb, 0, (int)emb_bytes, 0x00020000);
   unsigned long long n_eval = 0;
@@ -1600,7 +1673,7 @@ int inr_nerf_backward(const float* grad_sigma, const float* grad_rgb, const floa
 
 int inr_instance_render(const float* xyzs, const int32_t* rays, const float* weights, int64_t N, int64_t M, float bound,
                         const float* embeddings, const inr_grid_desc* desc, const float* packed, int32_t K,
-                        float* extra_out, inr_stream_t s) {
+                        float* extra_out, int32_t x_is_01, inr_stream_t s) {
   INR_REQUIRE(N >= 0 && M >= 0 && desc, "bad argument");
   if (N == 0) return INR_OK;
   INR_REQUIRE(rays && embeddings && packed && extra_out, "null pointer");
@@ -1616,14 +1689,16 @@ int inr_instance_render(const float* xyzs, const int32_t* rays, const float* wei
   const uint64_t emb_bytes64 = (uint64_t)desc->offsets[desc->num_levels] * 8ull;
   INR_REQUIRE(emb_bytes64 < (1ull << 31), "table larger than 2 GiB is not addressable by the 32-bit gather offsets");
   const uint32_t eb = (uint32_t)emb_bytes64;
-  const size_t lds = (size_t)(kIns2 + K * 64) * sizeof(float) + kLevelRecBytes;
+  // weights + level records + two buffers of eight partial [16 rays x K] sums
+  const size_t lds = (size_t)(kIns2 + K * 64) * sizeof(float) + kLevelRecBytes + 2 * (kFieldThreads / 64) * (size_t)K * 64;
   const int64_t n_groups = (N + 15) / 16;
+  const int64_t as_tiles = n_groups * (kFieldThreads / 64);        // one workgroup per group
   hipStream_t st = as_stream(s);
   switch (K / 16) {
-    case 1: k_instance_render<1><<<grid_for(k_instance_render<1>, lds, n_groups), kFieldThreads, lds, st>>>(xyzs, rays, weights, N, M, bound, e, eb, G, p, extra_out); break;
-    case 2: k_instance_render<2><<<grid_for(k_instance_render<2>, lds, n_groups), kFieldThreads, lds, st>>>(xyzs, rays, weights, N, M, bound, e, eb, G, p, extra_out); break;
-    case 3: k_instance_render<3><<<grid_for(k_instance_render<3>, lds, n_groups), kFieldThreads, lds, st>>>(xyzs, rays, weights, N, M, bound, e, eb, G, p, extra_out); break;
-    default: k_instance_render<4><<<grid_for(k_instance_render<4>, lds, n_groups), kFieldThreads, lds, st>>>(xyzs, rays, weights, N, M, bound, e, eb, G, p, extra_out); break;
+    case 1: k_instance_render<1><<<grid_for(k_instance_render<1>, lds, as_tiles), kFieldThreads, lds, st>>>(xyzs, rays, weights, N, M, bound, e, eb, G, p, extra_out, x_is_01); break;
+    case 2: k_instance_render<2><<<grid_for(k_instance_render<2>, lds, as_tiles), kFieldThreads, lds, st>>>(xyzs, rays, weights, N, M, bound, e, eb, G, p, extra_out, x_is_01); break;
+    case 3: k_instance_render<3><<<grid_for(k_instance_render<3>, lds, as_tiles), kFieldThreads, lds, st>>>(xyzs, rays, weights, N, M, bound, e, eb, G, p, extra_out, x_is_01); break;
+    default: k_instance_render<4><<<grid_for(k_instance_render<4>, lds, as_tiles), kFieldThreads, lds, st>>>(xyzs, rays, weights, N, M, bound, e, eb, G, p, extra_out, x_is_01); break;
   }
   return check_launch("instance_render");
 }

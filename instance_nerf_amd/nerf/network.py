@@ -442,9 +442,10 @@ class NeRFNetwork(NeRFRenderer):
         return ws, depth, image, wbuf, evaluated
 
     @torch.no_grad()
-    def instance_render(self, xyzs, rays, weights):
+    def instance_render(self, xyzs, rays, weights, normalised=False):
         """Rendered instance logits [N, K] from the patch-interleaved samples and their compositing weights, with
-        the per-sample logits kept on chip (inference only).  None when the fused kernel does not apply."""
+        the per-sample logits kept on chip (inference only).  None when the fused kernel does not apply.
+        normalised: ``xyzs`` are the (x + bound) / (2 bound) coordinates of the table feed."""
         if not (self.num_instances and self._fusable_inst):
             return None
         lib = _lib.load()
@@ -454,7 +455,8 @@ class NeRFNetwork(NeRFRenderer):
                                       ptr(weights, torch.float32, "weights", allow_none=M == 0), N, M, float(self.bound),
                                       ptr(self.instance_encoder.embeddings.data, torch.float32),
                                       self.instance_encoder.desc, ptr(self._packed_weights("instance")),
-                                      self.num_instances, ptr(out), stream_ptr()), "instance_render")
+                                      self.num_instances, ptr(out), 1 if normalised else 0, stream_ptr()),
+              "instance_render")
         return out
 
     def get_params(self, lr):

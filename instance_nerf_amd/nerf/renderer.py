@@ -226,9 +226,9 @@ class NeRFRenderer(nn.Module):
         elif not self.training and infer_mode in ("fused", "fused_terminate"):
             # full batch in four launches, patch-interleaved sample layout (csrc/raymarch.hip)
             counter = torch.zeros(2, dtype=torch.int32, device=device)
-            # without an instance head the samples are consumed by the NeRF field only: the writer then emits
-            # normalised coordinates + ray ids and the field reads a per-ray direction table (forward_table)
-            table = (not with_instance) and getattr(self, "_fusable", False) and hasattr(self, "forward_table")
+            # when the samples are consumed by the fused kernels only (NeRF field, fused instance render) the writer
+            # emits normalised coordinates + ray ids and the field reads a per-ray direction table (forward_table)
+            table = (fused_inst or not with_instance) and getattr(self, "_fusable", False) and hasattr(self, "forward_table")
             xyzs, dirs, deltas, rays = raymarching.march_rays_patch(
                 rays_o, rays_d, self.bound, self.density_bitfield, self.cascade, self.grid_size, nears, fars,
                 dt_gamma, max_steps, noises=noises if perturb else None, counter=counter, table=table)
@@ -244,7 +244,7 @@ class NeRFRenderer(nn.Module):
                 # weights first, then the instance field accumulates w * logits on chip (no [M, K] round trip)
                 weights_sum, depth, image, wbuf = raymarching.composite_rays_patch(sigmas, rgbs, deltas, rays, T_thresh,
                                                                                   return_weights=True, skippable=skippable)
-                results["instance"] = self.instance_render(xyzs, rays, wbuf).view(*prefix, -1)
+                results["instance"] = self.instance_render(xyzs, rays, wbuf, normalised=table).view(*prefix, -1)
             else:
                 extra = self.instance(xyzs) if with_instance else None
                 out = raymarching.composite_rays_patch(sigmas, rgbs, deltas, rays, T_thresh, extra=extra,
@@ -344,14 +344,15 @@ class NeRFRenderer(nn.Module):
         results["weights_sum"] = weights_sum.view(*prefix)
         return results
 
-    # infer_mode="auto": which kernel path pays?  The early-terminating kernel costs ~1.4x per EVALUATED sample (a
-    # wave owns a 16-ray group for all its steps) and skips every step at which the whole group is below T_thresh, so
-    # it wins when it skips more than ~30 % of the marched samples; 40 % is used (hysteresis against flapping).  The
-    # two-kernel path counts that fraction in its compositing kernel, the terminating kernel reports what it really
-    # evaluated.  (Round 1 switched on mean opacity > 0.5: a half-trained scene - opacity 0.88, only 9 % skippable -
-    # then rendered in 20.5 ms instead of 14.4, profiles/r02_NOTES.txt section 11.)  The value travels to the host
-    # through a pinned buffer + event and is only read once its copy has completed: no call waits for a previous frame.
-    terminate_above = 0.4
+    # infer_mode="auto": which kernel path pays?  The early-terminating kernel costs 1.26-1.37x per EVALUATED sample (a
+    # wave owns a 16-ray group for all its steps; measured on the bench scene and on a trained one, profiles/r02_NOTES.txt
+    # section 20) and skips every step at which the whole group is below T_thresh, so it wins when it skips more than
+    # 21-27 % of the marched samples; 35 % is used (hysteresis against flapping).  The two-kernel path counts that
+    # fraction in its compositing kernel, the terminating kernel reports what it really evaluated.  (Round 1 switched on
+    # mean opacity > 0.5: a half-trained scene - opacity 0.88, only 8 % skippable - then rendered in 20.5 ms instead of
+    # 14.4, section 11.)  The value travels to the host through a pinned buffer + event and is only read once its copy
+    # has completed: no call waits for a previous frame.
+    terminate_above = 0.35
 
     def _note_skippable(self, frac):
         if not frac.is_cuda:
