@@ -196,6 +196,37 @@ def config5_probe(dev):
             "roi_align_forward_ms": round(t_roi * 1e3, 3)}
 
 
+def instance_render_probe(dev, frames=8):
+    """Secondary measurement: the same 800x800 views rendered WITH the instance head (K = 64 logits composited per
+    pixel; SURVEY a13 at render time): march -> NeRF field (table feed) -> compositing with weights -> instance field
+    with `w * logits` accumulated on chip (k_instance_render).  2048 B of algorithmic table traffic per sample."""
+    from instance_nerf_amd.nerf import NeRFNetwork
+    from instance_nerf_amd.nerf.utils import get_rays
+    from instance_nerf_amd.scene import RoomScene
+    torch.manual_seed(0)
+    net = NeRFNetwork(cuda_ray=True, bound=1, min_near=0.05, density_thresh=10, num_instances=64).to(dev).eval()
+    room = RoomScene()
+    net.density_bitfield.copy_(torch.from_numpy(room.density_bitfield(128, 1.0)).to(dev))
+    poses, intr, H, W = room.cameras()
+    pd = torch.from_numpy(poses).to(dev)
+
+    def frame(v):
+        r = get_rays(pd[v:v + 1], intr, H, W, patch=4)
+        with torch.no_grad():
+            return net.render(r["rays_o"], r["rays_d"], bg_color=1, infer_mode="fused")
+    frame(0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    counts = [frame(v % pd.shape[0])["num_samples"] for v in range(frames)]
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    n = sum(int(c[0]) for c in counts)
+    return {"workload": "render 800x800 with the instance head, K=64 logits per pixel (both fields evaluated per sample)",
+            "ms_per_frame": round(dt / frames * 1e3, 3), "value": round(n / dt / 1e6, 1), "unit": "Msamples/s",
+            "algorithmic_bytes_per_sample": 2 * BYTES_PER_SAMPLE,
+            "frac_of_hbm_peak": round(n * 2 * BYTES_PER_SAMPLE / dt / 1e9 / HBM_PEAK_GBS, 4)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -437,6 +468,10 @@ def main():
                 line["extract_roialign"] = config5_probe(dev)
             except Exception as e:                            # noqa: BLE001
                 line["extract_roialign"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            try:
+                line["render_instance"] = instance_render_probe(dev)
+            except Exception as e:                            # noqa: BLE001
+                line["render_instance"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:
