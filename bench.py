@@ -50,14 +50,19 @@ def build_network(dev, seed=0):
     return net.eval(), room
 
 
-def cpu_baseline(room, chunk=16384, budget_s=12.0, max_chunks=40):
+def cpu_baseline(room, net, frame0=None, chunk=16384, budget_s=12.0, max_chunks=40):
     """The C restatement of the whole path (oracle/c/inr_oracle.c through oracle/c_port.py, kind 'port': slab test ->
     occupancy march -> hash-grid gather + SH + MLPs -> compositing, one ray at a time, OpenMP over rays on every
     host core) on a bounded sample of the same workload: chunks of random pixels of view 0 until ~budget_s seconds
-    of wall time have been used.  Same table, weights, bitfield and camera as the GPU measurement."""
-    from oracle import c_port, field, hashgrid, rays as orays
+    of wall time have been used.  Same table, weights (copied from the GPU network), bitfield and camera as the GPU
+    measurement, so the pixels it renders double as the parity check of the line: `frame0` (the GPU's view 0, row-major
+    [H, W, 3]) is compared with the oracle's colours at the sampled pixels -> second return value."""
+    from oracle import c_port, hashgrid, rays as orays
     table = hashgrid.level_table()
-    p = field.init_params(seed=0, table=table, table_std=1e-4)
+    sd = net.state_dict()
+    p = {"embeddings": sd["encoder.embeddings"], "sigma_w0": sd["sigma_net.0.weight"], "sigma_w1": sd["sigma_net.1.weight"],
+         "color_w0": sd["color_net.0.weight"], "color_w1": sd["color_net.1.weight"], "color_w2": sd["color_net.2.weight"]}
+    p = {k: v.detach().float().cpu() for k, v in p.items()}
     bits = room.density_bitfield(128, 1.0)
     poses, intr, H, W = room.cameras()
     perm = np.random.default_rng(7).permutation(H * W)
@@ -65,6 +70,7 @@ def cpu_baseline(room, chunk=16384, budget_s=12.0, max_chunks=40):
     c_port.render(*[orays.get_rays(poses[:1], intr, H, W, inds=perm[:256])[k][0] for k in ("rays_o", "rays_d")],
                   p, table, bits, min_near=0.05)                               # page the table in, untimed
     total, rays_done, t_used, n = 0, 0, 0.0, 0
+    seen, colours = [], []
     while t_used < budget_s and n < max_chunks:
         inds = np.sort(perm[n * chunk:(n + 1) * chunk])
         r = orays.get_rays(poses[:1], intr, H, W, inds=inds)
@@ -73,10 +79,23 @@ def cpu_baseline(room, chunk=16384, budget_s=12.0, max_chunks=40):
         t_used += time.perf_counter() - t0
         total += out["total"]
         rays_done += len(inds)
+        seen.append(inds)
+        colours.append(out["image"])
         n += 1
-    return {"value": round(total / t_used / 1e6, 5), "unit": "Msamples/s", "cores": threads, "kind": "port",
+    base = {"value": round(total / t_used / 1e6, 5), "unit": "Msamples/s", "cores": threads, "kind": "port",
             "sample": f"{rays_done} random rays of view 0 (800x800 camera) in {n} chunks of {chunk}, {total} samples, "
                       f"C oracle (gcc -O2, OpenMP x{threads}) march+field+composite, {t_used:.1f} s"}
+    parity = None
+    if frame0 is not None:
+        torch.cuda.synchronize()
+        ref = np.concatenate(colours).astype(np.float64)
+        got = frame0.reshape(-1, 3).cpu().numpy()[np.concatenate(seen)].astype(np.float64)
+        mse = float(np.mean((got - ref) ** 2))
+        parity = {"against": "C oracle, same weights / bitfield / camera, view 0", "pixels": int(ref.shape[0]),
+                  "max_abs_diff": float(np.abs(got - ref).max()),
+                  "psnr_db": round(10.0 * np.log10(1.0 / mse), 1) if mse > 0 else None,
+                  "tolerance": "tests: 1e-4 per channel (fp32 path, bf16x3-split MLP GEMMs)"}
+    return base, parity
 
 
 def train_probe(dev, rank=0, world=1, red_dev=None, steps=20, warmup=5, stage="instance"):
@@ -420,7 +439,7 @@ def main():
             except Exception as e:                            # noqa: BLE001
                 line["pipelined"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(room)
+            line["cpu_baseline"], line["parity"] = cpu_baseline(room, net, step(0)["frame"])
     if not args.no_train_probe:
         del net                                       # the probe builds its own (instance-head) network
         if world == 1:
