@@ -325,7 +325,7 @@ def main():
         pipe = FramePipeline(net, dev)
 
     def step_pipelined(i):
-        view = (i * world + rank) % poses_d.shape[0]
+        view = (i + rank) % poses_d.shape[0]       # every rank cycles through all views (their sample counts differ by +-25 %)
         st = pipe.next_stream()
         with torch.cuda.stream(st):
             r = get_rays(poses_d[view:view + 1], intr, H, W, patch=4)
@@ -341,7 +341,7 @@ def main():
     def step(i):
         if args.pipeline:
             return step_pipelined(i)
-        view = (i * world + rank) % poses_d.shape[0]
+        view = (i + rank) % poses_d.shape[0]       # every rank cycles through all views (their sample counts differ by +-25 %)
         r = get_rays(poses_d[view:view + 1], intr, H, W, patch=4)           # same rays, 4x4-patch order
         with torch.no_grad():
             out = net.render(r["rays_o"], r["rays_d"], staged=False, bg_color=1, perturb=False, dt_gamma=0,
