@@ -52,11 +52,16 @@ def test_allreduce_gradients_world2():
 
 
 def test_views_are_sharded_without_overlap():
-    """bench.py's view assignment (i*world+rank) % n covers distinct views per rank per step."""
-    world, n = 4, 8
-    for i in range(6):
-        views = [(i * world + r) % n for r in range(world)]
-        assert len(set(views)) == world
+    """bench.py's view assignment (i + rank) % n: distinct views per rank at every step, and over n steps every rank
+    renders every view once (the views' sample counts differ by +-25 %: a rank pinned to one view would make the
+    max-over-ranks time of the scaling bench depend on which view it drew)."""
+    n = 8
+    for world in (1, 2, 4, 8):
+        for i in range(6):
+            views = [(i + r) % n for r in range(world)]
+            assert len(set(views)) == world
+        for r in range(world):
+            assert sorted((i + r) % n for i in range(n)) == list(range(n))
 
 
 def test_shard_range_covers_rays_in_whole_groups():
