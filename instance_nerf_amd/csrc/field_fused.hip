@@ -1175,9 +1175,7 @@ __global__ void __launch_bounds__(kFieldThreads, INR_FIELD_MIN_WAVES) k_instance
     float4* mine = red + ((size_t)(parity * kWaves + wave) * K_MT) * 64;
 #pragma unroll
     for (int mt = 0; mt < K_MT; ++mt) mine[mt * 64 + lane] = make_float4(acc[mt][0], acc[mt][1], acc[mt][2], acc[mt][3]);
-#ifndef INR_EXPERIMENT_NO_GROUP_BARRIER
-    __syncthreads();
-#endif
+    __syncthreads();                                       // measured free: 14.5 ms per frame with and without it
     if (threadIdx.x < K_MT * 64 && ray < N) {              // thread t: tile row block t >> 6, lane position t & 63
       const float4* part = red + (size_t)parity * kWaves * K_MT * 64 + threadIdx.x;
       float4 sum = part[0];
