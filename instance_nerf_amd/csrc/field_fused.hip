@@ -600,6 +600,9 @@ __global__ void __launch_bounds__(kFieldThreads, INR_FIELD_MIN_WAVES) k_nerf_fwd
                                                                float* __restrict__ geo, const int32_t* __restrict__ ray_ids,
                                                                const float4* __restrict__ shq, NerfSave sv) {
   extern __shared__ __attribute__((aligned(16))) float4 wl[];
+  // the field kernel's waves outrank whatever shares the CU with them (FramePipeline: the next view's marchers run
+  // at priority 0 and take the issue slots this kernel leaves free); alone on the chip it changes nothing
+  __builtin_amdgcn_s_setprio(3);
   constexpr int kStage = (kColor ? kNerfFloats : kCol0) / 4;
   for (int i = threadIdx.x; i < kStage; i += kFieldThreads) wl[i] = packed[i];
   LevelRec* recs = reinterpret_cast<LevelRec*>(wl + kStage);
