@@ -228,7 +228,7 @@ int inr_sh_table_q(const float* d /*[N,3]*/, int64_t N, float* out /*[N,16], 16-
  * instance head, a9/a13; the MFMA kernel the north star asks for) ---------------------------
  * Weights are nn.Linear [out,in] row-major fp32, no bias:
  *   sigma_w0[64,32] sigma_w1[16,64] color_w0[64,31] color_w1[64,64] color_w2[3,64]
- *   inst_w0[64,32] inst_w1[64,64] inst_w2[K,64] (K <= 64, K % 16 == 0)
+ *   inst_w0[64,32] inst_w1[64,64] inst_w2[K,64] (K <= 64, K % 16 == 0: a caller with another K zero-pads the rows, as NeRFNetwork does)
  * inr_field_pack_* reorder them (on the host) into MFMA fragment order; the
  * packed buffer is then copied to the device by the caller.                              */
 int64_t inr_nerf_packed_floats(void);

@@ -251,7 +251,11 @@ class NeRFNetwork(NeRFRenderer):
         self._fusable = (encoding == "hashgrid" and encoding_dir == "sphere_harmonics" and num_layers == 2
                          and hidden_dim == 64 and geo_feat_dim == 15 and num_layers_color == 3
                          and hidden_dim_color == 64 and self.in_dim == 32)
-        self._fusable_inst = (self.num_instances in (16, 32, 48, 64) and num_layers_instance == 3
+        # the fused instance kernels work on 16-channel MFMA tiles: any K <= 64 runs on them with the output layer
+        # zero-padded to the next multiple of 16 (the reference's K is 30 detections + background = 31); the padded
+        # channels are cut off again before anything outside this class sees them
+        self._k_pad = 16 * ((self.num_instances + 15) // 16)
+        self._fusable_inst = (0 < self.num_instances <= 64 and num_layers_instance == 3
                               and hidden_dim_instance == 64)
         self._packed = {}
         self.fused_instance_train = True     # False: HIP encoder + rocBLAS layers (the composable path)
@@ -270,13 +274,15 @@ class NeRFNetwork(NeRFRenderer):
         if hit is not None and hit[0] == key:
             return hit[1]
         host = [w.detach().float().cpu().contiguous() for w in ws]
+        if which != "nerf" and self._k_pad != self.num_instances:
+            host[2] = torch.nn.functional.pad(host[2], (0, 0, 0, self._k_pad - self.num_instances)).contiguous()
         if which == "nerf":
             buf = torch.empty(lib.inr_nerf_packed_floats(), dtype=torch.float32)
             check(lib.inr_nerf_pack_weights(*[host_ptr(h, torch.float32) for h in host], host_ptr(buf, torch.float32)),
                   "nerf_pack_weights")
         else:
-            buf = torch.empty(lib.inr_instance_packed_floats(self.num_instances), dtype=torch.float32)
-            check(lib.inr_instance_pack_weights(*[host_ptr(h, torch.float32) for h in host], self.num_instances,
+            buf = torch.empty(lib.inr_instance_packed_floats(self._k_pad), dtype=torch.float32)
+            check(lib.inr_instance_pack_weights(*[host_ptr(h, torch.float32) for h in host], self._k_pad,
                                                 host_ptr(buf, torch.float32)), "instance_pack_weights")
         dev = buf.to(ws[0].device)
         self._packed[which] = (key, dev)
@@ -400,22 +406,32 @@ class NeRFNetwork(NeRFRenderer):
         """x [M,3] -> raw instance logits [M,K] (None when the network has no instance head)."""
         if not self.num_instances:
             return None
+        out = self._instance_for_compositing(x)
+        return out if out.shape[1] == self.num_instances else out[:, :self.num_instances].contiguous()
+
+    def _instance_for_compositing(self, x):
+        """Logits as the fused kernels produce them: [M, K rounded up to 16] (the extra channels are exactly zero and
+        the renderer drops them after compositing), or [M, K] from the composable path."""
         params = [self.instance_encoder.embeddings] + [l.weight for l in self.instance_net]
+        K, Kp = self.num_instances, self._k_pad
         if self._fusable_inst and not self._needs_grad(params):
             lib = _lib.load()
             x = x.contiguous().float()
             M = x.shape[0]
-            out = torch.empty(M, self.num_instances, dtype=torch.float32, device=x.device)
+            out = torch.empty(M, Kp, dtype=torch.float32, device=x.device)
             check(lib.inr_instance_forward(ptr(x, torch.float32, "x"), M, None, float(self.bound),
                                            ptr(self.instance_encoder.embeddings.data, torch.float32),
                                            self.instance_encoder.desc, ptr(self._packed_weights("instance")),
-                                           self.num_instances, ptr(out), stream_ptr()), "instance_forward")
+                                           Kp, ptr(out), stream_ptr()), "instance_forward")
             return out
         if (self._fusable_inst and self.fused_instance_train and x.is_cuda and all(p.requires_grad for p in params)
                 and torch.is_grad_enabled() and not x.requires_grad):
+            w2 = self.instance_net[2].weight
+            if Kp != K:
+                w2 = torch.nn.functional.pad(w2, (0, 0, 0, Kp - K))       # autograd cuts its gradient back to [K, 64]
             return _InstanceFieldFn.apply(x.contiguous().float(), self.instance_encoder.embeddings,
-                                          self.instance_net[0].weight, self.instance_net[1].weight,
-                                          self.instance_net[2].weight, self.instance_encoder.desc, self.bound)
+                                          self.instance_net[0].weight, self.instance_net[1].weight, w2,
+                                          self.instance_encoder.desc, self.bound)
         return _run_mlp(self.instance_net, self.instance_encoder(x, bound=self.bound))
 
     @torch.no_grad()
@@ -450,14 +466,14 @@ class NeRFNetwork(NeRFRenderer):
             return None
         lib = _lib.load()
         N, M = rays.shape[0], xyzs.shape[0]
-        out = torch.empty(N, self.num_instances, dtype=torch.float32, device=rays.device)
+        out = torch.empty(N, self._k_pad, dtype=torch.float32, device=rays.device)
         check(lib.inr_instance_render(ptr(xyzs, torch.float32, "xyzs", allow_none=M == 0), ptr(rays, torch.int32, "rays"),
                                       ptr(weights, torch.float32, "weights", allow_none=M == 0), N, M, float(self.bound),
                                       ptr(self.instance_encoder.embeddings.data, torch.float32),
                                       self.instance_encoder.desc, ptr(self._packed_weights("instance")),
-                                      self.num_instances, ptr(out), 1 if normalised else 0, stream_ptr()),
+                                      self._k_pad, ptr(out), 1 if normalised else 0, stream_ptr()),
               "instance_render")
-        return out
+        return out if self._k_pad == self.num_instances else out[:, :self.num_instances].contiguous()
 
     def get_params(self, lr):
         params = [{"params": self.encoder.parameters(), "lr": lr},

@@ -172,6 +172,11 @@ class NeRFRenderer(nn.Module):
             results["instance"] = torch.sum(weights.detach().unsqueeze(-1) * logits, dim=-2).view(*prefix, -1)
         return results
 
+    def _instance_for_compositing(self, x):
+        """Logits handed to the K-channel compositing kernels; a network may return more channels than
+        ``num_instances`` (zero-padded MFMA tiles) - the renderer keeps the first ``num_instances`` rendered ones."""
+        return self.instance(x)
+
     def run_cuda(self, rays_o, rays_d, dt_gamma=0, bg_color=None, perturb=False, force_all_rays=False,
                  max_steps=1024, T_thresh=1e-4, infer_mode="auto", noises=None, field_gate=None, **kwargs):
         """rays_o, rays_d [B,N,3] -> dict(image [B,N,3], depth [B,N], weights_sum [B,N] (, instance [B,N,K])).
@@ -246,12 +251,12 @@ class NeRFRenderer(nn.Module):
                                                                                   return_weights=True, skippable=skippable)
                 results["instance"] = self.instance_render(xyzs, rays, wbuf, normalised=table).view(*prefix, -1)
             else:
-                extra = self.instance(xyzs) if with_instance else None
+                extra = self._instance_for_compositing(xyzs) if with_instance else None
                 out = raymarching.composite_rays_patch(sigmas, rgbs, deltas, rays, T_thresh, extra=extra,
                                                        skippable=skippable)
                 weights_sum, depth, image = out[0], out[1], out[2]
                 if with_instance:
-                    results["instance"] = out[3].view(*prefix, -1)
+                    results["instance"] = out[3][:, :self.num_instances].reshape(*prefix, -1)
             results["num_samples"] = counter
             skipped_frac = skippable[0].float() / counter[0].float().clamp(min=1)
         elif self.training or infer_mode == "fused_raymajor":
@@ -270,11 +275,11 @@ class NeRFRenderer(nn.Module):
             sigmas, rgbs = self(xyzs, dirs)
             if self.density_scale != 1:
                 sigmas = self.density_scale * sigmas
-            extra = self.instance(xyzs) if with_instance else None
+            extra = self._instance_for_compositing(xyzs) if with_instance else None
             out = raymarching.composite_rays_train(sigmas, rgbs, deltas, rays, T_thresh, extra=extra)
             weights_sum, depth, image = out[0], out[1], out[2]
             if with_instance:
-                results["instance"] = out[3].view(*prefix, -1)
+                results["instance"] = out[3][:, :self.num_instances].reshape(*prefix, -1)
             results["num_samples"] = counter
         elif infer_mode == "wavefront":
             dtype = torch.float32

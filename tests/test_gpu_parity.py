@@ -956,7 +956,7 @@ def test_render_fuzz_against_the_c_oracle(level_table, seed):
     logits within 1e-4 / 1e-3."""
     from oracle import c_port, field
     rng = np.random.default_rng(4000 + seed)
-    K = int(rng.choice([0, 16, 48, 64]))
+    K = int(rng.choice([0, 5, 16, 31, 48, 64]))              # 31 = the reference's 30 detections + background
     p = field.init_params(seed=seed, table=level_table, table_std=1.0, K=K)
     fill = float(rng.choice([0.0, 0.002, 0.05, 0.5, 1.0]))
     bits = (rng.random(128 ** 3 // 8) < fill).astype(np.uint8) * rng.integers(1, 256, 128 ** 3 // 8).astype(np.uint8)
@@ -1015,7 +1015,7 @@ def test_training_gradients_fuzz_against_the_oracle(level_table, seed):
     of the fused training kernels against torch autograd through the numpy/torch oracle."""
     from oracle import field, render
     rng = np.random.default_rng(9000 + seed)
-    K = int(rng.choice([16, 64]))
+    K = [64, 31, 16, 5, 64][seed]                            # 31 = the reference's 30 detections + background
     stage = "nerf" if seed % 2 == 0 else "instance"
     p = field.init_params(seed=seed, table=level_table, table_std=1.0, K=K)
     fill = float(rng.choice([0.02, 0.2]))
@@ -1287,6 +1287,44 @@ def test_frame_pipeline_is_bit_identical(params_k16, room, room_bitfield, mode, 
             assert torch.equal(o[key], ref[k % 3][key]), (k, key)
     with pytest.raises(RuntimeError):
         pipe.render(rays[0]["rays_o"], rays[0]["rays_d"], staged=True)
+
+
+def test_instance_head_with_31_classes_runs_on_the_fused_kernels(level_table, room, room_bitfield):
+    """K = 31 (the reference's 30 detections + background, run_rcnn.py:75 / match_seg.py:69) is not a multiple of the
+    16-channel MFMA tile: the fused kernels run it with a zero-padded output layer.  Nothing padded leaks: logits,
+    rendered logits and the weight gradient have 31 channels, values equal the composable (unfused) path, and a
+    training step moves the loss."""
+    from oracle import field
+    from instance_nerf_amd.nerf.utils import get_rays
+    p = field.init_params(seed=3, table=level_table, table_std=1.0, K=31)
+    net = _network(p, K=31)
+    assert net._fusable_inst and net._k_pad == 32
+    net.density_bitfield.copy_(_t(room_bitfield))
+    x = torch.rand(1000, 3, device=DEV) * 1.8 - 0.9
+    net.eval()
+    with torch.no_grad():
+        fused = net.instance(x)
+        net._fusable_inst = False
+        plain = net.instance(x)
+        net._fusable_inst = True
+    assert fused.shape == plain.shape == (1000, 31) and fused.is_contiguous()
+    assert (fused - plain).abs().max() < 1e-3 * max(1.0, float(plain.abs().max()))
+    poses, intr, H, W = room.cameras(n=1, H=64, W=64, focal=32.0)
+    r = get_rays(_t(poses[:1]), intr, 64, 64, patch=4)
+    with torch.no_grad():
+        a = net.render(r["rays_o"], r["rays_d"], bg_color=1, infer_mode="fused")          # k_instance_render, 32 channels
+        b = net.render(r["rays_o"], r["rays_d"], bg_color=1, infer_mode="fused_raymajor")  # logits + K-channel compositing
+    assert a["instance"].shape == b["instance"].shape == (1, 4096, 31)
+    assert (a["instance"] - b["instance"]).abs().max() < 1e-3 * max(1.0, float(b["instance"].abs().max()))
+    net.train()
+    net.freeze_nerf()
+    out = net.render(r["rays_o"][:, :1024], r["rays_d"][:, :1024], bg_color=1, perturb=False, force_all_rays=True)
+    labels = torch.randint(0, 31, (1024,), device=DEV)
+    loss = torch.nn.functional.cross_entropy(out["instance"][0], labels)
+    loss.backward()
+    g = net.instance_net[2].weight.grad
+    assert g.shape == (31, 64) and torch.isfinite(g).all() and g.abs().max() > 0
+    assert net.instance_encoder.embeddings.grad.abs().max() > 0
 
 
 def test_auto_mode_follows_the_skippable_fraction(params_k16, room, room_bitfield):
