@@ -1404,6 +1404,32 @@ def test_staged_render_on_an_opaque_scene_two_frames(params_k16, room, room_bitf
         assert torch.isfinite(loss)
 
 
+def test_trainer_renders_row_major_views_in_patch_order(params_k16, room, room_bitfield):
+    """Upstream's evaluation loaders pass the H*W rays of a view in row-major order with H and W beside them; the
+    Trainer renders them patch by patch (compact 16-ray groups) and returns every per-ray output in the caller's order:
+    the same bits as rendering the row-major rays directly."""
+    from instance_nerf_amd.nerf.utils import get_rays, Trainer
+    net = _network(params_k16, K=16).eval()
+    net.density_bitfield.copy_(_t(room_bitfield))
+    poses, intr, H, W = room.cameras(n=1, H=64, W=96, focal=40.0)
+    r = get_rays(_t(poses[:1]), intr, 64, 96)                                  # row-major, as upstream's loader
+    with torch.no_grad():
+        direct = net.render(r["rays_o"], r["rays_d"], bg_color=1, infer_mode="fused")
+    tr = Trainer("t", None, net, stage="instance", device=torch.device(DEV))
+    seen = {}
+    inner = net.render
+    net.render = lambda ro, rd, **kw: (seen.setdefault("first_dirs", rd[0, :16].clone()), inner(ro, rd, **kw))[1]
+    data = {"rays_o": r["rays_o"], "rays_d": r["rays_d"], "H": 64, "W": 96}
+    img, dep, inst = tr.test_step(data)
+    net.render = inner
+    assert img.shape == (1, 64, 96, 3) and dep.shape == (1, 64, 96) and inst.shape == (1, 64, 96, 16)
+    assert torch.equal(img.reshape(1, -1, 3), direct["image"])
+    assert torch.equal(dep.reshape(1, -1), direct["depth"])
+    assert torch.equal(inst.reshape(1, -1, 16), direct["instance"])
+    # the renderer saw a 4x4 patch first - pixels (0..3, 0..3) - not the first 16 pixels of row 0
+    assert torch.equal(seen["first_dirs"], r["rays_d"][0].view(64, 96, 3)[:4, :4].reshape(16, 3))
+
+
 def test_composite_train_with_dropped_rays(rm, room, room_bitfield, bits_dev):
     """Sample buffers sized from mean_count: rays that overflow M are dropped by the writer and must composite to
     zero (and get zero gradients) - never be read past the end of the buffers (regression: GPU memory fault)."""
