@@ -115,7 +115,7 @@ def train_probe(dev, rank=0, world=1, red_dev=None, steps=20, warmup=5, stage="i
     ds = SyntheticRoomDataset(dev, num_rays=4096, num_instances=64, rank=rank)
     net.density_bitfield.copy_(torch.from_numpy(ds.room.density_bitfield(128, 1.0)).to(dev))
     tr = Trainer("bench", None, net, stage=stage, device=dev, iters=1000, update_extra_interval=16,
-                 local_rank=rank, world_size=world)
+                 local_rank=rank, world_size=world, ema_decay=0.95)     # upstream's main scripts train with the EMA on
     # Upstream's loop, occupancy update included: every 16 steps update_extra_state() queries the density of 128^3
     # (later 128^3 / 2) cells, refreshes the grid / bitfield and sets mean_count, which sizes the sample buffers of
     # the next 16 steps (no host sync inside a step).  The field is untrained here, so the grid it produces says
@@ -173,7 +173,7 @@ def train_probe(dev, rank=0, world=1, red_dev=None, steps=20, warmup=5, stage="i
     reduced = sum(p.numel() for g in tr.optimizer.param_groups for p in g["params"]) * 4
     what = ("instance-field training step, K=64, 4096 rays/batch per GPU, NeRF frozen "
             f"(BASELINE configs[{2 if world == 1 else 3}])") if stage == "instance" else \
-        "NeRF training step (MSE on rgb: hash table + sigma/colour nets), 4096 rays/batch per GPU"
+        "NeRF training step (MSE on rgb: hash table + sigma/colour nets, parameter EMA 0.95), 4096 rays/batch per GPU"
     return {"workload": what,
             "n_gpus": world, "ms_per_step": round(dt * 1e3, 3), "samples_per_step": int(n_all) // steps,
             "msamples_per_s": round(n_all / steps / dt / 1e6, 2),

@@ -344,6 +344,12 @@ int inr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
 int inr_adam_step_multi(int32_t n_tensors, float* const* params, const float* const* grads, float* const* exp_avgs,
                         float* const* exp_avg_sqs, const int64_t* numels, const float* lrs, float beta1, float beta2,
                         float eps, int32_t step, float grad_scale, inr_stream_t s);
+/* The same with the parameter EMA of upstream's Trainer (torch_ema: shadow += w * (param - shadow) after every step)
+ * applied while the new parameter is in registers: ema_shadows[t] (device, nullable per tensor), w = ema_weight. */
+int inr_adam_ema_step_multi(int32_t n_tensors, float* const* params, const float* const* grads, float* const* exp_avgs,
+                            float* const* exp_avg_sqs, const int64_t* numels, const float* lrs, float beta1, float beta2,
+                            float eps, int32_t step, float grad_scale, float* const* ema_shadows, float ema_weight,
+                            inr_stream_t s);
 /* The same with the step-dependent scalars in DEVICE memory (hyper_dev = [eps_t, lr_t[0..15]], written by
  * inr_adam_set_hyper on the stream - the values travel as kernel arguments, no host buffer has to stay alive): a
  * captured hipGraph of a training step can then be replayed with a new learning rate and bias correction. */

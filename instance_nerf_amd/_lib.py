@@ -54,6 +54,8 @@ _SIGS = {
     "inr_instance_forward_train": (c_int32, [P, c_int64, c_float, P, POINTER(GridDesc), P, c_int32, P, P, P, P, P]),
     "inr_instance_backward": (c_int32, [P, c_int32, P, P, c_int64, P, P, P, P, P]),
     "inr_adam_step_multi": (c_int32, [c_int32, P, P, P, P, P, P, c_float, c_float, c_float, c_int32, c_float, P]),
+    "inr_adam_ema_step_multi": (c_int32, [c_int32, P, P, P, P, P, P, c_float, c_float, c_float, c_int32, c_float, P,
+                                          c_float, P]),
     "inr_adam_set_hyper": (c_int32, [P, c_int32, c_float, c_float, c_float, c_int32, P, P]),
     "inr_adam_step_multi_dev": (c_int32, [c_int32, P, P, P, P, P, P, c_float, c_float, c_float, P]),
     "inr_cross_entropy": (c_int32, [P, P, c_int64, c_int32, c_int64, P, P, P, P]),

@@ -248,6 +248,7 @@ struct AdamJobs {
   float* v[kAdamMaxTensors];
   int64_t n[kAdamMaxTensors];
   float lr_t[kAdamMaxTensors];
+  float* s[kAdamMaxTensors];      // parameter EMA (nullable per tensor): s += ema_w * (p_new - s) while p is in registers
 };
 struct AdamHyper {
   float v[1 + kAdamMaxTensors];
@@ -259,7 +260,7 @@ __global__ void k_adam_set_hyper(AdamHyper h, float* __restrict__ hyper) {
 // hyper (nullable, device): [eps_t, lr_t[0..15]] - the step-dependent scalars live in memory so that a captured
 // hipGraph of the training step can be replayed with a new learning rate / bias correction
 __global__ void __launch_bounds__(256) k_adam_multi(AdamJobs J, float b1, float b2, float eps_t, float gscale,
-                                                    const float* __restrict__ hyper) {
+                                                    const float* __restrict__ hyper, float ema_w) {
   const int t = blockIdx.y;
   if (hyper) {
     eps_t = hyper[0];
@@ -269,9 +270,10 @@ __global__ void __launch_bounds__(256) k_adam_multi(AdamJobs J, float b1, float 
   const float* __restrict__ g = J.g[t];
   float* __restrict__ m = J.m[t];
   float* __restrict__ v = J.v[t];
+  float* __restrict__ sh = J.s[t];
   const int64_t n = J.n[t];
   const float lr_t = J.lr_t[t];
-  const bool aligned = (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0;
+  const bool aligned = (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v | (uintptr_t)sh) & 15) == 0;
   const int64_t n4 = aligned ? n / 4 : 0;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x, tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   for (int64_t i = tid; i < n4; i += stride) {
@@ -287,13 +289,21 @@ __global__ void __launch_bounds__(256) k_adam_multi(AdamJobs J, float b1, float 
     INR_ADAM1(x) INR_ADAM1(y) INR_ADAM1(z) INR_ADAM1(w)
 #undef INR_ADAM1
     reinterpret_cast<float4*>(p)[i] = pp; reinterpret_cast<float4*>(m)[i] = mm; reinterpret_cast<float4*>(v)[i] = vv;
+    if (sh) {
+      float4 ss = reinterpret_cast<float4*>(sh)[i];
+      ss.x += ema_w * (pp.x - ss.x); ss.y += ema_w * (pp.y - ss.y);
+      ss.z += ema_w * (pp.z - ss.z); ss.w += ema_w * (pp.w - ss.w);
+      reinterpret_cast<float4*>(sh)[i] = ss;
+    }
   }
   for (int64_t i = n4 * 4 + tid; i < n; i += stride) {
     const float gr = g[i] * gscale;
     const float mm = b1 * m[i] + (1.0f - b1) * gr;
     const float vv = b2 * v[i] + (1.0f - b2) * gr * gr;
     m[i] = mm; v[i] = vv;
-    p[i] = p[i] - lr_t * mm / (sqrtf(vv) + eps_t);
+    const float pn = p[i] - lr_t * mm / (sqrtf(vv) + eps_t);
+    p[i] = pn;
+    if (sh) sh[i] += ema_w * (pn - sh[i]);
   }
 }
 
@@ -561,9 +571,10 @@ int inr_linear_wgrad(const float* x, const float* grad_y, int64_t M, int32_t n_i
   return check_launch("linear_wgrad");
 }
 
-int inr_adam_step_multi(int32_t n_tensors, float* const* params, const float* const* grads, float* const* exp_avgs,
-                        float* const* exp_avg_sqs, const int64_t* numels, const float* lrs, float beta1, float beta2,
-                        float eps, int32_t step, float grad_scale, inr_stream_t s) {
+static int adam_multi_launch(int32_t n_tensors, float* const* params, const float* const* grads, float* const* exp_avgs,
+                             float* const* exp_avg_sqs, const int64_t* numels, const float* lrs, float beta1, float beta2,
+                             float eps, int32_t step, float grad_scale, float* const* ema, float ema_weight,
+                             inr_stream_t s, const char* what) {
   INR_REQUIRE(n_tensors >= 0 && n_tensors <= kAdamMaxTensors && step >= 1, "bad argument (at most 16 tensors per call)");
   if (n_tensors == 0) return INR_OK;
   INR_REQUIRE(params && grads && exp_avgs && exp_avg_sqs && numels && lrs, "null pointer");
@@ -574,14 +585,32 @@ int inr_adam_step_multi(int32_t n_tensors, float* const* params, const float* co
     INR_REQUIRE(numels[t] >= 0 && (numels[t] == 0 || (params[t] && grads[t] && exp_avgs[t] && exp_avg_sqs[t])),
                 "null tensor pointer");
     J.p[t] = params[t]; J.g[t] = grads[t]; J.m[t] = exp_avgs[t]; J.v[t] = exp_avg_sqs[t]; J.n[t] = numels[t];
+    J.s[t] = ema ? ema[t] : nullptr;
     J.lr_t[t] = (float)(lrs[t] * sqrt(bc2) / bc1);      // same folding as inr_adam_step
     n_max = std::max(n_max, numels[t]);
   }
   if (n_max == 0) return INR_OK;
   const unsigned nb = (unsigned)std::min<int64_t>((n_max / 4 + 255) / 256 + 1, 256 * 16);
   k_adam_multi<<<dim3(nb, n_tensors), 256, 0, as_stream(s)>>>(J, beta1, beta2, (float)(eps * sqrt(bc2)), grad_scale,
-                                                              nullptr);
-  return check_launch("adam_step_multi");
+                                                              nullptr, ema_weight);
+  return check_launch(what);
+}
+
+int inr_adam_step_multi(int32_t n_tensors, float* const* params, const float* const* grads, float* const* exp_avgs,
+                        float* const* exp_avg_sqs, const int64_t* numels, const float* lrs, float beta1, float beta2,
+                        float eps, int32_t step, float grad_scale, inr_stream_t s) {
+  return adam_multi_launch(n_tensors, params, grads, exp_avgs, exp_avg_sqs, numels, lrs, beta1, beta2, eps, step,
+                           grad_scale, nullptr, 0.f, s, "adam_step_multi");
+}
+
+int inr_adam_ema_step_multi(int32_t n_tensors, float* const* params, const float* const* grads, float* const* exp_avgs,
+                            float* const* exp_avg_sqs, const int64_t* numels, const float* lrs, float beta1, float beta2,
+                            float eps, int32_t step, float grad_scale, float* const* ema_shadows, float ema_weight,
+                            inr_stream_t s) {
+  INR_REQUIRE(n_tensors == 0 || ema_shadows, "null pointer");
+  INR_REQUIRE(ema_weight >= 0.f && ema_weight <= 1.f, "ema_weight outside [0, 1]");
+  return adam_multi_launch(n_tensors, params, grads, exp_avgs, exp_avg_sqs, numels, lrs, beta1, beta2, eps, step,
+                           grad_scale, ema_shadows, ema_weight, s, "adam_ema_step_multi");
 }
 
 int inr_adam_set_hyper(const float* lrs, int32_t n_tensors, float beta1, float beta2, float eps, int32_t step,
@@ -609,11 +638,12 @@ int inr_adam_step_multi_dev(int32_t n_tensors, float* const* params, const float
                 "null tensor pointer");
     J.p[t] = params[t]; J.g[t] = grads[t]; J.m[t] = exp_avgs[t]; J.v[t] = exp_avg_sqs[t]; J.n[t] = numels[t];
     J.lr_t[t] = 0.f;
+    J.s[t] = nullptr;
     n_max = std::max(n_max, numels[t]);
   }
   if (n_max == 0) return INR_OK;
   const unsigned nb = (unsigned)std::min<int64_t>((n_max / 4 + 255) / 256 + 1, 256 * 16);
-  k_adam_multi<<<dim3(nb, n_tensors), 256, 0, as_stream(s)>>>(J, beta1, beta2, 0.f, grad_scale, hyper_dev);
+  k_adam_multi<<<dim3(nb, n_tensors), 256, 0, as_stream(s)>>>(J, beta1, beta2, 0.f, grad_scale, hyper_dev, 0.f);
   return check_launch("adam_step_multi_dev");
 }
 

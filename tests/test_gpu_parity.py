@@ -1327,6 +1327,35 @@ def test_instance_head_with_31_classes_runs_on_the_fused_kernels(level_table, ro
     assert net.instance_encoder.embeddings.grad.abs().max() > 0
 
 
+def test_parameter_ema_inside_the_optimiser_launch():
+    """FusedAdam.attach_ema: shadow += (1 - d) * (param - shadow) applied in the Adam kernel equals torch_ema's update
+    applied after the step (ParamEMA.update), including for a tensor that has no gradient in one of the steps, an odd
+    length (scalar tail of the float4 loop) and the warm-up of the decay (d = min(decay, (1 + n) / (10 + n)))."""
+    from instance_nerf_amd.nerf.utils import FusedAdam, ParamEMA
+    torch.manual_seed(0)
+    shapes = [(1003,), (64, 32), (7,)]
+
+    def setup():
+        ps = [torch.nn.Parameter(torch.randn(*sh, device=DEV)) for sh in shapes]
+        return ps, FusedAdam([{"params": ps, "lr": 1e-2}]), ParamEMA(ps, 0.95)
+    torch.manual_seed(1); pa, oa, ea = setup()
+    torch.manual_seed(1); pb, ob, eb = setup()
+    oa.attach_ema(ea)
+    for step in range(12):
+        gs = [torch.randn_like(p) for p in pa]
+        for k, (x, y) in enumerate(zip(pa, pb)):
+            x.grad = y.grad = None
+            if not (step == 3 and k == 1):             # tensor 1 has no gradient in step 3
+                x.grad, y.grad = gs[k].clone(), gs[k].clone()
+        oa.step(); ea.update()                         # update(): nothing left to do
+        ob.step(); eb.update()                         # the reference order of upstream's loop
+        assert ea.num_updates == eb.num_updates == step + 1
+    for x, y in zip(pa, pb):
+        assert torch.equal(x, y)
+    for sa, sb in zip(ea.shadow, eb.shadow):
+        assert (sa - sb).abs().max() < 1e-6
+
+
 def test_auto_mode_follows_the_skippable_fraction(params_k16, room, room_bitfield):
     """infer_mode="auto": the fraction of marched samples that lie behind the point where their whole 16-ray group
     has terminated - counted by the compositing kernel of the two-kernel path, reported by the terminating kernel
