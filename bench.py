@@ -171,7 +171,7 @@ def train_probe(dev, rank=0, world=1, red_dev=None, steps=20, warmup=5, stage="i
         elapsed, n_all = float(tm.item()), float(ts.item())
     dt = elapsed / steps
     reduced = sum(p.numel() for g in tr.optimizer.param_groups for p in g["params"]) * 4
-    what = ("instance-field training step, K=64, 4096 rays/batch per GPU, NeRF frozen "
+    what = ("instance-field training step, K=64, 4096 rays/batch per GPU, NeRF frozen, parameter EMA 0.95 "
             f"(BASELINE configs[{2 if world == 1 else 3}])") if stage == "instance" else \
         "NeRF training step (MSE on rgb: hash table + sigma/colour nets, parameter EMA 0.95), 4096 rays/batch per GPU"
     return {"workload": what,
