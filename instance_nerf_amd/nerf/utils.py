@@ -410,33 +410,51 @@ def shard_range(n_rays, rank, world_size, align=16):
     return lo, hi
 
 
+def shard_indices(n_rays, rank, world_size, device=None, chunk_groups=64, align=16):
+    """Ray indices of this rank when a frame is split over the GPUs of a node: chunks of ``chunk_groups`` whole 16-ray
+    groups (1024 rays) dealt round robin.  Contiguous ranges (``shard_range``) are NOT balanced - the top rows of a
+    frame see the ceiling, the middle rows the whole room, and the frame is as slow as its slowest rank (the same
+    effect the XCD schedule of the group-owned kernels had, profiles/r02_NOTES.txt 20); interleaved chunks are, and a
+    chunk is still a compact run of patches."""
+    chunk = chunk_groups * align
+    n_chunks = (n_rays + chunk - 1) // chunk
+    if rank >= n_chunks:
+        return torch.empty(0, dtype=torch.int64, device=device)
+    mine = torch.arange(rank, n_chunks, world_size, device=device)
+    idx = (mine[:, None] * chunk + torch.arange(chunk, device=device)[None, :]).reshape(-1)
+    return idx[idx < n_rays]
+
+
 @torch.no_grad()
 def render_sharded(model, rays_o, rays_d, rank=0, world_size=1, keys=("image", "depth", "weights_sum", "instance"),
                    **kwargs):
     """One frame split over the GPUs of a node (render row): rays are independent, parameters and the
-    occupancy bitfield are replicated, every rank renders a contiguous range and the results are all-gathered
-    (RCCL; 16 + 4K bytes per ray, nothing on the critical path of the kernels).  rays_o, rays_d [B,N,3] -> dict of
-    full [B,N,...] tensors on every rank."""
+    occupancy bitfield are replicated, every rank renders its chunks of the ray list (``shard_indices``: 1024-ray
+    chunks dealt round robin, so that every rank gets the same mix of cheap and expensive image regions) and the
+    results are all-gathered (RCCL; 16 + 4K bytes per ray, nothing on the critical path of the kernels) and put back in
+    the caller's ray order.  rays_o, rays_d [B,N,3] -> dict of full [B,N,...] tensors on every rank."""
     B, N = rays_o.shape[:2]
-    bounds = [shard_range(N, r, world_size) for r in range(world_size)]
-    if any(b <= a for a, b in bounds):
-        raise ValueError(f"{N} rays cannot be split over {world_size} ranks in whole 16-ray groups")
-    lo, hi = bounds[rank]
-    out = model.render(rays_o[:, lo:hi].contiguous(), rays_d[:, lo:hi].contiguous(), **kwargs)
     if world_size == 1:
-        return out
+        return model.render(rays_o, rays_d, **kwargs)
+    index = [shard_indices(N, r, world_size, rays_o.device) for r in range(world_size)]
+    if any(i.numel() == 0 for i in index):
+        raise ValueError(f"{N} rays are fewer than one 1024-ray chunk per rank for {world_size} ranks")
+    out = model.render(rays_o[:, index[rank]].contiguous(), rays_d[:, index[rank]].contiguous(), **kwargs)
     result = {}
     for k in keys:
         if k not in out:
             continue
         tail = out[k].shape[2:]
-        parts = [torch.empty(B, b - a, *tail, dtype=out[k].dtype, device=rays_o.device) for a, b in bounds]
+        parts = [torch.empty(B, i.numel(), *tail, dtype=out[k].dtype, device=rays_o.device) for i in index]
         mine = out[k].contiguous()
-        if len({b - a for a, b in bounds}) == 1:
+        if len({i.numel() for i in index}) == 1:
             dist.all_gather(parts, mine)
         else:
             _all_gather_uneven(parts, mine, rank)
-        result[k] = torch.cat(parts, 1)
+        full = torch.empty(B, N, *tail, dtype=out[k].dtype, device=rays_o.device)
+        for i, part in zip(index, parts):
+            full[:, i] = part
+        result[k] = full
     return result
 
 

@@ -74,6 +74,21 @@ def test_shard_range_covers_rays_in_whole_groups():
             assert all(lo % 16 == 0 for lo, _ in b)
 
 
+def test_shard_indices_partition_the_rays_in_whole_groups():
+    from instance_nerf_amd.nerf.utils import shard_indices
+    for n in (640000, 4096, 5000, 2049):
+        for world in (1, 2, 3, 8):
+            parts = [shard_indices(n, r, world) for r in range(world)]
+            if n < 1024 * world:
+                continue
+            allidx = torch.cat(parts)
+            assert allidx.numel() == n and torch.equal(torch.sort(allidx).values, torch.arange(n))
+            for p in parts:                       # runs of whole 16-ray groups; sizes within one chunk of each other
+                assert int(p[0]) % 16 == 0 and abs(p.numel() - n / world) <= 1024
+                starts = p[::16]
+                assert bool((starts % 16 == 0).all())
+
+
 class _FakeModel:
     """render() stand-in with per-ray results that depend on the ray only (the sharding logic is host-side)."""
     def render(self, rays_o, rays_d, **kw):
@@ -95,7 +110,7 @@ def _render_worker(rank, world, port, q, n):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n", [64, 1000])          # even shards (all_gather) and uneven ones (broadcasts)
+@pytest.mark.parametrize("n", [4096, 5000])        # even shards (all_gather) and uneven ones (broadcasts)
 def test_render_sharded_world2(n):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
