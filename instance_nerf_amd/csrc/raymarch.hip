@@ -209,6 +209,18 @@ __device__ __forceinline__ Ray load_ray(const float* __restrict__ o, const float
 __device__ __forceinline__ float step_dt(const MarchParams& P, float t) {
   return clampf(t * P.dt_gamma, P.dt_min, P.dt_max);
 }
+// dt_gamma == 0 (indoor scenes, the reference's 3D-FRONT rooms): t * 0 is +-0 (or NaN for an infinite t), and
+// clamp(+-0 or NaN, dt_min, dt_max) is the same value for every t - fmaxf drops the NaN - so the three instructions
+// per step candidate are loop-invariant.  kConst: that value, formed once by the very same expression.
+template <bool kConst>
+struct StepRule {
+  float c;
+  __device__ __forceinline__ explicit StepRule(const MarchParams& P) : c(step_dt(P, 0.0f)) {}
+  __device__ __forceinline__ float operator()(const MarchParams& P, float t) const {
+    if constexpr (kConst) return c;
+    else return step_dt(P, t);
+  }
+};
 
 // Marches from t until t >= far or max_emit samples were emitted.  emit(px,py,pz,dt,delta,t); advance() is called
 // every time t moves on by one step, i.e. once per step CANDIDATE (the sequence t_0 = t, t_{i+1} = t_i + dt(t_i)
@@ -225,17 +237,18 @@ struct MortonLut {       // expand_bits10 of every coordinate < H tabulated in L
   }
 };
 
-template <bool kSingle = false, class Emit, class Advance, class Morton = MortonCalc>
+template <bool kSingle = false, bool kConstDt = false, class Emit, class Advance, class Morton = MortonCalc>
 __device__ __forceinline__ int march_ray(const MarchParams& P, const Ray& r, float t, float far,
                                          int max_emit, Emit&& emit, Advance&& advance, Morton morton = Morton()) {
   int n = 0;
   float last_t = t;
+  const StepRule<kConstDt> step(P);
   const float mb1 = fminf(ldexpf(1.0f, 0), P.bound), rmb1 = 1.0f / mb1;
   while (t < far && n < max_emit) {
     const float px = clampf(r.ox + t * r.dx, -P.bound, P.bound);
     const float py = clampf(r.oy + t * r.dy, -P.bound, P.bound);
     const float pz = clampf(r.oz + t * r.dz, -P.bound, P.bound);
-    const float dt = step_dt(P, t);
+    const float dt = step(P, t);
     int level = 0;
     float mb = mb1, rmb = rmb1;
     if constexpr (!kSingle) {
@@ -267,7 +280,7 @@ __device__ __forceinline__ int march_ray(const MarchParams& P, const Ray& r, flo
       const float cz = (((az * P.rH) * 2.0f - 1.0f) * mb - pz) * r.rdz;
       const float tt = t + fmaxf(0.0f, fminf(cx, fminf(cy, cz)));
       do {
-        t = t + step_dt(P, t);
+        t = t + step(P, t);
         advance();
       } while (t < tt);
     }
@@ -277,14 +290,18 @@ __device__ __forceinline__ int march_ray(const MarchParams& P, const Ray& r, flo
 template <class Emit>
 __device__ __forceinline__ int march_ray(const MarchParams& P, const Ray& r, float t, float far,
                                          int max_emit, Emit&& emit) {
-  return march_ray<false>(P, r, t, far, max_emit, emit, [] {});
+  return P.dt_gamma == 0.0f ? march_ray<false, true>(P, r, t, far, max_emit, emit, [] {})
+                            : march_ray<false, false>(P, r, t, far, max_emit, emit, [] {});
 }
 // run-time dispatch on the cascade count (wave-uniform)
 template <class Emit, class Advance, class Morton>
 __device__ __forceinline__ int march_ray_any(const MarchParams& P, const Ray& r, float t, float far,
                                              int max_emit, Emit&& emit, Advance&& advance, Morton morton) {
-  return P.C == 1 ? march_ray<true>(P, r, t, far, max_emit, emit, advance, morton)
-                  : march_ray<false>(P, r, t, far, max_emit, emit, advance, morton);
+  if (P.dt_gamma == 0.0f)
+    return P.C == 1 ? march_ray<true, true>(P, r, t, far, max_emit, emit, advance, morton)
+                    : march_ray<false, true>(P, r, t, far, max_emit, emit, advance, morton);
+  return P.C == 1 ? march_ray<true, false>(P, r, t, far, max_emit, emit, advance, morton)
+                  : march_ray<false, false>(P, r, t, far, max_emit, emit, advance, morton);
 }
 
 __device__ __forceinline__ float start_t(const MarchParams& P, float near, float noise) {
@@ -400,31 +417,51 @@ __global__ void __launch_bounds__(kRayBlock) k_finalize_offsets(const int32_t* _
 
 // Replays a ray from its candidate bit mask: emit(px,py,pz,dt,delta,t) with exactly the values the march produced
 // (same t accumulation, same clamp(o + t*d) and step_dt(t) operations).
-template <class Emit>
-__device__ __forceinline__ void replay_ray(const MarchParams& P, const Ray& r, const uint32_t* __restrict__ mask, int64_t N,
-                                           int64_t n, float t, int cnt, Emit&& emit) {
+template <bool kConstDt, class Emit>
+__device__ __forceinline__ void replay_ray_t(const MarchParams& P, const Ray& r, const uint32_t* __restrict__ mask, int64_t N,
+                                             int64_t n, float t, int cnt, Emit&& emit) {
+  const StepRule<kConstDt> step(P);
   // Candidate by candidate, all lanes in lockstep.  (Looping over the SAMPLES instead - every lane running its own
   // tight loop of additions up to its next set bit, the wave executing the emit body once per sample index - was
   // measured in round 2: 528 vs 332 us per frame.  The gaps between set bits do not line up across the rays of a
   // wave, and a divergent inner loop costs more than the emit bodies it saves.)
+  // Eight candidates per trip with constant bit positions (the loop control of a one-candidate trip was a dozen scalar
+  // instructions around seven vector ones), and a stretch in which NO ray of the wave has a sample - the rays of a wave
+  // are neighbours, their empty stretches mostly coincide - is eight bare additions.  A ray has exactly cnt set bits,
+  // so the zero bits behind its last sample only move a t nobody reads.
   float last_t = t;
   int emitted = 0;
   for (int w = 0; emitted < cnt; ++w) {
     const uint32_t bits = mask[(int64_t)w * N + n];
-    for (int b = 0; b < 32 && emitted < cnt; ++b) {
-      const float dt = step_dt(P, t);
-      const float tn = t + dt;
-      if ((bits >> b) & 1u) {
-        const float px = clampf(r.ox + t * r.dx, -P.bound, P.bound);
-        const float py = clampf(r.oy + t * r.dy, -P.bound, P.bound);
-        const float pz = clampf(r.oz + t * r.dz, -P.bound, P.bound);
-        emit(px, py, pz, dt, tn - last_t, t);
-        last_t = tn;
-        ++emitted;
+    for (int b0 = 0; b0 < 32; b0 += 8) {
+      const uint32_t sub = (bits >> b0) & 0xFFu;
+      if (__ballot(sub != 0u) == 0ull) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t = t + step(P, t);
+        continue;
       }
-      t = tn;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float dt = step(P, t);
+        const float tn = t + dt;
+        if (sub & (1u << j)) {
+          const float px = clampf(r.ox + t * r.dx, -P.bound, P.bound);
+          const float py = clampf(r.oy + t * r.dy, -P.bound, P.bound);
+          const float pz = clampf(r.oz + t * r.dz, -P.bound, P.bound);
+          emit(px, py, pz, dt, tn - last_t, t);
+          last_t = tn;
+          ++emitted;
+        }
+        t = tn;
+      }
     }
   }
+}
+template <class Emit>
+__device__ __forceinline__ void replay_ray(const MarchParams& P, const Ray& r, const uint32_t* __restrict__ mask, int64_t N,
+                                           int64_t n, float t, int cnt, Emit&& emit) {
+  if (P.dt_gamma == 0.0f) replay_ray_t<true>(P, r, mask, N, n, t, cnt, emit);     // wave-uniform
+  else replay_ray_t<false>(P, r, mask, N, n, t, cnt, emit);
 }
 
 // pass 4: write the samples into their slots (replay of the recorded samples, or a second march for rays
