@@ -1162,30 +1162,50 @@ __global__ void __launch_bounds__(kRayBlock) k_composite_patch_fwd(const float* 
   float T = 1.0f, r = 0, g = 0, b = 0, ws = 0, t = 0, dsum = 0;
   bool done = false;
   unsigned n_skip = 0;            // samples of steps at which every ray of the group is already below T_thresh
-  for (int k = 0; k < maxc; ++k) {
-    const bool active = k < cnt;
-    const unsigned long long m = __ballot(active);
-    const unsigned field = (unsigned)(m >> g0) & 0xFFFFu;
-    if (skippable) {              // (wave-uniform) what the early-terminating kernel would not have evaluated
-      const unsigned live = (unsigned)(__ballot(active && !done) >> g0) & 0xFFFFu;
-      if (rr == 0 && field != 0 && live == 0) n_skip += __popc(field);
+  // Eight steps per trip: the slots of steps k..k+7 depend on the counts only, so their 8 x 3 loads are requested
+  // together and the eight compositing updates then run in order - the same operations in the same order as a
+  // one-step loop (which waited for its loads once per step: 0.25 ms per frame, measured; this: see r02_NOTES 25).
+#ifndef INR_COMPOSITE_AHEAD
+#define INR_COMPOSITE_AHEAD 8
+#endif
+  constexpr int kAhead = INR_COMPOSITE_AHEAD;
+  for (int k = 0; k < maxc; k += kAhead) {
+    unsigned field[kAhead];
+    int64_t slot[kAhead];
+    bool active[kAhead];
+    float2 dl[kAhead];
+    float sg[kAhead], cr[kAhead], cg[kAhead], cb[kAhead];
+#pragma unroll
+    for (int j = 0; j < kAhead; ++j) {
+      active[j] = k + j < cnt;
+      field[j] = (unsigned)(__ballot(active[j]) >> g0) & 0xFFFFu;
+      slot[j] = (int64_t)S + __popc(field[j] & ((1u << rr) - 1u));
+      S += __popc(field[j]);
+      const int64_t i = (active[j] && !done) ? slot[j] : 0;      // a ray that is already opaque requests nothing new
+      dl[j] = reinterpret_cast<const float2*>(deltas)[i];
+      sg[j] = sigmas[i];
+      cr[j] = rgbs[i * 3]; cg[j] = rgbs[i * 3 + 1]; cb[j] = rgbs[i * 3 + 2];
     }
-    if (active && !done) {
-      const int64_t i = (int64_t)S + __popc(field & ((1u << rr) - 1u));
-      const float2 dl = reinterpret_cast<const float2*>(deltas)[i];
-      const float alpha = 1.0f - expf(-sigmas[i] * dl.x);
-      const float w = alpha * T;
-      r += w * rgbs[i * 3]; g += w * rgbs[i * 3 + 1]; b += w * rgbs[i * 3 + 2];
-      t += dl.y;
-      dsum += w * t;
-      ws += w;
-      if (wbuf) wbuf[i] = w;
-      T *= 1.0f - alpha;
-      if (T < T_thresh) done = true;
-    } else if (active && wbuf) {
-      wbuf[(int64_t)S + __popc(field & ((1u << rr) - 1u))] = 0.0f;     // behind the termination point
+#pragma unroll
+    for (int j = 0; j < kAhead; ++j) {
+      if (skippable) {            // (wave-uniform) what the early-terminating kernel would not have evaluated
+        const unsigned live = (unsigned)(__ballot(active[j] && !done) >> g0) & 0xFFFFu;
+        if (rr == 0 && field[j] != 0 && live == 0) n_skip += __popc(field[j]);
+      }
+      if (active[j] && !done) {
+        const float alpha = 1.0f - expf(-sg[j] * dl[j].x);
+        const float w = alpha * T;
+        r += w * cr[j]; g += w * cg[j]; b += w * cb[j];
+        t += dl[j].y;
+        dsum += w * t;
+        ws += w;
+        if (wbuf) wbuf[slot[j]] = w;
+        T *= 1.0f - alpha;
+        if (T < T_thresh) done = true;
+      } else if (active[j] && wbuf) {
+        wbuf[slot[j]] = 0.0f;                                    // behind the termination point
+      }
     }
-    S += __popc(field);
   }
   if (n < N) {
     weights_sum[rid] = ws; depth[rid] = dsum;
