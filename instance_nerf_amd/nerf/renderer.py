@@ -227,7 +227,7 @@ class NeRFRenderer(nn.Module):
                 results["instance"] = self.instance_render(xyzs, rays, wbuf).view(*prefix, -1)
             results["num_samples"] = counter
             results["num_evaluated"] = evaluated
-            skipped_frac = 1.0 - evaluated[0].float() / counter[0].float().clamp(min=1)
+            skipped_frac = (evaluated, int(xyzs.shape[0]), True)        # raw counter, marched total (host), "evaluated"
         elif not self.training and infer_mode in ("fused", "fused_terminate"):
             # full batch in four launches, patch-interleaved sample layout (csrc/raymarch.hip)
             counter = torch.zeros(2, dtype=torch.int32, device=device)
@@ -258,7 +258,7 @@ class NeRFRenderer(nn.Module):
                 if with_instance:
                     results["instance"] = out[3][:, :self.num_instances].reshape(*prefix, -1)
             results["num_samples"] = counter
-            skipped_frac = skippable[0].float() / counter[0].float().clamp(min=1)
+            skipped_frac = (skippable, int(xyzs.shape[0]), False)       # raw counter, marched total (host), "skippable"
         elif self.training or infer_mode == "fused_raymajor":
             if self.training:
                 counter = self.step_counter[self.local_step % 16]
@@ -313,7 +313,7 @@ class NeRFRenderer(nn.Module):
             raise ValueError(f"unknown infer_mode {infer_mode!r}")
 
         if not self.training and skipped_frac is not None:
-            self._note_skippable(skipped_frac)
+            self._note_skippable(*skipped_frac)
         # Depth.  Upstream's training compositing counts t from the ray's first step, its inference compositing uses
         # the absolute ray parameter (SURVEY Appendix A.1 "Inference loop").  The one-pass inference modes composite
         # like the training kernel, so they add the start parameter back: sum w (t0 + t_rel) = depth + t0 * sum w.
@@ -359,29 +359,34 @@ class NeRFRenderer(nn.Module):
     # has completed: no call waits for a previous frame.
     terminate_above = 0.35
 
-    def _note_skippable(self, frac):
-        if not frac.is_cuda:
-            self._skippable_value = float(frac)
+    def _note_skippable(self, counter, total, counts_evaluated):
+        """counter: the device counter of the frame (samples skippable / samples evaluated); total: marched samples, known
+        on the host.  The raw 8-byte counter is copied to a pinned scalar and divided on the host once it has landed (the
+        fraction used to be formed by four tiny device kernels per frame)."""
+        if not counter.is_cuda:
+            v = float(counter.reshape(-1)[0]) / max(total, 1)
+            self._skippable_value = 1.0 - v if counts_evaluated else v
             return
         d = self.__dict__
         if "_skippable_free" not in d:             # four pinned scalars, allocated once
-            d["_skippable_free"] = [torch.empty((), dtype=torch.float32, pin_memory=True) for _ in range(4)]
+            d["_skippable_free"] = [torch.empty(1, dtype=torch.int64, pin_memory=True) for _ in range(4)]
             d["_skippable_pending"] = []
         self._recent_skippable()                   # recycles the slots whose copies have landed
         if not d["_skippable_free"]:
             return                                 # four samples still in flight: skip this one
         host = d["_skippable_free"].pop()
-        host.copy_(frac.reshape(()), non_blocking=True)
+        host.copy_(counter.reshape(-1)[:1].view(torch.int64), non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        d["_skippable_pending"].append((ev, host))
+        d["_skippable_pending"].append((ev, host, total, counts_evaluated))
 
     def _recent_skippable(self):
         d = self.__dict__
         pending = d.get("_skippable_pending", [])
         while pending and pending[0][0].query():
-            _, host = pending.pop(0)
-            d["_skippable_value"] = float(host)
+            _, host, total, counts_evaluated = pending.pop(0)
+            v = float(int(host[0])) / max(total, 1)
+            d["_skippable_value"] = 1.0 - v if counts_evaluated else v
             d["_skippable_free"].append(host)
         return d.get("_skippable_value", 0.0)
 
