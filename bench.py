@@ -307,11 +307,11 @@ def main():
     ev_pairs = []
 
     def timed(fn):
-        def wrapper(x, *rest):
+        def wrapper(x, *rest, **kw):
             st = torch.cuda.current_stream()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(st)
-            out = fn(x, *rest)
+            out = fn(x, *rest, **kw)
             e1.record(st)
             ev_pairs.append((e0, e1, x.shape[0]))
             return out

@@ -312,18 +312,27 @@ class NeRFNetwork(NeRFRenderer):
         return sigma, rgb, geo
 
     @torch.no_grad()
-    def forward_table(self, x01, ray_ids, rays_d):
+    def sh_table(self, rays_d):
+        """Per-ray direction table [N,16] of ``forward_table`` (degree-4 SH in the lane order of the fused kernel)."""
+        lib = _lib.load()
+        rays_d = rays_d.contiguous().float().view(-1, 3)
+        shq = torch.empty(rays_d.shape[0], 16, dtype=torch.float32, device=rays_d.device)
+        check(lib.inr_sh_table_q(ptr(rays_d, torch.float32, "rays_d"), rays_d.shape[0], ptr(shq), stream_ptr()),
+              "sh_table_q")
+        return shq
+
+    def forward_table(self, x01, ray_ids, rays_d, shq=None):
         """forward() for the fused frame path: x01 [M,3] normalised samples and ray_ids int32 [M] from
         ``march_rays_patch(table=True)``, rays_d [N,3].  The direction encoding is evaluated once per RAY into a
-        table; results equal ``forward(x, rays_d[ray_ids])``.  None when the fused kernel does not apply."""
+        table (``shq``: that table when the caller has already built it); results equal
+        ``forward(x, rays_d[ray_ids])``.  None when the fused kernel does not apply."""
         if not self._fusable:
             return None
         lib = _lib.load()
-        rays_d = rays_d.contiguous().float().view(-1, 3)
-        N, M = rays_d.shape[0], x01.shape[0]
+        M = x01.shape[0]
         dev = x01.device
-        shq = torch.empty(N, 16, dtype=torch.float32, device=dev)
-        check(lib.inr_sh_table_q(ptr(rays_d, torch.float32, "rays_d"), N, ptr(shq), stream_ptr()), "sh_table_q")
+        if shq is None:
+            shq = self.sh_table(rays_d)
         sigma = torch.empty(M, dtype=torch.float32, device=dev)
         rgb = torch.empty(M, 3, dtype=torch.float32, device=dev)
         check(lib.inr_nerf_forward_table(ptr(x01, torch.float32, "x01", allow_none=M == 0),

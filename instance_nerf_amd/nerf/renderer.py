@@ -234,17 +234,26 @@ class NeRFRenderer(nn.Module):
             # when the samples are consumed by the fused kernels only (NeRF field, fused instance render) the writer
             # emits normalised coordinates + ray ids and the field reads a per-ray direction table (forward_table)
             table = (fused_inst or not with_instance) and getattr(self, "_fusable", False) and hasattr(self, "forward_table")
+            # the direction table and the counter of the compositing kernel do not depend on the sample count: they
+            # are queued behind the count pass and run while the host waits for the count and prepares the write pass
+            early = {}
+
+            def while_waiting():
+                early["skippable"] = torch.zeros(1, dtype=torch.int64, device=device)
+                if table and hasattr(self, "sh_table"):
+                    early["shq"] = self.sh_table(rays_d)
             xyzs, dirs, deltas, rays = raymarching.march_rays_patch(
                 rays_o, rays_d, self.bound, self.density_bitfield, self.cascade, self.grid_size, nears, fars,
-                dt_gamma, max_steps, noises=noises if perturb else None, counter=counter, table=table)
+                dt_gamma, max_steps, noises=noises if perturb else None, counter=counter, table=table,
+                while_waiting=while_waiting)
             if field_gate is not None:
                 field_gate.acquire()
-            sigmas, rgbs = self.forward_table(xyzs, dirs, rays_d) if table else self(xyzs, dirs)
+            sigmas, rgbs = self.forward_table(xyzs, dirs, rays_d, shq=early.get("shq")) if table else self(xyzs, dirs)
             if field_gate is not None:
                 field_gate.release()
             if self.density_scale != 1:
                 sigmas = self.density_scale * sigmas
-            skippable = torch.zeros(1, dtype=torch.int64, device=device)
+            skippable = early["skippable"]
             if fused_inst:
                 # weights first, then the instance field accumulates w * logits on chip (no [M, K] round trip)
                 weights_sum, depth, image, wbuf = raymarching.composite_rays_patch(sigmas, rgbs, deltas, rays, T_thresh,

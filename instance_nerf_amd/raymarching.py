@@ -151,8 +151,28 @@ def march_rays_train(rays_o, rays_d, bound, density_bitfield, C, H, nears, fars,
 GROUP = 16   # rays per group of the patch-interleaved layout (csrc/raymarch.hip::kGroup)
 
 
+_PINNED_COUNT = {}
+
+
+def _read_count(counter, while_waiting=None):
+    """counter[0] on the host.  The copy goes to a pinned buffer without blocking; ``while_waiting()`` may queue work
+    that does not depend on the count behind it (it runs on the GPU while the host waits for the copy and then
+    prepares the next launches - the one bubble of a frame), then the host waits for the copy alone."""
+    key = counter.device.index
+    host = _PINNED_COUNT.get(key)
+    if host is None:
+        host = _PINNED_COUNT[key] = torch.empty(2, dtype=I32, pin_memory=True)
+    host.copy_(counter[:2], non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    if while_waiting is not None:
+        while_waiting()
+    ev.synchronize()
+    return int(host[0])
+
+
 def march_rays_patch(rays_o, rays_d, bound, density_bitfield, C, H, nears, fars, dt_gamma=0, max_steps=1024,
-                     noises=None, counter=None, table=False):
+                     noises=None, counter=None, table=False, while_waiting=None):
     """Full-frame inference march in the PATCH-INTERLEAVED layout (no upstream counterpart; it
     replaces the alive-ray loop).  Rays are grouped 16 at a time in the order given; inside a group
     all k-th samples are adjacent:  slot(r,k) = rays[g0,1] + sum_i min(c_i,k) + #{i<r: c_i>k}.
@@ -162,6 +182,7 @@ def march_rays_patch(rays_o, rays_d, bound, density_bitfield, C, H, nears, fars,
 
     ``table=True`` is the feed of ``NeRFNetwork.forward_table``: xyzs come back NORMALISED,
     (p + bound) / (2 bound), and the second result is the int32 ray id of every sample instead of its direction.
+    ``while_waiting``: called once the count pass and the read-back of M are queued (see ``_read_count``).
     """
     lib = _lib.load()
     rays_o, rays_d = _f(rays_o).view(-1, 3), _f(rays_d).view(-1, 3)
@@ -180,7 +201,7 @@ def march_rays_patch(rays_o, rays_d, bound, density_bitfield, C, H, nears, fars,
                                          ptr(noises, F32, "noises", allow_none=True), ptr(rays),
                                          ptr(counter, I32, "counter"), ptr(ws), cap, stream_ptr()),
           "march_rays_train_count")
-    M = int(counter[0].item())
+    M = _read_count(counter, while_waiting)
     xyzs = torch.empty(M, 3, dtype=F32, device=dev)       # every row is written: no memset needed
     dirs = None if table else torch.empty(M, 3, dtype=F32, device=dev)
     ray_ids = torch.empty(M, dtype=I32, device=dev) if table else None
