@@ -1240,6 +1240,14 @@ __global__ void __launch_bounds__(kFieldThreads, INR_FIELD_MIN_WAVES) k_nerf_ren
     for (int ks = 0; ks < 4; ++ks) cin0[ks] = select4(q, sh[4 * ks], sh[4 * ks + 1], sh[4 * ks + 2], sh[4 * ks + 3]);
     float T = 1.0f, cr = 0.f, cg = 0.f, cb = 0.f, ws = 0.f, tt = 0.f, dsum = 0.f;   // meaningful in lanes q == 0
     bool done = false;
+    // the slot of a step depends on the counts only: the coordinates of step k + 1 are requested while step k is
+    // evaluated (they stream from HBM; a step used to start with that round trip)
+    float xn0 = 0.f, xn1 = 0.f, xn2 = 0.f;
+    if (fits && gtot > 0) {
+      const unsigned f0 = (unsigned)(__ballot(0 < cnt) & 0xFFFFull);
+      const int64_t m0 = ((f0 >> j) & 1u) ? S + __popc(f0 & ((1u << j) - 1u)) : 0;
+      xn0 = x[m0 * 3 + 0]; xn1 = x[m0 * 3 + 1]; xn2 = x[m0 * 3 + 2];
+    }
     for (int k = 0; fits; ++k) {
       const unsigned long long bal = __ballot(k < cnt);
       const unsigned field = (unsigned)(bal & 0xFFFFull);
@@ -1249,13 +1257,23 @@ __global__ void __launch_bounds__(kFieldThreads, INR_FIELD_MIN_WAVES) k_nerf_ren
       const bool active = (field >> j) & 1u, live = (livef >> j) & 1u;
       const int64_t slot = S + __popc(field & ((1u << j) - 1u));
       S += __popc(field);
+      const float xr0 = xn0, xr1 = xn1, xr2 = xn2;
+      {
+        // only while a ray of the group is alive (alive at k + 1 implies alive at k): an opaque group must not stream
+        // the coordinates of the samples it skips
+        const unsigned fn = livef != 0 ? (unsigned)(__ballot(k + 1 < cnt) & 0xFFFFull) : 0u;
+        if (fn != 0) {
+          const int64_t mn = ((fn >> j) & 1u) ? S + __popc(fn & ((1u << j) - 1u)) : 0;
+          xn0 = x[mn * 3 + 0]; xn1 = x[mn * 3 + 1]; xn2 = x[mn * 3 + 2];
+        }
+      }
       if (livef == 0) {                                   // every remaining ray of the group is opaque
         if (wbuf && active && q == 0) wbuf[slot] = 0.0f;
         continue;
       }
       if (lane == 0) n_eval += __popc(livef);
-      const int64_t m = live ? slot : (active ? slot : 0);
-      const float x0 = (x[m * 3 + 0] + bound) / rb, x1 = (x[m * 3 + 1] + bound) / rb, x2 = (x[m * 3 + 2] + bound) / rb;
+      const float2 dl = (q == 0 && live) ? reinterpret_cast<const float2*>(deltas)[slot] : make_float2(0.f, 0.f);
+      const float x0 = (xr0 + bound) / rb, x1 = (xr1 + bound) / rb, x2 = (xr2 + bound) / rb;
       f32x4 enc[2];
       {
         Gathered g;
@@ -1284,7 +1302,6 @@ __global__ void __launch_bounds__(kFieldThreads, INR_FIELD_MIN_WAVES) k_nerf_ren
       if (q == 0 && active) {
         float w = 0.0f;
         if (live) {
-          const float2 dl = reinterpret_cast<const float2*>(deltas)[slot];
           const float sg = __expf(h2[0][0]) * density_scale;
           const float alpha = 1.0f - expf(-sg * dl.x);
           w = alpha * T;
