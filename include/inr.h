@@ -316,7 +316,8 @@ int inr_roi_align_3d_backward(const float* grad_out, const float* rois, const in
 int inr_nerf_render(const float* xyzs, const float* deltas, const int32_t* rays, const float* rays_d /*[N,3]*/,
                     int64_t N, int64_t M, float bound, const float* embeddings, const inr_grid_desc* desc /*host*/,
                     const float* packed /*device*/, float density_scale, float T_thresh, float* weights_sum,
-                    float* depth, float* image, float* weights, uint64_t* evaluated, inr_stream_t s);
+                    float* depth, float* image, float* weights, uint64_t* evaluated, int32_t x_is_01 /* xyzs are the
+                    normalised coordinates of the patch writer's table feed */, inr_stream_t s);
 
 /* Instance logits rendered in place (inference, patch-interleaved layout): extra_out[ray][ch] =
  * sum_k weights[slot(ray,k)] * logits(xyzs[slot(ray,k)])[ch]; the [M,K] logits never exist in memory.

@@ -89,7 +89,7 @@ _SIGS = {
     "inr_roi_align_3d_backward": (c_int32, [P, P, P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int64, c_int32,
                                             c_int32, c_int32, c_float, P, P]),
     "inr_nerf_render": (c_int32, [P, P, P, P, c_int64, c_int64, c_float, P, POINTER(GridDesc), P, c_float, c_float,
-                                  P, P, P, P, P, P]),
+                                  P, P, P, P, P, c_int32, P]),
     "inr_instance_render": (c_int32, [P, P, P, c_int64, c_int64, c_float, P, POINTER(GridDesc), P, c_int32, P, c_int32, P]),
     "inr_linear_wgrad_workspace_bytes": (c_int64, []),
     "inr_linear_wgrad": (c_int32, [P, P, c_int64, c_int32, c_int32, P, P, P]),

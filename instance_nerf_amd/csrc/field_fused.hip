@@ -1207,7 +1207,7 @@ __global__ void __launch_bounds__(kFieldThreads, INR_FIELD_MIN_WAVES) k_nerf_ren
     const float* __restrict__ rays_d, int64_t N, int64_t M, float bound, const float2* __restrict__ emb,
     uint32_t emb_bytes, GridDesc G, const float4* __restrict__ packed, float density_scale, float T_thresh,
     float* __restrict__ weights_sum, float* __restrict__ depth, float* __restrict__ image, float* __restrict__ wbuf,
-    unsigned long long* __restrict__ evaluated) {
+    unsigned long long* __restrict__ evaluated, int x_is_01) {
   extern __shared__ __attribute__((aligned(16))) float4 wl[];
   constexpr int kStage = kNerfFloats / 4;
   for (int i = threadIdx.x; i < kStage; i += kFieldThreads) wl[i] = packed[i];
@@ -1218,6 +1218,7 @@ __global__ void __launch_bounds__(kFieldThreads, INR_FIELD_MIN_WAVES) k_nerf_ren
   constexpr int kWaves = kFieldThreads / 64;
   const int lane = threadIdx.x & 63, q = lane >> 4, j = lane & 15;
   const float rb = 2.0f * bound;
+  const float x_add = x_is_01 ? 0.0f : bound, x_div = x_is_01 ? 1.0f : rb;   // table feed: already normalised
   const TileSched sched = make_group_sched(rays, N, kWaves, threadIdx.x >> 6);
   const bool all_hashed[4] = {slot_all_hashed(G, 0), slot_all_hashed(G, 1), slot_all_hashed(G, 2), slot_all_hashed(G, 3)};
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)emb, 0, (int)emb_bytes, 0x00020000);
@@ -1268,12 +1269,13 @@ __global__ void __launch_bounds__(kFieldThreads, INR_FIELD_MIN_WAVES) k_nerf_ren
         }
       }
       if (livef == 0) {                                   // every remaining ray of the group is opaque
-        if (wbuf && active && q == 0) wbuf[slot] = 0.0f;
+        if (!wbuf) break;                                 // nothing left to do for this group
+        if (active && q == 0) wbuf[slot] = 0.0f;          // the instance render reads a weight for every sample
         continue;
       }
       if (lane == 0) n_eval += __popc(livef);
       const float2 dl = (q == 0 && live) ? reinterpret_cast<const float2*>(deltas)[slot] : make_float2(0.f, 0.f);
-      const float x0 = (xr0 + bound) / rb, x1 = (xr1 + bound) / rb, x2 = (xr2 + bound) / rb;
+      const float x0 = (xr0 + x_add) / x_div, x1 = (xr1 + x_add) / x_div, x2 = (xr2 + x_add) / x_div;
       f32x4 enc[2];
       {
         Gathered g;
@@ -1724,7 +1726,7 @@ int inr_instance_render(const float* xyzs, const int32_t* rays, const float* wei
 int inr_nerf_render(const float* xyzs, const float* deltas, const int32_t* rays, const float* rays_d, int64_t N,
                     int64_t M, float bound, const float* embeddings, const inr_grid_desc* desc, const float* packed,
                     float density_scale, float T_thresh, float* weights_sum, float* depth, float* image, float* weights,
-                    uint64_t* evaluated, inr_stream_t s) {
+                    uint64_t* evaluated, int32_t x_is_01, inr_stream_t s) {
   INR_REQUIRE(N >= 0 && M >= 0 && desc, "bad argument");
   if (N == 0) return INR_OK;
   INR_REQUIRE(rays && rays_d && embeddings && packed && weights_sum && depth && image, "null pointer");
@@ -1741,7 +1743,7 @@ int inr_nerf_render(const float* xyzs, const float* deltas, const int32_t* rays,
   k_nerf_render<<<grid_for(k_nerf_render, lds, n_groups), kFieldThreads, lds, as_stream(s)>>>(
       xyzs, deltas, rays, rays_d, N, M, bound, reinterpret_cast<const float2*>(embeddings), (uint32_t)emb_bytes64, G,
       reinterpret_cast<const float4*>(packed), density_scale, T_thresh, weights_sum, depth, image, weights,
-      reinterpret_cast<unsigned long long*>(evaluated));
+      reinterpret_cast<unsigned long long*>(evaluated), x_is_01);
   return check_launch("nerf_render");
 }
 

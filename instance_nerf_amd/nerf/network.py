@@ -444,7 +444,7 @@ class NeRFNetwork(NeRFRenderer):
         return _run_mlp(self.instance_net, self.instance_encoder(x, bound=self.bound))
 
     @torch.no_grad()
-    def nerf_render(self, xyzs, deltas, rays, rays_d, T_thresh=1e-4, want_weights=False):
+    def nerf_render(self, xyzs, deltas, rays, rays_d, T_thresh=1e-4, want_weights=False, normalised=False):
         """Field + compositing with early termination in one launch (inference, patch-interleaved layout).
         -> (weights_sum [N], depth [N], image [N,3], weights [M] | None, evaluated int64[1]); None if not fusable."""
         if not self._fusable:
@@ -463,7 +463,7 @@ class NeRFNetwork(NeRFRenderer):
                                   ptr(self.encoder.embeddings.data, torch.float32), self.encoder.desc,
                                   ptr(self._packed_weights("nerf")), float(self.density_scale), float(T_thresh),
                                   ptr(ws), ptr(depth), ptr(image), ptr(wbuf, allow_none=True), ptr(evaluated),
-                                  stream_ptr()), "nerf_render")
+                                  1 if normalised else 0, stream_ptr()), "nerf_render")
         return ws, depth, image, wbuf, evaluated
 
     @torch.no_grad()

@@ -214,17 +214,19 @@ class NeRFRenderer(nn.Module):
                 and (fused_inst or not with_instance)):
             # ONE launch for field + compositing, with early termination per 16-ray group (opaque scenes)
             counter = torch.zeros(2, dtype=torch.int32, device=device)
-            xyzs, dirs, deltas, rays = raymarching.march_rays_patch(
+            # both consumers take the writer's normalised coordinates and look the direction up per ray: the table
+            # feed (x01 + ray id, 24 instead of 32 bytes written per sample)
+            xyzs, _, deltas, rays = raymarching.march_rays_patch(
                 rays_o, rays_d, self.bound, self.density_bitfield, self.cascade, self.grid_size, nears, fars,
-                dt_gamma, max_steps, noises=noises if perturb else None, counter=counter)
+                dt_gamma, max_steps, noises=noises if perturb else None, counter=counter, table=True)
             if field_gate is not None:
                 field_gate.acquire()
             weights_sum, depth, image, wbuf, evaluated = self.nerf_render(xyzs, deltas, rays, rays_d, T_thresh,
-                                                                          want_weights=with_instance)
+                                                                          want_weights=with_instance, normalised=True)
             if field_gate is not None:
                 field_gate.release()
             if with_instance:
-                results["instance"] = self.instance_render(xyzs, rays, wbuf).view(*prefix, -1)
+                results["instance"] = self.instance_render(xyzs, rays, wbuf, normalised=True).view(*prefix, -1)
             results["num_samples"] = counter
             results["num_evaluated"] = evaluated
             skipped_frac = (evaluated, int(xyzs.shape[0]), True)        # raw counter, marched total (host), "evaluated"
