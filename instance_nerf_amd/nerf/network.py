@@ -74,8 +74,10 @@ def _table_backward(lib, x, denc, desc, M, bound, g_emb, emb):
                            "overlapped table-gradient all-reduce; set INR_GRAD_OVERLAP=0")
     overlap = grad_sync.active() and L > 8 and emb.grad is None
     for lo, hi in (((8, L), (0, 8)) if overlap else ((0, L),)):
-        check(lib.inr_grid_encode_backward_levels(ptr(x), ptr(denc), None, desc, M, float(bound), ptr(g_emb), lo, hi,
-                                                  stream_ptr()), "grid_encode_backward")
+        if M:          # a batch without a single sample still takes part in the collectives below (zeros): every rank
+            #            must issue the same sequence of all-reduces or the job hangs
+            check(lib.inr_grid_encode_backward_levels(ptr(x), ptr(denc), None, desc, M, float(bound), ptr(g_emb), lo, hi,
+                                                      stream_ptr()), "grid_encode_backward")
         if overlap:
             grad_sync.reduce_async(g_emb[int(desc.offsets[lo]):int(desc.offsets[hi])])
     if overlap:
@@ -131,7 +133,8 @@ class _InstanceFieldFn(torch.autograd.Function):
         if M:
             check(lib.inr_instance_backward(ptr(g, f32, "grad_logits"), K, ptr(h1), ptr(h2), M, ptr(pb), ptr(dz2),
                                             ptr(dz1), ptr(denc), stream_ptr()), "instance_backward")
-            g_emb = _table_backward(lib, x, denc, ctx.desc, M, ctx.bound, g_emb, emb)      # first: its all-reduce can start
+        g_emb = _table_backward(lib, x, denc, ctx.desc, M, ctx.bound, g_emb, emb)          # first: its all-reduce can start
+        if M:
             ws = torch.empty(lib.inr_linear_wgrad_workspace_bytes() // 4, dtype=f32, device=dev)   # reused in stream order
             for xin, gy, n_in, n_out, out in ((h2, g, 64, K, gw2), (h1, dz2, 64, 64, gw1), (enc, dz1, 32, 64, gw0)):
                 check(lib.inr_linear_wgrad(ptr(xin), ptr(gy), M, n_in, n_out, ptr(out), ptr(ws), stream_ptr()),
@@ -198,7 +201,8 @@ class _NerfFieldFn(torch.autograd.Function):
             check(lib.inr_nerf_backward(ptr(g_sigma), ptr(g_rgb), ptr(rgb), ptr(so), ptr(h1), ptr(c1), ptr(c2), M, 1.0,
                                         ptr(pb), ptr(d_o), ptr(dz_c2), ptr(dz_c1), ptr(d_so), ptr(dz_h1), ptr(d_enc),
                                         stream_ptr()), "nerf_backward")
-            g_emb = _table_backward(lib, x, d_enc, ctx.desc, M, ctx.bound, g_emb, emb)
+        g_emb = _table_backward(lib, x, d_enc, ctx.desc, M, ctx.bound, g_emb, emb)
+        if M:
             wsp = torch.empty(lib.inr_linear_wgrad_workspace_bytes() // 4, dtype=f32, device=dev)
             for xin, gy, n_in, n_out, out in ((c2, d_o, 64, 4, gwc2), (c1, dz_c2, 64, 64, gwc1), (cin, dz_c1, 32, 64, gwc0),
                                               (h1, d_so, 64, 16, gws1), (enc, dz_h1, 32, 64, gws0)):
@@ -248,6 +252,12 @@ class NeRFNetwork(NeRFRenderer):
         if self.num_instances:
             self.instance_encoder, in_dim_inst = get_encoder(encoding, desired_resolution=2048 * bound)
             self.instance_net = _mlp(in_dim_inst, hidden_dim_instance, self.num_instances, num_layers_instance)
+        # row at which the overlapped gradient all-reduce splits a table (levels 8.. first, then 0..7: _table_backward);
+        # allreduce_gradients uses the same split for a rank whose backward never ran (a batch without samples)
+        for enc in (self.encoder, getattr(self, "instance_encoder", None)):
+            desc = getattr(enc, "desc", None)
+            if desc is not None and int(desc.num_levels) > 8:
+                enc.embeddings._inr_split_row = int(desc.offsets[8])
         self._fusable = (encoding == "hashgrid" and encoding_dir == "sphere_harmonics" and num_layers == 2
                          and hidden_dim == 64 and geo_feat_dim == 15 and num_layers_color == 3
                          and hidden_dim_color == 64 and self.in_dim == 32)

@@ -370,23 +370,36 @@ def allreduce_gradients(params, world_size, bucket_bytes=64 << 20):
     into one bucket."""
     if world_size <= 1:
         return
-    grads = [p.grad for p in params if p.grad is not None]
+    # Every rank must issue the SAME sequence of collectives whatever its batch looked like.  A rank whose rays all
+    # missed the volume has no gradient at all (or an autograd function that never ran): it contributes zeros, and a
+    # table it did not hand to the collective from inside its backward goes in the same two level ranges, in the same
+    # order, that the other ranks used there.
+    params = [p for p in params if p.requires_grad]
+    for p in params:
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+    grads = [p.grad for p in params]
     small = []
     handles = []
     for p in params:
         g = p.grad
-        if g is None:
-            continue
         e = grad_sync.early.get(p.data_ptr())
         if e is not None:
             if e != (g.data_ptr(), g.numel()):
                 raise RuntimeError("the table gradient was replaced while its all-reduce was in flight "
                                    "(INR_GRAD_OVERLAP=0 turns the early all-reduce off)")
             continue                    # its row ranges were handed to the collective during the backward
-        if g.numel() * 4 >= bucket_bytes // 4:
+        split = getattr(p, "_inr_split_row", 0)
+        if grad_sync.active() and split:
+            g = g if g.is_contiguous() else g.contiguous()
+            p.grad = g
+            handles.append(dist.all_reduce(g[split:], async_op=True))       # fine levels first, as in _table_backward
+            handles.append(dist.all_reduce(g[:split], async_op=True))
+        elif g.numel() * 4 >= bucket_bytes // 4:
             handles.append(dist.all_reduce(g, async_op=True))
         else:
             small.append(g)
+    grads = [p.grad for p in params]
     if small:
         flat = torch.cat([g.reshape(-1) for g in small])
         dist.all_reduce(flat)

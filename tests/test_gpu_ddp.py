@@ -179,3 +179,54 @@ def test_one_frame_over_two_ranks_equals_the_single_process_render():
             p.kill()
     assert len(res) == 2, [p.exitcode for p in procs]
     assert all(ok for _, ok, _ in res) and all(shape == (1, 5120, 3) for _, _, shape in res)
+
+
+def _miss_worker(rank, world, port, q, stage, overlap):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), INR_GRAD_OVERLAP="1" if overlap else "0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from instance_nerf_amd.nerf import utils
+    utils.grad_sync.enabled = overlap
+    room, net, tr = _make(stage, world, rank)
+    losses = []
+    for s in range(2):
+        b = _batch(room, stage, rank, s)
+        if rank == 1 and s == 1:                                  # every ray of this rank misses the volume this step
+            b["rays_o"] = torch.full_like(b["rays_o"], 5.0)
+            b["rays_d"] = torch.nn.functional.normalize(torch.ones_like(b["rays_d"]), dim=-1)
+        losses.append(float(tr.train_one_step(b)))
+        if rank == 1 and s == 1:
+            assert int(net.step_counter[(net.local_step - 1) % 16, 0]) == 0
+    q.put((rank, losses, _trained(net)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("stage,overlap", [("instance", True), ("nerf", True), ("instance", False)])
+def test_a_rank_whose_batch_misses_the_volume_keeps_the_collectives_in_step(stage, overlap):
+    """One rank draws a batch without a single sample: it has nothing to scatter (its backward functions have no
+    samples), the other rank hands its table gradient to the all-reduce in two level ranges from inside its backward.
+    Both must issue the same collectives - the job neither hangs nor diverges: the ranks stay replicas."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_miss_worker, args=(r, 2, port, q, stage, overlap)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = []
+    import queue as _q
+    import time as _t
+    deadline = _t.time() + 90
+    while len(res) < 2 and _t.time() < deadline:
+        try:
+            res.append(q.get(timeout=2))
+        except _q.Empty:
+            if any(p.exitcode not in (None, 0) for p in procs):
+                break
+    for p in procs:
+        p.join(20)
+        if p.is_alive():
+            p.kill()
+    assert len(res) == 2, ("hung or died", [p.exitcode for p in procs])
+    res = sorted(res, key=lambda r: r[0])
+    for k in res[0][2]:
+        assert (res[0][2][k] == res[1][2][k]).all(), k
