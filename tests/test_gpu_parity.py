@@ -14,6 +14,15 @@ from conftest import scene_rays
 
 pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+def _seeds(n):
+    """Seeds of a fuzz test: 0..n-1, or the range INR_FUZZ_SEEDS=lo:hi names (bug hunts beyond the committed set)."""
+    spec = os.environ.get("INR_FUZZ_SEEDS")
+    if spec:
+        lo, hi = (int(v) for v in spec.split(":"))
+        return range(lo, hi)
+    return range(n)
+
+
 DEV = "cuda:0"
 
 
@@ -137,7 +146,7 @@ def test_march_train_cascades_and_max_steps(rm, marcher):
         assert (d.cpu().numpy()[:ref["total"]] == ref["dirs"]).all()
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", _seeds(12))
 def test_march_fuzz_against_the_c_oracle(rm, seed):
     """Random configurations - cascades 1..3 (bound 1, 2, 4), grid 32..128, occupancy 0.5 %..60 %, constant and growing
     steps, max_steps 16..1024, rays from inside and outside the volume, axis-aligned directions (infinite
@@ -243,7 +252,7 @@ def test_grid_indices_bit_exact(level_table):
         assert ((got - want).abs() / want.clamp(min=1) < 0.2).float().mean() > 0.9
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", _seeds(8))
 def test_grid_encoder_fuzz_against_the_c_oracle(seed):
     """Random grid shapes - 2..16 levels, base resolution 4..32, 2^8..2^19 rows per hashed level, finest resolution
     64..4096, bound 1..4 (dense-only, mixed and hashed-only tables) - stand-alone encoder forward and table gradient
@@ -918,7 +927,7 @@ def test_generic_sampler_without_cuda_ray(params_k16, room, level_table):
     assert net.encoder.embeddings.grad.abs().sum() > 0 and net.color_net[2].weight.grad.abs().sum() > 0
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", _seeds(6))
 def test_composite_fuzz_against_the_c_oracle(rm, seed):
     """Random ray sets - empty rays, single-sample rays, rays that terminate early (large sigma), K = 0 / 16 / 64 extra
     channels, sample buffers smaller than the total (dropped rays) - training compositing forward against the scalar
@@ -948,7 +957,7 @@ def test_composite_fuzz_against_the_c_oracle(rm, seed):
         assert float(out[0][int(rays[-1, 0])]) == 0.0                          # the dropped ray composites to nothing
 
 
-@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("seed", _seeds(10))
 def test_render_fuzz_against_the_c_oracle(level_table, seed):
     """Whole renders on random set-ups - occupancy from empty to full, 1..700 rays (ragged 16-ray groups), K = 0 / 16 /
     48 / 64 instance logits, opaque and transparent densities, constant and growing steps, every inference mode and
