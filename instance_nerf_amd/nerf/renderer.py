@@ -578,3 +578,10 @@ class FramePipeline:
     def close(self):
         self.synchronize()
         raymarching.set_overlap_placement(False)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
