@@ -484,21 +484,39 @@ __device__ __forceinline__ void load_tile_in(const float* __restrict__ x, const 
 // (next tile's gathers issued before this tile's MLP, 168 VGPRs) was built and measured twice: it is
 // not faster (6.95 vs 6.81 ms at 8 waves/CU) because it enlarges the per-CU working set exactly like a
 // higher occupancy does - see grid_for() - so it was removed.
-// XCD-aware persistent schedule.  Workgroup b runs on XCD b % 8 (observed dispatch order; used
-// for speed only - any placement gives the same results).  The sample stream is ray-major and
-// rays are image-ordered, so a contiguous range of tiles is a compact region of space: XCD k takes
-// the k-th eighth of the tiles and its workgroups stride through it, which keeps each XCD's
-// private 4 MB L2 on one part of the hash table's working set instead of all of it.
+// Workgroup b runs on XCD b % 8 (observed dispatch order, confirmed with HW_REG_XCC_ID; used for speed only - any
+// placement gives the same results).  The sample stream is ray-major and rays are image-ordered, so a contiguous run of
+// tiles is a compact region of space: the waves of an XCD sweep such runs together, which keeps the XCD's private 4 MB L2
+// on one part of the hash table's working set instead of all of it.
 #ifndef INR_TILE_RUN
-#define INR_TILE_RUN 1
+#define INR_TILE_RUN 1          // profiling knob: runs of consecutive tiles per wave (contiguous split only)
 #endif
-// Tile schedule of one wave: iteration i -> tile.  Waves of an XCD cover its range in runs of
-// INR_TILE_RUN consecutive tiles (run length 1 = plain striding).
+// XCD-aware persistent schedule.  Every XCD gets the same number of tiles, but NOT one contiguous eighth of the stream
+// (rounds 1 and most of 2 did that): equal sample counts are not equal work - a tile costs what its region of the
+// scene costs in cache misses, and the frame is ray-ordered top to bottom - so the XCD with the expensive eighth set
+// the kernel's time while the others idled (field kernel 5.53 -> 5.18 ms for 37 M samples once the eighths were
+// interleaved, profiles/r02_NOTES.txt section 28).  The stream is cut into chunks of 2^kXcdChunkLog2 tiles dealt round
+// robin to the XCDs (a chunk is still a compact run of patches: the XCD's private L2 keeps its locality); what is left
+// after the last complete round of eight chunks is split into eighths as before, so the counts stay equal.  Launches
+// with fewer than four rounds (training batches: random rays, no regional structure) keep the contiguous split.
+#ifndef INR_XCD_CHUNK_LOG2
+#define INR_XCD_CHUNK_LOG2 10
+#endif
+constexpr int kXcdChunkLog2 = INR_XCD_CHUNK_LOG2;
 struct TileSched {
-  int64_t lo, hi;      // tile range of this wave's XCD
-  int64_t first;       // first tile of this wave's first run
-  int64_t stride;      // distance between the starts of consecutive runs of this wave
+  int64_t lo, hi;      // hi: one past the last tile this wave may take
+  int64_t first;       // first tile (contiguous split) or first XCD-local index (interleaved split)
+  int64_t stride;      // distance between consecutive tiles / local indices of this wave
+  int64_t main_local = 0, tail_base = 0;   // interleaved split: local indices below main_local map into the chunked part
+  uint32_t xcd = 0;
+  bool interleaved = false;
   __device__ __forceinline__ int64_t tile(int64_t i) const {
+    if (interleaved) {
+      const int64_t u = first + i * stride;
+      if (u < main_local)
+        return ((((u >> kXcdChunkLog2) << 3) + xcd) << kXcdChunkLog2) + (u & ((1 << kXcdChunkLog2) - 1));
+      return tail_base + (u - main_local);
+    }
     return first + (i / INR_TILE_RUN) * stride + (i % INR_TILE_RUN);
   }
 };
@@ -508,6 +526,19 @@ __device__ __forceinline__ TileSched make_sched(int64_t n_tiles, int waves_per_b
   TileSched s;
   if (nb % 8 == 0) {
     const int xcd = b & 7, local = b >> 3, per = nb >> 3;
+    const int64_t rounds = n_tiles >> (kXcdChunkLog2 + 3);
+    if (rounds >= 4 && INR_TILE_RUN == 1) {
+      const int64_t n_main = rounds << (kXcdChunkLog2 + 3), tail = n_tiles - n_main;
+      s.interleaved = true;
+      s.xcd = (uint32_t)xcd;
+      s.main_local = rounds << kXcdChunkLog2;
+      s.tail_base = n_main + tail * xcd / 8;
+      s.lo = 0;
+      s.hi = n_main + tail * (xcd + 1) / 8;
+      s.first = (int64_t)local * waves_per_block + w;
+      s.stride = (int64_t)per * waves_per_block;
+      return s;
+    }
     s.lo = n_tiles * xcd / 8;
     s.hi = n_tiles * (xcd + 1) / 8;
     s.first = s.lo + ((int64_t)local * waves_per_block + w) * INR_TILE_RUN;
@@ -523,16 +554,34 @@ __device__ __forceinline__ TileSched make_sched(int64_t n_tiles, int waves_per_b
 
 // Schedule over 16-ray GROUPS (kernels in which a wave or a workgroup owns a group for all its steps).  An eighth of
 // the groups is not an eighth of the work - the top rows of a frame see the ceiling, the middle rows the whole room -
-// so an XCD's contiguous range holds an eighth of the SAMPLES: range ends by binary search on the groups' slot bases
-// (rays[.][1] is the prefix sum of the counts).  units_per_block: waves (wave-owned groups) or 1 (workgroup-owned).
+// and an eighth of the SAMPLES is not either (regions differ in what a sample costs, see make_sched).  Variants, kept
+// for the record (profiles/r02_NOTES.txt 20, 28):
+//   0  XCD x takes the groups [n x/8, n (x+1)/8)                        terminate 9.4 ms (transparent bench scene)
+//   1  plain striding over the whole grid                                7.7
+//   2  contiguous range holding an eighth of the samples (binary search on the slot bases)   7.2; trained scene 18.2
+//   3  chunks of as many consecutive groups as an XCD has units, dealt round robin to the XCDs: neighbouring patches
+//      still share an L2, every XCD sees every region                   7.45; trained scene 17.0, opaque 0.97 vs 1.05,
+//      instance render 11.6 vs 12.2 ms - the default
+// units_per_block: waves (wave-owned groups) or 1 (workgroup-owned).
 #ifndef INR_RENDER_SCHED
-#define INR_RENDER_SCHED 2      // 0: eighth of the groups per XCD, 1: plain striding, 2: eighth of the samples per XCD
+#define INR_RENDER_SCHED 3
 #endif
 __device__ __forceinline__ TileSched make_group_sched(const int32_t* __restrict__ rays, int64_t N, int units_per_block,
                                                       int unit) {
   const int64_t n_groups = (N + 15) >> 4;
   const int nb = gridDim.x, b = blockIdx.x;
   TileSched s;
+  if (nb % 8 == 0 && INR_RENDER_SCHED == 3) {
+    // chunks of (units of one XCD) consecutive groups dealt round robin to the XCDs: neighbouring patches still share an
+    // L2, every XCD sees every region of the frame
+    const int xcd = b & 7, local = b >> 3, per = nb >> 3;
+    const int64_t U = (int64_t)per * units_per_block;
+    s.lo = 0;
+    s.hi = n_groups;
+    s.first = (int64_t)xcd * U + (int64_t)local * units_per_block + unit;
+    s.stride = 8 * U;
+    return s;
+  }
   if (nb % 8 == 0 && INR_RENDER_SCHED != 1) {
     const int xcd = b & 7, local = b >> 3, per = nb >> 3;
     if (INR_RENDER_SCHED == 0) {

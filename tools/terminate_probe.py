@@ -18,8 +18,11 @@ for scale, name in ((1.0, "transparent (random init, no ray terminates)"), (3000
             with torch.no_grad():
                 return net.render(r["rays_o"], r["rays_d"], bg_color=1, infer_mode=mode)
         frame(0); torch.cuda.synchronize()
+        import gc
+        gc.collect(); gc.disable()      # a gen-2 pass inside the loop (~50 ms here) once read as "12 ms per frame"
         t0 = time.perf_counter(); tot = 0; ev = 0
         for v in range(8):
             o = frame(v); tot += int(o["num_samples"][0]); ev += int(o["num_evaluated"][0]) if "num_evaluated" in o else int(o["num_samples"][0])
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 8
+        gc.enable()
         print(f"{name:45s} {mode:16s} {dt*1e3:7.2f} ms/frame  marched {tot/8/1e6:.1f} M  evaluated {ev/8/1e6:.1f} M  mean opacity {float(o['weights_sum'].mean()):.3f}")
