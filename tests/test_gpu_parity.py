@@ -1368,6 +1368,25 @@ def test_parameter_ema_inside_the_optimiser_launch():
         assert (sa - sb).abs().max() < 1e-6
 
 
+@pytest.mark.parametrize("M", [524288 - 16, 524288, 524288 + 1, 524288 + 16 * 7 + 3, 2 * 524288 + 16 * 1024 * 3 + 5,
+                               8 * 524288 + 16 * 8191 + 15])
+def test_interleaved_xcd_schedule_covers_every_tile_once(params_k16, M):
+    """From 32768 tiles on, the fused field kernels deal 1024-tile chunks of the tile stream round robin to the XCDs and
+    split what is left after the last complete round into eighths (field_fused.hip::make_sched).  Sizes around the
+    switch-over, with empty / tiny / ragged remainders: every sample is evaluated exactly once - the outputs equal the
+    evaluation in pieces that are too small for the interleaved schedule, bit for bit."""
+    net = _network(params_k16, K=0).eval()
+    g = torch.Generator(device=DEV).manual_seed(M)
+    x = torch.rand(M, 3, device=DEV, generator=g) * 1.9 - 0.95
+    d = torch.nn.functional.normalize(torch.randn(M, 3, device=DEV, generator=g), dim=-1)
+    with torch.no_grad():
+        s_all, c_all = net(x, d)
+        pieces = [net(x[a:a + 400000], d[a:a + 400000]) for a in range(0, M, 400000)]
+    assert torch.equal(s_all, torch.cat([p[0] for p in pieces]))
+    assert torch.equal(c_all, torch.cat([p[1] for p in pieces]))
+    assert torch.isfinite(s_all).all() and torch.isfinite(c_all).all()
+
+
 def test_auto_mode_follows_the_skippable_fraction(params_k16, room, room_bitfield):
     """infer_mode="auto": the fraction of marched samples that lie behind the point where their whole 16-ray group
     has terminated - counted by the compositing kernel of the two-kernel path, reported by the terminating kernel
