@@ -34,7 +34,10 @@
 extern "C" {
 #endif
 
-#define INR_ABI_VERSION 1
+/* Bumped whenever an existing prototype changes or an entry point is removed (round 2 changed four argument lists
+ * without a bump: a stale library or an external caller built against the old header was only rejected by accident).
+ * instance_nerf_amd/_lib.py refuses a library whose version differs from the one it was written against. */
+#define INR_ABI_VERSION 3
 #define INR_MAX_LEVELS 16
 
 enum {
@@ -68,6 +71,10 @@ int inr_device_info(int32_t device, int64_t* props);
  * request extra LDS per workgroup, which is how a launch tells the dispatcher to keep one field workgroup and a
  * bounded number of march workgroups per CU.  Results do not change; process-wide; off by default.                */
 int inr_set_overlap_placement(int32_t on);
+/* No upstream counterpart.  Which marcher inr_march_rays_train_count / _write use: -1 (default) by batch size
+ * (wave per ray up to 32768 rays, lane per ray above), 0 lane per ray, 1 wave per ray.  Both produce the same
+ * bits; the parity tests run both.  Process-wide.  (The library reads no environment variables.)                  */
+int inr_set_march_mode(int32_t mode);
 
 /* ---- rays: generation (replaces nerf/utils.py::get_rays) and ray/AABB (a2) -------------
  * poses [B,4,4] camera-to-world row-major; pixel `inds[k]` (flat j*W+i; NULL = 0..n-1) -> rays_o/rays_d [B,n,3]:

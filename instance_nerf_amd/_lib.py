@@ -28,6 +28,7 @@ _SIGS = {
     "inr_abi_version": (c_int32, []),
     "inr_last_error": (c_char_p, []),
     "inr_set_overlap_placement": (c_int32, [c_int32]),
+    "inr_set_march_mode": (c_int32, [c_int32]),
     "inr_device_info": (c_int32, [c_int32, POINTER(c_int64)]),
     "inr_get_rays": (c_int32, [P, c_int64, c_float, c_float, c_float, c_float, c_int32, P, c_int64, P, P, P]),
     "inr_near_far_from_aabb": (c_int32, [P, P, P, c_int64, c_float, P, P, P]),
@@ -97,6 +98,7 @@ _SIGS = {
 }
 EXPORTS = tuple(_SIGS)
 
+ABI_VERSION = 3          # include/inr.h INR_ABI_VERSION this binding was written against
 _lib = None
 
 
@@ -114,8 +116,9 @@ def load():
         fn = getattr(lib, name)         # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.inr_abi_version() != 1:
-        raise RuntimeError("libinr_hip.so ABI version mismatch")
+    if lib.inr_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"libinr_hip.so ABI version {lib.inr_abi_version()} != {ABI_VERSION} (include/inr.h "
+                           "INR_ABI_VERSION): rebuild with `python -m instance_nerf_amd.build --force`")
     _lib = lib
     return lib
 

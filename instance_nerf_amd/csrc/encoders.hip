@@ -492,12 +492,8 @@ int inr_grid_encode_backward_levels(const float* x, const float* grad_out, const
   INR_REQUIRE(((uintptr_t)grad_out & 7) == 0, "grad_out must be 8-byte aligned");
   if (M == 0) return INR_OK;
   INR_REQUIRE((uint64_t)desc->offsets[desc->num_levels] * 2ull < (1ull << 32), "table too large for 32-bit element offsets");
-  int l0 = level_lo, l1 = level_hi;
-  if (const char* e = getenv("INR_GRID_BWD_LEVELS")) {      // profiling knob "lo:hi": only levels lo..hi-1
-    if (sscanf(e, "%d:%d", &l0, &l1) != 2 || l0 < 0 || l1 > G.num_levels || l0 >= l1) { l0 = level_lo; l1 = level_hi; }
-  }
-  const dim3 grid(blocks_for(M * 4, 256), (unsigned)(l1 - l0));
-  k_grid_bwd<<<grid, 256, 0, as_stream(s)>>>(x, grad_out, order, G, M, bound, grad_embeddings, l0);
+  const dim3 grid(blocks_for(M * 4, 256), (unsigned)(level_hi - level_lo));
+  k_grid_bwd<<<grid, 256, 0, as_stream(s)>>>(x, grad_out, order, G, M, bound, grad_embeddings, level_lo);
   return check_launch("grid_encode_backward");
 }
 

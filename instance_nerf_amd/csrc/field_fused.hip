@@ -68,17 +68,7 @@ __device__ __forceinline__ f32x4 mfma4(const float4 a, const f32x4 b, f32x4 c) {
 }
 // ReLU as ONE integer max on the bit pattern (negative floats, -0 and negative NaNs are negative integers);
 // fmaxf() costs two v_max_f32 here because the compiler canonicalises MFMA outputs first.
-#ifndef INR_TRIM_RELU
-#define INR_TRIM_RELU 1
-#endif
-#ifndef INR_TRIM_EXP
-#define INR_TRIM_EXP 1
-#endif
-#if INR_TRIM_RELU
 __device__ __forceinline__ float relu1(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
-#else
-__device__ __forceinline__ float relu1(float x) { return fmaxf(x, 0.f); }
-#endif
 __device__ __forceinline__ f32x4 relu4(f32x4 v) {
   v[0] = relu1(v[0]); v[1] = relu1(v[1]); v[2] = relu1(v[2]); v[3] = relu1(v[3]);
   return v;
@@ -137,18 +127,10 @@ __device__ __forceinline__ bool slot_all_hashed(const GridDesc& G, int li) {
 
 typedef unsigned int u32x2 __attribute__((__vector_size__(2 * sizeof(unsigned int))));
 
-// Cache-policy bits of the gather loads (raw_buffer_load aux: 1 = sc0, 2 = nt, 16 = sc1), separately for the slots
-// that hold levels 0..7 (reused lines) and 8..15 (one 8-byte row used per 128-byte line).  Profiling knobs; see
-// DESIGN.md for the measured matrix.
-#ifndef INR_AUX_COARSE
-#define INR_AUX_COARSE 0
-#endif
-#ifndef INR_AUX_FINE
-#define INR_AUX_FINE 0
-#endif
-template <int kAux>
+// Default cache policy on the gathers (raw_buffer_load aux 0).  Measured and rejected in round 2:
+// nt on the fine levels 15.5 ms, sc1 9.25 ms, sc0 = default 6.07 ms per 37 M samples.
 __device__ __forceinline__ u32x2 gather_row(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off) {
-  return __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)byte_off, 0, kAux);
+  return __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)byte_off, 0, 0);
 }
 
 // Lane-paired gather for the FINE slots (levels 8..15).  Measured on MI355X (tools/micro/gather_bench.hip): the vector
@@ -190,12 +172,8 @@ struct Gathered {
 // of the 16 coarse loads have landed and each later fine level waits until at most 4 loads are outstanding.  The
 // kernel is throughput-bound (look-ups, VALU issue), not latency-bound, and fewer lines in flight per wave leave
 // more of the 32 KB L1 to the other seven waves of the CU.  (-1 = no wait.)
-#ifndef INR_WAIT_AFTER_COARSE
-#define INR_WAIT_AFTER_COARSE 8
-#endif
-#ifndef INR_WAIT_BETWEEN_FINE
-#define INR_WAIT_BETWEEN_FINE 4
-#endif
+constexpr int kWaitAfterCoarse = 8;
+constexpr int kWaitBetweenFine = 4;
 // s_waitcnt vmcnt(N) only (gfx9 encoding: vmcnt[3:0] | expcnt 7 << 4 | lgkmcnt 15 << 8 | vmcnt[5:4] << 14)
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -226,7 +204,7 @@ __device__ __forceinline__ void issue_gathers_impl(const LevelRec* __restrict__ 
     for (int k = 0; k < 8; ++k) {
       const uint32_t c = cx + (k & 1);
       const uint32_t idx = (h ? (c ^ yz[k >> 1]) : (c + yz[k >> 1])) & mask;
-      g.c[li][k] = gather_row<INR_AUX_COARSE>(rsrc, base + idx * 8u);
+      g.c[li][k] = gather_row(rsrc, base + idx * 8u);
     }
   }
 #pragma unroll
@@ -243,13 +221,13 @@ __device__ __forceinline__ void issue_gathers_impl(const LevelRec* __restrict__ 
     const uint32_t c = (uint32_t)px + side, cy = (uint32_t)py, cz = (uint32_t)pz;
     const uint32_t hy0 = cy * pa, hy1 = hy0 + pa;
     const uint32_t hz0 = cz * pb, hz1 = hz0 + pb;
-    if (i == 0) wait_vmcnt<INR_WAIT_AFTER_COARSE>();
-    else wait_vmcnt<INR_WAIT_BETWEEN_FINE>();
+    if (i == 0) wait_vmcnt<kWaitAfterCoarse>();
+    else wait_vmcnt<kWaitBetweenFine>();
     if constexpr (kFineHashed) {       // every fine level of both pairs is hashed: xor-only index maths
-      g.f[i][0] = gather_row<INR_AUX_FINE>(rsrc, base + ((c ^ (hy0 ^ hz0)) & mask) * 8u);
-      g.f[i][1] = gather_row<INR_AUX_FINE>(rsrc, base + ((c ^ (hy1 ^ hz0)) & mask) * 8u);
-      g.f[i][2] = gather_row<INR_AUX_FINE>(rsrc, base + ((c ^ (hy0 ^ hz1)) & mask) * 8u);
-      g.f[i][3] = gather_row<INR_AUX_FINE>(rsrc, base + ((c ^ (hy1 ^ hz1)) & mask) * 8u);
+      g.f[i][0] = gather_row(rsrc, base + ((c ^ (hy0 ^ hz0)) & mask) * 8u);
+      g.f[i][1] = gather_row(rsrc, base + ((c ^ (hy1 ^ hz0)) & mask) * 8u);
+      g.f[i][2] = gather_row(rsrc, base + ((c ^ (hy0 ^ hz1)) & mask) * 8u);
+      g.f[i][3] = gather_row(rsrc, base + ((c ^ (hy1 ^ hz1)) & mask) * 8u);
     } else {
       const bool h = rec->b.y != 0;
       const uint32_t yz[4] = {h ? (hy0 ^ hz0) : (hy0 + hz0), h ? (hy1 ^ hz0) : (hy1 + hz0),
@@ -257,7 +235,7 @@ __device__ __forceinline__ void issue_gathers_impl(const LevelRec* __restrict__ 
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const uint32_t idx = (h ? (c ^ yz[k]) : (c + yz[k])) & mask;
-        g.f[i][k] = gather_row<INR_AUX_FINE>(rsrc, base + idx * 8u);
+        g.f[i][k] = gather_row(rsrc, base + idx * 8u);
       }
     }
   }
@@ -488,9 +466,6 @@ __device__ __forceinline__ void load_tile_in(const float* __restrict__ x, const 
 // placement gives the same results).  The sample stream is ray-major and rays are image-ordered, so a contiguous run of
 // tiles is a compact region of space: the waves of an XCD sweep such runs together, which keeps the XCD's private 4 MB L2
 // on one part of the hash table's working set instead of all of it.
-#ifndef INR_TILE_RUN
-#define INR_TILE_RUN 1          // profiling knob: runs of consecutive tiles per wave (contiguous split only)
-#endif
 // XCD-aware persistent schedule.  Every XCD gets the same number of tiles, but NOT one contiguous eighth of the stream
 // (rounds 1 and most of 2 did that): equal sample counts are not equal work - a tile costs what its region of the
 // scene costs in cache misses, and the frame is ray-ordered top to bottom - so the XCD with the expensive eighth set
@@ -499,10 +474,7 @@ __device__ __forceinline__ void load_tile_in(const float* __restrict__ x, const 
 // robin to the XCDs (a chunk is still a compact run of patches: the XCD's private L2 keeps its locality); what is left
 // after the last complete round of eight chunks is split into eighths as before, so the counts stay equal.  Launches
 // with fewer than four rounds (training batches: random rays, no regional structure) keep the contiguous split.
-#ifndef INR_XCD_CHUNK_LOG2
-#define INR_XCD_CHUNK_LOG2 10
-#endif
-constexpr int kXcdChunkLog2 = INR_XCD_CHUNK_LOG2;
+constexpr int kXcdChunkLog2 = 10;
 struct TileSched {
   int64_t lo, hi;      // hi: one past the last tile this wave may take
   int64_t first;       // first tile (contiguous split) or first XCD-local index (interleaved split)
@@ -517,7 +489,7 @@ struct TileSched {
         return ((((u >> kXcdChunkLog2) << 3) + xcd) << kXcdChunkLog2) + (u & ((1 << kXcdChunkLog2) - 1));
       return tail_base + (u - main_local);
     }
-    return first + (i / INR_TILE_RUN) * stride + (i % INR_TILE_RUN);
+    return first + i * stride;
   }
 };
 __device__ __forceinline__ TileSched make_sched(int64_t n_tiles, int waves_per_block) {
@@ -527,7 +499,7 @@ __device__ __forceinline__ TileSched make_sched(int64_t n_tiles, int waves_per_b
   if (nb % 8 == 0) {
     const int xcd = b & 7, local = b >> 3, per = nb >> 3;
     const int64_t rounds = n_tiles >> (kXcdChunkLog2 + 3);
-    if (rounds >= 4 && INR_TILE_RUN == 1) {
+    if (rounds >= 4) {
       const int64_t n_main = rounds << (kXcdChunkLog2 + 3), tail = n_tiles - n_main;
       s.interleaved = true;
       s.xcd = (uint32_t)xcd;
@@ -541,83 +513,46 @@ __device__ __forceinline__ TileSched make_sched(int64_t n_tiles, int waves_per_b
     }
     s.lo = n_tiles * xcd / 8;
     s.hi = n_tiles * (xcd + 1) / 8;
-    s.first = s.lo + ((int64_t)local * waves_per_block + w) * INR_TILE_RUN;
-    s.stride = (int64_t)per * waves_per_block * INR_TILE_RUN;
+    s.first = s.lo + (int64_t)local * waves_per_block + w;
+    s.stride = (int64_t)per * waves_per_block;
   } else {
     s.lo = 0;
     s.hi = n_tiles;
-    s.first = ((int64_t)b * waves_per_block + w) * INR_TILE_RUN;
-    s.stride = (int64_t)nb * waves_per_block * INR_TILE_RUN;
+    s.first = (int64_t)b * waves_per_block + w;
+    s.stride = (int64_t)nb * waves_per_block;
   }
   return s;
 }
 
 // Schedule over 16-ray GROUPS (kernels in which a wave or a workgroup owns a group for all its steps).  An eighth of
 // the groups is not an eighth of the work - the top rows of a frame see the ceiling, the middle rows the whole room -
-// and an eighth of the SAMPLES is not either (regions differ in what a sample costs, see make_sched).  Variants, kept
-// for the record (profiles/r02_NOTES.txt 20, 28):
-//   0  XCD x takes the groups [n x/8, n (x+1)/8)                        terminate 9.4 ms (transparent bench scene)
-//   1  plain striding over the whole grid                                7.7
-//   2  contiguous range holding an eighth of the samples (binary search on the slot bases)   7.2; trained scene 18.2
-//   3  chunks of as many consecutive groups as an XCD has units, dealt round robin to the XCDs: neighbouring patches
-//      still share an L2, every XCD sees every region                   7.45; trained scene 17.0, opaque 0.97 vs 1.05,
-//      instance render 11.6 vs 12.2 ms - the default
+// and an eighth of the SAMPLES is not either (regions differ in what a sample costs, see make_sched).  Measured in
+// round 2 (profiles/r02_NOTES.txt 20, 28; terminate path, transparent bench scene): XCD x takes the groups
+// [n x/8, n (x+1)/8) 9.4 ms; plain striding over the whole grid 7.7; a contiguous range holding an eighth of the
+// samples 7.2 (trained scene 18.2); chunks of as many consecutive groups as an XCD has units, dealt round robin to the
+// XCDs - neighbouring patches still share an L2, every XCD sees every region - 7.45 (trained 17.0, opaque 0.97 vs 1.05,
+// instance render 11.6 vs 12.2 ms): the last one is what this does.
 // units_per_block: waves (wave-owned groups) or 1 (workgroup-owned).
-#ifndef INR_RENDER_SCHED
-#define INR_RENDER_SCHED 3
-#endif
-__device__ __forceinline__ TileSched make_group_sched(const int32_t* __restrict__ rays, int64_t N, int units_per_block,
-                                                      int unit) {
+__device__ __forceinline__ TileSched make_group_sched(int64_t N, int units_per_block, int unit) {
   const int64_t n_groups = (N + 15) >> 4;
   const int nb = gridDim.x, b = blockIdx.x;
   TileSched s;
-  if (nb % 8 == 0 && INR_RENDER_SCHED == 3) {
-    // chunks of (units of one XCD) consecutive groups dealt round robin to the XCDs: neighbouring patches still share an
-    // L2, every XCD sees every region of the frame
+  s.lo = 0;
+  s.hi = n_groups;
+  if (nb % 8 == 0) {
     const int xcd = b & 7, local = b >> 3, per = nb >> 3;
     const int64_t U = (int64_t)per * units_per_block;
-    s.lo = 0;
-    s.hi = n_groups;
     s.first = (int64_t)xcd * U + (int64_t)local * units_per_block + unit;
     s.stride = 8 * U;
-    return s;
-  }
-  if (nb % 8 == 0 && INR_RENDER_SCHED != 1) {
-    const int xcd = b & 7, local = b >> 3, per = nb >> 3;
-    if (INR_RENDER_SCHED == 0) {
-      s.lo = n_groups * xcd / 8;
-      s.hi = n_groups * (xcd + 1) / 8;
-    } else {
-      const int64_t total = (int64_t)rays[(N - 1) * 3 + 1] + rays[(N - 1) * 3 + 2];
-      auto first_group_at = [&](int64_t target) {          // first group whose slot base is >= target
-        int64_t lo = 0, hi = n_groups;
-        while (lo < hi) {
-          const int64_t mid = (lo + hi) >> 1;
-          if ((int64_t)rays[mid * 16 * 3 + 1] < target) lo = mid + 1; else hi = mid;
-        }
-        return lo;
-      };
-      s.lo = xcd == 0 ? 0 : first_group_at(total * xcd / 8);
-      s.hi = xcd == 7 ? n_groups : first_group_at(total * (xcd + 1) / 8);
-    }
-    s.first = s.lo + (int64_t)local * units_per_block + unit;
-    s.stride = (int64_t)per * units_per_block;
   } else {
-    s.lo = 0;
-    s.hi = n_groups;
     s.first = (int64_t)b * units_per_block + unit;
     s.stride = (int64_t)nb * units_per_block;
   }
   return s;
 }
 
-#ifndef INR_FIELD_THREADS
-#define INR_FIELD_THREADS 512
-#endif
-#ifndef INR_FIELD_MIN_WAVES
-#define INR_FIELD_MIN_WAVES 2
-#endif
-constexpr int kFieldThreads = INR_FIELD_THREADS;   // waves of a workgroup share one 40 KB weight image in LDS
+constexpr int kFieldThreads = 512;     // waves of a workgroup share one 40 KB weight image in LDS
+constexpr int kFieldMinWaves = 2;      // __launch_bounds__ second argument: <= 128 VGPRs
 
 // kTable: fused-frame fast path - x is already normalised to [0,1] by the march writer and the direction
 // encoding comes from a per-ray SH table (shq[ray][q] = this lane's four components) via a per-sample ray id:
@@ -641,7 +576,7 @@ struct NerfSave {
 };
 
 template <bool kColor, bool kTable = false, bool kSave = false>
-__global__ void __launch_bounds__(kFieldThreads, INR_FIELD_MIN_WAVES) k_nerf_fwd(const float* __restrict__ x, const float* __restrict__ d,
+__global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_nerf_fwd(const float* __restrict__ x, const float* __restrict__ d,
                                                                int64_t M, const int32_t* __restrict__ n_dev, float bound,
                                                                const float2* __restrict__ emb, uint32_t emb_bytes, GridDesc G,
                                                                const float4* __restrict__ packed, float density_scale,
@@ -718,11 +653,7 @@ __global__ void __launch_bounds__(kFieldThreads, INR_FIELD_MIN_WAVES) k_nerf_fwd
     mlp_layer<1, 4>(wl + kSig1 / 4, lane, h1, h2);      // row 0 = raw density, rows 1..15 = geo features
 
     if (valid) {
-#if INR_TRIM_EXP
       if (q == 0) sigma[m] = __expf(h2[0][0]) * density_scale;
-#else
-      if (q == 0) sigma[m] = expf(h2[0][0]) * density_scale;
-#endif
       if (geo) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -772,15 +703,9 @@ __global__ void __launch_bounds__(kFieldThreads, INR_FIELD_MIN_WAVES) k_nerf_fwd
         }
       }
       if (valid && q == 0) {
-#if INR_TRIM_EXP
         rgb[m * 3 + 0] = __frcp_rn(1.0f + __expf(-o[0][0]));     // v_exp_f32 / v_rcp_f32: ~1e-7 relative
         rgb[m * 3 + 1] = __frcp_rn(1.0f + __expf(-o[0][1]));
         rgb[m * 3 + 2] = __frcp_rn(1.0f + __expf(-o[0][2]));
-#else
-        rgb[m * 3 + 0] = 1.0f / (1.0f + expf(-o[0][0]));
-        rgb[m * 3 + 1] = 1.0f / (1.0f + expf(-o[0][1]));
-        rgb[m * 3 + 2] = 1.0f / (1.0f + expf(-o[0][2]));
-#endif
       }
     }
   }
@@ -791,7 +716,7 @@ __global__ void __launch_bounds__(kFieldThreads, INR_FIELD_MIN_WAVES) k_nerf_fwd
 // sigma-net pass per point, then the colour net once per direction with the direction's SH row as a wave-uniform
 // operand (staged in LDS).  Replaces density() + D x color() through the unfused encoder / BLAS path.
 constexpr int kMaxExtractDirs = 8;
-__global__ void __launch_bounds__(kFieldThreads, INR_FIELD_MIN_WAVES) k_nerf_fwd_dirs(
+__global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_nerf_fwd_dirs(
     const float* __restrict__ x, int64_t M, float bound, const float2* __restrict__ emb, uint32_t emb_bytes, GridDesc G,
     const float4* __restrict__ packed, const float* __restrict__ sh_dirs /*[D,16]*/, int D, float4* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) float4 wl[];
@@ -858,7 +783,7 @@ __global__ void __launch_bounds__(kFieldThreads, INR_FIELD_MIN_WAVES) k_nerf_fwd
 // kSave (training): the encoder output and the two hidden activations are also written, row-major, for the
 // weight gradients and the ReLU masks of k_instance_bwd.
 template <int K_MT, bool kSave = false>
-__global__ void __launch_bounds__(kFieldThreads, INR_FIELD_MIN_WAVES) k_instance_fwd(const float* __restrict__ x, int64_t M,
+__global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_instance_fwd(const float* __restrict__ x, int64_t M,
                                                                    const int32_t* __restrict__ n_dev, float bound,
                                                                    const float2* __restrict__ emb, uint32_t emb_bytes,
                                                                    GridDesc G, const float4* __restrict__ packed,
@@ -939,7 +864,7 @@ constexpr int kBwd1 = kBwd2 + 64 * 64;
 constexpr int kBwd0 = kBwd1 + 64 * 64;
 constexpr int kBwdFloats = kBwd0 + 32 * 64;
 
-__global__ void __launch_bounds__(kFieldThreads, INR_FIELD_MIN_WAVES) k_instance_bwd(const float* __restrict__ dlogits, int K,
+__global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_instance_bwd(const float* __restrict__ dlogits, int K,
                                                                    const float* __restrict__ h1, const float* __restrict__ h2,
                                                                    int64_t M, const float4* __restrict__ packed,
                                                                    float* __restrict__ dz2, float* __restrict__ dz1,
@@ -1005,7 +930,7 @@ struct NerfBwdIO {
   float *d_o, *dz_c2, *dz_c1, *d_so, *dz_h1, *d_enc;           // outputs: [M,4] [M,64] [M,64] [M,16] [M,64] [M,32]
 };
 
-__global__ void __launch_bounds__(kFieldThreads, INR_FIELD_MIN_WAVES) k_nerf_bwd(NerfBwdIO io, int64_t M, float density_scale,
+__global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_nerf_bwd(NerfBwdIO io, int64_t M, float density_scale,
                                                                const float4* __restrict__ packed) {
   extern __shared__ __attribute__((aligned(16))) float4 wl[];
   for (int i = threadIdx.x; i < kNerfBwdFloats / 4; i += kFieldThreads) wl[i] = packed[i];
@@ -1141,7 +1066,7 @@ __global__ void __launch_bounds__(256) k_pack_weights(PackJobs jobs, float* __re
 // group has w == 0 (behind the termination point) skip the gather and the MLP.  x_is_01: the march writer already
 // normalised the coordinates (table feed).
 template <int K_MT>
-__global__ void __launch_bounds__(kFieldThreads, INR_FIELD_MIN_WAVES) k_instance_render(
+__global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_instance_render(
     const float* __restrict__ x, const int32_t* __restrict__ rays, const float* __restrict__ wbuf, int64_t N, int64_t M,
     float bound, const float2* __restrict__ emb, uint32_t emb_bytes, GridDesc G, const float4* __restrict__ packed,
     float* __restrict__ extra_out, int x_is_01) {
@@ -1159,7 +1084,7 @@ __global__ void __launch_bounds__(kFieldThreads, INR_FIELD_MIN_WAVES) k_instance
   const float rb = 2.0f * bound;
   const float x_add = x_is_01 ? 0.0f : bound, x_div = x_is_01 ? 1.0f : rb;
   // a WORKGROUP per group; the XCD's workgroups sweep its range side by side (neighbouring patches share the L2)
-  const TileSched sched = make_group_sched(rays, N, 1, 0);
+  const TileSched sched = make_group_sched(N, 1, 0);
   const int64_t g_first = sched.first, g_hi = sched.hi, g_stride = sched.stride;
   const bool all_hashed[4] = {slot_all_hashed(G, 0), slot_all_hashed(G, 1), slot_all_hashed(G, 2), slot_all_hashed(G, 3)};
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)emb, 0, (int)emb_bytes, 0x00020000);
@@ -1251,7 +1176,7 @@ __global__ void __launch_bounds__(kFieldThreads, INR_FIELD_MIN_WAVES) k_instance
 // This is what upstream's alive-ray loop buys on trained (opaque) scenes, without its per-iteration host sync.
 // On a transparent scene it evaluates exactly the samples of the two-kernel path.  weights (nullable) receives
 // w per sample (0 for skipped samples) for k_instance_render; evaluated[0] += samples actually evaluated.
-__global__ void __launch_bounds__(kFieldThreads, INR_FIELD_MIN_WAVES) k_nerf_render(
+__global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_nerf_render(
     const float* __restrict__ x, const float* __restrict__ deltas, const int32_t* __restrict__ rays,
     const float* __restrict__ rays_d, int64_t N, int64_t M, float bound, const float2* __restrict__ emb,
     uint32_t emb_bytes, GridDesc G, const float4* __restrict__ packed, float density_scale, float T_thresh,
@@ -1268,7 +1193,7 @@ __global__ void __launch_bounds__(kFieldThreads, INR_FIELD_MIN_WAVES) k_nerf_ren
   const int lane = threadIdx.x & 63, q = lane >> 4, j = lane & 15;
   const float rb = 2.0f * bound;
   const float x_add = x_is_01 ? 0.0f : bound, x_div = x_is_01 ? 1.0f : rb;   // table feed: already normalised
-  const TileSched sched = make_group_sched(rays, N, kWaves, threadIdx.x >> 6);
+  const TileSched sched = make_group_sched(N, kWaves, threadIdx.x >> 6);
   const bool all_hashed[4] = {slot_all_hashed(G, 0), slot_all_hashed(G, 1), slot_all_hashed(G, 2), slot_all_hashed(G, 3)};
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)emb, 0, (int)emb_bytes, 0x00020000);
   unsigned long long n_eval = 0;
@@ -1462,8 +1387,7 @@ static int grid_for(Kern kern, size_t lds_bytes, int64_t n_tiles) {
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, kern, kFieldThreads, lds_bytes) != hipSuccess || fit < 1) fit = 1;
     if (n_cached < 64) cache[n_cached++] = Entry{(const void*)kern, lds_bytes, fit};
   }
-  int per_cu = std::min(fit, kFieldBlocksPerCU);
-  if (const char* e = getenv("INR_FIELD_BLOCKS_PER_CU")) per_cu = std::max(1, std::min(fit, atoi(e)));   // profiling knob
+  const int per_cu = std::min(fit, kFieldBlocksPerCU);
   const int64_t want = (n_tiles + kFieldThreads / 64 - 1) / (kFieldThreads / 64);
   return (int)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)cus * per_cu));
 }

@@ -1165,10 +1165,7 @@ __global__ void __launch_bounds__(kRayBlock) k_composite_patch_fwd(const float* 
   // Eight steps per trip: the slots of steps k..k+7 depend on the counts only, so their 8 x 3 loads are requested
   // together and the eight compositing updates then run in order - the same operations in the same order as a
   // one-step loop (which waited for its loads once per step: 0.25 ms per frame, measured; this: see r02_NOTES 25).
-#ifndef INR_COMPOSITE_AHEAD
-#define INR_COMPOSITE_AHEAD 8
-#endif
-  constexpr int kAhead = INR_COMPOSITE_AHEAD;
+  constexpr int kAhead = 8;
   for (int k = 0; k < maxc; k += kAhead) {
     unsigned field[kAhead];
     int64_t slot[kAhead];
@@ -1398,12 +1395,17 @@ int inr_packbits_mean(const float* grid, int64_t n_cells, const double* mean_sum
 }
 
 // Small batches (training) take the wave-per-ray marcher; both marchers produce the same bits.
-// INR_MARCH_COOP=0/1 forces the choice (tests run both).
+// inr_set_march_mode() forces the choice (the parity tests run both); the library reads no environment variable.
+static int g_march_mode = -1;            // -1: by batch size, 0: lane per ray, 1: wave per ray
 static bool use_coop(int64_t N, int32_t sample_cap) {
   if (sample_cap > 0) return false;
-  const char* e = getenv("INR_MARCH_COOP");
-  if (e && *e) return atoi(e) != 0;
+  if (g_march_mode >= 0) return g_march_mode != 0;
   return N <= 32768;
+}
+int inr_set_march_mode(int32_t mode) {
+  INR_REQUIRE(mode >= -1 && mode <= 1, "mode must be -1 (automatic), 0 (lane per ray) or 1 (wave per ray)");
+  g_march_mode = mode;
+  return INR_OK;
 }
 
 static int64_t ws_ints(int64_t N) {

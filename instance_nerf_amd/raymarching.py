@@ -42,6 +42,13 @@ def set_overlap_placement(on):
     check(_lib.load().inr_set_overlap_placement(1 if on else 0), "set_overlap_placement")
 
 
+def set_march_mode(mode):
+    """Which training marcher runs: None / "auto" (by batch size), "lane_per_ray" or "wave_per_ray" - see
+    inr_set_march_mode in include/inr.h.  Both produce the same bits; process-wide."""
+    code = {None: -1, "auto": -1, "lane_per_ray": 0, "wave_per_ray": 1}[mode]
+    check(_lib.load().inr_set_march_mode(code), "set_march_mode")
+
+
 def near_far_from_aabb(rays_o, rays_d, aabb, min_near=0.2):
     """rays_o, rays_d [N,3]; aabb [6] -> nears, fars [N]."""
     lib = _lib.load()

@@ -62,7 +62,8 @@ def test_library_loads_and_exports_all_symbols():
         from instance_nerf_amd import build
         build.build(verbose=False)
     lib = _lib.load()
-    assert lib.inr_abi_version() == 1
+    header = open(os.path.join(ROOT, "include", "inr.h")).read()
+    assert lib.inr_abi_version() == _lib.ABI_VERSION == int(re.search(r"#define INR_ABI_VERSION (\d+)", header).group(1))
     for name in _declared():
         assert hasattr(lib, name), name
 

@@ -20,8 +20,10 @@ M = xyzs.shape[0]
 g = torch.randn(M, 32, device=dev)
 enc = net.instance_encoder
 gemb = torch.zeros_like(enc.embeddings.data)
+levels = [0, 16]
 def run():
-    check(lib.inr_grid_encode_backward_ordered(ptr(xyzs), ptr(g), None, enc.desc, M, 1.0, ptr(gemb), stream_ptr()), "bwd")
+    check(lib.inr_grid_encode_backward_levels(ptr(xyzs), ptr(g), None, enc.desc, M, 1.0, ptr(gemb), levels[0], levels[1],
+                                              stream_ptr()), "bwd")
 def timed(n=20):
     for _ in range(3): run()
     torch.cuda.synchronize()
@@ -33,5 +35,5 @@ def timed(n=20):
 print("M", M, "all levels", round(timed(), 1), "us")
 res = enc.table["resolutions"]
 for l in range(16):
-    os.environ["INR_GRID_BWD_LEVELS"] = f"{l}:{l+1}"
+    levels[:] = [l, l + 1]
     print(f"level {l:2d} res {int(res[l]):5d}: {timed():7.1f} us")
