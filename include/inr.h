@@ -182,12 +182,19 @@ int inr_compact_alive(const int32_t* rays_alive, int64_t n_alive, int32_t* out, 
  * M = rows of the sample arrays: a ray with offset + count > M was dropped by the march writer and
  * composites to zero (its gradient rows are left untouched - the caller zero-initialises them).
  * weights [M] (nullable unless extra is given): receives the per-sample compositing weight
- * w = alpha * T (0 behind the termination point); the K-channel forward/backward use it.          */
+ * w = alpha * T (0 behind the termination point); the K-channel forward/backward use it.
+ * sample_ray [M] (nullable; needs weights): receives, for every sample a ray owns, the row rays[n][0] of that ray's
+ * outputs - what inr_instance_head_backward looks dL/d(rendered logits) up by.                       */
 int inr_composite_rays_train_forward(const float* sigmas, const float* rgbs, const float* deltas,
                                      const int32_t* rays, int64_t N, int64_t M, float T_thresh,
                                      const float* extra /*[M,K] nullable*/, int32_t K,
                                      float* weights_sum, float* depth, float* image,
-                                     float* extra_out /*[N,K]*/, float* weights /*[M]*/, inr_stream_t s);
+                                     float* extra_out /*[N,K]*/, float* weights /*[M]*/,
+                                     int32_t* sample_ray /*[M]*/, inr_stream_t s);
+/* The K-channel half of the call above on its own: extra_out[rays[n][0]][ch] = sum over the ray's samples of
+ * weights[i] * extra[i][ch] (weights from an earlier inr_composite_rays_train_forward; rows of dropped rays are zero). */
+int inr_composite_rays_extra_forward(const float* weights /*[M]*/, const float* extra /*[M,K]*/, const int32_t* rays,
+                                     int64_t N, int64_t M, int32_t K, float* extra_out /*[N,K]*/, inr_stream_t s);
 int inr_composite_rays_train_backward(const float* grad_weights_sum, const float* grad_image,
                                       const float* grad_extra_out /*nullable*/, const float* sigmas,
                                       const float* rgbs, const float* extra, const float* deltas,
@@ -291,6 +298,24 @@ int inr_instance_forward_train(const float* x, int64_t M, float bound, const flo
 int inr_instance_backward(const float* grad_logits, int32_t K, const float* h1, const float* h2, int64_t M,
                           const float* packed_bwd, float* grad_z2, float* grad_z1, float* grad_enc,
                           inr_stream_t s);
+/* The instance head of the instance stage in two launches per direction (round 3).  Forward: as
+ * inr_instance_forward_train, but only the encoder output [M,32] is kept (n_samples_dev, nullable: device int32 with
+ * the number of live rows; rows beyond it are not evaluated).  Backward: ONE launch from dL/d(rendered logits)
+ * grad_pix [N,K] to dL/denc [M,32] (zero for rows >= *n_samples_dev) and the three weight gradients
+ * grad_w0 [64,32], grad_w1 [64,64], grad_w2 [K,64] (written, not accumulated): per sample g = weights[m] *
+ * grad_pix[sample_ray[m]] (the K-channel compositing backward, weights detached), the hidden layers are recomputed
+ * from enc with packed_fwd, the input-gradient chain uses packed_bwd, and dW += g^T h on the fp32 matrix cores with
+ * the tiles transposed through LDS - replaces inr_composite_rays_train_backward (K channels), inr_instance_backward
+ * and three inr_linear_wgrad calls, and ~3 KB of HBM traffic per sample.  workspace:
+ * inr_instance_head_workspace_bytes() bytes.  The table gradient stays inr_grid_encode_backward(grad_enc).      */
+int inr_instance_forward_enc(const float* x, int64_t M, const int32_t* n_samples_dev, float bound,
+                             const float* embeddings, const inr_grid_desc* desc /*host*/, const float* packed_fwd,
+                             int32_t K, float* logits, float* enc, inr_stream_t s);
+int64_t inr_instance_head_workspace_bytes(void);
+int inr_instance_head_backward(const float* enc, const float* weights, const int32_t* sample_ray,
+                               const float* grad_pix, int32_t K, int64_t N, int64_t M, const int32_t* n_samples_dev,
+                               const float* packed_fwd, const float* packed_bwd, float* grad_enc, void* workspace,
+                               float* grad_w0, float* grad_w1, float* grad_w2, inr_stream_t s);
 /* rgb-sigma lattice extraction (the step after the path that feeds NeRF-RCNN: /root/reference/nerf_rcnn/datasets.py:766-792
  * reads the result): out[m] = (mean over n_dirs fixed view directions of rgb(x_m, dir), raw density logit of x_m) -
  * one gather + one sigma-net pass per point, the colour net once per direction.  sh_dirs [n_dirs,16] = degree-4 SH rows

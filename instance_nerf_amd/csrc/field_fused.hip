@@ -780,9 +780,10 @@ __global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_nerf_fwd_dirs
   }
 }
 
-// kSave (training): the encoder output and the two hidden activations are also written, row-major, for the
-// weight gradients and the ReLU masks of k_instance_bwd.
-template <int K_MT, bool kSave = false>
+// kSave (training) 1: the encoder output and the two hidden activations are also written, row-major, for the
+// weight gradients and the ReLU masks of k_instance_bwd; 2: the encoder output only (k_instance_head_bwd recomputes
+// the hidden layers: 512 B per sample less to write here and to read there).
+template <int K_MT, int kSave = 0>
 __global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_instance_fwd(const float* __restrict__ x, int64_t M,
                                                                    const int32_t* __restrict__ n_dev, float bound,
                                                                    const float2* __restrict__ emb, uint32_t emb_bytes,
@@ -839,11 +840,13 @@ __global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_instance_fwd(
         float4 v = make_float4(o[mt][0], o[mt][1], o[mt][2], o[mt][3]);
         *reinterpret_cast<float4*>(logits + m * K + 16 * mt + 4 * q) = v;
       }
-      if constexpr (kSave) {
+      if constexpr (kSave != 0) {
         // lane q holds encoder features 4q..4q+3 and 16+4q..16+4q+3, and rows 16t+4q..+3 of every hidden tile
 #pragma unroll
         for (int t = 0; t < 2; ++t)
           *reinterpret_cast<float4*>(enc_out + m * 32 + 16 * t + 4 * q) = make_float4(enc[t][0], enc[t][1], enc[t][2], enc[t][3]);
+      }
+      if constexpr (kSave == 1) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           *reinterpret_cast<float4*>(h1_out + m * 64 + 16 * t + 4 * q) = make_float4(h1[t][0], h1[t][1], h1[t][2], h1[t][3]);
@@ -909,6 +912,178 @@ __global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_instance_bwd(
     if (valid) {
 #pragma unroll
       for (int t = 0; t < 2; ++t) store4(denc + m * 32 + 16 * t + 4 * q, c0[t]);
+    }
+  }
+}
+
+// ---- instance head: the WHOLE backward in one launch (round 3) -----------------------------------------------
+// Replaces, for the instance stage, k_composite_train_extra_bwd (dL/dlogits rows [M,K] written and read back),
+// k_instance_bwd (which read the saved h1 / h2 and wrote dz2 / dz1 for the weight gradients) and the three
+// k_linear_wgrad launches (which read all of them again): per sample it reads the saved encoder output (128 B), the
+// compositing weight and the ray's row of dL/d(rendered logits), and writes dL/denc (128 B) - ~0.3 KB instead of
+// ~3.5 KB of HBM traffic per sample.  Per 16-sample tile a wave
+//   1. forms g = w * dL/dpix[ray] (the K-channel compositing backward, weights detached),
+//   2. recomputes h1 = relu(W0 enc), h2 = relu(W1 h1) with the forward's own weights and code (same bits: the ReLU
+//      masks are the forward's),
+//   3. runs the input-gradient chain a = (W2^T g) . [h2 > 0], b = (W1^T a) . [h1 > 0], denc = W0^T b,
+//   4. and the weight gradients dW2 += g^T h2, dW1 += a^T h1, dW0 += b^T enc on the fp32 matrix cores
+//      (v_mfma_f32_16x16x4_f32, exact products, k = 4 samples per instruction).  The contraction runs over SAMPLES,
+//      which sit in lane & 15 of the D-layout registers: the (G, X) tiles of the workgroup's eight waves are staged in
+//      LDS row-major (row pitch 68 floats: the 16-byte writes of the 16 lanes of a q group fall into different
+//      banks) and read back as A[i = channel][k = sample], B[k = sample][j = channel].  The 40 accumulator tiles
+//      (16 + 16 + 8 of 16x16) are OWNED by the waves - wave w: tiles 2w, 2w+1 of dW2 and dW1, tile w of dW0, 20
+//      VGPRs - and every wave consumes all eight staged tiles for its own accumulators.
+// The workgroup's accumulators go to partial[block] (fragment order); k_head_wgrad_reduce sums over the workgroups.
+// Rows >= n (the device-side sample count; the buffer is sized from mean_count) are not read: their dL/denc is zero.
+constexpr int kHbPitch = 68;
+constexpr int kHbWaves = kFieldThreads / 64;
+constexpr int kHbTileFloats = 16 * kHbPitch;
+constexpr int kHbStageFloats = 2 * kHbWaves * kHbTileFloats;            // G and X of one round: 69.6 KB
+constexpr int kHbFwdFloats = kIns2;                                      // forward sections kIns0, kIns1
+constexpr int kHbAccTiles = 40;
+
+template <int N_T>
+__device__ __forceinline__ void hb_stage(float* __restrict__ tile_base, int q, int j, const f32x4* v) {
+#pragma unroll
+  for (int t = 0; t < N_T; ++t) store4(tile_base + j * kHbPitch + 16 * t + 4 * q, v[t]);
+}
+
+// acc0 += G[:, ot]^T X[:, it0], acc1 += G[:, ot]^T X[:, it1] over the 8 x 16 staged samples
+__device__ __forceinline__ void hb_accum(const float* __restrict__ gS, const float* __restrict__ xS, int q, int j, int ot,
+                                         int it0, int it1, bool two, f32x4& acc0, f32x4& acc1) {
+#pragma unroll 2
+  for (int T = 0; T < kHbWaves; ++T) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int row = T * kHbTileFloats + (4 * u + q) * kHbPitch;
+      const float a = gS[row + 16 * ot + j];
+      const float b0 = xS[row + 16 * it0 + j];
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0, acc0, 0, 0, 0);
+      if (two) {
+        const float b1 = xS[row + 16 * it1 + j];
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1, acc1, 0, 0, 0);
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_instance_head_bwd(
+    const float* __restrict__ enc, const float* __restrict__ wbuf, const int32_t* __restrict__ ray_of,
+    const float* __restrict__ g_pix, int Kp, int64_t M, const int32_t* __restrict__ n_dev,
+    const float4* __restrict__ packed_fwd, const float4* __restrict__ packed_bwd, float* __restrict__ denc,
+    float4* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) float4 wl[];
+  float4* wf = wl;
+  float4* wb = wl + kHbFwdFloats / 4;
+  float* gS = reinterpret_cast<float*>(wb + kBwdFloats / 4);
+  float* xS = gS + kHbWaves * kHbTileFloats;
+  for (int i = threadIdx.x; i < kHbFwdFloats / 4; i += kFieldThreads) wf[i] = packed_fwd[i];
+  for (int i = threadIdx.x; i < kBwdFloats / 4; i += kFieldThreads) wb[i] = packed_bwd[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, q = lane >> 4, j = lane & 15, wave = threadIdx.x >> 6;
+  int64_t n = M;
+  if (n_dev) n = min((int64_t)*n_dev, M);
+  const int64_t n_tiles = (M + 15) >> 4;
+  const int64_t per_round = (int64_t)gridDim.x * kHbWaves;
+  const int64_t n_rounds = (n_tiles + per_round - 1) / per_round;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 acc[5] = {zero4, zero4, zero4, zero4, zero4};
+  float* my_g = gS + wave * kHbTileFloats;
+  float* my_x = xS + wave * kHbTileFloats;
+  const int ot = wave >> 1, it0 = 2 * (wave & 1), it1 = it0 + 1;
+  for (int64_t round = 0; round < n_rounds; ++round) {
+    const int64_t tile = round * per_round + (int64_t)blockIdx.x * kHbWaves + wave;
+    const int64_t m = tile * 16 + j;
+    const bool valid = m < n;
+    f32x4 e[2] = {zero4, zero4}, g[4] = {zero4, zero4, zero4, zero4};
+    if (valid) {
+      e[0] = load4(enc + m * 32 + 4 * q);
+      e[1] = load4(enc + m * 32 + 16 + 4 * q);
+      const float w = wbuf[m];
+      if (w != 0.0f) {
+        const float* gp = g_pix + (int64_t)ray_of[m] * Kp;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int c = 16 * t + 4 * q;
+          if (c < Kp) g[t] = load4(gp + c) * w;
+        }
+      }
+    }
+    f32x4 h1[4], h2[4], a[4], b[4], c0[2];
+    mlp_layer<4, 2>(wf + kIns0 / 4, lane, e, h1);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) h1[t] = relu4(h1[t]);
+    mlp_layer<4, 4>(wf + kIns1 / 4, lane, h1, h2);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) h2[t] = relu4(h2[t]);
+    hb_stage<4>(my_g, q, j, g);
+    hb_stage<4>(my_x, q, j, h2);
+    mlp_layer<4, 4>(wb + kBwd2 / 4, lane, g, a);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) a[t] = mask4(a[t], h2[t]);
+    __syncthreads();
+    hb_accum(gS, xS, q, j, ot, it0, it1, true, acc[0], acc[1]);                 // dW2 tiles 2w, 2w+1
+    mlp_layer<4, 4>(wb + kBwd1 / 4, lane, a, b);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) b[t] = mask4(b[t], h1[t]);
+    __syncthreads();
+    hb_stage<4>(my_g, q, j, a);
+    hb_stage<4>(my_x, q, j, h1);
+    mlp_layer<2, 4>(wb + kBwd0 / 4, lane, b, c0);
+    if (m < M) {
+      store4(denc + m * 32 + 4 * q, c0[0]);
+      store4(denc + m * 32 + 16 + 4 * q, c0[1]);
+    }
+    __syncthreads();
+    hb_accum(gS, xS, q, j, ot, it0, it1, true, acc[2], acc[3]);                 // dW1 tiles 2w, 2w+1
+    __syncthreads();
+    hb_stage<4>(my_g, q, j, b);
+    hb_stage<2>(my_x, q, j, e);
+    __syncthreads();
+    hb_accum(gS, xS, q, j, ot, wave & 1, 0, false, acc[4], acc[4]);             // dW0 tile (ot, it = w & 1)
+    __syncthreads();
+  }
+  float4* out = partial + (size_t)blockIdx.x * kHbAccTiles * 64;
+  const int ids[5] = {2 * wave, 2 * wave + 1, 16 + 2 * wave, 16 + 2 * wave + 1, 32 + wave};
+#pragma unroll
+  for (int k = 0; k < 5; ++k) out[ids[k] * 64 + lane] = make_float4(acc[k][0], acc[k][1], acc[k][2], acc[k][3]);
+}
+
+// gw2 [Kp,64], gw1 [64,64], gw0 [64,32] = sum over the workgroups' partials (written, not accumulated).
+// Element idx of a partial: tile = idx >> 8, lane = (idx >> 2) & 63, r = idx & 3 -> D[4 (lane >> 4) + r][lane & 15].
+__global__ void __launch_bounds__(1024) k_head_wgrad_reduce(const float* __restrict__ partial, int n_groups, int Kp,
+                                                            float* __restrict__ gw0, float* __restrict__ gw1,
+                                                            float* __restrict__ gw2) {
+  __shared__ float red[16][64];
+  const int e = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  const int idx = blockIdx.x * 64 + e;
+  constexpr int per = kHbAccTiles * 256;
+  float s = 0.f;
+  int g = slice;
+  for (; g + 7 * 16 < n_groups; g += 8 * 16) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)(g + 16 * u) * per + idx];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; g < n_groups; g += 16) s += partial[(size_t)g * per + idx];
+  red[slice][e] = s;
+  __syncthreads();
+  if (slice == 0) {
+#pragma unroll
+    for (int k = 1; k < 16; ++k) s += red[k][e];
+    const int tile = idx >> 8, lane = (idx >> 2) & 63, r = idx & 3;
+    const int ol = 4 * (lane >> 4) + r, il = lane & 15;
+    if (tile < 16) {
+      const int o = 16 * (tile >> 2) + ol, i = 16 * (tile & 3) + il;
+      if (o < Kp) gw2[o * 64 + i] = s;
+    } else if (tile < 32) {
+      const int t = tile - 16;
+      gw1[(16 * (t >> 2) + ol) * 64 + 16 * (t & 3) + il] = s;
+    } else {
+      const int t = tile - 32;
+      gw0[(16 * (t >> 1) + ol) * 32 + 16 * (t & 1) + il] = s;
     }
   }
 }
@@ -1572,12 +1747,78 @@ int inr_instance_forward_train(const float* x, int64_t M, float bound, const flo
   const int64_t n_tiles = (M + 15) / 16;
   hipStream_t st = as_stream(s);
   switch (K / 16) {
-    case 1: k_instance_fwd<1, true><<<grid_for(k_instance_fwd<1, true>, lds, n_tiles), kFieldThreads, lds, st>>>(x, M, nullptr, bound, e, eb, G, p, logits, enc, h1, h2); break;
-    case 2: k_instance_fwd<2, true><<<grid_for(k_instance_fwd<2, true>, lds, n_tiles), kFieldThreads, lds, st>>>(x, M, nullptr, bound, e, eb, G, p, logits, enc, h1, h2); break;
-    case 3: k_instance_fwd<3, true><<<grid_for(k_instance_fwd<3, true>, lds, n_tiles), kFieldThreads, lds, st>>>(x, M, nullptr, bound, e, eb, G, p, logits, enc, h1, h2); break;
-    default: k_instance_fwd<4, true><<<grid_for(k_instance_fwd<4, true>, lds, n_tiles), kFieldThreads, lds, st>>>(x, M, nullptr, bound, e, eb, G, p, logits, enc, h1, h2); break;
+    case 1: k_instance_fwd<1, 1><<<grid_for(k_instance_fwd<1, 1>, lds, n_tiles), kFieldThreads, lds, st>>>(x, M, nullptr, bound, e, eb, G, p, logits, enc, h1, h2); break;
+    case 2: k_instance_fwd<2, 1><<<grid_for(k_instance_fwd<2, 1>, lds, n_tiles), kFieldThreads, lds, st>>>(x, M, nullptr, bound, e, eb, G, p, logits, enc, h1, h2); break;
+    case 3: k_instance_fwd<3, 1><<<grid_for(k_instance_fwd<3, 1>, lds, n_tiles), kFieldThreads, lds, st>>>(x, M, nullptr, bound, e, eb, G, p, logits, enc, h1, h2); break;
+    default: k_instance_fwd<4, 1><<<grid_for(k_instance_fwd<4, 1>, lds, n_tiles), kFieldThreads, lds, st>>>(x, M, nullptr, bound, e, eb, G, p, logits, enc, h1, h2); break;
   }
   return check_launch("instance_forward_train");
+}
+
+int inr_instance_forward_enc(const float* x, int64_t M, const int32_t* n_samples_dev, float bound, const float* embeddings,
+                             const inr_grid_desc* desc, const float* packed, int32_t K, float* logits, float* enc,
+                             inr_stream_t s) {
+  INR_REQUIRE(M >= 0 && desc, "bad argument");
+  if (M == 0) return INR_OK;
+  INR_REQUIRE(x && embeddings && packed && logits && enc, "null pointer");
+  INR_REQUIRE(K > 0 && K <= 64 && K % 16 == 0, "K must be 16, 32, 48 or 64");
+  INR_REQUIRE(((uintptr_t)embeddings & 7) == 0 && (((uintptr_t)packed | (uintptr_t)logits | (uintptr_t)enc) & 15) == 0,
+              "embeddings/packed/outputs misaligned");
+  GridDesc G;
+  int rc = make_grid_desc(desc, G);
+  if (rc) return rc;
+  const float2* e = reinterpret_cast<const float2*>(embeddings);
+  const float4* p = reinterpret_cast<const float4*>(packed);
+  const uint64_t emb_bytes64 = (uint64_t)desc->offsets[desc->num_levels] * 8ull;
+  INR_REQUIRE(emb_bytes64 < (1ull << 31), "table larger than 2 GiB is not addressable by the 32-bit gather offsets");
+  const uint32_t eb = (uint32_t)emb_bytes64;
+  const size_t lds = (size_t)(kIns2 + K * 64) * sizeof(float) + kLevelRecBytes;
+  const int64_t n_tiles = (M + 15) / 16;
+  hipStream_t st = as_stream(s);
+  switch (K / 16) {
+    case 1: k_instance_fwd<1, 2><<<grid_for(k_instance_fwd<1, 2>, lds, n_tiles), kFieldThreads, lds, st>>>(x, M, n_samples_dev, bound, e, eb, G, p, logits, enc, nullptr, nullptr); break;
+    case 2: k_instance_fwd<2, 2><<<grid_for(k_instance_fwd<2, 2>, lds, n_tiles), kFieldThreads, lds, st>>>(x, M, n_samples_dev, bound, e, eb, G, p, logits, enc, nullptr, nullptr); break;
+    case 3: k_instance_fwd<3, 2><<<grid_for(k_instance_fwd<3, 2>, lds, n_tiles), kFieldThreads, lds, st>>>(x, M, n_samples_dev, bound, e, eb, G, p, logits, enc, nullptr, nullptr); break;
+    default: k_instance_fwd<4, 2><<<grid_for(k_instance_fwd<4, 2>, lds, n_tiles), kFieldThreads, lds, st>>>(x, M, n_samples_dev, bound, e, eb, G, p, logits, enc, nullptr, nullptr); break;
+  }
+  return check_launch("instance_forward_enc");
+}
+
+static size_t head_bwd_lds() { return (size_t)(kHbFwdFloats + kBwdFloats + kHbStageFloats) * sizeof(float); }
+
+int64_t inr_instance_head_workspace_bytes(void) {
+  return (int64_t)cu_count() * kFieldBlocksPerCU * kHbAccTiles * 64 * (int64_t)sizeof(float4);
+}
+
+int inr_instance_head_backward(const float* enc, const float* weights, const int32_t* sample_ray, const float* grad_pix,
+                               int32_t K, int64_t N, int64_t M, const int32_t* n_samples_dev, const float* packed_fwd,
+                               const float* packed_bwd, float* grad_enc, void* workspace, float* grad_w0, float* grad_w1,
+                               float* grad_w2, inr_stream_t s) {
+  INR_REQUIRE(M >= 0 && N >= 0, "negative size");
+  INR_REQUIRE(K > 0 && K <= 64 && K % 16 == 0, "K must be 16, 32, 48 or 64");
+  INR_REQUIRE(grad_w0 && grad_w1 && grad_w2 && workspace && packed_fwd && packed_bwd, "null pointer");
+  INR_REQUIRE(M == 0 || (enc && weights && sample_ray && grad_pix && grad_enc), "null sample arrays");
+  INR_REQUIRE((((uintptr_t)enc | (uintptr_t)grad_pix | (uintptr_t)packed_fwd | (uintptr_t)packed_bwd | (uintptr_t)grad_enc |
+                (uintptr_t)workspace) & 15) == 0, "arrays must be 16-byte aligned");
+  hipStream_t st = as_stream(s);
+  const size_t lds = head_bwd_lds();
+  static bool attr_set = false;
+  if (!attr_set) {          // > 64 KB of dynamic LDS must be allowed explicitly
+    if (hipFuncSetAttribute((const void*)k_instance_head_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      set_error("instance_head_backward: %zu bytes of LDS refused", lds);
+      return INR_ELAUNCH;
+    }
+    attr_set = true;
+  }
+  const int64_t n_tiles = (M + 15) / 16;
+  const int grid = M == 0 ? 1 : grid_for(k_instance_head_bwd, lds, n_tiles);
+  k_instance_head_bwd<<<grid, kFieldThreads, lds, st>>>(enc, weights, sample_ray, grad_pix, K, M, n_samples_dev,
+                                                        reinterpret_cast<const float4*>(packed_fwd),
+                                                        reinterpret_cast<const float4*>(packed_bwd), grad_enc,
+                                                        reinterpret_cast<float4*>(workspace));
+  k_head_wgrad_reduce<<<kHbAccTiles * 256 / 64, 1024, 0, st>>>(reinterpret_cast<const float*>(workspace), grid, K, grad_w0,
+                                                               grad_w1, grad_w2);
+  return check_launch("instance_head_backward");
 }
 
 int inr_instance_backward(const float* grad_logits, int32_t K, const float* h1, const float* h2, int64_t M,

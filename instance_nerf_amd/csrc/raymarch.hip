@@ -907,13 +907,23 @@ __global__ void __launch_bounds__(kRayBlock) k_composite_train_fwd(const float* 
                                                                    float* __restrict__ weights_sum,
                                                                    float* __restrict__ depth,
                                                                    float* __restrict__ image,
-                                                                   float* __restrict__ wbuf) {
+                                                                   float* __restrict__ wbuf,
+                                                                   int32_t* __restrict__ sample_ray) {
   const int64_t n = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
   if (n >= N) return;
   const int32_t rid = rays[n * 3], off = rays[n * 3 + 1];
   int32_t cnt = rays[n * 3 + 2];
-  if ((int64_t)off + cnt > M) cnt = 0;     // the writer dropped this ray (sample buffer sized from mean_count)
+  if ((int64_t)off + cnt > M) {            // the writer dropped this ray (sample buffer sized from mean_count)
+    // the rows between its offset and the end of the buffer belong to nobody: zero weight, so that a consumer that
+    // walks the samples (k_instance_head_bwd) needs no ownership test
+    if (wbuf)
+      for (int64_t k = (int64_t)off + lane; k < M; k += 64) {
+        wbuf[k] = 0.0f;
+        if (sample_ray) sample_ray[k] = rid;
+      }
+    cnt = 0;
+  }
   float T_carry = 1.0f, t_carry = 0.0f, r = 0, g = 0, b = 0, ws = 0, dsum = 0;
   for (int base = 0; base < cnt; base += 64) {
     const bool act = base + lane < cnt;
@@ -934,11 +944,15 @@ __global__ void __launch_bounds__(kRayBlock) k_composite_train_fwd(const float* 
     const float t = t_carry + wave_incl_sum(dy, lane);
     r += w * cr; g += w * cg; b += w * cb; ws += w; dsum += w * t;
     if (wbuf && act) wbuf[i] = w;
+    if (sample_ray && act) sample_ray[i] = rid;      // row of the ray's outputs (k_instance_head_bwd looks dL/dpix up by it)
     T_carry *= __shfl(P, 63, 64);
     t_carry = __shfl(t, 63, 64);
     if (T_carry < T_thresh) {                        // wave-uniform: the rest of the ray is unused
       if (wbuf)
-        for (int64_t k = (int64_t)base + 64 + lane; k < cnt; k += 64) wbuf[(int64_t)off + k] = 0.0f;
+        for (int64_t k = (int64_t)base + 64 + lane; k < cnt; k += 64) {
+          wbuf[(int64_t)off + k] = 0.0f;
+          if (sample_ray) sample_ray[(int64_t)off + k] = rid;
+        }
       break;
     }
   }
@@ -1582,8 +1596,9 @@ int inr_finish_rays(const float* image, const float* depth, const float* weights
 int inr_composite_rays_train_forward(const float* sigmas, const float* rgbs, const float* deltas, const int32_t* rays,
                                      int64_t N, int64_t M, float T_thresh, const float* extra, int32_t K,
                                      float* weights_sum, float* depth, float* image, float* extra_out, float* weights,
-                                     inr_stream_t s) {
+                                     int32_t* sample_ray, inr_stream_t s) {
   INR_REQUIRE(rays && weights_sum && depth && image && N >= 0 && M >= 0, "bad argument");
+  INR_REQUIRE(!sample_ray || weights, "sample_ray needs weights");
   INR_REQUIRE(!extra || (extra_out && weights && K > 0 && K <= 64), "extra needs extra_out, weights and 0 < K <= 64");
   INR_REQUIRE(!extra_out || M == 0 || (extra && weights), "extra_out needs extra and weights");
   if (N == 0) return INR_OK;
@@ -1591,11 +1606,21 @@ int inr_composite_rays_train_forward(const float* sigmas, const float* rgbs, con
   INR_REQUIRE(((uintptr_t)deltas & 7) == 0, "deltas must be 8-byte aligned");
   hipStream_t st = as_stream(s);
   k_composite_train_fwd<<<blocks_for(N * 64, kRayBlock), kRayBlock, 0, st>>>(sigmas, rgbs, deltas, rays, N, M, T_thresh,
-                                                                             weights_sum, depth, image, weights);
+                                                                             weights_sum, depth, image, weights, sample_ray);
   if (extra_out && K > 0)     // also with no sample at all (M == 0, extra null): the rows of extra_out must be zeroed
     k_composite_train_extra_fwd<<<blocks_for(N * 64, kRayBlock), kRayBlock, 0, st>>>(weights, extra, rays, N, M, K,
                                                                                      extra_out);
   return check_launch("composite_rays_train_forward");
+}
+
+int inr_composite_rays_extra_forward(const float* weights, const float* extra, const int32_t* rays, int64_t N, int64_t M,
+                                     int32_t K, float* extra_out, inr_stream_t s) {
+  INR_REQUIRE(rays && extra_out && N >= 0 && M >= 0 && K > 0 && K <= 64, "bad argument");
+  if (N == 0) return INR_OK;
+  INR_REQUIRE(M == 0 || (weights && extra), "null sample arrays");
+  k_composite_train_extra_fwd<<<blocks_for(N * 64, kRayBlock), kRayBlock, 0, as_stream(s)>>>(weights, extra, rays, N, M, K,
+                                                                                            extra_out);
+  return check_launch("composite_rays_extra_forward");
 }
 
 int inr_composite_rays_train_backward(const float* grad_weights_sum, const float* grad_image,

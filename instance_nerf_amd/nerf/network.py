@@ -142,6 +142,64 @@ class _InstanceFieldFn(torch.autograd.Function):
         return None, g_emb, gw0, gw1, gw2, None, None
 
 
+class _InstanceHeadFn(torch.autograd.Function):
+    """The instance head of a TRAINING render as one autograd node: samples x [M,3] + their (detached) compositing
+    weights and owning rays -> rendered logits [N,K].  Forward: fused instance field (only the encoder output is kept)
+    + K-channel compositing.  Backward: ONE launch (csrc/field_fused.hip::k_instance_head_bwd) from dL/d(rendered
+    logits) to dL/denc and the three weight gradients - the [M,K] logit gradient, the saved hidden activations, their
+    gradients and the three split-K weight-gradient launches of ``_InstanceFieldFn`` never exist - then the table
+    scatter.  Same arithmetic as the composable chain ``_InstanceFieldFn`` -> ``composite_rays_train(extra=...)``
+    except that the weight gradients are summed in a different order (fp32 MFMA over 16-sample tiles)."""
+
+    @staticmethod
+    def forward(ctx, x, weights, sample_ray, rays, n_dev, emb, w0, w1, w2, desc, bound):
+        lib = _lib.load()
+        f32 = torch.float32
+        K, M, N, dev = w2.shape[0], x.shape[0], rays.shape[0], x.device
+        pf = torch.empty(lib.inr_instance_packed_floats(K), dtype=f32, device=dev)
+        pb = torch.empty(lib.inr_instance_bwd_packed_floats(), dtype=f32, device=dev)
+        check(lib.inr_instance_pack_weights_device(ptr(w0.detach().contiguous(), f32, "w0"),
+                                                   ptr(w1.detach().contiguous(), f32, "w1"),
+                                                   ptr(w2.detach().contiguous(), f32, "w2"), K, ptr(pf), ptr(pb),
+                                                   stream_ptr()), "instance_pack_weights_device")
+        logits = torch.empty(M, K, dtype=f32, device=dev)
+        enc = torch.empty(M, 32, dtype=f32, device=dev)
+        none_ok = M == 0
+        check(lib.inr_instance_forward_enc(ptr(x, f32, "x", allow_none=none_ok), M, ptr(n_dev, torch.int32, "n_dev", allow_none=True),
+                                           float(bound), ptr(emb.detach(), f32, "embeddings"), desc, ptr(pf), K,
+                                           ptr(logits, allow_none=none_ok), ptr(enc, allow_none=none_ok), stream_ptr()),
+              "instance_forward_enc")
+        out = torch.empty(N, K, dtype=f32, device=dev)
+        check(lib.inr_composite_rays_extra_forward(ptr(weights, f32, "weights", allow_none=none_ok),
+                                                   ptr(logits, allow_none=none_ok), ptr(rays, torch.int32, "rays"), N, M, K,
+                                                   ptr(out), stream_ptr()), "composite_rays_extra_forward")
+        ctx.save_for_backward(x, enc, weights, sample_ray, pf, pb, emb)
+        ctx.n_dev, ctx.desc, ctx.bound, ctx.K, ctx.N = n_dev, desc, bound, K, N
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        f32 = torch.float32
+        x, enc, weights, sample_ray, pf, pb, emb = ctx.saved_tensors
+        K, M, N, dev = ctx.K, x.shape[0], ctx.N, x.device
+        g = g.contiguous().float()
+        denc = torch.empty(M, 32, dtype=f32, device=dev)
+        gw = torch.empty(64 * 32 + 64 * 64 + K * 64, dtype=f32, device=dev)          # written by the reduce kernel
+        gw0, gw1, gw2 = gw[:2048].view(64, 32), gw[2048:6144].view(64, 64), gw[6144:].view(K, 64)
+        ws = torch.empty(lib.inr_instance_head_workspace_bytes() // 4, dtype=f32, device=dev)
+        none_ok = M == 0
+        check(lib.inr_instance_head_backward(ptr(enc, allow_none=none_ok), ptr(weights, allow_none=none_ok),
+                                             ptr(sample_ray, torch.int32, "sample_ray", allow_none=none_ok),
+                                             ptr(g, f32, "grad_pix", allow_none=N == 0), K, N, M,
+                                             ptr(ctx.n_dev, torch.int32, "n_dev", allow_none=True), ptr(pf), ptr(pb),
+                                             ptr(denc, allow_none=none_ok), ptr(ws), ptr(gw0), ptr(gw1), ptr(gw2),
+                                             stream_ptr()), "instance_head_backward")
+        g_emb = torch.zeros_like(emb)
+        g_emb = _table_backward(lib, x, denc, ctx.desc, M, ctx.bound, g_emb, emb)
+        return None, None, None, None, None, g_emb, gw0, gw1, gw2, None, None
+
+
 class _NerfFieldFn(torch.autograd.Function):
     """(x, d) -> (sigma, rgb) of the NeRF field for TRAINING: one fused forward that keeps the activations and one
     fused backward for the whole input-gradient chain (colour net -> geo features / density logit -> sigma net ->
@@ -452,6 +510,27 @@ class NeRFNetwork(NeRFRenderer):
                                           self.instance_net[0].weight, self.instance_net[1].weight, w2,
                                           self.instance_encoder.desc, self.bound)
         return _run_mlp(self.instance_net, self.instance_encoder(x, bound=self.bound))
+
+    fused_instance_head = True        # False: _InstanceFieldFn + composite_rays_train(extra=...) (round-2 path)
+
+    def instance_head_available(self, x):
+        """The one-node instance head applies: fused kernels, every instance parameter trained, x without gradient."""
+        if not (self.num_instances and self._fusable_inst and self.fused_instance_train and self.fused_instance_head):
+            return False
+        params = [self.instance_encoder.embeddings] + [l.weight for l in self.instance_net]
+        return (x.is_cuda and torch.is_grad_enabled() and all(p.requires_grad for p in params) and not x.requires_grad)
+
+    def instance_head_train(self, x, weights, sample_ray, rays, n_dev=None):
+        """Rendered instance logits [N, K_pad] of a training batch from the ray-major samples x [M,3], their detached
+        compositing weights [M] and owning-ray rows int32 [M] (``composite_rays_train(return_weights=True)``) and the
+        march's rays [N,3]; ``n_dev``: the march's device-side sample counter (rows beyond it are not evaluated)."""
+        K, Kp = self.num_instances, self._k_pad
+        w2 = self.instance_net[2].weight
+        if Kp != K:
+            w2 = torch.nn.functional.pad(w2, (0, 0, 0, Kp - K))       # autograd cuts its gradient back to [K, 64]
+        return _InstanceHeadFn.apply(x.contiguous().float(), weights, sample_ray, rays, n_dev,
+                                     self.instance_encoder.embeddings, self.instance_net[0].weight,
+                                     self.instance_net[1].weight, w2, self.instance_encoder.desc, self.bound)
 
     @torch.no_grad()
     def nerf_render(self, xyzs, deltas, rays, rays_d, T_thresh=1e-4, want_weights=False, normalised=False):

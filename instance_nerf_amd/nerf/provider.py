@@ -14,8 +14,9 @@ from .utils import get_rays
 
 class SyntheticRoomDataset:
     def __init__(self, device, H=800, W=800, n_views=8, num_rays=4096, training=True, ignore_frac=0.1, seed=2,
-                 num_instances=64, rank=0):
+                 num_instances=64, rank=0, sort_pixels=False):
         self.device, self.H, self.W, self.num_rays, self.training = device, H, W, num_rays, training
+        self.sort_pixels = sort_pixels      # the batch's random pixels in image order (same set of rays per batch)
         self.room = RoomScene()
         poses, self.intrinsics, _, _ = self.room.cameras(n=n_views, H=H, W=W, focal=W / 2.0)
         self.poses = torch.from_numpy(poses).to(device)
@@ -30,7 +31,9 @@ class SyntheticRoomDataset:
         """One training batch: num_rays random pixels of a random view."""
         view = int(self.rng.integers(0, len(self))) if view is None else view
         N = self.num_rays if self.training else -1
-        inds = torch.randint(0, self.H * self.W, (self.num_rays,), generator=self.gen).to(self.device) if N > 0 else None
+        inds = torch.randint(0, self.H * self.W, (self.num_rays,), generator=self.gen) if N > 0 else None
+        if inds is not None:
+            inds = (torch.sort(inds).values if self.sort_pixels else inds).to(self.device)
         r = get_rays(self.poses[view:view + 1], self.intrinsics, self.H, self.W, inds=inds)
         ro, rd = r["rays_o"][0].cpu().numpy(), r["rays_d"][0].cpu().numpy()
         rgb, ids, _ = self.room.trace(ro, rd)

@@ -286,11 +286,18 @@ class NeRFRenderer(nn.Module):
             sigmas, rgbs = self(xyzs, dirs)
             if self.density_scale != 1:
                 sigmas = self.density_scale * sigmas
-            extra = self._instance_for_compositing(xyzs) if with_instance else None
-            out = raymarching.composite_rays_train(sigmas, rgbs, deltas, rays, T_thresh, extra=extra)
-            weights_sum, depth, image = out[0], out[1], out[2]
-            if with_instance:
-                results["instance"] = out[3][:, :self.num_instances].reshape(*prefix, -1)
+            if with_instance and getattr(self, "instance_head_available", lambda x: False)(xyzs):
+                # the instance head as ONE autograd node (field + K-channel compositing; one backward launch)
+                weights_sum, depth, image, wbuf, sample_ray = raymarching.composite_rays_train(
+                    sigmas, rgbs, deltas, rays, T_thresh, return_weights=True)
+                inst = self.instance_head_train(xyzs, wbuf, sample_ray, rays, n_dev=counter)
+                results["instance"] = inst[:, :self.num_instances].reshape(*prefix, -1)
+            else:
+                extra = self._instance_for_compositing(xyzs) if with_instance else None
+                out = raymarching.composite_rays_train(sigmas, rgbs, deltas, rays, T_thresh, extra=extra)
+                weights_sum, depth, image = out[0], out[1], out[2]
+                if with_instance:
+                    results["instance"] = out[3][:, :self.num_instances].reshape(*prefix, -1)
             results["num_samples"] = counter
         elif infer_mode == "wavefront":
             dtype = torch.float32

@@ -276,7 +276,7 @@ def patch_slots(rays):
 
 class _CompositeRaysTrain(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, sigmas, rgbs, extra, deltas, rays, T_thresh):
+    def forward(ctx, sigmas, rgbs, extra, deltas, rays, T_thresh, want_weights=False):
         lib = _lib.load()
         sigmas, rgbs, deltas = _f(sigmas), _f(rgbs), _f(deltas)
         dev = sigmas.device
@@ -290,12 +290,14 @@ class _CompositeRaysTrain(torch.autograd.Function):
         depth = torch.empty(N, dtype=F32, device=dev)
         image = torch.empty(N, 3, dtype=F32, device=dev)
         extra_out = torch.empty(N, K, dtype=F32, device=dev) if K else None
-        wbuf = torch.empty(sigmas.shape[0], dtype=F32, device=dev) if K else None
+        wbuf = torch.empty(sigmas.shape[0], dtype=F32, device=dev) if (K or want_weights) else None
+        sample_ray = torch.empty(sigmas.shape[0], dtype=I32, device=dev) if want_weights else None
         check(lib.inr_composite_rays_train_forward(
             ptr(sigmas, F32, "sigmas"), ptr(rgbs, F32, "rgbs"), ptr(deltas, F32, "deltas"), ptr(rays, I32, "rays"),
             N, sigmas.shape[0], float(T_thresh), ptr(extra, F32, "extra", allow_none=True), K, ptr(ws), ptr(depth),
             ptr(image),
-            ptr(extra_out, allow_none=True), ptr(wbuf, allow_none=True), stream_ptr()), "composite_rays_train_forward")
+            ptr(extra_out, allow_none=True), ptr(wbuf, allow_none=True), ptr(sample_ray, allow_none=True), stream_ptr()),
+            "composite_rays_train_forward")
         ctx.save_for_backward(sigmas, rgbs, extra, deltas, rays, ws, image, wbuf)
         ctx.T_thresh = T_thresh
         ctx.K = K
@@ -304,12 +306,16 @@ class _CompositeRaysTrain(torch.autograd.Function):
             ctx.mark_non_differentiable(depth)
         else:                                      # frozen density/colour field: only the K channels carry gradient
             ctx.mark_non_differentiable(depth, ws, image)
-        if K:
-            return ws, depth, image, extra_out
-        return ws, depth, image
+        out = (ws, depth, image) + ((extra_out,) if K else ())
+        if want_weights:                           # per-sample weights (detached) + owning ray row, for the fused instance head
+            ctx.mark_non_differentiable(wbuf, sample_ray)
+            out = out + (wbuf, sample_ray)
+        ctx.n_out = len(out)
+        return out
 
     @staticmethod
-    def backward(ctx, g_ws, g_depth, g_image, g_extra=None):
+    def backward(ctx, g_ws, g_depth, g_image, *rest):
+        g_extra = rest[0] if ctx.K else None
         lib = _lib.load()
         sigmas, rgbs, extra, deltas, rays, ws, image, wbuf = ctx.saved_tensors
         N = rays.shape[0]
@@ -335,16 +341,18 @@ class _CompositeRaysTrain(torch.autograd.Function):
                 ptr(extra, allow_none=True), ptr(deltas), ptr(rays), ptr(ws), ptr(image), ptr(wbuf, allow_none=True), N,
                 sigmas.shape[0], float(ctx.T_thresh), K, ptr(gs, allow_none=True), ptr(gc, allow_none=True),
                 ptr(ge, allow_none=True), stream_ptr()), "composite_rays_train_backward")
-        return gs, gc, ge, None, None, None
+        return gs, gc, ge, None, None, None, None
 
 
-def composite_rays_train(sigmas, rgbs, deltas, rays, T_thresh=1e-4, extra=None):
-    """-> weights_sum [N], depth [N], image [N,3] (, extra_out [N,K] when ``extra`` [M,K] is given).
+def composite_rays_train(sigmas, rgbs, deltas, rays, T_thresh=1e-4, extra=None, return_weights=False):
+    """-> weights_sum [N], depth [N], image [N,3] (, extra_out [N,K] when ``extra`` [M,K] is given)
+    (, weights [M], sample_ray int32 [M] when ``return_weights``: the detached per-sample compositing weights and the
+    output row of the ray that owns each sample - the inputs of the fused instance head).
 
     Differentiable w.r.t. sigmas, rgbs and extra.  The K extra channels are
     composited with the weights detached (instance field vs. a frozen NeRF).
     """
-    return _CompositeRaysTrain.apply(sigmas, rgbs, extra, deltas, rays, T_thresh)
+    return _CompositeRaysTrain.apply(sigmas, rgbs, extra, deltas, rays, T_thresh, bool(return_weights))
 
 
 def march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, density_bitfield, C, H, near, far,

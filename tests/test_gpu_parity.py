@@ -1533,6 +1533,46 @@ def test_trainer_renders_row_major_views_in_patch_order(params_k16, room, room_b
     assert torch.equal(seen["first_dirs"], r["rays_d"][0].view(64, 96, 3)[:4, :4].reshape(16, 3))
 
 
+@pytest.mark.parametrize("K,drop", [(64, False), (31, False), (16, True)])
+def test_instance_head_node_equals_the_composable_chain(level_table, room, room_bitfield, K, drop):
+    """The one-node instance head (k_instance_fwd<.., enc only> + K-channel compositing forward; k_instance_head_bwd =
+    compositing backward + recomputed hidden layers + input-gradient chain + the three weight gradients in ONE launch)
+    against the round-2 chain of separate kernels on the same network and rays: rendered logits bit for bit (same
+    forward arithmetic), every instance gradient to fp32 summation-order accuracy.  drop: the sample buffer is sized
+    from a mean_count below the batch's total, so the last rays are dropped and rows nobody owns exist."""
+    from oracle import field
+    p = field.init_params(seed=21, table=level_table, table_std=1.0, K=K)
+    ro, rd = scene_rays(room, 700, cam=3, seed=55)
+    labels = np.random.default_rng(5).integers(-1, K, size=700)
+
+    def run(fused):
+        net = _network({k: v.clone() for k, v in p.items()}, K=K).train()
+        net.density_bitfield.copy_(_t(room_bitfield))
+        net.freeze_nerf()
+        net.fused_instance_head = fused
+        if drop:
+            with torch.no_grad():
+                full = net.render(_t(ro)[None], _t(rd)[None], bg_color=1, perturb=False, force_all_rays=True)
+            net.local_step = 0
+            net.mean_count = (int(full["num_samples"][0]) * 2 // 3 // 128) * 128
+        out = net.render(_t(ro)[None], _t(rd)[None], bg_color=1, perturb=False, force_all_rays=not drop)
+        loss = torch.nn.functional.cross_entropy(out["instance"][0], _t(labels).long(), ignore_index=-1)
+        loss.backward()
+        grads = {n: q.grad.clone() for n, q in net.named_parameters() if q.grad is not None}
+        return out["instance"][0].detach().clone(), grads
+    inst_a, ga = run(True)
+    inst_b, gb = run(False)
+    assert inst_a.shape == (700, K) and torch.equal(inst_a, inst_b)
+    if drop:
+        assert (inst_a[-20:] == 0).all() and (inst_a[:20] != 0).any()      # the tail of the ray list was dropped
+    assert sorted(ga) == sorted(gb) == ["instance_encoder.embeddings", "instance_net.0.weight", "instance_net.1.weight",
+                                        "instance_net.2.weight"]
+    for n in ga:
+        assert ga[n].shape == gb[n].shape and gb[n].abs().sum() > 0, n
+        rel = float(torch.linalg.norm(ga[n] - gb[n]) / torch.linalg.norm(gb[n]))
+        assert rel < 2e-5, (n, rel)
+
+
 def test_composite_train_with_dropped_rays(rm, room, room_bitfield, bits_dev):
     """Sample buffers sized from mean_count: rays that overflow M are dropped by the writer and must composite to
     zero (and get zero gradients) - never be read past the end of the buffers (regression: GPU memory fault)."""

@@ -71,7 +71,9 @@ static float best_of(int reps, hipEvent_t e0, hipEvent_t e1, F&& launch) {
   return best;
 }
 
-int main() {
+int main(int argc, char** argv) {
+  setvbuf(stdout, nullptr, _IONBF, 0);
+  const bool with_asm = argc > 1 && argv[1][0] == 'c';           // section C (inline-asm cache-policy bits) on request
   const uint32_t rows = 6119864, n_floats = rows * 2;       // the hash table of one field
   float* table; CK(hipMalloc(&table, (size_t)n_floats * 4 + 4096));
   float4* sink; CK(hipMalloc(&sink, 64));
@@ -95,10 +97,6 @@ int main() {
     printf("  store %.3f ms (%.1f G/s)   load+add+store %.3f ms (%.1f G/s)   load %.3f ms (%.1f G/s)\n", ms0, n / ms0 / 1e6,
            ms1, n / ms1 / 1e6, ms2, n / ms2 / 1e6);
   }
-  printf("C: cache-policy bits on the atomic (W=4, 48 M lanes)\n");
-#define RUN_C(P, name) { float ms = best_of(3, e0, e1, [&](int r) { k_atomic_groups<4, P><<<2048, 256>>>(table, n_floats, lanes, r); }); \
-    printf("  %-10s %.3f ms  %6.1f G lanes/s\n", name, ms, lanes / ms / 1e6); }
-  RUN_C(0, "atomicAdd") RUN_C(3, "asm plain") RUN_C(1, "asm sc1") RUN_C(2, "asm nt")
   printf("D: occupancy (W=4, 48 M lanes)\n");
   for (int nb : {256, 512, 1024, 4096, 16384}) {
     float ms = best_of(3, e0, e1, [&](int r) { k_atomic_groups<4, 0><<<nb, 256>>>(table, n_floats, lanes, r); });
@@ -116,6 +114,13 @@ int main() {
       float ms = best_of(3, e0, e1, [&](int r) { k_lds_add<<<256, 512>>>(out, 188 * 1024, r, cf); });
       printf("  %s: %.3f ms  %6.1f G adds/s\n", cf ? "one lane per bank" : "random banks   ", ms, 256.0 * 188 * 1024 / ms / 1e6);
     }
+  }
+  CK(hipDeviceSynchronize());
+  if (with_asm) {
+  printf("C: cache-policy bits on the atomic (W=4, 48 M lanes)\n");
+#define RUN_C(P, name) { float ms = best_of(3, e0, e1, [&](int r) { k_atomic_groups<4, P><<<2048, 256>>>(table, n_floats, lanes, r); }); \
+    printf("  %-10s %.3f ms  %6.1f G lanes/s\n", name, ms, lanes / ms / 1e6); }
+  RUN_C(0, "atomicAdd") RUN_C(3, "asm plain") RUN_C(1, "asm sc1") RUN_C(2, "asm nt")
   }
   CK(hipDeviceSynchronize());
   return 0;

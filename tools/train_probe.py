@@ -10,7 +10,8 @@ from instance_nerf_amd.nerf.utils import Trainer
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 net = NeRFNetwork(cuda_ray=True, bound=1, min_near=0.05, density_thresh=10, num_instances=64).to(dev)
-ds = SyntheticRoomDataset(dev, num_rays=4096, num_instances=64)
+ds = SyntheticRoomDataset(dev, num_rays=4096, num_instances=64, sort_pixels=os.environ.get("SORT_RAYS", "0") == "1")
+net.fused_instance_head = os.environ.get("FUSED_HEAD", "1") == "1"
 net.density_bitfield.copy_(torch.from_numpy(ds.room.density_bitfield(128, 1.0)).to(dev))
 tr = Trainer("probe", None, net, stage="instance", device=dev, iters=1000, update_extra_interval=10 ** 9)
 tr.global_step = 1          # keep the analytic occupancy grid (no update from the untrained NeRF)
