@@ -28,15 +28,22 @@ HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BYTES_PER_SAMPLE = 1024         # 16 levels x 8 corners x 2 features x 4 B
 
 
+TRAFFIC_JSON = os.path.join("profiles", "r03_traffic.json")
+
+
 def measured_traffic_bytes_per_sample(res):
     """HBM-side bytes per sample of the fused field kernel from the committed PMC profile
-    (profiles/r02_traffic.json: FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc passes, gfx950 x2
-    read correction).  PMC counters cannot be collected from inside this process; None if absent or
-    if the workload is not the profiled one."""
-    path = os.path.join(ROOT, "profiles", "r02_traffic.json")
+    (profiles/r03_traffic.json: FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc passes, gfx950 x2
+    read correction; written by tools/traffic_json.py from a tools/pmc_bench.sh run).  PMC counters cannot be
+    collected from inside this process, so the figure is only quoted for the kernel sources it was measured on (the
+    file carries their sha): None if the profile is absent, belongs to other sources, or the workload differs."""
+    from instance_nerf_amd import build
+    path = os.path.join(ROOT, TRAFFIC_JSON)
     if res != 800 or not os.path.exists(path):
         return None
     t = json.load(open(path))
+    if t.get("source_sha") != build.source_sha():
+        return None
     return float(t["read_bytes_per_sample"]) + float(t["write_bytes_per_sample"])
 
 
@@ -132,6 +139,20 @@ def train_probe(dev, rank=0, world=1, red_dev=None, steps=20, warmup=5, stage="i
     net.update_extra_state = update_and_restore
     tr.global_step = 1                     # the first update comes after 15 steps, like every later one
     batches = [ds.batch() for _ in range(4)]
+    # the step's dominant kernel is the table-gradient scatter (k_grid_bwd): events around its launch, on its stream
+    from instance_nerf_amd.nerf import network as _network_mod
+    scatter_events = []
+    real_table_backward = _network_mod._table_backward
+
+    def timed_table_backward(*a, **kw):
+        st = torch.cuda.current_stream()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        out = real_table_backward(*a, **kw)
+        e1.record(st)
+        scatter_events.append((e0, e1))
+        return out
+    _network_mod._table_backward = timed_table_backward
 
     def barrier():
         if world > 1:
@@ -150,6 +171,7 @@ def train_probe(dev, rank=0, world=1, red_dev=None, steps=20, warmup=5, stage="i
         marched += torch.clamp(net.step_counter[(net.local_step - 1) % 16, 0], max=net.mean_count)
     marched.zero_()
     n_updates[0] = 0
+    scatter_events.clear()
     import gc
     gc.collect()                           # the render network of the headline measurement dies here, not mid-loop
     gc.disable()
@@ -161,8 +183,10 @@ def train_probe(dev, rank=0, world=1, red_dev=None, steps=20, warmup=5, stage="i
     barrier()
     elapsed = time.perf_counter() - t0
     gc.enable()
+    _network_mod._table_backward = real_table_backward
     n = int(marched.item())
     n_all = float(n)
+    scatter_ms = sum(a.elapsed_time(b) for a, b in scatter_events) / max(len(scatter_events), 1)
     if world > 1:
         t = torch.tensor([elapsed, float(n)], dtype=torch.float64, device=red_dev)
         tm, ts = t[:1].clone(), t[1:].clone()
@@ -171,6 +195,25 @@ def train_probe(dev, rank=0, world=1, red_dev=None, steps=20, warmup=5, stage="i
         elapsed, n_all = float(tm.item()), float(ts.item())
     dt = elapsed / steps
     reduced = sum(p.numel() for g in tr.optimizer.param_groups for p in g["params"]) * 4
+    # per live sample 1024 B per grid forward + 2048 B per TRAINED grid backward; per step the optimiser
+    # sweep of the trained grid (7 x 49 MB).  Instance stage: frozen NeRF fwd + instance fwd + instance bwd = 4096 B;
+    # NeRF stage: fwd + bwd of the one grid = 3072 B.  Rank 0's own samples over its own step time.
+    per_sample = 4096 if stage == "instance" else 3072
+    table_bytes = int(net.encoder.embeddings.numel()) * 4
+    adam_bytes = 7 * table_bytes
+    own_dt = dt
+    step_bytes = per_sample * (n / steps) + adam_bytes
+    roofline = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                "kernel": "k_grid_bwd (table-gradient scatter, fp32 atomics; memory-side atomic request rate, "
+                          "profiles/r03_NOTES.txt)",
+                "algorithmic_bytes_per_sample": 2048, "launches": len(scatter_events),
+                "avg_launch_ms": round(scatter_ms, 4),
+                "achieved": round(2048 * (n / steps) / (scatter_ms / 1e3) / 1e9, 1) if scatter_ms > 0 else None,
+                "frac": round(2048 * (n / steps) / (scatter_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 4) if scatter_ms > 0 else None,
+                "traffic": None,
+                "step": {"algorithmic_bytes_per_sample": per_sample, "optimizer_bytes_per_step": adam_bytes,
+                         "achieved": round(step_bytes / own_dt / 1e9, 1),
+                         "frac": round(step_bytes / own_dt / 1e9 / HBM_PEAK_GBS, 4)}}
     what = ("instance-field training step, K=64, 4096 rays/batch per GPU, NeRF frozen, parameter EMA 0.95 "
             f"(BASELINE configs[{2 if world == 1 else 3}])") if stage == "instance" else \
         "NeRF training step (MSE on rgb: hash table + sigma/colour nets, parameter EMA 0.95), 4096 rays/batch per GPU"
@@ -178,7 +221,7 @@ def train_probe(dev, rank=0, world=1, red_dev=None, steps=20, warmup=5, stage="i
             "n_gpus": world, "ms_per_step": round(dt * 1e3, 3), "samples_per_step": int(n_all) // steps,
             "msamples_per_s": round(n_all / steps / dt / 1e6, 2),
             "allreduce_mb_per_step": round(reduced / 1e6, 1) if world > 1 else 0.0,
-            "occupancy_updates_in_timed_steps": n_updates[0],
+            "occupancy_updates_in_timed_steps": n_updates[0], "roofline": roofline,
             "loss_first": round(first, 4), "loss_last": round(float(last), 4)}
 
 
@@ -404,7 +447,9 @@ def main():
                        "parallelism": f"views sharded over {world} GPU(s), no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "traffic_source": "profiles/r02_traffic.json (rocprofv3 PMC, GB/s at this run's launch time)",
+                         "traffic_source": (TRAFFIC_JSON + " (rocprofv3 PMC on these kernel sources, GB/s at this run's "
+                                            "launch time)") if traffic is not None else
+                         "no PMC profile of these kernel sources under profiles/ (tools/pmc_bench.sh + tools/traffic_json.py)",
                          "kernel": "k_nerf_fwd<true,true> (fused hash gather + SH table + MLP)",
                          "avg_launch_ms": round(avg_kernel_s * 1e3, 4), "launches": n_launch,
                          "algorithmic_bytes_per_sample": BYTES_PER_SAMPLE},
@@ -465,7 +510,9 @@ def main():
                 def bail():
                     line["train_step"] = line["train_step_nerf"] = {"error": "training probe did not finish in 300 s"}
                     print(json.dumps(line), flush=True)
-                    os._exit(0)
+                    # a hung collective is a FAILED run: non-zero, so that the launcher tears the other ranks down and
+                    # the caller sees it (the headline is also in gpurun_out/bench_headline_n<N>.json)
+                    os._exit(3)
                 watchdog = threading.Timer(300.0, bail)
                 watchdog.daemon = True
                 watchdog.start()

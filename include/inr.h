@@ -193,8 +193,16 @@ int inr_composite_rays_train_forward(const float* sigmas, const float* rgbs, con
                                      int32_t* sample_ray /*[M]*/, inr_stream_t s);
 /* The K-channel half of the call above on its own: extra_out[rays[n][0]][ch] = sum over the ray's samples of
  * weights[i] * extra[i][ch] (weights from an earlier inr_composite_rays_train_forward; rows of dropped rays are zero). */
+/* Optional cross-entropy epilogue (labels non-null): the wave that has just rendered a ray's K logits also forms that
+ * ray's cross-entropy row against labels[row] (int64 [N]; ignore_index rows skipped; classes 0 .. n_classes-1, K may be
+ * padded beyond) - grad_pix [N,K] = softmax - onehot for the kept rows (NOT yet divided by their number), and a second
+ * small launch leaves loss_out[0..3] = {mean loss over the kept rows, 1 / kept, kept, labels out of range}; a label that
+ * is neither ignore_index nor a class makes the loss NaN.  workspace: N * 16 bytes.  inr_instance_head_backward takes
+ * grad_pix with loss_out + 1 as one of its scale pointers.                                                         */
 int inr_composite_rays_extra_forward(const float* weights /*[M]*/, const float* extra /*[M,K]*/, const int32_t* rays,
-                                     int64_t N, int64_t M, int32_t K, float* extra_out /*[N,K]*/, inr_stream_t s);
+                                     int64_t N, int64_t M, int32_t K, float* extra_out /*[N,K]*/,
+                                     const int64_t* labels /*nullable*/, int32_t n_classes, int64_t ignore_index,
+                                     float* grad_pix, void* workspace, float* loss_out, inr_stream_t s);
 int inr_composite_rays_train_backward(const float* grad_weights_sum, const float* grad_image,
                                       const float* grad_extra_out /*nullable*/, const float* sigmas,
                                       const float* rgbs, const float* extra, const float* deltas,
@@ -306,7 +314,8 @@ int inr_instance_backward(const float* grad_logits, int32_t K, const float* h1, 
  * grad_pix[sample_ray[m]] (the K-channel compositing backward, weights detached), the hidden layers are recomputed
  * from enc with packed_fwd, the input-gradient chain uses packed_bwd, and dW += g^T h on the fp32 matrix cores with
  * the tiles transposed through LDS - replaces inr_composite_rays_train_backward (K channels), inr_instance_backward
- * and three inr_linear_wgrad calls, and ~3 KB of HBM traffic per sample.  workspace:
+ * and three inr_linear_wgrad calls, and ~3 KB of HBM traffic per sample.  scale_a, scale_b: device scalars that
+ * multiply grad_pix (1 / kept rows and dL/dloss of the fused cross entropy; NULL = 1).  workspace:
  * inr_instance_head_workspace_bytes() bytes.  The table gradient stays inr_grid_encode_backward(grad_enc).      */
 int inr_instance_forward_enc(const float* x, int64_t M, const int32_t* n_samples_dev, float bound,
                              const float* embeddings, const inr_grid_desc* desc /*host*/, const float* packed_fwd,
@@ -314,6 +323,7 @@ int inr_instance_forward_enc(const float* x, int64_t M, const int32_t* n_samples
 int64_t inr_instance_head_workspace_bytes(void);
 int inr_instance_head_backward(const float* enc, const float* weights, const int32_t* sample_ray,
                                const float* grad_pix, int32_t K, int64_t N, int64_t M, const int32_t* n_samples_dev,
+                               const float* scale_a /*device scalar, nullable*/, const float* scale_b /*same*/,
                                const float* packed_fwd, const float* packed_bwd, float* grad_enc, void* workspace,
                                float* grad_w0, float* grad_w1, float* grad_w2, inr_stream_t s);
 /* rgb-sigma lattice extraction (the step after the path that feeds NeRF-RCNN: /root/reference/nerf_rcnn/datasets.py:766-792

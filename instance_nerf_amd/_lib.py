@@ -56,7 +56,7 @@ _SIGS = {
     "inr_instance_backward": (c_int32, [P, c_int32, P, P, c_int64, P, P, P, P, P]),
     "inr_instance_forward_enc": (c_int32, [P, c_int64, P, c_float, P, POINTER(GridDesc), P, c_int32, P, P, P]),
     "inr_instance_head_workspace_bytes": (c_int64, []),
-    "inr_instance_head_backward": (c_int32, [P, P, P, P, c_int32, c_int64, c_int64, P, P, P, P, P, P, P, P, P]),
+    "inr_instance_head_backward": (c_int32, [P, P, P, P, c_int32, c_int64, c_int64, P, P, P, P, P, P, P, P, P, P, P]),
     "inr_adam_step_multi": (c_int32, [c_int32, P, P, P, P, P, P, c_float, c_float, c_float, c_int32, c_float, P]),
     "inr_adam_ema_step_multi": (c_int32, [c_int32, P, P, P, P, P, P, c_float, c_float, c_float, c_int32, c_float, P,
                                           c_float, P]),
@@ -71,7 +71,7 @@ _SIGS = {
                                  P, P, P, P, P, P, P]),
     "inr_composite_rays": (c_int32, [c_int64, c_int32, P, P, P, P, P, P, P, P, c_float, P, P, c_int32, P]),
     "inr_compact_alive": (c_int32, [P, c_int64, P, P, P]),
-    "inr_composite_rays_extra_forward": (c_int32, [P, P, P, c_int64, c_int64, c_int32, P, P]),
+    "inr_composite_rays_extra_forward": (c_int32, [P, P, P, c_int64, c_int64, c_int32, P, P, c_int32, c_int64, P, P, P, P]),
     "inr_composite_rays_train_forward": (c_int32, [P, P, P, P, c_int64, c_int64, c_float, P, c_int32, P, P, P, P, P, P, P]),
     "inr_composite_rays_train_backward": (c_int32, [P, P, P, P, P, P, P, P, P, P, P, c_int64, c_int64, c_float, c_int32,
                                                     P, P, P, P]),

@@ -18,6 +18,17 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function"]
 
 
+def source_sha():
+    """sha256 over the kernel sources and headers the library is built from: profiles that describe a particular
+    build of the kernels (profiles/r0x_traffic.json) carry it, and bench.py only quotes them for the same sources."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(SOURCES + HEADERS):
+        h.update(f.encode())
+        h.update(open(os.path.join(CSRC, f), "rb").read())
+    return h.hexdigest()
+
+
 def _stale():
     if not os.path.exists(LIB):
         return True

@@ -77,9 +77,16 @@ __device__ __forceinline__ void run_reduce_atomic4(float* __restrict__ gemb, uin
 __global__ void __launch_bounds__(256) k_grid_bwd(const float* __restrict__ x, const float* __restrict__ gout,
                                                   const int32_t* __restrict__ order, GridDesc G, int64_t M, float bound,
                                                   float* __restrict__ gemb, int level0) {
-  const int64_t m = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+  // blockIdx.x = level (the FAST axis of the dispatch order), blockIdx.y = block of 64 samples: at any moment all
+  // levels of a window of samples are in flight.  With the level on the slow axis (rounds 1-2) the coarse levels ran
+  // alone at the start of the launch, and they are not throughput- but LATENCY-bound: all samples hit the same few
+  // hundred 64-byte chunks (one memory-side atomic request each, ~0.4 us, same-chunk requests one after the other -
+  // level 0 alone takes 36 us for 1 % of the requests, profiles/r03_NOTES.txt), while the hashed fine levels are bound
+  // by the request RATE (~21 G 64-byte requests/s).  Interleaved, the chains of the coarse levels hide under the
+  // stream of fine-level requests.
+  const int64_t m = ((int64_t)blockIdx.y * blockDim.x + threadIdx.x) >> 2;
   const int sub = threadIdx.x & 3, xb = sub >> 1, f = sub & 1;
-  const int l = level0 + blockIdx.y;
+  const int l = level0 + blockIdx.x;
   const int L = G.num_levels;
   bool valid = m < M;
   const int64_t ms = valid ? m : M - 1;
@@ -492,8 +499,14 @@ int inr_grid_encode_backward_levels(const float* x, const float* grad_out, const
   INR_REQUIRE(((uintptr_t)grad_out & 7) == 0, "grad_out must be 8-byte aligned");
   if (M == 0) return INR_OK;
   INR_REQUIRE((uint64_t)desc->offsets[desc->num_levels] * 2ull < (1ull << 32), "table too large for 32-bit element offsets");
-  const dim3 grid(blocks_for(M * 4, 256), (unsigned)(level_hi - level_lo));
-  k_grid_bwd<<<grid, 256, 0, as_stream(s)>>>(x, grad_out, order, G, M, bound, grad_embeddings, level_lo);
+  // grid.y is limited to 65535 blocks of 64 samples: longer sample arrays go in several launches
+  const int64_t chunk = (int64_t)65535 * 64;
+  for (int64_t m0 = 0; m0 < M; m0 += chunk) {
+    const int64_t mc = std::min(chunk, M - m0);
+    const dim3 grid((unsigned)(level_hi - level_lo), blocks_for(mc * 4, 256));
+    k_grid_bwd<<<grid, 256, 0, as_stream(s)>>>(order ? x : x + m0 * 3, order ? grad_out : grad_out + m0 * G.num_levels * 2,
+                                               order ? order + m0 : nullptr, G, mc, bound, grad_embeddings, level_lo);
+  }
   return check_launch("grid_encode_backward");
 }
 

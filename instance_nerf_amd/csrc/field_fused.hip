@@ -970,6 +970,7 @@ __device__ __forceinline__ void hb_accum(const float* __restrict__ gS, const flo
 __global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_instance_head_bwd(
     const float* __restrict__ enc, const float* __restrict__ wbuf, const int32_t* __restrict__ ray_of,
     const float* __restrict__ g_pix, int Kp, int64_t M, const int32_t* __restrict__ n_dev,
+    const float* __restrict__ scale_a, const float* __restrict__ scale_b,
     const float4* __restrict__ packed_fwd, const float4* __restrict__ packed_bwd, float* __restrict__ denc,
     float4* __restrict__ partial) {
   extern __shared__ __attribute__((aligned(16))) float4 wl[];
@@ -983,6 +984,9 @@ __global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_instance_head
   const int lane = threadIdx.x & 63, q = lane >> 4, j = lane & 15, wave = threadIdx.x >> 6;
   int64_t n = M;
   if (n_dev) n = min((int64_t)*n_dev, M);
+  // g_pix may be an unnormalised gradient (softmax - onehot of the fused cross entropy): the two device scalars -
+  // 1 / kept rows and dL/dloss - scale every sample's weight instead of a pass over [N,K]
+  const float g_scale = (scale_a ? *scale_a : 1.0f) * (scale_b ? *scale_b : 1.0f);
   const int64_t n_tiles = (M + 15) >> 4;
   const int64_t per_round = (int64_t)gridDim.x * kHbWaves;
   const int64_t n_rounds = (n_tiles + per_round - 1) / per_round;
@@ -991,24 +995,30 @@ __global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_instance_head
   float* my_g = gS + wave * kHbTileFloats;
   float* my_x = xS + wave * kHbTileFloats;
   const int ot = wave >> 1, it0 = 2 * (wave & 1), it1 = it0 + 1;
-  for (int64_t round = 0; round < n_rounds; ++round) {
-    const int64_t tile = round * per_round + (int64_t)blockIdx.x * kHbWaves + wave;
-    const int64_t m = tile * 16 + j;
-    const bool valid = m < n;
-    f32x4 e[2] = {zero4, zero4}, g[4] = {zero4, zero4, zero4, zero4};
-    if (valid) {
+  // Inputs of the NEXT round are requested while this round's weight-gradient phases run (the kernel is a chain of
+  // dependent round trips otherwise: 7 rounds x (HBM load -> dependent row load -> MFMA chain -> 6 barriers)):
+  // stage 1 (encoder row, weight, ray row) right after this round's inputs are consumed, stage 2 (the ray's
+  // dL/dpix row, which needs the ray row) before the last phase.
+  f32x4 e[2] = {zero4, zero4}, graw[4] = {zero4, zero4, zero4, zero4};
+  float w = 0.0f;
+  auto tile_row = [&](int64_t round) { return (round * per_round + (int64_t)blockIdx.x * kHbWaves + wave) * 16 + j; };
+  {
+    const int64_t m = tile_row(0);
+    if (m < n) {
       e[0] = load4(enc + m * 32 + 4 * q);
       e[1] = load4(enc + m * 32 + 16 + 4 * q);
-      const float w = wbuf[m];
-      if (w != 0.0f) {
-        const float* gp = g_pix + (int64_t)ray_of[m] * Kp;
+      w = wbuf[m] * g_scale;
+      const float* gp = g_pix + (int64_t)ray_of[m] * Kp;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int c = 16 * t + 4 * q;
-          if (c < Kp) g[t] = load4(gp + c) * w;
-        }
-      }
+      for (int t = 0; t < 4; ++t)
+        if (16 * t + 4 * q < Kp) graw[t] = load4(gp + 16 * t + 4 * q);
     }
+  }
+  for (int64_t round = 0; round < n_rounds; ++round) {
+    const int64_t m = tile_row(round);
+    f32x4 g[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) g[t] = graw[t] * w;
     f32x4 h1[4], h2[4], a[4], b[4], c0[2];
     mlp_layer<4, 2>(wf + kIns0 / 4, lane, e, h1);
 #pragma unroll
@@ -1018,6 +1028,19 @@ __global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_instance_head
     for (int t = 0; t < 4; ++t) h2[t] = relu4(h2[t]);
     hb_stage<4>(my_g, q, j, g);
     hb_stage<4>(my_x, q, j, h2);
+    const f32x4 e_cur[2] = {e[0], e[1]};
+    // stage 1 of the next round
+    const int64_t mn = tile_row(round + 1);
+    const bool next_valid = round + 1 < n_rounds && mn < n;
+    int32_t rid_n = 0;
+    e[0] = e[1] = zero4;
+    w = 0.0f;
+    if (next_valid) {
+      e[0] = load4(enc + mn * 32 + 4 * q);
+      e[1] = load4(enc + mn * 32 + 16 + 4 * q);
+      w = wbuf[mn] * g_scale;
+      rid_n = ray_of[mn];
+    }
     mlp_layer<4, 4>(wb + kBwd2 / 4, lane, g, a);
 #pragma unroll
     for (int t = 0; t < 4; ++t) a[t] = mask4(a[t], h2[t]);
@@ -1037,8 +1060,17 @@ __global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_instance_head
     __syncthreads();
     hb_accum(gS, xS, q, j, ot, it0, it1, true, acc[2], acc[3]);                 // dW1 tiles 2w, 2w+1
     __syncthreads();
+    // stage 2 of the next round: the ray row has arrived long ago
+#pragma unroll
+    for (int t = 0; t < 4; ++t) graw[t] = zero4;
+    if (next_valid) {
+      const float* gp = g_pix + (int64_t)rid_n * Kp;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if (16 * t + 4 * q < Kp) graw[t] = load4(gp + 16 * t + 4 * q);
+    }
     hb_stage<4>(my_g, q, j, b);
-    hb_stage<2>(my_x, q, j, e);
+    hb_stage<2>(my_x, q, j, e_cur);
     __syncthreads();
     hb_accum(gS, xS, q, j, ot, wave & 1, 0, false, acc[4], acc[4]);             // dW0 tile (ot, it = w & 1)
     __syncthreads();
@@ -1562,6 +1594,8 @@ static int grid_for(Kern kern, size_t lds_bytes, int64_t n_tiles) {
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, kern, kFieldThreads, lds_bytes) != hipSuccess || fit < 1) fit = 1;
     if (n_cached < 64) cache[n_cached++] = Entry{(const void*)kern, lds_bytes, fit};
   }
+  // (two workgroups per CU for small launches - training batches, ~6 tiles per wave - measured in round 3: no change,
+  //  92.2 vs 90.9 us per 209 k samples; those launches are bound by the L2 fills of a cold table, not by latency)
   const int per_cu = std::min(fit, kFieldBlocksPerCU);
   const int64_t want = (n_tiles + kFieldThreads / 64 - 1) / (kFieldThreads / 64);
   return (int)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)cus * per_cu));
@@ -1791,9 +1825,9 @@ int64_t inr_instance_head_workspace_bytes(void) {
 }
 
 int inr_instance_head_backward(const float* enc, const float* weights, const int32_t* sample_ray, const float* grad_pix,
-                               int32_t K, int64_t N, int64_t M, const int32_t* n_samples_dev, const float* packed_fwd,
-                               const float* packed_bwd, float* grad_enc, void* workspace, float* grad_w0, float* grad_w1,
-                               float* grad_w2, inr_stream_t s) {
+                               int32_t K, int64_t N, int64_t M, const int32_t* n_samples_dev, const float* scale_a,
+                               const float* scale_b, const float* packed_fwd, const float* packed_bwd, float* grad_enc,
+                               void* workspace, float* grad_w0, float* grad_w1, float* grad_w2, inr_stream_t s) {
   INR_REQUIRE(M >= 0 && N >= 0, "negative size");
   INR_REQUIRE(K > 0 && K <= 64 && K % 16 == 0, "K must be 16, 32, 48 or 64");
   INR_REQUIRE(grad_w0 && grad_w1 && grad_w2 && workspace && packed_fwd && packed_bwd, "null pointer");
@@ -1813,7 +1847,7 @@ int inr_instance_head_backward(const float* enc, const float* weights, const int
   const int64_t n_tiles = (M + 15) / 16;
   const int grid = M == 0 ? 1 : grid_for(k_instance_head_bwd, lds, n_tiles);
   k_instance_head_bwd<<<grid, kFieldThreads, lds, st>>>(enc, weights, sample_ray, grad_pix, K, M, n_samples_dev,
-                                                        reinterpret_cast<const float4*>(packed_fwd),
+                                                        scale_a, scale_b, reinterpret_cast<const float4*>(packed_fwd),
                                                         reinterpret_cast<const float4*>(packed_bwd), grad_enc,
                                                         reinterpret_cast<float4*>(workspace));
   k_head_wgrad_reduce<<<kHbAccTiles * 256 / 64, 1024, 0, st>>>(reinterpret_cast<const float*>(workspace), grid, K, grad_w0,

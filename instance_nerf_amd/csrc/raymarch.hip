@@ -622,15 +622,53 @@ __global__ void __launch_bounds__(kCoopRaysPerBlock * 64) k_march_count_coop(Mar
                                                                              int max_steps, const float* __restrict__ nears,
                                                                              const float* __restrict__ fars,
                                                                              const float* __restrict__ noises,
-                                                                             int32_t* __restrict__ counts) {
+                                                                             int32_t* __restrict__ counts,
+                                                                             float* __restrict__ stage, int stage_pitch) {
   const int64_t n = (int64_t)blockIdx.x * kCoopRaysPerBlock + (threadIdx.x >> 6);
   if (n >= N) return;
   const Ray r = load_ray(rays_o, rays_d, n);
   const float t0 = start_t(P, nears[n], noises ? noises[n] : 0.0f);
-  auto none = [](int, float, float, float, float, float, float) {};
-  const int cnt = P.C == 1 ? march_ray_coop<true>(P, r, t0, fars[n], max_steps, none)
-                           : march_ray_coop<false>(P, r, t0, fars[n], max_steps, none);
+  int cnt;
+  if (stage) {
+    // Staged: the samples of the ONE walk are parked in the workspace, ray n at row n * stage_pitch (pitch >=
+    // max_steps: every ray fits; only the rows that exist are written, the rest of the reservation is never touched),
+    // and the write pass is a copy to the scanned offsets instead of a second walk - a ray is a chain of dependent
+    // windows, so walking it twice cost twice the latency (45 + 45 us for 4096 rays; the copy takes ~5).
+    float* row = stage + (size_t)n * stage_pitch * 5;
+    auto park = [&](int k, float px, float py, float pz, float dt, float delta, float) {
+      float* q = row + (size_t)k * 5;
+      q[0] = px; q[1] = py; q[2] = pz; q[3] = dt; q[4] = delta;
+    };
+    cnt = P.C == 1 ? march_ray_coop<true>(P, r, t0, fars[n], max_steps, park)
+                   : march_ray_coop<false>(P, r, t0, fars[n], max_steps, park);
+  } else {
+    auto none = [](int, float, float, float, float, float, float) {};
+    cnt = P.C == 1 ? march_ray_coop<true>(P, r, t0, fars[n], max_steps, none)
+                   : march_ray_coop<false>(P, r, t0, fars[n], max_steps, none);
+  }
   if ((threadIdx.x & 63) == 0) counts[n] = cnt;
+}
+
+// write pass of the staged marcher: one wave per ray copies its parked samples to their slots
+__global__ void __launch_bounds__(kCoopRaysPerBlock * 64) k_march_write_staged(const float* __restrict__ rays_d, int64_t N,
+                                                                               int64_t M, const int32_t* __restrict__ rays,
+                                                                               const float* __restrict__ stage, int stage_pitch,
+                                                                               float* __restrict__ xyzs, float* __restrict__ dirs,
+                                                                               float* __restrict__ deltas) {
+  const int64_t n = (int64_t)blockIdx.x * kCoopRaysPerBlock + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const int off = rays[n * 3 + 1];
+  const int cnt = rays[n * 3 + 2];
+  if (cnt == 0 || (int64_t)off + cnt > M) return;
+  const float dx = rays_d[n * 3], dy = rays_d[n * 3 + 1], dz = rays_d[n * 3 + 2];
+  const float* row = stage + (size_t)n * stage_pitch * 5;
+  for (int k = threadIdx.x & 63; k < cnt; k += 64) {
+    const float* q = row + (size_t)k * 5;
+    const int64_t i = (int64_t)off + k;
+    xyzs[i * 3 + 0] = q[0]; xyzs[i * 3 + 1] = q[1]; xyzs[i * 3 + 2] = q[2];
+    dirs[i * 3 + 0] = dx; dirs[i * 3 + 1] = dy; dirs[i * 3 + 2] = dz;
+    deltas[i * 2 + 0] = q[3]; deltas[i * 2 + 1] = q[4];
+  }
 }
 
 // one workgroup: rays[n] = (n, exclusive scan of counts in ray order, count); counter = {total, N}
@@ -702,10 +740,11 @@ __global__ void __launch_bounds__(256) k_ce_rows(const float* __restrict__ logit
   const int lane = threadIdx.x & 63;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  float loss_sum = 0.f, kept = 0.f;
+  float loss_sum = 0.f, kept = 0.f, bad = 0.f;     // bad: labels that are neither ignore_index nor a class
   for (int64_t r = wave; r < N; r += n_waves) {
     const int64_t y = labels[r];
     const bool keep = y != ignore_index && y >= 0 && y < K;
+    if (y != ignore_index && !(y >= 0 && y < K)) bad += 1.f;
     const float x = lane < K ? logits[r * K + lane] : -INFINITY;
     float m = x;
 #pragma unroll
@@ -721,6 +760,9 @@ __global__ void __launch_bounds__(256) k_ce_rows(const float* __restrict__ logit
     }
     if (lane < K) dlogits[r * K + lane] = keep ? e / ssum - (lane == (int)y ? 1.f : 0.f) : 0.f;
   }
+  // a label that is neither ignore_index nor a class poisons the loss (NaN): torch's cross_entropy asserts on the device
+  // for such a label; dropping the row silently would train on fewer rows without anyone noticing
+  if (bad > 0.f) loss_sum = NAN;
   if (lane == 0) red[threadIdx.x >> 6] = make_float2(loss_sum, kept);
   __syncthreads();
   if (threadIdx.x == 0)
@@ -965,11 +1007,18 @@ __global__ void __launch_bounds__(kRayBlock) k_composite_train_fwd(const float* 
 
 // a13: K extra channels (instance logits): out[ray][ch] = sum_i w_i * extra[i][ch]; one wave per ray,
 // lane = channel (coalesced 4K-byte rows), no scan (weights come from k_composite_train_fwd)
+struct CeArgs {                  // optional cross-entropy epilogue of the K-channel compositing (labels == nullptr: none)
+  const int64_t* labels;         // [N] by output row (rays[n][0])
+  int n_classes;                 // logits 0 .. n_classes-1 take part (K may be padded beyond)
+  int64_t ignore_index;
+  float* dpix;                   // [N,K]: softmax - onehot for kept rows, 0 otherwise (NOT yet divided by the kept count)
+  float4* part;                  // [N]: (row loss, kept 0/1, label out of range 0/1, 0)
+};
 __global__ void __launch_bounds__(kRayBlock) k_composite_train_extra_fwd(const float* __restrict__ wbuf,
                                                                          const float* __restrict__ extra,
                                                                          const int32_t* __restrict__ rays, int64_t N,
                                                                          int64_t M, int K,
-                                                                         float* __restrict__ extra_out) {
+                                                                         float* __restrict__ extra_out, CeArgs ce) {
   const int64_t n = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
   if (n >= N) return;
@@ -990,6 +1039,50 @@ __global__ void __launch_bounds__(kRayBlock) k_composite_train_extra_fwd(const f
     }
     for (; s < cnt; ++s) acc += wbuf[(int64_t)off + s] * extra[((int64_t)off + s) * K + lane];
     extra_out[(int64_t)rid * K + lane] = acc;
+  }
+  if (ce.labels) {
+    // the rendered logits of this ray are in the lanes: its cross-entropy row right here (same arithmetic as k_ce_rows)
+    const int64_t y = ce.labels[rid];
+    const bool in_range = y >= 0 && y < ce.n_classes;
+    const bool keep = y != ce.ignore_index && in_range;
+    const bool live = lane < ce.n_classes;
+    const float x = live ? acc : -INFINITY;
+    float m = x;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
+    const float e = live ? expf(x - m) : 0.f;
+    float ssum = e;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) ssum += __shfl_xor(ssum, d, 64);
+    const float xy = __shfl(x, keep ? (int)y : 0, 64);
+    if (lane < K) ce.dpix[(int64_t)rid * K + lane] = (keep && live) ? e / ssum - (lane == (int)y ? 1.f : 0.f) : 0.f;
+    if (lane == 0)
+      ce.part[rid] = make_float4(keep ? (m + logf(ssum)) - xy : 0.f, keep ? 1.f : 0.f,
+                                 (y != ce.ignore_index && !in_range) ? 1.f : 0.f, 0.f);
+  }
+}
+
+// loss_out[0] = mean row loss over the kept rows (NaN when nothing is kept, as torch's mean over an empty set - and NaN
+// when a label is neither ignore_index nor a class: torch's cross_entropy asserts on the device for such a label, a
+// silent drop would train on fewer rows without anyone noticing), [1] = 1 / kept (0 if none), [2] = kept, [3] = bad.
+// One workgroup; sums in a fixed order (deterministic).
+__global__ void __launch_bounds__(1024) k_ce_finalize(const float4* __restrict__ part, int64_t N, float* __restrict__ loss_out) {
+  __shared__ float red[3][16];
+  float a = 0.f, b = 0.f, c = 0.f;
+  for (int64_t i = threadIdx.x; i < N; i += 1024) {
+    const float4 p = part[i];
+    a += p.x; b += p.y; c += p.z;
+  }
+  a = wave_sum(a); b = wave_sum(b); c = wave_sum(c);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = b; red[2][threadIdx.x >> 6] = c; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float sa = 0.f, sb = 0.f, sc = 0.f;
+    for (int w = 0; w < 16; ++w) { sa += red[0][w]; sb += red[1][w]; sc += red[2][w]; }
+    loss_out[0] = sc > 0.f ? NAN : sa / sb;
+    loss_out[1] = sb > 0.f ? 1.0f / sb : 0.f;
+    loss_out[2] = sb;
+    loss_out[3] = sc;
   }
 }
 
@@ -1428,9 +1521,21 @@ static int64_t ws_ints(int64_t N) {
 }
 // sample_cap: number of step candidates per ray the count pass records as a bit mask (rounded up to 32; 0 = none)
 static int cap_words_of(int32_t sample_cap) { return sample_cap > 0 ? (sample_cap + 31) / 32 : 0; }
-int64_t inr_march_workspace_bytes(int64_t N, int32_t sample_cap) {
+// Staged wave-per-ray marcher (training batches): rows of 5 floats, kStagePitch rows reserved per ray.  Address space,
+// not traffic: 4096 rays reserve 84 MB of the 288 GB and write ~4 MB of it.
+constexpr int kStagePitch = 1024;
+constexpr int64_t kStageMaxRays = 8192;
+static bool use_stage(int64_t N, int32_t sample_cap, int max_steps) {
+  return use_coop(N, sample_cap) && N <= kStageMaxRays && max_steps <= kStagePitch;
+}
+static int64_t stage_offset_bytes(int64_t N, int32_t sample_cap) {          // 16-byte aligned start of the stage rows
   const int w = cap_words_of(sample_cap);
-  return ws_ints(N) * (int64_t)sizeof(int32_t) + (w ? N * (int64_t)(w + 1) * (int64_t)sizeof(uint32_t) : 0);
+  const int64_t b = ws_ints(N) * (int64_t)sizeof(int32_t) + (w ? N * (int64_t)(w + 1) * (int64_t)sizeof(uint32_t) : 0);
+  return (b + 15) / 16 * 16;
+}
+int64_t inr_march_workspace_bytes(int64_t N, int32_t sample_cap) {
+  const int64_t base = stage_offset_bytes(N, sample_cap);
+  return base + (N <= kStageMaxRays && sample_cap == 0 ? N * (int64_t)kStagePitch * 5 * (int64_t)sizeof(float) : 0);
 }
 
 // extra dynamic LDS per march workgroup while overlap placement is on (inr_set_overlap_placement)
@@ -1451,8 +1556,11 @@ int inr_march_rays_train_count(const float* rays_o, const float* rays_d, const u
   uint32_t* mask = reinterpret_cast<uint32_t*>(counts + ws_ints(N));
   hipStream_t st = as_stream(s);
   if (use_coop(N, sample_cap)) {
+    float* stage = use_stage(N, sample_cap, max_steps)
+                       ? reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + stage_offset_bytes(N, sample_cap)) : nullptr;
     k_march_count_coop<<<blocks_for(N, kCoopRaysPerBlock), kCoopRaysPerBlock * 64, 0, st>>>(P, rays_o, rays_d, N, max_steps,
-                                                                                          nears, fars, noises, counts);
+                                                                                          nears, fars, noises, counts, stage,
+                                                                                          kStagePitch);
     k_scan_counts<<<1, 1024, 0, st>>>(counts, N, rays, counter);
     return check_launch("march_rays_train_count");
   }
@@ -1475,6 +1583,13 @@ int inr_march_rays_train_write(const float* rays_o, const float* rays_d, const u
   const MarchParams P = make_params(bitfield, bound, dt_gamma, max_steps, cascade, H);
   INR_REQUIRE(sample_cap == 0 || workspace, "sample_cap > 0 needs the workspace of the count pass");
   const uint32_t* mask = sample_cap > 0 ? reinterpret_cast<const uint32_t*>(reinterpret_cast<const int32_t*>(workspace) + ws_ints(N)) : nullptr;
+  if (use_stage(N, sample_cap, max_steps)) {     // the count pass parked the samples in the workspace
+    INR_REQUIRE(workspace, "the staged marcher needs the workspace of the count pass");
+    const float* stage = reinterpret_cast<const float*>(reinterpret_cast<const char*>(workspace) + stage_offset_bytes(N, sample_cap));
+    k_march_write_staged<<<blocks_for(N, kCoopRaysPerBlock), kCoopRaysPerBlock * 64, 0, as_stream(s)>>>(
+        rays_d, N, M, rays, stage, kStagePitch, xyzs, dirs, deltas);
+    return check_launch("march_rays_train_write");
+  }
   if (use_coop(N, sample_cap)) {
     k_march_write_coop<<<blocks_for(N, kCoopRaysPerBlock), kCoopRaysPerBlock * 64, 0, as_stream(s)>>>(
         P, rays_o, rays_d, N, M, nears, fars, noises, rays, xyzs, dirs, deltas);
@@ -1609,17 +1724,25 @@ int inr_composite_rays_train_forward(const float* sigmas, const float* rgbs, con
                                                                              weights_sum, depth, image, weights, sample_ray);
   if (extra_out && K > 0)     // also with no sample at all (M == 0, extra null): the rows of extra_out must be zeroed
     k_composite_train_extra_fwd<<<blocks_for(N * 64, kRayBlock), kRayBlock, 0, st>>>(weights, extra, rays, N, M, K,
-                                                                                     extra_out);
+                                                                                     extra_out, CeArgs{});
   return check_launch("composite_rays_train_forward");
 }
 
 int inr_composite_rays_extra_forward(const float* weights, const float* extra, const int32_t* rays, int64_t N, int64_t M,
-                                     int32_t K, float* extra_out, inr_stream_t s) {
+                                     int32_t K, float* extra_out, const int64_t* labels, int32_t n_classes,
+                                     int64_t ignore_index, float* grad_pix, void* workspace, float* loss_out,
+                                     inr_stream_t s) {
   INR_REQUIRE(rays && extra_out && N >= 0 && M >= 0 && K > 0 && K <= 64, "bad argument");
+  INR_REQUIRE(!labels || (grad_pix && workspace && loss_out && n_classes > 0 && n_classes <= K),
+              "labels need grad_pix, workspace, loss_out and 0 < n_classes <= K");
+  INR_REQUIRE(((uintptr_t)workspace & 15) == 0, "workspace must be 16-byte aligned");
   if (N == 0) return INR_OK;
   INR_REQUIRE(M == 0 || (weights && extra), "null sample arrays");
-  k_composite_train_extra_fwd<<<blocks_for(N * 64, kRayBlock), kRayBlock, 0, as_stream(s)>>>(weights, extra, rays, N, M, K,
-                                                                                            extra_out);
+  hipStream_t st = as_stream(s);
+  CeArgs ce{};
+  if (labels) ce = CeArgs{labels, n_classes, ignore_index, grad_pix, reinterpret_cast<float4*>(workspace)};
+  k_composite_train_extra_fwd<<<blocks_for(N * 64, kRayBlock), kRayBlock, 0, st>>>(weights, extra, rays, N, M, K, extra_out, ce);
+  if (labels) k_ce_finalize<<<1, 1024, 0, st>>>(reinterpret_cast<const float4*>(workspace), N, loss_out);
   return check_launch("composite_rays_extra_forward");
 }
 

@@ -80,6 +80,25 @@ def read_png_gray(path):
 
 
 # ---------------------------------------------------------------------------------------- f4
+def load_3d_masks(path):
+    """Reads ``masks/<scene>.npz`` as /root/reference/nerf_rcnn/run_rcnn.py:652-666 writes it: ``masks`` bool
+    [k, W, L, H] (the output of the reference's ``paste_masks_in_image``, model/utils.py:704-782, thresholded at 0.5),
+    ``scores`` float [k] sorted DESCENDING (top ``save_top_k`` detections, run_rcnn.py:658-664), ``labels`` int [k],
+    ``boxes`` float [k, 6] (x1, y1, z1, x2, y2, z2 in grid units).  Instance id of mask i is i + 1
+    (match_seg.py:99-102 skips ``*_0.png``).  -> dict of numpy arrays with those four keys."""
+    z = np.load(path)
+    missing = {"masks", "scores", "labels", "boxes"} - set(z.files)
+    if missing:
+        raise ValueError(f"{path}: missing keys {sorted(missing)} (expected the layout of run_rcnn.py:665-666)")
+    masks, scores, labels, boxes = z["masks"], z["scores"], z["labels"], z["boxes"]
+    k = masks.shape[0]
+    if masks.ndim != 4 or scores.shape != (k,) or labels.shape != (k,) or boxes.shape != (k, 6):
+        raise ValueError(f"{path}: masks {masks.shape}, scores {scores.shape}, labels {labels.shape}, boxes {boxes.shape} "
+                         "are not [k,W,L,H], [k], [k], [k,6]")
+    return {"masks": masks.astype(bool), "scores": scores.astype(np.float32), "labels": labels.astype(np.int64),
+            "boxes": boxes.astype(np.float32)}
+
+
 @torch.no_grad()
 def soft_project(model, masks, bbox_min, bbox_max, rays_o, rays_d, T_thresh=1e-4, dt_gamma=0, max_steps=1024):
     """NeRF-weighted projection of k voxel masks along rays.  masks [k, W, L, H]; rays [N, 3].

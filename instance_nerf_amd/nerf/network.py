@@ -144,15 +144,22 @@ class _InstanceFieldFn(torch.autograd.Function):
 
 class _InstanceHeadFn(torch.autograd.Function):
     """The instance head of a TRAINING render as one autograd node: samples x [M,3] + their (detached) compositing
-    weights and owning rays -> rendered logits [N,K].  Forward: fused instance field (only the encoder output is kept)
-    + K-channel compositing.  Backward: ONE launch (csrc/field_fused.hip::k_instance_head_bwd) from dL/d(rendered
-    logits) to dL/denc and the three weight gradients - the [M,K] logit gradient, the saved hidden activations, their
-    gradients and the three split-K weight-gradient launches of ``_InstanceFieldFn`` never exist - then the table
-    scatter.  Same arithmetic as the composable chain ``_InstanceFieldFn`` -> ``composite_rays_train(extra=...)``
-    except that the weight gradients are summed in a different order (fp32 MFMA over 16-sample tiles)."""
+    weights and owning rays -> rendered logits [N,K] (+ the mask loss, see below).  Forward: fused instance field (only
+    the encoder output is kept) + K-channel compositing.  Backward: ONE launch (csrc/field_fused.hip::
+    k_instance_head_bwd) from dL/d(rendered logits) to dL/denc and the three weight gradients - the [M,K] logit
+    gradient, the saved hidden activations, their gradients and the three split-K weight-gradient launches of
+    ``_InstanceFieldFn`` never exist - then the table scatter.  Same arithmetic as the composable chain
+    ``_InstanceFieldFn`` -> ``composite_rays_train(extra=...)`` except that the weight gradients are summed in a
+    different order (fp32 MFMA over 16-sample tiles).
+
+    ``labels`` (int64 [N], optional): the cross entropy of the rendered logits against them (``ignore_index`` rows
+    skipped, classes 0 .. n_classes-1) is formed by the compositing kernel itself while a ray's logits are in
+    registers, and the node returns it as a second output; its backward hands the unnormalised softmax - onehot rows to
+    the backward launch together with two device scalars (1 / kept rows, dL/dloss) - no [N,K] pass for the loss at all.
+    """
 
     @staticmethod
-    def forward(ctx, x, weights, sample_ray, rays, n_dev, emb, w0, w1, w2, desc, bound):
+    def forward(ctx, x, weights, sample_ray, rays, n_dev, labels, n_classes, ignore_index, emb, w0, w1, w2, desc, bound):
         lib = _lib.load()
         f32 = torch.float32
         K, M, N, dev = w2.shape[0], x.shape[0], rays.shape[0], x.device
@@ -170,20 +177,42 @@ class _InstanceHeadFn(torch.autograd.Function):
                                            ptr(logits, allow_none=none_ok), ptr(enc, allow_none=none_ok), stream_ptr()),
               "instance_forward_enc")
         out = torch.empty(N, K, dtype=f32, device=dev)
+        dpix = ce_ws = ce_out = None
+        if labels is not None:
+            labels = labels.contiguous().long().reshape(-1)
+            if labels.shape[0] != N:
+                raise RuntimeError(f"ce_labels: {labels.shape[0]} labels for {N} rays")
+            dpix = torch.empty(N, K, dtype=f32, device=dev)
+            ce_ws = torch.empty(max(N, 1) * 4, dtype=f32, device=dev)
+            ce_out = torch.empty(4, dtype=f32, device=dev)
         check(lib.inr_composite_rays_extra_forward(ptr(weights, f32, "weights", allow_none=none_ok),
                                                    ptr(logits, allow_none=none_ok), ptr(rays, torch.int32, "rays"), N, M, K,
-                                                   ptr(out), stream_ptr()), "composite_rays_extra_forward")
-        ctx.save_for_backward(x, enc, weights, sample_ray, pf, pb, emb)
+                                                   ptr(out, allow_none=N == 0), ptr(labels, torch.int64, "labels", allow_none=True),
+                                                   int(n_classes), int(ignore_index), ptr(dpix, allow_none=True),
+                                                   ptr(ce_ws, allow_none=True), ptr(ce_out, allow_none=True), stream_ptr()),
+              "composite_rays_extra_forward")
+        ctx.save_for_backward(x, enc, weights, sample_ray, pf, pb, emb, dpix, ce_out)
         ctx.n_dev, ctx.desc, ctx.bound, ctx.K, ctx.N = n_dev, desc, bound, K, N
-        return out
+        ctx.set_materialize_grads(False)
+        loss = ce_out[0] if labels is not None else out.new_zeros(())
+        return out, loss
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, g_loss):
         lib = _lib.load()
         f32 = torch.float32
-        x, enc, weights, sample_ray, pf, pb, emb = ctx.saved_tensors
+        x, enc, weights, sample_ray, pf, pb, emb, dpix, ce_out = ctx.saved_tensors
         K, M, N, dev = ctx.K, x.shape[0], ctx.N, x.device
-        g = g.contiguous().float()
+        scale_a = scale_b = None
+        if dpix is not None and g_loss is not None and g is None:
+            g_pix = dpix                                  # unnormalised: the launch scales by 1 / kept and dL/dloss
+            scale_a, scale_b = ce_out[1:2], g_loss.detach().float().reshape(1).contiguous()
+        elif dpix is not None and g_loss is not None:     # the caller also differentiates through the rendered logits
+            g_pix = (g.float() + dpix * (ce_out[1] * g_loss.float())).contiguous()
+        elif g is not None:
+            g_pix = g.contiguous().float()
+        else:
+            g_pix = torch.zeros(N, K, dtype=f32, device=dev)
         denc = torch.empty(M, 32, dtype=f32, device=dev)
         gw = torch.empty(64 * 32 + 64 * 64 + K * 64, dtype=f32, device=dev)          # written by the reduce kernel
         gw0, gw1, gw2 = gw[:2048].view(64, 32), gw[2048:6144].view(64, 64), gw[6144:].view(K, 64)
@@ -191,13 +220,15 @@ class _InstanceHeadFn(torch.autograd.Function):
         none_ok = M == 0
         check(lib.inr_instance_head_backward(ptr(enc, allow_none=none_ok), ptr(weights, allow_none=none_ok),
                                              ptr(sample_ray, torch.int32, "sample_ray", allow_none=none_ok),
-                                             ptr(g, f32, "grad_pix", allow_none=N == 0), K, N, M,
-                                             ptr(ctx.n_dev, torch.int32, "n_dev", allow_none=True), ptr(pf), ptr(pb),
+                                             ptr(g_pix, f32, "grad_pix", allow_none=N == 0), K, N, M,
+                                             ptr(ctx.n_dev, torch.int32, "n_dev", allow_none=True),
+                                             ptr(scale_a, f32, "scale_a", allow_none=True),
+                                             ptr(scale_b, f32, "scale_b", allow_none=True), ptr(pf), ptr(pb),
                                              ptr(denc, allow_none=none_ok), ptr(ws), ptr(gw0), ptr(gw1), ptr(gw2),
                                              stream_ptr()), "instance_head_backward")
         g_emb = torch.zeros_like(emb)
         g_emb = _table_backward(lib, x, denc, ctx.desc, M, ctx.bound, g_emb, emb)
-        return None, None, None, None, None, g_emb, gw0, gw1, gw2, None, None
+        return None, None, None, None, None, None, None, None, g_emb, gw0, gw1, gw2, None, None
 
 
 class _NerfFieldFn(torch.autograd.Function):
@@ -520,17 +551,20 @@ class NeRFNetwork(NeRFRenderer):
         params = [self.instance_encoder.embeddings] + [l.weight for l in self.instance_net]
         return (x.is_cuda and torch.is_grad_enabled() and all(p.requires_grad for p in params) and not x.requires_grad)
 
-    def instance_head_train(self, x, weights, sample_ray, rays, n_dev=None):
+    def instance_head_train(self, x, weights, sample_ray, rays, n_dev=None, ce_labels=None, ce_ignore_index=-1):
         """Rendered instance logits [N, K_pad] of a training batch from the ray-major samples x [M,3], their detached
         compositing weights [M] and owning-ray rows int32 [M] (``composite_rays_train(return_weights=True)``) and the
-        march's rays [N,3]; ``n_dev``: the march's device-side sample counter (rows beyond it are not evaluated)."""
+        march's rays [N,3]; ``n_dev``: the march's device-side sample counter (rows beyond it are not evaluated).
+        With ``ce_labels`` (int64 [N]) -> (logits, mean cross entropy over the rows whose label is not
+        ``ce_ignore_index``), the loss formed inside the compositing launch (see ``_InstanceHeadFn``)."""
         K, Kp = self.num_instances, self._k_pad
         w2 = self.instance_net[2].weight
         if Kp != K:
             w2 = torch.nn.functional.pad(w2, (0, 0, 0, Kp - K))       # autograd cuts its gradient back to [K, 64]
-        return _InstanceHeadFn.apply(x.contiguous().float(), weights, sample_ray, rays, n_dev,
-                                     self.instance_encoder.embeddings, self.instance_net[0].weight,
-                                     self.instance_net[1].weight, w2, self.instance_encoder.desc, self.bound)
+        out, loss = _InstanceHeadFn.apply(x.contiguous().float(), weights, sample_ray, rays, n_dev, ce_labels, K,
+                                          ce_ignore_index, self.instance_encoder.embeddings, self.instance_net[0].weight,
+                                          self.instance_net[1].weight, w2, self.instance_encoder.desc, self.bound)
+        return out if ce_labels is None else (out, loss)
 
     @torch.no_grad()
     def nerf_render(self, xyzs, deltas, rays, rays_d, T_thresh=1e-4, want_weights=False, normalised=False):

@@ -178,7 +178,8 @@ class NeRFRenderer(nn.Module):
         return self.instance(x)
 
     def run_cuda(self, rays_o, rays_d, dt_gamma=0, bg_color=None, perturb=False, force_all_rays=False,
-                 max_steps=1024, T_thresh=1e-4, infer_mode="auto", noises=None, field_gate=None, **kwargs):
+                 max_steps=1024, T_thresh=1e-4, infer_mode="auto", noises=None, field_gate=None, ce_labels=None,
+                 ce_ignore_index=-1, **kwargs):
         """rays_o, rays_d [B,N,3] -> dict(image [B,N,3], depth [B,N], weights_sum [B,N] (, instance [B,N,K])).
 
         infer_mode (eval only; all modes render the same image):
@@ -189,6 +190,11 @@ class NeRFRenderer(nn.Module):
           "auto" (default)   picks between the two from the fraction of samples the early-terminating kernel skips /
                              would skip, as counted by the previous inference calls (> terminate_above = 0.4)
           "fused_raymajor" / "wavefront"   reference paths kept for parity tests (ray-major layout / upstream's loop)
+
+        ce_labels (training, networks with an instance head; int64, one per ray): the cross entropy of the rendered
+        instance logits against them (``ce_ignore_index`` rows skipped) is returned as ``results["instance_ce"]`` when
+        the one-node instance head applies (``instance_head_available``); otherwise the key is absent and the caller
+        computes the loss from ``results["instance"]`` as usual.
 
         field_gate (eval, one-pass modes): an object with ``acquire()`` / ``release()`` called on the current stream
         right before and after the field evaluation.  FramePipeline uses it to keep the field kernels of views that
@@ -290,7 +296,14 @@ class NeRFRenderer(nn.Module):
                 # the instance head as ONE autograd node (field + K-channel compositing; one backward launch)
                 weights_sum, depth, image, wbuf, sample_ray = raymarching.composite_rays_train(
                     sigmas, rgbs, deltas, rays, T_thresh, return_weights=True)
-                inst = self.instance_head_train(xyzs, wbuf, sample_ray, rays, n_dev=counter)
+                if ce_labels is not None:
+                    # the mask loss of the instance stage inside the compositing launch (Trainer.train_step passes the
+                    # batch's matched-mask ids): results["instance_ce"] = mean CE over the rows != ce_ignore_index
+                    inst, results["instance_ce"] = self.instance_head_train(
+                        xyzs, wbuf, sample_ray, rays, n_dev=counter, ce_labels=ce_labels.reshape(-1),
+                        ce_ignore_index=ce_ignore_index)
+                else:
+                    inst = self.instance_head_train(xyzs, wbuf, sample_ray, rays, n_dev=counter)
                 results["instance"] = inst[:, :self.num_instances].reshape(*prefix, -1)
             else:
                 extra = self._instance_for_compositing(xyzs) if with_instance else None

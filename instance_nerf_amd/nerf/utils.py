@@ -656,15 +656,20 @@ class Trainer:
             if images.shape[-1] == 4:
                 bg_color = torch.rand_like(images[..., :3])
                 gt = images[..., :3] * images[..., 3:] + bg_color * (1 - images[..., 3:])
+        extra = {}
+        if self.stage == "instance" and getattr(self.model, "cuda_ray", False) and data["rays_o"].is_cuda:
+            extra["ce_labels"] = data["masks"]      # the renderer may form the mask loss inside its compositing launch
         outputs = self.model.render(data["rays_o"], data["rays_d"], staged=False, bg_color=bg_color, perturb=True,
-                                    force_all_rays=False, **self._render_kwargs())
+                                    force_all_rays=False, **extra, **self._render_kwargs())
         if self.stage == "nerf":
             pred = outputs["image"]
             loss = self.criterion(pred, gt).mean()
             return pred, gt, loss
         logits = outputs["instance"]
         K = logits.shape[-1]
-        if logits.is_cuda and K <= 64 and logits.dtype == torch.float32:
+        if "instance_ce" in outputs:
+            loss = outputs["instance_ce"]
+        elif logits.is_cuda and K <= 64 and logits.dtype == torch.float32:
             from .. import raymarching
             loss = raymarching.cross_entropy(logits.reshape(-1, K), data["masks"].reshape(-1), ignore_index=-1)
         else:

@@ -26,7 +26,6 @@ class _RoIAlign3D(torch.autograd.Function):
         ctx.save_for_backward(rois, roi_inds)
         ctx.shape = (N, C, W, L, H)
         ctx.cfg = (out_w, out_l, out_h, float(spatial_scale))
-        ctx.mark_non_differentiable(roi_inds)
         return out
 
     @staticmethod

@@ -31,3 +31,41 @@ def load_feature(npz, normalize_density=True, transpose_yz=False):
     if rgbsigma.dtype == np.uint8:
         rgbsigma = rgbsigma.astype(np.float32) / 255.0
     return rgbsigma
+
+
+def proposals_to_ngp_boxes(proposals, features):
+    """/root/reference/nerf_rcnn/scripts/proposals2ngp.py:9-61 (``ngp_matrix_to_nerf`` + ``proposals_to_ngp_boxes``):
+    axis-aligned proposals [n,6] in GRID units of a feature file -> oriented boxes in the NeRF's world frame, using the
+    metadata keys the feature file carries (``resolution, bbox_min, bbox_max, scale, offset, from_mitsuba`` -
+    proposals2ngp.py:24-29; the keys ``instance_nerf_amd.extract.write_features_npz`` writes).  Checked against the
+    reference's own function through tests/golden/reference_calls.npz.  -> (orientation [n,3,3], position [n,3],
+    extents [n,3])."""
+    res = np.asarray(features["resolution"], dtype=np.float64)
+    lo, hi = np.asarray(features["bbox_min"], np.float64), np.asarray(features["bbox_max"], np.float64)
+    scale, offset = float(features["scale"]), np.asarray(features["offset"], np.float64)
+    from_mitsuba = bool(features["from_mitsuba"])
+    perm = np.array([[0, 1, 0], [0, 0, 1], [1, 0, 0]], dtype=np.float64)          # z up -> y up
+    diag = hi - lo
+    p = np.asarray(proposals, np.float64)
+    box_min, box_max = p[:, :3] / res * diag + lo, p[:, 3:] / res * diag + lo
+    offset = perm @ offset
+    ori, pos, ext = [], [], []
+    for a, b in zip(box_min, box_max):
+        x = perm @ np.concatenate([np.eye(3), ((a + b) * 0.5)[:, None]], axis=1)
+        if from_mitsuba:
+            x[:, [0, 2]] *= -1
+        else:
+            x = x[[2, 0, 1], :]                                                    # cycle axes xyz -> yzx
+        x[:, [1, 2]] *= -1
+        x[:, 3] = (x[:, 3] - offset) / scale
+        ori.append(x[:3, :3]), pos.append(x[:3, 3]), ext.append((b - a) / scale)
+    return np.asarray(ori), np.asarray(pos), np.asarray(ext)
+
+
+def level_mapper(boxes, k_min, k_max, canonical_scale=160, canonical_level=4, eps=1e-6):
+    """/root/reference/nerf_rcnn/model/poolers.py:20-61 (``LevelMapper``, Eqn. 1 of the FPN paper on box volumes):
+    boxes [n,6] -> pyramid level index in [0, k_max - k_min].  float32 arithmetic as the reference's torch code."""
+    b = np.asarray(boxes, np.float32)
+    s = np.power((b[:, 3] - b[:, 0]) * (b[:, 4] - b[:, 1]) * (b[:, 5] - b[:, 2]), np.float32(1.0 / 3.0), dtype=np.float32)
+    lvl = np.floor(np.float32(canonical_level) + np.log2(s / np.float32(canonical_scale), dtype=np.float32) + np.float32(eps))
+    return (np.clip(lvl, k_min, k_max).astype(np.int64) - k_min)

@@ -122,6 +122,30 @@ def test_march_train_large_vs_oracle(rm, room, room_bitfield, bits_dev, marcher)
     assert (x2.cpu().numpy() == cut["xyzs"]).all()
 
 
+def test_march_train_three_wave_per_ray_regimes(rm, room, room_bitfield, bits_dev):
+    """The wave-per-ray marcher has two write passes: up to 8192 rays the count pass parks the samples of its one walk
+    in the workspace and the write pass copies them (staged); above that (up to 32768 rays) the write pass walks
+    again.  Both, and the lane-per-ray marcher, give the C oracle's bits - also when max_steps exceeds the stage's
+    row reservation (1024), which falls back to walking twice."""
+    from oracle import c_port
+    aabb = np.asarray([-1, -1, -1, 1, 1, 1], np.float32)
+    for n, max_steps in ((9000, 1024), (3000, 1500), (3000, 1024)):
+        ro, rd = scene_rays(room, n, cam=n % 8, seed=n)
+        nears, fars = c_port.near_far_from_aabb(ro, rd, aabb, 0.05)
+        ref = c_port.march_rays_train(ro, rd, room_bitfield, 1.0, 1, 128, nears, fars, None, 0.0, max_steps)
+        for mode in ("wave_per_ray", "lane_per_ray"):
+            rm.set_march_mode(mode)
+            try:
+                x, d, dl, rr = rm.march_rays_train(_t(ro), _t(rd), 1.0, bits_dev, 1, 128, _t(nears), _t(fars),
+                                                   max_steps=max_steps, force_all_rays=True)
+            finally:
+                rm.set_march_mode(None)
+            M = ref["total"]
+            assert x.shape[0] == M and (rr.cpu().numpy() == ref["rays"]).all(), (n, max_steps, mode)
+            assert (x.cpu().numpy() == ref["xyzs"]).all() and (dl.cpu().numpy() == ref["deltas"]).all()
+            assert (d.cpu().numpy() == ref["dirs"]).all()
+
+
 def test_march_train_cascades_and_max_steps(rm, marcher):
     """Two cascades with a growing step (dt_gamma > 0), a random sparse bitfield (long skips that leave a
     64-candidate window, isolated hits) and a max_steps small enough to cut rays short."""
@@ -1545,7 +1569,7 @@ def test_instance_head_node_equals_the_composable_chain(level_table, room, room_
     ro, rd = scene_rays(room, 700, cam=3, seed=55)
     labels = np.random.default_rng(5).integers(-1, K, size=700)
 
-    def run(fused):
+    def run(fused, fused_ce=False):
         net = _network({k: v.clone() for k, v in p.items()}, K=K).train()
         net.density_bitfield.copy_(_t(room_bitfield))
         net.freeze_nerf()
@@ -1555,14 +1579,24 @@ def test_instance_head_node_equals_the_composable_chain(level_table, room, room_
                 full = net.render(_t(ro)[None], _t(rd)[None], bg_color=1, perturb=False, force_all_rays=True)
             net.local_step = 0
             net.mean_count = (int(full["num_samples"][0]) * 2 // 3 // 128) * 128
-        out = net.render(_t(ro)[None], _t(rd)[None], bg_color=1, perturb=False, force_all_rays=not drop)
+        extra = {"ce_labels": _t(labels).long()[None]} if fused_ce else {}
+        out = net.render(_t(ro)[None], _t(rd)[None], bg_color=1, perturb=False, force_all_rays=not drop, **extra)
         loss = torch.nn.functional.cross_entropy(out["instance"][0], _t(labels).long(), ignore_index=-1)
+        if fused_ce:       # the loss formed inside the compositing launch: same value, and IT is what gets differentiated
+            assert abs(float(out["instance_ce"]) - float(loss)) < 1e-5 * max(1.0, abs(float(loss)))
+            loss = out["instance_ce"]
+        else:
+            assert "instance_ce" not in out
         loss.backward()
         grads = {n: q.grad.clone() for n, q in net.named_parameters() if q.grad is not None}
         return out["instance"][0].detach().clone(), grads
     inst_a, ga = run(True)
     inst_b, gb = run(False)
-    assert inst_a.shape == (700, K) and torch.equal(inst_a, inst_b)
+    inst_c, gc = run(True, fused_ce=True)
+    assert inst_a.shape == (700, K) and torch.equal(inst_a, inst_b) and torch.equal(inst_a, inst_c)
+    for n in ga:
+        rel = float(torch.linalg.norm(gc[n] - ga[n]) / torch.linalg.norm(ga[n]))
+        assert rel < 2e-5, ("fused ce", n, rel)
     if drop:
         assert (inst_a[-20:] == 0).all() and (inst_a[:20] != 0).any()      # the tail of the ray list was dropped
     assert sorted(ga) == sorted(gb) == ["instance_encoder.embeddings", "instance_net.0.weight", "instance_net.1.weight",
@@ -1571,6 +1605,31 @@ def test_instance_head_node_equals_the_composable_chain(level_table, room, room_
         assert ga[n].shape == gb[n].shape and gb[n].abs().sum() > 0, n
         rel = float(torch.linalg.norm(ga[n] - gb[n]) / torch.linalg.norm(gb[n]))
         assert rel < 2e-5, (n, rel)
+
+
+def test_label_outside_the_classes_poisons_the_loss(level_table, room, room_bitfield):
+    """torch's cross_entropy asserts on the device for a label that is neither ignore_index nor a class; both HIP
+    losses - inr_cross_entropy and the epilogue of the K-channel compositing - return NaN instead of dropping the row
+    silently (round-2 advisor: a detection-count mismatch would otherwise train on fewer rows unnoticed)."""
+    from instance_nerf_amd import raymarching
+    from oracle import field
+    K = 16
+    logits = torch.randn(50, K, device=DEV)
+    labels = torch.randint(0, K, (50,), device=DEV)
+    assert torch.isfinite(raymarching.cross_entropy(logits, labels))
+    labels[7] = K
+    assert torch.isnan(raymarching.cross_entropy(logits, labels))
+    p = field.init_params(seed=2, table=level_table, table_std=1.0, K=K)
+    net = _network(p, K=K).train()
+    net.density_bitfield.copy_(_t(room_bitfield))
+    net.freeze_nerf()
+    ro, rd = scene_rays(room, 64, seed=3)
+    lab = torch.randint(-1, K, (1, 64), device=DEV)
+    out = net.render(_t(ro)[None], _t(rd)[None], bg_color=1, perturb=False, force_all_rays=True, ce_labels=lab)
+    assert torch.isfinite(out["instance_ce"])
+    lab[0, 5] = K + 3
+    out = net.render(_t(ro)[None], _t(rd)[None], bg_color=1, perturb=False, force_all_rays=True, ce_labels=lab)
+    assert torch.isnan(out["instance_ce"])
 
 
 def test_composite_train_with_dropped_rays(rm, room, room_bitfield, bits_dev):

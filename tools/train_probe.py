@@ -18,15 +18,22 @@ tr.global_step = 1          # keep the analytic occupancy grid (no update from t
 batches = [ds.batch() for _ in range(8)]
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 losses = []
+peak = 0
 for i in range(8):
     losses.append(float(tr.train_one_step(batches[i % 8])))
+    peak = max(peak, int(net.step_counter[(net.local_step - 1) % 16, 0]))
+# steady state as after an occupancy update: sample buffers sized from mean_count, no host read-back inside a step
+net.mean_count = (int(peak * 1.02) + 127) // 128 * 128
+for i in range(8):
+    tr.train_one_step(batches[i % 8])
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-n0 = 0
+n_dev = torch.zeros((), dtype=torch.int64, device=dev)
 for i in range(steps):
     l = tr.train_one_step(batches[i % 8])
-    n0 += int(net.step_counter[(net.local_step - 1) % 16, 0])
+    n_dev += net.step_counter[(net.local_step - 1) % 16, 0]       # on the device: no host sync inside the loop
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
+n0 = int(n_dev)
 losses.append(float(l))
 print(f"train step {dt*1e3:.3f} ms, {n0/steps:.0f} samples/step, {n0/steps/dt/1e6:.2f} Msamples/s, loss {losses[0]:.4f} -> {losses[-1]:.4f}")
