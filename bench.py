@@ -297,6 +297,7 @@ def main():
     ap.add_argument("--res", type=int, default=800)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train-probe", action="store_true")
+    ap.add_argument("--train-steps", type=int, default=20, help="timed steps of the secondary training probes")
     ap.add_argument("--pipeline-probe", action="store_true",
                     help="also measure the same frames through FramePipeline (two streams) and report them as \"pipelined\"; "
                          "off by default so that a kernel trace of the default command holds one-stream launches only")
@@ -490,8 +491,8 @@ def main():
         if world == 1:
             # secondary measurements must never cost the headline line: report a failure instead of dying with it
             try:
-                ts = train_probe(dev, rank, world, red_dev)
-                tn = train_probe(dev, rank, world, red_dev, stage="nerf")
+                ts = train_probe(dev, rank, world, red_dev, steps=args.train_steps)
+                tn = train_probe(dev, rank, world, red_dev, steps=args.train_steps, stage="nerf")
             except Exception as e:                        # noqa: BLE001
                 ts = tn = {"error": f"{type(e).__name__}: {e}"[:300]}
         else:
@@ -517,8 +518,8 @@ def main():
                 watchdog.daemon = True
                 watchdog.start()
             try:
-                ts = train_probe(dev, rank, world, red_dev)   # every rank runs it
-                tn = train_probe(dev, rank, world, red_dev, stage="nerf")
+                ts = train_probe(dev, rank, world, red_dev, steps=args.train_steps)   # every rank runs it
+                tn = train_probe(dev, rank, world, red_dev, steps=args.train_steps, stage="nerf")
             except Exception as e:                            # noqa: BLE001
                 if rank == 0:
                     line["train_step"] = line["train_step_nerf"] = {"error": f"{type(e).__name__}: {e}"[:300]}

@@ -338,6 +338,11 @@ class _GradSync:
     def __init__(self):
         self.world_size = 1
         self.enabled = os.environ.get("INR_GRAD_OVERLAP", "1") != "0"
+        # INR_GRAD_DTYPE=bf16: the TABLE gradient travels over the links as bf16 (24.5 instead of 49 MB per trained
+        # grid and step; converted on the way out and back, summed by the collective in bf16 - 8 mantissa bits; Adam
+        # normalises the gradient's scale, so what changes is the direction of a step by ~0.4 %).  Off by default:
+        # the fp32 all-reduce is exact up to summation order.  MLP gradients (a few KB) always go as fp32.
+        self.payload = os.environ.get("INR_GRAD_DTYPE", "fp32").lower()
         self.handles = []
         self.early = {}                 # parameter data_ptr -> (data_ptr, numel) of the gradient whose slices are in flight
 
@@ -345,14 +350,21 @@ class _GradSync:
         return self.enabled and self.world_size > 1 and dist.is_available() and dist.is_initialized()
 
     def reduce_async(self, view):
-        self.handles.append(dist.all_reduce(view, async_op=True))
+        """Sum ``view`` (a contiguous slice of a table gradient) over the ranks, asynchronously; ``finish()`` waits."""
+        if self.payload == "bf16":
+            wire = view.to(torch.bfloat16)
+            self.handles.append((dist.all_reduce(wire, async_op=True), view, wire))
+        else:
+            self.handles.append((dist.all_reduce(view, async_op=True), None, None))
 
     def mark(self, param, grad):
         self.early[param.data_ptr()] = (grad.data_ptr(), grad.numel())
 
     def finish(self):
-        for h in self.handles:
+        for h, view, wire in self.handles:
             h.wait()
+            if wire is not None:
+                view.copy_(wire)
         self.handles = []
 
     def reset(self):
@@ -363,13 +375,16 @@ class _GradSync:
 grad_sync = _GradSync()
 
 
-def allreduce_gradients(params, world_size, bucket_bytes=64 << 20):
+def allreduce_gradients(params, world_size, bucket_bytes=64 << 20, average=True):
     """Gradient all-reduce for ray-batch data parallelism: dense fp32 buckets over
     RCCL (backend 'nccl' on ROCm) or gloo.  The hash-table gradient (49 MB) goes as ONE message - or is already in
     flight, started from inside the backward in two level ranges (``grad_sync``); small MLP gradients are flattened
-    into one bucket."""
+    into one bucket.  ``average=False`` leaves the SUM in the ``.grad`` tensors: the caller folds 1 / world_size into
+    the optimiser (``FusedAdam.step(grad_scale=1 / world_size)``) instead of paying a read-modify-write sweep over
+    every gradient (98 MB of traffic per trained table).  -> the factor the caller still has to apply (1 or
+    1 / world_size)."""
     if world_size <= 1:
-        return
+        return 1.0
     # Every rank must issue the SAME sequence of collectives whatever its batch looked like.  A rank whose rays all
     # missed the volume has no gradient at all (or an autograd function that never ran): it contributes zeros, and a
     # table it did not hand to the collective from inside its backward goes in the same two level ranges, in the same
@@ -393,10 +408,13 @@ def allreduce_gradients(params, world_size, bucket_bytes=64 << 20):
         if grad_sync.active() and split:
             g = g if g.is_contiguous() else g.contiguous()
             p.grad = g
-            handles.append(dist.all_reduce(g[split:], async_op=True))       # fine levels first, as in _table_backward
-            handles.append(dist.all_reduce(g[:split], async_op=True))
+            grad_sync.reduce_async(g[split:])       # fine levels first, as in _table_backward
+            grad_sync.reduce_async(g[:split])
         elif g.numel() * 4 >= bucket_bytes // 4:
-            handles.append(dist.all_reduce(g, async_op=True))
+            if g.is_contiguous():
+                grad_sync.reduce_async(g)           # a table gradient: with the configured payload type
+            else:
+                handles.append(dist.all_reduce(g, async_op=True))
         else:
             small.append(g)
     grads = [p.grad for p in params]
@@ -410,8 +428,11 @@ def allreduce_gradients(params, world_size, bucket_bytes=64 << 20):
     for h in handles:
         h.wait()
     grad_sync.reset()
+    if not average:
+        return 1.0 / world_size
     for g in grads:
         g.div_(world_size)
+    return 1.0
 
 
 def shard_range(n_rays, rank, world_size, align=16):
@@ -792,9 +813,14 @@ class Trainer:
         _, _, loss = self.train_step(data)
         loss.backward()
         params = [p for g in self.optimizer.param_groups for p in g["params"]]
-        allreduce_gradients(params, self.world_size)
+        fused = isinstance(self.optimizer, FusedAdam)
+        # FusedAdam takes the 1 / world_size of the gradient average as a factor inside its sweep
+        scale = allreduce_gradients(params, self.world_size, average=not fused)
         self._lr_step()
-        self.optimizer.step()
+        if fused:
+            self.optimizer.step(grad_scale=scale)
+        else:
+            self.optimizer.step()
         if self.lr_scheduler is not None and self.scheduler_update_every_step:
             self.lr_scheduler.step()
         if self.ema is not None:

@@ -45,22 +45,30 @@ def roi_align_3d(inp, rois, roi_inds, ow, ol, oh, spatial_scale):
     osz = (ow, ol, oh)
     for k in range(K):
         vol = inp[int(roi_inds[k])]
-        start = [float(np.float32(rois[k][a]) * np.float32(spatial_scale)) for a in range(3)]
-        end = [float(np.float32(rois[k][a + 3]) * np.float32(spatial_scale)) for a in range(3)]
-        size = [max(end[a] - start[a], 1.0) for a in range(3)]
-        binsz = [size[a] / osz[a] for a in range(3)]
-        grid = [int(math.ceil(size[a] / osz[a])) for a in range(3)]
+        # RoI geometry in float32, operation by operation as torchvision's kernels (T = float) and the HIP kernel do
+        # it: the sampling grid ceil(size / out) is an integer DECISION - a box whose scaled size is a whole multiple
+        # of the output size within float32 rounding gets one more sample per bin in float64 than in float32 (found
+        # by replaying the reference's recorded calls, tests/test_reference_calls.py: 0.03 absolute on such a box)
+        f32 = np.float32
+        start = [f32(rois[k][a]) * f32(spatial_scale) for a in range(3)]
+        end = [f32(rois[k][a + 3]) * f32(spatial_scale) for a in range(3)]
+        size = [np.maximum(end[a] - start[a], f32(1.0)) for a in range(3)]
+        binsz = [size[a] / f32(osz[a]) for a in range(3)]
+        grid = [int(np.ceil(size[a] / f32(osz[a]))) for a in range(3)]
         count = max(grid[0] * grid[1] * grid[2], 1)
+
+        def coord(a, p, i):        # start + p * bin + (i + 0.5) * bin / grid, float32, left to right
+            return float(start[a] + f32(p) * binsz[a] + (f32(i) + f32(0.5)) * binsz[a] / f32(grid[a]))
         for pw in range(ow):
             for pl in range(ol):
                 for ph in range(oh):
                     acc = np.zeros(C)
                     for ix in range(grid[0]):
-                        x = start[0] + pw * binsz[0] + (ix + 0.5) * binsz[0] / grid[0]
+                        x = coord(0, pw, ix)
                         for iy in range(grid[1]):
-                            y = start[1] + pl * binsz[1] + (iy + 0.5) * binsz[1] / grid[1]
+                            y = coord(1, pl, iy)
                             for iz in range(grid[2]):
-                                z = start[2] + ph * binsz[2] + (iz + 0.5) * binsz[2] / grid[2]
+                                z = coord(2, ph, iz)
                                 acc += _interp(vol, x, y, z)
                     out[k, :, pw, pl, ph] = acc / count
     return out.astype(np.float32)

@@ -25,8 +25,28 @@ def _worker(rank, world, port, q):
     smalls = [torch.nn.Parameter(torch.zeros(64, 32)), torch.nn.Parameter(torch.zeros(3, 64))]
     for i, p in enumerate([big] + smalls):
         p.grad = torch.full_like(p, float(rank + 1) * (i + 1))
-    allreduce_gradients([big] + smalls, world)
+    assert allreduce_gradients([big] + smalls, world) == 1.0
     ok = all(torch.allclose(p.grad, torch.full_like(p, 1.5 * (i + 1))) for i, p in enumerate([big] + smalls))
+    # average=False: the SUM stays in .grad and the caller gets the factor to fold into the optimiser
+    for i, p in enumerate([big] + smalls):
+        p.grad = torch.full_like(p, float(rank + 1) * (i + 1))
+    ok = ok and allreduce_gradients([big] + smalls, world, average=False) == 0.5
+    ok = ok and all(torch.allclose(p.grad, torch.full_like(p, 3.0 * (i + 1))) for i, p in enumerate([big] + smalls))
+    # bf16 payload for the table gradient (INR_GRAD_DTYPE=bf16): same sums to bf16 accuracy, small tensors stay fp32
+    from instance_nerf_amd.nerf import utils
+    utils.grad_sync.payload = "bf16"
+    gen = torch.Generator().manual_seed(rank)
+    mine = torch.randn(5_000_000, generator=gen)
+    other = torch.randn(5_000_000, generator=torch.Generator().manual_seed(1 - rank))
+    big.grad = mine.clone()
+    smalls[0].grad = torch.full_like(smalls[0], 1.0 + 2 ** -12)        # not representable in bf16
+    smalls[1].grad = torch.ones_like(smalls[1])
+    allreduce_gradients([big] + smalls, world, average=False)
+    want = mine + other
+    ok = ok and float((big.grad - want).abs().max()) < 2 ** -6 * float(want.abs().max())
+    ok = ok and float((big.grad - want).abs().max()) > 0                # it really went through bf16
+    ok = ok and torch.equal(smalls[0].grad, torch.full_like(smalls[0], 2.0 + 2 ** -11))
+    utils.grad_sync.payload = "fp32"
     # bench-style reductions: max of times, sum of samples
     t = torch.tensor([1.0 + rank], dtype=torch.float64)
     n = torch.tensor([100.0 * (rank + 1)], dtype=torch.float64)

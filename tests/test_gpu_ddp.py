@@ -230,3 +230,32 @@ def test_a_rank_whose_batch_misses_the_volume_keeps_the_collectives_in_step(stag
     res = sorted(res, key=lambda r: r[0])
     for k in res[0][2]:
         assert (res[0][2][k] == res[1][2][k]).all(), k
+
+
+def test_bench_logic_with_eight_ranks_on_one_gpu():
+    """The driver's 8-GPU command - `python -m torch.distributed.run --nproc-per-node 8 bench.py --gpus 8` - with the
+    eight ranks sharing this box's one GPU over gloo (INR_DIST_BACKEND=gloo): views sharded over 8 ranks, max-over-
+    ranks time, sum of samples, and the configs[3] training probe with its per-step gradient all-reduce in two level
+    ranges started from inside the backward - every collective of the N = 8 path runs, only the transport differs from
+    the RCCL run (which no single-GPU box can exercise)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, INR_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
+           "--res", "200", "--train-steps", "3"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{") and '"metric"' in l]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["scaling"] == "weak" and line["value"] > 0 and line["steps"] == 2
+    assert line["config"]["rays_per_step"] == 200 * 200 and "8 GPU" in line["config"]["parallelism"]
+    for key in ("train_step", "train_step_nerf"):
+        t = line[key]
+        assert "error" not in t, t
+        assert t["n_gpus"] == 8 and t["samples_per_step"] > 8 * 50_000       # the sum over the eight ranks' batches
+        assert 48.0 < t["allreduce_mb_per_step"] < 51.0                       # one 49 MB table + the MLP weights
+        assert t["loss_last"] == t["loss_last"] and t["roofline"]["frac"] > 0

@@ -128,6 +128,8 @@ def test_hip_roi_align_replays_the_reference_calls(ref):
         x = torch.from_numpy(c["input"]).cuda().requires_grad_(True)
         out = roi_align_3d(x, rois, inds, *c["sizes"], c["scale"])
         want = roialign.roi_align_3d(c["input"], c["rois"], c["roi_inds"], *c["sizes"], c["scale"])
-        assert out.shape == want.shape and np.abs(out.detach().cpu().numpy() - want).max() < 1e-5, i
+        # fp32 sums of up to 9^3 samples per bin (the 130-voxel box on the finest level) against the float64 oracle
+        err = np.abs(out.detach().cpu().numpy() - want).max()
+        assert out.shape == want.shape and err < 5e-5, (i, err)
         out.sum().backward()                                                # the pooler's output feeds a trained head
         assert x.grad is not None and torch.isfinite(x.grad).all()

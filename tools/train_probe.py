@@ -13,7 +13,8 @@ net = NeRFNetwork(cuda_ray=True, bound=1, min_near=0.05, density_thresh=10, num_
 ds = SyntheticRoomDataset(dev, num_rays=4096, num_instances=64, sort_pixels=os.environ.get("SORT_RAYS", "0") == "1")
 net.fused_instance_head = os.environ.get("FUSED_HEAD", "1") == "1"
 net.density_bitfield.copy_(torch.from_numpy(ds.room.density_bitfield(128, 1.0)).to(dev))
-tr = Trainer("probe", None, net, stage="instance", device=dev, iters=1000, update_extra_interval=10 ** 9)
+tr = Trainer("probe", None, net, stage="instance", device=dev, iters=1000, update_extra_interval=10 ** 9,
+             use_graph=os.environ.get("USE_GRAPH", "0") == "1")
 tr.global_step = 1          # keep the analytic occupancy grid (no update from the untrained NeRF)
 batches = [ds.batch() for _ in range(8)]
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 40
