@@ -43,6 +43,14 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define INR_PROBE_MODE 0
 #endif
 
+// ns-1 (BASELINE north star: "LDS staging of per-level feature tiles"): level 0 of the table (dense, 4 920 rows =
+// 39 KB) resident in LDS for the whole launch of the eval kernel k_nerf_fwd<true, true>, its eight look-ups per sample
+// served by ds_read_b64.  Built only by tools/build_probe.py (NAME=-DINR_LDS_LEVEL0=1) for the A/B of round 3; the
+// result is in profiles/r03_NOTES.txt.
+#ifndef INR_LDS_LEVEL0
+#define INR_LDS_LEVEL0 0
+#endif
+
 // packed-buffer section offsets, in floats
 constexpr int kSig0 = 0;                       // 64 x 32  : 4 mt x 8 ks
 constexpr int kSig1 = kSig0 + 64 * 32;         // 16 x 64  : 1 mt x 16 ks
@@ -182,7 +190,8 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 template <bool kFineHashed>
 __device__ __forceinline__ void issue_gathers_impl(const LevelRec* __restrict__ my_recs, __amdgpu_buffer_rsrc_t rsrc,
-                                                   float x0, float x1, float x2, Gathered& g) {
+                                                   float x0, float x1, float x2, Gathered& g,
+                                                   const u32x2* __restrict__ lds0 = nullptr) {
   const int q = (threadIdx.x >> 4) & 3;
   const uint32_t side = (uint32_t)(q & 1);
   const LevelRec* pair_recs = my_recs - 4 * (q & 1);     // records of the even lane of this pair
@@ -204,6 +213,17 @@ __device__ __forceinline__ void issue_gathers_impl(const LevelRec* __restrict__ 
     for (int k = 0; k < 8; ++k) {
       const uint32_t c = cx + (k & 1);
       const uint32_t idx = (h ? (c ^ yz[k >> 1]) : (c + yz[k >> 1])) & mask;
+#if INR_LDS_LEVEL0
+      if (lds0 && li == 0) {
+        // branch-free: every lane reads LDS (lanes q != 0 a valid but unused row) and every lane issues the buffer
+        // load - lanes q == 0 with an out-of-range offset, which the bounds-checked descriptor answers with 0
+        // without a cache look-up - then one select per register
+        const u32x2 lv = lds0[q == 0 ? idx : 0u];
+        const u32x2 gv = gather_row(rsrc, q == 0 ? 0xFFFFFFF0u : base + idx * 8u);
+        g.c[li][k] = q == 0 ? lv : gv;
+        continue;
+      }
+#endif
       g.c[li][k] = gather_row(rsrc, base + idx * 8u);
     }
   }
@@ -242,9 +262,10 @@ __device__ __forceinline__ void issue_gathers_impl(const LevelRec* __restrict__ 
 }
 
 __device__ __forceinline__ void issue_gathers(const LevelRec* __restrict__ my_recs, const bool (&all_hashed)[4],
-                                              __amdgpu_buffer_rsrc_t rsrc, float x0, float x1, float x2, Gathered& g) {
-  if (all_hashed[2] && all_hashed[3]) issue_gathers_impl<true>(my_recs, rsrc, x0, x1, x2, g);
-  else issue_gathers_impl<false>(my_recs, rsrc, x0, x1, x2, g);
+                                              __amdgpu_buffer_rsrc_t rsrc, float x0, float x1, float x2, Gathered& g,
+                                              const u32x2* __restrict__ lds0 = nullptr) {
+  if (all_hashed[2] && all_hashed[3]) issue_gathers_impl<true>(my_recs, rsrc, x0, x1, x2, g, lds0);
+  else issue_gathers_impl<false>(my_recs, rsrc, x0, x1, x2, g, lds0);
 }
 
 __device__ __forceinline__ f32x2 row2(const u32x2 v) {
@@ -591,6 +612,18 @@ __global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_nerf_fwd(cons
   for (int i = threadIdx.x; i < kStage; i += kFieldThreads) wl[i] = packed[i];
   LevelRec* recs = reinterpret_cast<LevelRec*>(wl + kStage);
   stage_level_recs(G, recs);
+  const u32x2* lds0 = nullptr;
+#if INR_LDS_LEVEL0
+  if constexpr (kTable) {
+    u32x2* l0 = reinterpret_cast<u32x2*>(recs + 16);
+    const uint32_t rows0 = G.offsets[1] - G.offsets[0];
+    if (G.mask[0] == 0 && rows0 * 8u <= 40960u) {            // dense level 0 that fits the reservation
+      const u32x2* src = reinterpret_cast<const u32x2*>(emb) + G.offsets[0];
+      for (uint32_t i = threadIdx.x; i < rows0; i += kFieldThreads) l0[i] = src[i];
+      lds0 = l0;
+    }
+  }
+#endif
   __syncthreads();
 
   constexpr int kWaves = kFieldThreads / 64;
@@ -628,7 +661,7 @@ __global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_nerf_fwd(cons
       uint32_t rec_off = (uint32_t)q * 4u * (uint32_t)sizeof(LevelRec);
       asm volatile("" : "+v"(rec_off));    // opaque per tile: keeps the records in LDS, not hoisted into VGPRs
       issue_gathers(reinterpret_cast<const LevelRec*>(reinterpret_cast<const char*>(recs) + rec_off), all_hashed, rsrc,
-                    me.x0, me.x1, me.x2, g);
+                    me.x0, me.x1, me.x2, g, lds0);
       __builtin_amdgcn_sched_barrier(0);   // all 32 gathers in flight before the first blend waits
       blend(g, enc[0], enc[1]);
     }
@@ -1676,7 +1709,7 @@ int inr_nerf_forward_table(const float* x01, const int32_t* ray_ids, const float
   if (rc) return rc;
   const uint64_t emb_bytes64 = (uint64_t)desc->offsets[desc->num_levels] * 8ull;
   INR_REQUIRE(emb_bytes64 < (1ull << 31), "table larger than 2 GiB is not addressable by the 32-bit gather offsets");
-  const size_t lds = std::max(kNerfFloats * sizeof(float) + kLevelRecBytes, (size_t)g_field_lds_min);
+  const size_t lds = std::max(kNerfFloats * sizeof(float) + kLevelRecBytes + (INR_LDS_LEVEL0 ? 40960 : 0), (size_t)g_field_lds_min);
   const int grid = grid_for(k_nerf_fwd<true, true>, lds, (M + 15) / 16);
   k_nerf_fwd<true, true><<<grid, kFieldThreads, lds, as_stream(s)>>>(
       x01, nullptr, M, nullptr, bound, reinterpret_cast<const float2*>(embeddings), (uint32_t)emb_bytes64, G,

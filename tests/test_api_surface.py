@@ -210,3 +210,31 @@ def test_hip_path_refuses_cpu_tensors():
         pytest.skip("library not built")
     with pytest.raises(RuntimeError, match="GPU tensor"):
         raymarching.near_far_from_aabb(torch.zeros(4, 3), torch.ones(4, 3), torch.tensor([-1., -1, -1, 1, 1, 1]), 0.2)
+
+
+def test_registered_custom_ops():
+    """BASELINE north star: "PyTorch-ROCm custom ops over a thin C-ABI" - the extension-level entry points are
+    registered with the dispatcher (torch.ops.inr.*) with schemas, fake implementations (shape inference without a
+    GPU: torch.compile / export can trace through them) and autograd formulas."""
+    import torch
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    from instance_nerf_amd import ops
+    from instance_nerf_amd.gridencoder import level_table
+    for name in ("near_far_from_aabb", "march_rays_train", "composite_rays_train", "grid_encode", "nerf_forward"):
+        assert name in ops.OPS and hasattr(torch.ops.inr, name), name
+    sch = str(torch.ops.inr.composite_rays_train.default._schema)
+    assert sch.startswith("inr::composite_rays_train(Tensor sigmas, Tensor rgbs, Tensor deltas, Tensor rays, float T_thresh)")
+    targs = ops.table_args(level_table(desired_resolution=2048))
+    assert len(targs[0]) == 17 and len(targs[1]) == 16 and targs[0][-1] == 6119864
+    with FakeTensorMode():
+        ro = torch.empty(40, 3)
+        n, f = torch.ops.inr.near_far_from_aabb(ro, ro, torch.empty(6), 0.2)
+        assert n.shape == f.shape == (40,)
+        x, d, dl, rays, counter = torch.ops.inr.march_rays_train(ro, ro, 1.0, torch.empty(128 ** 3 // 8, dtype=torch.uint8),
+                                                                 1, 128, n, f, None, 0.0, 1024, 4096)
+        assert x.shape == (4096, 3) and dl.shape == (4096, 2) and rays.shape == (40, 3) and counter.shape == (2,)
+        enc = torch.ops.inr.grid_encode(x, torch.empty(targs[0][-1], 2, requires_grad=True), 1.0, *targs)
+        assert enc.shape == (4096, 32) and enc.requires_grad
+        ws, depth, image = torch.ops.inr.composite_rays_train(torch.empty(4096, requires_grad=True), torch.empty(4096, 3), dl,
+                                                             rays, 1e-4)
+        assert ws.shape == depth.shape == (40,) and image.shape == (40, 3) and image.requires_grad

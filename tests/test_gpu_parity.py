@@ -2025,3 +2025,43 @@ def test_captured_training_step_equals_eager(stage):
         assert torch.linalg.norm(p - q) < 1e-2 * torch.linalg.norm(p)
     for p, q in zip(a[3], b[3]):
         assert torch.linalg.norm(p - q) < 1e-2 * torch.linalg.norm(p)
+
+
+def test_render_through_the_registered_custom_ops(params_k16, room, room_bitfield, level_table):
+    """torch.ops.inr.*: a training-mode render assembled from the registered ops - ray/box test, march, hash-grid
+    encode + tiny MLPs (torch), compositing - equals the module path (NeRFNetwork.render) on the same rays: sample
+    counts exactly, image within fp32 rounding of the unfused arithmetic, and gradients flow to the table through the
+    ops' registered autograd formulas; the fused no-grad op gives the module's sigma / rgb bit for bit."""
+    from instance_nerf_amd import ops  # noqa: F401  (registers torch.ops.inr)
+    net = _network({k: v.clone() for k, v in params_k16.items()}, K=0).train()
+    net.density_bitfield.copy_(_t(room_bitfield))
+    ro, rd = scene_rays(room, 300, seed=71)
+    ro_t, rd_t = _t(ro), _t(rd)
+    targs = ops.table_args(net.encoder.table)
+    nears, fars = torch.ops.inr.near_far_from_aabb(ro_t, rd_t, net.aabb_train, 0.05)
+    xyzs, dirs, deltas, rays, counter = torch.ops.inr.march_rays_train(ro_t, rd_t, 1.0, net.density_bitfield, 1, 128, nears,
+                                                                        fars, None, 0.0, 1024, -1)
+    emb = net.encoder.embeddings
+    enc = torch.ops.inr.grid_encode(xyzs, emb, 1.0, *targs)
+    h = torch.relu(enc @ net.sigma_net[0].weight.t()) @ net.sigma_net[1].weight.t()
+    sigma = torch.exp(h[:, 0])
+    cin = torch.cat([net.encoder_dir(dirs), h[:, 1:]], -1)
+    c = torch.relu(torch.relu(cin @ net.color_net[0].weight.t()) @ net.color_net[1].weight.t()) @ net.color_net[2].weight.t()
+    rgb = torch.sigmoid(c)
+    ws, depth, image = torch.ops.inr.composite_rays_train(sigma, rgb, deltas, rays, 1e-4)
+    image = image + (1 - ws)[:, None]
+    ref = net.render(ro_t[None], rd_t[None], bg_color=1, perturb=False, force_all_rays=True)
+    assert int(counter[0]) == int(ref["num_samples"][0]) == xyzs.shape[0] > 5000
+    assert (image - ref["image"][0]).abs().max() < 2e-4
+    image.square().mean().backward()
+    g_ops = emb.grad.clone()
+    emb.grad = None
+    ref["image"].square().mean().backward()
+    assert g_ops.abs().sum() > 0
+    assert float(torch.linalg.norm(g_ops - emb.grad) / torch.linalg.norm(emb.grad)) < 2e-3
+    with torch.no_grad():
+        s_mod, c_mod = net(xyzs, dirs)
+        s_op, c_op = torch.ops.inr.nerf_forward(xyzs, dirs, emb, net.sigma_net[0].weight, net.sigma_net[1].weight,
+                                                net.color_net[0].weight, net.color_net[1].weight, net.color_net[2].weight,
+                                                1.0, *targs)
+    assert torch.equal(s_mod, s_op) and torch.equal(c_mod, c_op)
