@@ -57,7 +57,7 @@ def build_network(dev, seed=0):
     return net.eval(), room
 
 
-def cpu_baseline(room, net, frame0=None, chunk=16384, budget_s=12.0, max_chunks=40):
+def cpu_baseline(room, net, frame0=None, chunk=16384, budget_s=12.0, max_chunks=40, render_view0=None):
     """The C restatement of the whole path (oracle/c/inr_oracle.c through oracle/c_port.py, kind 'port': slab test ->
     occupancy march -> hash-grid gather + SH + MLPs -> compositing, one ray at a time, OpenMP over rays on every
     host core) on a bounded sample of the same workload: chunks of random pixels of view 0 until ~budget_s seconds
@@ -102,6 +102,23 @@ def cpu_baseline(room, net, frame0=None, chunk=16384, budget_s=12.0, max_chunks=
                   "max_abs_diff": float(np.abs(got - ref).max()),
                   "psnr_db": round(10.0 * np.log10(1.0 / mse), 1) if mse > 0 else None,
                   "tolerance": "tests: 1e-4 per channel (fp32 path, bf16x3-split MLP GEMMs)"}
+        if render_view0 is not None:
+            # The throughput network is upstream's initialisation (table U(-1e-4, 1e-4)): sigma ~ 1 and rgb ~ 0.5
+            # everywhere, so the comparison above says little.  Once more with an O(1) table - U(-1, 1), every level
+            # matters, rays become semi-transparent - outside any timed region: 16384 random pixels of view 0.
+            with torch.no_grad():
+                net.encoder.embeddings.uniform_(-1.0, 1.0, generator=torch.Generator(device=net.encoder.embeddings.device).manual_seed(5))
+            got = render_view0().reshape(-1, 3).cpu().numpy()
+            p["embeddings"] = net.encoder.embeddings.detach().float().cpu()
+            inds = np.sort(perm[:16384])
+            r = orays.get_rays(poses[:1], intr, H, W, inds=inds)
+            ref = c_port.render(r["rays_o"][0], r["rays_d"][0], p, table, bits, min_near=0.05)
+            d = got[inds].astype(np.float64) - ref["image"].astype(np.float64)
+            parity["o1_table"] = {"what": "the same network with the table redrawn from U(-1,1) (O(1) densities and colours, "
+                                          "semi-transparent rays), 16384 random pixels of view 0, untimed",
+                                  "max_abs_diff": float(np.abs(d).max()),
+                                  "psnr_db": round(10.0 * np.log10(1.0 / float(np.mean(d ** 2))), 1) if np.any(d) else None,
+                                  "mean_opacity": round(float(ref["weights_sum"].mean()), 3)}
     return base, parity
 
 
@@ -289,6 +306,89 @@ def instance_render_probe(dev, frames=8):
             "frac_of_hbm_peak": round(n * 2 * BYTES_PER_SAMPLE / dt / 1e9 / HBM_PEAK_GBS, 4)}
 
 
+def trained_scene_probe(dev, steps=1500, with_oracle=True):
+    """Secondary measurement: rendering a TRAINED scene.  The headline scene is an untrained (transparent) field, so no
+    ray of it ever terminates; a trained 3D-FRONT room is opaque.  Here the NeRF of the synthetic room is trained for
+    `steps` steps (400x400 views, occupancy grid learned by update_extra_state - the product's own Trainer), then the
+    eight 800x800 bench views are rendered in the three inference modes: ms per frame, marched vs evaluated samples,
+    time and roofline fraction of the field kernel, and - on 4096 random pixels of view 0 - the difference to the C
+    oracle run with the trained weights and the learned bitfield."""
+    from instance_nerf_amd.nerf import NeRFNetwork
+    from instance_nerf_amd.nerf.provider import SyntheticRoomDataset
+    from instance_nerf_amd.nerf.utils import Trainer, get_rays
+    torch.manual_seed(0)
+    net = NeRFNetwork(cuda_ray=True, bound=1, min_near=0.05, density_thresh=10).to(dev)
+    ds = SyntheticRoomDataset(dev, H=400, W=400, n_views=24, num_rays=4096)
+    tr = Trainer("trained", None, net, stage="nerf", device=dev, lr=1e-2, iters=steps)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tr.train_one_step(ds.batch())
+    torch.cuda.synchronize()
+    train_s = time.perf_counter() - t0
+    net.eval()
+    poses, intr, H, W = ds.room.cameras()
+    pd = torch.from_numpy(poses).to(dev)
+    ev = []
+
+    def timed(fn):
+        def wrapper(*a, **kw):
+            st = torch.cuda.current_stream()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st)
+            out = fn(*a, **kw)
+            e1.record(st)
+            ev.append((e0, e1))
+            return out
+        return wrapper
+    net.forward_table = timed(net.forward_table)
+    net.nerf_render = timed(net.nerf_render)
+    out = {"workload": f"NeRF of the synthetic room trained {steps} steps (4096 rays, 400x400 views, learned occupancy "
+                       "grid), then the 8 bench views at 800x800", "train_seconds": round(train_s, 1),
+           "occupied_cells": round(float((net.density_grid > min(net.mean_density, net.density_thresh)).float().mean()), 4)}
+    frame0 = None
+    for mode in ("fused", "fused_terminate", "auto"):
+        def frame(v):
+            r = get_rays(pd[v:v + 1], intr, H, W, patch=4)
+            with torch.no_grad():
+                return r, net.render(r["rays_o"], r["rays_d"], bg_color=1, infer_mode=mode)
+        frame(0)
+        frame(1)                                       # "auto": the second call knows the first one's skippable fraction
+        torch.cuda.synchronize()
+        ev.clear()
+        t0 = time.perf_counter()
+        res = [frame(v) for v in range(8)]
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 8
+        marched = sum(int(o["num_samples"][0]) for _, o in res)
+        evaluated = sum(int(o["num_evaluated"][0]) if "num_evaluated" in o else int(o["num_samples"][0]) for _, o in res)
+        kms = sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1)
+        out[mode] = {"ms_per_frame": round(dt * 1e3, 3), "marched_msamples": round(marched / 8 / 1e6, 2),
+                     "evaluated_msamples": round(evaluated / 8 / 1e6, 2), "field_kernel_ms": round(kms, 3),
+                     "field_frac_of_hbm_peak": round(evaluated / 8 * BYTES_PER_SAMPLE / (kms / 1e3) / 1e9 / HBM_PEAK_GBS, 4),
+                     "path_taken": "terminate" if "num_evaluated" in res[-1][1] else "two-kernel"}
+        if mode == "auto":
+            r0, o0 = res[0]
+            frame0 = torch.empty(H * W, 3, device=dev)
+            frame0[r0["inds"][0]] = o0["image"][0]
+            out["mean_opacity"] = round(float(o0["weights_sum"].mean()), 3)
+    if with_oracle:
+        from oracle import c_port, hashgrid, rays as orays
+        sd = net.state_dict()
+        p = {"embeddings": sd["encoder.embeddings"], "sigma_w0": sd["sigma_net.0.weight"], "sigma_w1": sd["sigma_net.1.weight"],
+             "color_w0": sd["color_net.0.weight"], "color_w1": sd["color_net.1.weight"], "color_w2": sd["color_net.2.weight"]}
+        p = {k: v.detach().float().cpu() for k, v in p.items()}
+        inds = np.sort(np.random.default_rng(11).permutation(H * W)[:4096])
+        r = orays.get_rays(poses[:1], intr, H, W, inds=inds)
+        ref = c_port.render(r["rays_o"][0], r["rays_d"][0], p, hashgrid.level_table(), net.density_bitfield.cpu().numpy(),
+                            min_near=0.05)
+        got = frame0.cpu().numpy()[inds].astype(np.float64)
+        mse = float(np.mean((got - ref["image"].astype(np.float64)) ** 2))
+        out["parity"] = {"against": "C oracle, trained weights + learned bitfield, 4096 random pixels of view 0 (auto mode)",
+                         "max_abs_diff": float(np.abs(got - ref["image"]).max()),
+                         "psnr_db": round(10.0 * np.log10(1.0 / mse), 1) if mse > 0 else None}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -298,6 +398,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train-probe", action="store_true")
     ap.add_argument("--train-steps", type=int, default=20, help="timed steps of the secondary training probes")
+    ap.add_argument("--no-trained-scene", action="store_true", help="skip the trained-scene rendering leg (~15 s)")
     ap.add_argument("--pipeline-probe", action="store_true",
                     help="also measure the same frames through FramePipeline (two streams) and report them as \"pipelined\"; "
                          "off by default so that a kernel trace of the default command holds one-stream launches only")
@@ -485,7 +586,8 @@ def main():
             except Exception as e:                            # noqa: BLE001
                 line["pipelined"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"], line["parity"] = cpu_baseline(room, net, step(0)["frame"])
+            line["cpu_baseline"], line["parity"] = cpu_baseline(room, net, step(0)["frame"],
+                                                                render_view0=lambda: step(0)["frame"])
     if not args.no_train_probe:
         del net                                       # the probe builds its own (instance-head) network
         if world == 1:
@@ -539,6 +641,11 @@ def main():
                 line["render_instance"] = instance_render_probe(dev)
             except Exception as e:                            # noqa: BLE001
                 line["render_instance"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            if world == 1 and not args.no_trained_scene:
+                try:
+                    line["trained_scene"] = trained_scene_probe(dev, with_oracle=not args.no_cpu_baseline)
+                except Exception as e:                        # noqa: BLE001
+                    line["trained_scene"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -168,6 +168,9 @@ struct Gathered {
   u32x2 f[4][4];      // fine slots: this lane's x side, [level of the pair][yz corner]
   float cfx[2], cfy[2], cfz[2];
   float fwx[4], ffy[4], ffz[4];   // fine: weight of this lane's x side, y / z fractions
+#if INR_LDS_LEVEL0
+  u32x2 l0[8];        // level 0 out of LDS (lanes q == 0); selected against c[0][k] in blend(), AFTER all loads are out
+#endif
 };
 
 // ONE wave-uniform branch around the whole gather sequence, none inside it.  Round 1 chose between the xor-only and
@@ -218,9 +221,8 @@ __device__ __forceinline__ void issue_gathers_impl(const LevelRec* __restrict__ 
         // branch-free: every lane reads LDS (lanes q != 0 a valid but unused row) and every lane issues the buffer
         // load - lanes q == 0 with an out-of-range offset, which the bounds-checked descriptor answers with 0
         // without a cache look-up - then one select per register
-        const u32x2 lv = lds0[q == 0 ? idx : 0u];
-        const u32x2 gv = gather_row(rsrc, q == 0 ? 0xFFFFFFF0u : base + idx * 8u);
-        g.c[li][k] = q == 0 ? lv : gv;
+        g.l0[k] = lds0[q == 0 ? idx : 0u];
+        g.c[li][k] = gather_row(rsrc, q == 0 ? 0xFFFFFFF0u : base + idx * 8u);
         continue;
       }
 #endif
@@ -276,7 +278,10 @@ __device__ __forceinline__ f32x2 row2(const u32x2 v) {
 // trilinear blend: weight = (wx*wy)*wz, accumulated with fma - coarse levels in corner order 0..7, fine levels as
 // (this side's corners in yz order) and then x side 0 + x side 1.
 // out[s], s = 0..7 <-> feature 16*(s>>2) + 4q + (s&3).
-__device__ __forceinline__ void blend(const Gathered& g, f32x4& lo, f32x4& hi) {
+__device__ __forceinline__ void blend(const Gathered& g, f32x4& lo, f32x4& hi, bool use_l0 = false) {
+#if INR_LDS_LEVEL0
+  const bool from_lds = use_l0 && ((threadIdx.x >> 4) & 3) == 0;
+#endif
 #pragma unroll
   for (int li = 0; li < 2; ++li) {
     const f32x2 wx = {1.0f - g.cfx[li], g.cfx[li]};
@@ -287,6 +292,14 @@ __device__ __forceinline__ void blend(const Gathered& g, f32x4& lo, f32x4& hi) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const f32x2 wk = (k & 1) ? w[k >> 1].yy : w[k >> 1].xx;
+#if INR_LDS_LEVEL0
+      if (li == 0) {
+        const u32x2 a = g.l0[k], b = g.c[0][k];
+        const u32x2 r = {from_lds ? a[0] : b[0], from_lds ? a[1] : b[1]};
+        acc = __builtin_elementwise_fma(wk, row2(r), acc);
+        continue;
+      }
+#endif
       acc = __builtin_elementwise_fma(wk, row2(g.c[li][k]), acc);
     }
     lo[2 * li] = acc.x;
@@ -663,7 +676,7 @@ __global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_nerf_fwd(cons
       issue_gathers(reinterpret_cast<const LevelRec*>(reinterpret_cast<const char*>(recs) + rec_off), all_hashed, rsrc,
                     me.x0, me.x1, me.x2, g, lds0);
       __builtin_amdgcn_sched_barrier(0);   // all 32 gathers in flight before the first blend waits
-      blend(g, enc[0], enc[1]);
+      blend(g, enc[0], enc[1], lds0 != nullptr);
     }
     if constexpr (!kTable) {               // the table feed comes from the marcher, which clamps to the volume
       if (me.oob) enc[0] = enc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1415,7 +1428,8 @@ __global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_instance_rend
 // have all dropped below T_thresh is not evaluated at all: the group stops as soon as its last ray is opaque.
 // This is what upstream's alive-ray loop buys on trained (opaque) scenes, without its per-iteration host sync.
 // On a transparent scene it evaluates exactly the samples of the two-kernel path.  weights (nullable) receives
-// w per sample (0 for skipped samples) for k_instance_render; evaluated[0] += samples actually evaluated.
+// w per sample (0 for skipped samples) for k_instance_render; evaluated[0] += samples of the steps that were evaluated
+// (all rays of the group that have a sample at such a step, terminated or not).
 __global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_nerf_render(
     const float* __restrict__ x, const float* __restrict__ deltas, const int32_t* __restrict__ rays,
     const float* __restrict__ rays_d, int64_t N, int64_t M, float bound, const float2* __restrict__ emb,
@@ -1487,7 +1501,10 @@ __global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_nerf_render(
         if (active && q == 0) wbuf[slot] = 0.0f;          // the instance render reads a weight for every sample
         continue;
       }
-      if (lane == 0) n_eval += __popc(livef);
+      // group-level accounting, the same quantity the two-kernel path's compositing counts as NOT skippable: every
+      // sample of a step that is evaluated at all (a terminated ray inside a live group still rides through the
+      // MFMA tile).  Counting live rays only made infer_mode="auto" compare two different fractions (round-2 advisor).
+      if (lane == 0) n_eval += __popc(field);
       const float2 dl = (q == 0 && live) ? reinterpret_cast<const float2*>(deltas)[slot] : make_float2(0.f, 0.f);
       const float x0 = (xr0 + x_add) / x_div, x1 = (xr1 + x_add) / x_div, x2 = (xr2 + x_add) / x_div;
       f32x4 enc[2];

@@ -188,7 +188,7 @@ class NeRFRenderer(nn.Module):
                              are opaque (measured 4x faster than "fused" on an opaque scene, 1.4x slower on a
                              transparent one)
           "auto" (default)   picks between the two from the fraction of samples the early-terminating kernel skips /
-                             would skip, as counted by the previous inference calls (> terminate_above = 0.4)
+                             would skip, as counted by the previous inference calls (> terminate_above = 0.35)
           "fused_raymajor" / "wavefront"   reference paths kept for parity tests (ray-major layout / upstream's loop)
 
         ce_labels (training, networks with an instance head; int64, one per ray): the cross entropy of the rendered

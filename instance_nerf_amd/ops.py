@@ -62,7 +62,7 @@ def march_rays_train(rays_o: Tensor, rays_d: Tensor, bound: float, density_bitfi
     counter = torch.zeros(2, dtype=I32, device=rays_o.device)
     xyzs, dirs, deltas, rays = raymarching.march_rays_train(
         rays_o, rays_d, bound, density_bitfield, cascade, grid_size, nears, fars, counter, num_samples, False, -1,
-        num_samples <= 0, dt_gamma, max_steps, noises=noises)
+        num_samples <= 0, dt_gamma, max_steps, noises=noises, separate_buffers=True)
     return xyzs, dirs, deltas, rays, counter
 
 

@@ -113,7 +113,7 @@ def packbits(grid, thresh, bitfield=None):
 
 def march_rays_train(rays_o, rays_d, bound, density_bitfield, C, H, nears, fars, step_counter=None,
                      mean_count=-1, perturb=False, align=-1, force_all_rays=False, dt_gamma=0, max_steps=1024,
-                     noises=None):
+                     noises=None, separate_buffers=False):
     """-> xyzs [M,3], dirs [M,3], deltas [M,2], rays int32 [N,3] = (ray, offset, count).
 
     With ``mean_count <= 0`` or ``force_all_rays`` the exact sample count is read
@@ -147,8 +147,12 @@ def march_rays_train(rays_o, rays_d, bound, density_bitfield, C, H, nears, fars,
         M = int(mean_count)
     if align > 0:
         M += align - M % align if M % align else 0
-    buf = torch.zeros(M * 8, dtype=F32, device=dev)      # one fill: rows no ray owns (padding, dropped rays) are zero
-    xyzs, dirs, deltas = buf[:M * 3].view(M, 3), buf[M * 3:M * 6].view(M, 3), buf[M * 6:].view(M, 2)
+    if separate_buffers:     # three allocations (the registered custom op may not return views of one buffer)
+        xyzs, dirs, deltas = (torch.zeros(M, 3, dtype=F32, device=dev), torch.zeros(M, 3, dtype=F32, device=dev),
+                              torch.zeros(M, 2, dtype=F32, device=dev))
+    else:
+        buf = torch.zeros(M * 8, dtype=F32, device=dev)      # one fill: rows no ray owns (padding, dropped rays) are zero
+        xyzs, dirs, deltas = buf[:M * 3].view(M, 3), buf[M * 3:M * 6].view(M, 3), buf[M * 6:].view(M, 2)
     check(lib.inr_march_rays_train_write(*args, M, ptr(nears), ptr(fars), ptr(noises, F32, "noises", allow_none=True),
                                          ptr(rays), ptr(xyzs), ptr(dirs), ptr(deltas), ptr(ws), cap, stream_ptr()),
           "march_rays_train_write")

@@ -1490,6 +1490,21 @@ def test_auto_mode_follows_the_skippable_fraction(params_k16, room, room_bitfiel
                 net.render(r["rays_o"], r["rays_d"], bg_color=1, infer_mode="fused")
             torch.cuda.synchronize()
             assert abs(net._recent_skippable() - real) < 0.02, (net._recent_skippable(), real)
+    # a HALF-transparent scene (rays of a 16-ray group terminate at different depths): both paths must report the SAME
+    # fraction - samples of the steps at which the whole group is dead (round-2 advisor: the terminating kernel used to
+    # count live rays only, so its fraction was larger and "auto" stuck to it once entered)
+    net = _network(params_k16, K=16).eval()
+    net.density_bitfield.copy_(_t(room_bitfield))
+    for density_scale in (3.0, 20.0):
+        net.density_scale = density_scale
+        net.__dict__.pop("_skippable_value", None)
+        with torch.no_grad():
+            net.render(r["rays_o"], r["rays_d"], bg_color=1, infer_mode="fused")
+            torch.cuda.synchronize()
+            predicted = net._recent_skippable()
+            t = net.render(r["rays_o"], r["rays_d"], bg_color=1, infer_mode="fused_terminate")
+        real = 1.0 - int(t["num_evaluated"][0]) / int(t["num_samples"][0])
+        assert 0.0 < real < 0.95 and abs(predicted - real) < 1e-3, (density_scale, predicted, real)
 
 
 @pytest.mark.parametrize("mode", ["auto", "fused_terminate", "fused"])
