@@ -291,6 +291,22 @@ int inr_nerf_backward(const float* grad_sigma, const float* grad_rgb, const floa
                       const float* h1, const float* c1, const float* c2, int64_t M, float density_scale,
                       const float* packed_bwd, float* grad_o, float* grad_zc2, float* grad_zc1, float* grad_so,
                       float* grad_zh1, float* grad_enc, inr_stream_t s);
+/* The NeRF field of a training step in two launches per direction (round 3; the NeRF-stage twin of
+ * inr_instance_forward_enc / inr_instance_head_backward).  Forward: as inr_nerf_forward_train but only the encoder
+ * output [M,32] is kept.  Backward: ONE launch from (dL/dsigma [M], dL/drgb [M,3]) to dL/denc [M,32] and the five
+ * weight gradients - grad_ws0 [64,32], grad_ws1 [16,64], grad_wc0 [64,32] (column 31 is padding), grad_wc1 [64,64],
+ * grad_wc2 [16,64] (rows 0..2 live), written, not accumulated: the forward is recomputed from enc and the view
+ * directions d [M,3] with packed_fwd, the input-gradient chain is inr_nerf_backward's, and the weight gradients are
+ * accumulated on the fp32 matrix cores with the tiles transposed through LDS.  Replaces inr_nerf_backward and five
+ * inr_linear_wgrad calls and the 1088 B per sample of saved activations.  workspace:
+ * inr_instance_head_workspace_bytes() bytes.                                                                      */
+int inr_nerf_forward_enc(const float* x, const float* d, int64_t M, float bound, const float* embeddings,
+                         const inr_grid_desc* desc /*host*/, const float* packed_fwd, float* sigma, float* rgb,
+                         float* enc, inr_stream_t s);
+int inr_nerf_head_backward(const float* enc, const float* d, const float* grad_sigma, const float* grad_rgb, int64_t M,
+                           float density_scale, const float* packed_fwd, const float* packed_bwd, float* grad_enc,
+                           void* workspace, float* grad_ws0, float* grad_ws1, float* grad_wc0, float* grad_wc1,
+                           float* grad_wc2, inr_stream_t s);
 /* Training path of the instance field (a13): weights are packed ON THE DEVICE every step (forward layout as
  * inr_instance_pack_weights, plus the transposed sections the input-gradient kernel uses); the forward also
  * stores the encoder output [M,32] and both hidden activations [M,64]; inr_instance_backward turns

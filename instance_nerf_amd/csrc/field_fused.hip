@@ -43,13 +43,12 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define INR_PROBE_MODE 0
 #endif
 
-// ns-1 (BASELINE north star: "LDS staging of per-level feature tiles"): level 0 of the table (dense, 4 920 rows =
-// 39 KB) resident in LDS for the whole launch of the eval kernel k_nerf_fwd<true, true>, its eight look-ups per sample
-// served by ds_read_b64.  Built only by tools/build_probe.py (NAME=-DINR_LDS_LEVEL0=1) for the A/B of round 3; the
-// result is in profiles/r03_NOTES.txt.
-#ifndef INR_LDS_LEVEL0
-#define INR_LDS_LEVEL0 0
-#endif
+// (ns-1, BASELINE north star "LDS staging of per-level feature tiles": besides the weights and the level records,
+//  level 0 of the table - dense, 4 920 rows = 39 KB - was made LDS-resident for the eval kernel in round 3, its eight
+//  look-ups per sample served by ds_read_b64.  Bit-identical, measured, rejected: 5.37-5.40 vs 5.20-5.25 ms per 37 M
+//  samples with the select placed after all loads are out (-3.3 % L1 look-ups, +8 % VALU instructions: the look-ups it
+//  removes were the cheapest - 16 samples of a tile share one or two lines of level 0), 6.73 ms with the select inside
+//  the issue loop.  profiles/r03_NOTES.txt section 6, r03f / r03g PMC files.)
 
 // packed-buffer section offsets, in floats
 constexpr int kSig0 = 0;                       // 64 x 32  : 4 mt x 8 ks
@@ -168,9 +167,6 @@ struct Gathered {
   u32x2 f[4][4];      // fine slots: this lane's x side, [level of the pair][yz corner]
   float cfx[2], cfy[2], cfz[2];
   float fwx[4], ffy[4], ffz[4];   // fine: weight of this lane's x side, y / z fractions
-#if INR_LDS_LEVEL0
-  u32x2 l0[8];        // level 0 out of LDS (lanes q == 0); selected against c[0][k] in blend(), AFTER all loads are out
-#endif
 };
 
 // ONE wave-uniform branch around the whole gather sequence, none inside it.  Round 1 chose between the xor-only and
@@ -193,8 +189,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 template <bool kFineHashed>
 __device__ __forceinline__ void issue_gathers_impl(const LevelRec* __restrict__ my_recs, __amdgpu_buffer_rsrc_t rsrc,
-                                                   float x0, float x1, float x2, Gathered& g,
-                                                   const u32x2* __restrict__ lds0 = nullptr) {
+                                                   float x0, float x1, float x2, Gathered& g) {
   const int q = (threadIdx.x >> 4) & 3;
   const uint32_t side = (uint32_t)(q & 1);
   const LevelRec* pair_recs = my_recs - 4 * (q & 1);     // records of the even lane of this pair
@@ -216,16 +211,6 @@ __device__ __forceinline__ void issue_gathers_impl(const LevelRec* __restrict__ 
     for (int k = 0; k < 8; ++k) {
       const uint32_t c = cx + (k & 1);
       const uint32_t idx = (h ? (c ^ yz[k >> 1]) : (c + yz[k >> 1])) & mask;
-#if INR_LDS_LEVEL0
-      if (lds0 && li == 0) {
-        // branch-free: every lane reads LDS (lanes q != 0 a valid but unused row) and every lane issues the buffer
-        // load - lanes q == 0 with an out-of-range offset, which the bounds-checked descriptor answers with 0
-        // without a cache look-up - then one select per register
-        g.l0[k] = lds0[q == 0 ? idx : 0u];
-        g.c[li][k] = gather_row(rsrc, q == 0 ? 0xFFFFFFF0u : base + idx * 8u);
-        continue;
-      }
-#endif
       g.c[li][k] = gather_row(rsrc, base + idx * 8u);
     }
   }
@@ -264,10 +249,9 @@ __device__ __forceinline__ void issue_gathers_impl(const LevelRec* __restrict__ 
 }
 
 __device__ __forceinline__ void issue_gathers(const LevelRec* __restrict__ my_recs, const bool (&all_hashed)[4],
-                                              __amdgpu_buffer_rsrc_t rsrc, float x0, float x1, float x2, Gathered& g,
-                                              const u32x2* __restrict__ lds0 = nullptr) {
-  if (all_hashed[2] && all_hashed[3]) issue_gathers_impl<true>(my_recs, rsrc, x0, x1, x2, g, lds0);
-  else issue_gathers_impl<false>(my_recs, rsrc, x0, x1, x2, g, lds0);
+                                              __amdgpu_buffer_rsrc_t rsrc, float x0, float x1, float x2, Gathered& g) {
+  if (all_hashed[2] && all_hashed[3]) issue_gathers_impl<true>(my_recs, rsrc, x0, x1, x2, g);
+  else issue_gathers_impl<false>(my_recs, rsrc, x0, x1, x2, g);
 }
 
 __device__ __forceinline__ f32x2 row2(const u32x2 v) {
@@ -278,10 +262,7 @@ __device__ __forceinline__ f32x2 row2(const u32x2 v) {
 // trilinear blend: weight = (wx*wy)*wz, accumulated with fma - coarse levels in corner order 0..7, fine levels as
 // (this side's corners in yz order) and then x side 0 + x side 1.
 // out[s], s = 0..7 <-> feature 16*(s>>2) + 4q + (s&3).
-__device__ __forceinline__ void blend(const Gathered& g, f32x4& lo, f32x4& hi, bool use_l0 = false) {
-#if INR_LDS_LEVEL0
-  const bool from_lds = use_l0 && ((threadIdx.x >> 4) & 3) == 0;
-#endif
+__device__ __forceinline__ void blend(const Gathered& g, f32x4& lo, f32x4& hi) {
 #pragma unroll
   for (int li = 0; li < 2; ++li) {
     const f32x2 wx = {1.0f - g.cfx[li], g.cfx[li]};
@@ -292,14 +273,6 @@ __device__ __forceinline__ void blend(const Gathered& g, f32x4& lo, f32x4& hi, b
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const f32x2 wk = (k & 1) ? w[k >> 1].yy : w[k >> 1].xx;
-#if INR_LDS_LEVEL0
-      if (li == 0) {
-        const u32x2 a = g.l0[k], b = g.c[0][k];
-        const u32x2 r = {from_lds ? a[0] : b[0], from_lds ? a[1] : b[1]};
-        acc = __builtin_elementwise_fma(wk, row2(r), acc);
-        continue;
-      }
-#endif
       acc = __builtin_elementwise_fma(wk, row2(g.c[li][k]), acc);
     }
     lo[2 * li] = acc.x;
@@ -602,14 +575,14 @@ __device__ __forceinline__ f32x4 mask4(f32x4 g, f32x4 h) {
   return f32x4{h[0] > 0.f ? g[0] : 0.f, h[1] > 0.f ? g[1] : 0.f, h[2] > 0.f ? g[2] : 0.f, h[3] > 0.f ? g[3] : 0.f};
 }
 
-// kSave (training): activations the backward needs, row-major - enc [M,32], h1 [M,64], so [M,16] (raw sigma-net
+// kSave (training) 1: activations the backward needs, row-major - enc [M,32], h1 [M,64], so [M,16] (raw sigma-net
 // output: density logit + 15 geo features), cin [M,32] (colour-net input in weight-column order: 16 SH, 15 geo, 0),
-// c1, c2 [M,64].
+// c1, c2 [M,64]; 2: enc only (k_nerf_head_bwd recomputes the rest).
 struct NerfSave {
   float *enc, *h1, *so, *cin, *c1, *c2;
 };
 
-template <bool kColor, bool kTable = false, bool kSave = false>
+template <bool kColor, bool kTable = false, int kSave = 0>
 __global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_nerf_fwd(const float* __restrict__ x, const float* __restrict__ d,
                                                                int64_t M, const int32_t* __restrict__ n_dev, float bound,
                                                                const float2* __restrict__ emb, uint32_t emb_bytes, GridDesc G,
@@ -625,18 +598,6 @@ __global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_nerf_fwd(cons
   for (int i = threadIdx.x; i < kStage; i += kFieldThreads) wl[i] = packed[i];
   LevelRec* recs = reinterpret_cast<LevelRec*>(wl + kStage);
   stage_level_recs(G, recs);
-  const u32x2* lds0 = nullptr;
-#if INR_LDS_LEVEL0
-  if constexpr (kTable) {
-    u32x2* l0 = reinterpret_cast<u32x2*>(recs + 16);
-    const uint32_t rows0 = G.offsets[1] - G.offsets[0];
-    if (G.mask[0] == 0 && rows0 * 8u <= 40960u) {            // dense level 0 that fits the reservation
-      const u32x2* src = reinterpret_cast<const u32x2*>(emb) + G.offsets[0];
-      for (uint32_t i = threadIdx.x; i < rows0; i += kFieldThreads) l0[i] = src[i];
-      lds0 = l0;
-    }
-  }
-#endif
   __syncthreads();
 
   constexpr int kWaves = kFieldThreads / 64;
@@ -674,9 +635,9 @@ __global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_nerf_fwd(cons
       uint32_t rec_off = (uint32_t)q * 4u * (uint32_t)sizeof(LevelRec);
       asm volatile("" : "+v"(rec_off));    // opaque per tile: keeps the records in LDS, not hoisted into VGPRs
       issue_gathers(reinterpret_cast<const LevelRec*>(reinterpret_cast<const char*>(recs) + rec_off), all_hashed, rsrc,
-                    me.x0, me.x1, me.x2, g, lds0);
+                    me.x0, me.x1, me.x2, g);
       __builtin_amdgcn_sched_barrier(0);   // all 32 gathers in flight before the first blend waits
-      blend(g, enc[0], enc[1], lds0 != nullptr);
+      blend(g, enc[0], enc[1]);
     }
     if constexpr (!kTable) {               // the table feed comes from the marcher, which clamps to the volume
       if (me.oob) enc[0] = enc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -728,7 +689,13 @@ __global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_nerf_fwd(cons
 #pragma unroll
       for (int t = 0; t < 4; ++t) c2[t] = relu4(c2[t]);
       mlp_layer<1, 4>(wl + kCol2 / 4, lane, c2, o);
-      if constexpr (kSave) {
+      if constexpr (kSave == 2) {          // k_nerf_head_bwd recomputes everything else from the encoder output
+        if (valid) {
+#pragma unroll
+          for (int t = 0; t < 2; ++t) store4(sv.enc + m * 32 + 16 * t + 4 * q, enc[t]);
+        }
+      }
+      if constexpr (kSave == 1) {
         if (valid) {
 #pragma unroll
           for (int t = 0; t < 2; ++t) store4(sv.enc + m * 32 + 16 * t + 4 * q, enc[t]);
@@ -1253,6 +1220,185 @@ __global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_nerf_bwd(Nerf
   }
 }
 
+// ---- NeRF field: the WHOLE backward in one launch (round 3; the NeRF-stage twin of k_instance_head_bwd) ---------
+// Per 16-sample tile a wave recomputes the forward from the saved encoder output and the view direction (sigma net,
+// SH, colour net - the forward's own weights and code, so the ReLU masks and the sigmoid are the forward's), runs the
+// input-gradient chain of k_nerf_bwd, and accumulates the five weight gradients on the fp32 matrix cores through the
+// same LDS staging as k_instance_head_bwd: dWc2 += d_o^T c2 (4 tiles), dWc1 += dz_c2^T c1 (16), dWc0 += dz_c1^T cin (8),
+// dWs1 += d_so^T h1 (4), dWs0 += dz_h1^T enc (8) = 40 accumulator tiles, five per wave (wave w: tiles 2w, 2w+1 of dWc1,
+// tile w of dWc0 and dWs0, and tile w of dWc2 (w < 4) or tile w - 4 of dWs1 (w >= 4)).  Replaces the activation
+// stores of the training forward (1088 -> 128 B per sample), k_nerf_bwd and five k_linear_wgrad launches.
+constexpr int kNhFwdFloats = kNerfFloats;
+
+// colour-net input in weight-column order (16 SH, 15 geo, 1 zero) from the register layout of the forward:
+// cin0[ks] = SH component 4 ks + q, so[r] = sigma-net row 4 q + r (row 0 is the density logit: column 31 gets 0)
+__device__ __forceinline__ void nh_stage_cin(float* __restrict__ tile_base, int q, int j, const f32x4 cin0, const f32x4 so) {
+  float* row = tile_base + j * kHbPitch;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) row[4 * ks + q] = cin0[ks];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int srow = 4 * q + r;
+    row[srow >= 1 ? 15 + srow : 31] = srow >= 1 ? so[r] : 0.0f;
+  }
+}
+
+__global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_nerf_head_bwd(
+    const float* __restrict__ enc, const float* __restrict__ dirs, const float* __restrict__ g_sigma,
+    const float* __restrict__ g_rgb, int64_t M, float density_scale, const float4* __restrict__ packed_fwd,
+    const float4* __restrict__ packed_bwd, float* __restrict__ d_enc, float4* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) float4 wl[];
+  float4* wf = wl;
+  float4* wb = wl + kNhFwdFloats / 4;
+  float* gS = reinterpret_cast<float*>(wb + kNerfBwdFloats / 4);
+  float* xS = gS + kHbWaves * kHbTileFloats;
+  for (int i = threadIdx.x; i < kNhFwdFloats / 4; i += kFieldThreads) wf[i] = packed_fwd[i];
+  for (int i = threadIdx.x; i < kNerfBwdFloats / 4; i += kFieldThreads) wb[i] = packed_bwd[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, q = lane >> 4, j = lane & 15, wave = threadIdx.x >> 6;
+  const int64_t n_tiles = (M + 15) >> 4;
+  const int64_t per_round = (int64_t)gridDim.x * kHbWaves;
+  const int64_t n_rounds = (n_tiles + per_round - 1) / per_round;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 acc[5] = {zero4, zero4, zero4, zero4, zero4};
+  float* my_g = gS + wave * kHbTileFloats;
+  float* my_x = xS + wave * kHbTileFloats;
+  const int ot = wave >> 1, it0 = 2 * (wave & 1), it1 = it0 + 1;
+  for (int64_t round = 0; round < n_rounds; ++round) {
+    const int64_t tile = round * per_round + (int64_t)blockIdx.x * kHbWaves + wave;
+    const int64_t m = tile * 16 + j;
+    const bool valid = m < M;
+    f32x4 e[2] = {zero4, zero4};
+    float d0 = 0.f, d1 = 0.f, d2 = 1.f, gs = 0.f, gr0 = 0.f, gr1 = 0.f, gr2 = 0.f;
+    if (valid) {
+      e[0] = load4(enc + m * 32 + 4 * q);
+      e[1] = load4(enc + m * 32 + 16 + 4 * q);
+      d0 = dirs[m * 3]; d1 = dirs[m * 3 + 1]; d2 = dirs[m * 3 + 2];
+      if (q == 0) {
+        gs = g_sigma[m];
+        gr0 = g_rgb[m * 3]; gr1 = g_rgb[m * 3 + 1]; gr2 = g_rgb[m * 3 + 2];
+      }
+    }
+    // ---- forward, recomputed (same code as k_nerf_fwd) ----
+    f32x4 h1[4], so[1], cin[2], c1[4], c2[4], o[1];
+    mlp_layer<4, 2>(wf + kSig0 / 4, lane, e, h1);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) h1[t] = relu4(h1[t]);
+    mlp_layer<1, 4>(wf + kSig1 / 4, lane, h1, so);
+    {
+      float sh[16];
+      sh4(d0, d1, d2, sh);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) cin[0][ks] = select4(q, sh[4 * ks], sh[4 * ks + 1], sh[4 * ks + 2], sh[4 * ks + 3]);
+    }
+    cin[1] = so[0];
+    mlp_layer<4, 2>(wf + kCol0 / 4, lane, cin, c1);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) c1[t] = relu4(c1[t]);
+    mlp_layer<4, 4>(wf + kCol1 / 4, lane, c1, c2);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) c2[t] = relu4(c2[t]);
+    mlp_layer<1, 4>(wf + kCol2 / 4, lane, c2, o);
+    // ---- d(rgb logits): rows 0..2 of a 16-row tile live in lanes q == 0 ----
+    f32x4 g[2] = {zero4, zero4};
+    if (valid && q == 0) {
+      const float c0v = __frcp_rn(1.0f + __expf(-o[0][0])), c1v = __frcp_rn(1.0f + __expf(-o[0][1])),
+                  c2v = __frcp_rn(1.0f + __expf(-o[0][2]));
+      g[0][0] = gr0 * c0v * (1.0f - c0v);
+      g[0][1] = gr1 * c1v * (1.0f - c1v);
+      g[0][2] = gr2 * c2v * (1.0f - c2v);
+    }
+    // phase 1: dWc2 (16 x 64, 3 live rows) += d_o^T c2          [waves 0..3: tile it = wave]
+    hb_stage<1>(my_g, q, j, g);
+    hb_stage<4>(my_x, q, j, c2);
+    f32x4 a[4], b[4], ds[2], e0[2];
+    mlp_layer<4, 2>(wb + kNbC2 / 4, lane, g, a);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) a[t] = mask4(a[t], c2[t]);
+    __syncthreads();
+    if (wave < 4) hb_accum(gS, xS, q, j, 0, wave, 0, false, acc[4], acc[4]);
+    mlp_layer<4, 4>(wb + kNbC1 / 4, lane, a, b);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) b[t] = mask4(b[t], c1[t]);
+    __syncthreads();
+    // phase 2: dWc1 += dz_c2^T c1
+    hb_stage<4>(my_g, q, j, a);
+    hb_stage<4>(my_x, q, j, c1);
+    mlp_layer<1, 4>(wb + kNbC0 / 4, lane, b, ds);      // rows 1..15: d(geo); row 0: 0
+    ds[1] = zero4;
+    if (q == 0) ds[0][0] = valid ? gs * density_scale * __expf(fminf(fmaxf(so[0][0], -15.0f), 15.0f)) : 0.f;
+    __syncthreads();
+    hb_accum(gS, xS, q, j, ot, it0, it1, true, acc[0], acc[1]);
+    mlp_layer<4, 2>(wb + kNbS1 / 4, lane, ds, a);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) a[t] = mask4(a[t], h1[t]);
+    __syncthreads();
+    // phase 3: dWc0 (64 x 32) += dz_c1^T cin
+    hb_stage<4>(my_g, q, j, b);
+    nh_stage_cin(my_x, q, j, cin[0], so[0]);
+    mlp_layer<2, 4>(wb + kNbS0 / 4, lane, a, e0);
+    if (valid) {
+      store4(d_enc + m * 32 + 4 * q, e0[0]);
+      store4(d_enc + m * 32 + 16 + 4 * q, e0[1]);
+    }
+    __syncthreads();
+    hb_accum(gS, xS, q, j, ot, wave & 1, 0, false, acc[2], acc[2]);
+    __syncthreads();
+    // phase 4: dWs1 (16 x 64) += d_so^T h1                     [waves 4..7: tile it = wave - 4]
+    hb_stage<1>(my_g, q, j, ds);
+    hb_stage<4>(my_x, q, j, h1);
+    __syncthreads();
+    if (wave >= 4) hb_accum(gS, xS, q, j, 0, wave - 4, 0, false, acc[4], acc[4]);
+    __syncthreads();
+    // phase 5: dWs0 (64 x 32) += dz_h1^T enc
+    hb_stage<4>(my_g, q, j, a);
+    hb_stage<2>(my_x, q, j, e);
+    __syncthreads();
+    hb_accum(gS, xS, q, j, ot, wave & 1, 0, false, acc[3], acc[3]);
+    __syncthreads();
+  }
+  float4* out = partial + (size_t)blockIdx.x * kHbAccTiles * 64;
+  // tile ids: 0..15 dWc1 (ot, it), 16..23 dWc0, 24..31 dWs0, 32..35 dWc2 (it), 36..39 dWs1 (it)
+  const int ids[5] = {2 * wave, 2 * wave + 1, 16 + wave, 24 + wave, 32 + wave};
+#pragma unroll
+  for (int k = 0; k < 5; ++k) out[ids[k] * 64 + lane] = make_float4(acc[k][0], acc[k][1], acc[k][2], acc[k][3]);
+}
+
+// sums the workgroups' partials into gwc2 [16,64] (3 live rows), gwc1 [64,64], gwc0 [64,32] (31 live columns),
+// gws1 [16,64], gws0 [64,32] - written, not accumulated.
+__global__ void __launch_bounds__(1024) k_nerf_head_wgrad_reduce(const float* __restrict__ partial, int n_groups,
+                                                                 float* __restrict__ gwc2, float* __restrict__ gwc1,
+                                                                 float* __restrict__ gwc0, float* __restrict__ gws1,
+                                                                 float* __restrict__ gws0) {
+  __shared__ float red[16][64];
+  const int e = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  const int idx = blockIdx.x * 64 + e;
+  constexpr int per = kHbAccTiles * 256;
+  float s = 0.f;
+  int g = slice;
+  for (; g + 7 * 16 < n_groups; g += 8 * 16) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)(g + 16 * u) * per + idx];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; g < n_groups; g += 16) s += partial[(size_t)g * per + idx];
+  red[slice][e] = s;
+  __syncthreads();
+  if (slice == 0) {
+#pragma unroll
+    for (int k = 1; k < 16; ++k) s += red[k][e];
+    const int tile = idx >> 8, lane = (idx >> 2) & 63, r = idx & 3;
+    const int ol = 4 * (lane >> 4) + r, il = lane & 15;
+    if (tile < 16) gwc1[(16 * (tile >> 2) + ol) * 64 + 16 * (tile & 3) + il] = s;
+    else if (tile < 24) gwc0[(16 * ((tile - 16) >> 1) + ol) * 32 + 16 * ((tile - 16) & 1) + il] = s;
+    else if (tile < 32) gws0[(16 * ((tile - 24) >> 1) + ol) * 32 + 16 * ((tile - 24) & 1) + il] = s;
+    else if (tile < 36) gwc2[ol * 64 + 16 * (tile - 32) + il] = s;
+    else gws1[ol * 64 + 16 * (tile - 36) + il] = s;
+  }
+}
+
 // Device-side weight packing for training (the weights change every step; the host packers above would cost a
 // device->host->device round trip per step).  One thread per packed bf16 pair position; same layout and
 // rounding as pack_section_bf16.  transpose: the section holds W^T of the row-major [n_rows_w, n_cols_w] weight.
@@ -1726,7 +1872,7 @@ int inr_nerf_forward_table(const float* x01, const int32_t* ray_ids, const float
   if (rc) return rc;
   const uint64_t emb_bytes64 = (uint64_t)desc->offsets[desc->num_levels] * 8ull;
   INR_REQUIRE(emb_bytes64 < (1ull << 31), "table larger than 2 GiB is not addressable by the 32-bit gather offsets");
-  const size_t lds = std::max(kNerfFloats * sizeof(float) + kLevelRecBytes + (INR_LDS_LEVEL0 ? 40960 : 0), (size_t)g_field_lds_min);
+  const size_t lds = std::max(kNerfFloats * sizeof(float) + kLevelRecBytes, (size_t)g_field_lds_min);
   const int grid = grid_for(k_nerf_fwd<true, true>, lds, (M + 15) / 16);
   k_nerf_fwd<true, true><<<grid, kFieldThreads, lds, as_stream(s)>>>(
       x01, nullptr, M, nullptr, bound, reinterpret_cast<const float2*>(embeddings), (uint32_t)emb_bytes64, G,
@@ -1963,12 +2109,63 @@ int inr_nerf_forward_train(const float* x, const float* d, int64_t M, float boun
   const uint64_t emb_bytes64 = (uint64_t)desc->offsets[desc->num_levels] * 8ull;
   INR_REQUIRE(emb_bytes64 < (1ull << 31), "table larger than 2 GiB is not addressable by the 32-bit gather offsets");
   const size_t lds = kNerfFloats * sizeof(float) + kLevelRecBytes;
-  const int grid = grid_for(k_nerf_fwd<true, false, true>, lds, (M + 15) / 16);
-  k_nerf_fwd<true, false, true><<<grid, kFieldThreads, lds, as_stream(s)>>>(
+  const int grid = grid_for(k_nerf_fwd<true, false, 1>, lds, (M + 15) / 16);
+  k_nerf_fwd<true, false, 1><<<grid, kFieldThreads, lds, as_stream(s)>>>(
       x, d, M, nullptr, bound, reinterpret_cast<const float2*>(embeddings), (uint32_t)emb_bytes64, G,
       reinterpret_cast<const float4*>(packed), 1.0f, sigma, rgb, nullptr, nullptr, nullptr,
       NerfSave{enc, h1, so, cin, c1, c2});
   return check_launch("nerf_forward_train");
+}
+
+int inr_nerf_forward_enc(const float* x, const float* d, int64_t M, float bound, const float* embeddings,
+                         const inr_grid_desc* desc, const float* packed, float* sigma, float* rgb, float* enc, inr_stream_t s) {
+  INR_REQUIRE(M >= 0 && desc, "bad argument");
+  if (M == 0) return INR_OK;
+  INR_REQUIRE(x && d && embeddings && packed && sigma && rgb && enc, "null pointer");
+  INR_REQUIRE(((uintptr_t)embeddings & 7) == 0 && (((uintptr_t)packed | (uintptr_t)enc) & 15) == 0,
+              "embeddings/packed/enc misaligned");
+  GridDesc G;
+  int rc = make_grid_desc(desc, G);
+  if (rc) return rc;
+  const uint64_t emb_bytes64 = (uint64_t)desc->offsets[desc->num_levels] * 8ull;
+  INR_REQUIRE(emb_bytes64 < (1ull << 31), "table larger than 2 GiB is not addressable by the 32-bit gather offsets");
+  const size_t lds = kNerfFloats * sizeof(float) + kLevelRecBytes;
+  const int grid = grid_for(k_nerf_fwd<true, false, 2>, lds, (M + 15) / 16);
+  NerfSave sv{};
+  sv.enc = enc;
+  k_nerf_fwd<true, false, 2><<<grid, kFieldThreads, lds, as_stream(s)>>>(
+      x, d, M, nullptr, bound, reinterpret_cast<const float2*>(embeddings), (uint32_t)emb_bytes64, G,
+      reinterpret_cast<const float4*>(packed), 1.0f, sigma, rgb, nullptr, nullptr, nullptr, sv);
+  return check_launch("nerf_forward_enc");
+}
+
+int inr_nerf_head_backward(const float* enc, const float* d, const float* grad_sigma, const float* grad_rgb, int64_t M,
+                           float density_scale, const float* packed_fwd, const float* packed_bwd, float* grad_enc,
+                           void* workspace, float* grad_ws0, float* grad_ws1, float* grad_wc0, float* grad_wc1,
+                           float* grad_wc2, inr_stream_t s) {
+  INR_REQUIRE(M >= 0, "negative M");
+  INR_REQUIRE(packed_fwd && packed_bwd && workspace && grad_ws0 && grad_ws1 && grad_wc0 && grad_wc1 && grad_wc2, "null pointer");
+  INR_REQUIRE(M == 0 || (enc && d && grad_sigma && grad_rgb && grad_enc), "null sample arrays");
+  INR_REQUIRE((((uintptr_t)enc | (uintptr_t)packed_fwd | (uintptr_t)packed_bwd | (uintptr_t)grad_enc | (uintptr_t)workspace) & 15) == 0,
+              "arrays must be 16-byte aligned");
+  hipStream_t st = as_stream(s);
+  const size_t lds = (size_t)(kNhFwdFloats + kNerfBwdFloats + kHbStageFloats) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)k_nerf_head_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      set_error("nerf_head_backward: %zu bytes of LDS refused", lds);
+      return INR_ELAUNCH;
+    }
+    attr_set = true;
+  }
+  const int grid = M == 0 ? 1 : grid_for(k_nerf_head_bwd, lds, (M + 15) / 16);
+  k_nerf_head_bwd<<<grid, kFieldThreads, lds, st>>>(enc, d, grad_sigma, grad_rgb, M, density_scale,
+                                                    reinterpret_cast<const float4*>(packed_fwd),
+                                                    reinterpret_cast<const float4*>(packed_bwd), grad_enc,
+                                                    reinterpret_cast<float4*>(workspace));
+  k_nerf_head_wgrad_reduce<<<kHbAccTiles * 256 / 64, 1024, 0, st>>>(reinterpret_cast<const float*>(workspace), grid, grad_wc2,
+                                                                    grad_wc1, grad_wc0, grad_ws1, grad_ws0);
+  return check_launch("nerf_head_backward");
 }
 
 int inr_nerf_backward(const float* grad_sigma, const float* grad_rgb, const float* rgb, const float* so, const float* h1,

@@ -232,6 +232,61 @@ class _InstanceHeadFn(torch.autograd.Function):
 
 
 class _NerfFieldFn(torch.autograd.Function):
+    """(x, d) -> (sigma, rgb) of the NeRF field for TRAINING: a fused forward that keeps only the encoder output and
+    ONE backward launch (csrc/field_fused.hip::k_nerf_head_bwd) that recomputes the forward from it, runs the whole
+    input-gradient chain (colour net -> geo features / density logit -> sigma net -> encoder) and accumulates the five
+    weight gradients on the fp32 matrix cores; then the atomic table scatter.  (Rounds 1-2: six saved activation
+    arrays - 1088 B per sample -, k_nerf_bwd and five split-K weight-gradient launches; still available as
+    ``_NerfFieldFnUnfused`` / ``NeRFNetwork.fused_nerf_head = False``.)  sigma is returned WITHOUT density_scale
+    (the renderer applies it)."""
+
+    @staticmethod
+    def forward(ctx, x, d, emb, ws0, ws1, wc0, wc1, wc2, desc, bound):
+        lib = _lib.load()
+        f32 = torch.float32
+        M, dev = x.shape[0], x.device
+        pf = torch.empty(lib.inr_nerf_packed_floats(), dtype=f32, device=dev)
+        pb = torch.empty(lib.inr_nerf_bwd_packed_floats(), dtype=f32, device=dev)
+        ws = [w.detach().contiguous() for w in (ws0, ws1, wc0, wc1, wc2)]
+        check(lib.inr_nerf_pack_weights_device(*[ptr(w, f32, "weight") for w in ws], ptr(pf), ptr(pb), stream_ptr()),
+              "nerf_pack_weights_device")
+        sigma = torch.empty(M, dtype=f32, device=dev)
+        rgb = torch.empty(M, 3, dtype=f32, device=dev)
+        enc = torch.empty(M, 32, dtype=f32, device=dev)
+        if M:
+            check(lib.inr_nerf_forward_enc(ptr(x, f32, "x"), ptr(d, f32, "d"), M, float(bound),
+                                           ptr(emb.detach(), f32, "embeddings"), desc, ptr(pf), ptr(sigma), ptr(rgb),
+                                           ptr(enc), stream_ptr()), "nerf_forward_enc")
+        ctx.save_for_backward(x, d, enc, pf, pb, emb)
+        ctx.desc, ctx.bound = desc, bound
+        ctx.set_materialize_grads(False)
+        return sigma, rgb
+
+    @staticmethod
+    def backward(ctx, g_sigma, g_rgb):
+        lib = _lib.load()
+        f32 = torch.float32
+        x, d, enc, pf, pb, emb = ctx.saved_tensors
+        M, dev = x.shape[0], x.device
+        g_sigma = torch.zeros(M, dtype=f32, device=dev) if g_sigma is None else g_sigma.contiguous().float()
+        g_rgb = torch.zeros(M, 3, dtype=f32, device=dev) if g_rgb is None else g_rgb.contiguous().float()
+        d_enc = torch.empty(M, 32, dtype=f32, device=dev)
+        sizes = (16 * 64, 64 * 64, 64 * 32, 16 * 64, 64 * 32)   # wc2 (16 rows, 3 live), wc1, wc0 (32 cols, 31 live), ws1, ws0
+        gw = torch.empty(sum(sizes), dtype=f32, device=dev)     # written by the reduce kernel
+        gwc2, gwc1, gwc0, gws1, gws0 = [g.view(*shape) for g, shape in zip(
+            gw.split(sizes), ((16, 64), (64, 64), (64, 32), (16, 64), (64, 32)))]
+        wsp = torch.empty(lib.inr_instance_head_workspace_bytes() // 4, dtype=f32, device=dev)
+        none_ok = M == 0
+        check(lib.inr_nerf_head_backward(ptr(enc, allow_none=none_ok), ptr(d, allow_none=none_ok),
+                                         ptr(g_sigma, allow_none=none_ok), ptr(g_rgb, allow_none=none_ok), M, 1.0, ptr(pf),
+                                         ptr(pb), ptr(d_enc, allow_none=none_ok), ptr(wsp), ptr(gws0), ptr(gws1), ptr(gwc0),
+                                         ptr(gwc1), ptr(gwc2), stream_ptr()), "nerf_head_backward")
+        g_emb = torch.zeros_like(emb)
+        g_emb = _table_backward(lib, x, d_enc, ctx.desc, M, ctx.bound, g_emb, emb)
+        return None, None, g_emb, gws0, gws1, gwc0[:, :31], gwc1, gwc2[:3], None, None
+
+
+class _NerfFieldFnUnfused(torch.autograd.Function):
     """(x, d) -> (sigma, rgb) of the NeRF field for TRAINING: one fused forward that keeps the activations and one
     fused backward for the whole input-gradient chain (colour net -> geo features / density logit -> sigma net ->
     encoder), csrc/field_fused.hip::k_nerf_fwd<.., kSave> / k_nerf_bwd.  Weight gradients: the two-pass MFMA kernel;
@@ -359,6 +414,7 @@ class NeRFNetwork(NeRFRenderer):
         self._packed = {}
         self.fused_instance_train = True     # False: HIP encoder + rocBLAS layers (the composable path)
         self.fused_nerf_train = True
+        self.fused_nerf_head = True          # False: saved activations + k_nerf_bwd + five weight-gradient launches
 
     # ---- packed MFMA weights (cached until a weight tensor changes) ------------------------------
     def _packed_weights(self, which):
@@ -469,7 +525,8 @@ class NeRFNetwork(NeRFRenderer):
             return sigma, rgb
         if (self._fusable and self.fused_nerf_train and x.is_cuda and torch.is_grad_enabled()
                 and all(p.requires_grad for p in self._nerf_params()) and not (x.requires_grad or d.requires_grad)):
-            return _NerfFieldFn.apply(x.contiguous().float(), d.contiguous().float(), self.encoder.embeddings,
+            fn = _NerfFieldFn if self.fused_nerf_head else _NerfFieldFnUnfused
+            return fn.apply(x.contiguous().float(), d.contiguous().float(), self.encoder.embeddings,
                                       self.sigma_net[0].weight, self.sigma_net[1].weight, self.color_net[0].weight,
                                       self.color_net[1].weight, self.color_net[2].weight, self.encoder.desc, self.bound)
         h = _run_mlp(self.sigma_net, self.encoder(x, bound=self.bound))

@@ -1495,7 +1495,8 @@ def test_auto_mode_follows_the_skippable_fraction(params_k16, room, room_bitfiel
     # count live rays only, so its fraction was larger and "auto" stuck to it once entered)
     net = _network(params_k16, K=16).eval()
     net.density_bitfield.copy_(_t(room_bitfield))
-    for density_scale in (3.0, 20.0):
+    seen = []
+    for density_scale in (3.0, 20.0, 100.0):
         net.density_scale = density_scale
         net.__dict__.pop("_skippable_value", None)
         with torch.no_grad():
@@ -1504,7 +1505,9 @@ def test_auto_mode_follows_the_skippable_fraction(params_k16, room, room_bitfiel
             predicted = net._recent_skippable()
             t = net.render(r["rays_o"], r["rays_d"], bg_color=1, infer_mode="fused_terminate")
         real = 1.0 - int(t["num_evaluated"][0]) / int(t["num_samples"][0])
-        assert 0.0 < real < 0.95 and abs(predicted - real) < 1e-3, (density_scale, predicted, real)
+        assert abs(predicted - real) < 1e-3, (density_scale, predicted, real)
+        seen.append(real)
+    assert any(0.02 < v < 0.9 for v in seen), seen          # at least one of them is genuinely in between
 
 
 @pytest.mark.parametrize("mode", ["auto", "fused_terminate", "fused"])
@@ -1620,6 +1623,37 @@ def test_instance_head_node_equals_the_composable_chain(level_table, room, room_
         assert ga[n].shape == gb[n].shape and gb[n].abs().sum() > 0, n
         rel = float(torch.linalg.norm(ga[n] - gb[n]) / torch.linalg.norm(gb[n]))
         assert rel < 2e-5, (n, rel)
+
+
+@pytest.mark.parametrize("n", [900, 1])
+def test_nerf_head_node_equals_the_unfused_chain(level_table, room, room_bitfield, n):
+    """NeRF stage: the one-launch backward (k_nerf_head_bwd: forward recomputed from the saved encoder output, input-
+    gradient chain, five weight gradients on the fp32 matrix cores) against the round-2 chain (saved activations,
+    k_nerf_bwd, five split-K weight-gradient launches) on the same network and rays: image bit for bit, every
+    gradient to summation-order accuracy."""
+    from oracle import field
+    p = field.init_params(seed=23, table=level_table, table_std=1.0, K=0)
+    ro, rd = scene_rays(room, n, cam=2, seed=56)
+    target = np.random.default_rng(6).random((n, 3)).astype(np.float32)
+
+    def run(fused):
+        net = _network({k: v.clone() for k, v in p.items()}, K=0).train()
+        net.density_bitfield.copy_(_t(room_bitfield))
+        net.fused_nerf_head = fused
+        out = net.render(_t(ro)[None], _t(rd)[None], bg_color=1, perturb=False, force_all_rays=True)
+        ((out["image"][0] - _t(target)) ** 2).mean().backward()
+        return out["image"][0].detach().clone(), {k: q.grad.clone() for k, q in net.named_parameters() if q.grad is not None}
+    img_a, ga = run(True)
+    img_b, gb = run(False)
+    assert torch.equal(img_a, img_b)
+    assert sorted(ga) == sorted(gb) and len(ga) == 6
+    for k in ga:
+        assert ga[k].shape == gb[k].shape, k
+        if gb[k].abs().sum() == 0:
+            assert ga[k].abs().sum() == 0, k
+            continue
+        rel = float(torch.linalg.norm(ga[k] - gb[k]) / torch.linalg.norm(gb[k]))
+        assert rel < 2e-5, (k, rel)
 
 
 def test_label_outside_the_classes_poisons_the_loss(level_table, room, room_bitfield):
