@@ -571,7 +571,11 @@ class Trainer:
     ``lr_scheduler`` with the optimizer, ``metrics`` are meters with ``update / measure / report / clear``,
     ``use_checkpoint`` in {"latest", "latest_model", "best", "scratch", <path>} - so the construction in upstream's
     ``main_nerf.py`` works unchanged; ``fp16`` is accepted and ignored (this path computes in fp32: no autocast, no
-    GradScaler), as is ``use_tensorboardX``.  Same methods and step semantics (``train_step`` / ``eval_step`` /
+    GradScaler), as is ``use_tensorboardX``.  The DEFAULTS are upstream's too [U: recalled, the submodule is not
+    vendored] - ``use_checkpoint="latest"`` (a workspace that holds ``<name>_ep*.pth`` files is resumed from),
+    ``scheduler_update_every_step=False`` (a caller-supplied scheduler is stepped once per epoch unless the caller
+    says otherwise, as upstream's main script does) - rounds 1-2 had "scratch" / True here, which silently changed
+    what a script relying on the defaults did (round-2 advisor).  Same methods and step semantics (``train_step`` / ``eval_step`` /
     ``test_step`` / ``train`` / ``evaluate`` / ``test`` / ``save_checkpoint`` / ``load_checkpoint``).  Defaults when the
     caller passes neither optimizer nor scheduler are upstream's main-script values: Adam(betas .9/.99, eps 1e-15) as
     ``FusedAdam``, lr * 0.1^(step/iters), occupancy update every ``opt.update_extra_interval`` (16) steps.
@@ -584,7 +588,7 @@ class Trainer:
     def __init__(self, name, opt, model, criterion=None, optimizer=None, ema_decay=None, lr_scheduler=None, metrics=None,
                  local_rank=0, world_size=1, device=None, mute=False, fp16=False, eval_interval=1, max_keep_ckpt=2,
                  workspace="workspace", best_mode="min", use_loss_as_metric=True, report_metric_at_train=False,
-                 use_checkpoint="scratch", use_tensorboardX=False, scheduler_update_every_step=True, *,
+                 use_checkpoint="latest", use_tensorboardX=True, scheduler_update_every_step=False, *,
                  lr=1e-2, iters=30000, fused_adam=True, stage="nerf", update_extra_interval=None, use_graph=False):
         self.name, self.opt, self.model = name, opt, model
         self.world_size, self.local_rank = world_size, local_rank
