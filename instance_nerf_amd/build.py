@@ -29,6 +29,29 @@ def source_sha():
     return h.hexdigest()
 
 
+LIB_FP32 = os.path.join(CSRC, "libinr_hip_fp32.so")
+
+
+def build_fp32(force=False, verbose=True):
+    """The exact-fp32 A/B library: the same sources with -DINR_MLP_FP32=1 (MLP GEMMs on v_mfma_f32_16x16x4_f32 instead
+    of the 3-term bf16 split).  Inference entry points only (the device-side weight packers of the training paths
+    refuse that layout); tests/test_gpu_parity.py::test_exact_fp32_mlp_build loads it in a child process."""
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    if not force and os.path.exists(LIB_FP32) and all(os.path.getmtime(d) <= os.path.getmtime(LIB_FP32) for d in deps):
+        return LIB_FP32
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    objs = []
+    for src in SOURCES:
+        obj = os.path.join(CSRC, src.replace(".hip", ".fp32.o"))
+        cmd = [hipcc, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj, "-DINR_MLP_FP32=1"] + FLAGS
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        objs.append(obj)
+    subprocess.check_call([hipcc, "-shared", "-o", LIB_FP32] + objs + ["--offload-arch=gfx950"])
+    return LIB_FP32
+
+
 def _stale():
     if not os.path.exists(LIB):
         return True
@@ -60,4 +83,5 @@ def build(force=False, verbose=True):
 
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
+    build_fp32(force="--force" in sys.argv)
     print(LIB)

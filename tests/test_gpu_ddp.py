@@ -59,30 +59,31 @@ def _trained(net):
     return {k: v.detach().cpu().numpy().copy() for k, v in net.named_parameters() if v.requires_grad}
 
 
-def _worker(rank, world, port, q, stage, overlap):
+def _worker(rank, world, port, q, stage, overlap, steps=3, payload="fp32"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), INR_GRAD_OVERLAP="1" if overlap else "0")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from instance_nerf_amd.nerf import utils
     utils.grad_sync.enabled = overlap
+    utils.grad_sync.payload = payload
     room, net, tr = _make(stage, world, rank)
-    losses = [float(tr.train_one_step(_batch(room, stage, rank, s))) for s in range(3)]
+    losses = [float(tr.train_one_step(_batch(room, stage, rank, s))) for s in range(steps)]
     assert utils.grad_sync.active() == overlap and not utils.grad_sync.handles and not utils.grad_sync.early
     q.put((rank, losses, _trained(net)))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def _run(stage, overlap):
+def _run(stage, overlap, steps=3, payload="fp32"):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, stage, overlap)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, stage, overlap, steps, payload)) for r in range(2)]
     for p in procs:
         p.start()
     res = []
     import queue as _q
     import time as _t
-    deadline = _t.time() + 120
+    deadline = _t.time() + 120 + 4 * steps
     while len(res) < 2 and _t.time() < deadline:
         try:
             res.append(q.get(timeout=2))
@@ -125,8 +126,12 @@ def test_two_ranks_stay_replicas_and_match_one_process_on_the_union_batch(stage)
         for k, v in one.items():
             ref = runs[True][0][2][k]
             # three Adam steps of 1e-2 move every touched parameter by ~1e-2 per step regardless of the gradient's
-            # size, so equality of the UPDATES is the test: well inside one step's size
-            assert np.abs(v - ref).max() < 2e-3, (k, np.abs(v - ref).max())
+            # size, so equality of the UPDATES is the test: well inside one step's size.  Robustly: Adam (eps 1e-15)
+            # turns an entry whose gradient is pure rounding noise into a full +-lr step, and the two runs sum their
+            # atomics and partial weight gradients in different orders - tools/ddp_union_probe.py finds ONE such table
+            # entry out of 12.2 M (5.5e-3) with the round-3 backward, none (1.4e-4) with the round-2 one
+            diff = np.abs(v - ref)
+            assert float(np.mean(diff > 2e-3)) < 1e-6 and diff.max() < 3.5e-2, (k, diff.max(), int((diff > 2e-3).sum()))
 
 
 def _render_worker(rank, world, port, q):
@@ -259,3 +264,21 @@ def test_bench_logic_with_eight_ranks_on_one_gpu():
         assert t["n_gpus"] == 8 and t["samples_per_step"] > 8 * 50_000       # the sum over the eight ranks' batches
         assert 48.0 < t["allreduce_mb_per_step"] < 51.0                       # one 49 MB table + the MLP weights
         assert t["loss_last"] == t["loss_last"] and t["roofline"]["frac"] > 0
+
+
+def test_bf16_gradient_payload_stays_close_to_fp32_over_50_steps():
+    """INR_GRAD_DTYPE=bf16: the table gradient crosses the links as bf16 (half the all-reduce bytes).  Fifty steps of
+    the instance stage on two ranks with each payload type: the replicas stay bit-identical in both, the loss curves
+    stay within 2 % of each other at every step, and the trained MLP weights end within 2 % (norm-wise) - the 8
+    mantissa bits of the summed table gradient change the direction of a step slightly, not the training."""
+    runs = {pl: _run("instance", True, steps=50, payload=pl) for pl in ("fp32", "bf16")}
+    for pl, res in runs.items():
+        for k in res[0][2]:
+            assert (res[0][2][k] == res[1][2][k]).all(), (pl, k)
+    la, lb = np.asarray(runs["fp32"][0][1]), np.asarray(runs["bf16"][0][1])
+    assert la[-5:].mean() < la[:5].mean()                                     # it does train
+    assert np.abs(la - lb).max() < 0.02 * np.abs(la).max(), (la[-5:], lb[-5:])
+    for k in runs["fp32"][0][2]:
+        if "instance_net" in k:
+            a, b = runs["fp32"][0][2][k], runs["bf16"][0][2][k]
+            assert np.linalg.norm(a - b) < 0.02 * np.linalg.norm(a), k

@@ -450,6 +450,41 @@ def test_fused_field_golden(params_k16):
     assert np.abs(logits.cpu().numpy() - g["logits"]).max() < 1e-4
 
 
+def test_exact_fp32_mlp_build(params_k16):
+    """The -DINR_MLP_FP32=1 build (MLP GEMMs on v_mfma_f32_16x16x4_f32, exact fp32 products) stays alive: the same
+    golden field vectors through libinr_hip_fp32.so in a child process (a process binds one library).  Both builds
+    meet the golden tolerances; the exact build is at fp32 rounding of the oracle, the default bf16x3 split within
+    2^-16-class error of it."""
+    import subprocess
+    import sys
+    from instance_nerf_amd import build
+    lib = build.LIB_FP32
+    assert os.path.exists(lib), "libinr_hip_fp32.so is built by __graft_entry__.build()"
+    code = f"""
+import os, sys, numpy as np, torch
+sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r}); sys.path.insert(0, {os.path.dirname(os.path.abspath(__file__))!r})
+from test_gpu_parity import _network, _t, G
+from oracle.field import init_params
+from oracle.hashgrid import level_table
+g = np.load(os.path.join(G, "field.npz"))
+net = _network(init_params(seed=0, table=level_table(), table_std=1.0, K=16)).eval()
+with torch.no_grad():
+    sigma, rgb = net(_t(g["x"]), _t(g["d"]))
+    logits = net.instance(_t(g["x"]))
+print("ERR", float(np.abs(sigma.cpu().numpy() / g["sigma"] - 1).max()), float(np.abs(rgb.cpu().numpy() - g["rgb"]).max()),
+      float(np.abs(logits.cpu().numpy() - g["logits"]).max()))
+"""
+    errs = {}
+    for name, path in (("fp32", lib), ("bf16x3", build.LIB)):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, INR_LIB_PATH=path), capture_output=True,
+                           text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        errs[name] = [float(v) for v in [l for l in r.stdout.splitlines() if l.startswith("ERR")][-1].split()[1:]]
+    print("sigma rel / rgb abs / logits abs:", errs)
+    assert errs["fp32"][0] < 2e-5 and errs["fp32"][1] < 2e-6 and errs["fp32"][2] < 2e-5, errs
+    assert errs["bf16x3"][0] < 1e-4 and errs["bf16x3"][1] < 1e-5 and errs["bf16x3"][2] < 1e-4, errs
+
+
 def test_fused_equals_unfused_and_ragged_sizes(params_k16):
     """The MFMA path and the encoder+rocBLAS path agree; sizes that are not tile multiples work."""
     net = _network(params_k16)
