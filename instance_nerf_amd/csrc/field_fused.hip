@@ -1568,24 +1568,20 @@ __global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_instance_rend
 
 
 // ---- whole-ray rendering with early termination (inference) --------------------------------------------------
-// Field evaluation AND alpha compositing in one kernel; a 16-ray group of the patch-interleaved layout stops being
-// evaluated once all its rays are below T_thresh - what upstream's alive-ray loop buys on trained (opaque) scenes,
-// without its per-iteration host sync.  sigma / rgb never reach HBM.
-// Round 3: a WORKGROUP owns a group (rounds 1-2: a wave did, every wave of a CU on a different patch - 1.26-1.37x the
-// two-kernel path's time per evaluated sample).  Its eight waves take the group's steps round robin (wave w: steps w,
-// w + 8, ...), so the CU works on eight consecutive depths of one 4x4 patch - the access pattern the plain field
-// kernel and k_instance_render owe their L1 / L2 hit rates to.  Compositing is sequential in depth, so per ROUND of
-// eight steps every wave parks (sigma, delta, rgb, slot) of its step in LDS, one barrier, and wave 0 - lane (q = 0, j)
-// holds ray j's state (T, colour, opacity, depth) - walks the eight steps in order.  When it finds the whole group
-// below T_thresh it publishes the round from which nothing needs evaluating; the other waves read that after the NEXT
-// barrier (a uniform decision), so one round is evaluated speculatively - at most 8 steps x 16 rays per group.
-// weights (nullable) receives w per sample (0 for samples behind the termination point) for k_instance_render;
-// evaluated[0] += samples of the steps that were evaluated (all rays of the group that have a sample at such a step).
-struct RenderStep {          // one ray's sample of one step, parked by the wave that evaluated it
-  float sg, dt, dy, r, g, b;
-  int32_t slot;              // sample row (for the weight), -1: this ray has no sample at this step
-  int32_t pad;
-};
+// Field evaluation AND alpha compositing in one kernel: one wave owns a 16-ray group of the patch-interleaved
+// layout for all its steps, MFMA column j is fixed to ray j, the compositing state (T, colour, opacity, depth)
+// lives in the registers of lane (q = 0, j), sigma / rgb never reach HBM, and - the point - a step whose rays
+// have all dropped below T_thresh is not evaluated at all: the group stops as soon as its last ray is opaque.
+// This is what upstream's alive-ray loop buys on trained (opaque) scenes, without its per-iteration host sync.
+// On a transparent scene it evaluates exactly the samples of the two-kernel path.  weights (nullable) receives
+// w per sample (0 for skipped samples) for k_instance_render; evaluated[0] += samples of the steps that were evaluated
+// (all rays of the group that have a sample at such a step, terminated or not).
+// (Round 3 tried the k_instance_render pattern here - a WORKGROUP owns the group, its eight waves take eight consecutive
+//  steps, wave 0 composites a round at a time from LDS, one round evaluated speculatively: 1.18x instead of 1.25-1.37x
+//  the two-kernel path's time per evaluated sample, but termination at 8-16-step granularity: opaque scene 2.91 vs 0.94
+//  ms (10.2 M instead of 0.6 M samples evaluated), half-trained scene 15.3 vs 17.1 ms with the two-kernel path at 13.6.
+//  There is no skippable fraction at which it is the best of the three paths - profiles/r03_NOTES.txt 8 - so the
+//  wave-owned kernel stays.)
 __global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_nerf_render(
     const float* __restrict__ x, const float* __restrict__ deltas, const int32_t* __restrict__ rays,
     const float* __restrict__ rays_d, int64_t N, int64_t M, float bound, const float2* __restrict__ emb,
@@ -1594,156 +1590,123 @@ __global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_nerf_render(
     unsigned long long* __restrict__ evaluated, int x_is_01) {
   extern __shared__ __attribute__((aligned(16))) float4 wl[];
   constexpr int kStage = kNerfFloats / 4;
-  constexpr int kWaves = kFieldThreads / 64;
   for (int i = threadIdx.x; i < kStage; i += kFieldThreads) wl[i] = packed[i];
   LevelRec* recs = reinterpret_cast<LevelRec*>(wl + kStage);
-  RenderStep* park = reinterpret_cast<RenderStep*>(recs + 16);        // [2][kWaves][16]
-  int* dead_from = reinterpret_cast<int*>(park + 2 * kWaves * 16);    // first round that needs no evaluation
   stage_level_recs(G, recs);
   __syncthreads();
 
-  const int lane = threadIdx.x & 63, q = lane >> 4, j = lane & 15, wave = threadIdx.x >> 6;
+  constexpr int kWaves = kFieldThreads / 64;
+  const int lane = threadIdx.x & 63, q = lane >> 4, j = lane & 15;
   const float rb = 2.0f * bound;
   const float x_add = x_is_01 ? 0.0f : bound, x_div = x_is_01 ? 1.0f : rb;   // table feed: already normalised
-  const TileSched sched = make_group_sched(N, 1, 0);
+  const TileSched sched = make_group_sched(N, kWaves, threadIdx.x >> 6);
   const bool all_hashed[4] = {slot_all_hashed(G, 0), slot_all_hashed(G, 1), slot_all_hashed(G, 2), slot_all_hashed(G, 3)};
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)emb, 0, (int)emb_bytes, 0x00020000);
   unsigned long long n_eval = 0;
 
-  for (int64_t grp = sched.first; grp < sched.hi; grp += sched.stride) {
+  for (int64_t it = 0, grp = sched.tile(0); grp < sched.hi; grp = sched.tile(++it)) {
     const int64_t ray = grp * 16 + j;
     const bool has_ray = ray < N;
     const int cnt = has_ray ? rays[ray * 3 + 2] : 0;
-    const int64_t S0 = rays[grp * 16 * 3 + 1];
-    int gtot = cnt, kmax = cnt;
+    int64_t S = rays[grp * 16 * 3 + 1];
+    int gtot = cnt;
 #pragma unroll
-    for (int d = 1; d < 16; d <<= 1) {
-      gtot += __shfl_xor(gtot, d, 64);
-      kmax = max(kmax, __shfl_xor(kmax, d, 64));
-    }
-    if (S0 + gtot > M) kmax = 0;                           // a dropped group composites to zero
+    for (int d = 1; d < 16; d <<= 1) gtot += __shfl_xor(gtot, d, 64);
+    const bool fits = S + gtot <= M;
     const int64_t rc = has_ray ? ray : N - 1;
     float sh[16];
     sh4(rays_d[rc * 3], rays_d[rc * 3 + 1], rays_d[rc * 3 + 2], sh);   // the direction is constant along a ray
     f32x4 cin0;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) cin0[ks] = select4(q, sh[4 * ks], sh[4 * ks + 1], sh[4 * ks + 2], sh[4 * ks + 3]);
-    if (threadIdx.x == 0) *dead_from = 0x7FFFFFFF;
-    // compositing state of ray j: meaningful in wave 0, lanes q == 0
-    float T = 1.0f, cr = 0.f, cg = 0.f, cb = 0.f, ws = 0.f, tt = 0.f, dsum = 0.f;
+    float T = 1.0f, cr = 0.f, cg = 0.f, cb = 0.f, ws = 0.f, tt = 0.f, dsum = 0.f;   // meaningful in lanes q == 0
     bool done = false;
-
-    // the sample of (ray j, step k): its slot depends on the counts only - requested one step of this wave ahead
-    auto request = [&](int k, int64_t& slot, float& x0, float& x1, float& x2) {
-      int below = min(cnt, k);
-#pragma unroll
-      for (int d = 1; d < 16; d <<= 1) below += __shfl_xor(below, d, 64);
-      const unsigned field = (unsigned)(__ballot(k < cnt) & 0xFFFFull);
-      const bool active = k < cnt;
-      slot = active ? S0 + below + __popc(field & ((1u << j) - 1u)) : -1;
-      const int64_t sl = active ? slot : S0;
-      x0 = x[sl * 3 + 0]; x1 = x[sl * 3 + 1]; x2 = x[sl * 3 + 2];
-    };
-    int64_t slot = -1;
-    float x0 = 0.f, x1 = 0.f, x2 = 0.f;
-    if (wave < kmax) request(wave, slot, x0, x1, x2);
-    const int n_rounds = (kmax + kWaves - 1) / kWaves;
-    __syncthreads();                                       // dead_from initialised; the previous group's parking is free
-    int stop_round = n_rounds;                             // rounds [stop_round, n_rounds) were never evaluated
-    for (int r = 0; r < n_rounds; ++r) {
-      const int k = r * kWaves + wave;
-      RenderStep* mine = park + ((r & 1) * kWaves + wave) * 16;
-      if (k < kmax) {
-        int64_t slot_n = -1;
-        float xn0 = 0.f, xn1 = 0.f, xn2 = 0.f;
-        if (k + kWaves < kmax) request(k + kWaves, slot_n, xn0, xn1, xn2);
-        const unsigned field_k = (unsigned)(__ballot(k < cnt) & 0xFFFFull);       // all lanes take part in the ballot
-        if (lane == 0) n_eval += __popc(field_k);
-        const float2 dl = (q == 0 && slot >= 0) ? reinterpret_cast<const float2*>(deltas)[slot] : make_float2(0.f, 0.f);
-        const float p0 = (x0 + x_add) / x_div, p1 = (x1 + x_add) / x_div, p2 = (x2 + x_add) / x_div;
-        f32x4 enc[2];
-        {
-          Gathered g;
-          uint32_t rec_off = (uint32_t)q * 4u * (uint32_t)sizeof(LevelRec);
-          asm volatile("" : "+v"(rec_off));
-          issue_gathers(reinterpret_cast<const LevelRec*>(reinterpret_cast<const char*>(recs) + rec_off), all_hashed, rsrc,
-                        p0, p1, p2, g);
-          __builtin_amdgcn_sched_barrier(0);
-          blend(g, enc[0], enc[1]);
+    // the slot of a step depends on the counts only: the coordinates of step k + 1 are requested while step k is
+    // evaluated (they stream from HBM; a step used to start with that round trip)
+    float xn0 = 0.f, xn1 = 0.f, xn2 = 0.f;
+    if (fits && gtot > 0) {
+      const unsigned f0 = (unsigned)(__ballot(0 < cnt) & 0xFFFFull);
+      const int64_t m0 = ((f0 >> j) & 1u) ? S + __popc(f0 & ((1u << j) - 1u)) : 0;
+      xn0 = x[m0 * 3 + 0]; xn1 = x[m0 * 3 + 1]; xn2 = x[m0 * 3 + 2];
+    }
+    for (int k = 0; fits; ++k) {
+      const unsigned long long bal = __ballot(k < cnt);
+      const unsigned field = (unsigned)(bal & 0xFFFFull);
+      if (field == 0) break;
+      const unsigned donef = (unsigned)(__ballot(done) & 0xFFFFull);
+      const unsigned livef = field & ~donef;
+      const bool active = (field >> j) & 1u, live = (livef >> j) & 1u;
+      const int64_t slot = S + __popc(field & ((1u << j) - 1u));
+      S += __popc(field);
+      const float xr0 = xn0, xr1 = xn1, xr2 = xn2;
+      {
+        // only while a ray of the group is alive (alive at k + 1 implies alive at k): an opaque group must not stream
+        // the coordinates of the samples it skips
+        const unsigned fn = livef != 0 ? (unsigned)(__ballot(k + 1 < cnt) & 0xFFFFull) : 0u;
+        if (fn != 0) {
+          const int64_t mn = ((fn >> j) & 1u) ? S + __popc(fn & ((1u << j) - 1u)) : 0;
+          xn0 = x[mn * 3 + 0]; xn1 = x[mn * 3 + 1]; xn2 = x[mn * 3 + 2];
         }
-        f32x4 h1[4], h2[1];
-        mlp_layer<4, 2>(wl + kSig0 / 4, lane, enc, h1);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) h1[t] = relu4(h1[t]);
-        mlp_layer<1, 4>(wl + kSig1 / 4, lane, h1, h2);
-        f32x4 cin[2], c1[4], c2[4], o[1];
-        cin[0] = cin0;
-        cin[1] = h2[0];
-        mlp_layer<4, 2>(wl + kCol0 / 4, lane, cin, c1);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) c1[t] = relu4(c1[t]);
-        mlp_layer<4, 4>(wl + kCol1 / 4, lane, c1, c2);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) c2[t] = relu4(c2[t]);
-        mlp_layer<1, 4>(wl + kCol2 / 4, lane, c2, o);
-        if (q == 0) {
-          RenderStep st;
-          st.sg = __expf(h2[0][0]) * density_scale;
-          st.dt = dl.x; st.dy = dl.y;
-          st.r = __frcp_rn(1.0f + __expf(-o[0][0]));
-          st.g = __frcp_rn(1.0f + __expf(-o[0][1]));
-          st.b = __frcp_rn(1.0f + __expf(-o[0][2]));
-          st.slot = (int32_t)slot;
-          st.pad = 0;
-          mine[j] = st;
-        }
-        slot = slot_n; x0 = xn0; x1 = xn1; x2 = xn2;
       }
-      __syncthreads();
-      const int dead = *dead_from;                         // written by wave 0 BEFORE this barrier: a uniform read
-      if (dead <= r) {                                     // this round was evaluated for nothing: the group is opaque
-        stop_round = r;
-        break;
+      if (livef == 0) {                                   // every remaining ray of the group is opaque
+        if (!wbuf) break;                                 // nothing left to do for this group
+        if (active && q == 0) wbuf[slot] = 0.0f;          // the instance render reads a weight for every sample
+        continue;
       }
-      if (wave == 0 && q == 0) {
-        const RenderStep* rd = park + (r & 1) * kWaves * 16;
-        const int steps = min(kWaves, kmax - r * kWaves);
-        for (int sidx = 0; sidx < steps; ++sidx) {
-          const RenderStep st = rd[sidx * 16 + j];
-          if (st.slot >= 0) {
-            float w = 0.0f;
-            if (!done) {
-              const float alpha = 1.0f - expf(-st.sg * st.dt);
-              w = alpha * T;
-              cr += w * st.r; cg += w * st.g; cb += w * st.b;
-              tt += st.dy;
-              dsum += w * tt;
-              ws += w;
-              T *= 1.0f - alpha;
-              if (T < T_thresh) done = true;
-            }
-            if (wbuf) wbuf[st.slot] = w;
-          }
+      // group-level accounting, the same quantity the two-kernel path's compositing counts as NOT skippable: every
+      // sample of a step that is evaluated at all (a terminated ray inside a live group still rides through the
+      // MFMA tile).  Counting live rays only made infer_mode="auto" compare two different fractions (round-2 advisor).
+      if (lane == 0) n_eval += __popc(field);
+      const float2 dl = (q == 0 && live) ? reinterpret_cast<const float2*>(deltas)[slot] : make_float2(0.f, 0.f);
+      const float x0 = (xr0 + x_add) / x_div, x1 = (xr1 + x_add) / x_div, x2 = (xr2 + x_add) / x_div;
+      f32x4 enc[2];
+      {
+        Gathered g;
+        uint32_t rec_off = (uint32_t)q * 4u * (uint32_t)sizeof(LevelRec);
+        asm volatile("" : "+v"(rec_off));
+        issue_gathers(reinterpret_cast<const LevelRec*>(reinterpret_cast<const char*>(recs) + rec_off), all_hashed, rsrc,
+                      x0, x1, x2, g);
+        __builtin_amdgcn_sched_barrier(0);
+        blend(g, enc[0], enc[1]);
+      }
+      f32x4 h1[4], h2[1];
+      mlp_layer<4, 2>(wl + kSig0 / 4, lane, enc, h1);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) h1[t] = relu4(h1[t]);
+      mlp_layer<1, 4>(wl + kSig1 / 4, lane, h1, h2);
+      f32x4 cin[2], c1[4], c2[4], o[1];
+      cin[0] = cin0;
+      cin[1] = h2[0];
+      mlp_layer<4, 2>(wl + kCol0 / 4, lane, cin, c1);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) c1[t] = relu4(c1[t]);
+      mlp_layer<4, 4>(wl + kCol1 / 4, lane, c1, c2);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) c2[t] = relu4(c2[t]);
+      mlp_layer<1, 4>(wl + kCol2 / 4, lane, c2, o);
+      if (q == 0 && active) {
+        float w = 0.0f;
+        if (live) {
+          const float sg = __expf(h2[0][0]) * density_scale;
+          const float alpha = 1.0f - expf(-sg * dl.x);
+          w = alpha * T;
+          cr += w * __frcp_rn(1.0f + __expf(-o[0][0]));
+          cg += w * __frcp_rn(1.0f + __expf(-o[0][1]));
+          cb += w * __frcp_rn(1.0f + __expf(-o[0][2]));
+          tt += dl.y;
+          dsum += w * tt;
+          ws += w;
+          T *= 1.0f - alpha;
+          if (T < T_thresh) done = true;
         }
-        // rays without a sample left count as done
-        const bool finished = done || (r + 1) * kWaves >= cnt;
-        if ((__ballot(finished) & 0xFFFFull) == 0xFFFFull && j == 0) *dead_from = r + 1;
+        if (wbuf) wbuf[slot] = w;
       }
     }
-    // samples of the rounds that were not composited (evaluated speculatively or never): weight 0
-    if (wbuf && stop_round < n_rounds) {
-      for (int k = stop_round * kWaves + wave; k < kmax; k += kWaves) {
-        int64_t sl; float a0, a1, a2;
-        request(k, sl, a0, a1, a2);
-        if (q == 0 && sl >= 0) wbuf[sl] = 0.0f;
-      }
-    }
-    if (wave == 0 && q == 0 && has_ray) {
+    if (q == 0 && has_ray) {
       const int32_t rid = rays[ray * 3];
       weights_sum[rid] = ws; depth[rid] = dsum;
       image[rid * 3] = cr; image[rid * 3 + 1] = cg; image[rid * 3 + 2] = cb;
     }
-    __syncthreads();                                       // parking and dead_from are reused by the next group
   }
   if (evaluated && lane == 0 && n_eval) atomicAdd(evaluated, n_eval);
 }
@@ -2276,11 +2239,9 @@ int inr_nerf_render(const float* xyzs, const float* deltas, const int32_t* rays,
   if (rc) return rc;
   const uint64_t emb_bytes64 = (uint64_t)desc->offsets[desc->num_levels] * 8ull;
   INR_REQUIRE(emb_bytes64 < (1ull << 31), "table larger than 2 GiB is not addressable by the 32-bit gather offsets");
-  // weights + level records + two rounds of parked steps + the termination flag
-  const size_t lds = kNerfFloats * sizeof(float) + kLevelRecBytes + 2 * (kFieldThreads / 64) * 16 * sizeof(RenderStep) + 16;
+  const size_t lds = kNerfFloats * sizeof(float) + kLevelRecBytes;
   const int64_t n_groups = (N + 15) / 16;
-  const int64_t as_tiles = n_groups * (kFieldThreads / 64);        // one workgroup per group
-  k_nerf_render<<<grid_for(k_nerf_render, lds, as_tiles), kFieldThreads, lds, as_stream(s)>>>(
+  k_nerf_render<<<grid_for(k_nerf_render, lds, n_groups), kFieldThreads, lds, as_stream(s)>>>(
       xyzs, deltas, rays, rays_d, N, M, bound, reinterpret_cast<const float2*>(embeddings), (uint32_t)emb_bytes64, G,
       reinterpret_cast<const float4*>(packed), density_scale, T_thresh, weights_sum, depth, image, weights,
       reinterpret_cast<unsigned long long*>(evaluated), x_is_01);
