@@ -306,6 +306,47 @@ def instance_render_probe(dev, frames=8):
             "frac_of_hbm_peak": round(n * 2 * BYTES_PER_SAMPLE / dt / 1e9 / HBM_PEAK_GBS, 4)}
 
 
+def half_table_probe(dev, frames=8):
+    """Secondary measurement: the headline frames with the OPT-IN half-precision table copy (NeRFNetwork.half_table;
+    upstream's -O / fp16 storage): 512 B of algorithmic table traffic per sample.  Not the headline: its outputs differ
+    from the fp32 table's by ~1e-3 relative."""
+    from instance_nerf_amd.nerf.utils import get_rays
+    net, room = build_network(dev)
+    net.half_table = True
+    poses, intr, H, W = room.cameras()
+    pd = torch.from_numpy(poses).to(dev)
+    ev = []
+    inner = net.forward_table
+
+    def timed(*a, **kw):
+        st = torch.cuda.current_stream()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        out = inner(*a, **kw)
+        e1.record(st)
+        ev.append((e0, e1))
+        return out
+    net.forward_table = timed
+
+    def frame(v):
+        r = get_rays(pd[v:v + 1], intr, H, W, patch=4)
+        with torch.no_grad():
+            return net.render(r["rays_o"], r["rays_d"], bg_color=1, infer_mode="fused")
+    frame(0)
+    torch.cuda.synchronize()
+    ev.clear()
+    t0 = time.perf_counter()
+    counts = [frame(v % pd.shape[0])["num_samples"] for v in range(frames)]
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    n = sum(int(c[0]) for c in counts)
+    kms = sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1)
+    return {"workload": "render 800x800, sigma+rgb, fp16 copy of the hash table (opt-in, NeRFNetwork.half_table)",
+            "ms_per_frame": round(dt / frames * 1e3, 3), "value": round(n / dt / 1e6, 1), "unit": "Msamples/s",
+            "field_kernel_ms": round(kms, 4), "algorithmic_bytes_per_sample": BYTES_PER_SAMPLE // 2,
+            "field_frac_of_hbm_peak": round(n / frames * (BYTES_PER_SAMPLE // 2) / (kms / 1e3) / 1e9 / HBM_PEAK_GBS, 4)}
+
+
 def trained_scene_probe(dev, steps=1500, with_oracle=True):
     """Secondary measurement: rendering a TRAINED scene.  The headline scene is an untrained (transparent) field, so no
     ray of it ever terminates; a trained 3D-FRONT room is opaque.  Here the NeRF of the synthetic room is trained for
@@ -641,6 +682,10 @@ def main():
                 line["render_instance"] = instance_render_probe(dev)
             except Exception as e:                            # noqa: BLE001
                 line["render_instance"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            try:
+                line["render_half_table"] = half_table_probe(dev)
+            except Exception as e:                            # noqa: BLE001
+                line["render_half_table"] = {"error": f"{type(e).__name__}: {e}"[:300]}
             if world == 1 and not args.no_trained_scene:
                 try:
                     line["trained_scene"] = trained_scene_probe(dev, with_oracle=not args.no_cpu_baseline)

@@ -273,6 +273,14 @@ int inr_nerf_forward_table(const float* x01, const int32_t* ray_ids, const float
                            float bound, const float* embeddings, const inr_grid_desc* desc /*host*/,
                            const float* packed /*device*/, float density_scale, float* sigma, float* rgb,
                            inr_stream_t s);
+/* The same launch on a HALF-PRECISION copy of the table (fp16 [T,2], 4 bytes per row; upstream's `-O` / fp16 storage,
+ * here an opt-in for inference: NeRFNetwork.half_table).  Index arithmetic, blending and the MLPs are unchanged (fp32);
+ * the table VALUES carry 11 significant bits, so outputs differ from the fp32 table's by ~1e-3 relative.  512 instead of
+ * 1024 algorithmic bytes per sample.  embeddings_half: device pointer to T x 2 IEEE binary16 values.               */
+int inr_nerf_forward_table_half(const float* x01, const int32_t* ray_ids, const float* sh_table_q, int64_t M,
+                                float bound, const void* embeddings_half, const inr_grid_desc* desc /*host*/,
+                                const float* packed /*device*/, float density_scale, float* sigma, float* rgb,
+                                inr_stream_t s);
 /* Training path of the NeRF field (a9 under autograd): device-packed weights (forward layout of
  * inr_nerf_pack_weights + the transposed sections of the backward), a forward that also stores the activations
  * (enc [M,32], h1 [M,64], so [M,16] = raw sigma-net output, cin [M,32] = colour-net input with a zero pad column,

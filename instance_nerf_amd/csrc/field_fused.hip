@@ -136,8 +136,20 @@ typedef unsigned int u32x2 __attribute__((__vector_size__(2 * sizeof(unsigned in
 
 // Default cache policy on the gathers (raw_buffer_load aux 0).  Measured and rejected in round 2:
 // nt on the fine levels 15.5 ms, sc1 9.25 ms, sc0 = default 6.07 ms per 37 M samples.
+// kHalf: the table is a half-precision copy ([T,2] fp16, 4 bytes per row - upstream's `-O` / fp16 storage as an
+// OPT-IN for inference, NeRFNetwork.half_table): a row is one dword, its byte offset half the fp32 one, and the two
+// features are widened when they are blended (v_cvt_f32_f16 x 2 per corner).  512 instead of 1024 algorithmic bytes
+// per sample; 32 instead of 16 rows per 128-byte line.
+template <bool kHalf = false>
 __device__ __forceinline__ u32x2 gather_row(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off) {
-  return __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)byte_off, 0, 0);
+  if constexpr (kHalf) {
+    u32x2 r;
+    r[0] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(byte_off >> 1), 0, 0);
+    r[1] = 0u;
+    return r;
+  } else {
+    return __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)byte_off, 0, 0);
+  }
 }
 
 // Lane-paired gather for the FINE slots (levels 8..15).  Measured on MI355X (tools/micro/gather_bench.hip): the vector
@@ -187,7 +199,7 @@ __device__ __forceinline__ void wait_vmcnt() {
   if constexpr (N >= 0) __builtin_amdgcn_s_waitcnt((N & 0xF) | (0x7 << 4) | (0xF << 8) | ((N >> 4) << 14));
 }
 
-template <bool kFineHashed>
+template <bool kFineHashed, bool kHalf = false>
 __device__ __forceinline__ void issue_gathers_impl(const LevelRec* __restrict__ my_recs, __amdgpu_buffer_rsrc_t rsrc,
                                                    float x0, float x1, float x2, Gathered& g) {
   const int q = (threadIdx.x >> 4) & 3;
@@ -211,7 +223,7 @@ __device__ __forceinline__ void issue_gathers_impl(const LevelRec* __restrict__ 
     for (int k = 0; k < 8; ++k) {
       const uint32_t c = cx + (k & 1);
       const uint32_t idx = (h ? (c ^ yz[k >> 1]) : (c + yz[k >> 1])) & mask;
-      g.c[li][k] = gather_row(rsrc, base + idx * 8u);
+      g.c[li][k] = gather_row<kHalf>(rsrc, base + idx * 8u);
     }
   }
 #pragma unroll
@@ -231,10 +243,10 @@ __device__ __forceinline__ void issue_gathers_impl(const LevelRec* __restrict__ 
     if (i == 0) wait_vmcnt<kWaitAfterCoarse>();
     else wait_vmcnt<kWaitBetweenFine>();
     if constexpr (kFineHashed) {       // every fine level of both pairs is hashed: xor-only index maths
-      g.f[i][0] = gather_row(rsrc, base + ((c ^ (hy0 ^ hz0)) & mask) * 8u);
-      g.f[i][1] = gather_row(rsrc, base + ((c ^ (hy1 ^ hz0)) & mask) * 8u);
-      g.f[i][2] = gather_row(rsrc, base + ((c ^ (hy0 ^ hz1)) & mask) * 8u);
-      g.f[i][3] = gather_row(rsrc, base + ((c ^ (hy1 ^ hz1)) & mask) * 8u);
+      g.f[i][0] = gather_row<kHalf>(rsrc, base + ((c ^ (hy0 ^ hz0)) & mask) * 8u);
+      g.f[i][1] = gather_row<kHalf>(rsrc, base + ((c ^ (hy1 ^ hz0)) & mask) * 8u);
+      g.f[i][2] = gather_row<kHalf>(rsrc, base + ((c ^ (hy0 ^ hz1)) & mask) * 8u);
+      g.f[i][3] = gather_row<kHalf>(rsrc, base + ((c ^ (hy1 ^ hz1)) & mask) * 8u);
     } else {
       const bool h = rec->b.y != 0;
       const uint32_t yz[4] = {h ? (hy0 ^ hz0) : (hy0 + hz0), h ? (hy1 ^ hz0) : (hy1 + hz0),
@@ -242,26 +254,35 @@ __device__ __forceinline__ void issue_gathers_impl(const LevelRec* __restrict__ 
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const uint32_t idx = (h ? (c ^ yz[k]) : (c + yz[k])) & mask;
-        g.f[i][k] = gather_row(rsrc, base + idx * 8u);
+        g.f[i][k] = gather_row<kHalf>(rsrc, base + idx * 8u);
       }
     }
   }
 }
 
+template <bool kHalf = false>
 __device__ __forceinline__ void issue_gathers(const LevelRec* __restrict__ my_recs, const bool (&all_hashed)[4],
                                               __amdgpu_buffer_rsrc_t rsrc, float x0, float x1, float x2, Gathered& g) {
-  if (all_hashed[2] && all_hashed[3]) issue_gathers_impl<true>(my_recs, rsrc, x0, x1, x2, g);
-  else issue_gathers_impl<false>(my_recs, rsrc, x0, x1, x2, g);
+  if (all_hashed[2] && all_hashed[3]) issue_gathers_impl<true, kHalf>(my_recs, rsrc, x0, x1, x2, g);
+  else issue_gathers_impl<false, kHalf>(my_recs, rsrc, x0, x1, x2, g);
 }
 
+template <bool kHalf = false>
 __device__ __forceinline__ f32x2 row2(const u32x2 v) {
   const unsigned bx = v[0], by = v[1];     // (scalars first: see the note on __builtin_bit_cast below)
-  return f32x2{__uint_as_float(bx), __uint_as_float(by)};
+  if constexpr (kHalf) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const h2 h = __builtin_bit_cast(h2, bx);
+    return f32x2{(float)h[0], (float)h[1]};
+  } else {
+    return f32x2{__uint_as_float(bx), __uint_as_float(by)};
+  }
 }
 
 // trilinear blend: weight = (wx*wy)*wz, accumulated with fma - coarse levels in corner order 0..7, fine levels as
 // (this side's corners in yz order) and then x side 0 + x side 1.
 // out[s], s = 0..7 <-> feature 16*(s>>2) + 4q + (s&3).
+template <bool kHalf = false>
 __device__ __forceinline__ void blend(const Gathered& g, f32x4& lo, f32x4& hi) {
 #pragma unroll
   for (int li = 0; li < 2; ++li) {
@@ -273,7 +294,7 @@ __device__ __forceinline__ void blend(const Gathered& g, f32x4& lo, f32x4& hi) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const f32x2 wk = (k & 1) ? w[k >> 1].yy : w[k >> 1].xx;
-      acc = __builtin_elementwise_fma(wk, row2(g.c[li][k]), acc);
+      acc = __builtin_elementwise_fma(wk, row2<kHalf>(g.c[li][k]), acc);
     }
     lo[2 * li] = acc.x;
     lo[2 * li + 1] = acc.y;
@@ -285,10 +306,10 @@ __device__ __forceinline__ void blend(const Gathered& g, f32x4& lo, f32x4& hi) {
     const f32x2 xy = wy * g.fwx[i];                                    // (wx*wy): y side 0 / 1 (product commutes)
     const f32x2 w0 = xy * (1.0f - g.ffz[i]), w1 = xy * g.ffz[i];       // corners (y0z0, y1z0), (y0z1, y1z1)
     f32x2 acc = {0.f, 0.f};
-    acc = __builtin_elementwise_fma(w0.xx, row2(g.f[i][0]), acc);
-    acc = __builtin_elementwise_fma(w0.yy, row2(g.f[i][1]), acc);
-    acc = __builtin_elementwise_fma(w1.xx, row2(g.f[i][2]), acc);
-    acc = __builtin_elementwise_fma(w1.yy, row2(g.f[i][3]), acc);
+    acc = __builtin_elementwise_fma(w0.xx, row2<kHalf>(g.f[i][0]), acc);
+    acc = __builtin_elementwise_fma(w0.yy, row2<kHalf>(g.f[i][1]), acc);
+    acc = __builtin_elementwise_fma(w1.xx, row2<kHalf>(g.f[i][2]), acc);
+    acc = __builtin_elementwise_fma(w1.yy, row2<kHalf>(g.f[i][3]), acc);
     part[i] = acc;
   }
   // v_permlane16_swap_b32 vdst, src: the odd 16-lane rows of vdst trade places with the even rows of src.  With
@@ -582,7 +603,7 @@ struct NerfSave {
   float *enc, *h1, *so, *cin, *c1, *c2;
 };
 
-template <bool kColor, bool kTable = false, int kSave = 0>
+template <bool kColor, bool kTable = false, int kSave = 0, bool kHalf = false>
 __global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_nerf_fwd(const float* __restrict__ x, const float* __restrict__ d,
                                                                int64_t M, const int32_t* __restrict__ n_dev, float bound,
                                                                const float2* __restrict__ emb, uint32_t emb_bytes, GridDesc G,
@@ -634,10 +655,10 @@ __global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_nerf_fwd(cons
       Gathered g;
       uint32_t rec_off = (uint32_t)q * 4u * (uint32_t)sizeof(LevelRec);
       asm volatile("" : "+v"(rec_off));    // opaque per tile: keeps the records in LDS, not hoisted into VGPRs
-      issue_gathers(reinterpret_cast<const LevelRec*>(reinterpret_cast<const char*>(recs) + rec_off), all_hashed, rsrc,
-                    me.x0, me.x1, me.x2, g);
+      issue_gathers<kHalf>(reinterpret_cast<const LevelRec*>(reinterpret_cast<const char*>(recs) + rec_off), all_hashed, rsrc,
+                           me.x0, me.x1, me.x2, g);
       __builtin_amdgcn_sched_barrier(0);   // all 32 gathers in flight before the first blend waits
-      blend(g, enc[0], enc[1]);
+      blend<kHalf>(g, enc[0], enc[1]);
     }
     if constexpr (!kTable) {               // the table feed comes from the marcher, which clamps to the volume
       if (me.oob) enc[0] = enc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1865,9 +1886,27 @@ int inr_nerf_forward(const float* x, const float* d, int64_t M, const int32_t* n
   return check_launch("nerf_forward");
 }
 
+static int nerf_forward_table_impl(const float* x01, const int32_t* ray_ids, const float* sh_table_q, int64_t M, float bound,
+                                   const void* embeddings, bool half, const inr_grid_desc* desc, const float* packed,
+                                   float density_scale, float* sigma, float* rgb, inr_stream_t s);
+
 int inr_nerf_forward_table(const float* x01, const int32_t* ray_ids, const float* sh_table_q, int64_t M, float bound,
                            const float* embeddings, const inr_grid_desc* desc, const float* packed, float density_scale,
                            float* sigma, float* rgb, inr_stream_t s) {
+  return nerf_forward_table_impl(x01, ray_ids, sh_table_q, M, bound, embeddings, false, desc, packed, density_scale, sigma,
+                                 rgb, s);
+}
+
+int inr_nerf_forward_table_half(const float* x01, const int32_t* ray_ids, const float* sh_table_q, int64_t M, float bound,
+                                const void* embeddings_half, const inr_grid_desc* desc, const float* packed,
+                                float density_scale, float* sigma, float* rgb, inr_stream_t s) {
+  return nerf_forward_table_impl(x01, ray_ids, sh_table_q, M, bound, embeddings_half, true, desc, packed, density_scale,
+                                 sigma, rgb, s);
+}
+
+static int nerf_forward_table_impl(const float* x01, const int32_t* ray_ids, const float* sh_table_q, int64_t M, float bound,
+                                   const void* embeddings, bool half, const inr_grid_desc* desc, const float* packed,
+                                   float density_scale, float* sigma, float* rgb, inr_stream_t s) {
   INR_REQUIRE(M >= 0 && desc, "bad argument");
   if (M == 0) return INR_OK;
   INR_REQUIRE(x01 && ray_ids && sh_table_q && embeddings && packed && sigma && rgb, "null pointer");
@@ -1879,6 +1918,14 @@ int inr_nerf_forward_table(const float* x01, const int32_t* ray_ids, const float
   const uint64_t emb_bytes64 = (uint64_t)desc->offsets[desc->num_levels] * 8ull;
   INR_REQUIRE(emb_bytes64 < (1ull << 31), "table larger than 2 GiB is not addressable by the 32-bit gather offsets");
   const size_t lds = std::max(kNerfFloats * sizeof(float) + kLevelRecBytes, (size_t)g_field_lds_min);
+  if (half) {
+    const int grid = grid_for(k_nerf_fwd<true, true, 0, true>, lds, (M + 15) / 16);
+    k_nerf_fwd<true, true, 0, true><<<grid, kFieldThreads, lds, as_stream(s)>>>(
+        x01, nullptr, M, nullptr, bound, reinterpret_cast<const float2*>(embeddings), (uint32_t)(emb_bytes64 / 2), G,
+        reinterpret_cast<const float4*>(packed), density_scale, sigma, rgb, nullptr, ray_ids,
+        reinterpret_cast<const float4*>(sh_table_q), NerfSave{});
+    return check_launch("nerf_forward_table_half");
+  }
   const int grid = grid_for(k_nerf_fwd<true, true>, lds, (M + 15) / 16);
   k_nerf_fwd<true, true><<<grid, kFieldThreads, lds, as_stream(s)>>>(
       x01, nullptr, M, nullptr, bound, reinterpret_cast<const float2*>(embeddings), (uint32_t)emb_bytes64, G,

@@ -415,6 +415,11 @@ class NeRFNetwork(NeRFRenderer):
         self.fused_instance_train = True     # False: HIP encoder + rocBLAS layers (the composable path)
         self.fused_nerf_train = True
         self.fused_nerf_head = True          # False: saved activations + k_nerf_bwd + five weight-gradient launches
+        # Opt-in (upstream's `-O` stores and computes in fp16): full-frame inference gathers from a half-precision COPY
+        # of the hash table (512 instead of 1024 bytes of table traffic per sample); parameters, training, index
+        # arithmetic, blending and the MLPs stay fp32.  Outputs differ from the fp32 table's by ~1e-3 relative.
+        self.half_table = False
+        self._half_cache = None
 
     # ---- packed MFMA weights (cached until a weight tensor changes) ------------------------------
     def _packed_weights(self, which):
@@ -490,6 +495,20 @@ class NeRFNetwork(NeRFRenderer):
             shq = self.sh_table(rays_d)
         sigma = torch.empty(M, dtype=torch.float32, device=dev)
         rgb = torch.empty(M, 3, dtype=torch.float32, device=dev)
+        if self.half_table and not self.training:
+            # opt-in (upstream's -O / fp16 storage): the eval kernel gathers from a half-precision copy of the table,
+            # refreshed whenever the fp32 master changes
+            emb = self.encoder.embeddings
+            key = (emb.data_ptr(), emb._version)
+            if self._half_cache is None or self._half_cache[0] != key:
+                self._half_cache = (key, emb.detach().to(torch.float16).contiguous())
+            check(lib.inr_nerf_forward_table_half(ptr(x01, torch.float32, "x01", allow_none=M == 0),
+                                                  ptr(ray_ids, torch.int32, "ray_ids", allow_none=M == 0), ptr(shq), M,
+                                                  float(self.bound), ptr(self._half_cache[1], torch.float16),
+                                                  self.encoder.desc, ptr(self._packed_weights("nerf")), 1.0,
+                                                  ptr(sigma, allow_none=M == 0), ptr(rgb, allow_none=M == 0), stream_ptr()),
+                  "nerf_forward_table_half")
+            return sigma, rgb
         check(lib.inr_nerf_forward_table(ptr(x01, torch.float32, "x01", allow_none=M == 0),
                                          ptr(ray_ids, torch.int32, "ray_ids", allow_none=M == 0), ptr(shq), M,
                                          float(self.bound), ptr(self.encoder.embeddings.data, torch.float32),

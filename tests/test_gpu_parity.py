@@ -450,6 +450,42 @@ def test_fused_field_golden(params_k16):
     assert np.abs(logits.cpu().numpy() - g["logits"]).max() < 1e-4
 
 
+def test_half_precision_table_is_the_fp32_path_on_rounded_values(params_k16, room, room_bitfield):
+    """NeRFNetwork.half_table (opt-in; upstream's -O / fp16 storage; Trainer(fp16=True) switches it on for evaluation):
+    the eval kernel gathers from a half-precision copy of the table.  Everything else is unchanged, so the frame is
+    BIT-IDENTICAL to the fp32 path run on a table whose values were rounded to fp16 first - and within 3e-3 of the
+    unrounded one (11 significant bits per table value)."""
+    from instance_nerf_amd.nerf.utils import Trainer, get_rays
+    poses, intr, H, W = room.cameras(n=1, H=96, W=96, focal=48.0)
+    r = get_rays(_t(poses[:1]), intr, 96, 96, patch=4)
+
+    def frame(net):
+        with torch.no_grad():
+            return net.render(r["rays_o"], r["rays_d"], bg_color=1, infer_mode="fused")
+    net = _network({k: v.clone() for k, v in params_k16.items()}, K=0).eval()
+    net.density_bitfield.copy_(_t(room_bitfield))
+    full = frame(net)
+    net.half_table = True
+    half = frame(net)
+    assert int(half["num_samples"][0]) == int(full["num_samples"][0])
+    d = (half["image"] - full["image"]).abs().max()
+    assert 0 < float(d) < 3e-3, float(d)
+    rounded = _network({k: v.clone() for k, v in params_k16.items()}, K=0).eval()
+    rounded.density_bitfield.copy_(_t(room_bitfield))
+    with torch.no_grad():
+        rounded.encoder.embeddings.copy_(rounded.encoder.embeddings.half().float())
+    ref = frame(rounded)
+    assert torch.equal(half["image"], ref["image"]) and torch.equal(half["depth"], ref["depth"])
+    # the copy follows the master table
+    with torch.no_grad():
+        net.encoder.embeddings.mul_(0.5)
+    again = frame(net)
+    assert not torch.equal(again["image"], half["image"])
+    # upstream's flag
+    tr = Trainer("h", None, _network(params_k16, K=0), stage="nerf", device=torch.device(DEV), fp16=True, workspace=None)
+    assert tr.model.half_table and tr.fp16
+
+
 def test_exact_fp32_mlp_build(params_k16):
     """The -DINR_MLP_FP32=1 build (MLP GEMMs on v_mfma_f32_16x16x4_f32, exact fp32 products) stays alive: the same
     golden field vectors through libinr_hip_fp32.so in a child process (a process binds one library).  Both builds
