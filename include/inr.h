@@ -314,7 +314,7 @@ int inr_nerf_forward_enc(const float* x, const float* d, int64_t M, float bound,
 int inr_nerf_head_backward(const float* enc, const float* d, const float* grad_sigma, const float* grad_rgb, int64_t M,
                            float density_scale, const float* packed_fwd, const float* packed_bwd, float* grad_enc,
                            void* workspace, float* grad_ws0, float* grad_ws1, float* grad_wc0, float* grad_wc1,
-                           float* grad_wc2, inr_stream_t s);
+                           float* grad_wc2, float* zero_buf /*nullable*/, int64_t zero_floats, inr_stream_t s);
 /* Training path of the instance field (a13): weights are packed ON THE DEVICE every step (forward layout as
  * inr_instance_pack_weights, plus the transposed sections the input-gradient kernel uses); the forward also
  * stores the encoder output [M,32] and both hidden activations [M,64]; inr_instance_backward turns
@@ -339,7 +339,8 @@ int inr_instance_backward(const float* grad_logits, int32_t K, const float* h1, 
  * from enc with packed_fwd, the input-gradient chain uses packed_bwd, and dW += g^T h on the fp32 matrix cores with
  * the tiles transposed through LDS - replaces inr_composite_rays_train_backward (K channels), inr_instance_backward
  * and three inr_linear_wgrad calls, and ~3 KB of HBM traffic per sample.  scale_a, scale_b: device scalars that
- * multiply grad_pix (1 / kept rows and dL/dloss of the fused cross entropy; NULL = 1).  workspace:
+ * multiply grad_pix (1 / kept rows and dL/dloss of the fused cross entropy; NULL = 1).  zero_buf (nullable): zero_floats
+ * floats that the launch zero-fills on the side - the table-gradient buffer of the scatter that follows.  workspace:
  * inr_instance_head_workspace_bytes() bytes.  The table gradient stays inr_grid_encode_backward(grad_enc).      */
 int inr_instance_forward_enc(const float* x, int64_t M, const int32_t* n_samples_dev, float bound,
                              const float* embeddings, const inr_grid_desc* desc /*host*/, const float* packed_fwd,
@@ -349,7 +350,8 @@ int inr_instance_head_backward(const float* enc, const float* weights, const int
                                const float* grad_pix, int32_t K, int64_t N, int64_t M, const int32_t* n_samples_dev,
                                const float* scale_a /*device scalar, nullable*/, const float* scale_b /*same*/,
                                const float* packed_fwd, const float* packed_bwd, float* grad_enc, void* workspace,
-                               float* grad_w0, float* grad_w1, float* grad_w2, inr_stream_t s);
+                               float* grad_w0, float* grad_w1, float* grad_w2, float* zero_buf /*nullable*/,
+                               int64_t zero_floats, inr_stream_t s);
 /* rgb-sigma lattice extraction (the step after the path that feeds NeRF-RCNN: /root/reference/nerf_rcnn/datasets.py:766-792
  * reads the result): out[m] = (mean over n_dirs fixed view directions of rgb(x_m, dir), raw density logit of x_m) -
  * one gather + one sigma-net pass per point, the colour net once per direction.  sh_dirs [n_dirs,16] = degree-4 SH rows

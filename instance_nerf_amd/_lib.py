@@ -55,10 +55,10 @@ _SIGS = {
     "inr_instance_forward_train": (c_int32, [P, c_int64, c_float, P, POINTER(GridDesc), P, c_int32, P, P, P, P, P]),
     "inr_instance_backward": (c_int32, [P, c_int32, P, P, c_int64, P, P, P, P, P]),
     "inr_nerf_forward_enc": (c_int32, [P, P, c_int64, c_float, P, POINTER(GridDesc), P, P, P, P, P]),
-    "inr_nerf_head_backward": (c_int32, [P, P, P, P, c_int64, c_float, P, P, P, P, P, P, P, P, P, P]),
+    "inr_nerf_head_backward": (c_int32, [P, P, P, P, c_int64, c_float, P, P, P, P, P, P, P, P, P, P, c_int64, P]),
     "inr_instance_forward_enc": (c_int32, [P, c_int64, P, c_float, P, POINTER(GridDesc), P, c_int32, P, P, P]),
     "inr_instance_head_workspace_bytes": (c_int64, []),
-    "inr_instance_head_backward": (c_int32, [P, P, P, P, c_int32, c_int64, c_int64, P, P, P, P, P, P, P, P, P, P, P]),
+    "inr_instance_head_backward": (c_int32, [P, P, P, P, c_int32, c_int64, c_int64, P, P, P, P, P, P, P, P, P, P, P, c_int64, P]),
     "inr_adam_step_multi": (c_int32, [c_int32, P, P, P, P, P, P, c_float, c_float, c_float, c_int32, c_float, P]),
     "inr_adam_ema_step_multi": (c_int32, [c_int32, P, P, P, P, P, P, c_float, c_float, c_float, c_int32, c_float, P,
                                           c_float, P]),

@@ -976,6 +976,17 @@ constexpr int kHbStageFloats = 2 * kHbWaves * kHbTileFloats;            // G and
 constexpr int kHbFwdFloats = kIns2;                                      // forward sections kIns0, kIns1
 constexpr int kHbAccTiles = 40;
 
+// The table-gradient buffer of the scatter that FOLLOWS a head-backward launch is zero-filled by that launch (every
+// workgroup a slice, before its first tile): one launch and one exposed 49 MB fill less per training step.
+__device__ __forceinline__ void hb_zero_fill(float* __restrict__ buf, int64_t n) {
+  if (!buf) return;
+  float4* b4 = reinterpret_cast<float4*>(buf);
+  const int64_t n4 = n >> 2;
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) b4[i] = z;
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) buf[(n4 << 2) + threadIdx.x] = 0.f;
+}
+
 template <int N_T>
 __device__ __forceinline__ void hb_stage(float* __restrict__ tile_base, int q, int j, const f32x4* v) {
 #pragma unroll
@@ -1006,8 +1017,9 @@ __global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_instance_head
     const float* __restrict__ g_pix, int Kp, int64_t M, const int32_t* __restrict__ n_dev,
     const float* __restrict__ scale_a, const float* __restrict__ scale_b,
     const float4* __restrict__ packed_fwd, const float4* __restrict__ packed_bwd, float* __restrict__ denc,
-    float4* __restrict__ partial) {
+    float4* __restrict__ partial, float* __restrict__ zero_buf, int64_t zero_n) {
   extern __shared__ __attribute__((aligned(16))) float4 wl[];
+  hb_zero_fill(zero_buf, zero_n);
   float4* wf = wl;
   float4* wb = wl + kHbFwdFloats / 4;
   float* gS = reinterpret_cast<float*>(wb + kBwdFloats / 4);
@@ -1267,8 +1279,10 @@ __device__ __forceinline__ void nh_stage_cin(float* __restrict__ tile_base, int 
 __global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_nerf_head_bwd(
     const float* __restrict__ enc, const float* __restrict__ dirs, const float* __restrict__ g_sigma,
     const float* __restrict__ g_rgb, int64_t M, float density_scale, const float4* __restrict__ packed_fwd,
-    const float4* __restrict__ packed_bwd, float* __restrict__ d_enc, float4* __restrict__ partial) {
+    const float4* __restrict__ packed_bwd, float* __restrict__ d_enc, float4* __restrict__ partial,
+    float* __restrict__ zero_buf, int64_t zero_n) {
   extern __shared__ __attribute__((aligned(16))) float4 wl[];
+  hb_zero_fill(zero_buf, zero_n);
   float4* wf = wl;
   float4* wb = wl + kNhFwdFloats / 4;
   float* gS = reinterpret_cast<float*>(wb + kNerfBwdFloats / 4);
@@ -2076,7 +2090,9 @@ int64_t inr_instance_head_workspace_bytes(void) {
 int inr_instance_head_backward(const float* enc, const float* weights, const int32_t* sample_ray, const float* grad_pix,
                                int32_t K, int64_t N, int64_t M, const int32_t* n_samples_dev, const float* scale_a,
                                const float* scale_b, const float* packed_fwd, const float* packed_bwd, float* grad_enc,
-                               void* workspace, float* grad_w0, float* grad_w1, float* grad_w2, inr_stream_t s) {
+                               void* workspace, float* grad_w0, float* grad_w1, float* grad_w2, float* zero_buf,
+                               int64_t zero_floats, inr_stream_t s) {
+  INR_REQUIRE(zero_floats >= 0 && (!zero_buf || ((uintptr_t)zero_buf & 15) == 0), "zero_buf must be 16-byte aligned");
   INR_REQUIRE(M >= 0 && N >= 0, "negative size");
   INR_REQUIRE(K > 0 && K <= 64 && K % 16 == 0, "K must be 16, 32, 48 or 64");
   INR_REQUIRE(grad_w0 && grad_w1 && grad_w2 && workspace && packed_fwd && packed_bwd, "null pointer");
@@ -2098,7 +2114,7 @@ int inr_instance_head_backward(const float* enc, const float* weights, const int
   k_instance_head_bwd<<<grid, kFieldThreads, lds, st>>>(enc, weights, sample_ray, grad_pix, K, M, n_samples_dev,
                                                         scale_a, scale_b, reinterpret_cast<const float4*>(packed_fwd),
                                                         reinterpret_cast<const float4*>(packed_bwd), grad_enc,
-                                                        reinterpret_cast<float4*>(workspace));
+                                                        reinterpret_cast<float4*>(workspace), zero_buf, zero_floats);
   k_head_wgrad_reduce<<<kHbAccTiles * 256 / 64, 1024, 0, st>>>(reinterpret_cast<const float*>(workspace), grid, K, grad_w0,
                                                                grad_w1, grad_w2);
   return check_launch("instance_head_backward");
@@ -2195,8 +2211,9 @@ int inr_nerf_forward_enc(const float* x, const float* d, int64_t M, float bound,
 int inr_nerf_head_backward(const float* enc, const float* d, const float* grad_sigma, const float* grad_rgb, int64_t M,
                            float density_scale, const float* packed_fwd, const float* packed_bwd, float* grad_enc,
                            void* workspace, float* grad_ws0, float* grad_ws1, float* grad_wc0, float* grad_wc1,
-                           float* grad_wc2, inr_stream_t s) {
+                           float* grad_wc2, float* zero_buf, int64_t zero_floats, inr_stream_t s) {
   INR_REQUIRE(M >= 0, "negative M");
+  INR_REQUIRE(zero_floats >= 0 && (!zero_buf || ((uintptr_t)zero_buf & 15) == 0), "zero_buf must be 16-byte aligned");
   INR_REQUIRE(packed_fwd && packed_bwd && workspace && grad_ws0 && grad_ws1 && grad_wc0 && grad_wc1 && grad_wc2, "null pointer");
   INR_REQUIRE(M == 0 || (enc && d && grad_sigma && grad_rgb && grad_enc), "null sample arrays");
   INR_REQUIRE((((uintptr_t)enc | (uintptr_t)packed_fwd | (uintptr_t)packed_bwd | (uintptr_t)grad_enc | (uintptr_t)workspace) & 15) == 0,
@@ -2215,7 +2232,7 @@ int inr_nerf_head_backward(const float* enc, const float* d, const float* grad_s
   k_nerf_head_bwd<<<grid, kFieldThreads, lds, st>>>(enc, d, grad_sigma, grad_rgb, M, density_scale,
                                                     reinterpret_cast<const float4*>(packed_fwd),
                                                     reinterpret_cast<const float4*>(packed_bwd), grad_enc,
-                                                    reinterpret_cast<float4*>(workspace));
+                                                    reinterpret_cast<float4*>(workspace), zero_buf, zero_floats);
   k_nerf_head_wgrad_reduce<<<kHbAccTiles * 256 / 64, 1024, 0, st>>>(reinterpret_cast<const float*>(workspace), grid, grad_wc2,
                                                                     grad_wc1, grad_wc0, grad_ws1, grad_ws0);
   return check_launch("nerf_head_backward");

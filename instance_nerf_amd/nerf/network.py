@@ -217,6 +217,7 @@ class _InstanceHeadFn(torch.autograd.Function):
         gw = torch.empty(64 * 32 + 64 * 64 + K * 64, dtype=f32, device=dev)          # written by the reduce kernel
         gw0, gw1, gw2 = gw[:2048].view(64, 32), gw[2048:6144].view(64, 64), gw[6144:].view(K, 64)
         ws = torch.empty(lib.inr_instance_head_workspace_bytes() // 4, dtype=f32, device=dev)
+        g_emb = torch.empty_like(emb)              # zero-filled by the backward launch, on the side
         none_ok = M == 0
         check(lib.inr_instance_head_backward(ptr(enc, allow_none=none_ok), ptr(weights, allow_none=none_ok),
                                              ptr(sample_ray, torch.int32, "sample_ray", allow_none=none_ok),
@@ -225,8 +226,7 @@ class _InstanceHeadFn(torch.autograd.Function):
                                              ptr(scale_a, f32, "scale_a", allow_none=True),
                                              ptr(scale_b, f32, "scale_b", allow_none=True), ptr(pf), ptr(pb),
                                              ptr(denc, allow_none=none_ok), ptr(ws), ptr(gw0), ptr(gw1), ptr(gw2),
-                                             stream_ptr()), "instance_head_backward")
-        g_emb = torch.zeros_like(emb)
+                                             ptr(g_emb), g_emb.numel(), stream_ptr()), "instance_head_backward")
         g_emb = _table_backward(lib, x, denc, ctx.desc, M, ctx.bound, g_emb, emb)
         return None, None, None, None, None, None, None, None, g_emb, gw0, gw1, gw2, None, None
 
@@ -276,12 +276,12 @@ class _NerfFieldFn(torch.autograd.Function):
         gwc2, gwc1, gwc0, gws1, gws0 = [g.view(*shape) for g, shape in zip(
             gw.split(sizes), ((16, 64), (64, 64), (64, 32), (16, 64), (64, 32)))]
         wsp = torch.empty(lib.inr_instance_head_workspace_bytes() // 4, dtype=f32, device=dev)
+        g_emb = torch.empty_like(emb)              # zero-filled by the backward launch, on the side
         none_ok = M == 0
         check(lib.inr_nerf_head_backward(ptr(enc, allow_none=none_ok), ptr(d, allow_none=none_ok),
                                          ptr(g_sigma, allow_none=none_ok), ptr(g_rgb, allow_none=none_ok), M, 1.0, ptr(pf),
                                          ptr(pb), ptr(d_enc, allow_none=none_ok), ptr(wsp), ptr(gws0), ptr(gws1), ptr(gwc0),
-                                         ptr(gwc1), ptr(gwc2), stream_ptr()), "nerf_head_backward")
-        g_emb = torch.zeros_like(emb)
+                                         ptr(gwc1), ptr(gwc2), ptr(g_emb), g_emb.numel(), stream_ptr()), "nerf_head_backward")
         g_emb = _table_backward(lib, x, d_enc, ctx.desc, M, ctx.bound, g_emb, emb)
         return None, None, g_emb, gws0, gws1, gwc0[:, :31], gwc1, gwc2[:3], None, None
 

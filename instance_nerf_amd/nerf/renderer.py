@@ -278,8 +278,7 @@ class NeRFRenderer(nn.Module):
             skipped_frac = (skippable, int(xyzs.shape[0]), False)       # raw counter, marched total (host), "skippable"
         elif self.training or infer_mode == "fused_raymajor":
             if self.training:
-                counter = self.step_counter[self.local_step % 16]
-                counter.zero_()
+                counter = self.step_counter[self.local_step % 16]        # (total samples, N): written by the count pass
                 self.local_step += 1
                 mean_count = self.mean_count
             else:
