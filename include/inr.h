@@ -430,7 +430,9 @@ int inr_adam_step_multi_dev(int32_t n_tensors, float* const* params, const float
 /* Mask-supervised loss of the instance stage (a13; replaces F.cross_entropy(logits, labels, ignore_index) + its
  * backward in the fork's instance trainer): loss[0] = mean over rows with 0 <= label < K and label != ignore_index of
  * logsumexp(row) - row[label]; grad_logits [N,K] = d loss / d logits (zero rows where ignored); acc = 128 floats of
- * scratch (per-workgroup partial sums: no atomics), 8-byte aligned.  K <= 64.  NaN loss when no row is kept (torch's mean over an empty set).                               */
+ * scratch (per-workgroup partial sums: no atomics), 8-byte aligned.  K <= 64.  NaN loss when no row is kept (torch's
+ * mean over an empty set) AND when a label is neither ignore_index nor in [0, K) (torch asserts on the device for such
+ * a label; the row is never dropped silently).                                                                    */
 int inr_cross_entropy(const float* logits /*[N,K]*/, const int64_t* labels /*[N]*/, int64_t N, int32_t K,
                       int64_t ignore_index, float* grad_logits, float* acc, float* loss, inr_stream_t s);
 /* Tail of NeRFRenderer.run_cuda (a14): image_out = image + (1 - weights_sum) * bg;

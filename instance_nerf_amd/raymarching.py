@@ -431,5 +431,7 @@ class _CrossEntropy(torch.autograd.Function):
 def cross_entropy(logits, labels, ignore_index=-1):
     """Mean cross entropy of logits [N,K] (K <= 64) against int64 labels [N], rows with ``ignore_index`` skipped - the
     mask-supervised loss of the instance stage - value and gradient in two HIP launches instead of
-    torch's log_softmax / nll_loss pairs.  Same semantics as ``F.cross_entropy(logits, labels, ignore_index=...)``."""
+    torch's log_softmax / nll_loss pairs.  Same values as ``F.cross_entropy(logits, labels, ignore_index=...)``; a label
+    that is neither ``ignore_index`` nor a class - torch asserts on the device for it - makes the loss NaN here (such a
+    row is never dropped silently: a detection-count mismatch must not train on fewer rows unnoticed)."""
     return _CrossEntropy.apply(logits, labels, ignore_index)
