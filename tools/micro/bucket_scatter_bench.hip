@@ -81,7 +81,19 @@ __global__ void __launch_bounds__(512) k_accum(const Rec* __restrict__ recs, con
   __syncthreads();
   const Rec* r = recs + bin_base[bin];
   const int n = totals[bin];
-  for (int i = threadIdx.x; i < n; i += 512) {
+  // eight records in flight per thread: the loop is a chain of global loads otherwise (267 us -> see the printout)
+  int i = threadIdx.x;
+  for (; i + 7 * 512 < n; i += 8 * 512) {
+    Rec v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = r[i + u * 512];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      atomicAdd(&slice[2 * v[u].row], v[u].g0);
+      atomicAdd(&slice[2 * v[u].row + 1], v[u].g1);
+    }
+  }
+  for (; i < n; i += 512) {
     const Rec v = r[i];
     atomicAdd(&slice[2 * v.row], v.g0);
     atomicAdd(&slice[2 * v.row + 1], v.g1);
