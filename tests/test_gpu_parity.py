@@ -1646,7 +1646,7 @@ def test_trainer_renders_row_major_views_in_patch_order(params_k16, room, room_b
     assert torch.equal(seen["first_dirs"], r["rays_d"][0].view(64, 96, 3)[:4, :4].reshape(16, 3))
 
 
-@pytest.mark.parametrize("K,drop", [(64, False), (31, False), (16, True)])
+@pytest.mark.parametrize("K,drop", [(64, False), (31, False), (16, True), (40, False)])
 def test_instance_head_node_equals_the_composable_chain(level_table, room, room_bitfield, K, drop):
     """The one-node instance head (k_instance_fwd<.., enc only> + K-channel compositing forward; k_instance_head_bwd =
     compositing backward + recomputed hidden layers + input-gradient chain + the three weight gradients in ONE launch)
@@ -1750,6 +1750,13 @@ def test_label_outside_the_classes_poisons_the_loss(level_table, room, room_bitf
     lab[0, 5] = K + 3
     out = net.render(_t(ro)[None], _t(rd)[None], bg_color=1, perturb=False, force_all_rays=True, ce_labels=lab)
     assert torch.isnan(out["instance_ce"])
+    # every label ignored: the mean over an empty set, NaN as in torch - and a backward that does not crash
+    lab = torch.full((1, 64), -1, device=DEV)
+    out = net.render(_t(ro)[None], _t(rd)[None], bg_color=1, perturb=False, force_all_rays=True, ce_labels=lab)
+    assert torch.isnan(out["instance_ce"])
+    assert torch.isnan(torch.nn.functional.cross_entropy(out["instance"][0].detach(), lab[0], ignore_index=-1))
+    out["instance_ce"].backward()
+    assert net.instance_encoder.embeddings.grad is not None
 
 
 def test_composite_train_with_dropped_rays(rm, room, room_bitfield, bits_dev):
