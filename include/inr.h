@@ -123,6 +123,9 @@ int inr_packbits_mean(const float* grid, int64_t n_cells /*all cascades*/, const
  * regenerates the sequence and emits at the set bits instead of walking the occupancy grid again (rays that
  * need more candidates are re-marched); pass the SAME workspace and sample_cap to the write call.  Results
  * are identical.                                                                                        */
+/* 1 when inr_march_rays_train_write zero-fills the rows of xyzs / dirs / deltas that no ray owns by itself (the staged
+ * wave-per-ray marcher does; the caller may then pass uninitialised buffers), 0 when the caller must zero them first. */
+int inr_march_write_fills_unowned_rows(int64_t N, int32_t sample_cap, int32_t max_steps);
 int64_t inr_march_workspace_bytes(int64_t N, int32_t sample_cap);
 int inr_march_rays_train_count(const float* rays_o, const float* rays_d, const uint8_t* bitfield,
                                float bound, float dt_gamma, int32_t max_steps, int64_t N,

@@ -39,6 +39,7 @@ _SIGS = {
     "inr_occ_cell_positions": (c_int32, [P, P, c_int64, c_int32, c_float, P, P]),
     "inr_occ_update": (c_int32, [P, P, P, c_int64, c_int64, c_float, c_float, P, P, P]),
     "inr_packbits_mean": (c_int32, [P, c_int64, P, c_float, P, P, P]),
+    "inr_march_write_fills_unowned_rows": (c_int32, [c_int64, c_int32, c_int32]),
     "inr_march_workspace_bytes": (c_int64, [c_int64, c_int32]),
     "inr_march_rays_train_count": (c_int32, [P, P, P, c_float, c_float, c_int32, c_int64, c_int32, c_int32,
                                              P, P, P, P, P, P, c_int32, P]),

@@ -659,10 +659,30 @@ __global__ void __launch_bounds__(kCoopRaysPerBlock * 64) k_march_write_staged(c
   if (n >= N) return;
   const int off = rays[n * 3 + 1];
   const int cnt = rays[n * 3 + 2];
-  if (cnt == 0 || (int64_t)off + cnt > M) return;
+  const int lane = threadIdx.x & 63;
+  // Rows nobody owns are zero-filled HERE (the caller hands over uninitialised buffers: one fill launch less per
+  // step): the tail behind the last ray's samples is shared out over all waves, and the one dropped ray that starts
+  // inside the buffer (offset < M < offset + count; every later ray starts beyond M) clears from its offset on.
+  auto zero_rows = [&](int64_t lo, int64_t hi) {
+    for (int64_t i = lo + lane; i < hi; i += 64) {
+      xyzs[i * 3 + 0] = 0.f; xyzs[i * 3 + 1] = 0.f; xyzs[i * 3 + 2] = 0.f;
+      dirs[i * 3 + 0] = 0.f; dirs[i * 3 + 1] = 0.f; dirs[i * 3 + 2] = 0.f;
+      deltas[i * 2 + 0] = 0.f; deltas[i * 2 + 1] = 0.f;
+    }
+  };
+  const int64_t total = (int64_t)rays[(N - 1) * 3 + 1] + rays[(N - 1) * 3 + 2];
+  if (total < M) {
+    const int64_t per = (M - total + N - 1) / N;
+    zero_rows(total + n * per, min(M, total + (n + 1) * per));
+  }
+  if ((int64_t)off + cnt > M) {
+    if (cnt > 0 && off < M) zero_rows(off, M);
+    return;
+  }
+  if (cnt == 0) return;
   const float dx = rays_d[n * 3], dy = rays_d[n * 3 + 1], dz = rays_d[n * 3 + 2];
   const float* row = stage + (size_t)n * stage_pitch * 5;
-  for (int k = threadIdx.x & 63; k < cnt; k += 64) {
+  for (int k = lane; k < cnt; k += 64) {
     const float* q = row + (size_t)k * 5;
     const int64_t i = (int64_t)off + k;
     xyzs[i * 3 + 0] = q[0]; xyzs[i * 3 + 1] = q[1]; xyzs[i * 3 + 2] = q[2];
@@ -1532,6 +1552,9 @@ static int64_t stage_offset_bytes(int64_t N, int32_t sample_cap) {          // 1
   const int w = cap_words_of(sample_cap);
   const int64_t b = ws_ints(N) * (int64_t)sizeof(int32_t) + (w ? N * (int64_t)(w + 1) * (int64_t)sizeof(uint32_t) : 0);
   return (b + 15) / 16 * 16;
+}
+int inr_march_write_fills_unowned_rows(int64_t N, int32_t sample_cap, int32_t max_steps) {
+  return use_stage(N, sample_cap, max_steps) ? 1 : 0;
 }
 int64_t inr_march_workspace_bytes(int64_t N, int32_t sample_cap) {
   const int64_t base = stage_offset_bytes(N, sample_cap);

@@ -147,11 +147,13 @@ def march_rays_train(rays_o, rays_d, bound, density_bitfield, C, H, nears, fars,
         M = int(mean_count)
     if align > 0:
         M += align - M % align if M % align else 0
+    # rows no ray owns (padding, dropped rays) must be zero: the staged marcher's write pass clears them itself
+    alloc = torch.empty if lib.inr_march_write_fills_unowned_rows(N, cap, int(max_steps)) else torch.zeros
     if separate_buffers:     # three allocations (the registered custom op may not return views of one buffer)
-        xyzs, dirs, deltas = (torch.zeros(M, 3, dtype=F32, device=dev), torch.zeros(M, 3, dtype=F32, device=dev),
-                              torch.zeros(M, 2, dtype=F32, device=dev))
+        xyzs, dirs, deltas = (alloc(M, 3, dtype=F32, device=dev), alloc(M, 3, dtype=F32, device=dev),
+                              alloc(M, 2, dtype=F32, device=dev))
     else:
-        buf = torch.zeros(M * 8, dtype=F32, device=dev)      # one fill: rows no ray owns (padding, dropped rays) are zero
+        buf = alloc(M * 8, dtype=F32, device=dev)
         xyzs, dirs, deltas = buf[:M * 3].view(M, 3), buf[M * 3:M * 6].view(M, 3), buf[M * 6:].view(M, 2)
     check(lib.inr_march_rays_train_write(*args, M, ptr(nears), ptr(fars), ptr(noises, F32, "noises", allow_none=True),
                                          ptr(rays), ptr(xyzs), ptr(dirs), ptr(deltas), ptr(ws), cap, stream_ptr()),
