@@ -694,6 +694,7 @@ def main():
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()             # the ranks leave together (rank 0 alone ran the single-GPU legs after the probes)
         dist.destroy_process_group()
 
 
