@@ -37,7 +37,7 @@ extern "C" {
 /* Bumped whenever an existing prototype changes or an entry point is removed (round 2 changed four argument lists
  * without a bump: a stale library or an external caller built against the old header was only rejected by accident).
  * instance_nerf_amd/_lib.py refuses a library whose version differs from the one it was written against. */
-#define INR_ABI_VERSION 3
+#define INR_ABI_VERSION 4
 #define INR_MAX_LEVELS 16
 
 enum {
@@ -183,7 +183,9 @@ int inr_compact_alive(const int32_t* rays_alive, int64_t n_alive, int32_t* out, 
 
 /* ---- compositing for training (replaces raymarching.composite_rays_train fwd/bwd, a12/a13) ----
  * M = rows of the sample arrays: a ray with offset + count > M was dropped by the march writer and
- * composites to zero (its gradient rows are left untouched - the caller zero-initialises them).
+ * composites to zero (its gradient rows are left untouched - the caller zero-initialises them - unless the backward
+ * is given total_dev, the device int32 with the marcher's sample total: the rays' rows then tile [0, total) and the
+ * backward writes every row of grad_sigmas / grad_rgbs in [0, M) itself, zeros where no ray owns the row).
  * weights [M] (nullable unless extra is given): receives the per-sample compositing weight
  * w = alpha * T (0 behind the termination point); the K-channel forward/backward use it.
  * sample_ray [M] (nullable; needs weights): receives, for every sample a ray owns, the row rays[n][0] of that ray's
@@ -213,7 +215,8 @@ int inr_composite_rays_train_backward(const float* grad_weights_sum, const float
                                       const float* image, const float* weights /*[M] from forward*/,
                                       int64_t N, int64_t M, float T_thresh, int32_t K,
                                       float* grad_sigmas, float* grad_rgbs /*both nullable: frozen NeRF*/,
-                                      float* grad_extra /*[M,K] nullable*/, inr_stream_t s);
+                                      float* grad_extra /*[M,K] nullable*/, const int32_t* total_dev /*nullable*/,
+                                      inr_stream_t s);
 
 /* ---- hash grid (replaces gridencoder grid_encode_forward / _backward, a7/a8) -------- */
 int inr_grid_encode_forward(const float* x /*[M,3]*/, const float* embeddings /*[T,F]*/,
@@ -305,7 +308,7 @@ int inr_nerf_backward(const float* grad_sigma, const float* grad_rgb, const floa
 /* The NeRF field of a training step in two launches per direction (round 3; the NeRF-stage twin of
  * inr_instance_forward_enc / inr_instance_head_backward).  Forward: as inr_nerf_forward_train but only the encoder
  * output [M,32] is kept.  Backward: ONE launch from (dL/dsigma [M], dL/drgb [M,3]) to dL/denc [M,32] and the five
- * weight gradients - grad_ws0 [64,32], grad_ws1 [16,64], grad_wc0 [64,32] (column 31 is padding), grad_wc1 [64,64],
+ * weight gradients - grad_ws0 [64,32], grad_ws1 [16,64], grad_wc0 [64,31] (the colour net's 31 inputs, pitch 31), grad_wc1 [64,64],
  * grad_wc2 [16,64] (rows 0..2 live), written, not accumulated: the forward is recomputed from enc and the view
  * directions d [M,3] with packed_fwd, the input-gradient chain is inr_nerf_backward's, and the weight gradients are
  * accumulated on the fp32 matrix cores with the tiles transposed through LDS.  Replaces inr_nerf_backward and five
@@ -447,6 +450,18 @@ int inr_cross_entropy(const float* logits /*[N,K]*/, const int64_t* labels /*[N]
 int inr_finish_rays(const float* image /*[N,3]*/, const float* depth /*[N]*/, const float* weights_sum,
                     const float* nears, const float* fars, const float* t0 /*[N] nullable*/, float bg_r, float bg_g,
                     float bg_b, int64_t N, float* image_out, float* depth_out, inr_stream_t s);
+
+/* The training tail of the NeRF stage in one launch (Trainer.train_step, stage "nerf", default criterion): the blend and
+ * depth of inr_finish_rays (training: no t0), loss[0] = mean((image_out - target)^2) over the 3N channels - upstream's
+ * ``criterion(pred, gt).mean()`` with MSELoss(reduction='none') -, and the gradients of that loss:
+ * grad[0, 3N) = d loss / d image, grad[3N, 4N) = d loss / d weights_sum (the blend's -sum_c g_c * bg_c).
+ * bg_rays (nullable, [N,3]) replaces the uniform colour per ray.  One workgroup, fixed summation order:
+ * 0 < N <= INR_FINISH_MSE_MAX_RAYS; larger batches use inr_finish_rays / torch ops. */
+#define INR_FINISH_MSE_MAX_RAYS 65536
+int inr_finish_rays_mse(const float* image /*[N,3]*/, const float* depth /*[N]*/, const float* weights_sum,
+                        const float* nears, const float* fars, float bg_r, float bg_g, float bg_b,
+                        const float* bg_rays /*[N,3] nullable*/, const float* target /*[N,3]*/, int64_t N,
+                        float* image_out, float* depth_out, float* grad /*[4N]*/, float* loss /*[1]*/, inr_stream_t s);
 
 #ifdef __cplusplus
 }

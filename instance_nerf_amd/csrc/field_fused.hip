@@ -1399,7 +1399,7 @@ __global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_nerf_head_bwd
   for (int k = 0; k < 5; ++k) out[ids[k] * 64 + lane] = make_float4(acc[k][0], acc[k][1], acc[k][2], acc[k][3]);
 }
 
-// sums the workgroups' partials into gwc2 [16,64] (3 live rows), gwc1 [64,64], gwc0 [64,32] (31 live columns),
+// sums the workgroups' partials into gwc2 [16,64] (3 live rows), gwc1 [64,64], gwc0 [64,31],
 // gws1 [16,64], gws0 [64,32] - written, not accumulated.
 __global__ void __launch_bounds__(1024) k_nerf_head_wgrad_reduce(const float* __restrict__ partial, int n_groups,
                                                                  float* __restrict__ gwc2, float* __restrict__ gwc1,
@@ -1427,7 +1427,10 @@ __global__ void __launch_bounds__(1024) k_nerf_head_wgrad_reduce(const float* __
     const int tile = idx >> 8, lane = (idx >> 2) & 63, r = idx & 3;
     const int ol = 4 * (lane >> 4) + r, il = lane & 15;
     if (tile < 16) gwc1[(16 * (tile >> 2) + ol) * 64 + 16 * (tile & 3) + il] = s;
-    else if (tile < 24) gwc0[(16 * ((tile - 16) >> 1) + ol) * 32 + 16 * ((tile - 16) & 1) + il] = s;
+    else if (tile < 24) {                   // [64,31] as nn.Linear stores it (the padding column 31 is dropped)
+      const int col = 16 * ((tile - 16) & 1) + il;
+      if (col < 31) gwc0[(16 * ((tile - 16) >> 1) + ol) * 31 + col] = s;
+    }
     else if (tile < 32) gws0[(16 * ((tile - 24) >> 1) + ol) * 32 + 16 * ((tile - 24) & 1) + il] = s;
     else if (tile < 36) gwc2[ol * 64 + 16 * (tile - 32) + il] = s;
     else gws1[ol * 64 + 16 * (tile - 36) + il] = s;

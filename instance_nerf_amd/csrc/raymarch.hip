@@ -825,6 +825,52 @@ __global__ void __launch_bounds__(256) k_finish_rays(const float* image, const f
   depth_out[n] = fmaxf(d - nears[n], 0.0f) / (fars[n] - nears[n]);
 }
 
+// Training tail of the NeRF stage in ONE launch: background blend + depth normalisation (k_finish_rays) + the mean squared
+// error against the batch's pixels + its gradients.  Under autograd the same tail is ~18 element-wise / reduce launches
+// of 2-5 us each between the compositing forward and backward (profiles/r03_NOTES.txt section 11).  One workgroup: a
+// training batch is a few thousand rays, and a single workgroup sums in a fixed order (deterministic loss).
+//   image_out = image + (1 - ws) * bg          bg: one colour, or bg_rays [N,3] (upstream's random background for RGBA)
+//   loss      = mean over the 3N channels of (image_out - target)^2
+//   grad[0, 3N)  = d loss / d image  = 2 (image_out - target) / 3N
+//   grad[3N, 4N) = d loss / d ws     = -sum_c grad_image_c * bg_c
+constexpr int kFinishMseThreads = 1024;
+__global__ void __launch_bounds__(kFinishMseThreads) k_finish_rays_mse(
+    const float* __restrict__ image, const float* __restrict__ depth, const float* __restrict__ weights_sum,
+    const float* __restrict__ nears, const float* __restrict__ fars, float bg_r, float bg_g, float bg_b,
+    const float* __restrict__ bg_rays, const float* __restrict__ target, int64_t N, float* __restrict__ image_out,
+    float* __restrict__ depth_out, float* __restrict__ grad, float* __restrict__ loss) {
+  __shared__ float part[kFinishMseThreads / 64];
+  const float inv = 1.0f / (3.0f * (float)N);
+  float acc = 0.0f;
+  for (int64_t n = threadIdx.x; n < N; n += kFinishMseThreads) {
+    const float ws = weights_sum[n];
+    const float a = 1.0f - ws;
+    float bg[3] = {bg_r, bg_g, bg_b};
+    if (bg_rays) { bg[0] = bg_rays[n * 3 + 0]; bg[1] = bg_rays[n * 3 + 1]; bg[2] = bg_rays[n * 3 + 2]; }
+    float gws = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float px = image[n * 3 + c] + a * bg[c];
+      const float e = px - target[n * 3 + c];
+      const float g = 2.0f * e * inv;
+      image_out[n * 3 + c] = px;
+      grad[n * 3 + c] = g;
+      gws -= g * bg[c];
+      acc += e * e;
+    }
+    grad[3 * N + n] = gws;
+    depth_out[n] = fmaxf(depth[n] - nears[n], 0.0f) / (fars[n] - nears[n]);
+  }
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.0f;
+    for (int w = 0; w < kFinishMseThreads / 64; ++w) t += part[w];
+    loss[0] = t * inv;
+  }
+}
+
 // a5: inference march, up to n_step samples per live ray; buffers pre-zeroed by this kernel
 __global__ void __launch_bounds__(kRayBlock) k_march_rays(MarchParams P, int64_t n_alive, int n_step,
                                                           const int32_t* __restrict__ rays_alive,
@@ -1110,13 +1156,32 @@ __global__ void __launch_bounds__(kRayBlock) k_composite_train_bwd(
     const float* __restrict__ g_ws, const float* __restrict__ g_img, const float* __restrict__ sigmas,
     const float* __restrict__ rgbs, const float* __restrict__ deltas, const int32_t* __restrict__ rays,
     const float* __restrict__ weights_sum, const float* __restrict__ image, int64_t N, int64_t M, float T_thresh,
-    float* __restrict__ grad_sigmas, float* __restrict__ grad_rgbs) {
+    float* __restrict__ grad_sigmas, float* __restrict__ grad_rgbs, const int32_t* __restrict__ total_dev) {
   const int64_t n = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
   if (n >= N) return;
   const int32_t rid = rays[n * 3], off = rays[n * 3 + 1];
   int32_t cnt = rays[n * 3 + 2];
-  if ((int64_t)off + cnt > M) cnt = 0;     // dropped ray: its (zero-initialised) gradient rows stay untouched
+  // total_dev (the marcher's sample total): the rays' rows tile [0, total) without gaps, so every row of [0, M) has
+  // exactly one writer here and the caller's buffers need no zero fill (two fill launches less per training step) -
+  // owned rows below; the rows from the one dropped ray that starts inside the buffer to its end; and the padding
+  // [total, M), shared out over the waves.  Without it unowned rows are left untouched (the caller zero-initialises).
+  auto zero_rows = [&](int64_t lo, int64_t hi) {
+    for (int64_t i = lo + lane; i < hi; i += 64) {
+      grad_sigmas[i] = 0.f; grad_rgbs[i * 3] = 0.f; grad_rgbs[i * 3 + 1] = 0.f; grad_rgbs[i * 3 + 2] = 0.f;
+    }
+  };
+  if (total_dev) {
+    const int64_t total = total_dev[0];
+    if (total < M) {
+      const int64_t per = (M - total + N - 1) / N;
+      zero_rows(total + n * per, min(M, total + (n + 1) * per));
+    }
+  }
+  if ((int64_t)off + cnt > M) {            // dropped ray
+    if (total_dev && cnt > 0 && off < M) zero_rows(off, M);
+    cnt = 0;
+  }
   const float gr = g_img[rid * 3], gg = g_img[rid * 3 + 1], gb = g_img[rid * 3 + 2];
   const float gw = g_ws ? g_ws[rid] : 0.0f;
   const float rf = image[rid * 3], gf = image[rid * 3 + 1], bf = image[rid * 3 + 2];
@@ -1731,6 +1796,17 @@ int inr_finish_rays(const float* image, const float* depth, const float* weights
   return check_launch("finish_rays");
 }
 
+int inr_finish_rays_mse(const float* image, const float* depth, const float* weights_sum, const float* nears,
+                        const float* fars, float bg_r, float bg_g, float bg_b, const float* bg_rays, const float* target,
+                        int64_t N, float* image_out, float* depth_out, float* grad, float* loss, inr_stream_t s) {
+  INR_REQUIRE(N > 0 && N <= INR_FINISH_MSE_MAX_RAYS, "N out of range (one workgroup: 0 < N <= INR_FINISH_MSE_MAX_RAYS)");
+  INR_REQUIRE(image && depth && weights_sum && nears && fars && target && image_out && depth_out && grad && loss,
+              "null pointer");
+  k_finish_rays_mse<<<1, kFinishMseThreads, 0, as_stream(s)>>>(image, depth, weights_sum, nears, fars, bg_r, bg_g, bg_b,
+                                                               bg_rays, target, N, image_out, depth_out, grad, loss);
+  return check_launch("finish_rays_mse");
+}
+
 int inr_composite_rays_train_forward(const float* sigmas, const float* rgbs, const float* deltas, const int32_t* rays,
                                      int64_t N, int64_t M, float T_thresh, const float* extra, int32_t K,
                                      float* weights_sum, float* depth, float* image, float* extra_out, float* weights,
@@ -1774,7 +1850,7 @@ int inr_composite_rays_train_backward(const float* grad_weights_sum, const float
                                       const float* extra, const float* deltas, const int32_t* rays,
                                       const float* weights_sum, const float* image, const float* weights, int64_t N,
                                       int64_t M, float T_thresh, int32_t K, float* grad_sigmas, float* grad_rgbs,
-                                      float* grad_extra, inr_stream_t s) {
+                                      float* grad_extra, const int32_t* total_dev, inr_stream_t s) {
   (void)extra;
   INR_REQUIRE(rays && N >= 0 && M >= 0, "bad argument");
   INR_REQUIRE((grad_sigmas != nullptr) == (grad_rgbs != nullptr), "grad_sigmas and grad_rgbs go together");
@@ -1786,7 +1862,7 @@ int inr_composite_rays_train_backward(const float* grad_weights_sum, const float
   if (grad_sigmas)   // null: the density/colour field is frozen (instance stage) - only the K channels flow back
     k_composite_train_bwd<<<blocks_for(N * 64, kRayBlock), kRayBlock, 0, st>>>(grad_weights_sum, grad_image, sigmas,
                                                                                rgbs, deltas, rays, weights_sum, image, N, M,
-                                                                               T_thresh, grad_sigmas, grad_rgbs);
+                                                                               T_thresh, grad_sigmas, grad_rgbs, total_dev);
   if (grad_extra_out)
     k_composite_train_extra_bwd<<<blocks_for(N * 64, kRayBlock), kRayBlock, 0, st>>>(grad_extra_out, weights, rays, N,
                                                                                      M, K, grad_extra);

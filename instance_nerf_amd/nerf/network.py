@@ -271,10 +271,10 @@ class _NerfFieldFn(torch.autograd.Function):
         g_sigma = torch.zeros(M, dtype=f32, device=dev) if g_sigma is None else g_sigma.contiguous().float()
         g_rgb = torch.zeros(M, 3, dtype=f32, device=dev) if g_rgb is None else g_rgb.contiguous().float()
         d_enc = torch.empty(M, 32, dtype=f32, device=dev)
-        sizes = (16 * 64, 64 * 64, 64 * 32, 16 * 64, 64 * 32)   # wc2 (16 rows, 3 live), wc1, wc0 (32 cols, 31 live), ws1, ws0
+        sizes = (16 * 64, 64 * 64, 64 * 31, 16 * 64, 64 * 32)   # wc2 (16 rows, 3 live), wc1, wc0, ws1, ws0
         gw = torch.empty(sum(sizes), dtype=f32, device=dev)     # written by the reduce kernel
         gwc2, gwc1, gwc0, gws1, gws0 = [g.view(*shape) for g, shape in zip(
-            gw.split(sizes), ((16, 64), (64, 64), (64, 32), (16, 64), (64, 32)))]
+            gw.split(sizes), ((16, 64), (64, 64), (64, 31), (16, 64), (64, 32)))]
         wsp = torch.empty(lib.inr_instance_head_workspace_bytes() // 4, dtype=f32, device=dev)
         g_emb = torch.empty_like(emb)              # zero-filled by the backward launch, on the side
         none_ok = M == 0
@@ -283,7 +283,7 @@ class _NerfFieldFn(torch.autograd.Function):
                                          ptr(pb), ptr(d_enc, allow_none=none_ok), ptr(wsp), ptr(gws0), ptr(gws1), ptr(gwc0),
                                          ptr(gwc1), ptr(gwc2), ptr(g_emb), g_emb.numel(), stream_ptr()), "nerf_head_backward")
         g_emb = _table_backward(lib, x, d_enc, ctx.desc, M, ctx.bound, g_emb, emb)
-        return None, None, g_emb, gws0, gws1, gwc0[:, :31], gwc1, gwc2[:3], None, None
+        return None, None, g_emb, gws0, gws1, gwc0, gwc1, gwc2[:3], None, None
 
 
 class _NerfFieldFnUnfused(torch.autograd.Function):

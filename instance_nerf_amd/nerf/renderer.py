@@ -179,7 +179,7 @@ class NeRFRenderer(nn.Module):
 
     def run_cuda(self, rays_o, rays_d, dt_gamma=0, bg_color=None, perturb=False, force_all_rays=False,
                  max_steps=1024, T_thresh=1e-4, infer_mode="auto", noises=None, field_gate=None, ce_labels=None,
-                 ce_ignore_index=-1, **kwargs):
+                 ce_ignore_index=-1, mse_target=None, **kwargs):
         """rays_o, rays_d [B,N,3] -> dict(image [B,N,3], depth [B,N], weights_sum [B,N] (, instance [B,N,K])).
 
         infer_mode (eval only; all modes render the same image):
@@ -195,6 +195,11 @@ class NeRFRenderer(nn.Module):
         instance logits against them (``ce_ignore_index`` rows skipped) is returned as ``results["instance_ce"]`` when
         the one-node instance head applies (``instance_head_available``); otherwise the key is absent and the caller
         computes the loss from ``results["instance"]`` as usual.
+
+        mse_target (training, [.., 3] per ray): the mean squared error of the shaded image against it is returned as
+        ``results["image_mse"]`` when the fused tail applies (gradient flows through the image, uniform or per-ray
+        background, <= 65536 rays): blend, depth normalisation, loss and its gradients are then one launch each way
+        instead of ~18 element-wise launches; otherwise the key is absent and the caller forms the loss itself.
 
         field_gate (eval, one-pass modes): an object with ``acquire()`` / ``release()`` called on the current stream
         right before and after the field evaluation.  FramePipeline uses it to keep the field kernels of views that
@@ -294,7 +299,7 @@ class NeRFRenderer(nn.Module):
             if with_instance and getattr(self, "instance_head_available", lambda x: False)(xyzs):
                 # the instance head as ONE autograd node (field + K-channel compositing; one backward launch)
                 weights_sum, depth, image, wbuf, sample_ray = raymarching.composite_rays_train(
-                    sigmas, rgbs, deltas, rays, T_thresh, return_weights=True)
+                    sigmas, rgbs, deltas, rays, T_thresh, return_weights=True, total_dev=counter)
                 if ce_labels is not None:
                     # the mask loss of the instance stage inside the compositing launch (Trainer.train_step passes the
                     # batch's matched-mask ids): results["instance_ce"] = mean CE over the rows != ce_ignore_index
@@ -306,7 +311,8 @@ class NeRFRenderer(nn.Module):
                 results["instance"] = inst[:, :self.num_instances].reshape(*prefix, -1)
             else:
                 extra = self._instance_for_compositing(xyzs) if with_instance else None
-                out = raymarching.composite_rays_train(sigmas, rgbs, deltas, rays, T_thresh, extra=extra)
+                out = raymarching.composite_rays_train(sigmas, rgbs, deltas, rays, T_thresh, extra=extra,
+                                                       total_dev=counter)
                 weights_sum, depth, image = out[0], out[1], out[2]
                 if with_instance:
                     results["instance"] = out[3][:, :self.num_instances].reshape(*prefix, -1)
@@ -356,7 +362,13 @@ class NeRFRenderer(nn.Module):
                 dt_max = 2 * math.sqrt(3) * 2 ** (self.cascade - 1) / self.grid_size
                 t_start = nears + torch.clamp(nears * dt_gamma, dt_min, dt_max) * noises.to(nears)
         bg3 = self._bg_triplet(bg_color)
-        if bg3 is not None and not (torch.is_grad_enabled() and (image.requires_grad or weights_sum.requires_grad)):
+        flows = torch.is_grad_enabled() and (image.requires_grad or weights_sum.requires_grad)
+        bg_per_ray = torch.is_tensor(bg_color) and bg_color.is_cuda and bg_color.numel() == 3 * N
+        if (self.training and mse_target is not None and flows and t_start is None and image.is_cuda
+                and 0 < N <= raymarching.FINISH_MSE_MAX_RAYS and (bg3 is not None or bg_per_ray)):
+            image, depth, results["image_mse"] = raymarching.finish_rays_mse(
+                image, weights_sum, depth, nears, fars, bg3 if bg3 is not None else bg_color, mse_target)
+        elif bg3 is not None and not (torch.is_grad_enabled() and (image.requires_grad or weights_sum.requires_grad)):
             # no gradient flows through the shaded image (inference, or the instance stage on a frozen NeRF):
             # background blend + depth normalisation in one launch, in place on this call's own buffers
             lib = _lib.load()
@@ -370,6 +382,8 @@ class NeRFRenderer(nn.Module):
                                       ptr(t_start, torch.float32, "t0", allow_none=True),
                                       bg3[0], bg3[1], bg3[2], N, ptr(image), ptr(depth), stream_ptr()), "finish_rays")
         else:
+            if isinstance(bg_color, (list, tuple)):
+                bg_color = image.new_tensor(bg_color)
             image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
             if t_start is not None:
                 depth = depth + t_start * weights_sum.detach()

@@ -610,6 +610,7 @@ class Trainer:
         if update_extra_interval is None:
             update_extra_interval = getattr(opt, "update_extra_interval", 16) if opt is not None else 16
         self.update_extra_interval = update_extra_interval
+        self._default_criterion = criterion is None      # upstream's MSELoss(reduction='none') + .mean(): fusable
         self.criterion = criterion or (torch.nn.MSELoss(reduction="none") if stage == "nerf" else None)
         model.to(self.device)
         if stage == "instance":
@@ -689,11 +690,14 @@ class Trainer:
         extra = {}
         if self.stage == "instance" and getattr(self.model, "cuda_ray", False) and data["rays_o"].is_cuda:
             extra["ce_labels"] = data["masks"]      # the renderer may form the mask loss inside its compositing launch
+        if (self.stage == "nerf" and self._default_criterion and getattr(self.model, "cuda_ray", False)
+                and data["rays_o"].is_cuda):
+            extra["mse_target"] = gt                # the renderer may fold blend + loss + gradients into one launch
         outputs = self.model.render(data["rays_o"], data["rays_d"], staged=False, bg_color=bg_color, perturb=True,
                                     force_all_rays=False, **extra, **self._render_kwargs())
         if self.stage == "nerf":
             pred = outputs["image"]
-            loss = self.criterion(pred, gt).mean()
+            loss = outputs["image_mse"] if "image_mse" in outputs else self.criterion(pred, gt).mean()
             return pred, gt, loss
         logits = outputs["instance"]
         K = logits.shape[-1]
@@ -820,7 +824,11 @@ class Trainer:
             return self._replay(data)
         self.optimizer.zero_grad()
         _, _, loss = self.train_step(data)
-        loss.backward()
+        if loss.is_cuda and loss.dim() == 0 and loss.dtype == torch.float32:
+            from .. import raymarching
+            loss.backward(gradient=raymarching.unit_gradient(loss.device))     # no ones_like fill launch
+        else:
+            loss.backward()
         params = [p for g in self.optimizer.param_groups for p in g["params"]]
         fused = isinstance(self.optimizer, FusedAdam)
         # FusedAdam takes the 1 / world_size of the gradient average as a factor inside its sweep

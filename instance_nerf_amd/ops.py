@@ -108,7 +108,7 @@ def composite_rays_train_backward(grad_ws: Tensor, grad_image: Tensor, sigmas: T
         check(lib.inr_composite_rays_train_backward(ptr(grad_ws.contiguous().float()), ptr(grad_image.contiguous().float()),
                                                     None, ptr(sigmas), ptr(rgbs), None, ptr(deltas), ptr(rays, I32, "rays"),
                                                     ptr(weights_sum), ptr(image), None, N, M, float(T_thresh), 0, ptr(gs),
-                                                    ptr(gc), None, stream_ptr()), "composite_rays_train_backward")
+                                                    ptr(gc), None, None, stream_ptr()), "composite_rays_train_backward")
     return gs, gc
 
 

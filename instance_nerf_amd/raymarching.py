@@ -282,7 +282,7 @@ def patch_slots(rays):
 
 class _CompositeRaysTrain(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, sigmas, rgbs, extra, deltas, rays, T_thresh, want_weights=False):
+    def forward(ctx, sigmas, rgbs, extra, deltas, rays, T_thresh, want_weights=False, total_dev=None):
         lib = _lib.load()
         sigmas, rgbs, deltas = _f(sigmas), _f(rgbs), _f(deltas)
         dev = sigmas.device
@@ -304,7 +304,7 @@ class _CompositeRaysTrain(torch.autograd.Function):
             ptr(image),
             ptr(extra_out, allow_none=True), ptr(wbuf, allow_none=True), ptr(sample_ray, allow_none=True), stream_ptr()),
             "composite_rays_train_forward")
-        ctx.save_for_backward(sigmas, rgbs, extra, deltas, rays, ws, image, wbuf)
+        ctx.save_for_backward(sigmas, rgbs, extra, deltas, rays, ws, image, wbuf, total_dev)
         ctx.T_thresh = T_thresh
         ctx.K = K
         ctx.set_materialize_grads(False)          # unused outputs reach backward as None, not as zero fills
@@ -323,7 +323,7 @@ class _CompositeRaysTrain(torch.autograd.Function):
     def backward(ctx, g_ws, g_depth, g_image, *rest):
         g_extra = rest[0] if ctx.K else None
         lib = _lib.load()
-        sigmas, rgbs, extra, deltas, rays, ws, image, wbuf = ctx.saved_tensors
+        sigmas, rgbs, extra, deltas, rays, ws, image, wbuf, total_dev = ctx.saved_tensors
         N = rays.shape[0]
         K = ctx.K
         dev = sigmas.device
@@ -332,8 +332,10 @@ class _CompositeRaysTrain(torch.autograd.Function):
         if need_field:
             g_ws = _f(g_ws) if g_ws is not None else None
             g_image = _f(g_image) if g_image is not None else torch.zeros(N, 3, dtype=F32, device=dev)
-            gs = torch.zeros_like(sigmas)
-            gc = torch.zeros_like(rgbs)
+            # with the marcher's total the launch writes every row itself (zeros where no ray owns one)
+            alloc = torch.empty_like if total_dev is not None else torch.zeros_like
+            gs = alloc(sigmas)
+            gc = alloc(rgbs)
         ge = None
         if K and g_extra is not None and ctx.needs_input_grad[2]:
             g_extra = _f(g_extra)
@@ -346,19 +348,24 @@ class _CompositeRaysTrain(torch.autograd.Function):
                 ptr(g_extra, allow_none=True), ptr(sigmas), ptr(rgbs),
                 ptr(extra, allow_none=True), ptr(deltas), ptr(rays), ptr(ws), ptr(image), ptr(wbuf, allow_none=True), N,
                 sigmas.shape[0], float(ctx.T_thresh), K, ptr(gs, allow_none=True), ptr(gc, allow_none=True),
-                ptr(ge, allow_none=True), stream_ptr()), "composite_rays_train_backward")
-        return gs, gc, ge, None, None, None, None
+                ptr(ge, allow_none=True), ptr(total_dev, I32, "total_dev", allow_none=True), stream_ptr()),
+                "composite_rays_train_backward")
+        return gs, gc, ge, None, None, None, None, None
 
 
-def composite_rays_train(sigmas, rgbs, deltas, rays, T_thresh=1e-4, extra=None, return_weights=False):
+def composite_rays_train(sigmas, rgbs, deltas, rays, T_thresh=1e-4, extra=None, return_weights=False, total_dev=None):
     """-> weights_sum [N], depth [N], image [N,3] (, extra_out [N,K] when ``extra`` [M,K] is given)
     (, weights [M], sample_ray int32 [M] when ``return_weights``: the detached per-sample compositing weights and the
     output row of the ray that owns each sample - the inputs of the fused instance head).
 
     Differentiable w.r.t. sigmas, rgbs and extra.  The K extra channels are
     composited with the weights detached (instance field vs. a frozen NeRF).
+
+    ``total_dev`` (int32 device tensor whose first element is the marcher's sample total - ``step_counter`` of
+    ``march_rays_train``; the rays' rows must tile [0, total), as the marcher leaves them): the backward then writes
+    every gradient row itself and skips the two zero fills.
     """
-    return _CompositeRaysTrain.apply(sigmas, rgbs, extra, deltas, rays, T_thresh, bool(return_weights))
+    return _CompositeRaysTrain.apply(sigmas, rgbs, extra, deltas, rays, T_thresh, bool(return_weights), total_dev)
 
 
 def march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, density_bitfield, C, H, near, far,
@@ -406,6 +413,91 @@ def compact_alive(rays_alive, n_alive):
           "compact_alive")
     n = int(n_out[0].item())
     return out[:n], n
+
+
+FINISH_MSE_MAX_RAYS = 65536          # include/inr.h INR_FINISH_MSE_MAX_RAYS
+
+_UNIT = {}
+
+
+def unit_gradient(device):
+    """A cached 0-dim float32 one on ``device``: ``loss.backward(gradient=unit_gradient(dev))`` starts the backward
+    without the fill launch of the implicit ``ones_like(loss)``, and a loss node of this module that is handed this very
+    tensor skips its multiplication by one (each a ~5 us launch per training step).  Never written to."""
+    device = torch.device(device)
+    key = (device.type, device.index if device.index is not None else (torch.cuda.current_device() if device.type == "cuda" else 0))
+    t = _UNIT.get(key)
+    if t is None:
+        t = _UNIT[key] = torch.ones((), dtype=F32, device=device)
+    return t
+
+
+def _is_unit(g):
+    u = _UNIT.get((g.device.type, g.device.index if g.device.index is not None else 0))
+    return u is not None and g.dim() == 0 and g.dtype == F32 and g.data_ptr() == u.data_ptr()
+
+
+class _FinishRaysMSE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, image, weights_sum, depth, nears, fars, bg3, bg_rays, target):
+        lib = _lib.load()
+        image, weights_sum, depth, target = _f(image), _f(weights_sum), _f(depth), _f(target).view(-1, 3)
+        N = image.shape[0]
+        dev = image.device
+        image_out = torch.empty_like(image)
+        depth_out = torch.empty_like(depth)
+        grad = torch.empty(4 * N, dtype=F32, device=dev)
+        loss = torch.empty((), dtype=F32, device=dev)
+        if bg_rays is not None:
+            bg_rays = _f(bg_rays).view(-1, 3)
+            bg3 = (0.0, 0.0, 0.0)
+        check(lib.inr_finish_rays_mse(ptr(image, F32, "image"), ptr(depth, F32, "depth"),
+                                      ptr(weights_sum, F32, "weights_sum"), ptr(_f(nears), F32, "nears"),
+                                      ptr(_f(fars), F32, "fars"), bg3[0], bg3[1], bg3[2],
+                                      ptr(bg_rays, F32, "bg_rays", allow_none=True), ptr(target, F32, "target"), N,
+                                      ptr(image_out), ptr(depth_out), ptr(grad), ptr(loss), stream_ptr()),
+              "finish_rays_mse")
+        ctx.save_for_backward(grad, bg_rays)
+        ctx.bg3 = bg3
+        ctx.N = N
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(depth_out)
+        return image_out, depth_out, loss
+
+    @staticmethod
+    def backward(ctx, g_image, g_depth, g_loss):
+        grad, bg_rays = ctx.saved_tensors
+        N = ctx.N
+        gi = gw = None
+        if g_loss is not None:
+            # one launch for both gradients ([0, 3N) image, [3N, 4N) weights_sum); none for the unit seed
+            g = grad if _is_unit(g_loss) else grad * g_loss
+            gi, gw = g[:3 * N].view(N, 3), g[3 * N:]
+        if g_image is not None:                    # the shaded image is also used outside the loss
+            bg = bg_rays if bg_rays is not None else g_image.new_tensor(ctx.bg3)
+            gw_img = -(g_image.reshape(N, 3) * bg).sum(-1)
+            gi = g_image.reshape(N, 3) if gi is None else gi + g_image.reshape(N, 3)
+            gw = gw_img if gw is None else gw + gw_img
+        return gi, gw, None, None, None, None, None, None
+
+
+def finish_rays_mse(image, weights_sum, depth, nears, fars, bg_color, target):
+    """The training tail of the NeRF stage as ONE autograd node and one launch each way (inr_finish_rays_mse):
+    -> (image + (1 - weights_sum) * bg, clamp(depth - nears, 0) / (fars - nears), mean((shaded image - target)^2)).
+    ``bg_color``: a number, a host-side triple, or a per-ray tensor [N,3] (upstream's random background for RGBA
+    batches).  The loss is upstream's ``MSELoss(reduction='none')(pred, gt).mean()``; gradients flow to ``image`` and
+    ``weights_sum`` (from the loss and, if the caller uses it elsewhere, from the shaded image).  N <= 65536 rays."""
+    bg_rays = None
+    if torch.is_tensor(bg_color):
+        if bg_color.numel() == 3 * image.shape[0]:
+            bg_rays, bg3 = bg_color, (0.0, 0.0, 0.0)
+        else:
+            bg3 = tuple(float(c) for c in bg_color.reshape(-1).expand(3).tolist())
+    elif isinstance(bg_color, (int, float)):
+        bg3 = (float(bg_color),) * 3
+    else:
+        bg3 = tuple(float(c) for c in bg_color)
+    return _FinishRaysMSE.apply(image, weights_sum, depth, nears, fars, bg3, bg_rays, target)
 
 
 class _CrossEntropy(torch.autograd.Function):

@@ -15,17 +15,31 @@ net.density_bitfield.copy_(torch.from_numpy(ds.room.density_bitfield(128, 1.0)).
 tr = Trainer("probe", None, net, stage="nerf", device=dev, iters=1000, update_extra_interval=10 ** 9)
 tr.global_step = 1
 batches = [ds.batch() for _ in range(8)]
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+peak = 0
 for i in range(8):
-    l0 = float(tr.train_one_step(batches[i % 8])) if i == 0 else l0
+    l = tr.train_one_step(batches[i % 8])
+    if i == 0:
+        l0 = float(l)
+    peak = max(peak, int(net.step_counter[(net.local_step - 1) % 16, 0]))
+# steady state as after an occupancy update: sample buffers sized from mean_count, no host read-back inside a step
+net.mean_count = (int(peak * 1.02) + 127) // 128 * 128
+for i in range(8):
     tr.train_one_step(batches[i % 8])
 torch.cuda.synchronize()
-steps = 40
-t0 = time.perf_counter(); n = 0
+t0 = time.perf_counter()
+n_dev = torch.zeros((), dtype=torch.int64, device=dev)
 for i in range(steps):
-    l = tr.train_one_step(batches[i % 8]); n += int(net.step_counter[(net.local_step - 1) % 16, 0])
+    l = tr.train_one_step(batches[i % 8])
+    n_dev += net.step_counter[(net.local_step - 1) % 16, 0]       # on the device: no host sync inside the loop
+t_host = (time.perf_counter() - t0) / steps      # host time to enqueue a step (== the step time when host-bound)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
+print(f"host enqueue {t_host*1e3:.3f} ms per step")
+n = int(n_dev)
 print(f"nerf train step {dt*1e3:.3f} ms, {n/steps:.0f} samples/step, {n/steps/dt/1e6:.2f} Msamples/s, loss {l0:.4f} -> {float(l):.4f}")
+if os.environ.get("NO_UPDATE", "0") == "1":
+    sys.exit(0)
 net.density_grid.zero_()
 for i in range(4):
     torch.cuda.synchronize(); t0 = time.perf_counter()

@@ -33,8 +33,10 @@ n_dev = torch.zeros((), dtype=torch.int64, device=dev)
 for i in range(steps):
     l = tr.train_one_step(batches[i % 8])
     n_dev += net.step_counter[(net.local_step - 1) % 16, 0]       # on the device: no host sync inside the loop
+t_host = (time.perf_counter() - t0) / steps      # host time to enqueue a step (== the step time when host-bound)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
+print(f"host enqueue {t_host*1e3:.3f} ms per step")
 n0 = int(n_dev)
 losses.append(float(l))
 print(f"train step {dt*1e3:.3f} ms, {n0/steps:.0f} samples/step, {n0/steps/dt/1e6:.2f} Msamples/s, loss {losses[0]:.4f} -> {losses[-1]:.4f}")
