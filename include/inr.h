@@ -37,7 +37,7 @@ extern "C" {
 /* Bumped whenever an existing prototype changes or an entry point is removed (round 2 changed four argument lists
  * without a bump: a stale library or an external caller built against the old header was only rejected by accident).
  * instance_nerf_amd/_lib.py refuses a library whose version differs from the one it was written against. */
-#define INR_ABI_VERSION 4
+#define INR_ABI_VERSION 5
 #define INR_MAX_LEVELS 16
 
 enum {
@@ -98,7 +98,9 @@ int inr_packbits(const float* grid, int64_t n_bytes, float thresh, uint8_t* bitf
  * cells (morton_idx NULL, m == n_cells, sigma in Morton order) or the listed ones (tmp = scratch [n_cells]);
  * *mean_sum (double, caller zeroes it once per update) accumulates sum(max(grid, 0)).
  * inr_packbits_mean: packbits with thresh = min(*mean_sum / n_cells, density_thresh) formed on the device (no host
- * round trip between the update and the bitfield); mean_out (nullable) receives the mean.                       */
+ * round trip between the update and the bitfield); mean_out (nullable) receives the mean; with n_counters > 0
+ * stats_out = {mean, sum_k counters[k * counter_stride]} - the one 16-byte read-back of an update (mean density and
+ * the sample totals of the last steps, which size the next steps' buffers).                                         */
 /* mark_untrained_grid (a3): grid[cas][cell] = -1 for every cell (Morton order) that none of the B training cameras
  * sees - poses [B,4,4] camera-to-world row-major, pinhole (fx, fy, cx, cy): the cell centre x in camera frame
  * cam = R^T (x - t) is seen if z > 0, |x| < cx/fx z + 2 half, |y| < cy/fy z + 2 half (half = half a cell).        */
@@ -110,7 +112,19 @@ int inr_occ_update(float* grid /*[n_cells]*/, const float* sigma /*[m]*/, const 
                    int64_t n_cells, int64_t m, float decay, float density_scale, float* tmp, double* mean_sum,
                    inr_stream_t s);
 int inr_packbits_mean(const float* grid, int64_t n_cells /*all cascades*/, const double* mean_sum, float density_thresh,
-                      uint8_t* bitfield, float* mean_out, inr_stream_t s);
+                      uint8_t* bitfield, float* mean_out /*nullable*/, const int32_t* counters /*nullable*/,
+                      int32_t n_counters, int32_t counter_stride /*in int32*/, double* stats_out /*[2]*/,
+                      inr_stream_t s);
+/* The steady-state cell choice of update_extra_state (after the first 16 updates; one cascade): n cells uniformly at
+ * random + n picks, with replacement, among the cells with grid > 0 - upstream's randint coordinates and
+ * nonzero(grid > 0)[randint] - in three launches.  u [4n] uniform in [0,1): slice draws [2n] then in-slice draws [2n]
+ * (uniform half first).  morton_idx [2n] receives the cells (Morton indices), uniform half first; each half comes out
+ * grouped by 4096 slices of the Morton range / of the occupied ranks (an i.i.d. sample drawn as multinomial slice
+ * counts + uniform positions inside the slices), which is what lets the field kernel evaluate them at its coherent
+ * rate.  No cell occupied: the occupied half is cell 0.  Exact restatement: oracle/occupancy.py::sample_cells.   */
+int64_t inr_occ_sample_workspace_bytes(int64_t n_cells);
+int inr_occ_sample_cells(const float* grid /*[n_cells] Morton order*/, int64_t n_cells, const float* u /*[4n]*/,
+                         int64_t n, int32_t* morton_idx /*[2n]*/, void* workspace, inr_stream_t s);
 
 /* ---- training march (replaces raymarching.march_rays_train, a4) ----------------------
  * Deterministic: sample slots are an exclusive scan of the per-ray counts in ray

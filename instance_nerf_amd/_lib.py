@@ -38,7 +38,9 @@ _SIGS = {
     "inr_mark_untrained_grid": (c_int32, [P, c_int32, c_float, c_float, c_float, c_float, c_int32, c_int32, c_float, P, P]),
     "inr_occ_cell_positions": (c_int32, [P, P, c_int64, c_int32, c_float, P, P]),
     "inr_occ_update": (c_int32, [P, P, P, c_int64, c_int64, c_float, c_float, P, P, P]),
-    "inr_packbits_mean": (c_int32, [P, c_int64, P, c_float, P, P, P]),
+    "inr_packbits_mean": (c_int32, [P, c_int64, P, c_float, P, P, P, c_int32, c_int32, P, P]),
+    "inr_occ_sample_workspace_bytes": (c_int64, [c_int64]),
+    "inr_occ_sample_cells": (c_int32, [P, c_int64, P, c_int64, P, P, P]),
     "inr_march_write_fills_unowned_rows": (c_int32, [c_int64, c_int32, c_int32]),
     "inr_march_workspace_bytes": (c_int64, [c_int64, c_int32]),
     "inr_march_rays_train_count": (c_int32, [P, P, P, c_float, c_float, c_int32, c_int64, c_int32, c_int32,
@@ -107,7 +109,7 @@ _SIGS = {
 }
 EXPORTS = tuple(_SIGS)
 
-ABI_VERSION = 4          # include/inr.h INR_ABI_VERSION this binding was written against
+ABI_VERSION = 5          # include/inr.h INR_ABI_VERSION this binding was written against
 _lib = None
 
 

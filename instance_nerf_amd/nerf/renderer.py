@@ -486,21 +486,15 @@ class NeRFRenderer(nn.Module):
                 idx, m = None, n_cells
             else:
                 n = n_cells // 4
-                coords = torch.randint(0, H, (n, 3), device=dev, dtype=torch.int32)
-                idx = raymarching.morton3D(coords)
-                # random occupied cells without a host round trip (upstream: torch.nonzero -> sync): stable
-                # compaction through a prefix sum into occ_list[0 .. n_occ), picks = floor(rand * n_occ) with n_occ
-                # read on the device.  No occupied cell at all: the picks fall on cell 0 (one more visit of a cell
-                # that may be visited anyway; upstream skips the occupied half in that case).
-                occ = grid[cas] > 0
-                pos = torch.cumsum(occ, 0)
-                n_occ = pos[-1:]
-                occ_list = torch.zeros(n_cells + 1, dtype=torch.int32, device=dev)
-                cells = torch.arange(n_cells, dtype=torch.int32, device=dev)
-                occ_list.scatter_(0, torch.where(occ, pos - 1, n_cells), cells)
-                pick = torch.minimum((torch.rand(n, device=dev) * n_occ).long(), (n_occ - 1).clamp(min=0))
-                idx = torch.cat([idx, occ_list[pick]]).contiguous()
-                m = idx.shape[0]
+                # n uniformly random cells + n random occupied cells (with replacement), chosen on the device in three
+                # launches and grouped by slices of the Morton range (inr_occ_sample_cells; upstream: randint coords,
+                # nonzero -> sync, randint picks - here no host round trip and no tensor-op chain)
+                u = torch.rand(4 * n, dtype=torch.float32, device=dev)
+                idx = torch.empty(2 * n, dtype=torch.int32, device=dev)
+                work = torch.empty(lib.inr_occ_sample_workspace_bytes(n_cells) // 8 + 1, dtype=torch.int64, device=dev)
+                check(lib.inr_occ_sample_cells(ptr(grid[cas], torch.float32, "density_grid"), n_cells, ptr(u), n, ptr(idx),
+                                               ptr(work), st), "occ_sample_cells")
+                m = 2 * n
             xyz = torch.empty(m, 3, dtype=torch.float32, device=dev)
             noise = torch.rand_like(xyz)
             check(lib.inr_occ_cell_positions(ptr(idx, torch.int32, "morton_idx", allow_none=True),
@@ -512,14 +506,15 @@ class NeRFRenderer(nn.Module):
                                      ptr(idx, torch.int32, "morton_idx", allow_none=True), n_cells, m, float(decay),
                                      float(self.density_scale), ptr(tmp, allow_none=True), ptr(mean_sum), st),
                   "occ_update")
-        mean_out = torch.empty(1, dtype=torch.float32, device=dev)
+        total_step = min(16, self.local_step)
+        stats = torch.empty(2, dtype=torch.float64, device=dev)
         check(lib.inr_packbits_mean(ptr(grid, torch.float32, "density_grid"), C * n_cells, ptr(mean_sum),
                                     float(self.density_thresh), ptr(self.density_bitfield, torch.uint8, "density_bitfield"),
-                                    ptr(mean_out), st), "packbits_mean")
+                                    None, ptr(self.step_counter, torch.int32, "step_counter"), max(total_step, 1),
+                                    self.step_counter.stride(0), ptr(stats), st), "packbits_mean")
         self.iter_density += 1
-        total_step = min(16, self.local_step)
         # one read-back: [mean density, sum of the sample totals of the last steps]
-        host = torch.cat([mean_out.double(), self.step_counter[:max(total_step, 1), 0].sum().double().view(1)]).cpu()
+        host = stats.cpu()
         self.mean_density = float(host[0])
         if total_step > 0:
             self.mean_count = int(float(host[1]) / total_step)

@@ -121,3 +121,32 @@ def mark_untrained_cells(poses, intrinsic, H, cascade, bound):
                 & (np.abs(cam[:, 1]) < cy / fy * cam[:, 2] + half * 2)
         unseen[cas, idx] = ~seen
     return unseen
+
+
+def sample_cells(grid, u, n, n_slices=4096):
+    """The steady-state cell choice of the occupancy update: n uniformly random cells + n picks, with replacement,
+    among the occupied cells (grid > 0) of one cascade - upstream's ``randint`` coordinates / ``nonzero(grid > 0)
+    [randint]`` (SURVEY Appendix A.1 "Occupancy update"), drawn so that the picks come out grouped by slices of the
+    Morton range without a sort: an i.i.d. uniform sample = multinomial counts per slice (the histogram of one set of
+    uniform draws) + uniform positions inside the slices (a second set).  Restates csrc/raymarch.hip::k_occ_hist /
+    k_occ_pick exactly (float32 slice draw, float64 position arithmetic).
+
+    grid float32 [n_cells] (Morton order); u float32 [4n]: slice draws [2n] (uniform half, occupied half), in-slice
+    draws [2n].  -> int32 [2n] Morton indices, uniform half first."""
+    grid = np.asarray(grid, F32)
+    u = np.asarray(u, F32)
+    n_cells = grid.shape[0]
+    occ = np.nonzero(grid > 0)[0]
+    out = np.empty(2 * n, np.int64)
+    for half in range(2):
+        draws = u[half * n:(half + 1) * n]
+        b = np.minimum((draws * F32(n_slices)).astype(np.int64), n_slices - 1)
+        b_sorted = np.sort(b)                             # slot j lies in the slice whose scanned count range holds j
+        v = (b_sorted.astype(np.float64) + u[2 * n + half * n:2 * n + (half + 1) * n].astype(np.float64)) / n_slices
+        if half == 0:
+            out[:n] = np.minimum((v * n_cells).astype(np.int64), n_cells - 1)
+        elif occ.size == 0:
+            out[n:] = 0
+        else:
+            out[n:] = occ[np.minimum((v * occ.size).astype(np.int64), occ.size - 1)]
+    return out.astype(np.int32)

@@ -718,6 +718,41 @@ def test_occupancy_update_two_cascades_with_unseen_cells():
     assert not (diff & ~near).any() and diff.mean() < 1e-3
 
 
+@pytest.mark.parametrize("H,density", [(128, 0.05), (64, 0.5), (32, 0.0), (128, 1.0)])
+def test_occupancy_cell_sampling_equals_the_oracle(H, density):
+    """inr_occ_sample_cells (three launches: ballot masks + block counts, slice histogram, picks) against
+    oracle/occupancy.py::sample_cells on the same uniform draws: every pick bit for bit - uniform half and occupied
+    half, also with no cell occupied (all picks on cell 0) and with every cell occupied - and the statistics the
+    update relies on: the occupied half only hits occupied cells, both halves are spread over the whole range."""
+    from instance_nerf_amd import _lib
+    from oracle import occupancy
+    lib = _lib.load()
+    gen = torch.Generator().manual_seed(H)
+    n_cells = H ** 3
+    grid = torch.rand(n_cells, generator=gen) * 10.0
+    grid[torch.rand(n_cells, generator=gen) >= density] = 0.0
+    grid[::53] = -1.0                                                        # unseen cells are not occupied either
+    n = n_cells // 4
+    u = torch.rand(4 * n, generator=gen)
+    g_dev, u_dev = grid.to(DEV), u.to(DEV)
+    idx = torch.full((2 * n,), -7, dtype=torch.int32, device=DEV)
+    work = torch.empty(lib.inr_occ_sample_workspace_bytes(n_cells) // 8 + 1, dtype=torch.int64, device=DEV)
+    _lib.check(lib.inr_occ_sample_cells(_lib.ptr(g_dev), n_cells, _lib.ptr(u_dev), n, _lib.ptr(idx), _lib.ptr(work),
+                                        _lib.stream_ptr()), "occ_sample_cells")
+    got = idx.cpu().numpy()
+    want = occupancy.sample_cells(grid.numpy(), u.numpy(), n)
+    assert np.array_equal(got, want)
+    assert got.min() >= 0 and got.max() < n_cells
+    occupied = grid.numpy() > 0
+    if occupied.any():
+        assert occupied[got[n:]].all()
+        assert len(np.unique(got[n:])) > 0.3 * min(n, occupied.sum())
+    else:
+        assert (got[n:] == 0).all()
+    assert len(np.unique(got[:n])) > 0.2 * n_cells                          # n = n_cells / 4 draws: ~22 % distinct cells
+    assert (np.diff(got[:n] // (n_cells // 4096)) >= 0).all()               # grouped by slice, never sorted inside
+
+
 def test_occupancy_update_steady_state_sweep(params_k16, level_table):
     """After the first 16 updates only H^3/4 random cells + H^3/4 random OCCUPIED cells are refreshed per call
     (device-side compaction of the occupied set, no host round trip).  Every cell either keeps its value or becomes

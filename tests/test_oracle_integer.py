@@ -28,6 +28,31 @@ def test_packbits_matches_numpy():
     assert (ours == ref).all()
 
 
+def test_sample_cells_is_a_uniform_sample_grouped_by_slices():
+    """oracle/occupancy.py::sample_cells (restated by inr_occ_sample_cells): the uniform half is uniform over the cells
+    (chi-square over 512 coarse bins), the occupied half is uniform over the occupied cells and hits nothing else, both
+    come out grouped by slice, and an empty occupied set falls back to cell 0."""
+    rng = np.random.default_rng(0)
+    n_cells = 64 ** 3
+    n = n_cells // 4
+    grid = np.where(rng.random(n_cells) < 0.1, rng.random(n_cells) + 0.1, 0.0).astype(np.float32)
+    grid[::97] = -1.0
+    idx = occupancy.sample_cells(grid, rng.random(4 * n, dtype=np.float32), n)
+    assert idx.dtype == np.int32 and idx.shape == (2 * n,) and idx.min() >= 0 and idx.max() < n_cells
+    counts = np.bincount(idx[:n] // (n_cells // 512), minlength=512)
+    chi2 = float(((counts - n / 512) ** 2 / (n / 512)).sum())
+    assert 380 < chi2 < 660                                   # 511 degrees of freedom: mean 511, sigma 32
+    occ = np.nonzero(grid > 0)[0]
+    assert np.isin(idx[n:], occ).all()
+    rank = np.searchsorted(occ, idx[n:])
+    counts = np.bincount(rank * 64 // occ.size, minlength=64)
+    chi2 = float(((counts - n / 64) ** 2 / (n / 64)).sum())
+    assert 25 < chi2 < 115                                    # 63 degrees of freedom
+    assert (np.diff(idx[:n] // (n_cells // 4096)) >= 0).all()
+    assert (np.diff(rank) >= -(occ.size // 4096 + 1)).all()     # never further back than one slice of the ranks
+    assert (occupancy.sample_cells(np.zeros(n_cells, np.float32), rng.random(4 * n, dtype=np.float32), n)[n:] == 0).all()
+
+
 def test_scene_bitfield_is_morton_packbits(room, room_bitfield):
     occ = room.occupancy_grid(128, 1.0)
     r = np.arange(128)
