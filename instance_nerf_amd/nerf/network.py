@@ -79,7 +79,8 @@ def _table_backward(lib, x, denc, desc, M, bound, g_emb, emb):
             check(lib.inr_grid_encode_backward_levels(ptr(x), ptr(denc), None, desc, M, float(bound), ptr(g_emb), lo, hi,
                                                       stream_ptr()), "grid_encode_backward")
         if overlap:
-            grad_sync.reduce_async(g_emb[int(desc.offsets[lo]):int(desc.offsets[hi])])
+            a, b = int(desc.offsets[lo]), int(desc.offsets[hi])
+            grad_sync.reduce_async(g_emb[a:b], emb, a * g_emb.shape[1])
     if overlap:
         emb.grad = g_emb
         grad_sync.mark(emb, g_emb)

@@ -233,14 +233,39 @@ class FusedAdam(torch.optim.Optimizer):
                     st[k] = st[k].to(p.device, torch.float32).contiguous()
 
     def _jobs(self):
+        """(tensor to update, gradient, exp_avg, exp_avg_sq, group, owner parameter, (first flat element, count) or None).
+        A parameter whose gradient arrived as reduce-scattered pieces (``grad_sync`` schedule "reduce_scatter":
+        ``_inr_grad_shards``) is updated on this rank's pieces only - flat views of the parameter and its moments."""
         jobs = []
         for g in self.param_groups:
             for p in g["params"]:
-                if p.grad is None or not p.requires_grad:
+                if not p.requires_grad:
+                    continue
+                pieces = getattr(p, "_inr_grad_shards", None)
+                if pieces:
+                    st = self._moments(p)
+                    flat = lambda t: t.view(-1)
+                    for piece in pieces:
+                        a, n = piece["own"], piece["grad"].numel()
+                        jobs.append((flat(p.data)[a:a + n], piece["grad"], flat(st["exp_avg"])[a:a + n],
+                                     flat(st["exp_avg_sq"])[a:a + n], g, p, (a, n)))
+                    continue
+                if p.grad is None:
                     continue
                 st = self._moments(p)
-                jobs.append((p, p.grad, st["exp_avg"], st["exp_avg_sq"], g))
+                jobs.append((p, p.grad, st["exp_avg"], st["exp_avg_sq"], g, p, None))
         return jobs
+
+    def sync_shards(self):
+        """Reduce-scatter schedule: every rank advances the moments of its own rows only; before the state is saved (or
+        the schedule is switched off) the pieces are gathered so that every rank holds the complete moments.  A
+        collective: all ranks call it."""
+        for g in self.param_groups:
+            for p in g["params"]:
+                layout = getattr(p, "_inr_shard_layout", None)
+                if layout and p in self.state and "exp_avg" in self.state[p]:
+                    for k in ("exp_avg", "exp_avg_sq"):
+                        grad_sync.allgather_pieces(self.state[p][k], layout)
 
     @torch.no_grad()
     def attach_ema(self, ema):
@@ -256,13 +281,24 @@ class FusedAdam(torch.optim.Optimizer):
         lib = _lib.load()
         self.step_count += 1
         jobs = []
-        for p, grad, m, v, g in self._jobs():
+        owners = []
+        for p, grad, m, v, g, owner, piece in self._jobs():
             grad = grad if grad.is_contiguous() else grad.contiguous()
             for t, name in ((p.data, "param"), (grad, "grad"), (m, "exp_avg"), (v, "exp_avg_sq")):
                 _lib.ptr(t, torch.float32, name)         # device / dtype / contiguity checks
-            jobs.append((p, grad, m, v, float(g["lr"])))
+            jobs.append((p, grad, m, v, float(g["lr"]), owner, piece))
+            if not any(o is owner for o in owners):
+                owners.append(owner)
         ema = self._ema
         shadow_of = ema.begin_fused_update() if ema is not None else None       # {id(param): shadow}, weight set
+
+        def shadow_ptr(j):                  # the shadow rows that go with the job's tensor (a piece of a sharded table)
+            sh = shadow_of.get(id(j[5]))
+            if sh is None:
+                return None
+            if j[6] is not None:
+                sh = sh.view(-1)[j[6][0]:j[6][0] + j[6][1]]
+            return sh.data_ptr()
         for i in range(0, len(jobs), 16):
             chunk = jobs[i:i + 16]
             n = len(chunk)
@@ -274,15 +310,14 @@ class FusedAdam(torch.optim.Optimizer):
                                                    self.betas[1], self.eps, self.step_count, float(grad_scale),
                                                    _lib.stream_ptr()), "adam_step_multi")
             else:
-                shadows = (ctypes.c_void_p * n)(*[shadow_of[id(j[0])].data_ptr() if id(j[0]) in shadow_of else None
-                                                  for j in chunk])
+                shadows = (ctypes.c_void_p * n)(*[shadow_ptr(j) for j in chunk])
                 _lib.check(lib.inr_adam_ema_step_multi(n, arr(0), arr(1), arr(2), arr(3), numels, lrs, self.betas[0],
                                                        self.betas[1], self.eps, self.step_count, float(grad_scale),
                                                        shadows, float(ema.fused_weight), _lib.stream_ptr()),
                            "adam_ema_step_multi")
         if ema is not None:
-            ema.end_fused_update({id(j[0]) for j in jobs})
-        for p, *_ in jobs:
+            ema.end_fused_update({id(o) for o in owners})
+        for p in owners:
             # the C ABI wrote p in place behind autograd's back: bump the version counter so
             # cached MFMA-packed weights (NeRFNetwork._packed_weights) are refreshed
             torch.autograd.graph.increment_version(p)
@@ -309,6 +344,8 @@ class FusedAdam(torch.optim.Optimizer):
         jobs = self._jobs()
         if len(jobs) > 16:
             raise RuntimeError("step_captured handles at most 16 parameter tensors")
+        if any(j[6] is not None for j in jobs):
+            raise RuntimeError("step_captured does not take reduce-scattered gradient pieces")
         if getattr(self, "_hyper_dev", None) is None:
             dev = jobs[0][0].device
             self._hyper_dev = torch.zeros(17, dtype=torch.float32, device=dev)
@@ -324,7 +361,7 @@ class FusedAdam(torch.optim.Optimizer):
 
     def bump_versions(self):
         for j in getattr(self, "_hyper_jobs", []):
-            torch.autograd.graph.increment_version(j[0])
+            torch.autograd.graph.increment_version(j[5])
 
 
 class _GradSync:
@@ -343,15 +380,40 @@ class _GradSync:
         # normalises the gradient's scale, so what changes is the direction of a step by ~0.4 %).  Off by default:
         # the fp32 all-reduce is exact up to summation order.  MLP gradients (a few KB) always go as fp32.
         self.payload = os.environ.get("INR_GRAD_DTYPE", "fp32").lower()
+        # INR_GRAD_SCHEDULE=reduce_scatter: every row range of a table gradient is reduce-SCATTERED instead of
+        # all-reduced - each rank receives the summed gradient of 1 / world of the rows, runs Adam (and the parameter
+        # EMA) on those rows only and the updated rows are all-gathered: the same bytes on the links (an all-reduce IS
+        # a reduce-scatter + an all-gather), but the optimiser sweep over a 49 MB table (7-9 memory streams, 340-440 MB)
+        # shrinks to 1 / world per rank.  Moments and EMA rows of the other ranks go stale locally and are gathered
+        # when somebody needs them (checkpoint, evaluation: ``Trainer._sync_shards``).  FusedAdam only; off by default.
+        self.schedule = os.environ.get("INR_GRAD_SCHEDULE", "all_reduce").lower()
+        self.sharded_ok = False         # set by allreduce_gradients(sharded=True) callers: the optimiser takes pieces
         self.handles = []
         self.early = {}                 # parameter data_ptr -> (data_ptr, numel) of the gradient whose slices are in flight
+        self.pieces = {}                # parameter data_ptr -> [piece]: reduce-scattered row ranges of its gradient
 
     def active(self):
         return self.enabled and self.world_size > 1 and dist.is_available() and dist.is_initialized()
 
-    def reduce_async(self, view):
-        """Sum ``view`` (a contiguous slice of a table gradient) over the ranks, asynchronously; ``finish()`` waits."""
-        if self.payload == "bf16":
+    def scatter_mode(self, numel):
+        return (self.schedule == "reduce_scatter" and self.sharded_ok and self.world_size > 1
+                and numel % self.world_size == 0)
+
+    def reduce_async(self, view, param=None, flat_lo=0):
+        """Sum ``view`` (a contiguous slice of a table gradient) over the ranks, asynchronously; ``finish()`` waits.
+        ``param`` / ``flat_lo`` (the parameter the slice belongs to and the slice's first flat element): with the
+        reduce-scatter schedule the rank receives only its 1 / world of the slice, kept as a piece for the optimiser."""
+        if param is not None and self.scatter_mode(view.numel()):
+            n = view.numel() // self.world_size
+            dt = torch.bfloat16 if self.payload == "bf16" else torch.float32
+            wire = view.reshape(-1).to(dt)                    # fp32: a view, nothing is copied
+            out = torch.empty(n, dtype=dt, device=view.device)
+            h = dist.reduce_scatter_tensor(out, wire, async_op=True)
+            piece = {"lo": int(flat_lo), "n": view.numel(), "own": int(flat_lo) + dist.get_rank() * n, "grad": out,
+                     "wire": wire}
+            self.pieces.setdefault(param.data_ptr(), []).append(piece)
+            self.handles.append((h, None, None))
+        elif self.payload == "bf16":
             wire = view.to(torch.bfloat16)
             self.handles.append((dist.all_reduce(wire, async_op=True), view, wire))
         else:
@@ -366,25 +428,60 @@ class _GradSync:
             if wire is not None:
                 view.copy_(wire)
         self.handles = []
+        for pieces in self.pieces.values():
+            for piece in pieces:
+                piece.pop("wire", None)
+                if piece["grad"].dtype != torch.float32:
+                    piece["grad"] = piece["grad"].float()
 
     def reset(self):
         self.finish()
         self.early = {}
 
+    def hand_over_pieces(self, params):
+        """After ``finish()``: the reduce-scattered pieces move onto their parameters (``_inr_grad_shards`` for
+        ``FusedAdam``; ``_inr_shard_layout`` remembers which rows this rank keeps current)."""
+        for p in params:
+            pieces = self.pieces.pop(p.data_ptr(), None)
+            if pieces:
+                p._inr_grad_shards = pieces
+                p._inr_shard_layout = [(q["lo"], q["n"], q["own"], q["grad"].numel()) for q in pieces]
+        self.pieces = {}
+
+    @staticmethod
+    def allgather_pieces(tensor, layout):
+        """Every rank's piece (own, count) of each range (lo, n) of the flat ``tensor`` -> all ranks, in place."""
+        flat = tensor.view(-1)
+        for lo, n, own, cnt in layout:
+            dist.all_gather_into_tensor(flat[lo:lo + n], flat[own:own + cnt].clone())
+
+    def allgather_params(self, params):
+        """After the optimiser step of the reduce-scatter schedule: the updated rows of every rank travel to all."""
+        for p in params:
+            if getattr(p, "_inr_grad_shards", None):
+                self.allgather_pieces(p.data, p._inr_shard_layout)
+                p._inr_grad_shards = None
+                torch.autograd.graph.increment_version(p)
+
 
 grad_sync = _GradSync()
 
 
-def allreduce_gradients(params, world_size, bucket_bytes=64 << 20, average=True):
+def allreduce_gradients(params, world_size, bucket_bytes=64 << 20, average=True, sharded=False):
     """Gradient all-reduce for ray-batch data parallelism: dense fp32 buckets over
     RCCL (backend 'nccl' on ROCm) or gloo.  The hash-table gradient (49 MB) goes as ONE message - or is already in
     flight, started from inside the backward in two level ranges (``grad_sync``); small MLP gradients are flattened
     into one bucket.  ``average=False`` leaves the SUM in the ``.grad`` tensors: the caller folds 1 / world_size into
     the optimiser (``FusedAdam.step(grad_scale=1 / world_size)``) instead of paying a read-modify-write sweep over
     every gradient (98 MB of traffic per trained table).  -> the factor the caller still has to apply (1 or
-    1 / world_size)."""
+    1 / world_size).  ``sharded=True`` (the caller's optimiser is ``FusedAdam`` and ``grad_sync.allgather_params`` follows
+    its step): with ``grad_sync.schedule == "reduce_scatter"`` the table gradients come back as this rank's pieces
+    (``param._inr_grad_shards``) instead of full sums in ``param.grad``."""
     if world_size <= 1:
         return 1.0
+    if sharded != grad_sync.sharded_ok and grad_sync.early:
+        raise RuntimeError("grad_sync.sharded_ok must be set before the backward (Trainer does it at construction)")
+    grad_sync.sharded_ok = bool(sharded)
     # Every rank must issue the SAME sequence of collectives whatever its batch looked like.  A rank whose rays all
     # missed the volume has no gradient at all (or an autograd function that never ran): it contributes zeros, and a
     # table it did not hand to the collective from inside its backward goes in the same two level ranges, in the same
@@ -408,11 +505,12 @@ def allreduce_gradients(params, world_size, bucket_bytes=64 << 20, average=True)
         if grad_sync.active() and split:
             g = g if g.is_contiguous() else g.contiguous()
             p.grad = g
-            grad_sync.reduce_async(g[split:])       # fine levels first, as in _table_backward
-            grad_sync.reduce_async(g[:split])
+            w = g.shape[1] if g.dim() > 1 else 1
+            grad_sync.reduce_async(g[split:], p, split * w)       # fine levels first, as in _table_backward
+            grad_sync.reduce_async(g[:split], p, 0)
         elif g.numel() * 4 >= bucket_bytes // 4:
             if g.is_contiguous():
-                grad_sync.reduce_async(g)           # a table gradient: with the configured payload type
+                grad_sync.reduce_async(g, p, 0)     # a table gradient: with the configured payload type
             else:
                 handles.append(dist.all_reduce(g, async_op=True))
         else:
@@ -428,10 +526,14 @@ def allreduce_gradients(params, world_size, bucket_bytes=64 << 20, average=True)
     for h in handles:
         h.wait()
     grad_sync.reset()
+    grad_sync.hand_over_pieces(params)
     if not average:
         return 1.0 / world_size
-    for g in grads:
-        g.div_(world_size)
+    for p in params:
+        for piece in getattr(p, "_inr_grad_shards", None) or ():
+            piece["grad"].div_(world_size)
+        if not getattr(p, "_inr_grad_shards", None):
+            p.grad.div_(world_size)
     return 1.0
 
 
@@ -539,6 +641,15 @@ class ParamEMA:
         self._fused_done = True
 
     @torch.no_grad()
+    def sync_shards(self):
+        """Reduce-scatter schedule (``grad_sync``): the fused update advanced only this rank's rows of a sharded table's
+        average; gather the other ranks' rows.  A collective: all ranks call it (``Trainer._sync_shards``)."""
+        for p, s in zip(self.params, self.shadow):
+            layout = getattr(p, "_inr_shard_layout", None)
+            if layout:
+                grad_sync.allgather_pieces(s, layout)
+
+    @torch.no_grad()
     def store(self):
         self.backup = [p.detach().clone() for p in self.params]
 
@@ -624,6 +735,9 @@ class Trainer:
                 self.optimizer = FusedAdam(groups, lr=lr, betas=(0.9, 0.99), eps=1e-15)
             else:
                 self.optimizer = torch.optim.Adam(groups, lr=lr, betas=(0.9, 0.99), eps=1e-15)
+        # the reduce-scatter gradient schedule (grad_sync.schedule) needs an optimiser that takes gradient pieces and a
+        # captured graph cannot hold its collectives: FusedAdam, eager steps
+        grad_sync.sharded_ok = isinstance(self.optimizer, FusedAdam) and world_size > 1 and not use_graph
         self.iters = iters
         # upstream: lr_scheduler = lambda optimizer: LambdaLR(optimizer, lambda it: 0.1 ** min(it / opt.iters, 1)),
         # stepped after every optimiser step; without one, exactly that rule is applied to the param groups
@@ -832,10 +946,12 @@ class Trainer:
         params = [p for g in self.optimizer.param_groups for p in g["params"]]
         fused = isinstance(self.optimizer, FusedAdam)
         # FusedAdam takes the 1 / world_size of the gradient average as a factor inside its sweep
-        scale = allreduce_gradients(params, self.world_size, average=not fused)
+        scale = allreduce_gradients(params, self.world_size, average=not fused, sharded=grad_sync.sharded_ok)
         self._lr_step()
         if fused:
             self.optimizer.step(grad_scale=scale)
+            if self.world_size > 1:
+                grad_sync.allgather_params(params)      # reduce-scatter schedule: the rows each rank updated -> all
         else:
             self.optimizer.step()
         if self.lr_scheduler is not None and self.scheduler_update_every_step:
@@ -843,6 +959,16 @@ class Trainer:
         if self.ema is not None:
             self.ema.update()
         return loss.detach()
+
+    def _sync_shards(self):
+        """Reduce-scatter gradient schedule: Adam moments and EMA rows are kept current on their owner rank only; gather
+        them before anything reads them whole (checkpoint, evaluation on the averaged parameters).  A collective - every
+        rank calls it at the same point; a no-op for the default all-reduce schedule."""
+        if self.world_size > 1 and dist.is_available() and dist.is_initialized():
+            if isinstance(self.optimizer, FusedAdam):
+                self.optimizer.sync_shards()
+            if self.ema is not None:
+                self.ema.sync_shards()
 
     def train(self, train_loader, valid_loader=None, max_epochs=1):
         """Upstream's epoch loop: cells no training camera sees are marked once (loaders that expose ``_data.poses`` /
@@ -855,6 +981,8 @@ class Trainer:
         for _ in range(self.epoch + 1, self.epoch + max_epochs + 1):
             self.epoch += 1
             self.train_one_epoch(train_loader)
+            if self.workspace is not None:
+                self._sync_shards()                     # all ranks: rank 0 then writes complete moments / averages
             if self.workspace is not None and self.local_rank == 0:
                 self.save_checkpoint(full=True, best=False)
             if valid_loader is not None and self.epoch % max(self.eval_interval, 1) == 0:
@@ -886,6 +1014,7 @@ class Trainer:
         meters = self.metrics or [PSNRMeter() if self.stage == "nerf" else MIoUMeter(self.model.num_instances)]
         for m in meters:
             m.clear()
+        self._sync_shards()
         if self.ema is not None:
             self.ema.store()
             self.ema.copy_to()
