@@ -183,10 +183,10 @@ def train_probe(dev, rank=0, world=1, red_dev=None, steps=20, warmup=5, stage="i
     while tr.global_step % 16 != 1:        # start the timed region right after an update: K timed steps then
         tr.train_one_step(batches[0])      # contain floor(K / 16) updates (1 for the default K = 20)
     assert net.mean_count > 0
-    marched = torch.zeros((), dtype=torch.int64, device=dev)
-    for i in range(2):                     # loads the code objects of the counting ops below, untimed
-        marched += torch.clamp(net.step_counter[(net.local_step - 1) % 16, 0], max=net.mean_count)
-    marched.zero_()
+    per_step = torch.zeros(steps, dtype=torch.int32, device=dev)      # samples of each timed step: ONE tiny launch per step
+    for i in range(2):                     # loads the code object of the counting op below, untimed
+        torch.clamp(net.step_counter[(net.local_step - 1) % 16, 0], max=net.mean_count, out=per_step[0])
+    per_step.zero_()
     n_updates[0] = 0
     scatter_events.clear()
     import gc
@@ -196,12 +196,13 @@ def train_probe(dev, rank=0, world=1, red_dev=None, steps=20, warmup=5, stage="i
     t0 = time.perf_counter()
     for i in range(steps):
         last = tr.train_one_step(batches[i % 4])
-        marched += torch.clamp(net.step_counter[(net.local_step - 1) % 16, 0], max=net.mean_count)
+        torch.clamp(net.step_counter[(net.local_step - 1) % 16, 0], max=net.mean_count, out=per_step[i])
+    host_s = time.perf_counter() - t0      # time the host needed to QUEUE the steps (== elapsed when the host is the limit)
     barrier()
     elapsed = time.perf_counter() - t0
     gc.enable()
     _network_mod._table_backward = real_table_backward
-    n = int(marched.item())
+    n = int(per_step.sum().item())
     n_all = float(n)
     scatter_ms = sum(a.elapsed_time(b) for a, b in scatter_events) / max(len(scatter_events), 1)
     if world > 1:
@@ -235,7 +236,9 @@ def train_probe(dev, rank=0, world=1, red_dev=None, steps=20, warmup=5, stage="i
             f"(BASELINE configs[{2 if world == 1 else 3}])") if stage == "instance" else \
         "NeRF training step (MSE on rgb: hash table + sigma/colour nets, parameter EMA 0.95), 4096 rays/batch per GPU"
     return {"workload": what,
-            "n_gpus": world, "ms_per_step": round(dt * 1e3, 3), "samples_per_step": int(n_all) // steps,
+            "n_gpus": world, "ms_per_step": round(dt * 1e3, 3),
+            "host_enqueue_ms_per_step": round(host_s / steps * 1e3, 3),     # a busy host shows here first
+            "samples_per_step": int(n_all) // steps,
             "msamples_per_s": round(n_all / steps / dt / 1e6, 2),
             "allreduce_mb_per_step": round(reduced / 1e6, 1) if world > 1 else 0.0,
             "occupancy_updates_in_timed_steps": n_updates[0], "roofline": roofline,

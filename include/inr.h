@@ -37,7 +37,7 @@ extern "C" {
 /* Bumped whenever an existing prototype changes or an entry point is removed (round 2 changed four argument lists
  * without a bump: a stale library or an external caller built against the old header was only rejected by accident).
  * instance_nerf_amd/_lib.py refuses a library whose version differs from the one it was written against. */
-#define INR_ABI_VERSION 5
+#define INR_ABI_VERSION 6
 #define INR_MAX_LEVELS 16
 
 enum {
@@ -400,7 +400,8 @@ int inr_roi_align_3d_backward(const float* grad_out, const float* rois, const in
  * compositing in one launch; a 16-ray group stops being evaluated once all its rays are below T_thresh (what the
  * alive-ray loop of NeRFRenderer.run_cuda achieves, a5, without host round trips).  Same results as
  * inr_nerf_forward + inr_composite_rays_patch_forward up to fp32 rounding.  weights [M] nullable (w per sample,
- * 0 when skipped); evaluated (device uint64, nullable) is incremented by the number of samples evaluated.        */
+ * 0 when skipped); evaluated: device uint64 [33], ZEROED BY THE CALLER - [0] receives the number of samples evaluated,
+ * [1..32] are the cursors of the launch's dynamic group schedule (scratch).                                        */
 int inr_nerf_render(const float* xyzs, const float* deltas, const int32_t* rays, const float* rays_d /*[N,3]*/,
                     int64_t N, int64_t M, float bound, const float* embeddings, const inr_grid_desc* desc /*host*/,
                     const float* packed /*device*/, float density_scale, float T_thresh, float* weights_sum,
@@ -414,7 +415,9 @@ int inr_nerf_render(const float* xyzs, const float* deltas, const int32_t* rays,
  * the normalised coordinates (x + bound) / (2 bound) the patch writer emits with normalise = 1.          */
 int inr_instance_render(const float* xyzs, const int32_t* rays, const float* weights, int64_t N, int64_t M,
                         float bound, const float* embeddings, const inr_grid_desc* desc /*host*/,
-                        const float* packed /*device*/, int32_t K, float* extra_out, int32_t x_is_01, inr_stream_t s);
+                        const float* packed /*device*/, int32_t K, float* extra_out, int32_t x_is_01,
+                        uint64_t* cursors /*device [32], ZEROED BY THE CALLER: the launch's dynamic group schedule*/,
+                        inr_stream_t s);
 
 /* ---- weight gradient of the tiny bias-free MLP layers (replaces the BLAS call autograd makes for
  * nn.Linear in NeRFNetwork, a9/a13):  grad_w[o][i] += sum_m grad_y[m][o] * x[m][i],  n_in, n_out <= 64.

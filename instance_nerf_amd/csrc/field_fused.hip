@@ -552,34 +552,43 @@ __device__ __forceinline__ TileSched make_sched(int64_t n_tiles, int waves_per_b
   return s;
 }
 
-// Schedule over 16-ray GROUPS (kernels in which a wave or a workgroup owns a group for all its steps).  An eighth of
-// the groups is not an eighth of the work - the top rows of a frame see the ceiling, the middle rows the whole room -
-// and an eighth of the SAMPLES is not either (regions differ in what a sample costs, see make_sched).  Measured in
-// round 2 (profiles/r02_NOTES.txt 20, 28; terminate path, transparent bench scene): XCD x takes the groups
-// [n x/8, n (x+1)/8) 9.4 ms; plain striding over the whole grid 7.7; a contiguous range holding an eighth of the
-// samples 7.2 (trained scene 18.2); chunks of as many consecutive groups as an XCD has units, dealt round robin to the
-// XCDs - neighbouring patches still share an L2, every XCD sees every region - 7.45 (trained 17.0, opaque 0.97 vs 1.05,
-// instance render 11.6 vs 12.2 ms): the last one is what this does.
-// units_per_block: waves (wave-owned groups) or 1 (workgroup-owned).
-__device__ __forceinline__ TileSched make_group_sched(int64_t N, int units_per_block, int unit) {
-  const int64_t n_groups = (N + 15) >> 4;
-  const int nb = gridDim.x, b = blockIdx.x;
-  TileSched s;
-  s.lo = 0;
-  s.hi = n_groups;
-  if (nb % 8 == 0) {
-    const int xcd = b & 7, local = b >> 3, per = nb >> 3;
-    const int64_t U = (int64_t)per * units_per_block;
-    s.first = (int64_t)xcd * U + (int64_t)local * units_per_block + unit;
-    s.stride = 8 * U;
-  } else {
-    s.first = (int64_t)b * units_per_block + unit;
-    s.stride = (int64_t)nb * units_per_block;
-  }
-  return s;
-}
-
 constexpr int kFieldThreads = 512;     // waves of a workgroup share one 40 KB weight image in LDS
+constexpr int kGroupChunkLog2 = 6;     // dynamic group schedules: 2^k consecutive 16-ray groups per cursor and round
+constexpr int kGroupDraw = 1;          // groups an owner takes per draw (must divide the chunk)
+constexpr int kGroupPools = 4;                            // cursors per XCD, wave-owned groups (see GroupDraw)
+// DYNAMIC schedule over 16-ray groups (kernels in which a wave or a workgroup owns a group for all its steps).  A group
+// costs what its rays' sample counts and termination points make it cost (the ceiling rows of a frame: a dozen steps;
+// the middle rows: seventy; an opaque group: two), so a fixed deal of ~20 groups per wave leaves the launch waiting for
+// its unluckiest wave (round 2 measured 7.2 - 9.4 ms for the same work under four static deals).  Instead the owner of
+// a group draws the next one from a cursor (zeroed by the caller): chunks of 2^kGroupChunkLog2 consecutive groups are
+// dealt round robin to the XCDs - neighbouring patches still share an L2, every XCD sees every region of the frame -
+// and inside an XCD groups go to whoever is free.  Same-address atomics are applied one after the other (~60 ns each):
+// with one cursor per XCD an opaque frame of the wave-owned kernel - two steps per group, 2048 waves drawing - spent a
+// quarter of its time queueing for it (1.22 vs 0.98 ms), so that kernel uses kGroupPools cursors per XCD, one per
+// quarter of its workgroups (one chunk at a time each: the same window of the frame); the workgroup-owned kernel draws
+// an eighth as often and is faster with ONE window per XCD (instance render 11.4 ms; four pools 12.0; the static deal
+// 11.6).  Measured and not kept: 4 groups per draw (9.8 instead of 6.9 ms: the waves of an XCD then span four times the
+// window and the L2 hit rate collapses), chunks of 16 / 256 / 1024 groups (6.9-7.0 / 7.1-7.5 / 7.2-8.0 ms), super-tiled
+// pixel order (within noise).  Workgroup b runs on XCD b % 8 (observed; speed only - any placement gives the same results).
+struct GroupDraw {
+  unsigned long long* cursor;
+  int owner, n_owner;
+  __device__ __forceinline__ void init(unsigned long long* cursors, int pools) {
+    const int n_xcd = (gridDim.x % 8 == 0) ? 8 : 1;
+    const int n_pool = (gridDim.x % (8 * pools) == 0) ? pools : 1;
+    const int xcd = (n_xcd == 8) ? (int)(blockIdx.x & 7) : 0;
+    const int pool = (n_pool > 1) ? (int)((blockIdx.x >> 3) % pools) : 0;
+    owner = pool * n_xcd + xcd;
+    n_owner = n_pool * n_xcd;
+    cursor = cursors + owner;
+  }
+  __device__ __forceinline__ int64_t group_of(uint32_t u) const {
+    const int64_t chunk = (int64_t)(u >> kGroupChunkLog2) * n_owner + owner;
+    return (chunk << kGroupChunkLog2) + (u & ((1u << kGroupChunkLog2) - 1u));
+  }
+  // called by ONE lane: the first of the kGroupDraw consecutive groups it now owns
+  __device__ __forceinline__ int64_t draw() const { return group_of((uint32_t)atomicAdd(cursor, (unsigned long long)kGroupDraw)); }
+};
 constexpr int kFieldMinWaves = 2;      // __launch_bounds__ second argument: <= 128 VGPRs
 
 // kTable: fused-frame fast path - x is already normalised to [0,1] by the march writer and the direction
@@ -1506,8 +1515,9 @@ template <int K_MT>
 __global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_instance_render(
     const float* __restrict__ x, const int32_t* __restrict__ rays, const float* __restrict__ wbuf, int64_t N, int64_t M,
     float bound, const float2* __restrict__ emb, uint32_t emb_bytes, GridDesc G, const float4* __restrict__ packed,
-    float* __restrict__ extra_out, int x_is_01) {
+    float* __restrict__ extra_out, int x_is_01, unsigned long long* __restrict__ cursors) {
   extern __shared__ __attribute__((aligned(16))) float4 wl[];
+  __shared__ int64_t drawn[2];
   constexpr int K = K_MT * 16;
   constexpr int kStage = (kIns2 + K * 64) / 4;
   constexpr int kWaves = kFieldThreads / 64;
@@ -1520,14 +1530,19 @@ __global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_instance_rend
   const int lane = threadIdx.x & 63, q = lane >> 4, j = lane & 15, wave = threadIdx.x >> 6;
   const float rb = 2.0f * bound;
   const float x_add = x_is_01 ? 0.0f : bound, x_div = x_is_01 ? 1.0f : rb;
-  // a WORKGROUP per group; the XCD's workgroups sweep its range side by side (neighbouring patches share the L2)
-  const TileSched sched = make_group_sched(N, 1, 0);
-  const int64_t g_first = sched.first, g_hi = sched.hi, g_stride = sched.stride;
+  // a WORKGROUP per group, drawn dynamically (GroupDraw): thread 0 requests the next group while this one is evaluated
+  // and hands it over through LDS behind the barrier every group ends with.  (kGroupDraw == 1 here.)
+  const int64_t n_groups = (N + 15) >> 4;
+  GroupDraw gd;
+  gd.init(cursors, 1);
   const bool all_hashed[4] = {slot_all_hashed(G, 0), slot_all_hashed(G, 1), slot_all_hashed(G, 2), slot_all_hashed(G, 3)};
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)emb, 0, (int)emb_bytes, 0x00020000);
 
+  if (threadIdx.x == 0) drawn[0] = gd.draw();
+  __syncthreads();
   int parity = 0;
-  for (int64_t grp = g_first; grp < g_hi; grp += g_stride, parity ^= 1) {
+  for (int64_t grp = drawn[0]; grp < n_groups; grp = drawn[parity ^= 1]) {
+    if (threadIdx.x == 0) drawn[parity ^ 1] = gd.draw();
     const int64_t ray = grp * 16 + j;
     const int cnt = ray < N ? rays[ray * 3 + 2] : 0;
     const int64_t S0 = rays[grp * 16 * 3 + 1];             // slot base of the group (offset of its first ray)
@@ -1633,16 +1648,35 @@ __global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_nerf_render(
   stage_level_recs(G, recs);
   __syncthreads();
 
-  constexpr int kWaves = kFieldThreads / 64;
   const int lane = threadIdx.x & 63, q = lane >> 4, j = lane & 15;
   const float rb = 2.0f * bound;
   const float x_add = x_is_01 ? 0.0f : bound, x_div = x_is_01 ? 1.0f : rb;   // table feed: already normalised
-  const TileSched sched = make_group_sched(N, kWaves, threadIdx.x >> 6);
   const bool all_hashed[4] = {slot_all_hashed(G, 0), slot_all_hashed(G, 1), slot_all_hashed(G, 2), slot_all_hashed(G, 3)};
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)emb, 0, (int)emb_bytes, 0x00020000);
   unsigned long long n_eval = 0;
+  // dynamic group schedule (GroupDraw): the wave draws its next group(s) while it evaluates the current one
+  const int64_t n_groups = (N + 15) >> 4;
+  GroupDraw gd;
+  gd.init(evaluated + 1, kGroupPools);
+  auto draw = [&]() -> int64_t {
+    int64_t g = 0;
+    if (lane == 0) g = gd.draw();
+    return ((int64_t)__builtin_amdgcn_readfirstlane((int)(g >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)g);
+  };
 
-  for (int64_t it = 0, grp = sched.tile(0); grp < sched.hi; grp = sched.tile(++it)) {
+  int64_t base = draw(), base_next = draw();      // the next draw is always in flight while a batch is evaluated
+  for (int sub = 0;;) {
+    if (sub == kGroupDraw) {
+      base = base_next;
+      base_next = draw();
+      sub = 0;
+    }
+    const int64_t grp = base + sub++;
+    if (grp >= n_groups) {
+      if (base >= n_groups) break;                 // the XCD's share is used up
+      sub = kGroupDraw;                            // the frame ends inside this batch
+      continue;
+    }
     const int64_t ray = grp * 16 + j;
     const bool has_ray = ray < N;
     const int cnt = has_ray ? rays[ray * 3 + 2] : 0;
@@ -1746,7 +1780,7 @@ __global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_nerf_render(
       image[rid * 3] = cr; image[rid * 3 + 1] = cg; image[rid * 3 + 2] = cb;
     }
   }
-  if (evaluated && lane == 0 && n_eval) atomicAdd(evaluated, n_eval);
+  if (lane == 0 && n_eval) atomicAdd(evaluated, n_eval);
 }
 
 // ---- host-side packing into fragment order ------------------------------------------------------
@@ -2261,10 +2295,10 @@ int inr_nerf_backward(const float* grad_sigma, const float* grad_rgb, const floa
 
 int inr_instance_render(const float* xyzs, const int32_t* rays, const float* weights, int64_t N, int64_t M, float bound,
                         const float* embeddings, const inr_grid_desc* desc, const float* packed, int32_t K,
-                        float* extra_out, int32_t x_is_01, inr_stream_t s) {
+                        float* extra_out, int32_t x_is_01, uint64_t* cursors, inr_stream_t s) {
   INR_REQUIRE(N >= 0 && M >= 0 && desc, "bad argument");
   if (N == 0) return INR_OK;
-  INR_REQUIRE(rays && embeddings && packed && extra_out, "null pointer");
+  INR_REQUIRE(rays && embeddings && packed && extra_out && cursors && ((uintptr_t)cursors & 7) == 0, "null pointer");
   INR_REQUIRE(M == 0 || (xyzs && weights), "null sample arrays");
   INR_REQUIRE(K > 0 && K <= 64 && K % 16 == 0, "K must be 16, 32, 48 or 64");
   INR_REQUIRE(((uintptr_t)embeddings & 7) == 0 && ((uintptr_t)packed & 15) == 0 && ((uintptr_t)extra_out & 15) == 0,
@@ -2281,12 +2315,14 @@ int inr_instance_render(const float* xyzs, const int32_t* rays, const float* wei
   const size_t lds = (size_t)(kIns2 + K * 64) * sizeof(float) + kLevelRecBytes + 2 * (kFieldThreads / 64) * (size_t)K * 64;
   const int64_t n_groups = (N + 15) / 16;
   const int64_t as_tiles = n_groups * (kFieldThreads / 64);        // one workgroup per group
+  INR_REQUIRE(n_groups < ((int64_t)1 << 31) - 65536, "too many rays for the 32-bit group cursor");
+  unsigned long long* cur = reinterpret_cast<unsigned long long*>(cursors);
   hipStream_t st = as_stream(s);
   switch (K / 16) {
-    case 1: k_instance_render<1><<<grid_for(k_instance_render<1>, lds, as_tiles), kFieldThreads, lds, st>>>(xyzs, rays, weights, N, M, bound, e, eb, G, p, extra_out, x_is_01); break;
-    case 2: k_instance_render<2><<<grid_for(k_instance_render<2>, lds, as_tiles), kFieldThreads, lds, st>>>(xyzs, rays, weights, N, M, bound, e, eb, G, p, extra_out, x_is_01); break;
-    case 3: k_instance_render<3><<<grid_for(k_instance_render<3>, lds, as_tiles), kFieldThreads, lds, st>>>(xyzs, rays, weights, N, M, bound, e, eb, G, p, extra_out, x_is_01); break;
-    default: k_instance_render<4><<<grid_for(k_instance_render<4>, lds, as_tiles), kFieldThreads, lds, st>>>(xyzs, rays, weights, N, M, bound, e, eb, G, p, extra_out, x_is_01); break;
+    case 1: k_instance_render<1><<<grid_for(k_instance_render<1>, lds, as_tiles), kFieldThreads, lds, st>>>(xyzs, rays, weights, N, M, bound, e, eb, G, p, extra_out, x_is_01, cur); break;
+    case 2: k_instance_render<2><<<grid_for(k_instance_render<2>, lds, as_tiles), kFieldThreads, lds, st>>>(xyzs, rays, weights, N, M, bound, e, eb, G, p, extra_out, x_is_01, cur); break;
+    case 3: k_instance_render<3><<<grid_for(k_instance_render<3>, lds, as_tiles), kFieldThreads, lds, st>>>(xyzs, rays, weights, N, M, bound, e, eb, G, p, extra_out, x_is_01, cur); break;
+    default: k_instance_render<4><<<grid_for(k_instance_render<4>, lds, as_tiles), kFieldThreads, lds, st>>>(xyzs, rays, weights, N, M, bound, e, eb, G, p, extra_out, x_is_01, cur); break;
   }
   return check_launch("instance_render");
 }
@@ -2297,10 +2333,10 @@ int inr_nerf_render(const float* xyzs, const float* deltas, const int32_t* rays,
                     uint64_t* evaluated, int32_t x_is_01, inr_stream_t s) {
   INR_REQUIRE(N >= 0 && M >= 0 && desc, "bad argument");
   if (N == 0) return INR_OK;
-  INR_REQUIRE(rays && rays_d && embeddings && packed && weights_sum && depth && image, "null pointer");
+  INR_REQUIRE(rays && rays_d && embeddings && packed && weights_sum && depth && image && evaluated, "null pointer");
   INR_REQUIRE(M == 0 || (xyzs && deltas), "null sample arrays");
-  INR_REQUIRE(((uintptr_t)embeddings & 7) == 0 && ((uintptr_t)packed & 15) == 0 && ((uintptr_t)deltas & 7) == 0,
-              "embeddings/packed/deltas misaligned");
+  INR_REQUIRE(((uintptr_t)embeddings & 7) == 0 && ((uintptr_t)packed & 15) == 0 && ((uintptr_t)deltas & 7) == 0 &&
+                  ((uintptr_t)evaluated & 7) == 0, "embeddings/packed/deltas/evaluated misaligned");
   GridDesc G;
   int rc = make_grid_desc(desc, G);
   if (rc) return rc;
@@ -2308,6 +2344,7 @@ int inr_nerf_render(const float* xyzs, const float* deltas, const int32_t* rays,
   INR_REQUIRE(emb_bytes64 < (1ull << 31), "table larger than 2 GiB is not addressable by the 32-bit gather offsets");
   const size_t lds = kNerfFloats * sizeof(float) + kLevelRecBytes;
   const int64_t n_groups = (N + 15) / 16;
+  INR_REQUIRE(n_groups < ((int64_t)1 << 31) - 65536, "too many rays for the 32-bit group cursor");
   k_nerf_render<<<grid_for(k_nerf_render, lds, n_groups), kFieldThreads, lds, as_stream(s)>>>(
       xyzs, deltas, rays, rays_d, N, M, bound, reinterpret_cast<const float2*>(embeddings), (uint32_t)emb_bytes64, G,
       reinterpret_cast<const float4*>(packed), density_scale, T_thresh, weights_sum, depth, image, weights,

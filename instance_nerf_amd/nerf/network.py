@@ -656,7 +656,7 @@ class NeRFNetwork(NeRFRenderer):
         depth = torch.empty(N, dtype=torch.float32, device=dev)
         image = torch.empty(N, 3, dtype=torch.float32, device=dev)
         wbuf = torch.empty(max(M, 1), dtype=torch.float32, device=dev) if want_weights else None
-        evaluated = torch.zeros(1, dtype=torch.int64, device=dev)
+        evaluated = torch.zeros(33, dtype=torch.int64, device=dev)     # [0] evaluated samples, [1..32] the launch's group cursors
         check(lib.inr_nerf_render(ptr(xyzs, torch.float32, "xyzs", allow_none=M == 0),
                                   ptr(deltas, torch.float32, "deltas", allow_none=M == 0), ptr(rays, torch.int32, "rays"),
                                   ptr(rays_d.contiguous(), torch.float32, "rays_d"), N, M, float(self.bound),
@@ -664,7 +664,7 @@ class NeRFNetwork(NeRFRenderer):
                                   ptr(self._packed_weights("nerf")), float(self.density_scale), float(T_thresh),
                                   ptr(ws), ptr(depth), ptr(image), ptr(wbuf, allow_none=True), ptr(evaluated),
                                   1 if normalised else 0, stream_ptr()), "nerf_render")
-        return ws, depth, image, wbuf, evaluated
+        return ws, depth, image, wbuf, evaluated[:1]
 
     @torch.no_grad()
     def instance_render(self, xyzs, rays, weights, normalised=False):
@@ -676,11 +676,12 @@ class NeRFNetwork(NeRFRenderer):
         lib = _lib.load()
         N, M = rays.shape[0], xyzs.shape[0]
         out = torch.empty(N, self._k_pad, dtype=torch.float32, device=rays.device)
+        cursors = torch.zeros(32, dtype=torch.int64, device=rays.device)        # the launch's dynamic group schedule
         check(lib.inr_instance_render(ptr(xyzs, torch.float32, "xyzs", allow_none=M == 0), ptr(rays, torch.int32, "rays"),
                                       ptr(weights, torch.float32, "weights", allow_none=M == 0), N, M, float(self.bound),
                                       ptr(self.instance_encoder.embeddings.data, torch.float32),
                                       self.instance_encoder.desc, ptr(self._packed_weights("instance")),
-                                      self._k_pad, ptr(out), 1 if normalised else 0, stream_ptr()),
+                                      self._k_pad, ptr(out), 1 if normalised else 0, ptr(cursors), stream_ptr()),
               "instance_render")
         return out if self._k_pad == self.num_instances else out[:, :self.num_instances].contiguous()
 

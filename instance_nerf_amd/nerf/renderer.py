@@ -188,7 +188,7 @@ class NeRFRenderer(nn.Module):
                              are opaque (measured 4x faster than "fused" on an opaque scene, 1.4x slower on a
                              transparent one)
           "auto" (default)   picks between the two from the fraction of samples the early-terminating kernel skips /
-                             would skip, as counted by the previous inference calls (> terminate_above = 0.35)
+                             would skip, as counted by the previous inference calls (> terminate_above = 0.28)
           "fused_raymajor" / "wavefront"   reference paths kept for parity tests (ray-major layout / upstream's loop)
 
         ce_labels (training, networks with an instance head; int64, one per ray): the cross entropy of the rendered
@@ -393,15 +393,17 @@ class NeRFRenderer(nn.Module):
         results["weights_sum"] = weights_sum.view(*prefix)
         return results
 
-    # infer_mode="auto": which kernel path pays?  The early-terminating kernel costs 1.26-1.37x per EVALUATED sample (a
-    # wave owns a 16-ray group for all its steps; measured on the bench scene and on a trained one, profiles/r02_NOTES.txt
-    # section 20) and skips every step at which the whole group is below T_thresh, so it wins when it skips more than
-    # 21-27 % of the marched samples; 35 % is used (hysteresis against flapping).  The two-kernel path counts that
-    # fraction in its compositing kernel, the terminating kernel reports what it really evaluated.  (Round 1 switched on
-    # mean opacity > 0.5: a half-trained scene - opacity 0.88, only 8 % skippable - then rendered in 20.5 ms instead of
-    # 14.4, section 11.)  The value travels to the host through a pinned buffer + event and is only read once its copy
-    # has completed: no call waits for a previous frame.
-    terminate_above = 0.35
+    # infer_mode="auto": which kernel path pays?  The early-terminating kernel costs 1.20-1.26x per EVALUATED sample (a
+    # wave owns a 16-ray group for all its steps, so the 256 waves of an XCD hold 256 patches at 256 different depths
+    # where the two-kernel path holds a few patches' consecutive tiles: L2 miss rate 55 % against 37 %, measured -
+    # profiles/r03_NOTES.txt section 13; 1.26-1.37x before the dynamic group schedule of round 3) and skips every step
+    # at which the whole group is below T_thresh, so it wins when it skips more than 17-21 % of the marched samples;
+    # 28 % is used (hysteresis against flapping).  The two-kernel path counts that fraction in its compositing kernel,
+    # the terminating kernel reports what it really evaluated.  (Round 1 switched on mean opacity > 0.5: a half-trained
+    # scene - opacity 0.88, only 8 % skippable - then rendered in 20.5 ms instead of 14.4, r02 notes section 11.)  The
+    # value travels to the host through a pinned buffer + event and is only read once its copy has completed: no call
+    # waits for a previous frame.
+    terminate_above = 0.28
 
     def _note_skippable(self, counter, total, counts_evaluated):
         """counter: the device counter of the frame (samples skippable / samples evaluated); total: marched samples, known
