@@ -13,6 +13,7 @@ Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -309,13 +310,15 @@ def instance_render_probe(dev, frames=8):
             "frac_of_hbm_peak": round(n * 2 * BYTES_PER_SAMPLE / dt / 1e9 / HBM_PEAK_GBS, 4)}
 
 
-def half_table_probe(dev, frames=8):
+def half_table_probe(dev, frames=8, mlp_fp16=False):
     """Secondary measurement: the headline frames with the OPT-IN half-precision table copy (NeRFNetwork.half_table;
     upstream's -O / fp16 storage): 512 B of algorithmic table traffic per sample.  Not the headline: its outputs differ
-    from the fp32 table's by ~1e-3 relative."""
+    from the fp32 table's by ~1e-3 relative.  mlp_fp16: additionally the single-pass fp16 MLP (NeRFNetwork.mlp_fp16) -
+    both halves of upstream's -O; the object then carries the largest difference to the default path on view 0."""
     from instance_nerf_amd.nerf.utils import get_rays
     net, room = build_network(dev)
     net.half_table = True
+    net.mlp_fp16 = bool(mlp_fp16)
     poses, intr, H, W = room.cameras()
     pd = torch.from_numpy(poses).to(dev)
     ev = []
@@ -344,10 +347,19 @@ def half_table_probe(dev, frames=8):
     dt = time.perf_counter() - t0
     n = sum(int(c[0]) for c in counts)
     kms = sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1)
-    return {"workload": "render 800x800, sigma+rgb, fp16 copy of the hash table (opt-in, NeRFNetwork.half_table)",
-            "ms_per_frame": round(dt / frames * 1e3, 3), "value": round(n / dt / 1e6, 1), "unit": "Msamples/s",
-            "field_kernel_ms": round(kms, 4), "algorithmic_bytes_per_sample": BYTES_PER_SAMPLE // 2,
-            "field_frac_of_hbm_peak": round(n / frames * (BYTES_PER_SAMPLE // 2) / (kms / 1e3) / 1e9 / HBM_PEAK_GBS, 4)}
+    out = {"workload": "render 800x800, sigma+rgb, fp16 copy of the hash table (opt-in, NeRFNetwork.half_table)"
+                       + (" + single-pass fp16 MLP (opt-in, NeRFNetwork.mlp_fp16): upstream's -O numerics class" if mlp_fp16 else ""),
+           "ms_per_frame": round(dt / frames * 1e3, 3), "value": round(n / dt / 1e6, 1), "unit": "Msamples/s",
+           "field_kernel_ms": round(kms, 4), "algorithmic_bytes_per_sample": BYTES_PER_SAMPLE // 2,
+           "field_frac_of_hbm_peak": round(n / frames * (BYTES_PER_SAMPLE // 2) / (kms / 1e3) / 1e9 / HBM_PEAK_GBS, 4)}
+    if mlp_fp16:
+        fast = frame(0)["image"]
+        net.half_table = net.mlp_fp16 = False
+        ref = frame(0)["image"]
+        mse = float(((fast - ref) ** 2).mean())
+        out["vs_default_path"] = {"max_abs_diff": float((fast - ref).abs().max()),
+                                  "psnr_db": round(-10 * math.log10(max(mse, 1e-20)), 1)}
+    return out
 
 
 def trained_scene_probe(dev, steps=1500, with_oracle=True):
@@ -389,12 +401,15 @@ def trained_scene_probe(dev, steps=1500, with_oracle=True):
     out = {"workload": f"NeRF of the synthetic room trained {steps} steps (4096 rays, 400x400 views, learned occupancy "
                        "grid), then the 8 bench views at 800x800", "train_seconds": round(train_s, 1),
            "occupied_cells": round(float((net.density_grid > min(net.mean_density, net.density_thresh)).float().mean()), 4)}
-    frame0 = None
-    for mode in ("fused", "fused_terminate", "auto"):
-        def frame(v):
+    frame0 = frame0_fast = None
+    # "fused_O": the two-kernel path with both opt-in halves of upstream's -O (fp16 table copy + single-pass fp16 MLP)
+    for mode in ("fused", "fused_terminate", "auto", "fused_O"):
+        net.half_table = net.mlp_fp16 = mode == "fused_O"
+
+        def frame(v, mode=mode):
             r = get_rays(pd[v:v + 1], intr, H, W, patch=4)
             with torch.no_grad():
-                return r, net.render(r["rays_o"], r["rays_d"], bg_color=1, infer_mode=mode)
+                return r, net.render(r["rays_o"], r["rays_d"], bg_color=1, infer_mode="fused" if mode == "fused_O" else mode)
         frame(0)
         frame(1)                                       # "auto": the second call knows the first one's skippable fraction
         torch.cuda.synchronize()
@@ -410,11 +425,23 @@ def trained_scene_probe(dev, steps=1500, with_oracle=True):
                      "evaluated_msamples": round(evaluated / 8 / 1e6, 2), "field_kernel_ms": round(kms, 3),
                      "field_frac_of_hbm_peak": round(evaluated / 8 * BYTES_PER_SAMPLE / (kms / 1e3) / 1e9 / HBM_PEAK_GBS, 4),
                      "path_taken": "terminate" if "num_evaluated" in res[-1][1] else "two-kernel"}
-        if mode == "auto":
+        if mode == "fused_O":
+            out[mode]["algorithmic_bytes_per_sample"] = BYTES_PER_SAMPLE // 2
+            out[mode]["field_frac_of_hbm_peak"] = round(out[mode]["field_frac_of_hbm_peak"] / 2, 4)
+        if mode in ("auto", "fused_O"):
             r0, o0 = res[0]
-            frame0 = torch.empty(H * W, 3, device=dev)
-            frame0[r0["inds"][0]] = o0["image"][0]
-            out["mean_opacity"] = round(float(o0["weights_sum"].mean()), 3)
+            f = torch.empty(H * W, 3, device=dev)
+            f[r0["inds"][0]] = o0["image"][0]
+            if mode == "auto":
+                frame0 = f
+                out["mean_opacity"] = round(float(o0["weights_sum"].mean()), 3)
+            else:
+                frame0_fast = f
+    net.half_table = net.mlp_fp16 = False
+    if frame0 is not None and frame0_fast is not None:      # the -O numerics against the default path, all pixels of view 0
+        d = (frame0_fast - frame0).double()
+        out["fused_O"]["vs_default_path"] = {"max_abs_diff": float(d.abs().max()),
+                                             "psnr_db": round(-10 * math.log10(max(float((d ** 2).mean()), 1e-20)), 1)}
     if with_oracle:
         from oracle import c_port, hashgrid, rays as orays
         sd = net.state_dict()
@@ -430,6 +457,12 @@ def trained_scene_probe(dev, steps=1500, with_oracle=True):
         out["parity"] = {"against": "C oracle, trained weights + learned bitfield, 4096 random pixels of view 0 (auto mode)",
                          "max_abs_diff": float(np.abs(got - ref["image"]).max()),
                          "psnr_db": round(10.0 * np.log10(1.0 / mse), 1) if mse > 0 else None}
+        if frame0_fast is not None:
+            got = frame0_fast.cpu().numpy()[inds].astype(np.float64)
+            mse = float(np.mean((got - ref["image"].astype(np.float64)) ** 2))
+            out["fused_O"]["parity"] = {"against": "the same oracle pixels (fp32 oracle; -O numerics on the GPU)",
+                                        "max_abs_diff": float(np.abs(got - ref["image"]).max()),
+                                        "psnr_db": round(10.0 * np.log10(1.0 / mse), 1) if mse > 0 else None}
     return out
 
 
@@ -689,6 +722,10 @@ def main():
                 line["render_half_table"] = half_table_probe(dev)
             except Exception as e:                            # noqa: BLE001
                 line["render_half_table"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            try:
+                line["render_fast"] = half_table_probe(dev, mlp_fp16=True)
+            except Exception as e:                            # noqa: BLE001
+                line["render_fast"] = {"error": f"{type(e).__name__}: {e}"[:300]}
             if world == 1 and not args.no_trained_scene:
                 try:
                     line["trained_scene"] = trained_scene_probe(dev, with_oracle=not args.no_cpu_baseline)

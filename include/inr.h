@@ -301,6 +301,17 @@ int inr_nerf_forward_table_half(const float* x01, const int32_t* ray_ids, const 
                                 float bound, const void* embeddings_half, const inr_grid_desc* desc /*host*/,
                                 const float* packed /*device*/, float density_scale, float* sigma, float* rgb,
                                 inr_stream_t s);
+/* The same launch with upstream's `-O` numerics (opt-in, inference: NeRFNetwork.mlp_fp16): the MLP GEMMs take ONE fp16
+ * MFMA pass - weights and activations rounded to fp16, fp32 accumulation - instead of the three-pass bf16 split that
+ * keeps the default path fp32-class; 2^-12 relative per operand.  `packed` must come from inr_nerf_pack_weights_f16
+ * (same size and fragment layout as inr_nerf_pack_weights, fp16 values in the head slots).  embeddings: the fp32
+ * table, or the fp16 copy when table_is_half != 0.  Not available in the -DINR_MLP_FP32 build.                     */
+int inr_nerf_pack_weights_f16(const float* sigma_w0, const float* sigma_w1, const float* color_w0,
+                              const float* color_w1, const float* color_w2, float* packed /*host*/);
+int inr_nerf_forward_table_fast(const float* x01, const int32_t* ray_ids, const float* sh_table_q, int64_t M,
+                                float bound, const void* embeddings, int32_t table_is_half,
+                                const inr_grid_desc* desc /*host*/, const float* packed /*device*/,
+                                float density_scale, float* sigma, float* rgb, inr_stream_t s);
 /* Training path of the NeRF field (a9 under autograd): device-packed weights (forward layout of
  * inr_nerf_pack_weights + the transposed sections of the backward), a forward that also stores the activations
  * (enc [M,32], h1 [M,64], so [M,16] = raw sigma-net output, cin [M,32] = colour-net input with a zero pad column,

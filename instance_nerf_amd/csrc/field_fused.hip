@@ -443,16 +443,54 @@ __device__ __forceinline__ void layer_bf(const uint4* __restrict__ w, int lane, 
   }
 }
 
+// Opt-in single-pass variant (kFast; upstream's `-O` numerics: fp16 MLP operands, fp32 accumulation): weights packed as
+// fp16 in the head slots of the same fragment layout (pack_section_f16), activations rounded to fp16
+// (v_cvt_pk_f16_f32, round to nearest even), ONE v_mfma_f32_16x16x32_f16 per (tile, step) instead of three bf16 passes,
+// one conversion per activation pair instead of the head / remainder split.  2^-12 relative per operand: close to, but
+// NOT, the fp32-class default.
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_f16x2(float a, float b) {
+  const f32x2_t v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t));
+}
+template <int N_MT, int N_S>
+__device__ __forceinline__ void layer_h1(const uint4* __restrict__ w, int lane, const uint4* in, f32x4* out) {
+  f32x4 acc[N_MT];
+#pragma unroll
+  for (int mt = 0; mt < N_MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int st = 0; st < N_S; ++st) {
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int mt = 0; mt < N_MT; ++mt)
+      acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, w[((mt * N_S + st) * 2 + 0) * 64 + lane]),
+                                                       __builtin_bit_cast(f16x8_t, in[st]), acc[mt], 0, 0, 0);
+  }
+#pragma unroll
+  for (int mt = 0; mt < N_MT; ++mt) out[mt] = acc[mt];
+}
+
 // Layer entry points used by the kernels: `in` is N_G groups of 4 registers (N_G = K/16).
-template <int N_MT, int N_G>
+template <int N_MT, int N_G, bool kFast = false>
 __device__ __forceinline__ void mlp_layer(const float4* __restrict__ wsec, int lane, const f32x4* in, f32x4* out) {
 #if INR_MLP_FP32
   layer<N_MT, N_G>(wsec, lane, in, out);
 #else
-  SplitB b[N_G / 2];
+  if constexpr (kFast) {
+    uint4 b[N_G / 2];
 #pragma unroll
-  for (int st = 0; st < N_G / 2; ++st) b[st] = split8(in[2 * st], in[2 * st + 1]);
-  layer_bf<N_MT, N_G / 2>(reinterpret_cast<const uint4*>(wsec), lane, b, out);
+    for (int st = 0; st < N_G / 2; ++st)
+      b[st] = uint4{pack_f16x2(in[2 * st][0], in[2 * st][1]), pack_f16x2(in[2 * st][2], in[2 * st][3]),
+                    pack_f16x2(in[2 * st + 1][0], in[2 * st + 1][1]), pack_f16x2(in[2 * st + 1][2], in[2 * st + 1][3])};
+    layer_h1<N_MT, N_G / 2>(reinterpret_cast<const uint4*>(wsec), lane, b, out);
+  } else {
+    SplitB b[N_G / 2];
+#pragma unroll
+    for (int st = 0; st < N_G / 2; ++st) b[st] = split8(in[2 * st], in[2 * st + 1]);
+    layer_bf<N_MT, N_G / 2>(reinterpret_cast<const uint4*>(wsec), lane, b, out);
+  }
 #endif
 }
 
@@ -612,7 +650,7 @@ struct NerfSave {
   float *enc, *h1, *so, *cin, *c1, *c2;
 };
 
-template <bool kColor, bool kTable = false, int kSave = 0, bool kHalf = false>
+template <bool kColor, bool kTable = false, int kSave = 0, bool kHalf = false, bool kFast = false>
 __global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_nerf_fwd(const float* __restrict__ x, const float* __restrict__ d,
                                                                int64_t M, const int32_t* __restrict__ n_dev, float bound,
                                                                const float2* __restrict__ emb, uint32_t emb_bytes, GridDesc G,
@@ -683,11 +721,11 @@ __global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_nerf_fwd(cons
 #endif
 
     f32x4 h1[4];
-    mlp_layer<4, 2>(wl + kSig0 / 4, lane, enc, h1);
+    mlp_layer<4, 2, kFast>(wl + kSig0 / 4, lane, enc, h1);
 #pragma unroll
     for (int t = 0; t < 4; ++t) h1[t] = relu4(h1[t]);
     f32x4 h2[1];
-    mlp_layer<1, 4>(wl + kSig1 / 4, lane, h1, h2);      // row 0 = raw density, rows 1..15 = geo features
+    mlp_layer<1, 4, kFast>(wl + kSig1 / 4, lane, h1, h2);      // row 0 = raw density, rows 1..15 = geo features
 
     if (valid) {
       if (q == 0) sigma[m] = __expf(h2[0][0]) * density_scale;
@@ -712,13 +750,13 @@ __global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_nerf_fwd(cons
       }
       cin[1] = h2[0];                                 // k-slot (q, r) = sigma-net row 4q+r (row 0 has zero weight)
       f32x4 c1[4], c2[4], o[1];
-      mlp_layer<4, 2>(wl + kCol0 / 4, lane, cin, c1);
+      mlp_layer<4, 2, kFast>(wl + kCol0 / 4, lane, cin, c1);
 #pragma unroll
       for (int t = 0; t < 4; ++t) c1[t] = relu4(c1[t]);
-      mlp_layer<4, 4>(wl + kCol1 / 4, lane, c1, c2);
+      mlp_layer<4, 4, kFast>(wl + kCol1 / 4, lane, c1, c2);
 #pragma unroll
       for (int t = 0; t < 4; ++t) c2[t] = relu4(c2[t]);
-      mlp_layer<1, 4>(wl + kCol2 / 4, lane, c2, o);
+      mlp_layer<1, 4, kFast>(wl + kCol2 / 4, lane, c2, o);
       if constexpr (kSave == 2) {          // k_nerf_head_bwd recomputes everything else from the encoder output
         if (valid) {
 #pragma unroll
@@ -1818,6 +1856,28 @@ static void pack_section_bf16(float* dst_f, const float* W, int n_out, int n_in,
         }
 }
 
+// fp16 variant of the same layout for the opt-in single-pass MLP: the head slot holds the weight rounded to fp16, the
+// remainder slot is unused (zero).
+template <class KIdx>
+static void pack_section_f16(float* dst_f, const float* W, int n_out, int n_in, int n_mt, int n_ks, KIdx kidx) {
+  uint16_t* dst = reinterpret_cast<uint16_t*>(dst_f);
+  const int n_s = n_ks / 8;
+  for (int mt = 0; mt < n_mt; ++mt)
+    for (int st = 0; st < n_s; ++st)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int e = 0; e < 8; ++e) {
+          const int row = 16 * mt + (lane & 15);
+          const int col = kidx(4 * (2 * st + (e >> 2)) + (e & 3), lane >> 4);
+          float v = 0.f;
+          if (row < n_out && col >= 0 && col < n_in) v = W[(size_t)row * n_in + col];
+          const _Float16 h = (_Float16)v;                 // round to nearest even
+          uint16_t bits;
+          memcpy(&bits, &h, 2);
+          dst[((((size_t)(mt * n_s + st) * 2 + 0) * 64 + lane) * 8) + e] = bits;
+          dst[((((size_t)(mt * n_s + st) * 2 + 1) * 64 + lane) * 8) + e] = 0;
+        }
+}
+
 template <class KIdx>
 static void pack_section_f32(float* dst, const float* W, int n_out, int n_in, int n_mt, int n_ks, KIdx kidx) {
   for (int mt = 0; mt < n_mt; ++mt)
@@ -1894,6 +1954,17 @@ int inr_nerf_pack_weights(const float* sigma_w0, const float* sigma_w1, const fl
   return INR_OK;
 }
 
+int inr_nerf_pack_weights_f16(const float* sigma_w0, const float* sigma_w1, const float* color_w0, const float* color_w1,
+                              const float* color_w2, float* packed) {
+  INR_REQUIRE(sigma_w0 && sigma_w1 && color_w0 && color_w1 && color_w2 && packed, "null pointer");
+  pack_section_f16(packed + kSig0, sigma_w0, 64, 32, 4, 8, kidx_enc);
+  pack_section_f16(packed + kSig1, sigma_w1, 16, 64, 1, 16, kidx_hidden);
+  pack_section_f16(packed + kCol0, color_w0, 64, 31, 4, 8, kidx_color_in);
+  pack_section_f16(packed + kCol1, color_w1, 64, 64, 4, 16, kidx_hidden);
+  pack_section_f16(packed + kCol2, color_w2, 3, 64, 1, 16, kidx_hidden);
+  return INR_OK;
+}
+
 int64_t inr_instance_packed_floats(int32_t K) { return (K > 0 && K <= 64 && K % 16 == 0) ? kIns2 + K * 64 : -1; }
 
 int inr_instance_pack_weights(const float* w0, const float* w1, const float* w2, int32_t K, float* packed) {
@@ -1938,26 +2009,54 @@ int inr_nerf_forward(const float* x, const float* d, int64_t M, const int32_t* n
 }
 
 static int nerf_forward_table_impl(const float* x01, const int32_t* ray_ids, const float* sh_table_q, int64_t M, float bound,
-                                   const void* embeddings, bool half, const inr_grid_desc* desc, const float* packed,
-                                   float density_scale, float* sigma, float* rgb, inr_stream_t s);
+                                   const void* embeddings, bool half, bool fast, const inr_grid_desc* desc,
+                                   const float* packed, float density_scale, float* sigma, float* rgb, inr_stream_t s);
 
 int inr_nerf_forward_table(const float* x01, const int32_t* ray_ids, const float* sh_table_q, int64_t M, float bound,
                            const float* embeddings, const inr_grid_desc* desc, const float* packed, float density_scale,
                            float* sigma, float* rgb, inr_stream_t s) {
-  return nerf_forward_table_impl(x01, ray_ids, sh_table_q, M, bound, embeddings, false, desc, packed, density_scale, sigma,
-                                 rgb, s);
+  return nerf_forward_table_impl(x01, ray_ids, sh_table_q, M, bound, embeddings, false, false, desc, packed, density_scale,
+                                 sigma, rgb, s);
 }
 
 int inr_nerf_forward_table_half(const float* x01, const int32_t* ray_ids, const float* sh_table_q, int64_t M, float bound,
                                 const void* embeddings_half, const inr_grid_desc* desc, const float* packed,
                                 float density_scale, float* sigma, float* rgb, inr_stream_t s) {
-  return nerf_forward_table_impl(x01, ray_ids, sh_table_q, M, bound, embeddings_half, true, desc, packed, density_scale,
-                                 sigma, rgb, s);
+  return nerf_forward_table_impl(x01, ray_ids, sh_table_q, M, bound, embeddings_half, true, false, desc, packed,
+                                 density_scale, sigma, rgb, s);
 }
 
+int inr_nerf_forward_table_fast(const float* x01, const int32_t* ray_ids, const float* sh_table_q, int64_t M, float bound,
+                                const void* embeddings, int32_t table_is_half, const inr_grid_desc* desc,
+                                const float* packed, float density_scale, float* sigma, float* rgb, inr_stream_t s) {
+#if INR_MLP_FP32
+  (void)x01; (void)ray_ids; (void)sh_table_q; (void)M; (void)bound; (void)embeddings; (void)table_is_half; (void)desc;
+  (void)packed; (void)density_scale; (void)sigma; (void)rgb; (void)s;
+  set_error("nerf_forward_table_fast: not available in the exact-fp32 build");
+  return INR_EINVAL;
+#else
+  return nerf_forward_table_impl(x01, ray_ids, sh_table_q, M, bound, embeddings, table_is_half != 0, true, desc, packed,
+                                 density_scale, sigma, rgb, s);
+#endif
+}
+
+extern "C++" {
+template <bool kHalf, bool kFast>
+static int launch_nerf_table(const float* x01, const int32_t* ray_ids, const float* sh_table_q, int64_t M, float bound,
+                             const void* embeddings, uint32_t emb_bytes, const GridDesc& G, const float* packed,
+                             float density_scale, float* sigma, float* rgb, size_t lds, inr_stream_t s) {
+  const int grid = grid_for(k_nerf_fwd<true, true, 0, kHalf, kFast>, lds, (M + 15) / 16);
+  k_nerf_fwd<true, true, 0, kHalf, kFast><<<grid, kFieldThreads, lds, as_stream(s)>>>(
+      x01, nullptr, M, nullptr, bound, reinterpret_cast<const float2*>(embeddings), emb_bytes, G,
+      reinterpret_cast<const float4*>(packed), density_scale, sigma, rgb, nullptr, ray_ids,
+      reinterpret_cast<const float4*>(sh_table_q), NerfSave{});
+  return check_launch("nerf_forward_table");
+}
+}  // extern "C++"
+
 static int nerf_forward_table_impl(const float* x01, const int32_t* ray_ids, const float* sh_table_q, int64_t M, float bound,
-                                   const void* embeddings, bool half, const inr_grid_desc* desc, const float* packed,
-                                   float density_scale, float* sigma, float* rgb, inr_stream_t s) {
+                                   const void* embeddings, bool half, bool fast, const inr_grid_desc* desc,
+                                   const float* packed, float density_scale, float* sigma, float* rgb, inr_stream_t s) {
   INR_REQUIRE(M >= 0 && desc, "bad argument");
   if (M == 0) return INR_OK;
   INR_REQUIRE(x01 && ray_ids && sh_table_q && embeddings && packed && sigma && rgb, "null pointer");
@@ -1969,20 +2068,17 @@ static int nerf_forward_table_impl(const float* x01, const int32_t* ray_ids, con
   const uint64_t emb_bytes64 = (uint64_t)desc->offsets[desc->num_levels] * 8ull;
   INR_REQUIRE(emb_bytes64 < (1ull << 31), "table larger than 2 GiB is not addressable by the 32-bit gather offsets");
   const size_t lds = std::max(kNerfFloats * sizeof(float) + kLevelRecBytes, (size_t)g_field_lds_min);
-  if (half) {
-    const int grid = grid_for(k_nerf_fwd<true, true, 0, true>, lds, (M + 15) / 16);
-    k_nerf_fwd<true, true, 0, true><<<grid, kFieldThreads, lds, as_stream(s)>>>(
-        x01, nullptr, M, nullptr, bound, reinterpret_cast<const float2*>(embeddings), (uint32_t)(emb_bytes64 / 2), G,
-        reinterpret_cast<const float4*>(packed), density_scale, sigma, rgb, nullptr, ray_ids,
-        reinterpret_cast<const float4*>(sh_table_q), NerfSave{});
-    return check_launch("nerf_forward_table_half");
-  }
-  const int grid = grid_for(k_nerf_fwd<true, true>, lds, (M + 15) / 16);
-  k_nerf_fwd<true, true><<<grid, kFieldThreads, lds, as_stream(s)>>>(
-      x01, nullptr, M, nullptr, bound, reinterpret_cast<const float2*>(embeddings), (uint32_t)emb_bytes64, G,
-      reinterpret_cast<const float4*>(packed), density_scale, sigma, rgb, nullptr, ray_ids,
-      reinterpret_cast<const float4*>(sh_table_q), NerfSave{});
-  return check_launch("nerf_forward_table");
+  const uint32_t eb = (uint32_t)(half ? emb_bytes64 / 2 : emb_bytes64);
+#define INR_TABLE_LAUNCH(H, F) \
+  launch_nerf_table<H, F>(x01, ray_ids, sh_table_q, M, bound, embeddings, eb, G, packed, density_scale, sigma, rgb, lds, s)
+#if INR_MLP_FP32
+  (void)fast;
+  return half ? INR_TABLE_LAUNCH(true, false) : INR_TABLE_LAUNCH(false, false);
+#else
+  if (fast) return half ? INR_TABLE_LAUNCH(true, true) : INR_TABLE_LAUNCH(false, true);
+  return half ? INR_TABLE_LAUNCH(true, false) : INR_TABLE_LAUNCH(false, false);
+#endif
+#undef INR_TABLE_LAUNCH
 }
 
 int inr_nerf_forward_dirs(const float* x, int64_t M, float bound, const float* embeddings, const inr_grid_desc* desc,

@@ -421,11 +421,15 @@ class NeRFNetwork(NeRFRenderer):
         # arithmetic, blending and the MLPs stay fp32.  Outputs differ from the fp32 table's by ~1e-3 relative.
         self.half_table = False
         self._half_cache = None
+        # Opt-in, the other half of `-O`: full-frame inference runs the MLP GEMMs as ONE fp16 MFMA pass (weights and
+        # activations rounded to fp16, fp32 accumulation) instead of the three-pass bf16 split that keeps the default
+        # fp32-class.  Outputs within a few 1e-3 of the default's; training and every other path are unaffected.
+        self.mlp_fp16 = False
 
     # ---- packed MFMA weights (cached until a weight tensor changes) ------------------------------
     def _packed_weights(self, which):
         lib = _lib.load()
-        if which == "nerf":
+        if which in ("nerf", "nerf_f16"):
             ws = [self.sigma_net[0].weight, self.sigma_net[1].weight, self.color_net[0].weight,
                   self.color_net[1].weight, self.color_net[2].weight]
         else:
@@ -435,12 +439,12 @@ class NeRFNetwork(NeRFRenderer):
         if hit is not None and hit[0] == key:
             return hit[1]
         host = [w.detach().float().cpu().contiguous() for w in ws]
-        if which != "nerf" and self._k_pad != self.num_instances:
+        if which == "instance" and self._k_pad != self.num_instances:
             host[2] = torch.nn.functional.pad(host[2], (0, 0, 0, self._k_pad - self.num_instances)).contiguous()
-        if which == "nerf":
+        if which in ("nerf", "nerf_f16"):
             buf = torch.empty(lib.inr_nerf_packed_floats(), dtype=torch.float32)
-            check(lib.inr_nerf_pack_weights(*[host_ptr(h, torch.float32) for h in host], host_ptr(buf, torch.float32)),
-                  "nerf_pack_weights")
+            pack = lib.inr_nerf_pack_weights if which == "nerf" else lib.inr_nerf_pack_weights_f16
+            check(pack(*[host_ptr(h, torch.float32) for h in host], host_ptr(buf, torch.float32)), "nerf_pack_weights")
         else:
             buf = torch.empty(lib.inr_instance_packed_floats(self._k_pad), dtype=torch.float32)
             check(lib.inr_instance_pack_weights(*[host_ptr(h, torch.float32) for h in host], self._k_pad,
@@ -496,13 +500,25 @@ class NeRFNetwork(NeRFRenderer):
             shq = self.sh_table(rays_d)
         sigma = torch.empty(M, dtype=torch.float32, device=dev)
         rgb = torch.empty(M, 3, dtype=torch.float32, device=dev)
-        if self.half_table and not self.training:
+        half = self.half_table and not self.training
+        if half:
             # opt-in (upstream's -O / fp16 storage): the eval kernel gathers from a half-precision copy of the table,
             # refreshed whenever the fp32 master changes
             emb = self.encoder.embeddings
             key = (emb.data_ptr(), emb._version)
             if self._half_cache is None or self._half_cache[0] != key:
                 self._half_cache = (key, emb.detach().to(torch.float16).contiguous())
+        if self.mlp_fp16 and not self.training:
+            # opt-in (the other half of upstream's -O): one fp16 MFMA pass per MLP GEMM instead of the fp32-class split
+            table = self._half_cache[1] if half else self.encoder.embeddings.data
+            check(lib.inr_nerf_forward_table_fast(ptr(x01, torch.float32, "x01", allow_none=M == 0),
+                                                  ptr(ray_ids, torch.int32, "ray_ids", allow_none=M == 0), ptr(shq), M,
+                                                  float(self.bound), ptr(table), 1 if half else 0,
+                                                  self.encoder.desc, ptr(self._packed_weights("nerf_f16")), 1.0,
+                                                  ptr(sigma, allow_none=M == 0), ptr(rgb, allow_none=M == 0), stream_ptr()),
+                  "nerf_forward_table_fast")
+            return sigma, rgb
+        if half:
             check(lib.inr_nerf_forward_table_half(ptr(x01, torch.float32, "x01", allow_none=M == 0),
                                                   ptr(ray_ids, torch.int32, "ray_ids", allow_none=M == 0), ptr(shq), M,
                                                   float(self.bound), ptr(self._half_cache[1], torch.float16),

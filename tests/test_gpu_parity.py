@@ -486,6 +486,43 @@ def test_half_precision_table_is_the_fp32_path_on_rounded_values(params_k16, roo
     assert tr.model.half_table and tr.fp16
 
 
+def test_single_pass_fp16_mlp_is_the_opt_in_fast_path(level_table, room, room_bitfield):
+    """NeRFNetwork.mlp_fp16 (opt-in, inference; with half_table the two halves of upstream's -O): the MLP GEMMs take ONE
+    fp16 MFMA pass with fp32 accumulation.  Same samples, an image within 3e-3 (6e-3 on the fp16 table) of the default
+    path's and NOT equal to it (fp16 operands: 2^-12 relative), at least 50 dB on O(1) densities and colours;
+    training renders and the default path are untouched; on both table formats."""
+    from instance_nerf_amd.nerf.utils import get_rays
+    poses, intr, H, W = room.cameras(n=1, H=96, W=96, focal=48.0)
+    r = get_rays(_t(poses[:1]), intr, 96, 96, patch=4)
+    from oracle import field
+    net = _network(field.init_params(seed=41, table=level_table, table_std=1.0, K=0), K=0).eval()   # O(1) outputs
+    net.density_bitfield.copy_(_t(room_bitfield))
+
+    def frame():
+        with torch.no_grad():
+            return net.render(r["rays_o"], r["rays_d"], bg_color=1, infer_mode="fused")
+    full = frame()
+    assert 0.05 < float(full["weights_sum"].mean()) < 0.999
+    for half in (False, True):
+        net.half_table, net.mlp_fp16 = half, True
+        fast = frame()
+        assert int(fast["num_samples"][0]) == int(full["num_samples"][0])
+        d = (fast["image"] - full["image"]).abs()
+        psnr = -10 * np.log10(float((d ** 2).mean()))
+        print(f"fp16 MLP, half table {half}: max abs {float(d.max()):.2e}, {psnr:.1f} dB")
+        assert 0 < float(d.max()) < (6e-3 if half else 3e-3) and psnr > 50, (half, float(d.max()), psnr)
+    net.half_table = net.mlp_fp16 = False
+    assert torch.equal(frame()["image"], full["image"])
+    net.mlp_fp16 = True
+    net.train()
+    with torch.no_grad():
+        a = net.render(r["rays_o"][:, :256], r["rays_d"][:, :256], bg_color=1, perturb=False, force_all_rays=True)["image"]
+    net.mlp_fp16 = False
+    with torch.no_grad():
+        b = net.render(r["rays_o"][:, :256], r["rays_d"][:, :256], bg_color=1, perturb=False, force_all_rays=True)["image"]
+    assert torch.equal(a, b)                           # the training path never takes the fast kernel
+
+
 def test_exact_fp32_mlp_build(params_k16):
     """The -DINR_MLP_FP32=1 build (MLP GEMMs on v_mfma_f32_16x16x4_f32, exact fp32 products) stays alive: the same
     golden field vectors through libinr_hip_fp32.so in a child process (a process binds one library).  Both builds
