@@ -682,7 +682,8 @@ class Trainer:
     ``lr_scheduler`` with the optimizer, ``metrics`` are meters with ``update / measure / report / clear``,
     ``use_checkpoint`` in {"latest", "latest_model", "best", "scratch", <path>} - so the construction in upstream's
     ``main_nerf.py`` works unchanged; ``fp16=True`` keeps training in fp32 (no autocast, no GradScaler) and switches the
-    evaluation / test renders to a half-precision copy of the hash table (``NeRFNetwork.half_table``);
+    evaluation / test renders to -O's numerics (``NeRFNetwork.half_table`` + ``NeRFNetwork.mlp_fp16``: fp16 table copy,
+    single-pass fp16 MLP);
     ``use_tensorboardX`` is accepted and ignored.  The DEFAULTS are upstream's too [U: recalled, the submodule is not
     vendored] - ``use_checkpoint="latest"`` (a workspace that holds ``<name>_ep*.pth`` files is resumed from),
     ``scheduler_update_every_step=False`` (a caller-supplied scheduler is stepped once per epoch unless the caller
@@ -708,11 +709,13 @@ class Trainer:
         self.device = device or (torch.device("cuda", local_rank) if torch.cuda.is_available() else torch.device("cpu"))
         self.stage = stage
         self.workspace = workspace
-        # upstream's fp16 / -O flag: training stays fp32 here (no autocast, no GradScaler); what it switches on is the
-        # half-precision table copy for evaluation / test renders (NeRFNetwork.half_table)
+        # upstream's fp16 / -O flag: training stays fp32 here (no autocast, no GradScaler); what it switches on are the
+        # two inference options with -O's numerics: the half-precision table copy and the single-pass fp16 MLP of the
+        # evaluation / test renders (NeRFNetwork.half_table, NeRFNetwork.mlp_fp16)
         self.mute, self.fp16 = mute, bool(fp16)
         if self.fp16 and hasattr(model, "half_table"):
             model.half_table = True
+            model.mlp_fp16 = True
         self.metrics = list(metrics) if metrics else []
         self.eval_interval, self.max_keep_ckpt = eval_interval, max_keep_ckpt
         self.best_mode, self.use_loss_as_metric = best_mode, use_loss_as_metric

@@ -483,7 +483,7 @@ def test_half_precision_table_is_the_fp32_path_on_rounded_values(params_k16, roo
     assert not torch.equal(again["image"], half["image"])
     # upstream's flag
     tr = Trainer("h", None, _network(params_k16, K=0), stage="nerf", device=torch.device(DEV), fp16=True, workspace=None)
-    assert tr.model.half_table and tr.fp16
+    assert tr.model.half_table and tr.model.mlp_fp16 and tr.fp16
 
 
 def test_single_pass_fp16_mlp_is_the_opt_in_fast_path(level_table, room, room_bitfield):
