@@ -304,10 +304,25 @@ def instance_render_probe(dev, frames=8):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     n = sum(int(c[0]) for c in counts)
-    return {"workload": "render 800x800 with the instance head, K=64 logits per pixel (both fields evaluated per sample)",
-            "ms_per_frame": round(dt / frames * 1e3, 3), "value": round(n / dt / 1e6, 1), "unit": "Msamples/s",
-            "algorithmic_bytes_per_sample": 2 * BYTES_PER_SAMPLE,
-            "frac_of_hbm_peak": round(n * 2 * BYTES_PER_SAMPLE / dt / 1e9 / HBM_PEAK_GBS, 4)}
+    out = {"workload": "render 800x800 with the instance head, K=64 logits per pixel (both fields evaluated per sample)",
+           "ms_per_frame": round(dt / frames * 1e3, 3), "value": round(n / dt / 1e6, 1), "unit": "Msamples/s",
+           "algorithmic_bytes_per_sample": 2 * BYTES_PER_SAMPLE,
+           "frac_of_hbm_peak": round(n * 2 * BYTES_PER_SAMPLE / dt / 1e9 / HBM_PEAK_GBS, 4)}
+    # the same frames with upstream's -O numerics on BOTH fields (opt-in: fp16 table copies, single-pass fp16 MLPs)
+    ref = frame(0)
+    net.half_table = net.mlp_fp16 = True
+    fast = frame(0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for v in range(frames):
+        frame(v % pd.shape[0])
+    torch.cuda.synchronize()
+    dt_o = time.perf_counter() - t0
+    out["O_numerics"] = {"ms_per_frame": round(dt_o / frames * 1e3, 3), "value": round(n / dt_o / 1e6, 1),
+                         "max_abs_diff_image": float((fast["image"] - ref["image"]).abs().max()),
+                         "max_abs_diff_logits": float((fast["instance"] - ref["instance"]).abs().max()),
+                         "max_abs_logit": float(ref["instance"].abs().max())}
+    return out
 
 
 def half_table_probe(dev, frames=8, mlp_fp16=False):

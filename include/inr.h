@@ -418,6 +418,13 @@ int inr_nerf_render(const float* xyzs, const float* deltas, const int32_t* rays,
                     const float* packed /*device*/, float density_scale, float T_thresh, float* weights_sum,
                     float* depth, float* image, float* weights, uint64_t* evaluated, int32_t x_is_01 /* xyzs are the
                     normalised coordinates of the patch writer's table feed */, inr_stream_t s);
+/* The same launch with upstream's `-O` numerics (opt-in: NeRFNetwork.half_table + mlp_fp16): fp16 copy of the table,
+ * weights from inr_nerf_pack_weights_f16, one fp16 MFMA pass per MLP GEMM.  Not in the -DINR_MLP_FP32 build.      */
+int inr_nerf_render_fast(const float* xyzs, const float* deltas, const int32_t* rays, const float* rays_d, int64_t N,
+                         int64_t M, float bound, const void* embeddings_half, const inr_grid_desc* desc /*host*/,
+                         const float* packed_f16 /*device*/, float density_scale, float T_thresh, float* weights_sum,
+                         float* depth, float* image, float* weights, uint64_t* evaluated, int32_t x_is_01,
+                         inr_stream_t s);
 
 /* Instance logits rendered in place (inference, patch-interleaved layout): extra_out[ray][ch] =
  * sum_k weights[slot(ray,k)] * logits(xyzs[slot(ray,k)])[ch]; the [M,K] logits never exist in memory.
@@ -429,6 +436,15 @@ int inr_instance_render(const float* xyzs, const int32_t* rays, const float* wei
                         const float* packed /*device*/, int32_t K, float* extra_out, int32_t x_is_01,
                         uint64_t* cursors /*device [32], ZEROED BY THE CALLER: the launch's dynamic group schedule*/,
                         inr_stream_t s);
+/* The same launch with upstream's `-O` numerics (opt-in: NeRFNetwork.half_table + mlp_fp16): embeddings_half is the fp16
+ * copy of the instance table (T x 2 binary16), packed_f16 comes from inr_instance_pack_weights_f16 (same size and
+ * fragment layout as inr_instance_pack_weights, fp16 values in the head slots); one fp16 MFMA pass per MLP GEMM.
+ * Not available in the -DINR_MLP_FP32 build.                                                                      */
+int inr_instance_pack_weights_f16(const float* w0, const float* w1, const float* w2, int32_t K, float* packed /*host*/);
+int inr_instance_render_fast(const float* xyzs, const int32_t* rays, const float* weights, int64_t N, int64_t M,
+                             float bound, const void* embeddings_half, const inr_grid_desc* desc /*host*/,
+                             const float* packed_f16 /*device*/, int32_t K, float* extra_out, int32_t x_is_01,
+                             uint64_t* cursors /*device [32], zeroed by the caller*/, inr_stream_t s);
 
 /* ---- weight gradient of the tiny bias-free MLP layers (replaces the BLAS call autograd makes for
  * nn.Linear in NeRFNetwork, a9/a13):  grad_w[o][i] += sum_m grad_y[m][o] * x[m][i],  n_in, n_out <= 64.

@@ -104,7 +104,11 @@ _SIGS = {
                                             c_int32, c_int32, c_float, P, P]),
     "inr_nerf_render": (c_int32, [P, P, P, P, c_int64, c_int64, c_float, P, POINTER(GridDesc), P, c_float, c_float,
                                   P, P, P, P, P, c_int32, P]),
+    "inr_nerf_render_fast": (c_int32, [P, P, P, P, c_int64, c_int64, c_float, P, POINTER(GridDesc), P, c_float, c_float,
+                                  P, P, P, P, P, c_int32, P]),
     "inr_instance_render": (c_int32, [P, P, P, c_int64, c_int64, c_float, P, POINTER(GridDesc), P, c_int32, P, c_int32, P, P]),
+    "inr_instance_render_fast": (c_int32, [P, P, P, c_int64, c_int64, c_float, P, POINTER(GridDesc), P, c_int32, P, c_int32, P, P]),
+    "inr_instance_pack_weights_f16": (c_int32, [P, P, P, c_int32, P]),
     "inr_linear_wgrad_workspace_bytes": (c_int64, []),
     "inr_linear_wgrad": (c_int32, [P, P, c_int64, c_int32, c_int32, P, P, P]),
     "inr_adam_step": (c_int32, [P, P, P, P, c_int64, c_float, c_float, c_float, c_float, c_int32, c_float, P]),

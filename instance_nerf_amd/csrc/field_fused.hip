@@ -1549,7 +1549,8 @@ __global__ void __launch_bounds__(256) k_pack_weights(PackJobs jobs, float* __re
 // (waves 0..3 add up and store group g while waves 4..7 already run group g + 1).  Steps where every live ray of the
 // group has w == 0 (behind the termination point) skip the gather and the MLP.  x_is_01: the march writer already
 // normalised the coordinates (table feed).
-template <int K_MT>
+// kO: upstream's -O numerics (opt-in) - the table is the fp16 copy and the MLP GEMMs take one fp16 MFMA pass.
+template <int K_MT, bool kO = false>
 __global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_instance_render(
     const float* __restrict__ x, const int32_t* __restrict__ rays, const float* __restrict__ wbuf, int64_t N, int64_t M,
     float bound, const float2* __restrict__ emb, uint32_t emb_bytes, GridDesc G, const float4* __restrict__ packed,
@@ -1618,19 +1619,19 @@ __global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_instance_rend
           Gathered g;
           uint32_t rec_off = (uint32_t)q * 4u * (uint32_t)sizeof(LevelRec);
           asm volatile("" : "+v"(rec_off));
-          issue_gathers(reinterpret_cast<const LevelRec*>(reinterpret_cast<const char*>(recs) + rec_off), all_hashed, rsrc,
-                        p0, p1, p2, g);
+          issue_gathers<kO>(reinterpret_cast<const LevelRec*>(reinterpret_cast<const char*>(recs) + rec_off), all_hashed,
+                            rsrc, p0, p1, p2, g);
           __builtin_amdgcn_sched_barrier(0);
-          blend(g, enc[0], enc[1]);
+          blend<kO>(g, enc[0], enc[1]);
         }
         f32x4 h1[4], h2[4], o[K_MT];
-        mlp_layer<4, 2>(wl + kIns0 / 4, lane, enc, h1);
+        mlp_layer<4, 2, kO>(wl + kIns0 / 4, lane, enc, h1);
 #pragma unroll
         for (int t = 0; t < 4; ++t) h1[t] = relu4(h1[t]);
-        mlp_layer<4, 4>(wl + kIns1 / 4, lane, h1, h2);
+        mlp_layer<4, 4, kO>(wl + kIns1 / 4, lane, h1, h2);
 #pragma unroll
         for (int t = 0; t < 4; ++t) h2[t] = relu4(h2[t]);
-        mlp_layer<K_MT, 4>(wl + kIns2 / 4, lane, h2, o);
+        mlp_layer<K_MT, 4, kO>(wl + kIns2 / 4, lane, h2, o);
 #pragma unroll
         for (int mt = 0; mt < K_MT; ++mt) {
           acc[mt][0] = fmaf(w, o[mt][0], acc[mt][0]); acc[mt][1] = fmaf(w, o[mt][1], acc[mt][1]);
@@ -1673,6 +1674,7 @@ __global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_instance_rend
 //  ms (10.2 M instead of 0.6 M samples evaluated), half-trained scene 15.3 vs 17.1 ms with the two-kernel path at 13.6.
 //  There is no skippable fraction at which it is the best of the three paths - profiles/r03_NOTES.txt 8 - so the
 //  wave-owned kernel stays.)
+template <bool kO = false>      // kO: upstream's -O numerics (opt-in) - fp16 table copy, one fp16 MFMA pass per MLP GEMM
 __global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_nerf_render(
     const float* __restrict__ x, const float* __restrict__ deltas, const int32_t* __restrict__ rays,
     const float* __restrict__ rays_d, int64_t N, int64_t M, float bound, const float2* __restrict__ emb,
@@ -1774,26 +1776,26 @@ __global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_nerf_render(
         Gathered g;
         uint32_t rec_off = (uint32_t)q * 4u * (uint32_t)sizeof(LevelRec);
         asm volatile("" : "+v"(rec_off));
-        issue_gathers(reinterpret_cast<const LevelRec*>(reinterpret_cast<const char*>(recs) + rec_off), all_hashed, rsrc,
-                      x0, x1, x2, g);
+        issue_gathers<kO>(reinterpret_cast<const LevelRec*>(reinterpret_cast<const char*>(recs) + rec_off), all_hashed, rsrc,
+                          x0, x1, x2, g);
         __builtin_amdgcn_sched_barrier(0);
-        blend(g, enc[0], enc[1]);
+        blend<kO>(g, enc[0], enc[1]);
       }
       f32x4 h1[4], h2[1];
-      mlp_layer<4, 2>(wl + kSig0 / 4, lane, enc, h1);
+      mlp_layer<4, 2, kO>(wl + kSig0 / 4, lane, enc, h1);
 #pragma unroll
       for (int t = 0; t < 4; ++t) h1[t] = relu4(h1[t]);
-      mlp_layer<1, 4>(wl + kSig1 / 4, lane, h1, h2);
+      mlp_layer<1, 4, kO>(wl + kSig1 / 4, lane, h1, h2);
       f32x4 cin[2], c1[4], c2[4], o[1];
       cin[0] = cin0;
       cin[1] = h2[0];
-      mlp_layer<4, 2>(wl + kCol0 / 4, lane, cin, c1);
+      mlp_layer<4, 2, kO>(wl + kCol0 / 4, lane, cin, c1);
 #pragma unroll
       for (int t = 0; t < 4; ++t) c1[t] = relu4(c1[t]);
-      mlp_layer<4, 4>(wl + kCol1 / 4, lane, c1, c2);
+      mlp_layer<4, 4, kO>(wl + kCol1 / 4, lane, c1, c2);
 #pragma unroll
       for (int t = 0; t < 4; ++t) c2[t] = relu4(c2[t]);
-      mlp_layer<1, 4>(wl + kCol2 / 4, lane, c2, o);
+      mlp_layer<1, 4, kO>(wl + kCol2 / 4, lane, c2, o);
       if (q == 0 && active) {
         float w = 0.0f;
         if (live) {
@@ -2389,9 +2391,45 @@ int inr_nerf_backward(const float* grad_sigma, const float* grad_rgb, const floa
   return check_launch("nerf_backward");
 }
 
+static int instance_render_impl(const float* xyzs, const int32_t* rays, const float* weights, int64_t N, int64_t M,
+                                float bound, const void* embeddings, bool fast, const inr_grid_desc* desc,
+                                const float* packed, int32_t K, float* extra_out, int32_t x_is_01, uint64_t* cursors,
+                                inr_stream_t s);
+
 int inr_instance_render(const float* xyzs, const int32_t* rays, const float* weights, int64_t N, int64_t M, float bound,
                         const float* embeddings, const inr_grid_desc* desc, const float* packed, int32_t K,
                         float* extra_out, int32_t x_is_01, uint64_t* cursors, inr_stream_t s) {
+  return instance_render_impl(xyzs, rays, weights, N, M, bound, embeddings, false, desc, packed, K, extra_out, x_is_01,
+                              cursors, s);
+}
+
+int inr_instance_render_fast(const float* xyzs, const int32_t* rays, const float* weights, int64_t N, int64_t M, float bound,
+                             const void* embeddings_half, const inr_grid_desc* desc, const float* packed_f16, int32_t K,
+                             float* extra_out, int32_t x_is_01, uint64_t* cursors, inr_stream_t s) {
+#if INR_MLP_FP32
+  (void)xyzs; (void)rays; (void)weights; (void)N; (void)M; (void)bound; (void)embeddings_half; (void)desc;
+  (void)packed_f16; (void)K; (void)extra_out; (void)x_is_01; (void)cursors; (void)s;
+  set_error("instance_render_fast: not available in the exact-fp32 build");
+  return INR_EINVAL;
+#else
+  return instance_render_impl(xyzs, rays, weights, N, M, bound, embeddings_half, true, desc, packed_f16, K, extra_out,
+                              x_is_01, cursors, s);
+#endif
+}
+
+int inr_instance_pack_weights_f16(const float* w0, const float* w1, const float* w2, int32_t K, float* packed) {
+  INR_REQUIRE(w0 && w1 && w2 && packed, "null pointer");
+  INR_REQUIRE(K > 0 && K <= 64 && K % 16 == 0, "K must be 16, 32, 48 or 64");
+  pack_section_f16(packed + kIns0, w0, 64, 32, 4, 8, kidx_enc);
+  pack_section_f16(packed + kIns1, w1, 64, 64, 4, 16, kidx_hidden);
+  pack_section_f16(packed + kIns2, w2, K, 64, K / 16, 16, kidx_hidden);
+  return INR_OK;
+}
+
+static int instance_render_impl(const float* xyzs, const int32_t* rays, const float* weights, int64_t N, int64_t M,
+                                float bound, const void* embeddings, bool fast, const inr_grid_desc* desc,
+                                const float* packed, int32_t K, float* extra_out, int32_t x_is_01, uint64_t* cursors,
+                                inr_stream_t s) {
   INR_REQUIRE(N >= 0 && M >= 0 && desc, "bad argument");
   if (N == 0) return INR_OK;
   INR_REQUIRE(rays && embeddings && packed && extra_out && cursors && ((uintptr_t)cursors & 7) == 0, "null pointer");
@@ -2406,7 +2444,7 @@ int inr_instance_render(const float* xyzs, const int32_t* rays, const float* wei
   const float4* p = reinterpret_cast<const float4*>(packed);
   const uint64_t emb_bytes64 = (uint64_t)desc->offsets[desc->num_levels] * 8ull;
   INR_REQUIRE(emb_bytes64 < (1ull << 31), "table larger than 2 GiB is not addressable by the 32-bit gather offsets");
-  const uint32_t eb = (uint32_t)emb_bytes64;
+  const uint32_t eb = (uint32_t)(fast ? emb_bytes64 / 2 : emb_bytes64);
   // weights + level records + two buffers of eight partial [16 rays x K] sums
   const size_t lds = (size_t)(kIns2 + K * 64) * sizeof(float) + kLevelRecBytes + 2 * (kFieldThreads / 64) * (size_t)K * 64;
   const int64_t n_groups = (N + 15) / 16;
@@ -2414,19 +2452,71 @@ int inr_instance_render(const float* xyzs, const int32_t* rays, const float* wei
   INR_REQUIRE(n_groups < ((int64_t)1 << 31) - 65536, "too many rays for the 32-bit group cursor");
   unsigned long long* cur = reinterpret_cast<unsigned long long*>(cursors);
   hipStream_t st = as_stream(s);
+#define INR_IR_LAUNCH(KMT, O)                                                                                         \
+  k_instance_render<KMT, O><<<grid_for(k_instance_render<KMT, O>, lds, as_tiles), kFieldThreads, lds, st>>>(              \
+      xyzs, rays, weights, N, M, bound, e, eb, G, p, extra_out, x_is_01, cur)
+#if INR_MLP_FP32
+  (void)fast;
   switch (K / 16) {
-    case 1: k_instance_render<1><<<grid_for(k_instance_render<1>, lds, as_tiles), kFieldThreads, lds, st>>>(xyzs, rays, weights, N, M, bound, e, eb, G, p, extra_out, x_is_01, cur); break;
-    case 2: k_instance_render<2><<<grid_for(k_instance_render<2>, lds, as_tiles), kFieldThreads, lds, st>>>(xyzs, rays, weights, N, M, bound, e, eb, G, p, extra_out, x_is_01, cur); break;
-    case 3: k_instance_render<3><<<grid_for(k_instance_render<3>, lds, as_tiles), kFieldThreads, lds, st>>>(xyzs, rays, weights, N, M, bound, e, eb, G, p, extra_out, x_is_01, cur); break;
-    default: k_instance_render<4><<<grid_for(k_instance_render<4>, lds, as_tiles), kFieldThreads, lds, st>>>(xyzs, rays, weights, N, M, bound, e, eb, G, p, extra_out, x_is_01, cur); break;
+    case 1: INR_IR_LAUNCH(1, false); break;
+    case 2: INR_IR_LAUNCH(2, false); break;
+    case 3: INR_IR_LAUNCH(3, false); break;
+    default: INR_IR_LAUNCH(4, false); break;
   }
+#else
+  if (fast) {
+    switch (K / 16) {
+      case 1: INR_IR_LAUNCH(1, true); break;
+      case 2: INR_IR_LAUNCH(2, true); break;
+      case 3: INR_IR_LAUNCH(3, true); break;
+      default: INR_IR_LAUNCH(4, true); break;
+    }
+  } else {
+    switch (K / 16) {
+      case 1: INR_IR_LAUNCH(1, false); break;
+      case 2: INR_IR_LAUNCH(2, false); break;
+      case 3: INR_IR_LAUNCH(3, false); break;
+      default: INR_IR_LAUNCH(4, false); break;
+    }
+  }
+#endif
+#undef INR_IR_LAUNCH
   return check_launch("instance_render");
 }
+
+static int nerf_render_impl(const float* xyzs, const float* deltas, const int32_t* rays, const float* rays_d, int64_t N,
+                            int64_t M, float bound, const void* embeddings, bool fast, const inr_grid_desc* desc,
+                            const float* packed, float density_scale, float T_thresh, float* weights_sum, float* depth,
+                            float* image, float* weights, uint64_t* evaluated, int32_t x_is_01, inr_stream_t s);
 
 int inr_nerf_render(const float* xyzs, const float* deltas, const int32_t* rays, const float* rays_d, int64_t N,
                     int64_t M, float bound, const float* embeddings, const inr_grid_desc* desc, const float* packed,
                     float density_scale, float T_thresh, float* weights_sum, float* depth, float* image, float* weights,
                     uint64_t* evaluated, int32_t x_is_01, inr_stream_t s) {
+  return nerf_render_impl(xyzs, deltas, rays, rays_d, N, M, bound, embeddings, false, desc, packed, density_scale, T_thresh,
+                          weights_sum, depth, image, weights, evaluated, x_is_01, s);
+}
+
+int inr_nerf_render_fast(const float* xyzs, const float* deltas, const int32_t* rays, const float* rays_d, int64_t N,
+                         int64_t M, float bound, const void* embeddings_half, const inr_grid_desc* desc,
+                         const float* packed_f16, float density_scale, float T_thresh, float* weights_sum, float* depth,
+                         float* image, float* weights, uint64_t* evaluated, int32_t x_is_01, inr_stream_t s) {
+#if INR_MLP_FP32
+  (void)xyzs; (void)deltas; (void)rays; (void)rays_d; (void)N; (void)M; (void)bound; (void)embeddings_half; (void)desc;
+  (void)packed_f16; (void)density_scale; (void)T_thresh; (void)weights_sum; (void)depth; (void)image; (void)weights;
+  (void)evaluated; (void)x_is_01; (void)s;
+  set_error("nerf_render_fast: not available in the exact-fp32 build");
+  return INR_EINVAL;
+#else
+  return nerf_render_impl(xyzs, deltas, rays, rays_d, N, M, bound, embeddings_half, true, desc, packed_f16, density_scale,
+                          T_thresh, weights_sum, depth, image, weights, evaluated, x_is_01, s);
+#endif
+}
+
+static int nerf_render_impl(const float* xyzs, const float* deltas, const int32_t* rays, const float* rays_d, int64_t N,
+                            int64_t M, float bound, const void* embeddings, bool fast, const inr_grid_desc* desc,
+                            const float* packed, float density_scale, float T_thresh, float* weights_sum, float* depth,
+                            float* image, float* weights, uint64_t* evaluated, int32_t x_is_01, inr_stream_t s) {
   INR_REQUIRE(N >= 0 && M >= 0 && desc, "bad argument");
   if (N == 0) return INR_OK;
   INR_REQUIRE(rays && rays_d && embeddings && packed && weights_sum && depth && image && evaluated, "null pointer");
@@ -2441,7 +2531,17 @@ int inr_nerf_render(const float* xyzs, const float* deltas, const int32_t* rays,
   const size_t lds = kNerfFloats * sizeof(float) + kLevelRecBytes;
   const int64_t n_groups = (N + 15) / 16;
   INR_REQUIRE(n_groups < ((int64_t)1 << 31) - 65536, "too many rays for the 32-bit group cursor");
-  k_nerf_render<<<grid_for(k_nerf_render, lds, n_groups), kFieldThreads, lds, as_stream(s)>>>(
+#if !INR_MLP_FP32
+  if (fast) {
+    k_nerf_render<true><<<grid_for(k_nerf_render<true>, lds, n_groups), kFieldThreads, lds, as_stream(s)>>>(
+        xyzs, deltas, rays, rays_d, N, M, bound, reinterpret_cast<const float2*>(embeddings), (uint32_t)(emb_bytes64 / 2), G,
+        reinterpret_cast<const float4*>(packed), density_scale, T_thresh, weights_sum, depth, image, weights,
+        reinterpret_cast<unsigned long long*>(evaluated), x_is_01);
+    return check_launch("nerf_render_fast");
+  }
+#endif
+  (void)fast;
+  k_nerf_render<false><<<grid_for(k_nerf_render<false>, lds, n_groups), kFieldThreads, lds, as_stream(s)>>>(
       xyzs, deltas, rays, rays_d, N, M, bound, reinterpret_cast<const float2*>(embeddings), (uint32_t)emb_bytes64, G,
       reinterpret_cast<const float4*>(packed), density_scale, T_thresh, weights_sum, depth, image, weights,
       reinterpret_cast<unsigned long long*>(evaluated), x_is_01);

@@ -421,6 +421,7 @@ class NeRFNetwork(NeRFRenderer):
         # arithmetic, blending and the MLPs stay fp32.  Outputs differ from the fp32 table's by ~1e-3 relative.
         self.half_table = False
         self._half_cache = None
+        self._half_cache_inst = None
         # Opt-in, the other half of `-O`: full-frame inference runs the MLP GEMMs as ONE fp16 MFMA pass (weights and
         # activations rounded to fp16, fp32 accumulation) instead of the three-pass bf16 split that keeps the default
         # fp32-class.  Outputs within a few 1e-3 of the default's; training and every other path are unaffected.
@@ -432,14 +433,14 @@ class NeRFNetwork(NeRFRenderer):
         if which in ("nerf", "nerf_f16"):
             ws = [self.sigma_net[0].weight, self.sigma_net[1].weight, self.color_net[0].weight,
                   self.color_net[1].weight, self.color_net[2].weight]
-        else:
+        else:                                  # "instance", "instance_f16"
             ws = [l.weight for l in self.instance_net]
         key = tuple((w.data_ptr(), w._version) for w in ws)
         hit = self._packed.get(which)
         if hit is not None and hit[0] == key:
             return hit[1]
         host = [w.detach().float().cpu().contiguous() for w in ws]
-        if which == "instance" and self._k_pad != self.num_instances:
+        if which.startswith("instance") and self._k_pad != self.num_instances:
             host[2] = torch.nn.functional.pad(host[2], (0, 0, 0, self._k_pad - self.num_instances)).contiguous()
         if which in ("nerf", "nerf_f16"):
             buf = torch.empty(lib.inr_nerf_packed_floats(), dtype=torch.float32)
@@ -447,8 +448,9 @@ class NeRFNetwork(NeRFRenderer):
             check(pack(*[host_ptr(h, torch.float32) for h in host], host_ptr(buf, torch.float32)), "nerf_pack_weights")
         else:
             buf = torch.empty(lib.inr_instance_packed_floats(self._k_pad), dtype=torch.float32)
-            check(lib.inr_instance_pack_weights(*[host_ptr(h, torch.float32) for h in host], self._k_pad,
-                                                host_ptr(buf, torch.float32)), "instance_pack_weights")
+            pack = lib.inr_instance_pack_weights if which == "instance" else lib.inr_instance_pack_weights_f16
+            check(pack(*[host_ptr(h, torch.float32) for h in host], self._k_pad, host_ptr(buf, torch.float32)),
+                  "instance_pack_weights")
         dev = buf.to(ws[0].device)
         self._packed[which] = (key, dev)
         return dev
@@ -673,13 +675,18 @@ class NeRFNetwork(NeRFRenderer):
         image = torch.empty(N, 3, dtype=torch.float32, device=dev)
         wbuf = torch.empty(max(M, 1), dtype=torch.float32, device=dev) if want_weights else None
         evaluated = torch.zeros(33, dtype=torch.int64, device=dev)     # [0] evaluated samples, [1..32] the launch's group cursors
-        check(lib.inr_nerf_render(ptr(xyzs, torch.float32, "xyzs", allow_none=M == 0),
-                                  ptr(deltas, torch.float32, "deltas", allow_none=M == 0), ptr(rays, torch.int32, "rays"),
-                                  ptr(rays_d.contiguous(), torch.float32, "rays_d"), N, M, float(self.bound),
-                                  ptr(self.encoder.embeddings.data, torch.float32), self.encoder.desc,
-                                  ptr(self._packed_weights("nerf")), float(self.density_scale), float(T_thresh),
-                                  ptr(ws), ptr(depth), ptr(image), ptr(wbuf, allow_none=True), ptr(evaluated),
-                                  1 if normalised else 0, stream_ptr()), "nerf_render")
+        fn, table, packed = lib.inr_nerf_render, self.encoder.embeddings.data, "nerf"
+        if self.half_table and self.mlp_fp16 and not self.training:        # opt-in: upstream's -O numerics
+            emb = self.encoder.embeddings
+            key = (emb.data_ptr(), emb._version)
+            if self._half_cache is None or self._half_cache[0] != key:
+                self._half_cache = (key, emb.detach().to(torch.float16).contiguous())
+            fn, table, packed = lib.inr_nerf_render_fast, self._half_cache[1], "nerf_f16"
+        check(fn(ptr(xyzs, torch.float32, "xyzs", allow_none=M == 0), ptr(deltas, torch.float32, "deltas", allow_none=M == 0),
+                 ptr(rays, torch.int32, "rays"), ptr(rays_d.contiguous(), torch.float32, "rays_d"), N, M, float(self.bound),
+                 ptr(table), self.encoder.desc, ptr(self._packed_weights(packed)), float(self.density_scale),
+                 float(T_thresh), ptr(ws), ptr(depth), ptr(image), ptr(wbuf, allow_none=True), ptr(evaluated),
+                 1 if normalised else 0, stream_ptr()), "nerf_render")
         return ws, depth, image, wbuf, evaluated[:1]
 
     @torch.no_grad()
@@ -693,6 +700,19 @@ class NeRFNetwork(NeRFRenderer):
         N, M = rays.shape[0], xyzs.shape[0]
         out = torch.empty(N, self._k_pad, dtype=torch.float32, device=rays.device)
         cursors = torch.zeros(32, dtype=torch.int64, device=rays.device)        # the launch's dynamic group schedule
+        if self.half_table and self.mlp_fp16 and not self.training:
+            # opt-in, upstream's -O numerics for the instance field too: fp16 copy of its table, one-pass fp16 MLP
+            emb = self.instance_encoder.embeddings
+            key = (emb.data_ptr(), emb._version)
+            if self._half_cache_inst is None or self._half_cache_inst[0] != key:
+                self._half_cache_inst = (key, emb.detach().to(torch.float16).contiguous())
+            check(lib.inr_instance_render_fast(ptr(xyzs, torch.float32, "xyzs", allow_none=M == 0), ptr(rays, torch.int32, "rays"),
+                                               ptr(weights, torch.float32, "weights", allow_none=M == 0), N, M,
+                                               float(self.bound), ptr(self._half_cache_inst[1], torch.float16),
+                                               self.instance_encoder.desc, ptr(self._packed_weights("instance_f16")),
+                                               self._k_pad, ptr(out), 1 if normalised else 0, ptr(cursors), stream_ptr()),
+                  "instance_render_fast")
+            return out if self._k_pad == self.num_instances else out[:, :self.num_instances].contiguous()
         check(lib.inr_instance_render(ptr(xyzs, torch.float32, "xyzs", allow_none=M == 0), ptr(rays, torch.int32, "rays"),
                                       ptr(weights, torch.float32, "weights", allow_none=M == 0), N, M, float(self.bound),
                                       ptr(self.instance_encoder.embeddings.data, torch.float32),

@@ -511,6 +511,19 @@ def test_single_pass_fp16_mlp_is_the_opt_in_fast_path(level_table, room, room_bi
         psnr = -10 * np.log10(float((d ** 2).mean()))
         print(f"fp16 MLP, half table {half}: max abs {float(d.max()):.2e}, {psnr:.1f} dB")
         assert 0 < float(d.max()) < (6e-3 if half else 3e-3) and psnr > 50, (half, float(d.max()), psnr)
+    # the early-terminating kernel takes the same numerics when both options are on (density x300: rays do terminate)
+    net.half_table = net.mlp_fp16 = False
+    net.density_scale = 300.0
+    with torch.no_grad():
+        t_full = net.render(r["rays_o"], r["rays_d"], bg_color=1, infer_mode="fused_terminate")
+        net.half_table = net.mlp_fp16 = True
+        t_fast = net.render(r["rays_o"], r["rays_d"], bg_color=1, infer_mode="fused_terminate")
+        two = net.render(r["rays_o"], r["rays_d"], bg_color=1, infer_mode="fused")
+    assert "num_evaluated" in t_fast and int(t_fast["num_evaluated"][0]) < int(t_fast["num_samples"][0])
+    d = float((t_fast["image"] - t_full["image"]).abs().max())
+    assert 0 < d < 3e-3, d
+    assert float((t_fast["image"] - two["image"]).abs().max()) < 2e-4       # both -O paths agree up to T_thresh effects
+    net.density_scale = 1.0
     net.half_table = net.mlp_fp16 = False
     assert torch.equal(frame()["image"], full["image"])
     net.mlp_fp16 = True
@@ -521,6 +534,33 @@ def test_single_pass_fp16_mlp_is_the_opt_in_fast_path(level_table, room, room_bi
     with torch.no_grad():
         b = net.render(r["rays_o"][:, :256], r["rays_d"][:, :256], bg_color=1, perturb=False, force_all_rays=True)["image"]
     assert torch.equal(a, b)                           # the training path never takes the fast kernel
+
+
+def test_instance_render_with_O_numerics(level_table, room, room_bitfield):
+    """half_table + mlp_fp16 on a network with an instance head: the rendered logits come from k_instance_render<K, true>
+    (fp16 copy of the instance table, one fp16 MFMA pass per layer) - same samples, logits within 2e-3 of the default
+    path's relative to their size and not identical; K = 64 and a padded K = 20."""
+    from instance_nerf_amd.nerf.utils import get_rays
+    from oracle import field
+    poses, intr, H, W = room.cameras(n=1, H=64, W=64, focal=32.0)
+    r = get_rays(_t(poses[:1]), intr, 64, 64, patch=4)
+    for K in (64, 20):
+        net = _network(field.init_params(seed=43, table=level_table, table_std=1.0, K=K), K=K).eval()
+        net.density_bitfield.copy_(_t(room_bitfield))
+
+        def frame():
+            with torch.no_grad():
+                return net.render(r["rays_o"], r["rays_d"], bg_color=1, infer_mode="fused")
+        full = frame()
+        net.half_table = net.mlp_fp16 = True
+        fast = frame()
+        assert fast["instance"].shape == full["instance"].shape == (1, 64 * 64, K)
+        assert int(fast["num_samples"][0]) == int(full["num_samples"][0])
+        d = float((fast["instance"] - full["instance"]).abs().max())
+        scale = float(full["instance"].abs().max())
+        assert 0 < d < 2e-3 * scale, (K, d, scale)
+        net.half_table = net.mlp_fp16 = False
+        assert torch.equal(frame()["instance"], full["instance"])
 
 
 def test_exact_fp32_mlp_build(params_k16):
