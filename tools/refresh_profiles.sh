@@ -26,3 +26,5 @@ bash tools/pmc_train.sh ${TAG}_pmct > $O/pmc_train.txt 2>&1; tail -25 $O/pmc_tra
 python tools/step_launches.py $O/trace_inst > $O/launches_inst.txt 2>&1
 python tools/step_launches.py $O/trace_nerf > $O/launches_nerf.txt 2>&1
 ls $O
+python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; tail -1 $O/smoke.txt
+python bench.py --pipeline-probe --no-cpu-baseline --no-train-probe --no-trained-scene > $O/bench_pipeline_probe.json 2>/dev/null
