@@ -195,10 +195,14 @@ def train_probe(dev, rank=0, world=1, red_dev=None, steps=20, warmup=5, stage="i
     gc.disable()
     barrier()
     t0 = time.perf_counter()
+    stamps = [t0]
     for i in range(steps):
         last = tr.train_one_step(batches[i % 4])
         torch.clamp(net.step_counter[(net.local_step - 1) % 16, 0], max=net.mean_count, out=per_step[i])
-    host_s = time.perf_counter() - t0      # time the host needed to QUEUE the steps (== elapsed when the host is the limit)
+        stamps.append(time.perf_counter())
+    # the time the host needs to QUEUE a step: the median over the steps (the step with the occupancy update waits for
+    # the device inside its read-back); == ms_per_step when the host is the limit
+    host_s = float(np.median(np.diff(stamps))) * steps
     barrier()
     elapsed = time.perf_counter() - t0
     gc.enable()
