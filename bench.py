@@ -48,6 +48,23 @@ def measured_traffic_bytes_per_sample(res):
     return float(t["read_bytes_per_sample"]) + float(t["write_bytes_per_sample"])
 
 
+SCATTER_JSON = os.path.join("profiles", "r03_scatter_requests.json")
+
+
+def scatter_requests(stage):
+    """Memory-side atomic requests per sample of the table-gradient scatter and the unit's measured rate, from the
+    committed PMC profile (profiles/r03_scatter_requests.json, tools/pmc_train.sh + tools/scatter_requests_json.py);
+    quoted only for the kernel sources it was measured on.  -> (requests per sample, unit rate in requests/s) or None."""
+    from instance_nerf_amd import build
+    path = os.path.join(ROOT, SCATTER_JSON)
+    if not os.path.exists(path):
+        return None
+    t = json.load(open(path))
+    if t.get("source_sha") != build.source_sha():
+        return None
+    return float(t["instance_stage" if stage == "instance" else "nerf_stage"]["requests_per_sample"]), float(t["unit_rate_requests_per_s"])
+
+
 def build_network(dev, seed=0):
     from instance_nerf_amd.nerf import NeRFNetwork
     from instance_nerf_amd.scene import RoomScene
@@ -234,9 +251,21 @@ def train_probe(dev, rank=0, world=1, red_dev=None, steps=20, warmup=5, stage="i
                 "achieved": round(2048 * (n / steps) / (scatter_ms / 1e3) / 1e9, 1) if scatter_ms > 0 else None,
                 "frac": round(2048 * (n / steps) / (scatter_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 4) if scatter_ms > 0 else None,
                 "traffic": None,
+                "atomic_unit": None,
                 "step": {"algorithmic_bytes_per_sample": per_sample, "optimizer_bytes_per_step": adam_bytes,
                          "achieved": round(step_bytes / own_dt / 1e9, 1),
                          "frac": round(step_bytes / own_dt / 1e9 / HBM_PEAK_GBS, 4)}}
+    sr = scatter_requests(stage)
+    if sr is not None and scatter_ms > 0:
+        # what really bounds the scatter: every fp32 atomic is forwarded to the memory side, which takes ~21 G 64-byte
+        # requests per second whatever their width, the table size or the occupancy (profiles/r03_NOTES.txt 1)
+        req = sr[0] * (n / steps)
+        roofline["atomic_unit"] = {"requests_per_sample": sr[0], "requests_per_launch": int(req),
+                                   "achieved_g_requests_per_s": round(req / (scatter_ms / 1e3) / 1e9, 2),
+                                   "peak_g_requests_per_s": round(sr[1] / 1e9, 1),
+                                   "frac": round(req / (scatter_ms / 1e3) / sr[1], 4),
+                                   "source": SCATTER_JSON + " (rocprofv3 PMC on these kernel sources; peak from "
+                                             "tools/micro/atomic_width_bench.hip)"}
     what = ("instance-field training step, K=64, 4096 rays/batch per GPU, NeRF frozen, parameter EMA 0.95 "
             f"(BASELINE configs[{2 if world == 1 else 3}])") if stage == "instance" else \
         "NeRF training step (MSE on rgb: hash table + sigma/colour nets, parameter EMA 0.95), 4096 rays/batch per GPU"

@@ -1,16 +1,17 @@
 #!/bin/bash
 # PMC passes over the instance-stage training step (tools/train_probe.py), summarised for the table-gradient scatter.
 # Each counter group runs in its own process, kernel-trace only, bounded by `timeout`.
-# usage (GPU box, repo root): bash tools/pmc_train.sh <tag> [kernel-substring]
+# usage (GPU box, repo root): bash tools/pmc_train.sh <tag> [kernel-substring] [probe script, default tools/train_probe.py]
 TAG=${1:-pmct}
 KERNEL=${2:-k_grid_bwd}
+PROBE=${3:-tools/train_probe.py}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 export TMPDIR=/tmp
 cd /tmp
 run() {
   name=$1; shift
   timeout 240 rocprofv3 --kernel-trace --output-format csv --pmc "$@" -d $R/gpurun_out/$TAG -o $name -- \
-    python3 $R/tools/train_probe.py 12 > $R/gpurun_out/$TAG.$name.log 2>&1
+    python3 $R/$PROBE 12 > $R/gpurun_out/$TAG.$name.log 2>&1
   echo "$name rc=$? $(tail -1 $R/gpurun_out/$TAG.$name.log)"
 }
 run grbm GRBM_GUI_ACTIVE TCC_CYCLE_sum TCC_BUSY_sum
