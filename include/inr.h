@@ -286,6 +286,13 @@ int inr_nerf_forward(const float* x, const float* d, int64_t M, const int32_t* n
                      float bound, const float* embeddings, const inr_grid_desc* desc /*host*/,
                      const float* packed /*device*/, float density_scale, float* sigma, float* rgb,
                      float* geo_feat, inr_stream_t s);
+/* inr_nerf_forward (sigma + rgb) with upstream's `-O` numerics, opt-in: fp16 copy of the table (T x 2 binary16),
+ * weights from inr_nerf_pack_weights_f16, one fp16 MFMA pass per MLP GEMM.  Used for the FROZEN NeRF of the instance
+ * stage when Trainer(fp16=True) / NeRFNetwork.half_table + mlp_fp16 are set.  Not in the -DINR_MLP_FP32 build.   */
+int inr_nerf_forward_fast(const float* x, const float* d, int64_t M, const int32_t* n_samples_dev, float bound,
+                          const void* embeddings_half, const inr_grid_desc* desc /*host*/,
+                          const float* packed_f16 /*device*/, float density_scale, float* sigma, float* rgb,
+                          inr_stream_t s);
 /* Fused-frame variant of inr_nerf_forward: x01 [M,3] already normalised by inr_march_rays_patch_write
  * (normalise = 1), directions given as a per-sample ray id + the per-ray table of inr_sh_table_q
  * ([N,4,4]: row q holds SH components q, 4+q, 8+q, 12+q).  Same results, ~100 VALU instructions per tile less. */

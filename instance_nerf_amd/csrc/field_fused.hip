@@ -1978,6 +1978,33 @@ int inr_instance_pack_weights(const float* w0, const float* w1, const float* w2,
   return INR_OK;
 }
 
+int inr_nerf_forward_fast(const float* x, const float* d, int64_t M, const int32_t* n_samples_dev, float bound,
+                          const void* embeddings_half, const inr_grid_desc* desc, const float* packed_f16,
+                          float density_scale, float* sigma, float* rgb, inr_stream_t s) {
+#if INR_MLP_FP32
+  (void)x; (void)d; (void)M; (void)n_samples_dev; (void)bound; (void)embeddings_half; (void)desc; (void)packed_f16;
+  (void)density_scale; (void)sigma; (void)rgb; (void)s;
+  set_error("nerf_forward_fast: not available in the exact-fp32 build");
+  return INR_EINVAL;
+#else
+  INR_REQUIRE(M >= 0 && desc, "bad argument");
+  if (M == 0) return INR_OK;
+  INR_REQUIRE(x && d && embeddings_half && packed_f16 && sigma && rgb, "null pointer");
+  INR_REQUIRE(((uintptr_t)embeddings_half & 3) == 0 && ((uintptr_t)packed_f16 & 15) == 0, "embeddings/packed misaligned");
+  GridDesc G;
+  int rc = make_grid_desc(desc, G);
+  if (rc) return rc;
+  const uint64_t emb_bytes64 = (uint64_t)desc->offsets[desc->num_levels] * 4ull;
+  INR_REQUIRE(emb_bytes64 < (1ull << 31), "table larger than 2 GiB is not addressable by the 32-bit gather offsets");
+  const size_t lds = kNerfFloats * sizeof(float) + kLevelRecBytes;
+  const int grid = grid_for(k_nerf_fwd<true, false, 0, true, true>, lds, (M + 15) / 16);
+  k_nerf_fwd<true, false, 0, true, true><<<grid, kFieldThreads, lds, as_stream(s)>>>(
+      x, d, M, n_samples_dev, bound, reinterpret_cast<const float2*>(embeddings_half), (uint32_t)emb_bytes64, G,
+      reinterpret_cast<const float4*>(packed_f16), density_scale, sigma, rgb, nullptr, nullptr, nullptr, NerfSave{});
+  return check_launch("nerf_forward_fast");
+#endif
+}
+
 int inr_nerf_forward(const float* x, const float* d, int64_t M, const int32_t* n_samples_dev, float bound,
                      const float* embeddings, const inr_grid_desc* desc, const float* packed, float density_scale,
                      float* sigma, float* rgb, float* geo_feat, inr_stream_t s) {

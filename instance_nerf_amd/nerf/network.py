@@ -455,6 +455,14 @@ class NeRFNetwork(NeRFRenderer):
         self._packed[which] = (key, dev)
         return dev
 
+    def _half_table(self):
+        """fp16 copy of the NeRF table (the opt-in -O paths), refreshed whenever the fp32 master changes."""
+        emb = self.encoder.embeddings
+        key = (emb.data_ptr(), emb._version)
+        if self._half_cache is None or self._half_cache[0] != key:
+            self._half_cache = (key, emb.detach().to(torch.float16).contiguous())
+        return self._half_cache[1]
+
     def _needs_grad(self, params):
         return torch.is_grad_enabled() and any(p.requires_grad for p in params)
 
@@ -471,6 +479,15 @@ class NeRFNetwork(NeRFRenderer):
         geo = torch.empty(M, self.geo_feat_dim, dtype=torch.float32, device=dev) if want_geo else None
         if want_rgb:
             d = d.contiguous().float()
+        if (want_rgb and not want_geo and self.half_table and self.mlp_fp16
+                and (not self.training or not self.encoder.embeddings.requires_grad)):
+            # opt-in -O numerics for a NeRF that is only evaluated: inference, and the FROZEN NeRF of the instance stage
+            # (its forward is bound by every XCD pulling the whole table through its fabric port: half the bytes)
+            check(lib.inr_nerf_forward_fast(ptr(x, torch.float32, "x"), ptr(d, torch.float32, "d"), M, None, float(self.bound),
+                                            ptr(self._half_table(), torch.float16), self.encoder.desc,
+                                            ptr(self._packed_weights("nerf_f16")), 1.0, ptr(sigma), ptr(rgb), stream_ptr()),
+                  "nerf_forward_fast")
+            return sigma, rgb, geo
         check(lib.inr_nerf_forward(ptr(x, torch.float32, "x"), ptr(d, torch.float32, "d", allow_none=not want_rgb),
                                    M, None, float(self.bound), ptr(self.encoder.embeddings.data, torch.float32),
                                    self.encoder.desc, ptr(self._packed_weights("nerf")), 1.0, ptr(sigma),
@@ -506,10 +523,7 @@ class NeRFNetwork(NeRFRenderer):
         if half:
             # opt-in (upstream's -O / fp16 storage): the eval kernel gathers from a half-precision copy of the table,
             # refreshed whenever the fp32 master changes
-            emb = self.encoder.embeddings
-            key = (emb.data_ptr(), emb._version)
-            if self._half_cache is None or self._half_cache[0] != key:
-                self._half_cache = (key, emb.detach().to(torch.float16).contiguous())
+            self._half_table()
         if self.mlp_fp16 and not self.training:
             # opt-in (the other half of upstream's -O): one fp16 MFMA pass per MLP GEMM instead of the fp32-class split
             table = self._half_cache[1] if half else self.encoder.embeddings.data
@@ -677,11 +691,7 @@ class NeRFNetwork(NeRFRenderer):
         evaluated = torch.zeros(33, dtype=torch.int64, device=dev)     # [0] evaluated samples, [1..32] the launch's group cursors
         fn, table, packed = lib.inr_nerf_render, self.encoder.embeddings.data, "nerf"
         if self.half_table and self.mlp_fp16 and not self.training:        # opt-in: upstream's -O numerics
-            emb = self.encoder.embeddings
-            key = (emb.data_ptr(), emb._version)
-            if self._half_cache is None or self._half_cache[0] != key:
-                self._half_cache = (key, emb.detach().to(torch.float16).contiguous())
-            fn, table, packed = lib.inr_nerf_render_fast, self._half_cache[1], "nerf_f16"
+            fn, table, packed = lib.inr_nerf_render_fast, self._half_table(), "nerf_f16"
         check(fn(ptr(xyzs, torch.float32, "xyzs", allow_none=M == 0), ptr(deltas, torch.float32, "deltas", allow_none=M == 0),
                  ptr(rays, torch.int32, "rays"), ptr(rays_d.contiguous(), torch.float32, "rays_d"), N, M, float(self.bound),
                  ptr(table), self.encoder.desc, ptr(self._packed_weights(packed)), float(self.density_scale),

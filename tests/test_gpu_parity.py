@@ -563,6 +563,43 @@ def test_instance_render_with_O_numerics(level_table, room, room_bitfield):
         assert torch.equal(frame()["instance"], full["instance"])
 
 
+def test_frozen_nerf_of_the_instance_stage_takes_O_numerics_when_asked(level_table, room, room_bitfield):
+    """half_table + mlp_fp16 also cover a NeRF that is only EVALUATED during training - the frozen NeRF of the instance
+    stage (inr_nerf_forward_fast) - and nothing that is trained: instance-stage renders move by a little (and the
+    instance gradients with them), NeRF-stage training renders and gradients keep their bits."""
+    from oracle import field
+    p = field.init_params(seed=47, table=level_table, table_std=1.0, K=16)
+    ro, rd = scene_rays(room, 600, cam=2, seed=61)
+    labels = _t(np.random.default_rng(3).integers(-1, 16, size=(1, 600))).long()
+
+    def run(stage, flags):
+        net = _network({k: v.clone() for k, v in p.items()}, K=16).train()
+        net.density_bitfield.copy_(_t(room_bitfield))
+        net.half_table = net.mlp_fp16 = flags
+        if stage == "instance":
+            net.freeze_nerf()
+            out = net.render(_t(ro)[None], _t(rd)[None], bg_color=1, perturb=False, force_all_rays=True, ce_labels=labels)
+            out["instance_ce"].backward()
+        else:
+            out = net.render(_t(ro)[None], _t(rd)[None], bg_color=1, perturb=False, force_all_rays=True)
+            (out["image"] ** 2).mean().backward()
+        grads = {k: q.grad.clone() for k, q in net.named_parameters() if q.grad is not None}
+        return out["image"].detach().clone(), grads
+    img_a, ga = run("instance", False)
+    img_b, gb = run("instance", True)
+    d = float((img_a - img_b).abs().max())
+    assert 0 < d < 3e-3, d
+    for k in ga:
+        rel = float(torch.linalg.norm(ga[k] - gb[k]) / torch.linalg.norm(ga[k]))
+        assert rel < 2e-2, (k, rel)
+    img_c, gc = run("nerf", False)
+    img_d, gd = run("nerf", True)
+    assert torch.equal(img_c, img_d)
+    for k in gc:
+        rel = float(torch.linalg.norm(gc[k] - gd[k]) / torch.linalg.norm(gc[k]))
+        assert rel < 2e-5, (k, rel)              # the scatter's atomics round in launch order; nothing else differs
+
+
 def test_exact_fp32_mlp_build(params_k16):
     """The -DINR_MLP_FP32=1 build (MLP GEMMs on v_mfma_f32_16x16x4_f32, exact fp32 products) stays alive: the same
     golden field vectors through libinr_hip_fp32.so in a child process (a process binds one library).  Both builds

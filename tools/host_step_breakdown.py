@@ -17,6 +17,8 @@ ds = SyntheticRoomDataset(dev, num_rays=4096, num_instances=64)
 net.density_bitfield.copy_(torch.from_numpy(ds.room.density_bitfield(128, 1.0)).to(dev))
 tr = Trainer("probe", None, net, stage=stage, device=dev, iters=1000, update_extra_interval=10 ** 9, ema_decay=0.95)
 tr.global_step = 1
+if os.environ.get("O_FLAGS", "0") == "1":      # upstream's -O numerics where a field is only evaluated (frozen NeRF)
+    net.half_table = net.mlp_fp16 = True
 batches = [ds.batch() for _ in range(8)]
 peak = 0
 for i in range(8):
