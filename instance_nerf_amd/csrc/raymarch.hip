@@ -1222,7 +1222,15 @@ __global__ void __launch_bounds__(kRayBlock) k_composite_train_extra_fwd(const f
   float acc = 0.0f;
   if (lane < K) {
     int s = 0;
-    for (; s + 4 <= cnt; s += 4) {                   // 4 independent row loads in flight
+    for (; s + 8 <= cnt; s += 8) {                   // 8 independent row loads in flight (a ray is a chain of round trips)
+      const int64_t i = (int64_t)off + s;
+      float e[8], w[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { e[u] = extra[(i + u) * K + lane]; w[u] = wbuf[i + u]; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += w[u] * e[u];       // same order of additions as the scalar tail
+    }
+    for (; s + 4 <= cnt; s += 4) {
       const int64_t i = (int64_t)off + s;
       const float e0 = extra[i * K + lane], e1 = extra[(i + 1) * K + lane], e2 = extra[(i + 2) * K + lane],
                   e3 = extra[(i + 3) * K + lane];
