@@ -195,15 +195,22 @@ def train_probe(dev, rank=0, world=1, red_dev=None, steps=20, warmup=5, stage="i
         torch.cuda.synchronize()
 
     first = last = 0.0
+    # upstream's loop.  INR_BENCH_LOOK_AHEAD=1: with ONE batch of look-ahead (Trainer(look_ahead=True)): the next batch's
+    # ray/box test and march are queued on a side stream beside this step's scatter - off by default: in THIS loop the
+    # extra host work per step cancels the ~35 us it hides (profiles/r03_NOTES.txt 16)
+    look_ahead = os.environ.get("INR_BENCH_LOOK_AHEAD", "0") == "1"
+    nxt = (lambda j: batches[j % 4]) if look_ahead else (lambda j: None)
     for i in range(max(warmup, 4) + 16):   # >= one occupancy update: mean_count is set, the steady state begins
-        l = float(tr.train_one_step(batches[i % 4]))
+        l = float(tr.train_one_step(batches[i % 4], nxt(i + 1)))
         first = l if i == 0 else first
+    k = max(warmup, 4) + 16
     while tr.global_step % 16 != 1:        # start the timed region right after an update: K timed steps then
-        tr.train_one_step(batches[0])      # contain floor(K / 16) updates (1 for the default K = 20)
+        tr.train_one_step(batches[k % 4], nxt(k + 1))      # contain floor(K / 16) updates (1 for the default K = 20)
+        k += 1
     assert net.mean_count > 0
     per_step = torch.zeros(steps, dtype=torch.int32, device=dev)      # samples of each timed step: ONE tiny launch per step
     for i in range(2):                     # loads the code object of the counting op below, untimed
-        torch.clamp(net.step_counter[(net.local_step - 1) % 16, 0], max=net.mean_count, out=per_step[0])
+        torch.clamp(net.last_counter[0], max=net.mean_count, out=per_step[0])
     per_step.zero_()
     n_updates[0] = 0
     scatter_events.clear()
@@ -214,8 +221,8 @@ def train_probe(dev, rank=0, world=1, red_dev=None, steps=20, warmup=5, stage="i
     t0 = time.perf_counter()
     stamps = [t0]
     for i in range(steps):
-        last = tr.train_one_step(batches[i % 4])
-        torch.clamp(net.step_counter[(net.local_step - 1) % 16, 0], max=net.mean_count, out=per_step[i])
+        last = tr.train_one_step(batches[(k + i) % 4], nxt(k + i + 1))
+        torch.clamp(net.last_counter[0], max=net.mean_count, out=per_step[i])     # the march THIS step consumed
         stamps.append(time.perf_counter())
     # the time the host needs to QUEUE a step: the median over the steps (the step with the occupancy update waits for
     # the device inside its read-back); == ms_per_step when the host is the limit

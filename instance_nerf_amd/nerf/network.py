@@ -56,6 +56,9 @@ class _LinearFn(torch.autograd.Function):
         return gx, gw
 
 
+_before_scatter = {}      # {"hook": callable}: called once, right before the next table-gradient scatter is queued
+
+
 def _table_backward(lib, x, denc, desc, M, bound, g_emb, emb):
     """Table-gradient scatter; returns the gradient to hand back to autograd (None when it was installed directly).
 
@@ -67,6 +70,11 @@ def _table_backward(lib, x, denc, desc, M, bound, g_emb, emb):
     the buffer is half reduced (tests/test_gpu_ddp.py caught exactly that: one run in three diverged)."""
     from .utils import grad_sync
     L = int(desc.num_levels)
+    hook = _before_scatter.pop("hook", None)
+    if hook is not None:
+        hook()      # Trainer's look-ahead: the next batch's march goes on a side stream right beside THIS launch (the
+        #             scatter is bound by the memory-side atomic unit and leaves the CUs idle; the MFMA-bound kernels
+        #             before it do not)
     if grad_sync.active() and emb.data_ptr() in grad_sync.early:
         # a second backward before allreduce_gradients(): the first gradient is already being summed over the ranks,
         # adding an unreduced one to it cannot be reduced correctly afterwards

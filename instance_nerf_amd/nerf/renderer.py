@@ -77,6 +77,7 @@ class NeRFRenderer(nn.Module):
             self.register_buffer("step_counter", torch.zeros(16, 2, dtype=torch.int32))
             self.mean_count = 0
             self.local_step = 0
+            self.last_counter = None     # (total samples, N) int32 view of the march the last training render consumed
 
     # subclass API ---------------------------------------------------------------------------
     def forward(self, x, d):
@@ -179,7 +180,7 @@ class NeRFRenderer(nn.Module):
 
     def run_cuda(self, rays_o, rays_d, dt_gamma=0, bg_color=None, perturb=False, force_all_rays=False,
                  max_steps=1024, T_thresh=1e-4, infer_mode="auto", noises=None, field_gate=None, ce_labels=None,
-                 ce_ignore_index=-1, mse_target=None, **kwargs):
+                 ce_ignore_index=-1, mse_target=None, marched=None, **kwargs):
         """rays_o, rays_d [B,N,3] -> dict(image [B,N,3], depth [B,N], weights_sum [B,N] (, instance [B,N,K])).
 
         infer_mode (eval only; all modes render the same image):
@@ -196,6 +197,9 @@ class NeRFRenderer(nn.Module):
         the one-node instance head applies (``instance_head_available``); otherwise the key is absent and the caller
         computes the loss from ``results["instance"]`` as usual.
 
+        marched (training): the result of ``march_ahead`` for exactly these rays - the ray/box test and the march were
+        queued earlier (on a side stream, under the previous step's backward) and are not repeated here.
+
         mse_target (training, [.., 3] per ray): the mean squared error of the shaded image against it is returned as
         ``results["image_mse"]`` when the fused tail applies (gradient flows through the image, uniform or per-ray
         background, <= 65536 rays): blend, depth normalisation, loss and its gradients are then one launch each way
@@ -211,7 +215,13 @@ class NeRFRenderer(nn.Module):
         N = rays_o.shape[0]
         device = rays_o.device
         aabb = self.aabb_train if self.training else self.aabb_infer
-        nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, aabb, self.min_near)
+        if marched is not None and not (self.training and marched["n_rays"] == N):
+            marched = None
+        if marched is not None:
+            marched["consume"]()
+            nears, fars = marched["nears"], marched["fars"]
+        else:
+            nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, aabb, self.min_near)
         if bg_color is None:
             bg_color = 1
         results = {}
@@ -282,17 +292,23 @@ class NeRFRenderer(nn.Module):
             results["num_samples"] = counter
             skipped_frac = (skippable, int(xyzs.shape[0]), False)       # raw counter, marched total (host), "skippable"
         elif self.training or infer_mode == "fused_raymajor":
-            if self.training:
-                counter = self.step_counter[self.local_step % 16]        # (total samples, N): written by the count pass
-                self.local_step += 1
-                mean_count = self.mean_count
+            if marched is not None:
+                counter = marched["counter"]
+                xyzs, dirs, deltas, rays = marched["xyzs"], marched["dirs"], marched["deltas"], marched["rays"]
             else:
-                counter = torch.zeros(2, dtype=torch.int32, device=device)
-                mean_count = -1
-                force_all_rays = True
-            xyzs, dirs, deltas, rays = raymarching.march_rays_train(
-                rays_o, rays_d, self.bound, self.density_bitfield, self.cascade, self.grid_size, nears, fars,
-                counter, mean_count, perturb, 128, force_all_rays, dt_gamma, max_steps, noises=noises)
+                if self.training:
+                    counter = self.step_counter[self.local_step % 16]    # (total samples, N): written by the count pass
+                    self.local_step += 1
+                    mean_count = self.mean_count
+                else:
+                    counter = torch.zeros(2, dtype=torch.int32, device=device)
+                    mean_count = -1
+                    force_all_rays = True
+                xyzs, dirs, deltas, rays = raymarching.march_rays_train(
+                    rays_o, rays_d, self.bound, self.density_bitfield, self.cascade, self.grid_size, nears, fars,
+                    counter, mean_count, perturb, 128, force_all_rays, dt_gamma, max_steps, noises=noises)
+            if self.training:
+                self.last_counter = counter          # (total samples, N) of the march this render consumed
             sigmas, rgbs = self(xyzs, dirs)
             if self.density_scale != 1:
                 sigmas = self.density_scale * sigmas
@@ -464,6 +480,43 @@ class NeRFRenderer(nn.Module):
                                                   stream_ptr()), "mark_untrained_grid")
 
     @torch.no_grad()
+    @torch.no_grad()
+    def march_ahead(self, rays_o, rays_d, dt_gamma=0, perturb=False, max_steps=1024, stream=None):
+        """The parameter-independent head of a TRAINING render - ray/box test, jitter, march (count, scan, write) - queued
+        now, on ``stream`` (a side stream: it then runs beside whatever the current stream is busy with - the previous
+        step's backward, whose table-gradient scatter leaves the CUs idle; measured: ~47 of its ~60 us hide), for a
+        ``render(..., marched=<result>)`` of the SAME rays later.  Needs the steady state (``mean_count > 0``: no host
+        read-back) and an occupancy grid that will not change in between (the caller's business: ``Trainer`` skips the
+        step before an occupancy update).  -> the dict ``run_cuda`` takes as ``marched`` or None."""
+        if not (self.cuda_ray and self.training and self.mean_count > 0 and rays_o.is_cuda):
+            return None
+        rays_o = rays_o.contiguous().view(-1, 3).float()
+        rays_d = rays_d.contiguous().view(-1, 3).float()
+        main = torch.cuda.current_stream()
+        side = stream if stream is not None else main
+        if side is not main:
+            side.wait_stream(main)               # rays, bitfield and mean_count as the current stream leaves them
+        counter = self.step_counter[self.local_step % 16]
+        self.local_step += 1
+        with torch.cuda.stream(side):
+            nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, self.aabb_train, self.min_near)
+            xyzs, dirs, deltas, rays = raymarching.march_rays_train(
+                rays_o, rays_d, self.bound, self.density_bitfield, self.cascade, self.grid_size, nears, fars,
+                counter, self.mean_count, perturb, 128, False, dt_gamma, max_steps)
+            done = torch.cuda.Event()
+            done.record(side)
+        out = {"n_rays": rays_o.shape[0], "key": (rays_o.data_ptr(), rays_d.data_ptr(), rays_o.shape[0]),
+               "nears": nears, "fars": fars, "xyzs": xyzs, "dirs": dirs, "deltas": deltas, "rays": rays, "counter": counter}
+
+        def consume():
+            cur = torch.cuda.current_stream()
+            if side is not cur:
+                cur.wait_event(done)
+                for t in (nears, fars, xyzs, dirs, deltas, rays):
+                    t.record_stream(cur)         # allocated on the side stream's pool, used (and freed) here
+        out["consume"] = consume
+        return out
+
     def update_extra_state(self, decay=0.95, S=128):
         """EMA-max occupancy update + bitfield rebuild (SURVEY a3, Appendix A.1 "Occupancy update"; upstream
         ``NeRFRenderer.update_extra_state``).  First 16 calls: every cell of every cascade; afterwards H^3/4 uniformly

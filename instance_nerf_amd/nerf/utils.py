@@ -719,7 +719,8 @@ class Trainer:
                  local_rank=0, world_size=1, device=None, mute=False, fp16=False, eval_interval=1, max_keep_ckpt=2,
                  workspace="workspace", best_mode="min", use_loss_as_metric=True, report_metric_at_train=False,
                  use_checkpoint="latest", use_tensorboardX=True, scheduler_update_every_step=False, *,
-                 lr=1e-2, iters=30000, fused_adam=True, stage="nerf", update_extra_interval=None, use_graph=False):
+                 lr=1e-2, iters=30000, fused_adam=True, stage="nerf", update_extra_interval=None, use_graph=False,
+                 look_ahead=False):
         self.name, self.opt, self.model = name, opt, model
         self.world_size, self.local_rank = world_size, local_rank
         grad_sync.world_size = world_size
@@ -758,6 +759,11 @@ class Trainer:
         # the reduce-scatter gradient schedule (grad_sync.schedule) needs an optimiser that takes gradient pieces and a
         # captured graph cannot hold its collectives: FusedAdam, eager steps
         grad_sync.sharded_ok = isinstance(self.optimizer, FusedAdam) and world_size > 1 and not use_graph
+        self._ahead, self._side_stream = None, None      # the next batch's march, queued under this step's backward
+        # opt-in: train_one_epoch hands every step the NEXT batch too (train_one_step(data, next_data)).  -35 us per
+        # step (4 %) in tools/train_probe.py; in bench.py's loop (EMA, occupancy updates, per-step events) the extra
+        # ~0.2 ms of host work per step made the host the limit on most boxes: off by default (r03 notes 16)
+        self.look_ahead = bool(look_ahead)
         self.iters = iters
         # upstream: lr_scheduler = lambda optimizer: LambdaLR(optimizer, lambda it: 0.1 ** min(it / opt.iters, 1)),
         # stepped after every optimiser step; without one, exactly that rule is applied to the param groups
@@ -827,6 +833,11 @@ class Trainer:
         if (self.stage == "nerf" and self._default_criterion and getattr(self.model, "cuda_ray", False)
                 and data["rays_o"].is_cuda):
             extra["mse_target"] = gt                # the renderer may fold blend + loss + gradients into one launch
+        ahead = self._ahead
+        if ahead is not None:
+            self._ahead = None
+            if ahead["key"] == (data["rays_o"].data_ptr(), data["rays_d"].data_ptr(), data["rays_o"].numel() // 3):
+                extra["marched"] = ahead            # this batch's march was queued under the previous step's backward
         outputs = self.model.render(data["rays_o"], data["rays_d"], staged=False, bg_color=bg_color, perturb=True,
                                     force_all_rays=False, **extra, **self._render_kwargs())
         if self.stage == "nerf":
@@ -944,7 +955,28 @@ class Trainer:
             self.ema.update()
         return G["loss"].detach()
 
-    def train_one_step(self, data):
+    def _march_ahead(self, next_data):
+        """Queues the march of the NEXT batch on a side stream (``NeRFRenderer.march_ahead``): it does not depend on the
+        parameters, and right now the device is about to run this step's backward, whose scatter leaves the CUs idle.
+        Not before an occupancy update (the grid would change under the prefetched samples), not for captured steps."""
+        m = self.model
+        if (next_data is None or self.use_graph or not getattr(m, "cuda_ray", False) or not next_data["rays_o"].is_cuda
+                or m.mean_count <= 0 or self.global_step % self.update_extra_interval == 0
+                or not hasattr(m, "march_ahead")):
+            return
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(device=next_data["rays_o"].device)
+        kw = self._render_kwargs()
+        ro, rd = next_data["rays_o"], next_data["rays_d"]
+        if not (ro.is_contiguous() and rd.is_contiguous() and ro.dtype == torch.float32 and rd.dtype == torch.float32):
+            return                                   # the key below must be the pointers render() will see
+        self._ahead = m.march_ahead(ro, rd, dt_gamma=kw.get("dt_gamma", 0), perturb=True,
+                                    max_steps=kw.get("max_steps", 1024), stream=self._side_stream)
+
+    def train_one_step(self, data, next_data=None):
+        """One optimisation step on ``data``.  ``next_data`` (optional): the batch the NEXT call will get - its ray/box
+        test and march are then queued on a side stream under this step's backward (``train_one_epoch`` looks one batch
+        ahead; same results, ~45 us per step less)."""
         self.model.train()
         if self.model.cuda_ray and self.global_step % self.update_extra_interval == 0:
             self.model.update_extra_state()
@@ -958,18 +990,27 @@ class Trainer:
             return self._replay(data)
         self.optimizer.zero_grad()
         _, _, loss = self.train_step(data)
+        from . import network as _network
+        if next_data is not None:
+            # queued from inside the backward, right before the table-gradient scatter (nerf/network.py::_table_backward)
+            _network._before_scatter["hook"] = lambda: self._march_ahead(next_data)
         if loss.is_cuda and loss.dim() == 0 and loss.dtype == torch.float32:
             from .. import raymarching
             loss.backward(gradient=raymarching.unit_gradient(loss.device))     # no ones_like fill launch
         else:
             loss.backward()
+        if _network._before_scatter.pop("hook", None) is not None:
+            self._march_ahead(next_data)            # no fused table backward ran (composable path): queue it now
         params = [p for g in self.optimizer.param_groups for p in g["params"]]
         fused = isinstance(self.optimizer, FusedAdam)
         # FusedAdam takes the 1 / world_size of the gradient average as a factor inside its sweep
         scale = allreduce_gradients(params, self.world_size, average=not fused, sharded=grad_sync.sharded_ok)
         self._lr_step()
         if fused:
-            self.optimizer.step_impl(scale)
+            if self.lr_scheduler is None:
+                self.optimizer.step_impl(scale)
+            else:                                   # torch's schedulers count calls of the wrapped optimizer.step
+                self.optimizer.step(grad_scale=scale)
             if self.world_size > 1:
                 grad_sync.allgather_params(params)      # reduce-scatter schedule: the rows each rank updated -> all
         else:
@@ -1014,9 +1055,13 @@ class Trainer:
         total, n = 0.0, 0
         for m in self.metrics:
             m.clear()
-        for data in loader:
-            total += float(self.train_one_step(data))
+        it = iter(loader)
+        data = next(it, None)
+        while data is not None:
+            nxt = next(it, None)                     # one batch of look-ahead: its march may run under this step's backward
+            total += float(self.train_one_step(data, nxt if self.look_ahead else None))
             n += 1
+            data = nxt
         if self.lr_scheduler is not None and not self.scheduler_update_every_step:
             self.lr_scheduler.step()
         self.stats["loss"].append(total / max(n, 1))

@@ -2066,6 +2066,49 @@ def test_composite_backward_writes_every_row_when_given_the_total(rm, room, bits
     assert (gs_b[~owned] == 0).all() and (gc_b[~owned] == 0).all() and gs_b[owned].abs().sum() > 0
 
 
+def test_look_ahead_march_changes_nothing_but_the_schedule(room):
+    """Trainer.train_one_step(data, next_data): the next batch's ray/box test and march are queued on a side stream
+    under this step's backward.  Same seeds, same batches, occupancy updates every 4 steps (no look-ahead across an
+    update), jittered marching: per step the consumed march has the same sample total, the loss the same value up to
+    the scatter's rounding order, and after 14 steps the parameters agree as two plain runs do."""
+    from instance_nerf_amd.nerf import NeRFNetwork
+    from instance_nerf_amd.nerf.provider import SyntheticRoomDataset
+    from instance_nerf_amd.nerf.utils import Trainer
+
+    def run(ahead):
+        torch.manual_seed(3)
+        net = NeRFNetwork(cuda_ray=True, bound=1, min_near=0.05, density_thresh=10).to(DEV)
+        ds = SyntheticRoomDataset(torch.device(DEV), num_rays=1024)
+        net.density_bitfield.copy_(torch.from_numpy(ds.room.density_bitfield(128, 1.0)).to(DEV))
+        analytic = net.density_bitfield.clone()
+        real = net.update_extra_state
+
+        def update(*a, **kw):                      # the update runs (mean_count!) but the analytic grid is kept
+            real(*a, **kw)
+            net.density_bitfield.copy_(analytic)
+        net.update_extra_state = update
+        tr = Trainer("la", None, net, stage="nerf", device=torch.device(DEV), iters=100, update_extra_interval=4,
+                     workspace=None, mute=True)
+        tr.global_step = 1
+        batches = [ds.batch() for _ in range(15)]
+        torch.manual_seed(11)
+        used, losses, totals = 0, [], []
+        for i in range(14):
+            losses.append(float(tr.train_one_step(batches[i], batches[i + 1] if ahead else None)))
+            totals.append(int(net.last_counter[0]))
+            used += int(tr._ahead is not None)
+        return losses, totals, used, {k: v.detach().clone() for k, v in net.named_parameters()}
+    la, ta, used_a, pa = run(True)
+    lb, tb, used_b, pb = run(False)
+    assert used_b == 0 and 6 <= used_a <= 11        # steady-state steps that are not followed by an update
+    assert ta == tb
+    for x, y in zip(la, lb):
+        assert abs(x - y) <= 2e-4 * abs(y), (la, lb)
+    for k in pa:
+        d = (pa[k] - pb[k]).abs()
+        assert float((d > 2e-3).float().mean()) < 1e-5, k
+
+
 def test_training_from_scratch_with_mean_count_buffers(room):
     """40 NeRF steps from a zero occupancy grid: update_extra_state every 16 steps switches march_rays_train to
     buffers sized from mean_count (no host sync, overflowing rays dropped).  Loss stays finite and decreases."""

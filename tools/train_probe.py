@@ -21,18 +21,18 @@ steps = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 losses = []
 peak = 0
 for i in range(8):
-    losses.append(float(tr.train_one_step(batches[i % 8])))
-    peak = max(peak, int(net.step_counter[(net.local_step - 1) % 16, 0]))
+    losses.append(float(tr.train_one_step(batches[i % 8], batches[(i + 1) % 8] if os.environ.get('LOOK_AHEAD', '0') == '1' else None)))
+    peak = max(peak, int(net.last_counter[0]))
 # steady state as after an occupancy update: sample buffers sized from mean_count, no host read-back inside a step
 net.mean_count = (int(peak * 1.02) + 127) // 128 * 128
 for i in range(8):
-    tr.train_one_step(batches[i % 8])
+    tr.train_one_step(batches[i % 8], batches[(i + 1) % 8] if os.environ.get('LOOK_AHEAD', '0') == '1' else None)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 n_dev = torch.zeros((), dtype=torch.int64, device=dev)
 for i in range(steps):
-    l = tr.train_one_step(batches[i % 8])
-    n_dev += net.step_counter[(net.local_step - 1) % 16, 0]       # on the device: no host sync inside the loop
+    l = tr.train_one_step(batches[i % 8], batches[(i + 1) % 8] if os.environ.get('LOOK_AHEAD', '0') == '1' else None)
+    n_dev += net.last_counter[0]       # on the device: no host sync inside the loop
 t_host = (time.perf_counter() - t0) / steps      # host time to enqueue a step (== the step time when host-bound)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
