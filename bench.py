@@ -493,6 +493,17 @@ def trained_scene_probe(dev, steps=1500, with_oracle=True):
             else:
                 frame0_fast = f
     net.half_table = net.mlp_fp16 = False
+    if frame0 is not None:
+        # the metric's "PSNR": view 0 (800x800; training saw 24 views at 400x400) against the scene's analytic ground truth,
+        # traced on the host for every fourth pixel row and column - for the default path and for the -O numerics
+        pix = (np.arange(0, H, 4)[:, None] * W + np.arange(0, W, 4)[None, :]).reshape(-1)
+        r = get_rays(pd[:1], intr, H, W, inds=torch.from_numpy(pix).to(dev))
+        gt, _, _ = ds.room.trace(r["rays_o"][0].cpu().numpy(), r["rays_d"][0].cpu().numpy())
+        gt = torch.from_numpy(gt).to(dev)
+        psnr = lambda f: round(-10 * math.log10(max(float(((f[pix] - gt) ** 2).mean()), 1e-20)), 2)
+        out["psnr_db_vs_ground_truth"] = {"default": psnr(frame0), "pixels": int(pix.shape[0])}
+        if frame0_fast is not None:
+            out["psnr_db_vs_ground_truth"]["O_numerics"] = psnr(frame0_fast)
     if frame0 is not None and frame0_fast is not None:      # the -O numerics against the default path, all pixels of view 0
         d = (frame0_fast - frame0).double()
         out["fused_O"]["vs_default_path"] = {"max_abs_diff": float(d.abs().max()),
