@@ -494,16 +494,54 @@ def trained_scene_probe(dev, steps=1500, with_oracle=True):
                 frame0_fast = f
     net.half_table = net.mlp_fp16 = False
     if frame0 is not None:
-        # the metric's "PSNR": view 0 (800x800; training saw 24 views at 400x400) against the scene's analytic ground truth,
-        # traced on the host for every fourth pixel row and column - for the default path and for the -O numerics
+        # the metric's "PSNR" and "instance mIoU" against the scene's analytic ground truth (traced on the host):
+        #   view 0 of the bench views = TRAINING view 0 at twice the training resolution (every fourth row and column);
+        #   a HELD-OUT pose at 400x400, for the default path and for the -O numerics;
+        #   instance stage on the frozen trained NeRF (K = 16 head, 400 steps of 4096 rays, masks with 10 % ignore
+        #   labels): mIoU of the argmax of the rendered logits on the held-out pose
+        psnr = lambda a, b: round(-10 * math.log10(max(float(((a - b) ** 2).mean()), 1e-20)), 2)
         pix = (np.arange(0, H, 4)[:, None] * W + np.arange(0, W, 4)[None, :]).reshape(-1)
         r = get_rays(pd[:1], intr, H, W, inds=torch.from_numpy(pix).to(dev))
         gt, _, _ = ds.room.trace(r["rays_o"][0].cpu().numpy(), r["rays_d"][0].cpu().numpy())
         gt = torch.from_numpy(gt).to(dev)
-        psnr = lambda f: round(-10 * math.log10(max(float(((f[pix] - gt) ** 2).mean()), 1e-20)), 2)
-        out["psnr_db_vs_ground_truth"] = {"default": psnr(frame0), "pixels": int(pix.shape[0])}
+        q = {"training_view_0_at_800": {"default": psnr(frame0[pix], gt), "pixels": int(pix.shape[0])}}
         if frame0_fast is not None:
-            out["psnr_db_vs_ground_truth"]["O_numerics"] = psnr(frame0_fast)
+            q["training_view_0_at_800"]["O_numerics"] = psnr(frame0_fast[pix], gt)
+        held = torch.from_numpy(ds.room.look_at([0.3, -0.2, 0.1])[None]).to(dev)
+        rh = get_rays(held, ds.intrinsics, ds.H, ds.W, patch=4)
+        gt_h, ids_h, _ = ds.room.trace(rh["rays_o"][0].cpu().numpy(), rh["rays_d"][0].cpu().numpy())
+        gt_h = torch.from_numpy(gt_h).to(dev)
+        q["held_out_pose_at_400"] = {"pixels": int(gt_h.shape[0])}
+        for name, flag in (("default", False), ("O_numerics", True)):
+            net.half_table = net.mlp_fp16 = flag
+            with torch.no_grad():
+                q["held_out_pose_at_400"][name] = psnr(net.render(rh["rays_o"], rh["rays_d"], bg_color=1)["image"][0], gt_h)
+        net.half_table = net.mlp_fp16 = False
+        out["psnr_db_vs_ground_truth"] = q
+        try:
+            from instance_nerf_amd.nerf.utils import MIoUMeter
+            K = 16
+            net2 = NeRFNetwork(cuda_ray=True, bound=1, min_near=0.05, density_thresh=10, num_instances=K).to(dev)
+            net2.load_state_dict(net.state_dict(), strict=False)          # the trained NeRF + its occupancy grid
+            net2.mean_density, net2.iter_density, net2.mean_count = net.mean_density, net.iter_density, net.mean_count
+            ds2 = SyntheticRoomDataset(dev, H=400, W=400, n_views=24, num_rays=4096, num_instances=K, ignore_frac=0.1)
+            tr2 = Trainer("trained_inst", None, net2, stage="instance", device=dev, lr=1e-2, iters=400,
+                          update_extra_interval=10 ** 9)
+            tr2.global_step = 1
+            t0 = time.perf_counter()
+            ce = [float(tr2.train_one_step(ds2.batch())) if i in (0, 399) else tr2.train_one_step(ds2.batch()) for i in range(400)]
+            torch.cuda.synchronize()
+            inst_s = time.perf_counter() - t0
+            net2.eval()
+            with torch.no_grad():
+                pred = net2.render(rh["rays_o"], rh["rays_d"], bg_color=1)["instance"][0].argmax(-1)
+            m = MIoUMeter(K)
+            m.update(pred, torch.from_numpy(ids_h % K))
+            out["instance_miou_vs_ground_truth"] = {"held_out_pose_at_400": round(m.measure(), 3), "classes": K, "steps": 400,
+                                                    "ce_first": round(ce[0], 4), "ce_last": round(ce[-1], 4),
+                                                    "train_seconds": round(inst_s, 2)}
+        except Exception as e:                                # noqa: BLE001
+            out["instance_miou_vs_ground_truth"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     if frame0 is not None and frame0_fast is not None:      # the -O numerics against the default path, all pixels of view 0
         d = (frame0_fast - frame0).double()
         out["fused_O"]["vs_default_path"] = {"max_abs_diff": float(d.abs().max()),
