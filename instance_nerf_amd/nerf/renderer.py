@@ -496,24 +496,36 @@ class NeRFRenderer(nn.Module):
         side = stream if stream is not None else main
         if side is not main:
             side.wait_stream(main)               # rays, bitfield and mean_count as the current stream leaves them
+        # Two persistent buffer sets, used in turn and allocated HERE, on the current stream's pool: nothing is allocated
+        # on the side stream (the caching allocator keeps a pool per stream; blocks that cross streams are freed late and
+        # cost ~0.2 ms of host time per step - measured, profiles/r03_NOTES.txt 16).  Set A is read by step i (forward
+        # and, through autograd's saved tensors, backward) while the side stream fills set B for step i + 1; set A is
+        # written again for step i + 2 only after `side.wait_stream(main)` below, i.e. behind all of step i's launches.
+        N = rays_o.shape[0]
+        M_al = (int(self.mean_count) + 127) // 128 * 128
+        bufs = getattr(self, "_ahead_bufs", None)
+        if bufs is None or bufs[0]["n_rays"] != N or bufs[0]["n_samples"] != M_al or bufs[0]["nears"].device != rays_o.device:
+            bufs = self._ahead_bufs = [raymarching.march_train_buffers(N, M_al, rays_o.device) for _ in range(2)]
+            self._ahead_turn = 0
+        b = bufs[self._ahead_turn]
+        self._ahead_turn ^= 1
         counter = self.step_counter[self.local_step % 16]
         self.local_step += 1
         with torch.cuda.stream(side):
-            nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, self.aabb_train, self.min_near)
+            nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, self.aabb_train, self.min_near,
+                                                         out=(b["nears"], b["fars"]))
             xyzs, dirs, deltas, rays = raymarching.march_rays_train(
                 rays_o, rays_d, self.bound, self.density_bitfield, self.cascade, self.grid_size, nears, fars,
-                counter, self.mean_count, perturb, 128, False, dt_gamma, max_steps)
+                counter, self.mean_count, perturb, 128, False, dt_gamma, max_steps, out=b)
             done = torch.cuda.Event()
             done.record(side)
-        out = {"n_rays": rays_o.shape[0], "key": (rays_o.data_ptr(), rays_d.data_ptr(), rays_o.shape[0]),
+        out = {"n_rays": N, "key": (rays_o.data_ptr(), rays_d.data_ptr(), N),
                "nears": nears, "fars": fars, "xyzs": xyzs, "dirs": dirs, "deltas": deltas, "rays": rays, "counter": counter}
 
         def consume():
             cur = torch.cuda.current_stream()
             if side is not cur:
                 cur.wait_event(done)
-                for t in (nears, fars, xyzs, dirs, deltas, rays):
-                    t.record_stream(cur)         # allocated on the side stream's pool, used (and freed) here
         out["consume"] = consume
         return out
 

@@ -49,13 +49,16 @@ def set_march_mode(mode):
     check(_lib.load().inr_set_march_mode(code), "set_march_mode")
 
 
-def near_far_from_aabb(rays_o, rays_d, aabb, min_near=0.2):
-    """rays_o, rays_d [N,3]; aabb [6] -> nears, fars [N]."""
+def near_far_from_aabb(rays_o, rays_d, aabb, min_near=0.2, out=None):
+    """rays_o, rays_d [N,3]; aabb [6] -> nears, fars [N] (written into ``out = (nears, fars)`` when given)."""
     lib = _lib.load()
     rays_o, rays_d, aabb = _f(rays_o).view(-1, 3), _f(rays_d).view(-1, 3), _f(aabb)
     N = rays_o.shape[0]
-    nears = torch.empty(N, dtype=F32, device=rays_o.device)
-    fars = torch.empty(N, dtype=F32, device=rays_o.device)
+    if out is not None:
+        nears, fars = out
+    else:
+        nears = torch.empty(N, dtype=F32, device=rays_o.device)
+        fars = torch.empty(N, dtype=F32, device=rays_o.device)
     check(lib.inr_near_far_from_aabb(ptr(rays_o, F32, "rays_o"), ptr(rays_d, F32, "rays_d"), ptr(aabb, F32, "aabb"),
                                      N, float(min_near), ptr(nears), ptr(fars), stream_ptr()), "near_far_from_aabb")
     return nears, fars
@@ -111,9 +114,21 @@ def packbits(grid, thresh, bitfield=None):
     return bitfield
 
 
+def march_train_buffers(n_rays, n_samples, device):
+    """Persistent buffers for ``march_rays_train(..., out=)``: a caller that marches on a side stream every step
+    (``NeRFRenderer.march_ahead``) must not allocate there - the caching allocator keeps one pool per stream, and blocks
+    handed across streams cost ~0.2 ms of host time per step in deferred frees."""
+    lib = _lib.load()
+    return {"n_rays": n_rays, "n_samples": n_samples,
+            "nears": torch.empty(n_rays, dtype=F32, device=device), "fars": torch.empty(n_rays, dtype=F32, device=device),
+            "noises": torch.empty(n_rays, dtype=F32, device=device), "rays": torch.empty(n_rays, 3, dtype=I32, device=device),
+            "ws": torch.empty(lib.inr_march_workspace_bytes(n_rays, SAMPLE_CAP_TRAIN) // 8 + 1, dtype=torch.int64, device=device),
+            "buf": torch.empty(n_samples * 8, dtype=F32, device=device)}
+
+
 def march_rays_train(rays_o, rays_d, bound, density_bitfield, C, H, nears, fars, step_counter=None,
                      mean_count=-1, perturb=False, align=-1, force_all_rays=False, dt_gamma=0, max_steps=1024,
-                     noises=None, separate_buffers=False):
+                     noises=None, separate_buffers=False, out=None):
     """-> xyzs [M,3], dirs [M,3], deltas [M,2], rays int32 [N,3] = (ray, offset, count).
 
     With ``mean_count <= 0`` or ``force_all_rays`` the exact sample count is read
@@ -127,14 +142,24 @@ def march_rays_train(rays_o, rays_d, bound, density_bitfield, C, H, nears, fars,
     N = rays_o.shape[0]
     nears, fars = _f(nears), _f(fars)
     if noises is None:
-        noises = torch.rand(N, dtype=F32, device=dev) if perturb else None
+        if not perturb:
+            noises = None
+        elif out is not None:
+            noises = torch.rand(N, dtype=F32, device=dev, out=out["noises"])
+        else:
+            noises = torch.rand(N, dtype=F32, device=dev)
     else:
         noises = _f(noises)
     if step_counter is None:
         step_counter = torch.zeros(2, dtype=I32, device=dev)
-    rays = torch.empty(N, 3, dtype=I32, device=dev)
     cap = SAMPLE_CAP_TRAIN
-    ws = torch.empty(lib.inr_march_workspace_bytes(N, cap) // 8 + 1, dtype=torch.int64, device=dev)
+    if out is not None:                       # ``march_train_buffers``: nothing is allocated (steady state only)
+        if force_all_rays or mean_count <= 0 or out["n_rays"] != N or out["n_samples"] < int(mean_count):
+            raise RuntimeError("march_rays_train(out=) needs the steady state and buffers of the batch's size")
+        rays, ws = out["rays"], out["ws"]
+    else:
+        rays = torch.empty(N, 3, dtype=I32, device=dev)
+        ws = torch.empty(lib.inr_march_workspace_bytes(N, cap) // 8 + 1, dtype=torch.int64, device=dev)
     args = (ptr(rays_o, F32, "rays_o"), ptr(rays_d, F32, "rays_d"), ptr(density_bitfield, U8, "density_bitfield"),
             float(bound), float(dt_gamma), int(max_steps), N, int(C), int(H))
     check(lib.inr_march_rays_train_count(*args, ptr(nears, F32, "nears"), ptr(fars, F32, "fars"),
@@ -149,7 +174,12 @@ def march_rays_train(rays_o, rays_d, bound, density_bitfield, C, H, nears, fars,
         M += align - M % align if M % align else 0
     # rows no ray owns (padding, dropped rays) must be zero: the staged marcher's write pass clears them itself
     alloc = torch.empty if lib.inr_march_write_fills_unowned_rows(N, cap, int(max_steps)) else torch.zeros
-    if separate_buffers:     # three allocations (the registered custom op may not return views of one buffer)
+    if out is not None:
+        if alloc is not torch.empty or M > out["n_samples"]:
+            raise RuntimeError("march_rays_train(out=) needs the staged marcher (it clears unowned rows itself)")
+        buf = out["buf"]
+        xyzs, dirs, deltas = buf[:M * 3].view(M, 3), buf[M * 3:M * 6].view(M, 3), buf[M * 6:M * 8].view(M, 2)
+    elif separate_buffers:     # three allocations (the registered custom op may not return views of one buffer)
         xyzs, dirs, deltas = (alloc(M, 3, dtype=F32, device=dev), alloc(M, 3, dtype=F32, device=dev),
                               alloc(M, 2, dtype=F32, device=dev))
     else:
