@@ -220,9 +220,12 @@ def train_probe(dev, rank=0, world=1, red_dev=None, steps=20, warmup=5, stage="i
     barrier()
     t0 = time.perf_counter()
     stamps = [t0]
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    marks[0].record()
     for i in range(steps):
         last = tr.train_one_step(batches[(k + i) % 4], nxt(k + i + 1))
         torch.clamp(net.last_counter[0], max=net.mean_count, out=per_step[i])     # the march THIS step consumed
+        marks[i + 1].record()
         stamps.append(time.perf_counter())
     # the time the host needs to QUEUE a step: the median over the steps (the step with the occupancy update waits for
     # the device inside its read-back); == ms_per_step when the host is the limit
@@ -232,6 +235,7 @@ def train_probe(dev, rank=0, world=1, red_dev=None, steps=20, warmup=5, stage="i
     gc.enable()
     _network_mod._table_backward = real_table_backward
     n = int(per_step.sum().item())
+    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]       # device-side time of every step
     n_all = float(n)
     scatter_ms = sum(a.elapsed_time(b) for a, b in scatter_events) / max(len(scatter_events), 1)
     if world > 1:
@@ -278,6 +282,10 @@ def train_probe(dev, rank=0, world=1, red_dev=None, steps=20, warmup=5, stage="i
         "NeRF training step (MSE on rgb: hash table + sigma/colour nets, parameter EMA 0.95), 4096 rays/batch per GPU"
     return {"workload": what,
             "n_gpus": world, "ms_per_step": round(dt * 1e3, 3),
+            # median / max of the steps' device-side times: one stalled step (a host hiccup, an allocator slow path, the
+            # occupancy update) moves the mean above but not the median
+            "ms_per_step_median": round(float(np.median(step_ms)), 3), "ms_per_step_max": round(max(step_ms), 3),
+            "ms_of_each_step": [round(v, 3) for v in step_ms],
             "host_enqueue_ms_per_step": round(host_s / steps * 1e3, 3),     # a busy host shows here first
             "samples_per_step": int(n_all) // steps,
             "msamples_per_s": round(n_all / steps / dt / 1e6, 2),

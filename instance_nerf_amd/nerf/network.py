@@ -447,6 +447,29 @@ class NeRFNetwork(NeRFRenderer):
         hit = self._packed.get(which)
         if hit is not None and hit[0] == key:
             return hit[1]
+        if which in ("nerf", "instance") and ws[0].is_cuda and not getattr(self, "_host_pack_only", False):
+            # weights that live on the device are packed there (same layout and rounding as the host packers): the
+            # host route costs five device->host copies, each a synchronisation - ~1 ms per occupancy update of the
+            # NeRF stage, whose weights change every step
+            f32 = torch.float32
+            dev_ws = [w.detach().float().contiguous() for w in ws]
+            try:
+                if which == "nerf":
+                    pf = torch.empty(lib.inr_nerf_packed_floats(), dtype=f32, device=ws[0].device)
+                    pb = torch.empty(lib.inr_nerf_bwd_packed_floats(), dtype=f32, device=ws[0].device)
+                    check(lib.inr_nerf_pack_weights_device(*[ptr(w, f32, "weight") for w in dev_ws], ptr(pf), ptr(pb),
+                                                           stream_ptr()), "nerf_pack_weights_device")
+                else:
+                    if self._k_pad != self.num_instances:
+                        dev_ws[2] = torch.nn.functional.pad(dev_ws[2], (0, 0, 0, self._k_pad - self.num_instances)).contiguous()
+                    pf = torch.empty(lib.inr_instance_packed_floats(self._k_pad), dtype=f32, device=ws[0].device)
+                    pb = torch.empty(lib.inr_instance_bwd_packed_floats(), dtype=f32, device=ws[0].device)
+                    check(lib.inr_instance_pack_weights_device(*[ptr(w, f32, "weight") for w in dev_ws], self._k_pad,
+                                                               ptr(pf), ptr(pb), stream_ptr()), "instance_pack_weights_device")
+                self._packed[which] = (key, pf)
+                return pf
+            except RuntimeError:
+                self._host_pack_only = True          # the exact-fp32 build has no device packer
         host = [w.detach().float().cpu().contiguous() for w in ws]
         if which.startswith("instance") and self._k_pad != self.num_instances:
             host[2] = torch.nn.functional.pad(host[2], (0, 0, 0, self._k_pad - self.num_instances)).contiguous()

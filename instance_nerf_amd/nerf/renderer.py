@@ -529,6 +529,8 @@ class NeRFRenderer(nn.Module):
         out["consume"] = consume
         return out
 
+    @torch.no_grad()        # as upstream's: without it the NeRF stage's update ran the density query through the
+    #                          composable autograd path (HIP encoder + BLAS layers, graph and all): 2.0 instead of 1.0 ms
     def update_extra_state(self, decay=0.95, S=128):
         """EMA-max occupancy update + bitfield rebuild (SURVEY a3, Appendix A.1 "Occupancy update"; upstream
         ``NeRFRenderer.update_extra_state``).  First 16 calls: every cell of every cascade; afterwards H^3/4 uniformly

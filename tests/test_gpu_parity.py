@@ -600,6 +600,26 @@ def test_frozen_nerf_of_the_instance_stage_takes_O_numerics_when_asked(level_tab
         assert rel < 2e-5, (k, rel)              # the scatter's atomics round in launch order; nothing else differs
 
 
+def test_device_packers_equal_the_host_packers(level_table):
+    """NeRFNetwork._packed_weights packs device-resident weights ON the device (no device->host copies: the occupancy
+    update of the NeRF stage re-packs every 16 steps): the forward image has the bits of the host packers', for both
+    fields and a padded K."""
+    from instance_nerf_amd import _lib
+    from oracle import field
+    lib = _lib.load()
+    for K in (64, 20):
+        net = _network(field.init_params(seed=53, table=level_table, table_std=1.0, K=K), K=K).eval()
+        for which in ("nerf", "instance"):
+            net._packed.clear()
+            net._host_pack_only = False
+            dev_img = net._packed_weights(which).clone()
+            net._packed.clear()
+            net._host_pack_only = True
+            host_img = net._packed_weights(which)
+            assert dev_img.shape == host_img.shape and torch.equal(dev_img.view(torch.int32), host_img.view(torch.int32)), (K, which)
+        net._host_pack_only = False
+
+
 def test_exact_fp32_mlp_build(params_k16):
     """The -DINR_MLP_FP32=1 build (MLP GEMMs on v_mfma_f32_16x16x4_f32, exact fp32 products) stays alive: the same
     golden field vectors through libinr_hip_fp32.so in a child process (a process binds one library).  Both builds
