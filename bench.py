@@ -285,6 +285,9 @@ def train_probe(dev, rank=0, world=1, red_dev=None, steps=20, warmup=5, stage="i
             # median / max of the steps' device-side times: one stalled step (a host hiccup, an allocator slow path, the
             # occupancy update) moves the mean above but not the median
             "ms_per_step_median": round(float(np.median(step_ms)), 3), "ms_per_step_max": round(max(step_ms), 3),
+            # the loop as it runs between two synchronisations: the first timed step starts on a device the barrier has
+            # just idled (host-paced, ~2x a step) - the mean device time of the others, occupancy update included
+            "ms_per_step_running": round(float(np.mean(step_ms[1:])), 3) if steps > 1 else None,
             "ms_of_each_step": [round(v, 3) for v in step_ms],
             "host_enqueue_ms_per_step": round(host_s / steps * 1e3, 3),     # a busy host shows here first
             "samples_per_step": int(n_all) // steps,
