@@ -659,6 +659,9 @@ __global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_nerf_fwd(cons
                                                                float* __restrict__ geo, const int32_t* __restrict__ ray_ids,
                                                                const float4* __restrict__ shq, NerfSave sv) {
   extern __shared__ __attribute__((aligned(16))) float4 wl[];
+#if INR_PROBE_MODE == 3
+  const unsigned long long probe_t0 = wall_clock64();
+#endif
   // the field kernel's waves outrank whatever shares the CU with them (FramePipeline: the next view's marchers run
   // at priority 0 and take the issue slots this kernel leaves free); alone on the chip it changes nothing
   __builtin_amdgcn_s_setprio(3);
@@ -729,6 +732,7 @@ __global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_nerf_fwd(cons
 
     if (valid) {
       if (q == 0) sigma[m] = __expf(h2[0][0]) * density_scale;
+#if INR_PROBE_MODE != 3
       if (geo) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -736,6 +740,7 @@ __global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_nerf_fwd(cons
           if (row >= 1) geo[m * 15 + row - 1] = h2[0][r];
         }
       }
+#endif
     }
 
     if constexpr (kColor) {
@@ -790,6 +795,14 @@ __global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_nerf_fwd(cons
       }
     }
   }
+#if INR_PROBE_MODE == 3
+  // profiling build only (tools/build_probe.py 3): when does each workgroup run dry?  geo = uint64 [gridDim.x][2]
+  if (geo && (threadIdx.x & 63) == 0) {
+    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(geo);
+    atomicMax(&dbg[2 * blockIdx.x + 1], (unsigned long long)wall_clock64());
+    if (threadIdx.x == 0) dbg[2 * blockIdx.x] = probe_t0;
+  }
+#endif
 }
 
 // ---- rgb-sigma lattice extraction (BASELINE configs[4]) ---------------------------------------
