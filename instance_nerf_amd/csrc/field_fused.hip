@@ -1047,10 +1047,17 @@ __device__ __forceinline__ void hb_zero_fill(float* __restrict__ buf, int64_t n)
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) buf[(n4 << 2) + threadIdx.x] = 0.f;
 }
 
+#if INR_MLP_FP32
+// exact-fp32 build: the (G, X) tiles staged row-major as fp32, contraction with v_mfma_f32_16x16x4_f32
+typedef float HbStage;
+__device__ __forceinline__ HbStage* hb_my_tile(float* plane, int wave) { return plane + wave * kHbTileFloats; }
 template <int N_T>
-__device__ __forceinline__ void hb_stage(float* __restrict__ tile_base, int q, int j, const f32x4* v) {
+__device__ __forceinline__ void hb_stage(HbStage* __restrict__ tile_base, int q, int j, const f32x4* v) {
 #pragma unroll
   for (int t = 0; t < N_T; ++t) store4(tile_base + j * kHbPitch + 16 * t + 4 * q, v[t]);
+}
+__device__ __forceinline__ void hb_stage_value(HbStage* __restrict__ tile_base, int j, int channel, float v) {
+  tile_base[j * kHbPitch + channel] = v;
 }
 
 // acc0 += G[:, ot]^T X[:, it0], acc1 += G[:, ot]^T X[:, it1] over the 8 x 16 staged samples
@@ -1071,6 +1078,77 @@ __device__ __forceinline__ void hb_accum(const float* __restrict__ gS, const flo
     }
   }
 }
+#else
+// Default build (late round 3): the weight gradients take the bf16 matrix cores too.  The fp32 contraction
+// (v_mfma_f32_16x16x4_f32: 4 samples per 32-cycle instruction) was 62 % of these kernels' MFMA time; split into bf16
+// head + remainder like the MLP layers (hi*hi + lo*hi + hi*lo, fp32 accumulation: 2^-16 relative per product, random
+// over ~2e5 samples) the same 32 samples cost three 16-cycle v_mfma_f32_16x16x32_bf16.  The operands of that
+// instruction hold 8 CONSECUTIVE k (= samples) per lane, so the tiles are staged TRANSPOSED - [channel][sample], a head
+// plane and a remainder plane of 64 x 136 bf16 each (pitch 136 halfwords = 68 dwords: rows land 4 banks apart, the
+// 16-byte reads of a 16-lane row spread over all banks) - exactly the 34 816 bytes per operand of the fp32 staging.
+typedef uint16_t HbStage;
+constexpr int kHbPitchH = 136;                           // halfwords per channel row: 128 samples + 8
+constexpr int kHbPlaneH = 64 * kHbPitchH;                // halfwords per plane (head | remainder)
+static_assert(2 * kHbPlaneH * 2 == kHbWaves * kHbTileFloats * 4, "bf16 staging must fit the fp32 staging's footprint");
+__device__ __forceinline__ HbStage* hb_my_tile(float* plane, int wave) {
+  return reinterpret_cast<HbStage*>(plane) + wave * 16;  // this wave's 16 sample columns
+}
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2h_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t hb_pack_bf16x2(float a, float b) {       // v_cvt_pk_bf16_f32: round to nearest even
+  const f32x2h_t v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
+// head / remainder of two values -> (hi0 | hi1 << 16), (lo0 | lo1 << 16)
+__device__ __forceinline__ void hb_split2(float v0, float v1, uint32_t& hi, uint32_t& lo) {
+  hi = hb_pack_bf16x2(v0, v1);
+  lo = hb_pack_bf16x2(v0 - __uint_as_float(hi << 16), v1 - __uint_as_float(hi & 0xFFFF0000u));
+}
+__device__ __forceinline__ void hb_put(HbStage* __restrict__ tile_base, int j, int channel, uint32_t hi16, uint32_t lo16) {
+  tile_base[channel * kHbPitchH + j] = (uint16_t)hi16;
+  tile_base[kHbPlaneH + channel * kHbPitchH + j] = (uint16_t)lo16;
+}
+template <int N_T>
+__device__ __forceinline__ void hb_stage(HbStage* __restrict__ tile_base, int q, int j, const f32x4* v) {
+#pragma unroll
+  for (int t = 0; t < N_T; ++t) {
+#pragma unroll
+    for (int r = 0; r < 4; r += 2) {
+      uint32_t hi, lo;
+      hb_split2(v[t][r], v[t][r + 1], hi, lo);
+      hb_put(tile_base, j, 16 * t + 4 * q + r, hi & 0xFFFFu, lo & 0xFFFFu);
+      hb_put(tile_base, j, 16 * t + 4 * q + r + 1, hi >> 16, lo >> 16);
+    }
+  }
+}
+__device__ __forceinline__ void hb_stage_value(HbStage* __restrict__ tile_base, int j, int channel, float v) {
+  uint32_t hi, lo;
+  hb_split2(v, 0.0f, hi, lo);
+  hb_put(tile_base, j, channel, hi & 0xFFFFu, lo & 0xFFFFu);
+}
+
+// acc0 += G[:, ot]^T X[:, it0], acc1 += G[:, ot]^T X[:, it1] over the 128 staged samples (4 k-blocks of 32)
+__device__ __forceinline__ void hb_accum(const float* __restrict__ gS, const float* __restrict__ xS, int q, int j, int ot,
+                                         int it0, int it1, bool two, f32x4& acc0, f32x4& acc1) {
+  const uint16_t* G = reinterpret_cast<const uint16_t*>(gS) + (16 * ot + j) * kHbPitchH + 8 * q;
+  const uint16_t* X0 = reinterpret_cast<const uint16_t*>(xS) + (16 * it0 + j) * kHbPitchH + 8 * q;
+  const uint16_t* X1 = reinterpret_cast<const uint16_t*>(xS) + (16 * it1 + j) * kHbPitchH + 8 * q;
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb) {
+    const uint4 a_hi = *reinterpret_cast<const uint4*>(G + 32 * kb), a_lo = *reinterpret_cast<const uint4*>(G + kHbPlaneH + 32 * kb);
+    const uint4 b_hi = *reinterpret_cast<const uint4*>(X0 + 32 * kb), b_lo = *reinterpret_cast<const uint4*>(X0 + kHbPlaneH + 32 * kb);
+    acc0 = mfma_bf(a_hi, b_hi, acc0);
+    acc0 = mfma_bf(a_lo, b_hi, acc0);
+    acc0 = mfma_bf(a_hi, b_lo, acc0);
+    if (two) {
+      const uint4 c_hi = *reinterpret_cast<const uint4*>(X1 + 32 * kb), c_lo = *reinterpret_cast<const uint4*>(X1 + kHbPlaneH + 32 * kb);
+      acc1 = mfma_bf(a_hi, c_hi, acc1);
+      acc1 = mfma_bf(a_lo, c_hi, acc1);
+      acc1 = mfma_bf(a_hi, c_lo, acc1);
+    }
+  }
+}
+#endif
 
 __global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_instance_head_bwd(
     const float* __restrict__ enc, const float* __restrict__ wbuf, const int32_t* __restrict__ ray_of,
@@ -1098,8 +1176,8 @@ __global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_instance_head
   const int64_t n_rounds = (n_tiles + per_round - 1) / per_round;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   f32x4 acc[5] = {zero4, zero4, zero4, zero4, zero4};
-  float* my_g = gS + wave * kHbTileFloats;
-  float* my_x = xS + wave * kHbTileFloats;
+  HbStage* my_g = hb_my_tile(gS, wave);
+  HbStage* my_x = hb_my_tile(xS, wave);
   const int ot = wave >> 1, it0 = 2 * (wave & 1), it1 = it0 + 1;
   // Inputs of the NEXT round are requested while this round's weight-gradient phases run (the kernel is a chain of
   // dependent round trips otherwise: 7 rounds x (HBM load -> dependent row load -> MFMA chain -> 6 barriers)):
@@ -1325,14 +1403,13 @@ constexpr int kNhFwdFloats = kNerfFloats;
 
 // colour-net input in weight-column order (16 SH, 15 geo, 1 zero) from the register layout of the forward:
 // cin0[ks] = SH component 4 ks + q, so[r] = sigma-net row 4 q + r (row 0 is the density logit: column 31 gets 0)
-__device__ __forceinline__ void nh_stage_cin(float* __restrict__ tile_base, int q, int j, const f32x4 cin0, const f32x4 so) {
-  float* row = tile_base + j * kHbPitch;
+__device__ __forceinline__ void nh_stage_cin(HbStage* __restrict__ tile_base, int q, int j, const f32x4 cin0, const f32x4 so) {
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) row[4 * ks + q] = cin0[ks];
+  for (int ks = 0; ks < 4; ++ks) hb_stage_value(tile_base, j, 4 * ks + q, cin0[ks]);
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int srow = 4 * q + r;
-    row[srow >= 1 ? 15 + srow : 31] = srow >= 1 ? so[r] : 0.0f;
+    hb_stage_value(tile_base, j, srow >= 1 ? 15 + srow : 31, srow >= 1 ? so[r] : 0.0f);
   }
 }
 
@@ -1356,8 +1433,8 @@ __global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_nerf_head_bwd
   const int64_t n_rounds = (n_tiles + per_round - 1) / per_round;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   f32x4 acc[5] = {zero4, zero4, zero4, zero4, zero4};
-  float* my_g = gS + wave * kHbTileFloats;
-  float* my_x = xS + wave * kHbTileFloats;
+  HbStage* my_g = hb_my_tile(gS, wave);
+  HbStage* my_x = hb_my_tile(xS, wave);
   const int ot = wave >> 1, it0 = 2 * (wave & 1), it1 = it0 + 1;
   for (int64_t round = 0; round < n_rounds; ++round) {
     const int64_t tile = round * per_round + (int64_t)blockIdx.x * kHbWaves + wave;
