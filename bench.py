@@ -150,7 +150,7 @@ def train_probe(dev, rank=0, world=1, red_dev=None, steps=20, warmup=5, stage="i
     import torch.distributed as dist
     from instance_nerf_amd.nerf import NeRFNetwork
     from instance_nerf_amd.nerf.provider import SyntheticRoomDataset
-    from instance_nerf_amd.nerf.utils import Trainer
+    from instance_nerf_amd.nerf.utils import Trainer, grad_sync as _grad_sync
     torch.manual_seed(0)                   # replicated initial parameters
     net = NeRFNetwork(cuda_ray=True, bound=1, min_near=0.05, density_thresh=10,
                       num_instances=64 if stage == "instance" else 0).to(dev)
@@ -312,6 +312,8 @@ def train_probe(dev, rank=0, world=1, red_dev=None, steps=20, warmup=5, stage="i
             "samples_per_step": int(n_all) // steps,
             "msamples_per_s": round(n_all / steps / dt / 1e6, 2),
             "allreduce_mb_per_step": round(reduced / 1e6, 1) if world > 1 else 0.0,
+            "gradient_schedule": (f"{_grad_sync.schedule}, payload {_grad_sync.payload}, "
+                                  f"{'started inside the backward' if _grad_sync.enabled else 'after the backward'}") if world > 1 else None,
             "occupancy_updates_in_timed_steps": n_upd, "roofline": roofline,
             "ms_per_step_of_both_timed_regions": [round(r[0] / steps * 1e3, 3) for r in regions],
             "loss_first": round(first, 4), "loss_last": round(float(last), 4)}
