@@ -534,9 +534,21 @@ __device__ __forceinline__ int march_ray_coop(const MarchParams& P, const Ray& r
   while (t < far && n < max_emit) {                       // wave-uniform
     // candidate of this lane: `lane` sequential additions, exactly the serial accumulation
     float c = t;
-    if (P.dt_gamma == 0.0f) {          // constant step (indoor scenes): clamp(c * 0) is dt_min for every c - two
-      const float dt0 = step_dt(P, t);  // instructions per addition instead of five, the same sums (x + 0 = x)
-      for (int j = 0; j < 63; ++j) c = c + (j < lane ? dt0 : 0.0f);
+    if (P.dt_gamma == 0.0f) {
+      // constant step (indoor scenes): clamp(c * 0) is dt_min for every c.  The chain runs along the wave: each
+      // wave_shr:1 addition gives lane j (j >= 1) the value of lane j-1 plus dt0 and leaves lane 0 (no source lane:
+      // disabled) at t, so after 63 of them lane j holds t after j sequential additions - one VALU instruction per
+      // addition where compare + select + add took three (the kernel is issue bound: 4 waves per SIMD, and 73 % of
+      // its vector instructions were this chain; profiles/r03_NOTES.txt 20).  All 64 lanes are active here (the
+      // callers branch per wave); s_nop 1 covers the two wait states a DPP read needs after a VALU write.
+      const float dt0 = step_dt(P, t);
+      asm volatile(
+          ".rept 63\n"
+          "s_nop 1\n"
+          "v_add_f32_dpp %0, %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf\n"
+          ".endr\n"
+          : "+v"(c)
+          : "v"(dt0));
     } else {
       for (int j = 0; j < 63; ++j) c = j < lane ? c + step_dt(P, c) : c;
     }
@@ -571,13 +583,34 @@ __device__ __forceinline__ int march_ray_coop(const MarchParams& P, const Ray& r
     // a miss continues at the first later candidate that is not below tt (do { t += dt } while (t < tt));
     // candidates increase with the lane, so a binary search over the lanes finds it (64 = beyond this window)
     int lo = lane + 1, hi = 64;
+    bool settled_all = false;
+    if (P.dt_gamma == 0.0f) {
+      // constant step: the candidates are c + k * dt up to rounding (far below one step over 64 additions), so
+      // the landing lane is lane + floor((tt - c) / dt) or the one after it.  Three independent lane reads check
+      // that guess against the very predicate of the search (c_i < tt); any lane it does not settle sends the
+      // wave through the search below - the estimate only ever saves time, it never decides a sample.
+      const int i0 = lane + (int)fminf((tt - c) * (1.0f / dt), 64.0f);          // lane .. lane + 64
+      const float ca = __shfl(c, clampi(i0 - 1, 0, 63), 64);
+      const float cb = __shfl(c, min(i0, 63), 64);
+      const float cc = __shfl(c, min(i0 + 1, 63), 64);
+      const bool lt_a = i0 - 1 <= lane || ca < tt;
+      const bool ge_b = i0 >= 64 || !(cb < tt);
+      const bool ge_c = i0 + 1 >= 64 || !(cc < tt);
+      const bool take_b = i0 > lane && ge_b;
+      const bool settled = take_b ? lt_a : ge_c;
+      lo = take_b ? min(i0, 64) : i0 + 1;
+      settled_all = __ballot(in && !occ && !settled) == 0;
+    }
+    if (!settled_all) {                                    // wave-uniform
+      lo = lane + 1;
 #pragma unroll
-    for (int it = 0; it < 7; ++it) {
-      const int mid = (lo + hi) >> 1;
-      const float cm = __shfl(c, min(mid, 63), 64);
-      const bool below = mid < 64 && cm < tt;
-      if (lo < hi) {
-        if (below) lo = mid + 1; else hi = mid;
+      for (int it = 0; it < 7; ++it) {
+        const int mid = (lo + hi) >> 1;
+        const float cm = __shfl(c, min(mid, 63), 64);
+        const bool below = mid < 64 && cm < tt;
+        if (lo < hi) {
+          if (below) lo = mid + 1; else hi = mid;
+        }
       }
     }
     const int next = lo;

@@ -79,6 +79,22 @@ class NeRFRenderer(nn.Module):
             self.local_step = 0
             self.last_counter = None     # (total samples, N) int32 view of the march the last training render consumed
 
+    # ``mean_density`` (upstream: a float set by every occupancy update) is a host float that the update leaves on the
+    # device until somebody asks: the bit field's threshold min(mean, density_thresh) is formed on the device, so the
+    # training loop never needs the number and the update ends without waiting for its own kernels.
+    @property
+    def mean_density(self):
+        pending = self.__dict__.get("_mean_density_dev")
+        if pending is not None:
+            self.__dict__["_mean_density"] = float(pending[0].item())
+            self.__dict__["_mean_density_dev"] = None
+        return self.__dict__.get("_mean_density", 0)
+
+    @mean_density.setter
+    def mean_density(self, value):
+        self.__dict__["_mean_density_dev"] = None
+        self.__dict__["_mean_density"] = value
+
     # subclass API ---------------------------------------------------------------------------
     def forward(self, x, d):
         raise NotImplementedError()
@@ -537,8 +553,12 @@ class NeRFRenderer(nn.Module):
         random cells plus H^3/4 random occupied cells per cascade.  All on the device: query positions
         (inr_occ_cell_positions, Morton order), sigma through the fused field kernel, EMA-max + mean
         (inr_occ_update) and the bitfield with its threshold min(mean, density_thresh) formed on the device
-        (inr_packbits_mean); ONE host read-back per call (mean density and the sample counters that size the next
-        16 steps' buffers together).  ``S`` is accepted for upstream's signature; nothing is chunked here."""
+        (inr_packbits_mean).  The host needs ONE number back, the mean sample count that sizes the next 16 steps'
+        buffers, and the counters it comes from are final before the update starts: their read-back is queued first
+        and waited for last, so the call returns with its kernels still queued and the next step is enqueued under
+        them (waiting for the update's own result left the device idle for ~0.3 ms while the host caught up;
+        profiles/r03_NOTES.txt 20).  The mean density stays on the device until it is asked for (``mean_density``).
+        ``S`` is accepted for upstream's signature; nothing is chunked here."""
         if not self.cuda_ray:
             return
         lib = _lib.load()
@@ -546,6 +566,15 @@ class NeRFRenderer(nn.Module):
         H, C = self.grid_size, self.cascade
         n_cells = H ** 3
         st = stream_ptr()
+        total_step = min(16, self.local_step)
+        counted = None
+        if total_step > 0:
+            host = self.__dict__.get("_count_host")
+            if host is None:
+                host = self.__dict__["_count_host"] = torch.empty(1, dtype=torch.int64).pin_memory()
+            host.copy_(self.step_counter[:total_step, 0].sum(0, keepdim=True, dtype=torch.int64), non_blocking=True)
+            counted = torch.cuda.Event()
+            counted.record()
         mean_sum = torch.zeros(1, dtype=torch.float64, device=dev)
         grid = self.density_grid
         full = self.iter_density < 16
@@ -575,18 +604,16 @@ class NeRFRenderer(nn.Module):
                                      ptr(idx, torch.int32, "morton_idx", allow_none=True), n_cells, m, float(decay),
                                      float(self.density_scale), ptr(tmp, allow_none=True), ptr(mean_sum), st),
                   "occ_update")
-        total_step = min(16, self.local_step)
         stats = torch.empty(2, dtype=torch.float64, device=dev)
         check(lib.inr_packbits_mean(ptr(grid, torch.float32, "density_grid"), C * n_cells, ptr(mean_sum),
                                     float(self.density_thresh), ptr(self.density_bitfield, torch.uint8, "density_bitfield"),
                                     None, ptr(self.step_counter, torch.int32, "step_counter"), max(total_step, 1),
                                     self.step_counter.stride(0), ptr(stats), st), "packbits_mean")
         self.iter_density += 1
-        # one read-back: [mean density, sum of the sample totals of the last steps]
-        host = stats.cpu()
-        self.mean_density = float(host[0])
-        if total_step > 0:
-            self.mean_count = int(float(host[1]) / total_step)
+        self.__dict__["_mean_density_dev"] = stats         # [mean density, sum of the sample totals]: read on demand
+        if counted is not None:
+            counted.synchronize()                          # reached before the first kernel of this update ran
+            self.mean_count = int(float(host[0]) / total_step)
         self.local_step = 0
 
     # ----------------------------------------------------------------------------------------
