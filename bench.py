@@ -140,6 +140,85 @@ def cpu_baseline(room, net, frame0=None, chunk=16384, budget_s=12.0, max_chunks=
     return base, parity
 
 
+class SclkSampler:
+    """Shader clock of THIS GPU while the timed region runs (sysfs pp_dpm_sclk of the card with the device's PCI
+    address, one 30-byte read every 10 ms on a side thread).  The field kernel's time follows the clock one for one
+    (tools/placement_probe.py), and the boxes are GPUs of shared 8-GPU nodes whose clock under this load sits
+    anywhere between ~1.95 and ~2.15 GHz depending on the node's power / thermal state: the line says which it was."""
+
+    def __init__(self, dev):
+        import glob
+        self.path, self.seen, self._stop, self._thread = None, [], None, None
+        try:
+            pr = torch.cuda.get_device_properties(dev)
+            want = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}."
+            for f in glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"):
+                if want in os.path.realpath(os.path.dirname(f)):
+                    self.path = f
+        except Exception:                                  # noqa: BLE001 - a diagnostic, never a reason to fail
+            self.path = None
+
+    def _read(self):
+        for line in open(self.path).read().splitlines():
+            if line.rstrip().endswith("*"):
+                return int(line.split(":")[1].lower().split("mhz")[0])
+        return None
+
+    def _hwmon(self):
+        """socket power (W) and the temperatures the card's hwmon node reports (deg C), read once after the region"""
+        import glob
+        out = {}
+        base = os.path.dirname(self.path)
+        for f in glob.glob(os.path.join(base, "hwmon", "hwmon*", "power1_average")):
+            out["power_w"] = round(int(open(f).read()) / 1e6, 1)
+        for f in sorted(glob.glob(os.path.join(base, "hwmon", "hwmon*", "temp*_input"))):
+            lab = f.replace("_input", "_label")
+            name = open(lab).read().strip() if os.path.exists(lab) else os.path.basename(f)[:5]
+            out["temp_c_" + name] = round(int(open(f).read()) / 1e3, 1)
+        for clk in ("mclk", "fclk", "socclk"):
+            try:
+                for line in open(os.path.join(base, "pp_dpm_" + clk)).read().splitlines():
+                    if line.rstrip().endswith("*"):
+                        out[clk + "_mhz"] = int(line.split(":")[1].lower().split("mhz")[0])
+            except Exception:                              # noqa: BLE001
+                pass
+        return out
+
+    def start(self):
+        if self.path is None:
+            return
+        import threading
+        self._stop = threading.Event()
+
+        def loop():
+            while not self._stop.is_set():
+                try:
+                    v = self._read()
+                    if v:
+                        self.seen.append(v)
+                except Exception:                          # noqa: BLE001
+                    pass
+                self._stop.wait(0.01)
+        self._thread = threading.Thread(target=loop, daemon=True)
+        self._thread.start()
+
+    def stop(self):
+        if self._thread is None:
+            return None
+        self._stop.set()
+        self._thread.join()
+        v = sorted(self.seen)
+        if not v:
+            return None
+        try:
+            extra = self._hwmon()
+        except Exception:                                  # noqa: BLE001
+            extra = {}
+        return {"sclk_mhz_median": v[len(v) // 2], "sclk_mhz_min": v[0], "sclk_mhz_max": v[-1], "samples": len(v), **extra,
+                "source": "pp_dpm_sclk of this GPU, every 10 ms of the timed region; the field kernel's time follows "
+                          "it one for one (profiles/r03_NOTES.txt 21)"}
+
+
 def train_probe(dev, rank=0, world=1, red_dev=None, steps=20, warmup=5, stage="instance"):
     """Secondary measurement (not the headline value): instance-field training step, BASELINE configs[2]
     (K=64 logits, 4096 rays/batch per GPU, NeRF frozen): march -> frozen NeRF (fused) -> instance grid encode ->
@@ -720,9 +799,12 @@ def main():
         step(i)
     gc.collect()
     gc.disable()               # no collector pause inside the timed region (a frame is 6 ms, a gen-2 pass ~10 ms)
+    sclk = SclkSampler(dev) if rank == 0 else None
     barrier()
     ev_pairs.clear()
     counters = []
+    if sclk is not None:
+        sclk.start()
     t0 = time.perf_counter()
     for i in range(args.steps):
         out = step(args.warmup + i)
@@ -730,6 +812,7 @@ def main():
         counters.append(out["num_evaluated"] if "num_evaluated" in out else out["num_samples"])
     barrier()
     elapsed = time.perf_counter() - t0
+    clocks = sclk.stop() if sclk is not None else None
     gc.enable()
 
     n_samples = int(sum(int(c[0]) for c in counters))
@@ -769,6 +852,7 @@ def main():
                          "kernel": "k_nerf_fwd<true,true> (fused hash gather + SH table + MLP)",
                          "avg_launch_ms": round(avg_kernel_s * 1e3, 4), "launches": n_launch,
                          "algorithmic_bytes_per_sample": BYTES_PER_SAMPLE},
+            "clocks": clocks,
         }
         if args.pipeline_probe and not args.pipeline:
             # the same frames with the march of view i+1 under the field kernel of view i (FramePipeline): reported

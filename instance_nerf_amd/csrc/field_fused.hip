@@ -24,6 +24,9 @@
 //
 // Compiled with -ffp-contract=off (cell selection is the oracle's decision); blending and the
 // MFMA chain are explicit fmaf / MFMA.
+#include <atomic>
+#include <mutex>
+
 #include "common.h"
 #include "grid_common.h"
 
@@ -541,13 +544,25 @@ __device__ __forceinline__ void load_tile_in(const float* __restrict__ x, const 
 // after the last complete round of eight chunks is split into eighths as before, so the counts stay equal.  Launches
 // with fewer than four rounds (training batches: random rays, no regional structure) keep the contiguous split.
 constexpr int kXcdChunkLog2 = 10;
+#ifndef INR_STEAL_SHIFT
+#define INR_STEAL_SHIFT 1
+#endif
+constexpr int kStealRoundsShift = INR_STEAL_SHIFT;     // hybrid schedule: the last rounds >> shift rounds are drawn (TileWalk)
 struct TileSched {
   int64_t lo, hi;      // hi: one past the last tile this wave may take
   int64_t first;       // first tile (contiguous split) or first XCD-local index (interleaved split)
   int64_t stride;      // distance between consecutive tiles / local indices of this wave
   int64_t main_local = 0, tail_base = 0;   // interleaved split: local indices below main_local map into the chunked part
+  int64_t n_main = 0, tail = 0;            // tiles in complete rounds of eight chunks / behind them (interleaved split)
+  int64_t static_local = 0;                // hybrid: local indices from here on are handed out by cursors (TileWalk)
   uint32_t xcd = 0;
-  bool interleaved = false;
+  bool interleaved = false, hybrid = false;
+  // local index u of XCD y -> tile; one past XCD y's last local index
+  __device__ __forceinline__ int64_t tile_of(int y, int64_t u) const {
+    if (u < main_local) return ((((u >> kXcdChunkLog2) << 3) + y) << kXcdChunkLog2) + (u & ((1 << kXcdChunkLog2) - 1));
+    return n_main + tail * y / 8 + (u - main_local);
+  }
+  __device__ __forceinline__ int64_t local_end(int y) const { return main_local + tail * (y + 1) / 8 - tail * y / 8; }
   __device__ __forceinline__ int64_t tile(int64_t i) const {
     if (interleaved) {
       const int64_t u = first + i * stride;
@@ -558,7 +573,7 @@ struct TileSched {
     return first + i * stride;
   }
 };
-__device__ __forceinline__ TileSched make_sched(int64_t n_tiles, int waves_per_block) {
+__device__ __forceinline__ TileSched make_sched(int64_t n_tiles, int waves_per_block, bool steal = false) {
   const int nb = gridDim.x, b = blockIdx.x;
   const int w = threadIdx.x >> 6;
   TileSched s;
@@ -570,6 +585,10 @@ __device__ __forceinline__ TileSched make_sched(int64_t n_tiles, int waves_per_b
       s.interleaved = true;
       s.xcd = (uint32_t)xcd;
       s.main_local = rounds << kXcdChunkLog2;
+      s.n_main = n_main;
+      s.tail = tail;
+      s.hybrid = steal;
+      s.static_local = steal ? (rounds - max((int64_t)1, rounds >> kStealRoundsShift)) << kXcdChunkLog2 : s.main_local;
       s.tail_base = n_main + tail * xcd / 8;
       s.lo = 0;
       s.hi = n_main + tail * (xcd + 1) / 8;
@@ -627,6 +646,98 @@ struct GroupDraw {
   // called by ONE lane: the first of the kGroupDraw consecutive groups it now owns
   __device__ __forceinline__ int64_t draw() const { return group_of((uint32_t)atomicAdd(cursor, (unsigned long long)kGroupDraw)); }
 };
+// HYBRID schedule of the big field launches (frames): equal shares per XCD are equal WORK only while the eight XCDs
+// run at the same speed, and on some boxes they do not - the same build, the same frame: 4.6 ms on one call, 5.1 ms on
+// another, the trained scene 11.6 against 15.0 ms, while the kernels that draw their work (k_nerf_render,
+// k_instance_render) and the ones that are not bound by the memory path (-O numerics) read the same on both
+// (profiles/r03_NOTES.txt 21): with a static deal the launch waits for its slowest XCD.  So the second half of the
+// rounds (and the ragged tail) is not dealt but DRAWN: every XCD's part of it sits behind kStealPools cursors
+// (blocks of 64 local tiles dealt round robin to the pools, kStealDraw tiles per draw, the next draw in flight while
+// the current tiles are evaluated), a wave draws from the cursor of its own XCD and pool, and when that runs dry it
+// looks at all cursors at once (one 256-byte load) and moves to the first live one - its XCD's other pools first, then
+// the next XCD's.  A fast XCD finishes its own part early and takes over what a slow one has left; with equal XCDs
+// the drawn part is the same tiles in the same windows as before.  Cursors are zeroed by the launcher; nullptr (all
+// other launches) is the static schedule.  Any order gives the same results: a tile's outputs depend on nothing else.
+// Measured (view 0, 37 M samples, tools/field_probe.py on the profiling builds of tools/build_probe.py): static deal
+// 5.12 ms, a quarter / half / all of the rounds drawn 4.88 / 4.85 / 4.91 ms; with one XCD made ~64 % slower
+// (s_sleep per tile) 8.51 / 6.35 / 5.17 / 5.23 ms - half it is (kStealRoundsShift = 1).
+constexpr int kStealPools = 4, kStealOwners = 8 * kStealPools, kStealDraw = 4, kStealBlockLog2 = 6;
+struct TileWalk {
+  TileSched s;
+  unsigned long long* cur;
+  int lane, own, owner, sub;
+  int64_t it, k_base;
+  unsigned long long raw_next;           // the draw in flight (lane 0), not looked at until it is needed
+  bool dyn;
+  __device__ __forceinline__ void init(const TileSched& sched, unsigned long long* cursors) {
+    s = sched; cur = cursors; lane = threadIdx.x & 63; it = 0; dyn = false; sub = kStealDraw; k_base = 0; raw_next = 0;
+    own = owner = (int)(((blockIdx.x >> 3) % kStealPools) * 8 + (blockIdx.x & 7));
+    if (!cursors) s.hybrid = false;
+    if (!s.hybrid) s.static_local = s.main_local;
+  }
+  // owner o = pool * 8 + xcd: number of cursor positions that map to local indices below the XCD's end (a multiple of
+  // the block), and the local index of position k
+  __device__ __forceinline__ int64_t pool_len(int o) const {
+    const int64_t nb = (s.local_end(o & 7) - s.static_local + (1 << kStealBlockLog2) - 1) >> kStealBlockLog2;
+    const int p = o >> 3;
+    return nb > p ? ((nb - p + kStealPools - 1) / kStealPools) << kStealBlockLog2 : 0;
+  }
+  __device__ __forceinline__ int64_t local_of(int o, int64_t k) const {
+    return s.static_local + ((((k >> kStealBlockLog2) * kStealPools) + (o >> 3)) << kStealBlockLog2) +
+           (k & ((1 << kStealBlockLog2) - 1));
+  }
+  __device__ __forceinline__ unsigned long long issue(int o) const {
+    unsigned long long v = 0;
+    if (lane == 0) v = atomicAdd(cur + o, (unsigned long long)kStealDraw);
+    return v;
+  }
+  __device__ __forceinline__ static int64_t uniform(unsigned long long v) {
+    return (int64_t)(((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+                     (uint32_t)__builtin_amdgcn_readfirstlane((int)v));
+  }
+  // first live owner in this wave's order (own XCD's pools, then the following XCDs'), -1: every cursor has run dry
+  __device__ __forceinline__ int scan() const {
+    bool live = false;
+    if (lane < kStealOwners) live = (int64_t)__hip_atomic_load(cur + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < pool_len(lane);
+    const uint32_t mask = (uint32_t)__ballot(live);
+    for (int i = 0; i < kStealOwners; ++i) {
+      const int o = (((own >> 3) + i) % kStealPools) * 8 + (((own & 7) + i / kStealPools) & 7);
+      if ((mask >> o) & 1u) return o;
+    }
+    return -1;
+  }
+  // the wave's next tile, -1 when there is none
+  __device__ __forceinline__ int64_t next() {
+    if (!dyn) {
+      if (!s.hybrid) {
+        const int64_t t = s.tile(it++);
+        return t < s.hi ? t : -1;
+      }
+      const int64_t u = s.first + (it++) * s.stride;
+      if (u < s.static_local) return s.tile_of((int)s.xcd, u);
+      dyn = true;
+      raw_next = issue(owner);
+    }
+    for (;;) {
+      if (sub < kStealDraw) {
+        const int64_t u = local_of(owner, k_base + sub);
+        ++sub;
+        if (u < s.local_end(owner & 7)) return s.tile_of(owner & 7, u);
+        continue;                                          // behind the ragged end of the XCD's part
+      }
+      int64_t k = uniform(raw_next);
+      while (k >= pool_len(owner)) {
+        const int o = scan();
+        if (o < 0) return -1;
+        owner = o;
+        k = uniform(issue(owner));
+      }
+      k_base = k;
+      sub = 0;
+      raw_next = issue(owner);
+    }
+  }
+};
 constexpr int kFieldMinWaves = 2;      // __launch_bounds__ second argument: <= 128 VGPRs
 
 // kTable: fused-frame fast path - x is already normalised to [0,1] by the march writer and the direction
@@ -657,7 +768,8 @@ __global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_nerf_fwd(cons
                                                                const float4* __restrict__ packed, float density_scale,
                                                                float* __restrict__ sigma, float* __restrict__ rgb,
                                                                float* __restrict__ geo, const int32_t* __restrict__ ray_ids,
-                                                               const float4* __restrict__ shq, NerfSave sv) {
+                                                               const float4* __restrict__ shq, NerfSave sv,
+                                                               unsigned long long* __restrict__ steal) {
   extern __shared__ __attribute__((aligned(16))) float4 wl[];
 #if INR_PROBE_MODE == 3
   const unsigned long long probe_t0 = wall_clock64();
@@ -678,7 +790,11 @@ __global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_nerf_fwd(cons
   const int64_t n_tiles = (n + 15) >> 4;
   const float rb = 2.0f * bound;
   const float rb_inv = 0.0f;
-  const TileSched sched = make_sched(n_tiles, kWaves);
+#if INR_PROBE_STATIC            // profiling builds (tools/build_probe.py): the static deal again / XCD 3 made slower
+  steal = nullptr;
+#endif
+  TileWalk walk;
+  walk.init(make_sched(n_tiles, kWaves, steal != nullptr), steal);
 
   const bool all_hashed[4] = {slot_all_hashed(G, 0), slot_all_hashed(G, 1), slot_all_hashed(G, 2), slot_all_hashed(G, 3)};
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)emb, 0, (int)emb_bytes, 0x00020000);
@@ -686,7 +802,10 @@ __global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_nerf_fwd(cons
   // (Requesting the NEXT tile's coordinates and ray id one tile ahead - so that neither the gather addresses nor the
   //  dependent direction-table load wait for a fresh trip through the memory system - was measured twice, in round 1
   //  on the plain feed and in round 2 on this table feed: 0 % and -2 %; removed.)
-  for (int64_t it = 0, tile = sched.tile(0); tile < sched.hi; tile = sched.tile(++it)) {
+  for (int64_t tile = walk.next(); tile >= 0; tile = walk.next()) {
+#if INR_PROBE_SLOW_XCD
+    if ((blockIdx.x & 7) == 3) __builtin_amdgcn_s_sleep(127);    // ~3 us per tile on one XCD: what does the schedule do?
+#endif
     const int64_t m = tile * 16 + j;
     const bool valid = m < n;
     TileIn me;
@@ -2027,6 +2146,35 @@ static int grid_for(Kern kern, size_t lds_bytes, int64_t n_tiles) {
   return (int)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)cus * per_cu));
 }
 
+// Cursors of the hybrid schedule (TileWalk): a ring of kStealRing sets per device, the next one zeroed on the launch's
+// stream right before the launch - launches on different streams (FramePipeline) never share a set unless more than
+// kStealRing field kernels are in flight at once.
+constexpr int kStealRing = 16;
+static unsigned long long* steal_cursors(hipStream_t s) {
+  static unsigned long long* ring[64] = {};
+  static std::atomic<unsigned> turn{0};
+  static std::mutex mu;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  if (!ring[dev]) {
+    std::lock_guard<std::mutex> lock(mu);
+    if (!ring[dev]) {
+      void* p = nullptr;
+      if (hipMalloc(&p, (size_t)kStealRing * kStealOwners * sizeof(unsigned long long)) != hipSuccess) {
+        set_error("hybrid schedule: hipMalloc of the cursor ring failed");
+        return nullptr;
+      }
+      ring[dev] = (unsigned long long*)p;
+    }
+  }
+  unsigned long long* p = ring[dev] + (size_t)(turn.fetch_add(1) % kStealRing) * kStealOwners;
+  if (hipMemsetAsync(p, 0, kStealOwners * sizeof(unsigned long long), s) != hipSuccess) {
+    set_error("hybrid schedule: hipMemsetAsync failed");
+    return nullptr;
+  }
+  return p;
+}
+
 }  // namespace inr
 
 using namespace inr;
@@ -2090,7 +2238,7 @@ int inr_nerf_forward_fast(const float* x, const float* d, int64_t M, const int32
   const int grid = grid_for(k_nerf_fwd<true, false, 0, true, true>, lds, (M + 15) / 16);
   k_nerf_fwd<true, false, 0, true, true><<<grid, kFieldThreads, lds, as_stream(s)>>>(
       x, d, M, n_samples_dev, bound, reinterpret_cast<const float2*>(embeddings_half), (uint32_t)emb_bytes64, G,
-      reinterpret_cast<const float4*>(packed_f16), density_scale, sigma, rgb, nullptr, nullptr, nullptr, NerfSave{});
+      reinterpret_cast<const float4*>(packed_f16), density_scale, sigma, rgb, nullptr, nullptr, nullptr, NerfSave{}, nullptr);
   return check_launch("nerf_forward_fast");
 #endif
 }
@@ -2113,16 +2261,22 @@ int inr_nerf_forward(const float* x, const float* d, int64_t M, const int32_t* n
   INR_REQUIRE(emb_bytes64 < (1ull << 31), "table larger than 2 GiB is not addressable by the 32-bit gather offsets");
   const uint32_t emb_bytes = (uint32_t)emb_bytes64;
   const int64_t n_tiles = (M + 15) / 16;
+  // frames and occupancy sweeps (four rounds of eight 1024-tile chunks and more): hybrid schedule, see TileWalk
+  unsigned long long* steal = nullptr;
+  if ((n_tiles >> (kXcdChunkLog2 + 3)) >= 4) {
+    steal = steal_cursors(as_stream(s));
+    if (!steal) return INR_ELAUNCH;
+  }
   if (rgb) {
     const size_t lds = kNerfFloats * sizeof(float) + kLevelRecBytes;
     const int grid = grid_for(k_nerf_fwd<true>, lds, n_tiles);
     k_nerf_fwd<true><<<grid, kFieldThreads, lds, as_stream(s)>>>(x, d, M, n_samples_dev, bound, e, emb_bytes, G, p,
-                                                      density_scale, sigma, rgb, geo_feat, nullptr, nullptr, NerfSave{});
+                                                      density_scale, sigma, rgb, geo_feat, nullptr, nullptr, NerfSave{}, steal);
   } else {
     const size_t lds = kCol0 * sizeof(float) + kLevelRecBytes;
     const int grid = grid_for(k_nerf_fwd<false>, lds, n_tiles);
     k_nerf_fwd<false><<<grid, kFieldThreads, lds, as_stream(s)>>>(x, d, M, n_samples_dev, bound, e, emb_bytes, G, p,
-                                                       density_scale, sigma, nullptr, geo_feat, nullptr, nullptr, NerfSave{});
+                                                       density_scale, sigma, nullptr, geo_feat, nullptr, nullptr, NerfSave{}, steal);
   }
   return check_launch("nerf_forward");
 }
@@ -2165,10 +2319,16 @@ static int launch_nerf_table(const float* x01, const int32_t* ray_ids, const flo
                              const void* embeddings, uint32_t emb_bytes, const GridDesc& G, const float* packed,
                              float density_scale, float* sigma, float* rgb, size_t lds, inr_stream_t s) {
   const int grid = grid_for(k_nerf_fwd<true, true, 0, kHalf, kFast>, lds, (M + 15) / 16);
+  // frames (four rounds of eight 1024-tile chunks and more) take the hybrid schedule: its cursors, zeroed on this stream
+  unsigned long long* steal = nullptr;
+  if ((((M + 15) / 16) >> (kXcdChunkLog2 + 3)) >= 4) {
+    steal = steal_cursors(as_stream(s));
+    if (!steal) return INR_ELAUNCH;
+  }
   k_nerf_fwd<true, true, 0, kHalf, kFast><<<grid, kFieldThreads, lds, as_stream(s)>>>(
       x01, nullptr, M, nullptr, bound, reinterpret_cast<const float2*>(embeddings), emb_bytes, G,
       reinterpret_cast<const float4*>(packed), density_scale, sigma, rgb, nullptr, ray_ids,
-      reinterpret_cast<const float4*>(sh_table_q), NerfSave{});
+      reinterpret_cast<const float4*>(sh_table_q), NerfSave{}, steal);
   return check_launch("nerf_forward_table");
 }
 }  // extern "C++"
@@ -2434,7 +2594,7 @@ int inr_nerf_forward_train(const float* x, const float* d, int64_t M, float boun
   k_nerf_fwd<true, false, 1><<<grid, kFieldThreads, lds, as_stream(s)>>>(
       x, d, M, nullptr, bound, reinterpret_cast<const float2*>(embeddings), (uint32_t)emb_bytes64, G,
       reinterpret_cast<const float4*>(packed), 1.0f, sigma, rgb, nullptr, nullptr, nullptr,
-      NerfSave{enc, h1, so, cin, c1, c2});
+      NerfSave{enc, h1, so, cin, c1, c2}, nullptr);
   return check_launch("nerf_forward_train");
 }
 
@@ -2456,7 +2616,7 @@ int inr_nerf_forward_enc(const float* x, const float* d, int64_t M, float bound,
   sv.enc = enc;
   k_nerf_fwd<true, false, 2><<<grid, kFieldThreads, lds, as_stream(s)>>>(
       x, d, M, nullptr, bound, reinterpret_cast<const float2*>(embeddings), (uint32_t)emb_bytes64, G,
-      reinterpret_cast<const float4*>(packed), 1.0f, sigma, rgb, nullptr, nullptr, nullptr, sv);
+      reinterpret_cast<const float4*>(packed), 1.0f, sigma, rgb, nullptr, nullptr, nullptr, sv, nullptr);
   return check_launch("nerf_forward_enc");
 }
 

@@ -817,6 +817,29 @@ def test_occupancy_update_matches_oracle(params_k16, level_table):
     assert not (diff & ~near).any()
 
 
+def test_occupancy_update_reads_back_the_sample_count_first_and_the_mean_on_demand(params_k16):
+    """update_extra_state sets ``mean_count`` from the counters of the steps before it (upstream: the mean of
+    step_counter[:total_step, 0]) and leaves the mean density on the device until ``mean_density`` is read; reading it
+    gives the number the bit field's threshold was formed from, and setting it (checkpoint load) overrides a pending one."""
+    net = _network(params_k16, K=0).train()
+    totals = [1000, 3000, 2001]
+    for i, t in enumerate(totals):
+        net.step_counter[i, 0] = t
+    net.local_step = len(totals)
+    net.update_extra_state()
+    assert net.mean_count == int(sum(totals) / len(totals)) and net.local_step == 0
+    pending = net.__dict__["_mean_density_dev"]
+    assert pending is not None and pending.is_cuda
+    expect = float(net.density_grid.clamp(min=0).double().mean())
+    assert abs(net.mean_density - expect) <= 1e-5 * expect
+    assert net.__dict__["_mean_density_dev"] is None and isinstance(net.mean_density, float)
+    assert float(pending[1]) == sum(totals)                # the kernel's own total agrees with the early read-back
+    net.update_extra_state()                               # no step in between: the count stays, the mean is pending
+    assert net.mean_count == int(sum(totals) / len(totals))
+    net.mean_density = 0.25
+    assert net.mean_density == 0.25 and net.__dict__["_mean_density_dev"] is None
+
+
 def test_occupancy_update_two_cascades_with_unseen_cells():
     """bound = 2 (two cascades, 64^3 grid, desired resolution 4096), cells marked -1 beforehand, density_scale != 1:
     the full sweep of update_extra_state (jitter disabled) against the oracle's update - grid, mean, bitfield."""

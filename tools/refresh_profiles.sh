@@ -23,6 +23,7 @@ cd $R
 bash tools/pmc_bench.sh ${TAG}_pmc > $O/pmc_bench.txt 2>&1
 python tools/traffic_json.py gpurun_out/${TAG}_pmc gpurun_out/${TAG}_pmc.hbm_rd.log $O/r03_traffic.json; echo "traffic rc=$?"
 bash tools/pmc_train.sh ${TAG}_pmct > $O/pmc_train.txt 2>&1; tail -25 $O/pmc_train.txt
+python tools/timed_launches.py $O/trace $O/bench_profiled.json > $O/bench_timed_launches.txt 2>&1
 python tools/step_launches.py $O/trace_inst > $O/launches_inst.txt 2>&1
 python tools/step_launches.py $O/trace_nerf > $O/launches_nerf.txt 2>&1
 ls $O
