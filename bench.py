@@ -142,9 +142,10 @@ def cpu_baseline(room, net, frame0=None, chunk=16384, budget_s=12.0, max_chunks=
 
 class SclkSampler:
     """Shader clock of THIS GPU while the timed region runs (sysfs pp_dpm_sclk of the card with the device's PCI
-    address, one 30-byte read every 10 ms on a side thread).  The field kernel's time follows the clock one for one
-    (tools/placement_probe.py), and the boxes are GPUs of shared 8-GPU nodes whose clock under this load sits
-    anywhere between ~1.95 and ~2.15 GHz depending on the node's power / thermal state: the line says which it was."""
+    address, one 30-byte read every 10 ms on a side thread), temperatures and the other clocks once after it.  The boxes
+    are GPUs of shared 8-GPU nodes; under this load the clock sits anywhere between ~1.95 and ~2.25 GHz.  Recorded
+    because about one call in three reads 10 % slower on the same build (profiles/r03_NOTES.txt 21) - these numbers
+    turned out NOT to tell the two kinds of call apart, which is worth knowing too."""
 
     def __init__(self, dev):
         import glob
@@ -215,8 +216,35 @@ class SclkSampler:
         except Exception:                                  # noqa: BLE001
             extra = {}
         return {"sclk_mhz_median": v[len(v) // 2], "sclk_mhz_min": v[0], "sclk_mhz_max": v[-1], "samples": len(v), **extra,
-                "source": "pp_dpm_sclk of this GPU, every 10 ms of the timed region; the field kernel's time follows "
-                          "it one for one (profiles/r03_NOTES.txt 21)"}
+                "source": "pp_dpm_sclk / hwmon of this GPU, sclk every 10 ms of the timed region; diagnostics for the "
+                          "run-to-run spread of profiles/r03_NOTES.txt 21 (which they do not explain)"}
+
+
+def xcd_map_probe():
+    """On which XCD did workgroup b of a 256 x 512-thread launch on THIS stream land (HW_REG_XCC_ID)?  The field kernels'
+    schedules take b % 8 (for locality only).  A diagnostic from tools/_probe/libxcdmap.so (tools/micro/xcd_map_probe.hip,
+    built by __graft_entry__.build()); None when it is not there."""
+    import ctypes
+    path = os.path.join(ROOT, "tools", "_probe", "libxcdmap.so")
+    if not os.path.exists(path):
+        return None
+    try:
+        lib = ctypes.CDLL(path)
+        lib.xcd_map.restype = ctypes.c_int
+        lib.xcd_map.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int32),
+                                ctypes.c_void_p]
+        blocks = torch.cuda.get_device_properties(0).multi_processor_count
+        out = (ctypes.c_int32 * blocks)()
+        st = torch.cuda.current_stream().cuda_stream
+        if lib.xcd_map(blocks, 512, 44 * 1024, 2000, out, ctypes.c_void_p(st)) != 0:
+            return None
+        ids = [v & 15 for v in out]
+        rot = [(ids[b] - b) % 8 for b in range(blocks)]
+        hist = [ids.count(x) for x in range(8)]
+        return {"xcd_of_block_is_block_mod_8_up_to_rotation": len(set(rot)) == 1, "rotation": rot[0] if len(set(rot)) == 1 else None,
+                "workgroups_per_xcd": hist, "first_16_blocks": ids[:16]}
+    except Exception as e:                                 # noqa: BLE001 - a diagnostic
+        return {"error": f"{type(e).__name__}: {e}"[:120]}
 
 
 def train_probe(dev, rank=0, world=1, red_dev=None, steps=20, warmup=5, stage="instance"):
@@ -814,6 +842,8 @@ def main():
     elapsed = time.perf_counter() - t0
     clocks = sclk.stop() if sclk is not None else None
     gc.enable()
+    if clocks is not None:
+        clocks["xcd_map"] = xcd_map_probe()
 
     n_samples = int(sum(int(c[0]) for c in counters))
     kernel_ms = sum(a.elapsed_time(b) for a, b, _ in ev_pairs)

@@ -205,7 +205,7 @@ class NeRFRenderer(nn.Module):
                              are opaque (measured 4x faster than "fused" on an opaque scene, 1.4x slower on a
                              transparent one)
           "auto" (default)   picks between the two from the fraction of samples the early-terminating kernel skips /
-                             would skip, as counted by the previous inference calls (> terminate_above = 0.28)
+                             would skip, as counted by the previous inference calls (> terminate_above = 0.35)
           "fused_raymajor" / "wavefront"   reference paths kept for parity tests (ray-major layout / upstream's loop)
 
         ce_labels (training, networks with an instance head; int64, one per ray): the cross entropy of the rendered
@@ -429,13 +429,15 @@ class NeRFRenderer(nn.Module):
     # wave owns a 16-ray group for all its steps, so the 256 waves of an XCD hold 256 patches at 256 different depths
     # where the two-kernel path holds a few patches' consecutive tiles: L2 miss rate 55 % against 37 %, measured -
     # profiles/r03_NOTES.txt section 13; 1.26-1.37x before the dynamic group schedule of round 3) and skips every step
-    # at which the whole group is below T_thresh, so it wins when it skips more than 17-21 % of the marched samples;
-    # 28 % is used (hysteresis against flapping).  The two-kernel path counts that fraction in its compositing kernel,
+    # at which the whole group is below T_thresh, so it wins when it skips more than 17-21 % of the marched samples -
+    # against the statically dealt two-kernel path; with its hybrid schedule (late round 3: frames 3 % faster, the
+    # trained scene 9 %) the ratio is 1.26-1.42x and the break-even 21-30 %: 35 % is used (margin against flapping).
+    # The two-kernel path counts that fraction in its compositing kernel,
     # the terminating kernel reports what it really evaluated.  (Round 1 switched on mean opacity > 0.5: a half-trained
     # scene - opacity 0.88, only 8 % skippable - then rendered in 20.5 ms instead of 14.4, r02 notes section 11.)  The
     # value travels to the host through a pinned buffer + event and is only read once its copy has completed: no call
     # waits for a previous frame.
-    terminate_above = 0.28
+    terminate_above = 0.35
 
     def _note_skippable(self, counter, total, counts_evaluated):
         """counter: the device counter of the frame (samples skippable / samples evaluated); total: marched samples, known

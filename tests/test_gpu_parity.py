@@ -1702,9 +1702,10 @@ def test_parameter_ema_inside_the_optimiser_launch():
                                8 * 524288 + 16 * 8191 + 15])
 def test_interleaved_xcd_schedule_covers_every_tile_once(params_k16, M):
     """From 32768 tiles on, the fused field kernels deal 1024-tile chunks of the tile stream round robin to the XCDs and
-    split what is left after the last complete round into eighths (field_fused.hip::make_sched).  Sizes around the
-    switch-over, with empty / tiny / ragged remainders: every sample is evaluated exactly once - the outputs equal the
-    evaluation in pieces that are too small for the interleaved schedule, bit for bit."""
+    split what is left after the last complete round into eighths (field_fused.hip::make_sched); the second half of the
+    rounds and the remainder are drawn from per-XCD cursors, with stealing (TileWalk).  Sizes around the switch-over,
+    with empty / tiny / ragged remainders: every sample is evaluated - the outputs equal the evaluation in pieces that
+    are too small for either schedule, bit for bit."""
     net = _network(params_k16, K=0).eval()
     g = torch.Generator(device=DEV).manual_seed(M)
     x = torch.rand(M, 3, device=DEV, generator=g) * 1.9 - 0.95
