@@ -721,8 +721,9 @@ def main():
     ap.add_argument("--train-steps", type=int, default=20, help="timed steps of the secondary training probes")
     ap.add_argument("--no-trained-scene", action="store_true", help="skip the trained-scene rendering leg (~15 s)")
     ap.add_argument("--pipeline-probe", action="store_true",
-                    help="also measure the same frames through FramePipeline (two streams) and report them as \"pipelined\"; "
-                         "off by default so that a kernel trace of the default command holds one-stream launches only")
+                    help="(default since late round 3; kept for old command lines) measure the same frames through "
+                         "FramePipeline (two streams) AFTER the headline's timed region and report them as \"pipelined\"")
+    ap.add_argument("--no-pipeline-probe", action="store_true", help="skip the \"pipelined\" object")
     ap.add_argument("--pipeline", type=int, default=0,
                     help="1: headline loop through FramePipeline (views alternate on two streams)")
     args = ap.parse_args()
@@ -884,7 +885,7 @@ def main():
                          "algorithmic_bytes_per_sample": BYTES_PER_SAMPLE},
             "clocks": clocks,
         }
-        if args.pipeline_probe and not args.pipeline:
+        if not args.no_pipeline_probe and not args.pipeline:
             # the same frames with the march of view i+1 under the field kernel of view i (FramePipeline): reported
             # beside the headline, which stays the one-stream loop the roofline figure is measured in
             try:

@@ -28,6 +28,5 @@ python tools/step_launches.py $O/trace_inst > $O/launches_inst.txt 2>&1
 python tools/step_launches.py $O/trace_nerf > $O/launches_nerf.txt 2>&1
 ls $O
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; tail -1 $O/smoke.txt
-python bench.py --pipeline-probe --no-cpu-baseline --no-train-probe --no-trained-scene > $O/bench_pipeline_probe.json 2>/dev/null
 NO_UPDATE=1 bash tools/pmc_train.sh ${TAG}_pmcn k_grid_bwd tools/train_nerf_probe.py > $O/pmc_train_nerf.txt 2>&1
 python tools/scatter_requests_json.py gpurun_out/${TAG}_pmct 207610 gpurun_out/${TAG}_pmcn 207610 $O/r03_scatter_requests.json > /dev/null; echo "scatter json rc=$?"

@@ -20,8 +20,9 @@ ms = [(e - s) / 1e6 for s, e in rows]
 d = json.loads(open(line).read().strip().splitlines()[-1])
 print(f"k_nerf_fwd<true,true,0,false,false> in the kernel trace of the profiled default command "
       f"(profiles/r03z_bench_kernel_stats.csv is the\n--stats summary of the same trace: its average runs over ALL "
-      f"{len(ms)} launches of the process - the headline's {warmup} warm-up + {steps} timed\nframes, the parity "
-      f"re-renders, the instance-render probe and the 72 M-sample frames of the trained-scene leg).")
+      f"{len(ms)} launches of the process - the headline's {warmup} warm-up + {steps} timed\nframes, the 25 frames of "
+      f"the two-stream `pipelined` leg right behind them, the parity re-renders, the instance-render probe and the\n"
+      f"72 M-sample frames of the trained-scene leg).")
 print("launch  ms")
 for i, t in enumerate(ms[:warmup + steps + 3]):
     tag = "   warm-up" if i < warmup else (f"   <- timed frame {i - warmup}" if i < warmup + steps else "")
