@@ -142,3 +142,30 @@ def test_render_sharded_world2(n):
     for p in procs:
         p.join(60)
     assert all(ok for _, ok in res)
+
+
+def test_bench_diagnostics_never_raise_without_a_gpu(tmp_path):
+    """bench.py's run-to-run diagnostics (`clocks`: shader clock sampled through sysfs, the XCD map of the process) are
+    decoration around the timed region: with no GPU, no sysfs node or no probe library they report nothing instead of
+    failing the run; the sysfs parser takes the starred line of a pp_dpm_sclk file."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    s = bench.SclkSampler("cpu")
+    assert s.path is None
+    s.start()
+    assert s.stop() is None
+    got = bench.xcd_map_probe()
+    assert got is None or "error" in got or "workgroups_per_xcd" in got
+    f = tmp_path / "pp_dpm_sclk"
+    f.write_text("0: 500Mhz\n1: 2151Mhz *\n2: 2400Mhz\n")
+    s.path = str(f)
+    assert s._read() == 2151
+    s.start()
+    import time
+    time.sleep(0.05)
+    out = s.stop()
+    assert out["sclk_mhz_median"] == 2151 and out["samples"] >= 1
