@@ -406,6 +406,11 @@ int inr_instance_forward(const float* x, int64_t M, const int32_t* n_samples_dev
  * (aligned=False, adaptive ceil(roi/out) sampling grid, average) on three axes: x<->W, y<->L, z<->H.
  * input [N,C,W,L,H], rois [K,6] = (x1,y1,z1,x2,y2,z2) in input-scale units, roi_inds int32 [K],
  * out [K,C,out_w,out_l,out_h].  backward ACCUMULATES into grad_input (caller zeroes it).          */
+/* No reference counterpart.  Which kernels the two calls below use: 0 (default) the separable ones (per-axis weight
+ * tables built once per RoI in LDS, z -> y -> x contraction, 4 channels per lane) whenever the tables fit the LDS
+ * window, 1 one lane per output element (the torchvision kernel shape; also the fallback), 2 separable or INR_EINVAL.
+ * Same sample geometry in both; sums differ by fp32 rounding.  Process-wide.                                        */
+int inr_roi_align_3d_set_mode(int32_t mode);
 int inr_roi_align_3d_forward(const float* input, const float* rois, const int32_t* roi_inds, int32_t N,
                              int32_t C, int32_t W, int32_t L, int32_t H, int64_t K, int32_t out_w,
                              int32_t out_l, int32_t out_h, float spatial_scale, float* out, inr_stream_t s);

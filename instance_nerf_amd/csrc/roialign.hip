@@ -3,7 +3,20 @@
 // model/poolers.py:144,174 and model/nerf_rcnn.py:831).  Semantics = torchvision roi_align
 // (aligned=False, adaptive ceil(roi/out) sampling grid, average pooling) on three axes, as the
 // reference's wrapper documents (utils.py:556-592); the extension itself is an un-vendored submodule.
-// HBM-bound trilinear gathers: one lane per output voxel, h (the contiguous axis of [N,C,W,L,H]) fastest.
+//
+// Two implementations, same sample geometry (float32, operation by operation as oracle/roialign.py):
+//  * SEPARABLE (round 4, the default): the op is linear and its sample weights factor per axis - a sample's
+//    trilinear weight is wx*wy*wz and its inside test is a conjunction of per-axis tests - so
+//        out[pw,pl,ph] = 1/count * sum_{x,y,z} Tx[pw][x] * Ty[pl][y] * Tz[ph][z] * in[x,y,z]
+//    with T_a[p][cell] = the summed lo/hi weights of output index p's grid samples on axis a.  A workgroup owns
+//    one RoI and a run of channels: it builds the three small tables ONCE in LDS (the torchvision kernel shape
+//    recomputes the geometry and 8 weights per sample PER CHANNEL), then per group of 4 channels contracts
+//    z (global loads, h is the contiguous axis of [N,C,W,L,H]) -> y (LDS) -> x (LDS -> registers) over x slabs
+//    and writes [K,C,ow*ol*oh] coalesced.  8 g^3 loads per output become ~(g+2) per axis pass: 24 000 -> ~4 000
+//    global loads per (RoI, channel) on BASELINE configs[4].  Workgroups are dealt so that the ones resident on
+//    an XCD at a time share ONE run of channels (2 MB of the volume: stays in that XCD's 4 MB L2).
+//  * one lane per output element (rounds 1-3, the torchvision kernel shape): kept for shapes whose tables do not
+//    fit the LDS budget and as the A/B the tests compare with (inr_roi_align_3d_set_mode).
 #include "common.h"
 
 namespace inr {
@@ -118,11 +131,435 @@ __global__ void __launch_bounds__(256) k_roi_align3d_bwd(const float* __restrict
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Separable implementation.
+// LDS image of one RoI (floats / ints, in this order):
+//   T[0] [ow][W], T[1] [ol][L], T[2] [oh][H]   dense per-axis weight rows over ABSOLUTE cell indices
+//   first/last cell of every row (ints; first > last: no sample of that output index lies inside the volume)
+//   (backward only) first/last output index of every cell
+//   tmp1, tmp2: the slab intermediates, SEP_CH channels interleaved (float4)
+constexpr int SEP_THREADS = 256;
+constexpr int SEP_CH = 4;            // channels a thread carries through every pass (weights and indices are shared)
+constexpr int SEP_TMP_FLOATS = 8192; // tmp1 + tmp2 budget per workgroup (32 KB): ~37 KB in all -> 4 workgroups per CU
+
+struct SepArgs {
+  int C, W, L, H, ow, ol, oh;
+  float scale;
+  int cpb;       // channels per workgroup (a multiple of SEP_CH)
+  int ngroups;   // ceil(C / cpb)
+  int K;
+  int tmp_floats;
+};
+
+struct SepRoi {       // in LDS
+  float start[3], bin[3];
+  int grid[3];
+  float inv_count;
+  int lo[3], hi[3];   // region of cells any output index touches (lo > hi: empty)
+};
+
+__device__ __forceinline__ int fdiv(int n, float inv) { return (int)(((float)n + 0.5f) * inv); }
+
+// Builds the per-axis tables of RoI k (all threads of the workgroup; ends with a barrier).
+// n[a] = volume extent, o[a] = output extent.  T rows are zero outside [first, last].
+__device__ __forceinline__ void sep_build_tables(const float* __restrict__ roi, const SepArgs& A, SepRoi* R,
+                                                 float* const T[3], int* const first[3], int* const last[3]) {
+  const int n[3] = {A.W, A.L, A.H};
+  const int o[3] = {A.ow, A.ol, A.oh};
+  const int t = threadIdx.x;
+  if (t < 3) {
+    // the same float32 operations, in the same order, as roi_geom() / oracle/roialign.py
+    const float s = roi[t] * A.scale, e = roi[t + 3] * A.scale;
+    const float size = fmaxf(e - s, 1.0f);
+    R->start[t] = s;
+    R->bin[t] = size / (float)o[t];
+    R->grid[t] = (int)ceilf(size / (float)o[t]);
+  }
+  const int ntab = o[0] * n[0] + o[1] * n[1] + o[2] * n[2];
+  for (int i = t; i < ntab; i += SEP_THREADS) T[0][i] = 0.0f;     // the three tables are contiguous
+  __syncthreads();
+  const int nrow = o[0] + o[1] + o[2];
+  for (int r = t; r < nrow; r += SEP_THREADS) {
+    const int a = r < o[0] ? 0 : (r < o[0] + o[1] ? 1 : 2);
+    const int p = r - (a == 0 ? 0 : (a == 1 ? o[0] : o[0] + o[1]));
+    const float start = R->start[a], bin = R->bin[a];
+    const int g = R->grid[a], na = n[a];
+    float* row = T[a] + p * na;
+    int f = na, l = -1;
+    for (int i = 0; i < g; ++i) {
+      const float v = start + p * bin + ((float)i + 0.5f) * bin / (float)g;
+      if (v < -1.0f || v > (float)na) continue;
+      float c = fmaxf(v, 0.0f);
+      int lo = (int)c, hi;
+      if (lo >= na - 1) { lo = hi = na - 1; c = (float)lo; } else { hi = lo + 1; }
+      const float fr = c - (float)lo;
+      row[lo] += 1.0f - fr;
+      row[hi] += fr;
+      f = min(f, lo);
+      l = max(l, hi);
+    }
+    first[a][p] = f;
+    last[a][p] = l;
+  }
+  __syncthreads();
+  if (t < 3) {
+    int lo = n[t], hi = -1;
+    for (int p = 0; p < o[t]; ++p) { lo = min(lo, first[t][p]); hi = max(hi, last[t][p]); }
+    R->lo[t] = lo;
+    R->hi[t] = hi;
+  }
+  if (t == 0) {
+    const int count = R->grid[0] * R->grid[1] * R->grid[2];
+    R->inv_count = 1.0f / (float)max(count, 1);
+  }
+  __syncthreads();
+}
+
+// Which (RoI, channel run) a workgroup owns: workgroups are dispatched round robin over the 8 XCDs, so
+// blockIdx % 8 is the XCD; within an XCD the RoI is the fast index and the channel run the slow one - the ~128
+// workgroups an XCD holds at a time read the same cpb channels of the volume (cpb * W*L*H*4 bytes: 2 MB for 8
+// channels of 40^3) out of its L2 instead of pulling every channel through the fabric once per RoI.
+__device__ __forceinline__ bool sep_assign(const SepArgs& A, int* k, int* c0) {
+  const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
+  const int gi = i / A.K;
+  const int grp = xcd + 8 * gi;
+  if (grp >= A.ngroups) return false;
+  *k = i - gi * A.K;
+  *c0 = grp * A.cpb;
+  return true;
+}
+
+template <int NOUT>   // output elements per thread: ow*ol*oh <= NOUT * SEP_THREADS
+__global__ void __launch_bounds__(SEP_THREADS) k_roi_align3d_sep_fwd(const float* __restrict__ in,
+                                                                     const float* __restrict__ rois,
+                                                                     const int32_t* __restrict__ roi_inds, SepArgs A,
+                                                                     float* __restrict__ out) {
+  extern __shared__ float4 lds4[];
+  int k, c0;
+  if (!sep_assign(A, &k, &c0)) return;
+  float* lds = reinterpret_cast<float*>(lds4);
+  const int t = threadIdx.x;
+  const int W = A.W, L = A.L, H = A.H, ow = A.ow, ol = A.ol, oh = A.oh;
+  float* T[3];
+  int* first[3];
+  int* last[3];
+  T[0] = lds; T[1] = T[0] + ow * W; T[2] = T[1] + ol * L;
+  int* ip = reinterpret_cast<int*>(T[2] + oh * H);
+  first[0] = ip; last[0] = first[0] + ow; first[1] = last[0] + ow; last[1] = first[1] + ol;
+  first[2] = last[1] + ol; last[2] = first[2] + oh;
+  SepRoi* R = reinterpret_cast<SepRoi*>(last[2] + oh);
+  float* tmpbase = reinterpret_cast<float*>(R + 1);
+  tmpbase = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(tmpbase) + 15) & ~(uintptr_t)15);
+
+  sep_build_tables(rois + (int64_t)k * 6, A, R, T, first, last);
+
+  const int olh = ol * oh, nout = ow * olh;
+  const int64_t WLH = (int64_t)W * L * H;
+  const int cend = min(c0 + A.cpb, A.C);
+  const int x0 = R->lo[0], y0 = R->lo[1], z0 = R->lo[2];
+  const int sx = R->hi[0] - x0 + 1, sy = R->hi[1] - y0 + 1, sz = R->hi[2] - z0 + 1;
+  float* obase = out + ((int64_t)k * A.C) * nout;
+  if (sx <= 0 || sy <= 0 || sz <= 0) {       // no sample inside the volume: zeros
+    for (int c = c0; c < cend; ++c)
+      for (int o = t; o < nout; o += SEP_THREADS) obase[(int64_t)c * nout + o] = 0.0f;
+    return;
+  }
+  const float inv_count = R->inv_count;
+  // x slab: XB planes at a time so that tmp1 [XB][sy][oh] + tmp2 [XB][ol][oh] (x SEP_CH) fit the budget
+  int XB = A.tmp_floats / (SEP_CH * (sy * oh + olh));
+  XB = max(1, min(XB, sx));
+  float4* tmp1 = reinterpret_cast<float4*>(tmpbase);
+  float4* tmp2 = tmp1 + XB * sy * oh;
+  const float inv_oh = 1.0f / (float)oh, inv_sy = 1.0f / (float)sy, inv_olh = 1.0f / (float)olh;
+
+  // the output elements this thread owns: pw (its x taps) and the (pl, ph) index r
+  int opw[NOUT], orr[NOUT], ofx[NOUT], olx[NOUT];
+#pragma unroll
+  for (int i = 0; i < NOUT; ++i) {
+    const int o = t + i * SEP_THREADS;
+    const int pw = o < nout ? fdiv(o, inv_olh) : 0;
+    opw[i] = pw;
+    orr[i] = o - pw * olh;
+    ofx[i] = o < nout ? first[0][pw] : 1;
+    olx[i] = o < nout ? last[0][pw] : 0;
+  }
+  const float* vol0 = in + ((int64_t)roi_inds[k] * A.C) * WLH;
+
+  for (int c = c0; c < cend; c += SEP_CH) {
+    // channel pointers (a run shorter than SEP_CH re-reads its last channel and skips the stores)
+    const float* vc[SEP_CH];
+#pragma unroll
+    for (int ch = 0; ch < SEP_CH; ++ch) vc[ch] = vol0 + (int64_t)min(c + ch, A.C - 1) * WLH;
+    float4 acc[NOUT];
+#pragma unroll
+    for (int i = 0; i < NOUT; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    for (int xs = 0; xs < sx; xs += XB) {
+      const int nx = min(XB, sx - xs);
+      // ---- pass 1 (z): tmp1[x][y][ph] = sum_z Tz[ph][z] * in[x0+xs+x][y0+y][z]
+      const int n1 = nx * sy * oh;
+      for (int item = t; item < n1; item += SEP_THREADS) {
+        const int row = fdiv(item, inv_oh), ph = item - row * oh;
+        const int x = fdiv(row, inv_sy), y = row - x * sy;
+        const int f = first[2][ph], l = last[2][ph];
+        const int base = ((x0 + xs + x) * L + (y0 + y)) * H;
+        const float* tz = T[2] + ph * H;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j0 = f; j0 <= l; j0 += 4) {
+          float w[4];
+          int cell[4];
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            cell[jj] = min(j0 + jj, H - 1);
+            w[jj] = (j0 + jj <= l) ? tz[cell[jj]] : 0.0f;
+          }
+          float v[SEP_CH][4];
+#pragma unroll
+          for (int ch = 0; ch < SEP_CH; ++ch)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) v[ch][jj] = vc[ch][base + cell[jj]];
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            a.x += w[jj] * v[0][jj];
+            a.y += w[jj] * v[1][jj];
+            a.z += w[jj] * v[2][jj];
+            a.w += w[jj] * v[3][jj];
+          }
+        }
+        tmp1[item] = a;
+      }
+      __syncthreads();
+      // ---- pass 2 (y): tmp2[x][pl][ph] = sum_y Ty[pl][y] * tmp1[x][y - y0][ph]
+      const int n2 = nx * olh;
+      for (int item = t; item < n2; item += SEP_THREADS) {
+        const int x = fdiv(item, inv_olh), r = item - x * olh;
+        const int pl = fdiv(r, inv_oh), ph = r - pl * oh;
+        const int f = first[1][pl], l = last[1][pl];
+        const float* ty = T[1] + pl * L;
+        const float4* src = tmp1 + (x * sy - y0) * oh + ph;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j0 = f; j0 <= l; j0 += 4) {
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            const int cell = min(j0 + jj, l);
+            const float w = (j0 + jj <= l) ? ty[cell] : 0.0f;
+            const float4 v = src[cell * oh];
+            a.x += w * v.x; a.y += w * v.y; a.z += w * v.z; a.w += w * v.w;
+          }
+        }
+        tmp2[item] = a;
+      }
+      __syncthreads();
+      // ---- pass 3 (x), this slab's share: acc[o] += sum_{x in slab} Tx[pw][x] * tmp2[x][pl][ph]
+      const int xlo = x0 + xs, xhi = x0 + xs + nx - 1;
+#pragma unroll
+      for (int i = 0; i < NOUT; ++i) {
+        const int f = max(ofx[i], xlo), l = min(olx[i], xhi);
+        const float* tx = T[0] + opw[i] * W;
+        const float4* src = tmp2 + orr[i] - xlo * olh;
+        for (int xx = f; xx <= l; ++xx) {
+          const float w = tx[xx];
+          const float4 v = src[xx * olh];
+          acc[i].x += w * v.x; acc[i].y += w * v.y; acc[i].z += w * v.z; acc[i].w += w * v.w;
+        }
+      }
+      // no barrier here: the next slab's pass 1 writes tmp1 only, and its barrier orders the writes of tmp2 behind
+      // these reads
+    }
+#pragma unroll
+    for (int i = 0; i < NOUT; ++i) {
+      const int o = t + i * SEP_THREADS;
+      if (o < nout) {
+        float* dst = obase + (int64_t)c * nout + o;
+        dst[0] = acc[i].x * inv_count;
+        if (c + 1 < cend) dst[nout] = acc[i].y * inv_count;
+        if (c + 2 < cend) dst[2 * (int64_t)nout] = acc[i].z * inv_count;
+        if (c + 3 < cend) dst[3 * (int64_t)nout] = acc[i].w * inv_count;
+      }
+    }
+    __syncthreads();   // tmp2 is rewritten by the next channel run's pass 2 only after ITS pass-1 barrier, but a
+                       // single-slab RoI of few items can let a fast wave get there first: keep the runs apart
+  }
+}
+
+// Backward = the transpose, pass by pass: gout [ow][ol][oh] -(x^T)-> [sx][ol][oh] -(y^T)-> [sx][sy][oh] -(z^T)->
+// [sx][sy][sz], added into grad_input with one atomic per touched cell and channel (the lane-per-output kernel
+// issues 8 g^3 per output element); lanes run along z, so the atomics of a wave hit adjacent addresses.
+__global__ void __launch_bounds__(SEP_THREADS) k_roi_align3d_sep_bwd(const float* __restrict__ gout,
+                                                                     const float* __restrict__ rois,
+                                                                     const int32_t* __restrict__ roi_inds, SepArgs A,
+                                                                     float* __restrict__ gin) {
+  extern __shared__ float4 lds4[];
+  int k, c0;
+  if (!sep_assign(A, &k, &c0)) return;
+  float* lds = reinterpret_cast<float*>(lds4);
+  const int t = threadIdx.x;
+  const int W = A.W, L = A.L, H = A.H, ow = A.ow, ol = A.ol, oh = A.oh;
+  float* T[3];
+  int* first[3];
+  int* last[3];
+  T[0] = lds; T[1] = T[0] + ow * W; T[2] = T[1] + ol * L;
+  int* ip = reinterpret_cast<int*>(T[2] + oh * H);
+  first[0] = ip; last[0] = first[0] + ow; first[1] = last[0] + ow; last[1] = first[1] + ol;
+  first[2] = last[1] + ol; last[2] = first[2] + oh;
+  // per cell: the output indices whose rows reach it (rows start and end monotonically in p)
+  int* pfirst[3];
+  int* plast[3];
+  pfirst[0] = last[2] + oh; plast[0] = pfirst[0] + W; pfirst[1] = plast[0] + W; plast[1] = pfirst[1] + L;
+  pfirst[2] = plast[1] + L; plast[2] = pfirst[2] + H;
+  SepRoi* R = reinterpret_cast<SepRoi*>(plast[2] + H);
+  float* tmpbase = reinterpret_cast<float*>(R + 1);
+  tmpbase = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(tmpbase) + 15) & ~(uintptr_t)15);
+
+  sep_build_tables(rois + (int64_t)k * 6, A, R, T, first, last);
+  {
+    const int n[3] = {W, L, H};
+    const int o[3] = {ow, ol, oh};
+    for (int r = t; r < W + L + H; r += SEP_THREADS) {
+      const int a = r < W ? 0 : (r < W + L ? 1 : 2);
+      const int cell = r - (a == 0 ? 0 : (a == 1 ? W : W + L));
+      int f = o[a], l = -1;
+      for (int p = 0; p < o[a]; ++p)
+        if (first[a][p] <= cell && cell <= last[a][p]) { f = min(f, p); l = max(l, p); }
+      pfirst[a][cell] = f;
+      plast[a][cell] = l;
+      (void)n;
+    }
+  }
+  __syncthreads();
+
+  const int olh = ol * oh, nout = ow * olh;
+  const int64_t WLH = (int64_t)W * L * H;
+  const int cend = min(c0 + A.cpb, A.C);
+  const int x0 = R->lo[0], y0 = R->lo[1], z0 = R->lo[2];
+  const int sx = R->hi[0] - x0 + 1, sy = R->hi[1] - y0 + 1, sz = R->hi[2] - z0 + 1;
+  if (sx <= 0 || sy <= 0 || sz <= 0) return;
+  const float inv_count = R->inv_count;
+  // LDS: go [ow][ol][oh], then per x slab t2 [XB][ol][oh] and t1 [XB][sy][oh]
+  float4* go = reinterpret_cast<float4*>(tmpbase);
+  int XB = (A.tmp_floats - SEP_CH * nout) / (SEP_CH * (sy * oh + olh));
+  XB = max(1, min(XB, sx));
+  float4* t2 = go + nout;
+  float4* t1 = t2 + XB * olh;
+  const float inv_oh = 1.0f / (float)oh, inv_sy = 1.0f / (float)sy, inv_olh = 1.0f / (float)olh,
+              inv_sz = 1.0f / (float)sz;
+  const float* gbase = gout + ((int64_t)k * A.C) * nout;
+  float* vol0 = gin + ((int64_t)roi_inds[k] * A.C) * WLH;
+
+  for (int c = c0; c < cend; c += SEP_CH) {
+    for (int o = t; o < nout; o += SEP_THREADS) {
+      const float* src = gbase + (int64_t)c * nout + o;
+      float4 g;
+      g.x = src[0] * inv_count;
+      g.y = c + 1 < cend ? src[nout] * inv_count : 0.0f;
+      g.z = c + 2 < cend ? src[2 * (int64_t)nout] * inv_count : 0.0f;
+      g.w = c + 3 < cend ? src[3 * (int64_t)nout] * inv_count : 0.0f;
+      go[o] = g;
+    }
+    __syncthreads();
+    for (int xs = 0; xs < sx; xs += XB) {
+      const int nx = min(XB, sx - xs);
+      // ---- x^T: t2[x][pl][ph] = sum_pw Tx[pw][x] * go[pw][pl][ph]
+      const int n2 = nx * olh;
+      for (int item = t; item < n2; item += SEP_THREADS) {
+        const int x = fdiv(item, inv_olh), r = item - x * olh;
+        const int cell = x0 + xs + x;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int p = pfirst[0][cell]; p <= plast[0][cell]; ++p) {
+          const float w = T[0][p * W + cell];
+          const float4 v = go[p * olh + r];
+          a.x += w * v.x; a.y += w * v.y; a.z += w * v.z; a.w += w * v.w;
+        }
+        t2[item] = a;
+      }
+      __syncthreads();
+      // ---- y^T: t1[x][y][ph] = sum_pl Ty[pl][y] * t2[x][pl][ph]
+      const int n1 = nx * sy * oh;
+      for (int item = t; item < n1; item += SEP_THREADS) {
+        const int row = fdiv(item, inv_oh), ph = item - row * oh;
+        const int x = fdiv(row, inv_sy), y = row - x * sy;
+        const int cell = y0 + y;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int p = pfirst[1][cell]; p <= plast[1][cell]; ++p) {
+          const float w = T[1][p * L + cell];
+          const float4 v = t2[(x * ol + p) * oh + ph];
+          a.x += w * v.x; a.y += w * v.y; a.z += w * v.z; a.w += w * v.w;
+        }
+        t1[item] = a;
+      }
+      __syncthreads();
+      // ---- z^T: grad_input[x][y][z] += sum_ph Tz[ph][z] * t1[x][y][ph]
+      const int n0 = nx * sy * sz;
+      for (int item = t; item < n0; item += SEP_THREADS) {
+        const int row = fdiv(item, inv_sz), z = item - row * sz;
+        const int x = fdiv(row, inv_sy), y = row - x * sy;
+        const int cell = z0 + z;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int p = pfirst[2][cell]; p <= plast[2][cell]; ++p) {
+          const float w = T[2][p * H + cell];
+          const float4 v = t1[row * oh + p];
+          a.x += w * v.x; a.y += w * v.y; a.z += w * v.z; a.w += w * v.w;
+        }
+        float* dst = vol0 + (int64_t)c * WLH + ((x0 + xs + x) * L + (y0 + y)) * H + cell;
+        atomicAdd(dst, a.x);
+        if (c + 1 < cend) atomicAdd(dst + WLH, a.y);
+        if (c + 2 < cend) atomicAdd(dst + 2 * WLH, a.z);
+        if (c + 3 < cend) atomicAdd(dst + 3 * WLH, a.w);
+      }
+      // t2 is rewritten by the next slab's first pass while slow waves may still read t1 here, never t2: fine; t1 is
+      // rewritten after that pass's barrier
+    }
+    __syncthreads();   // go is reloaded
+  }
+}
+
+static int g_roi_mode = 0;   // 0 auto, 1 one lane per output element, 2 separable (error if it does not fit)
+
+// LDS bytes of the separable kernels for these extents (0: does not fit the device's 64 KB default window)
+static int sep_lds_bytes(int W, int L, int H, int ow, int ol, int oh, bool bwd, int* tmp_floats) {
+  const int64_t tab = (int64_t)ow * W + (int64_t)ol * L + (int64_t)oh * H;
+  const int64_t ints = 2 * (int64_t)(ow + ol + oh) + (bwd ? 2 * (int64_t)(W + L + H) : 0);
+  const int64_t fixed = (tab + ints) * 4 + (int64_t)sizeof(SepRoi) + 16;
+  // one x plane of the widest region must fit: SEP_CH * (L*oh + ol*oh) floats (+ gout in the backward)
+  const int64_t need = (int64_t)SEP_CH * ((int64_t)L * oh + (int64_t)ol * oh) + (bwd ? (int64_t)SEP_CH * ow * ol * oh : 0);
+  int64_t tmp = std::max<int64_t>(need, SEP_TMP_FLOATS + (bwd ? (int64_t)SEP_CH * ow * ol * oh : 0));
+  const int64_t total = fixed + tmp * 4;
+  if (total > 64 * 1024) {
+    tmp = need;
+    if (fixed + tmp * 4 > 64 * 1024) return 0;
+  }
+  *tmp_floats = (int)tmp;
+  return (int)(fixed + tmp * 4);
+}
+
+static int sep_channels_per_block(int C, int64_t K) {
+  // enough workgroups to fill the chip several times over (256 CUs x 4 resident), whole SEP_CH runs
+  int cpb = 16;
+  while (cpb > SEP_CH && K * ((C + cpb - 1) / cpb) < 8192) cpb /= 2;
+  return cpb;
+}
+
+static bool sep_grid_fits(int C, int64_t K) {
+  if (K >= (1 << 24)) return false;
+  const int cpb = sep_channels_per_block(C, K);
+  const int64_t ngroups = (C + cpb - 1) / cpb;
+  return 8 * K * ((ngroups + 7) / 8) < (1ll << 31);
+}
+
 }  // namespace inr
 
 using namespace inr;
 
 extern "C" {
+
+int inr_roi_align_3d_set_mode(int32_t mode) {
+  if (mode < 0 || mode > 2) {
+    set_error("inr_roi_align_3d_set_mode: mode must be 0 (auto), 1 (lane per output) or 2 (separable)");
+    return INR_EINVAL;
+  }
+  g_roi_mode = mode;
+  return INR_OK;
+}
 
 int inr_roi_align_3d_forward(const float* input, const float* rois, const int32_t* roi_inds, int32_t N, int32_t C,
                              int32_t W, int32_t L, int32_t H, int64_t K, int32_t out_w, int32_t out_l, int32_t out_h,
@@ -130,7 +567,28 @@ int inr_roi_align_3d_forward(const float* input, const float* rois, const int32_
   INR_REQUIRE(K >= 0 && N >= 0 && C > 0 && W > 0 && L > 0 && H > 0 && out_w > 0 && out_l > 0 && out_h > 0, "bad sizes");
   if (K == 0) return INR_OK;
   INR_REQUIRE(input && rois && roi_inds && out && N > 0, "null pointer");
-  const int64_t total = K * C * out_w * out_l * out_h;
+  const int64_t nout = (int64_t)out_w * out_l * out_h;
+  const int64_t total = K * C * nout;
+  int tmp_floats = 0;
+  const int lds = (nout <= 16 * SEP_THREADS && sep_grid_fits(C, K) && (int64_t)W * L * H < (1ll << 30))
+                      ? sep_lds_bytes(W, L, H, out_w, out_l, out_h, false, &tmp_floats) : 0;
+  INR_REQUIRE(g_roi_mode != 2 || lds > 0, "separable kernel: tables do not fit the LDS window for these extents");
+  if (g_roi_mode != 1 && lds > 0) {
+    SepArgs A;
+    A.C = C; A.W = W; A.L = L; A.H = H; A.ow = out_w; A.ol = out_l; A.oh = out_h; A.scale = spatial_scale;
+    A.cpb = sep_channels_per_block(C, K);
+    A.ngroups = (C + A.cpb - 1) / A.cpb;
+    A.K = (int)K;
+    A.tmp_floats = tmp_floats;
+    const unsigned grid = 8u * (unsigned)K * (unsigned)((A.ngroups + 7) / 8);
+    if (nout <= 4 * SEP_THREADS)
+      k_roi_align3d_sep_fwd<4><<<grid, SEP_THREADS, lds, as_stream(s)>>>(input, rois, roi_inds, A, out);
+    else if (nout <= 8 * SEP_THREADS)
+      k_roi_align3d_sep_fwd<8><<<grid, SEP_THREADS, lds, as_stream(s)>>>(input, rois, roi_inds, A, out);
+    else
+      k_roi_align3d_sep_fwd<16><<<grid, SEP_THREADS, lds, as_stream(s)>>>(input, rois, roi_inds, A, out);
+    return check_launch("roi_align_3d_forward (separable)");
+  }
   k_roi_align3d_fwd<<<blocks_for(total, 256), 256, 0, as_stream(s)>>>(input, rois, roi_inds, C, W, L, H, total, out_w,
                                                                       out_l, out_h, spatial_scale, out);
   return check_launch("roi_align_3d_forward");
@@ -142,7 +600,23 @@ int inr_roi_align_3d_backward(const float* grad_out, const float* rois, const in
   INR_REQUIRE(K >= 0 && N >= 0 && C > 0 && W > 0 && L > 0 && H > 0 && out_w > 0 && out_l > 0 && out_h > 0, "bad sizes");
   if (K == 0) return INR_OK;
   INR_REQUIRE(grad_out && rois && roi_inds && grad_input && N > 0, "null pointer");
-  const int64_t total = K * C * out_w * out_l * out_h;
+  const int64_t nout = (int64_t)out_w * out_l * out_h;
+  const int64_t total = K * C * nout;
+  int tmp_floats = 0;
+  const int lds = (sep_grid_fits(C, K) && (int64_t)W * L * H < (1ll << 30))
+                      ? sep_lds_bytes(W, L, H, out_w, out_l, out_h, true, &tmp_floats) : 0;
+  INR_REQUIRE(g_roi_mode != 2 || lds > 0, "separable kernel: tables do not fit the LDS window for these extents");
+  if (g_roi_mode != 1 && lds > 0) {
+    SepArgs A;
+    A.C = C; A.W = W; A.L = L; A.H = H; A.ow = out_w; A.ol = out_l; A.oh = out_h; A.scale = spatial_scale;
+    A.cpb = sep_channels_per_block(C, K);
+    A.ngroups = (C + A.cpb - 1) / A.cpb;
+    A.K = (int)K;
+    A.tmp_floats = tmp_floats;
+    const unsigned grid = 8u * (unsigned)K * (unsigned)((A.ngroups + 7) / 8);
+    k_roi_align3d_sep_bwd<<<grid, SEP_THREADS, lds, as_stream(s)>>>(grad_out, rois, roi_inds, A, grad_input);
+    return check_launch("roi_align_3d_backward (separable)");
+  }
   k_roi_align3d_bwd<<<blocks_for(total, 256), 256, 0, as_stream(s)>>>(grad_out, rois, roi_inds, C, W, L, H, total,
                                                                       out_w, out_l, out_h, spatial_scale, grad_input);
   return check_launch("roi_align_3d_backward");

@@ -36,29 +36,33 @@ def _interp(vol, x, y, z):
     return out
 
 
+def _geometry(roi, osz, spatial_scale):
+    """RoI geometry in float32, operation by operation as torchvision's kernels (T = float) and the HIP kernels do
+    it: the sampling grid ceil(size / out) is an integer DECISION - a box whose scaled size is a whole multiple of
+    the output size within float32 rounding gets one more sample per bin in float64 than in float32 (found by
+    replaying the reference's recorded calls, tests/test_reference_calls.py: 0.03 absolute on such a box)."""
+    f32 = np.float32
+    start = [f32(roi[a]) * f32(spatial_scale) for a in range(3)]
+    end = [f32(roi[a + 3]) * f32(spatial_scale) for a in range(3)]
+    size = [np.maximum(end[a] - start[a], f32(1.0)) for a in range(3)]
+    binsz = [size[a] / f32(osz[a]) for a in range(3)]
+    grid = [int(np.ceil(size[a] / f32(osz[a]))) for a in range(3)]
+    count = max(grid[0] * grid[1] * grid[2], 1)
+
+    def coord(a, p, i):        # start + p * bin + (i + 0.5) * bin / grid, float32, left to right
+        return float(start[a] + f32(p) * binsz[a] + (f32(i) + f32(0.5)) * binsz[a] / f32(grid[a]))
+    return grid, count, coord
+
+
 def roi_align_3d(inp, rois, roi_inds, ow, ol, oh, spatial_scale):
     """inp f32[N,C,W,L,H], rois f32[K,6] (x1,y1,z1,x2,y2,z2), roi_inds i32[K] -> f32[K,C,ow,ol,oh]."""
     inp = np.asarray(inp, dtype=np.float64)
     K = len(rois)
     C = inp.shape[1]
     out = np.zeros((K, C, ow, ol, oh), dtype=np.float64)
-    osz = (ow, ol, oh)
     for k in range(K):
         vol = inp[int(roi_inds[k])]
-        # RoI geometry in float32, operation by operation as torchvision's kernels (T = float) and the HIP kernel do
-        # it: the sampling grid ceil(size / out) is an integer DECISION - a box whose scaled size is a whole multiple
-        # of the output size within float32 rounding gets one more sample per bin in float64 than in float32 (found
-        # by replaying the reference's recorded calls, tests/test_reference_calls.py: 0.03 absolute on such a box)
-        f32 = np.float32
-        start = [f32(rois[k][a]) * f32(spatial_scale) for a in range(3)]
-        end = [f32(rois[k][a + 3]) * f32(spatial_scale) for a in range(3)]
-        size = [np.maximum(end[a] - start[a], f32(1.0)) for a in range(3)]
-        binsz = [size[a] / f32(osz[a]) for a in range(3)]
-        grid = [int(np.ceil(size[a] / f32(osz[a]))) for a in range(3)]
-        count = max(grid[0] * grid[1] * grid[2], 1)
-
-        def coord(a, p, i):        # start + p * bin + (i + 0.5) * bin / grid, float32, left to right
-            return float(start[a] + f32(p) * binsz[a] + (f32(i) + f32(0.5)) * binsz[a] / f32(grid[a]))
+        grid, count, coord = _geometry(rois[k], (ow, ol, oh), spatial_scale)
         for pw in range(ow):
             for pl in range(ol):
                 for ph in range(oh):
@@ -71,4 +75,23 @@ def roi_align_3d(inp, rois, roi_inds, ow, ol, oh, spatial_scale):
                                 z = coord(2, ph, iz)
                                 acc += _interp(vol, x, y, z)
                     out[k, :, pw, pl, ph] = acc / count
+    return out.astype(np.float32)
+
+
+def roi_align_3d_at(inp, rois, roi_inds, ow, ol, oh, spatial_scale, points):
+    """The same op at chosen output elements only (full-size checks: BASELINE configs[4] has 65.5 M of them).
+    points int[P,5] = (k, c, pw, pl, ph) -> f32[P]."""
+    inp = np.asarray(inp)
+    out = np.zeros(len(points), dtype=np.float64)
+    for n, (k, c, pw, pl, ph) in enumerate(np.asarray(points).tolist()):
+        vol = inp[int(roi_inds[k]), c:c + 1].astype(np.float64)
+        grid, count, coord = _geometry(rois[k], (ow, ol, oh), spatial_scale)
+        acc = 0.0
+        for ix in range(grid[0]):
+            x = coord(0, pw, ix)
+            for iy in range(grid[1]):
+                y = coord(1, pl, iy)
+                for iz in range(grid[2]):
+                    acc += _interp(vol, x, y, coord(2, ph, iz))[0]
+        out[n] = acc / count
     return out.astype(np.float32)

@@ -75,3 +75,26 @@ def test_extract_matches_oracle_field(level_table, params_k16):
         d3 = field.density(x.cpu(), params_k16, 1.0, level_table)
         rgb3 = sum(field.color(torch.from_numpy(VIEW_DIRS[v]).expand(1003, 3), d3["geo_feat"], params_k16) for v in range(3)) / 3
     assert (out[:, :3].cpu() - rgb3).abs().max() < 1e-4 and torch.allclose(out[:, 3].cpu(), d3["sigma_raw"], atol=1e-4, rtol=1e-4)
+
+
+@pytest.mark.gpu
+def test_extract_at_baseline_config4_size(level_table):
+    """BASELINE configs[4] at its stated size: the 160^3 lattice (4 096 000 voxel centres, BASELINE table T = 6 119 864),
+    4 096 sampled voxels against the oracle field."""
+    from instance_nerf_amd.extract import VIEW_DIRS, extract_rgbsigma, lattice
+    from oracle import field
+    from test_gpu_parity import _network
+    p = field.init_params(seed=4, table=level_table, table_std=1.0, K=0)
+    net = _network(p, K=0).eval()
+    grid, res = extract_rgbsigma(net, max_side=160)
+    assert tuple(grid.shape) == (160, 160, 160, 4) and res.tolist() == [160, 160, 160]
+    rng = np.random.default_rng(8)
+    idx = torch.from_numpy(rng.choice(160 ** 3, 4096, replace=False))
+    pts = lattice([-1, -1, -1], [1, 1, 1], res, "cpu")[idx]
+    with torch.no_grad():
+        den = field.density(pts, p, 1.0, level_table)
+        rgb = sum(field.color(torch.from_numpy(VIEW_DIRS[v]).expand(pts.shape[0], 3), den["geo_feat"], p)
+                  for v in range(4)) / 4
+    got = grid.view(-1, 4)[idx.to(grid.device)].cpu()
+    assert torch.allclose(got[:, 3], den["sigma_raw"], atol=1e-4, rtol=1e-4)
+    assert (got[:, :3] - rgb).abs().max() < 1e-4

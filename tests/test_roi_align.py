@@ -33,25 +33,116 @@ def test_signature_matches_reference_call():
     assert list(sig.parameters) == ["input", "rois", "roi_inds", "out_w", "out_l", "out_h", "spatial_scale"]
 
 
+def test_oracle_at_points_equals_the_full_oracle():
+    rng = np.random.default_rng(3)
+    vol = rng.normal(size=(2, 3, 6, 5, 7)).astype(np.float32)
+    rois = np.asarray([[0.4, 0.2, 1.0, 9.0, 8.0, 11.0], [-2, 1, 3, 30, 6, 9]], np.float32)
+    inds = np.asarray([1, 0], np.int32)
+    full = roialign.roi_align_3d(vol, rois, inds, 3, 2, 4, 0.5)
+    pts = np.stack([rng.integers(0, n, 64) for n in full.shape], 1)
+    got = roialign.roi_align_3d_at(vol, rois, inds, 3, 2, 4, 0.5, pts)
+    assert np.array_equal(got, full[tuple(pts.T)])
+
+
+def _set_mode(mode):
+    from instance_nerf_amd import _lib
+    _lib.check(_lib.load().inr_roi_align_3d_set_mode(mode), "roi_align_3d_set_mode")
+
+
 @pytest.mark.gpu
-def test_hip_roi_align_matches_oracle_and_autograd():
+@pytest.mark.parametrize("mode", [2, 1, 0])       # separable, one lane per output element, auto
+def test_hip_roi_align_matches_oracle_and_autograd(mode):
     from instance_nerf_amd.roi_align.roi_align import roi_align_3d
     rng = np.random.default_rng(0)
     vol = rng.normal(size=(2, 3, 9, 8, 7)).astype(np.float32)
     rois = np.asarray([[0, 0, 0, 9, 8, 7], [1.3, 0.7, 2.2, 6.1, 7.5, 6.9], [2, 2, 2, 2.4, 2.5, 2.2],
-                       [-3, -2, -1, 4, 5, 3], [5, 4, 3, 20, 20, 20], [0.5, 0.5, 0.5, 8.5, 7.5, 6.5]], np.float32) * 2
-    inds = np.asarray([0, 1, 1, 0, 1, 0], np.int32)
-    for osz, scale in (((3, 3, 3), 0.5), ((5, 4, 2), 0.5), ((2, 2, 2), 0.25)):
-        ref = roialign.roi_align_3d(vol, rois, inds, *osz, scale)
-        x = torch.tensor(vol, device="cuda", requires_grad=True)
-        out = roi_align_3d(x, torch.tensor(rois, device="cuda"), torch.tensor(inds, device="cuda"), *osz, scale)
-        assert np.abs(out.detach().cpu().numpy() - ref).max() < 1e-5
-        # backward = transpose of the (linear) forward: <out, g> == <x, grad>
-        g = torch.randn(out.shape, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
-        out.backward(g)
-        lhs = (out.detach() * g).sum().item()
-        rhs = (x.detach() * x.grad).sum().item()
-        assert abs(lhs - rhs) < 1e-3 * max(1.0, abs(lhs))
-    empty = roi_align_3d(torch.tensor(vol, device="cuda"), torch.zeros(0, 6, device="cuda"),
-                         torch.zeros(0, dtype=torch.int32, device="cuda"), 3, 3, 3, 1.0)
-    assert empty.shape == (0, 3, 3, 3, 3)
+                       [-3, -2, -1, 4, 5, 3], [5, 4, 3, 20, 20, 20], [0.5, 0.5, 0.5, 8.5, 7.5, 6.5],
+                       [40, 40, 40, 60, 60, 60], [-30, -30, -30, -20, -20, -20], [-50, 1, 1, 90, 7, 6]], np.float32) * 2
+    inds = np.asarray([0, 1, 1, 0, 1, 0, 1, 0, 1], np.int32)
+    _set_mode(mode)
+    try:
+        for osz, scale in (((3, 3, 3), 0.5), ((5, 4, 2), 0.5), ((2, 2, 2), 0.25), ((7, 7, 7), 1.0), ((11, 13, 12), 0.5)):
+            ref = roialign.roi_align_3d(vol, rois, inds, *osz, scale)
+            x = torch.tensor(vol, device="cuda", requires_grad=True)
+            out = roi_align_3d(x, torch.tensor(rois, device="cuda"), torch.tensor(inds, device="cuda"), *osz, scale)
+            assert np.abs(out.detach().cpu().numpy() - ref).max() < 1e-5, (mode, osz)
+            # backward = transpose of the (linear) forward: <out, g> == <x, grad>
+            g = torch.randn(out.shape, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+            out.backward(g)
+            lhs = (out.detach() * g).sum().item()
+            rhs = (x.detach() * x.grad).sum().item()
+            assert abs(lhs - rhs) < 1e-3 * max(1.0, abs(lhs)), (mode, osz)
+        empty = roi_align_3d(torch.tensor(vol, device="cuda"), torch.zeros(0, 6, device="cuda"),
+                             torch.zeros(0, dtype=torch.int32, device="cuda"), 3, 3, 3, 1.0)
+        assert empty.shape == (0, 3, 3, 3, 3)
+    finally:
+        _set_mode(0)
+
+
+def config4_boxes(gen_seed=0, K=256, dev="cuda"):
+    """bench.py's BASELINE configs[4] boxes (input-scale units, spatial_scale 0.25 onto a 40^3 level) plus the shapes
+    a detector really emits: one box larger than the volume, one thinner than a voxel, one outside."""
+    gen = torch.Generator(device=dev).manual_seed(gen_seed)
+    lo = torch.rand(K, 3, device=dev, generator=gen) * 100
+    rois = torch.cat([lo, lo + 10 + torch.rand(K, 3, device=dev, generator=gen) * 50], 1)
+    rois[0] = torch.tensor([-20.0, -8, -4, 190, 170, 200], device=dev)
+    rois[1] = torch.tensor([50.0, 60, 70, 50.5, 61, 70.2], device=dev)
+    rois[2] = torch.tensor([400.0, 400, 400, 440, 450, 460], device=dev)
+    rois[3] = torch.tensor([0.0, 0, 0, 160, 160, 160], device=dev)
+    return rois
+
+
+@pytest.mark.gpu
+def test_roi_align_at_baseline_config4_size():
+    """BASELINE configs[4] at its stated size: [1,256,40,40,40], 256 boxes -> 10^3.  2000 sampled output elements
+    against the oracle; the two HIP implementations against each other on all 65.5 M; the backward as the
+    transpose of the forward and separable against lane-per-output."""
+    from instance_nerf_amd.roi_align.roi_align import roi_align_3d
+    dev = "cuda"
+    feat = torch.randn(1, 256, 40, 40, 40, device=dev, generator=torch.Generator(device=dev).manual_seed(5))
+    rois = config4_boxes()
+    inds = torch.zeros(256, dtype=torch.int32, device=dev)
+    outs, grads = {}, {}
+    g = torch.randn(256, 256, 10, 10, 10, device=dev, generator=torch.Generator(device=dev).manual_seed(6))
+    try:
+        for mode in (2, 1):
+            _set_mode(mode)
+            x = feat.clone().requires_grad_(True)
+            out = roi_align_3d(x, rois, inds, 10, 10, 10, 0.25)
+            out.backward(g)
+            outs[mode], grads[mode] = out.detach(), x.grad
+            lhs, rhs = (out.detach().double() * g.double()).sum().item(), (feat.double() * x.grad.double()).sum().item()
+            assert abs(lhs - rhs) < 1e-5 * max(1.0, abs(lhs)), (mode, lhs, rhs)
+    finally:
+        _set_mode(0)
+    assert (outs[2] - outs[1]).abs().max().item() < 2e-5
+    assert (grads[2] - grads[1]).abs().max().item() < 1e-3 * grads[1].abs().max().item()
+    assert outs[2][2].abs().max().item() == 0.0          # the box outside the volume pools nothing
+    rng = np.random.default_rng(7)
+    pts = np.stack([rng.integers(0, n, 2000) for n in (256, 256, 10, 10, 10)], 1)
+    pts[:200, 0] = rng.integers(0, 4, 200)                # the special boxes get their share
+    ref = roialign.roi_align_3d_at(feat.cpu().numpy(), rois.cpu().numpy(), inds.cpu().numpy(), 10, 10, 10, 0.25, pts)
+    got = outs[2].cpu().numpy()[tuple(pts.T)]
+    assert np.abs(got - ref).max() < 2e-5
+
+
+@pytest.mark.gpu
+def test_roi_align_channel_tails_and_batches():
+    """Channel counts that are not multiples of the 4 a lane carries, several volumes, non-cubic levels."""
+    from instance_nerf_amd.roi_align.roi_align import roi_align_3d
+    rng = np.random.default_rng(11)
+    try:
+        for C, shape in ((1, (5, 6, 4)), (5, (8, 5, 9)), (18, (6, 6, 6))):
+            vol = rng.normal(size=(3, C) + shape).astype(np.float32)
+            K = 7
+            lo = rng.uniform(-2, 6, size=(K, 3))
+            rois = np.concatenate([lo, lo + rng.uniform(0.2, 12, size=(K, 3))], 1).astype(np.float32)
+            inds = rng.integers(0, 3, K).astype(np.int32)
+            ref = roialign.roi_align_3d(vol, rois, inds, 4, 3, 5, 0.7)
+            for mode in (2, 1):
+                _set_mode(mode)
+                out = roi_align_3d(torch.tensor(vol, device="cuda"), torch.tensor(rois, device="cuda"),
+                                   torch.tensor(inds, device="cuda"), 4, 3, 5, 0.7)
+                assert np.abs(out.cpu().numpy() - ref).max() < 1e-5, (C, shape, mode)
+    finally:
+        _set_mode(0)
