@@ -137,10 +137,12 @@ __global__ void __launch_bounds__(256) k_roi_align3d_bwd(const float* __restrict
 //   T[0] [ow][W], T[1] [ol][L], T[2] [oh][H]   dense per-axis weight rows over ABSOLUTE cell indices
 //   first/last cell of every row (ints; first > last: no sample of that output index lies inside the volume)
 //   (backward only) first/last output index of every cell
-//   tmp1, tmp2: the slab intermediates, SEP_CH channels interleaved (float4)
+//   tmp1, tmp2: the slab intermediates, SEP_CH channels interleaved (f32x4)
 constexpr int SEP_THREADS = 256;
 constexpr int SEP_CH = 4;            // channels a thread carries through every pass (weights and indices are shared)
-constexpr int SEP_TMP_FLOATS = 8192; // tmp1 + tmp2 budget per workgroup (32 KB): ~37 KB in all -> 4 workgroups per CU
+constexpr int SEP_TMP_FLOATS = 10240; // tmp1 + tmp2 budget per workgroup (40 KB): ~45 KB in all -> 3 workgroups per CU,
+                                      // what the forward kernel's registers allow anyway; fewer x slabs beat a 4th
+                                      // workgroup (tools/micro/roialign_bench.hip: 0.152 vs 0.160 ms at 8192)
 
 struct SepArgs {
   int C, W, L, H, ow, ol, oh;
@@ -151,41 +153,54 @@ struct SepArgs {
   int tmp_floats;
 };
 
-struct SepRoi {       // in LDS
+struct SepRoi {       // in LDS (lSepRoi)
   float start[3], bin[3];
   int grid[3];
   float inv_count;
   int lo[3], hi[3];   // region of cells any output index touches (lo > hi: empty)
 };
 
+// LDS pointers carry their address space in the type: the tables are reached through small arrays of pointers, and
+// for a pointer the compiler cannot trace back to the __shared__ array it emits FLAT instructions (found in the ISA:
+// flat_store_dwordx4 for the slab writes) - the slow path through the vector memory unit.
+typedef __attribute__((address_space(3))) float lfloat;
+typedef __attribute__((address_space(3))) int lint;
+typedef float f32x4 __attribute__((ext_vector_type(4)));          // a native vector: HIP's f32x4 class has no LDS overloads
+typedef __attribute__((address_space(3))) f32x4 lfloat4;
+
+struct __attribute__((packed, aligned(4))) F4U { float v[4]; };   // four consecutive floats at dword alignment
+
+typedef __attribute__((address_space(3))) SepRoi lSepRoi;
+
 __device__ __forceinline__ int fdiv(int n, float inv) { return (int)(((float)n + 0.5f) * inv); }
 
-// Builds the per-axis tables of RoI k (all threads of the workgroup; ends with a barrier).
-// n[a] = volume extent, o[a] = output extent.  T rows are zero outside [first, last].
-__device__ __forceinline__ void sep_build_tables(const float* __restrict__ roi, const SepArgs& A, SepRoi* R,
-                                                 float* const T[3], int* const first[3], int* const last[3]) {
+// Builds the per-axis tables of RoI k (all threads of the workgroup; two barriers, the second one last).
+// n[a] = volume extent, o[a] = output extent.  A row is written over [first, last] only - nothing reads outside.
+__device__ __forceinline__ void sep_build_tables(const float* __restrict__ roi, const SepArgs& A, lSepRoi* R,
+                                                 lfloat* const T[3], lint* const first[3], lint* const last[3]) {
   const int n[3] = {A.W, A.L, A.H};
   const int o[3] = {A.ow, A.ol, A.oh};
   const int t = threadIdx.x;
-  if (t < 3) {
-    // the same float32 operations, in the same order, as roi_geom() / oracle/roialign.py
-    const float s = roi[t] * A.scale, e = roi[t + 3] * A.scale;
-    const float size = fmaxf(e - s, 1.0f);
-    R->start[t] = s;
-    R->bin[t] = size / (float)o[t];
-    R->grid[t] = (int)ceilf(size / (float)o[t]);
-  }
-  const int ntab = o[0] * n[0] + o[1] * n[1] + o[2] * n[2];
-  for (int i = t; i < ntab; i += SEP_THREADS) T[0][i] = 0.0f;     // the three tables are contiguous
-  __syncthreads();
   const int nrow = o[0] + o[1] + o[2];
   for (int r = t; r < nrow; r += SEP_THREADS) {
     const int a = r < o[0] ? 0 : (r < o[0] + o[1] ? 1 : 2);
     const int p = r - (a == 0 ? 0 : (a == 1 ? o[0] : o[0] + o[1]));
-    const float start = R->start[a], bin = R->bin[a];
-    const int g = R->grid[a], na = n[a];
-    float* row = T[a] + p * na;
+    const int na = n[a];
+    // the same float32 operations, in the same order, as roi_geom() / oracle/roialign.py
+    const float start = roi[a] * A.scale, e = roi[a + 3] * A.scale;
+    const float size = fmaxf(e - start, 1.0f);
+    const float bin = size / (float)o[a];
+    const int g = (int)ceilf(size / (float)o[a]);
+    lfloat* row = T[a] + p * na;
     int f = na, l = -1;
+    for (int i = 0; i < g; ++i) {                       // which cells do this output index's samples touch
+      const float v = start + p * bin + ((float)i + 0.5f) * bin / (float)g;
+      if (v < -1.0f || v > (float)na) continue;
+      const int lo = min((int)fmaxf(v, 0.0f), na - 1);
+      f = min(f, lo);
+      l = max(l, min(lo + 1, na - 1));
+    }
+    for (int c = f; c <= l; ++c) row[c] = 0.0f;
     for (int i = 0; i < g; ++i) {
       const float v = start + p * bin + ((float)i + 0.5f) * bin / (float)g;
       if (v < -1.0f || v > (float)na) continue;
@@ -193,13 +208,16 @@ __device__ __forceinline__ void sep_build_tables(const float* __restrict__ roi, 
       int lo = (int)c, hi;
       if (lo >= na - 1) { lo = hi = na - 1; c = (float)lo; } else { hi = lo + 1; }
       const float fr = c - (float)lo;
-      row[lo] += 1.0f - fr;
+      row[lo] += 1.0f - fr;                             // one lane owns the row: its LDS operations are ordered
       row[hi] += fr;
-      f = min(f, lo);
-      l = max(l, hi);
     }
     first[a][p] = f;
     last[a][p] = l;
+    if (p == 0) {
+      R->grid[a] = g;
+      R->start[a] = start;
+      R->bin[a] = bin;
+    }
   }
   __syncthreads();
   if (t < 3) {
@@ -208,7 +226,7 @@ __device__ __forceinline__ void sep_build_tables(const float* __restrict__ roi, 
     R->lo[t] = lo;
     R->hi[t] = hi;
   }
-  if (t == 0) {
+  if (t == 3) {
     const int count = R->grid[0] * R->grid[1] * R->grid[2];
     R->inv_count = 1.0f / (float)max(count, 1);
   }
@@ -229,32 +247,49 @@ __device__ __forceinline__ bool sep_assign(const SepArgs& A, int* k, int* c0) {
   return true;
 }
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void fma4(f32x4& a, float w, const f32x4 v) {
+  a.x = __builtin_fmaf(w, v.x, a.x);
+  a.y = __builtin_fmaf(w, v.y, a.y);
+  a.z = __builtin_fmaf(w, v.z, a.z);
+  a.w = __builtin_fmaf(w, v.w, a.w);
+}
+
+// A thread's ROLE in a pass is fixed for the whole RoI - output index ph in the z pass, (pl, ph) in the y pass, its
+// NOUT output elements in the x pass - so the taps of that role (first cell + four weights: every row of a RoI whose
+// sampling grid is <= 2 per bin, i.e. every box up to 2 x out cells on a side) are loaded into registers once and
+// the passes are loads + fused multiply-adds; longer rows take the remaining cells from the LDS table (`more*`).
+// The kernel is bound by vector-instruction issue (PMC, profiles/r04_roialign_pmc.txt: a wave64 instruction holds a
+// SIMD for four cycles), so instructions per element are what is trimmed: buffer loads (one 32-bit offset per row
+// for all four channels, the channel in the scalar offset), explicit fma, no index decoding in the inner loops.
 template <int NOUT>   // output elements per thread: ow*ol*oh <= NOUT * SEP_THREADS
 __global__ void __launch_bounds__(SEP_THREADS) k_roi_align3d_sep_fwd(const float* __restrict__ in,
                                                                      const float* __restrict__ rois,
                                                                      const int32_t* __restrict__ roi_inds, SepArgs A,
                                                                      float* __restrict__ out) {
-  extern __shared__ float4 lds4[];
+  extern __shared__ f32x4 lds4[];
   int k, c0;
   if (!sep_assign(A, &k, &c0)) return;
-  float* lds = reinterpret_cast<float*>(lds4);
+  lfloat* lds = (lfloat*)lds4;
   const int t = threadIdx.x;
   const int W = A.W, L = A.L, H = A.H, ow = A.ow, ol = A.ol, oh = A.oh;
-  float* T[3];
-  int* first[3];
-  int* last[3];
+  lfloat* T[3];
+  lint* first[3];
+  lint* last[3];
   T[0] = lds; T[1] = T[0] + ow * W; T[2] = T[1] + ol * L;
-  int* ip = reinterpret_cast<int*>(T[2] + oh * H);
+  lint* ip = (lint*)(T[2] + oh * H);
   first[0] = ip; last[0] = first[0] + ow; first[1] = last[0] + ow; last[1] = first[1] + ol;
   first[2] = last[1] + ol; last[2] = first[2] + oh;
-  SepRoi* R = reinterpret_cast<SepRoi*>(last[2] + oh);
-  float* tmpbase = reinterpret_cast<float*>(R + 1);
-  tmpbase = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(tmpbase) + 15) & ~(uintptr_t)15);
+  lSepRoi* R = (lSepRoi*)(last[2] + oh);
+  // the slab intermediates start at the next 16-byte boundary (LDS offsets: the dynamic window starts at 0)
+  const int fixed_words = ow * W + ol * L + oh * H + 2 * (ow + ol + oh) + (int)(sizeof(SepRoi) / 4);
+  lfloat* tmpbase = lds + ((fixed_words + 3) & ~3);
 
   sep_build_tables(rois + (int64_t)k * 6, A, R, T, first, last);
 
   const int olh = ol * oh, nout = ow * olh;
-  const int64_t WLH = (int64_t)W * L * H;
+  const int WLH = W * L * H;
   const int cend = min(c0 + A.cpb, A.C);
   const int x0 = R->lo[0], y0 = R->lo[1], z0 = R->lo[2];
   const int sx = R->hi[0] - x0 + 1, sy = R->hi[1] - y0 + 1, sz = R->hi[2] - z0 + 1;
@@ -266,101 +301,136 @@ __global__ void __launch_bounds__(SEP_THREADS) k_roi_align3d_sep_fwd(const float
   }
   const float inv_count = R->inv_count;
   // x slab: XB planes at a time so that tmp1 [XB][sy][oh] + tmp2 [XB][ol][oh] (x SEP_CH) fit the budget
-  int XB = A.tmp_floats / (SEP_CH * (sy * oh + olh));
+  int XB = (A.tmp_floats - 4 * ow) / (SEP_CH * (sy * oh + olh));
   XB = max(1, min(XB, sx));
-  float4* tmp1 = reinterpret_cast<float4*>(tmpbase);
-  float4* tmp2 = tmp1 + XB * sy * oh;
-  const float inv_oh = 1.0f / (float)oh, inv_sy = 1.0f / (float)sy, inv_olh = 1.0f / (float)olh;
+  lfloat4* xt = (lfloat4*)tmpbase;           // x taps per output index pw: four weights from its first cell on
+  lfloat4* tmp1 = xt + ow;
+  lfloat4* tmp2 = tmp1 + XB * sy * oh;
+  const float inv_sy = 1.0f / (float)sy;
 
-  // the output elements this thread owns: pw (its x taps) and the (pl, ph) index r
-  int opw[NOUT], orr[NOUT], ofx[NOUT], olx[NOUT];
+  // ---- z role: output index ph, row slot
+  const int NS1 = SEP_THREADS / oh;
+  const int slot1 = fdiv(t, 1.0f / (float)oh), ph1 = t - slot1 * oh;
+  const bool act1 = slot1 < NS1;
+  const int fz = first[2][ph1], lz = last[2][ph1];
+  // the taps of an output index are consecutive cells: ONE 16-byte load per channel covers four of them (the vector
+  // memory path charges a gather per 128-byte line an INSTRUCTION touches: four one-tap loads touched the same lines
+  // four times); the window is pulled back from the end of the row, cells outside [fz, lz] get weight zero
+  const int jz = min(min(fz, H - 1), H - 4);
+  float wz[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) wz[j] = (jz + j >= fz && jz + j <= lz) ? T[2][ph1 * H + jz + j] : 0.0f;
+  const bool morez = lz >= jz + 4;
+
+  // ---- y role: (pl, ph), plane slot
+  const int NS2 = SEP_THREADS / olh;
+  const int slot2 = fdiv(t, 1.0f / (float)olh), r2 = t - slot2 * olh;
+  const bool act2 = slot2 < NS2;
+  const int pl2 = fdiv(r2, 1.0f / (float)oh), ph2 = r2 - pl2 * oh;
+  const int fy = first[1][pl2], ly = last[1][pl2];
+  const int fyc = fy <= ly ? fy : y0;
+  float wy[4];
+  const int ny = max(ly - fy, 0);             // tap j reads row fy + min(j, ny): always a row this RoI wrote
+#pragma unroll
+  for (int j = 0; j < 4; ++j) wy[j] = (fy + j <= ly) ? T[1][pl2 * L + fy + j] : 0.0f;
+  const bool morey = ly >= fy + 4;
+
+  // ---- x role: the output elements this thread owns
+  // (the taps themselves stay in LDS as one 16-byte record per pw: sixteen more live registers cost a wave per SIMD)
+  int orr[NOUT], opw[NOUT];
 #pragma unroll
   for (int i = 0; i < NOUT; ++i) {
     const int o = t + i * SEP_THREADS;
-    const int pw = o < nout ? fdiv(o, inv_olh) : 0;
-    opw[i] = pw;
-    orr[i] = o - pw * olh;
-    ofx[i] = o < nout ? first[0][pw] : 1;
-    olx[i] = o < nout ? last[0][pw] : 0;
+    opw[i] = o < nout ? fdiv(o, 1.0f / (float)olh) : 0;
+    orr[i] = o < nout ? o - opw[i] * olh : 0;
   }
-  const float* vol0 = in + ((int64_t)roi_inds[k] * A.C) * WLH;
+  bool morex = false;
+  if (t < ow) {
+    const int f = first[0][t], l = last[0][t];
+    f32x4 w;
+    w.x = (f <= l) ? T[0][t * W + f] : 0.0f;
+    w.y = (f + 1 <= l) ? T[0][t * W + f + 1] : 0.0f;
+    w.z = (f + 2 <= l) ? T[0][t * W + f + 2] : 0.0f;
+    w.w = (f + 3 <= l) ? T[0][t * W + f + 3] : 0.0f;
+    xt[t] = w;
+    if (f > l) first[0][t] = x0;              // a row without taps: all weights zero, any cell of the region will do
+    morex = l >= f + 4;
+  }
+  morex = __syncthreads_or(morex);            // uniform: the rare path is skipped with one scalar branch; and xt is visible
+
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(in + (int64_t)roi_inds[k] * A.C * WLH), 0, (int)((int64_t)A.C * WLH * 4), 0x00020000);
 
   for (int c = c0; c < cend; c += SEP_CH) {
-    // channel pointers (a run shorter than SEP_CH re-reads its last channel and skips the stores)
-    const float* vc[SEP_CH];
+    // a run shorter than SEP_CH re-reads its last channel and skips the stores
+    int soff[SEP_CH];
 #pragma unroll
-    for (int ch = 0; ch < SEP_CH; ++ch) vc[ch] = vol0 + (int64_t)min(c + ch, A.C - 1) * WLH;
-    float4 acc[NOUT];
+    for (int ch = 0; ch < SEP_CH; ++ch) soff[ch] = min(c + ch, A.C - 1) * WLH * 4;
+    f32x4 acc[NOUT];
 #pragma unroll
-    for (int i = 0; i < NOUT; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < NOUT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     for (int xs = 0; xs < sx; xs += XB) {
       const int nx = min(XB, sx - xs);
       // ---- pass 1 (z): tmp1[x][y][ph] = sum_z Tz[ph][z] * in[x0+xs+x][y0+y][z]
-      const int n1 = nx * sy * oh;
-      for (int item = t; item < n1; item += SEP_THREADS) {
-        const int row = fdiv(item, inv_oh), ph = item - row * oh;
-        const int x = fdiv(row, inv_sy), y = row - x * sy;
-        const int f = first[2][ph], l = last[2][ph];
-        const int base = ((x0 + xs + x) * L + (y0 + y)) * H;
-        const float* tz = T[2] + ph * H;
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int j0 = f; j0 <= l; j0 += 4) {
-          float w[4];
-          int cell[4];
+      const int nrows = act1 ? nx * sy : 0;
+      for (int r = slot1; r < nrows; r += NS1) {
+        const int x = fdiv(r, inv_sy), y = r - x * sy;
+        const int voff = (((x0 + xs + x) * L + (y0 + y)) * H + jz) * 4;
+        u32x4 q[SEP_CH];
 #pragma unroll
-          for (int jj = 0; jj < 4; ++jj) {
-            cell[jj] = min(j0 + jj, H - 1);
-            w[jj] = (j0 + jj <= l) ? tz[cell[jj]] : 0.0f;
-          }
-          float v[SEP_CH][4];
-#pragma unroll
-          for (int ch = 0; ch < SEP_CH; ++ch)
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) v[ch][jj] = vc[ch][base + cell[jj]];
-#pragma unroll
-          for (int jj = 0; jj < 4; ++jj) {
-            a.x += w[jj] * v[0][jj];
-            a.y += w[jj] * v[1][jj];
-            a.z += w[jj] * v[2][jj];
-            a.w += w[jj] * v[3][jj];
+        for (int ch = 0; ch < SEP_CH; ++ch) q[ch] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff[ch], 0);
+        f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+        fma4(a, wz[0], f32x4{__uint_as_float(q[0].x), __uint_as_float(q[1].x), __uint_as_float(q[2].x), __uint_as_float(q[3].x)});
+        fma4(a, wz[1], f32x4{__uint_as_float(q[0].y), __uint_as_float(q[1].y), __uint_as_float(q[2].y), __uint_as_float(q[3].y)});
+        fma4(a, wz[2], f32x4{__uint_as_float(q[0].z), __uint_as_float(q[1].z), __uint_as_float(q[2].z), __uint_as_float(q[3].z)});
+        fma4(a, wz[3], f32x4{__uint_as_float(q[0].w), __uint_as_float(q[1].w), __uint_as_float(q[2].w), __uint_as_float(q[3].w)});
+        if (morez) {
+          for (int j = jz + 4; j <= lz; ++j) {
+            const float w = T[2][ph1 * H + j];
+            const int vo = voff + (j - jz) * 4;
+            fma4(a, w, f32x4{__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, vo, soff[0], 0)),
+                                   __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, vo, soff[1], 0)),
+                                   __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, vo, soff[2], 0)),
+                                   __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, vo, soff[3], 0))});
           }
         }
-        tmp1[item] = a;
+        tmp1[r * oh + ph1] = a;
       }
       __syncthreads();
       // ---- pass 2 (y): tmp2[x][pl][ph] = sum_y Ty[pl][y] * tmp1[x][y - y0][ph]
-      const int n2 = nx * olh;
-      for (int item = t; item < n2; item += SEP_THREADS) {
-        const int x = fdiv(item, inv_olh), r = item - x * olh;
-        const int pl = fdiv(r, inv_oh), ph = r - pl * oh;
-        const int f = first[1][pl], l = last[1][pl];
-        const float* ty = T[1] + pl * L;
-        const float4* src = tmp1 + (x * sy - y0) * oh + ph;
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int j0 = f; j0 <= l; j0 += 4) {
+      const int nx2 = act2 ? nx : 0;
+      for (int x = slot2; x < nx2; x += NS2) {
+        const lfloat4* src = tmp1 + (x * sy + fyc - y0) * oh + ph2;
+        f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int jj = 0; jj < 4; ++jj) {
-            const int cell = min(j0 + jj, l);
-            const float w = (j0 + jj <= l) ? ty[cell] : 0.0f;
-            const float4 v = src[cell * oh];
-            a.x += w * v.x; a.y += w * v.y; a.z += w * v.z; a.w += w * v.w;
-          }
-        }
-        tmp2[item] = a;
+        for (int j = 0; j < 4; ++j) fma4(a, wy[j], src[min(j, ny) * oh]);
+        if (morey)
+          for (int j = fy + 4; j <= ly; ++j) fma4(a, T[1][pl2 * L + j], src[(j - fy) * oh]);
+        tmp2[x * olh + r2] = a;
       }
       __syncthreads();
       // ---- pass 3 (x), this slab's share: acc[o] += sum_{x in slab} Tx[pw][x] * tmp2[x][pl][ph]
       const int xlo = x0 + xs, xhi = x0 + xs + nx - 1;
 #pragma unroll
       for (int i = 0; i < NOUT; ++i) {
-        const int f = max(ofx[i], xlo), l = min(olx[i], xhi);
-        const float* tx = T[0] + opw[i] * W;
-        const float4* src = tmp2 + orr[i] - xlo * olh;
-        for (int xx = f; xx <= l; ++xx) {
-          const float w = tx[xx];
-          const float4 v = src[xx * olh];
-          acc[i].x += w * v.x; acc[i].y += w * v.y; acc[i].z += w * v.z; acc[i].w += w * v.w;
+        const lfloat4* src = tmp2 + orr[i] - xlo * olh;
+        const f32x4 w = xt[opw[i]];
+        const int f = first[0][opw[i]];
+        const float wj[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int cell = f + j, cc = min(max(cell, xlo), xhi);
+          fma4(acc[i], cell == cc ? wj[j] : 0.0f, src[cc * olh]);
+        }
+      }
+      if (morex) {        // rows longer than the four register taps (sampling grid > 2): the rest from the table
+#pragma unroll
+        for (int i = 0; i < NOUT; ++i) {
+          if (t + i * SEP_THREADS >= nout) continue;
+          const int pw = opw[i], lx = last[0][pw];
+          const lfloat4* src = tmp2 + orr[i] - xlo * olh;
+          for (int xx = max(first[0][pw] + 4, xlo); xx <= min(lx, xhi); ++xx) fma4(acc[i], T[0][pw * W + xx], src[xx * olh]);
         }
       }
       // no barrier here: the next slab's pass 1 writes tmp1 only, and its barrier orders the writes of tmp2 behind
@@ -377,8 +447,8 @@ __global__ void __launch_bounds__(SEP_THREADS) k_roi_align3d_sep_fwd(const float
         if (c + 3 < cend) dst[3 * (int64_t)nout] = acc[i].w * inv_count;
       }
     }
-    __syncthreads();   // tmp2 is rewritten by the next channel run's pass 2 only after ITS pass-1 barrier, but a
-                       // single-slab RoI of few items can let a fast wave get there first: keep the runs apart
+    __syncthreads();   // keeps the channel runs apart: a fast wave of a small RoI must not write tmp1 / tmp2 of the
+                       // next run while a slow one still reads this run's
   }
 }
 
@@ -389,27 +459,27 @@ __global__ void __launch_bounds__(SEP_THREADS) k_roi_align3d_sep_bwd(const float
                                                                      const float* __restrict__ rois,
                                                                      const int32_t* __restrict__ roi_inds, SepArgs A,
                                                                      float* __restrict__ gin) {
-  extern __shared__ float4 lds4[];
+  extern __shared__ f32x4 lds4[];
   int k, c0;
   if (!sep_assign(A, &k, &c0)) return;
-  float* lds = reinterpret_cast<float*>(lds4);
+  lfloat* lds = (lfloat*)lds4;
   const int t = threadIdx.x;
   const int W = A.W, L = A.L, H = A.H, ow = A.ow, ol = A.ol, oh = A.oh;
-  float* T[3];
-  int* first[3];
-  int* last[3];
+  lfloat* T[3];
+  lint* first[3];
+  lint* last[3];
   T[0] = lds; T[1] = T[0] + ow * W; T[2] = T[1] + ol * L;
-  int* ip = reinterpret_cast<int*>(T[2] + oh * H);
+  lint* ip = (lint*)(T[2] + oh * H);
   first[0] = ip; last[0] = first[0] + ow; first[1] = last[0] + ow; last[1] = first[1] + ol;
   first[2] = last[1] + ol; last[2] = first[2] + oh;
   // per cell: the output indices whose rows reach it (rows start and end monotonically in p)
-  int* pfirst[3];
-  int* plast[3];
+  lint* pfirst[3];
+  lint* plast[3];
   pfirst[0] = last[2] + oh; plast[0] = pfirst[0] + W; pfirst[1] = plast[0] + W; plast[1] = pfirst[1] + L;
   pfirst[2] = plast[1] + L; plast[2] = pfirst[2] + H;
-  SepRoi* R = reinterpret_cast<SepRoi*>(plast[2] + H);
-  float* tmpbase = reinterpret_cast<float*>(R + 1);
-  tmpbase = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(tmpbase) + 15) & ~(uintptr_t)15);
+  lSepRoi* R = (lSepRoi*)(plast[2] + H);
+  const int fixed_words = ow * W + ol * L + oh * H + 2 * (ow + ol + oh) + 2 * (W + L + H) + (int)(sizeof(SepRoi) / 4);
+  lfloat* tmpbase = lds + ((fixed_words + 3) & ~3);
 
   sep_build_tables(rois + (int64_t)k * 6, A, R, T, first, last);
   {
@@ -436,11 +506,11 @@ __global__ void __launch_bounds__(SEP_THREADS) k_roi_align3d_sep_bwd(const float
   if (sx <= 0 || sy <= 0 || sz <= 0) return;
   const float inv_count = R->inv_count;
   // LDS: go [ow][ol][oh], then per x slab t2 [XB][ol][oh] and t1 [XB][sy][oh]
-  float4* go = reinterpret_cast<float4*>(tmpbase);
+  lfloat4* go = (lfloat4*)tmpbase;
   int XB = (A.tmp_floats - SEP_CH * nout) / (SEP_CH * (sy * oh + olh));
   XB = max(1, min(XB, sx));
-  float4* t2 = go + nout;
-  float4* t1 = t2 + XB * olh;
+  lfloat4* t2 = go + nout;
+  lfloat4* t1 = t2 + XB * olh;
   const float inv_oh = 1.0f / (float)oh, inv_sy = 1.0f / (float)sy, inv_olh = 1.0f / (float)olh,
               inv_sz = 1.0f / (float)sz;
   const float* gbase = gout + ((int64_t)k * A.C) * nout;
@@ -449,7 +519,7 @@ __global__ void __launch_bounds__(SEP_THREADS) k_roi_align3d_sep_bwd(const float
   for (int c = c0; c < cend; c += SEP_CH) {
     for (int o = t; o < nout; o += SEP_THREADS) {
       const float* src = gbase + (int64_t)c * nout + o;
-      float4 g;
+      f32x4 g;
       g.x = src[0] * inv_count;
       g.y = c + 1 < cend ? src[nout] * inv_count : 0.0f;
       g.z = c + 2 < cend ? src[2 * (int64_t)nout] * inv_count : 0.0f;
@@ -464,10 +534,10 @@ __global__ void __launch_bounds__(SEP_THREADS) k_roi_align3d_sep_bwd(const float
       for (int item = t; item < n2; item += SEP_THREADS) {
         const int x = fdiv(item, inv_olh), r = item - x * olh;
         const int cell = x0 + xs + x;
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int p = pfirst[0][cell]; p <= plast[0][cell]; ++p) {
           const float w = T[0][p * W + cell];
-          const float4 v = go[p * olh + r];
+          const f32x4 v = go[p * olh + r];
           a.x += w * v.x; a.y += w * v.y; a.z += w * v.z; a.w += w * v.w;
         }
         t2[item] = a;
@@ -479,10 +549,10 @@ __global__ void __launch_bounds__(SEP_THREADS) k_roi_align3d_sep_bwd(const float
         const int row = fdiv(item, inv_oh), ph = item - row * oh;
         const int x = fdiv(row, inv_sy), y = row - x * sy;
         const int cell = y0 + y;
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int p = pfirst[1][cell]; p <= plast[1][cell]; ++p) {
           const float w = T[1][p * L + cell];
-          const float4 v = t2[(x * ol + p) * oh + ph];
+          const f32x4 v = t2[(x * ol + p) * oh + ph];
           a.x += w * v.x; a.y += w * v.y; a.z += w * v.z; a.w += w * v.w;
         }
         t1[item] = a;
@@ -494,10 +564,10 @@ __global__ void __launch_bounds__(SEP_THREADS) k_roi_align3d_sep_bwd(const float
         const int row = fdiv(item, inv_sz), z = item - row * sz;
         const int x = fdiv(row, inv_sy), y = row - x * sy;
         const int cell = z0 + z;
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int p = pfirst[2][cell]; p <= plast[2][cell]; ++p) {
           const float w = T[2][p * H + cell];
-          const float4 v = t1[row * oh + p];
+          const f32x4 v = t1[row * oh + p];
           a.x += w * v.x; a.y += w * v.y; a.z += w * v.z; a.w += w * v.w;
         }
         float* dst = vol0 + (int64_t)c * WLH + ((x0 + xs + x) * L + (y0 + y)) * H + cell;
@@ -521,7 +591,8 @@ static int sep_lds_bytes(int W, int L, int H, int ow, int ol, int oh, bool bwd, 
   const int64_t ints = 2 * (int64_t)(ow + ol + oh) + (bwd ? 2 * (int64_t)(W + L + H) : 0);
   const int64_t fixed = (tab + ints) * 4 + (int64_t)sizeof(SepRoi) + 16;
   // one x plane of the widest region must fit: SEP_CH * (L*oh + ol*oh) floats (+ gout in the backward)
-  const int64_t need = (int64_t)SEP_CH * ((int64_t)L * oh + (int64_t)ol * oh) + (bwd ? (int64_t)SEP_CH * ow * ol * oh : 0);
+  const int64_t need = (int64_t)SEP_CH * ((int64_t)L * oh + (int64_t)ol * oh) +
+                       (bwd ? (int64_t)SEP_CH * ow * ol * oh : 4 * (int64_t)ow);
   int64_t tmp = std::max<int64_t>(need, SEP_TMP_FLOATS + (bwd ? (int64_t)SEP_CH * ow * ol * oh : 0));
   const int64_t total = fixed + tmp * 4;
   if (total > 64 * 1024) {
@@ -533,9 +604,10 @@ static int sep_lds_bytes(int W, int L, int H, int ow, int ol, int oh, bool bwd, 
 }
 
 static int sep_channels_per_block(int C, int64_t K) {
-  // enough workgroups to fill the chip several times over (256 CUs x 4 resident), whole SEP_CH runs
+  // enough workgroups to fill the chip several times over (256 CUs x 3 resident), whole SEP_CH runs; the tables of a
+  // RoI are built once per workgroup, so longer runs amortise them (16 channels: 0.152 ms, 8: 0.168, 32: 0.162)
   int cpb = 16;
-  while (cpb > SEP_CH && K * ((C + cpb - 1) / cpb) < 8192) cpb /= 2;
+  while (cpb > SEP_CH && K * ((C + cpb - 1) / cpb) < 4096) cpb /= 2;
   return cpb;
 }
 
@@ -570,8 +642,9 @@ int inr_roi_align_3d_forward(const float* input, const float* rois, const int32_
   const int64_t nout = (int64_t)out_w * out_l * out_h;
   const int64_t total = K * C * nout;
   int tmp_floats = 0;
-  const int lds = (nout <= 16 * SEP_THREADS && sep_grid_fits(C, K) && (int64_t)W * L * H < (1ll << 30))
-                      ? sep_lds_bytes(W, L, H, out_w, out_l, out_h, false, &tmp_floats) : 0;
+  const bool sep_ok = nout <= 16 * SEP_THREADS && (int64_t)out_l * out_h <= SEP_THREADS && H >= 4 &&
+                      sep_grid_fits(C, K) && (int64_t)C * W * L * H * 4 < (1ll << 31);
+  const int lds = sep_ok ? sep_lds_bytes(W, L, H, out_w, out_l, out_h, false, &tmp_floats) : 0;
   INR_REQUIRE(g_roi_mode != 2 || lds > 0, "separable kernel: tables do not fit the LDS window for these extents");
   if (g_roi_mode != 1 && lds > 0) {
     SepArgs A;
