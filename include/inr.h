@@ -489,6 +489,18 @@ int inr_adam_set_hyper(const float* lrs /*host*/, int32_t n_tensors, float beta1
 int inr_adam_step_multi_dev(int32_t n_tensors, float* const* params, const float* const* grads,
                             float* const* exp_avgs, float* const* exp_avg_sqs, const int64_t* numels,
                             const float* hyper_dev, float beta1, float beta2, float grad_scale, inr_stream_t s);
+/* No upstream counterpart.  n <= 8 device-to-device copies in one launch (the fixed input buffers of a captured training
+ * step); dsts / srcs / nbytes are HOST arrays, addresses and byte counts multiples of 4.                                */
+int inr_copy_multi(int32_t n, void* const* dsts, const void* const* srcs, const int64_t* nbytes, inr_stream_t s);
+/* The same two calls with the parameter EMA inside the captured sweep (no upstream counterpart; torch_ema's update folded
+ * into the optimiser's launch as inr_adam_ema_step_multi does for eager steps): hyper_dev holds 18 floats, the last one
+ * the EMA weight 1 - decay_t of the step, written by inr_adam_set_hyper_ema; ema_shadows[t] nullable per tensor.      */
+int inr_adam_set_hyper_ema(const float* lrs /*host*/, int32_t n_tensors, float beta1, float beta2, float eps, int32_t step,
+                           float ema_weight, float* hyper_dev, inr_stream_t s);
+int inr_adam_ema_step_multi_dev(int32_t n_tensors, float* const* params /*host array of device pointers*/,
+                                const float* const* grads, float* const* exp_avgs, float* const* exp_avg_sqs,
+                                const int64_t* numels /*host*/, const float* hyper_dev, float beta1, float beta2,
+                                float grad_scale, float* const* ema_shadows /*host array*/, inr_stream_t s);
 /* Mask-supervised loss of the instance stage (a13; replaces F.cross_entropy(logits, labels, ignore_index) + its
  * backward in the fork's instance trainer): loss[0] = mean over rows with 0 <= label < K and label != ignore_index of
  * logsumexp(row) - row[label]; grad_logits [N,K] = d loss / d logits (zero rows where ignored); acc = 128 floats of

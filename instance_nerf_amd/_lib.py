@@ -67,6 +67,9 @@ _SIGS = {
                                           c_float, P]),
     "inr_adam_set_hyper": (c_int32, [P, c_int32, c_float, c_float, c_float, c_int32, P, P]),
     "inr_adam_step_multi_dev": (c_int32, [c_int32, P, P, P, P, P, P, c_float, c_float, c_float, P]),
+    "inr_copy_multi": (c_int32, [c_int32, P, P, P, P]),
+    "inr_adam_set_hyper_ema": (c_int32, [P, c_int32, c_float, c_float, c_float, c_int32, c_float, P, P]),
+    "inr_adam_ema_step_multi_dev": (c_int32, [c_int32, P, P, P, P, P, P, c_float, c_float, c_float, P, P]),
     "inr_cross_entropy": (c_int32, [P, P, c_int64, c_int32, c_int64, P, P, P, P]),
     "inr_finish_rays": (c_int32, [P, P, P, P, P, P, c_float, c_float, c_float, c_int64, P, P, P]),
     "inr_finish_rays_mse": (c_int32, [P, P, P, P, P, c_float, c_float, c_float, P, P, c_int64, P, P, P, P, P]),

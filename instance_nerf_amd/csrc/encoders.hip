@@ -258,10 +258,27 @@ struct AdamJobs {
   float* s[kAdamMaxTensors];      // parameter EMA (nullable per tensor): s += ema_w * (p_new - s) while p is in registers
 };
 struct AdamHyper {
-  float v[1 + kAdamMaxTensors];
+  float v[2 + kAdamMaxTensors];     // [eps_t, lr_t[0..15], ema weight]
 };
-__global__ void k_adam_set_hyper(AdamHyper h, float* __restrict__ hyper) {
-  if (threadIdx.x < 1 + kAdamMaxTensors) hyper[threadIdx.x] = h.v[threadIdx.x];
+__global__ void k_adam_set_hyper(AdamHyper h, float* __restrict__ hyper, int n) {
+  if ((int)threadIdx.x < n) hyper[threadIdx.x] = h.v[threadIdx.x];
+}
+
+// Up to 8 small device-to-device copies in ONE launch (the static inputs of a captured training step: rays, labels and
+// the sample counter are handed to the graph through fixed buffers - five copy launches per step serialised in front
+// of every replay, ~25 us of a 0.85 ms step).  Byte counts and addresses must be multiples of 4.
+constexpr int kCopyMaxJobs = 8;
+struct CopyJobs {
+  uint32_t* dst[kCopyMaxJobs];
+  const uint32_t* src[kCopyMaxJobs];
+  int64_t words[kCopyMaxJobs];
+};
+__global__ void __launch_bounds__(256) k_copy_multi(CopyJobs J) {
+  const int t = blockIdx.y;
+  const int64_t n = J.words[t], stride = (int64_t)gridDim.x * blockDim.x;
+  uint32_t* __restrict__ d = J.dst[t];
+  const uint32_t* __restrict__ s = J.src[t];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) d[i] = s[i];
 }
 
 // hyper (nullable, device): [eps_t, lr_t[0..15]] - the step-dependent scalars live in memory so that a captured
@@ -272,6 +289,7 @@ __global__ void __launch_bounds__(256) k_adam_multi(AdamJobs J, float b1, float 
   if (hyper) {
     eps_t = hyper[0];
     J.lr_t[t] = hyper[1 + t];
+    if (J.s[t]) ema_w = hyper[1 + kAdamMaxTensors];
   }
   float* __restrict__ p = J.p[t];
   const float* __restrict__ g = J.g[t];
@@ -622,6 +640,24 @@ int inr_adam_ema_step_multi(int32_t n_tensors, float* const* params, const float
                            grad_scale, ema_shadows, ema_weight, s, "adam_ema_step_multi");
 }
 
+int inr_copy_multi(int32_t n, void* const* dsts, const void* const* srcs, const int64_t* nbytes, inr_stream_t s) {
+  INR_REQUIRE(n >= 0 && n <= kCopyMaxJobs, "bad argument (at most 8 copies per call)");
+  if (n == 0) return INR_OK;
+  INR_REQUIRE(dsts && srcs && nbytes, "null pointer");
+  CopyJobs J;
+  int64_t w_max = 0;
+  for (int t = 0; t < n; ++t) {
+    INR_REQUIRE(nbytes[t] >= 0 && nbytes[t] % 4 == 0 && (nbytes[t] == 0 || (dsts[t] && srcs[t])), "bad copy job");
+    INR_REQUIRE((((uintptr_t)dsts[t] | (uintptr_t)srcs[t]) & 3) == 0, "copy job not 4-byte aligned");
+    J.dst[t] = (uint32_t*)dsts[t]; J.src[t] = (const uint32_t*)srcs[t]; J.words[t] = nbytes[t] / 4;
+    w_max = std::max(w_max, J.words[t]);
+  }
+  if (w_max == 0) return INR_OK;
+  const unsigned nb = (unsigned)std::min<int64_t>((w_max + 255) / 256, 1024);
+  k_copy_multi<<<dim3(nb, n), 256, 0, as_stream(s)>>>(J);
+  return check_launch("copy_multi");
+}
+
 int inr_adam_set_hyper(const float* lrs, int32_t n_tensors, float beta1, float beta2, float eps, int32_t step,
                        float* hyper_dev, inr_stream_t s) {
   INR_REQUIRE(lrs && hyper_dev && n_tensors >= 0 && n_tensors <= kAdamMaxTensors && step >= 1, "bad argument");
@@ -630,13 +666,49 @@ int inr_adam_set_hyper(const float* lrs, int32_t n_tensors, float beta1, float b
   h.v[0] = (float)(eps * sqrt(bc2));
   for (int t = 0; t < kAdamMaxTensors; ++t) h.v[1 + t] = t < n_tensors ? (float)(lrs[t] * sqrt(bc2) / bc1) : 0.f;
   // the values travel as kernel arguments (copied at launch), so the caller's buffers may change right away
-  k_adam_set_hyper<<<1, 32, 0, as_stream(s)>>>(h, hyper_dev);
+  h.v[1 + kAdamMaxTensors] = 0.f;
+  k_adam_set_hyper<<<1, 32, 0, as_stream(s)>>>(h, hyper_dev, 1 + kAdamMaxTensors);
   return check_launch("adam_set_hyper");
 }
+
+int inr_adam_set_hyper_ema(const float* lrs, int32_t n_tensors, float beta1, float beta2, float eps, int32_t step,
+                           float ema_weight, float* hyper_dev, inr_stream_t s) {
+  INR_REQUIRE(lrs && hyper_dev && n_tensors >= 0 && n_tensors <= kAdamMaxTensors && step >= 1, "bad argument");
+  INR_REQUIRE(ema_weight >= 0.f && ema_weight <= 1.f, "ema_weight outside [0, 1]");
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  AdamHyper h;
+  h.v[0] = (float)(eps * sqrt(bc2));
+  for (int t = 0; t < kAdamMaxTensors; ++t) h.v[1 + t] = t < n_tensors ? (float)(lrs[t] * sqrt(bc2) / bc1) : 0.f;
+  h.v[1 + kAdamMaxTensors] = ema_weight;
+  k_adam_set_hyper<<<1, 32, 0, as_stream(s)>>>(h, hyper_dev, 2 + kAdamMaxTensors);
+  return check_launch("adam_set_hyper_ema");
+}
+
+static int adam_multi_dev_launch(int32_t n_tensors, float* const* params, const float* const* grads,
+                                 float* const* exp_avgs, float* const* exp_avg_sqs, const int64_t* numels,
+                                 const float* hyper_dev, float beta1, float beta2, float grad_scale,
+                                 float* const* ema_shadows, inr_stream_t s);
 
 int inr_adam_step_multi_dev(int32_t n_tensors, float* const* params, const float* const* grads, float* const* exp_avgs,
                             float* const* exp_avg_sqs, const int64_t* numels, const float* hyper_dev, float beta1,
                             float beta2, float grad_scale, inr_stream_t s) {
+  return adam_multi_dev_launch(n_tensors, params, grads, exp_avgs, exp_avg_sqs, numels, hyper_dev, beta1, beta2,
+                               grad_scale, nullptr, s);
+}
+
+int inr_adam_ema_step_multi_dev(int32_t n_tensors, float* const* params, const float* const* grads,
+                                float* const* exp_avgs, float* const* exp_avg_sqs, const int64_t* numels,
+                                const float* hyper_dev, float beta1, float beta2, float grad_scale,
+                                float* const* ema_shadows, inr_stream_t s) {
+  INR_REQUIRE(n_tensors == 0 || ema_shadows, "null pointer");
+  return adam_multi_dev_launch(n_tensors, params, grads, exp_avgs, exp_avg_sqs, numels, hyper_dev, beta1, beta2,
+                               grad_scale, ema_shadows, s);
+}
+
+static int adam_multi_dev_launch(int32_t n_tensors, float* const* params, const float* const* grads,
+                                 float* const* exp_avgs, float* const* exp_avg_sqs, const int64_t* numels,
+                                 const float* hyper_dev, float beta1, float beta2, float grad_scale,
+                                 float* const* ema_shadows, inr_stream_t s) {
   INR_REQUIRE(n_tensors >= 0 && n_tensors <= kAdamMaxTensors, "bad argument (at most 16 tensors per call)");
   if (n_tensors == 0) return INR_OK;
   INR_REQUIRE(params && grads && exp_avgs && exp_avg_sqs && numels && hyper_dev, "null pointer");
@@ -647,7 +719,7 @@ int inr_adam_step_multi_dev(int32_t n_tensors, float* const* params, const float
                 "null tensor pointer");
     J.p[t] = params[t]; J.g[t] = grads[t]; J.m[t] = exp_avgs[t]; J.v[t] = exp_avg_sqs[t]; J.n[t] = numels[t];
     J.lr_t[t] = 0.f;
-    J.s[t] = nullptr;
+    J.s[t] = ema_shadows ? ema_shadows[t] : nullptr;
     n_max = std::max(n_max, numels[t]);
   }
   if (n_max == 0) return INR_OK;

@@ -500,13 +500,18 @@ class NeRFNetwork(NeRFRenderer):
     def _nerf_params(self):
         return [self.encoder.embeddings] + [l.weight for l in self.sigma_net] + [l.weight for l in self.color_net]
 
-    def _fused_nerf(self, x, d, want_rgb, want_geo):
+    def _fused_nerf(self, x, d, want_rgb, want_geo, out=None):
+        """``out`` = (sigma [M], rgb [M,3]): caller-owned result buffers (``march_ahead(shade=True)`` runs this on a
+        side stream, where nothing may be allocated)."""
         lib = _lib.load()
         x = x.contiguous().float()
         M = x.shape[0]
         dev = x.device
-        sigma = torch.empty(M, dtype=torch.float32, device=dev)
-        rgb = torch.empty(M, 3, dtype=torch.float32, device=dev) if want_rgb else None
+        if out is not None:
+            sigma, rgb = out
+        else:
+            sigma = torch.empty(M, dtype=torch.float32, device=dev)
+            rgb = torch.empty(M, 3, dtype=torch.float32, device=dev) if want_rgb else None
         geo = torch.empty(M, self.geo_feat_dim, dtype=torch.float32, device=dev) if want_geo else None
         if want_rgb:
             d = d.contiguous().float()

@@ -326,12 +326,18 @@ class NeRFRenderer(nn.Module):
                     counter, mean_count, perturb, 128, force_all_rays, dt_gamma, max_steps, noises=noises)
             if self.training:
                 self.last_counter = counter          # (total samples, N) of the march this render consumed
-            sigmas, rgbs = self(xyzs, dirs)
-            if self.density_scale != 1:
-                sigmas = self.density_scale * sigmas
-            if with_instance and getattr(self, "instance_head_available", lambda x: False)(xyzs):
+            head = with_instance and getattr(self, "instance_head_available", lambda x: False)(xyzs)
+            shaded = None
+            if (marched is not None and marched.get("shaded") is not None and head and self.shade_ahead_applies()
+                    and marched["T_thresh"] == float(T_thresh) and marched["density_scale"] == float(self.density_scale)):
+                shaded = marched["shaded"]           # frozen field + compositing forward were queued with the march
+            else:
+                sigmas, rgbs = self(xyzs, dirs)
+                if self.density_scale != 1:
+                    sigmas = self.density_scale * sigmas
+            if head:
                 # the instance head as ONE autograd node (field + K-channel compositing; one backward launch)
-                weights_sum, depth, image, wbuf, sample_ray = raymarching.composite_rays_train(
+                weights_sum, depth, image, wbuf, sample_ray = shaded if shaded is not None else raymarching.composite_rays_train(
                     sigmas, rgbs, deltas, rays, T_thresh, return_weights=True, total_dev=counter)
                 if ce_labels is not None:
                     # the mask loss of the instance stage inside the compositing launch (Trainer.train_step passes the
@@ -498,19 +504,48 @@ class NeRFRenderer(nn.Module):
                                                   float(self.bound), ptr(self.density_grid, torch.float32, "density_grid"),
                                                   stream_ptr()), "mark_untrained_grid")
 
+    def shade_ahead_applies(self):
+        """``march_ahead(shade=True)`` may also run the field and the compositing forward: a FROZEN NeRF on the fused
+        kernel (nothing of it is trained, so neither launch depends on what the step in flight updates) rendered
+        together with the one-node instance head."""
+        if not (getattr(self, "num_instances", 0) > 0 and getattr(self, "_fusable", False)
+                and hasattr(self, "_nerf_params") and hasattr(self, "instance_head_train")):
+            return False
+        if any(p.requires_grad for p in self._nerf_params()):
+            return False
+        inst = [self.instance_encoder.embeddings] + [l.weight for l in self.instance_net]
+        return bool(self._fusable_inst and self.fused_instance_train and self.fused_instance_head
+                    and all(p.requires_grad for p in inst))
+
     @torch.no_grad()
-    @torch.no_grad()
-    def march_ahead(self, rays_o, rays_d, dt_gamma=0, perturb=False, max_steps=1024, stream=None):
+    def march_ahead(self, rays_o, rays_d, dt_gamma=0, perturb=False, max_steps=1024, stream=None, shade=False,
+                    T_thresh=1e-4, bufs=None, counter=None):
         """The parameter-independent head of a TRAINING render - ray/box test, jitter, march (count, scan, write) - queued
         now, on ``stream`` (a side stream: it then runs beside whatever the current stream is busy with - the previous
         step's backward, whose table-gradient scatter leaves the CUs idle; measured: ~47 of its ~60 us hide), for a
         ``render(..., marched=<result>)`` of the SAME rays later.  Needs the steady state (``mean_count > 0``: no host
         read-back) and an occupancy grid that will not change in between (the caller's business: ``Trainer`` skips the
-        step before an occupancy update).  -> the dict ``run_cuda`` takes as ``marched`` or None."""
+        step before an occupancy update).  -> the dict ``run_cuda`` takes as ``marched`` or None (nothing queued,
+        nothing counted: the caller marches in the step as usual).
+
+        shade (round 4): with a frozen NeRF under the one-node instance head (``shade_ahead_applies``) the field
+        evaluation and the compositing forward do not depend on the trained parameters either: both are queued behind
+        the march, into the same persistent buffer set - ~165 us of the instance stage's ~0.83 ms step that can run
+        beside the atomic-bound scatter.  ``bufs`` / ``counter``: a caller-owned buffer set
+        (``raymarching.march_train_buffers(shade=...)``) and sample counter (int32 [2]) instead of the renderer's two
+        alternating sets and its ``step_counter`` slot - the captured pipeline of ``Trainer`` owns both."""
         if not (self.cuda_ray and self.training and self.mean_count > 0 and rays_o.is_cuda):
             return None
+        rays_o_in, rays_d_in = rays_o, rays_d
         rays_o = rays_o.contiguous().view(-1, 3).float()
         rays_d = rays_d.contiguous().view(-1, 3).float()
+        N = rays_o.shape[0]
+        # the persistent buffers need the staged wave-per-ray marcher (its write pass clears the rows no ray owns):
+        # larger batches, longer rays or set_march_mode(0) fall back to the in-step march - asked BEFORE a counter slot
+        # is taken (round-3 advisor: the refusal used to surface as a RuntimeError inside the backward hook)
+        if not _lib.load().inr_march_write_fills_unowned_rows(N, raymarching.SAMPLE_CAP_TRAIN, int(max_steps)):
+            return None
+        shade = bool(shade) and self.shade_ahead_applies()
         main = torch.cuda.current_stream()
         side = stream if stream is not None else main
         if side is not main:
@@ -520,33 +555,59 @@ class NeRFRenderer(nn.Module):
         # cost ~0.2 ms of host time per step - measured, profiles/r03_NOTES.txt 16).  Set A is read by step i (forward
         # and, through autograd's saved tensors, backward) while the side stream fills set B for step i + 1; set A is
         # written again for step i + 2 only after `side.wait_stream(main)` below, i.e. behind all of step i's launches.
-        N = rays_o.shape[0]
         M_al = (int(self.mean_count) + 127) // 128 * 128
-        bufs = getattr(self, "_ahead_bufs", None)
-        if bufs is None or bufs[0]["n_rays"] != N or bufs[0]["n_samples"] != M_al or bufs[0]["nears"].device != rays_o.device:
-            bufs = self._ahead_bufs = [raymarching.march_train_buffers(N, M_al, rays_o.device) for _ in range(2)]
-            self._ahead_turn = 0
-        b = bufs[self._ahead_turn]
-        self._ahead_turn ^= 1
-        counter = self.step_counter[self.local_step % 16]
-        self.local_step += 1
+        if bufs is not None:
+            b = bufs
+            if b["n_rays"] != N or b["n_samples"] < M_al or (shade and "sigmas" not in b):
+                raise RuntimeError("march_ahead(bufs=): buffer set of another batch size")
+        else:
+            own = getattr(self, "_ahead_bufs", None)
+            if (own is None or own[0]["n_rays"] != N or own[0]["n_samples"] != M_al or own[0]["nears"].device != rays_o.device
+                    or (shade and "sigmas" not in own[0])):
+                own = self._ahead_bufs = [raymarching.march_train_buffers(N, M_al, rays_o.device, shade=shade) for _ in range(2)]
+                self._ahead_turn = 0
+            b = own[self._ahead_turn]
+            self._ahead_turn ^= 1
+        slot_taken = counter is None
+        if counter is None:
+            counter = self.step_counter[self.local_step % 16]
+            self.local_step += 1
         with torch.cuda.stream(side):
             nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, self.aabb_train, self.min_near,
                                                          out=(b["nears"], b["fars"]))
             xyzs, dirs, deltas, rays = raymarching.march_rays_train(
                 rays_o, rays_d, self.bound, self.density_bitfield, self.cascade, self.grid_size, nears, fars,
                 counter, self.mean_count, perturb, 128, False, dt_gamma, max_steps, out=b)
-            done = torch.cuda.Event()
-            done.record(side)
-        out = {"n_rays": N, "key": (rays_o.data_ptr(), rays_d.data_ptr(), N),
-               "nears": nears, "fars": fars, "xyzs": xyzs, "dirs": dirs, "deltas": deltas, "rays": rays, "counter": counter}
+            shaded = None
+            if shade:
+                M = xyzs.shape[0]
+                sigmas, rgbs = b["sigmas"][:M], b["rgbs"][:M]
+                self._fused_nerf(xyzs, dirs, True, False, out=(sigmas, rgbs))
+                if self.density_scale != 1:
+                    sigmas.mul_(self.density_scale)
+                shaded = raymarching.composite_rays_train_into(sigmas, rgbs, deltas, rays, T_thresh, b)
+            done = None
+            if side is not main:
+                done = torch.cuda.Event()
+                done.record(side)
+        out = {"n_rays": N, "key": (rays_o.data_ptr(), rays_d.data_ptr(), N), "rays_o": rays_o_in, "rays_d": rays_d_in,
+               "nears": nears, "fars": fars, "xyzs": xyzs, "dirs": dirs, "deltas": deltas, "rays": rays, "counter": counter,
+               "shaded": shaded, "T_thresh": float(T_thresh), "density_scale": float(self.density_scale),
+               "slot_taken": slot_taken}
 
         def consume():
             cur = torch.cuda.current_stream()
-            if side is not cur:
+            if done is not None and side is not cur:
                 cur.wait_event(done)
         out["consume"] = consume
         return out
+
+    def drop_ahead(self, marched):
+        """A prefetched march that no render will consume: give its ``step_counter`` slot back (it would otherwise count
+        as a step of its own in the next ``mean_count``)."""
+        if marched is not None and marched.get("slot_taken") and self.local_step > 0:
+            self.local_step -= 1
+            marched["slot_taken"] = False
 
     @torch.no_grad()        # as upstream's: without it the NeRF stage's update ran the density query through the
     #                          composable autograd path (HIP encoder + BLAS layers, graph and all): 2.0 instead of 1.0 ms

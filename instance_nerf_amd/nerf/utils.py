@@ -342,20 +342,31 @@ class FusedAdam(torch.optim.Optimizer):
 
     # -- hipGraph support: the step-dependent scalars live in a device tensor --------------------------------
     def refresh_hyper(self):
-        """Advance the step counter and write [eps_t, lr_t...] for the NEXT launch of ``step_captured`` (a tiny
-        kernel on the stream whose arguments carry the values: call it right before the launch / graph replay)."""
+        """Advance the step counter and write [eps_t, lr_t..., ema weight] for the NEXT launch of ``step_captured`` (a
+        tiny kernel on the stream whose arguments carry the values: call it right before the launch / graph replay)."""
         import ctypes
         lib = _lib.load()
         self.step_count += 1
         lrs = [float(j[4]["lr"]) for j in self._hyper_jobs]
-        _lib.check(lib.inr_adam_set_hyper((ctypes.c_float * len(lrs))(*lrs), len(lrs), self.betas[0], self.betas[1],
-                                          self.eps, self.step_count, _lib.ptr(self._hyper_dev), _lib.stream_ptr()),
-                   "adam_set_hyper")
+        arr = (ctypes.c_float * len(lrs))(*lrs)
+        if self._ema is not None:
+            self._ema.begin_fused_update()                # counts the update, sets fused_weight = 1 - decay_t
+            _lib.check(lib.inr_adam_set_hyper_ema(arr, len(lrs), self.betas[0], self.betas[1], self.eps, self.step_count,
+                                                  float(self._ema.fused_weight), _lib.ptr(self._hyper_dev),
+                                                  _lib.stream_ptr()), "adam_set_hyper_ema")
+        else:
+            _lib.check(lib.inr_adam_set_hyper(arr, len(lrs), self.betas[0], self.betas[1], self.eps, self.step_count,
+                                              _lib.ptr(self._hyper_dev), _lib.stream_ptr()), "adam_set_hyper")
+
+    def hyper_tensor(self, device):
+        if getattr(self, "_hyper_dev", None) is None:
+            self._hyper_dev = torch.zeros(18, dtype=torch.float32, device=device)
+        return self._hyper_dev
 
     @torch.no_grad()
     def step_captured(self):
-        """``step()`` for use inside a captured graph: identical arithmetic, learning rate and bias correction read
-        from device memory (``refresh_hyper``).  At most 16 tensors."""
+        """``step()`` for use inside a captured graph: identical arithmetic, learning rate, bias correction and - with an
+        attached ``ParamEMA`` - the average's weight read from device memory (``refresh_hyper``).  At most 16 tensors."""
         import ctypes
         lib = _lib.load()
         jobs = self._jobs()
@@ -363,9 +374,7 @@ class FusedAdam(torch.optim.Optimizer):
             raise RuntimeError("step_captured handles at most 16 parameter tensors")
         if any(j[6] is not None for j in jobs):
             raise RuntimeError("step_captured does not take reduce-scattered gradient pieces")
-        if getattr(self, "_hyper_dev", None) is None:
-            dev = jobs[0][0].device
-            self._hyper_dev = torch.zeros(17, dtype=torch.float32, device=dev)
+        self.hyper_tensor(jobs[0][0].device)
         self._hyper_jobs = jobs
         n = len(jobs)
         for j in jobs:
@@ -373,12 +382,26 @@ class FusedAdam(torch.optim.Optimizer):
                 _lib.ptr(t, torch.float32, name)
         arr = lambda k: (ctypes.c_void_p * n)(*[j[k].data_ptr() for j in jobs])
         numels = (ctypes.c_int64 * n)(*[j[0].numel() for j in jobs])
-        _lib.check(lib.inr_adam_step_multi_dev(n, arr(0), arr(1), arr(2), arr(3), numels, _lib.ptr(self._hyper_dev),
-                                               self.betas[0], self.betas[1], 1.0, _lib.stream_ptr()), "adam_step_multi_dev")
+        if self._ema is not None:
+            shadow_of = {id(p): sh for p, sh in zip(self._ema.params, self._ema.shadow)}
+            shadows = (ctypes.c_void_p * n)(*[(shadow_of[id(j[5])].data_ptr() if id(j[5]) in shadow_of else None)
+                                              for j in jobs])
+            _lib.check(lib.inr_adam_ema_step_multi_dev(n, arr(0), arr(1), arr(2), arr(3), numels,
+                                                       _lib.ptr(self._hyper_dev), self.betas[0], self.betas[1], 1.0,
+                                                       shadows, _lib.stream_ptr()), "adam_ema_step_multi_dev")
+        else:
+            _lib.check(lib.inr_adam_step_multi_dev(n, arr(0), arr(1), arr(2), arr(3), numels, _lib.ptr(self._hyper_dev),
+                                                   self.betas[0], self.betas[1], 1.0, _lib.stream_ptr()),
+                       "adam_step_multi_dev")
 
     def bump_versions(self):
-        for j in getattr(self, "_hyper_jobs", []):
-            torch.autograd.graph.increment_version(j[5])
+        """After a replay of the captured step: the parameters changed behind autograd's back (packed-weight caches key
+        on the version), and the attached average has been advanced by the sweep."""
+        owners = [j[5] for j in getattr(self, "_hyper_jobs", [])]
+        for p in owners:
+            torch.autograd.graph.increment_version(p)
+        if self._ema is not None:
+            self._ema.end_fused_update({id(p) for p in owners})
 
 
 class _GradSync:
@@ -690,6 +713,26 @@ class ParamEMA:
             s.copy_(v.to(s.device))
 
 
+def copy_tensors(pairs):
+    """[(dst, src)] device tensors of equal size: ONE launch for up to 8 of them (``inr_copy_multi``) when they are
+    contiguous GPU tensors of the same dtype with 4-byte-multiple sizes, ``dst.copy_(src)`` otherwise."""
+    import ctypes
+    fast = [(d, s) for d, s in pairs if d.is_cuda and s.is_cuda and d.dtype == s.dtype and d.is_contiguous()
+            and s.is_contiguous() and d.numel() == s.numel() and (d.numel() * d.element_size()) % 4 == 0
+            and d.device == s.device and d.data_ptr() % 4 == 0 and s.data_ptr() % 4 == 0]
+    for d, s in pairs:
+        if not any(d is f[0] for f in fast):
+            d.copy_(s, non_blocking=True)
+    lib = _lib.load()
+    for i in range(0, len(fast), 8):
+        chunk = fast[i:i + 8]
+        n = len(chunk)
+        _lib.check(lib.inr_copy_multi(n, (ctypes.c_void_p * n)(*[d.data_ptr() for d, _ in chunk]),
+                                      (ctypes.c_void_p * n)(*[s.data_ptr() for _, s in chunk]),
+                                      (ctypes.c_int64 * n)(*[d.numel() * d.element_size() for d, _ in chunk]),
+                                      _lib.stream_ptr()), "copy_multi")
+
+
 class Trainer:
     """Counterpart of upstream's ``Trainer`` (``nerf/utils.py`` of the un-vendored submodule) for the two stages the
     reference runs: NeRF training (MSE on rgb) and instance-field training (NeRF frozen,
@@ -720,7 +763,7 @@ class Trainer:
                  workspace="workspace", best_mode="min", use_loss_as_metric=True, report_metric_at_train=False,
                  use_checkpoint="latest", use_tensorboardX=True, scheduler_update_every_step=False, *,
                  lr=1e-2, iters=30000, fused_adam=True, stage="nerf", update_extra_interval=None, use_graph=False,
-                 look_ahead=False):
+                 look_ahead=False, shade_ahead=None):
         self.name, self.opt, self.model = name, opt, model
         self.world_size, self.local_rank = world_size, local_rank
         grad_sync.world_size = world_size
@@ -764,6 +807,15 @@ class Trainer:
         # step (4 %) in tools/train_probe.py; in bench.py's loop (EMA, occupancy updates, per-step events) the extra
         # ~0.2 ms of host work per step made the host the limit on most boxes: off by default (r03 notes 16)
         self.look_ahead = bool(look_ahead)
+        # opt-in on top of look_ahead, instance stage: the look-ahead also runs the frozen NeRF's forward and the weight
+        # compositing of the next batch (NeRFRenderer.march_ahead(shade=True)).  Bit-identical.  What it buys is small:
+        # beside the table-gradient scatter the gather-bound forward takes 350-415 us instead of 100, the scatter
+        # 370 -> 456 and the optimiser sweep 51 -> 117 - all three queue on the L2's fabric ports
+        # (profiles/r04_NOTES.txt 2); the march (VALU-bound, bitfield in the L2) is what really hides.
+        # (default: on exactly when the step is the captured pipeline, where it measured -4..-6 % on the step in spite of
+        # that; in the eager look-ahead it only adds host work)
+        self.shade_ahead = bool(use_graph and look_ahead) if shade_ahead is None else bool(shade_ahead)
+        self.pipe_fork = os.environ.get("INR_PIPE_FORK", "scatter")     # probe switch: where the captured step forks
         self.iters = iters
         # upstream: lr_scheduler = lambda optimizer: LambdaLR(optimizer, lambda it: 0.1 ** min(it / opt.iters, 1)),
         # stepped after every optimiser step; without one, exactly that rule is applied to the param groups
@@ -777,9 +829,11 @@ class Trainer:
         # replayed; one process, FusedAdam only, built-in learning-rate rule.  Falls back to the eager step otherwise.
         self.use_graph = (bool(use_graph) and world_size == 1 and isinstance(self.optimizer, FusedAdam)
                           and self.lr_scheduler is None)
-        if self.ema is not None and isinstance(self.optimizer, FusedAdam) and not self.use_graph:
-            self.optimizer.attach_ema(self.ema)        # the average advances inside the optimiser's launch
+        if self.ema is not None and isinstance(self.optimizer, FusedAdam):
+            self.optimizer.attach_ema(self.ema)        # the average advances inside the optimiser's launch (eager and
+            #                                            captured steps: inr_adam_ema_step_multi / _dev)
         self._graph = None
+        self._pipe = None                              # captured two-stream pipeline (use_graph and look_ahead)
         self.global_step = 0
         self.local_step = 0
         self.epoch = 0
@@ -836,8 +890,12 @@ class Trainer:
         ahead = self._ahead
         if ahead is not None:
             self._ahead = None
-            if ahead["key"] == (data["rays_o"].data_ptr(), data["rays_d"].data_ptr(), data["rays_o"].numel() // 3):
+            # the prefetch belongs to THESE tensors (identity, not addresses: a freshly allocated batch may reuse the
+            # address of a freed one - round-3 advisor)
+            if ahead["rays_o"] is data["rays_o"] and ahead["rays_d"] is data["rays_d"]:
                 extra["marched"] = ahead            # this batch's march was queued under the previous step's backward
+            elif hasattr(self.model, "drop_ahead"):
+                self.model.drop_ahead(ahead)        # never consumed: its step_counter slot is given back
         outputs = self.model.render(data["rays_o"], data["rays_d"], staged=False, bg_color=bg_color, perturb=True,
                                     force_all_rays=False, **extra, **self._render_kwargs())
         if self.stage == "nerf":
@@ -926,8 +984,7 @@ class Trainer:
             for p in g["params"]:               # (an allocation + zero fill inside it would be replayed every step)
                 if p.requires_grad:
                     opt._moments(p)
-        if getattr(opt, "_hyper_dev", None) is None:
-            opt._hyper_dev = torch.zeros(17, dtype=torch.float32, device=self.device)
+        opt.hyper_tensor(self.device)
         self.optimizer.zero_grad()
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
@@ -940,9 +997,7 @@ class Trainer:
 
     def _replay(self, data):
         G, m = self._graph, self.model
-        for k, v in data.items():
-            if torch.is_tensor(v):
-                G["static"][k].copy_(v, non_blocking=True)
+        copy_tensors([(G["static"][k], v) for k, v in data.items() if torch.is_tensor(v)])
         self._lr_step()
         self.optimizer.refresh_hyper()
         G["graph"].replay()
@@ -953,6 +1008,129 @@ class Trainer:
         self.optimizer.bump_versions()
         if self.ema is not None:
             self.ema.update()
+        return G["loss"].detach()
+
+    # -- captured two-stream pipeline (use_graph and look_ahead) -------------------------------------------------
+    # The step is bound by the table-gradient scatter (memory-side atomic unit; the CUs idle for most of it) and by the
+    # host (0.6-0.85 ms to enqueue 0.83 ms of kernels; a second queue costs the runtime ~0.3 ms more per step,
+    # profiles/r03_NOTES.txt 16).  Both at once: ONE hipGraph per step holds the step's own launches on the capture
+    # stream and, forked off right before the scatter, the parameter-independent head of the NEXT batch on a second
+    # stream - ray/box test, march and, in the instance stage, the frozen NeRF's forward and the weight compositing
+    # (``NeRFRenderer.march_ahead(shade=True)``) - joined again before the graph ends.  Two persistent buffer sets
+    # alternate (step i reads set A and fills B, step i+1 reads B and fills A), so there is one graph per (set, does the
+    # step compute its own head, does it look ahead): the first step after an occupancy update computes its own head
+    # (the grid changed), the last one before an update does not look ahead.
+    def _pipe_applies(self, data):
+        m = self.model
+        return (self.use_graph and self.look_ahead and m.cuda_ray and m.mean_count > 0 and data["rays_o"].is_cuda
+                and hasattr(m, "march_ahead"))
+
+    def _pipe_args(self):
+        kw = self._render_kwargs()
+        return dict(dt_gamma=kw.get("dt_gamma", 0), perturb=True, max_steps=kw.get("max_steps", 1024),
+                    shade=self.stage == "instance" and self.shade_ahead, T_thresh=kw.get("T_thresh", 1e-4))
+
+    def _pipe_init(self, data):
+        from .. import raymarching
+        m, dev = self.model, data["rays_o"].device
+        N = data["rays_o"].numel() // 3
+        M_al = (int(m.mean_count) + 127) // 128 * 128
+        shade = self.stage == "instance" and self.shade_ahead and m.shade_ahead_applies()
+        sets = []
+        for _ in range(2):
+            sets.append({"bufs": raymarching.march_train_buffers(N, M_al, dev, shade=shade),
+                         "static": {k: (v.clone() if torch.is_tensor(v) else v) for k, v in data.items()},
+                         "counter": torch.zeros(2, dtype=torch.int32, device=dev), "marched": None})
+        opt = self.optimizer
+        for g in opt.param_groups:              # moments and the hyper-parameter tensor must exist BEFORE a capture
+            for p in g["params"]:
+                if p.requires_grad:
+                    opt._moments(p)
+        opt.hyper_tensor(dev)
+        self._pipe = {"key": self._graph_key(data), "sets": sets, "graphs": {}, "turn": 0, "primed": False,
+                      "expect": None, "side": torch.cuda.Stream(device=dev)}
+
+    def _pipe_capture(self, turn, prime, ahead):
+        from . import network as _network
+        from .. import raymarching
+        P, m = self._pipe, self.model
+        S, Nx = P["sets"][turn], P["sets"][turn ^ 1]
+        args = self._pipe_args()
+        if not prime and S["marched"] is None:
+            raise RuntimeError("pipeline: a step that consumes a prefetched head was asked for before any prefetch")
+        self.optimizer.zero_grad()
+        torch.cuda.synchronize()
+        step0 = m.local_step
+        side = P["side"]
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            if prime:
+                S["marched"] = m.march_ahead(S["static"]["rays_o"], S["static"]["rays_d"], stream=None, bufs=S["bufs"],
+                                             counter=S["counter"], **args)
+                if S["marched"] is None:
+                    raise RuntimeError("pipeline: march_ahead refused the batch (not the steady state / staged marcher)")
+            marched = dict(S["marched"])
+            marched["consume"] = lambda: None        # same graph or an earlier replay on the same stream: ordered already
+            self._ahead = marched
+
+            def hook():
+                Nx["marched"] = m.march_ahead(Nx["static"]["rays_o"], Nx["static"]["rays_d"], stream=side, bufs=Nx["bufs"],
+                                              counter=Nx["counter"], **args)
+            if ahead and self.pipe_fork == "start":
+                hook()                               # fork right away: beside the whole step
+            elif ahead:
+                _network._before_scatter["hook"] = hook      # fork from inside the backward, right before the scatter
+            _, _, loss = self.train_step(S["static"])
+            if self._ahead is not None:
+                raise RuntimeError("pipeline: the render did not take the prefetched head")
+            loss.backward(gradient=raymarching.unit_gradient(loss.device))
+            if ahead and _network._before_scatter.pop("hook", None) is not None:
+                hook()                               # no fused table backward ran (composable path): fork here
+            self.optimizer.step_captured()
+            if ahead:
+                torch.cuda.current_stream().wait_stream(side)        # join: the graph ends with both branches done
+        m.local_step = step0                    # the capture pass launched nothing; undo its bookkeeping
+        G = {"graph": g, "loss": loss}
+        P["graphs"][(turn, prime, ahead)] = G
+        return G
+
+    def _pipe_step(self, data, next_data):
+        m = self.model
+        key = self._graph_key(data)
+        if self._pipe is None or self._pipe["key"] != key:
+            self._pipe_init(data)
+        P = self._pipe
+        t = P["turn"]
+        S, Nx = P["sets"][t], P["sets"][t ^ 1]
+        prime = not (P["primed"] and P["expect"] is data["rays_o"])
+        pairs = []
+        if prime:
+            pairs += [(S["static"][k], v) for k, v in data.items() if torch.is_tensor(v)]
+        # no look-ahead across an occupancy update (global_step is already advanced: the next call starts with one
+        # when it is a multiple of the interval), nor into a batch of another shape
+        ahead = (next_data is not None and self.global_step % self.update_extra_interval != 0
+                 and all(torch.is_tensor(next_data.get(k)) and next_data[k].shape == v.shape and next_data[k].dtype == v.dtype
+                         for k, v in Nx["static"].items() if torch.is_tensor(v)))
+        if ahead:
+            pairs += [(Nx["static"][k], v) for k, v in next_data.items() if torch.is_tensor(v)]
+        if not prime:
+            # the march of THIS batch ran in the previous replay, into the set's own counter: it goes to the renderer's
+            # slot together with the inputs (one launch); a step that marches itself copies after its replay
+            pairs.append((m.step_counter[m.local_step % 16], S["counter"]))
+        G = P["graphs"].get((t, prime, ahead)) or self._pipe_capture(t, prime, ahead)
+        copy_tensors(pairs)
+        self._lr_step()
+        self.optimizer.refresh_hyper()
+        G["graph"].replay()
+        if prime:
+            m.step_counter[m.local_step % 16].copy_(S["counter"])
+        m.local_step += 1
+        m.last_counter = S["counter"]
+        self.optimizer.bump_versions()
+        if self.ema is not None:
+            self.ema.update()
+        P["primed"], P["expect"] = ahead, (next_data["rays_o"] if ahead else None)
+        P["turn"] = t ^ 1
         return G["loss"].detach()
 
     def _march_ahead(self, next_data):
@@ -969,9 +1147,10 @@ class Trainer:
         kw = self._render_kwargs()
         ro, rd = next_data["rays_o"], next_data["rays_d"]
         if not (ro.is_contiguous() and rd.is_contiguous() and ro.dtype == torch.float32 and rd.dtype == torch.float32):
-            return                                   # the key below must be the pointers render() will see
+            return                                   # the buffers marched from must be the ones render() will see
         self._ahead = m.march_ahead(ro, rd, dt_gamma=kw.get("dt_gamma", 0), perturb=True,
-                                    max_steps=kw.get("max_steps", 1024), stream=self._side_stream)
+                                    max_steps=kw.get("max_steps", 1024), stream=self._side_stream,
+                                    shade=self.stage == "instance" and self.shade_ahead, T_thresh=kw.get("T_thresh", 1e-4))
 
     def train_one_step(self, data, next_data=None):
         """One optimisation step on ``data``.  ``next_data`` (optional): the batch the NEXT call will get - its ray/box
@@ -984,6 +1163,8 @@ class Trainer:
                 a = self.GRAPH_ALIGN
                 self.model.mean_count = (self.model.mean_count + a - 1) // a * a
         self.global_step += 1
+        if self._pipe_applies(data):
+            return self._pipe_step(data, next_data)
         if self.use_graph and self.model.cuda_ray and self.model.mean_count > 0:
             if self._graph is None or self._graph["key"] != self._graph_key(data):
                 self._capture(data)

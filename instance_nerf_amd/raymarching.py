@@ -114,16 +114,26 @@ def packbits(grid, thresh, bitfield=None):
     return bitfield
 
 
-def march_train_buffers(n_rays, n_samples, device):
+def march_train_buffers(n_rays, n_samples, device, shade=False):
     """Persistent buffers for ``march_rays_train(..., out=)``: a caller that marches on a side stream every step
     (``NeRFRenderer.march_ahead``) must not allocate there - the caching allocator keeps one pool per stream, and blocks
-    handed across streams cost ~0.2 ms of host time per step in deferred frees."""
+    handed across streams cost ~0.2 ms of host time per step in deferred frees.  ``shade``: also the outputs of the
+    frozen field and of the compositing forward (``march_ahead(shade=True)``)."""
     lib = _lib.load()
-    return {"n_rays": n_rays, "n_samples": n_samples,
-            "nears": torch.empty(n_rays, dtype=F32, device=device), "fars": torch.empty(n_rays, dtype=F32, device=device),
-            "noises": torch.empty(n_rays, dtype=F32, device=device), "rays": torch.empty(n_rays, 3, dtype=I32, device=device),
-            "ws": torch.empty(lib.inr_march_workspace_bytes(n_rays, SAMPLE_CAP_TRAIN) // 8 + 1, dtype=torch.int64, device=device),
-            "buf": torch.empty(n_samples * 8, dtype=F32, device=device)}
+    b = {"n_rays": n_rays, "n_samples": n_samples,
+         "nears": torch.empty(n_rays, dtype=F32, device=device), "fars": torch.empty(n_rays, dtype=F32, device=device),
+         "noises": torch.empty(n_rays, dtype=F32, device=device), "rays": torch.empty(n_rays, 3, dtype=I32, device=device),
+         "ws": torch.empty(lib.inr_march_workspace_bytes(n_rays, SAMPLE_CAP_TRAIN) // 8 + 1, dtype=torch.int64, device=device),
+         "buf": torch.empty(n_samples * 8, dtype=F32, device=device)}
+    if shade:
+        b.update({"sigmas": torch.empty(n_samples, dtype=F32, device=device),
+                  "rgbs": torch.empty(n_samples, 3, dtype=F32, device=device),
+                  "weights_sum": torch.empty(n_rays, dtype=F32, device=device),
+                  "depth": torch.empty(n_rays, dtype=F32, device=device),
+                  "image": torch.empty(n_rays, 3, dtype=F32, device=device),
+                  "weights": torch.empty(n_samples, dtype=F32, device=device),
+                  "sample_ray": torch.empty(n_samples, dtype=I32, device=device)})
+    return b
 
 
 def march_rays_train(rays_o, rays_d, bound, density_bitfield, C, H, nears, fars, step_counter=None,
@@ -381,6 +391,22 @@ class _CompositeRaysTrain(torch.autograd.Function):
                 ptr(ge, allow_none=True), ptr(total_dev, I32, "total_dev", allow_none=True), stream_ptr()),
                 "composite_rays_train_backward")
         return gs, gc, ge, None, None, None, None, None
+
+
+@torch.no_grad()
+def composite_rays_train_into(sigmas, rgbs, deltas, rays, T_thresh, out):
+    """The forward of ``composite_rays_train(return_weights=True)`` into the buffers of ``march_train_buffers(shade=True)``
+    - the same launch with the same arguments, nothing allocated, no autograd node (a frozen field: every output is
+    non-differentiable anyway).  -> weights_sum [N], depth [N], image [N,3], weights [M], sample_ray int32 [M]."""
+    lib = _lib.load()
+    N, M = rays.shape[0], sigmas.shape[0]
+    ws, depth, image = out["weights_sum"], out["depth"], out["image"]
+    wbuf, sample_ray = out["weights"][:M], out["sample_ray"][:M]
+    check(lib.inr_composite_rays_train_forward(
+        ptr(sigmas, F32, "sigmas"), ptr(rgbs, F32, "rgbs"), ptr(deltas, F32, "deltas"), ptr(rays, I32, "rays"),
+        N, M, float(T_thresh), None, 0, ptr(ws), ptr(depth), ptr(image), None, ptr(wbuf), ptr(sample_ray), stream_ptr()),
+        "composite_rays_train_forward")
+    return ws, depth, image, wbuf, sample_ray
 
 
 def composite_rays_train(sigmas, rgbs, deltas, rays, T_thresh=1e-4, extra=None, return_weights=False, total_dev=None):

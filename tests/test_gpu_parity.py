@@ -2523,6 +2523,101 @@ def test_captured_training_step_equals_eager(stage):
         assert torch.linalg.norm(p - q) < 1e-2 * torch.linalg.norm(p)
 
 
+@pytest.mark.parametrize("stage", ["instance", "instance+shade", "nerf"])
+def test_pipelined_captured_step_equals_eager(stage):
+    """Trainer(use_graph=True, look_ahead=True): ONE hipGraph per step holds the step and, forked off before the
+    table-gradient scatter, the parameter-independent head of the NEXT batch on a second stream - ray/box test and
+    march, and in the instance stage the frozen NeRF's forward and the weight compositing.  Against the eager trainer
+    on the same batches, with occupancy updates every 4 steps (the first step after one computes its own head, the last
+    one before it does not look ahead): the same sample total at every step - the same rays, the same jitter - losses
+    that agree as two eager runs do, parameters and their EMA as close as the scatter's summation order allows."""
+    from instance_nerf_amd.nerf import NeRFNetwork
+    from instance_nerf_amd.nerf.provider import SyntheticRoomDataset
+    from instance_nerf_amd.nerf.utils import Trainer
+    dev = torch.device(DEV)
+    runs = {}
+    stage, shade = stage.split("+")[0], stage.endswith("+shade")
+    for piped in (False, True):
+        torch.manual_seed(0)
+        net = NeRFNetwork(cuda_ray=True, bound=1, min_near=0.05, num_instances=16 if stage == "instance" else 0).to(dev)
+        ds = SyntheticRoomDataset(dev, num_rays=1024, num_instances=16, seed=5)
+        net.density_bitfield.copy_(_t(ds.room.density_bitfield(128, 1.0)))
+        analytic = net.density_bitfield.clone()
+        real = net.update_extra_state
+
+        def update(*a, real=real, net=net, analytic=analytic, **kw):
+            real(*a, **kw)                           # the update runs (mean_count!) but the analytic grid is kept,
+            net.density_bitfield.copy_(analytic)     # and both runs size their buffers like the captured one does
+            if net.mean_count > 0:
+                net.mean_count = (net.mean_count + 16383) // 16384 * 16384
+        net.update_extra_state = update
+        tr = Trainer("p", None, net, stage=stage, device=dev, iters=200, update_extra_interval=4, use_graph=piped,
+                     look_ahead=piped, shade_ahead=shade, ema_decay=0.95, workspace=None, mute=True)
+        tr.global_step = 1
+        batches = [ds.batch() for _ in range(19)]
+        torch.manual_seed(11)
+        losses, totals = [], []
+        for i in range(18):
+            losses.append(float(tr.train_one_step(batches[i], batches[i + 1])) if piped
+                          else float(tr.train_one_step(batches[i])))
+            totals.append(int(net.last_counter[0]))
+        kinds = sorted(k[1:] for k in tr._pipe["graphs"]) if piped else None
+        runs[piped] = (losses, totals, [p.detach().clone() for g in tr.optimizer.param_groups for p in g["params"]],
+                       [s.clone() for s in tr.ema.shadow], tr.optimizer.step_count, net.local_step, kinds)
+    a, b = runs[False], runs[True]
+    # every kind of step was captured and replayed: own head + look-ahead, prefetched head + look-ahead, prefetched head only
+    assert (True, True) in b[6] and (False, True) in b[6] and (False, False) in b[6], b[6]
+    assert a[1] == b[1], (a[1], b[1])
+    assert a[4] == b[4] == 18 and a[5] == b[5]
+    assert np.allclose(a[0], b[0], rtol=2e-3), (a[0], b[0])
+    for p, q in zip(a[2], b[2]):
+        assert torch.linalg.norm(p - q) < 1e-2 * torch.linalg.norm(p)
+    for p, q in zip(a[3], b[3]):
+        assert torch.linalg.norm(p - q) < 1e-2 * torch.linalg.norm(p)
+
+
+def test_shade_ahead_is_bit_identical_to_the_inline_head(room):
+    """march_ahead(shade=True): ray/box test, march, frozen NeRF forward and compositing forward queued on a side stream
+    into persistent buffers give the render the same bits as computing them in the step (eager, no graph): loss and every
+    gradient of the instance stage identical."""
+    from instance_nerf_amd.nerf import NeRFNetwork
+    from instance_nerf_amd.nerf.provider import SyntheticRoomDataset
+    dev = torch.device(DEV)
+    torch.manual_seed(1)
+    net = NeRFNetwork(cuda_ray=True, bound=1, min_near=0.05, num_instances=16).to(dev).train()
+    net.freeze_nerf()
+    ds = SyntheticRoomDataset(dev, num_rays=1024, num_instances=16, seed=5)
+    net.density_bitfield.copy_(_t(ds.room.density_bitfield(128, 1.0)))
+    b = ds.batch()
+    net.mean_count = 65536
+    assert net.shade_ahead_applies()
+    out = {}
+    for ahead in (False, True):
+        for q in net.parameters():
+            q.grad = None
+        torch.manual_seed(4)
+        kw = dict(staged=False, bg_color=1, perturb=True, force_all_rays=False, ce_labels=b["masks"])
+        if ahead:
+            side = torch.cuda.Stream()
+            marched = net.march_ahead(b["rays_o"], b["rays_d"], perturb=True, stream=side, shade=True)
+            assert marched is not None and marched["shaded"] is not None
+            kw["marched"] = marched
+        r = net.render(b["rays_o"], b["rays_d"], **kw)
+        r["instance_ce"].backward()
+        torch.cuda.synchronize()
+        out[ahead] = (float(r["instance_ce"]), r["instance"].detach().clone(), r["image"].detach().clone(),
+                      int(net.last_counter[0]),
+                      {k: v.grad.clone() for k, v in net.named_parameters() if v.grad is not None})
+    x, y = out[False], out[True]
+    assert x[3] == y[3] and x[0] == y[0]
+    assert torch.equal(x[1], y[1]) and torch.equal(x[2], y[2])
+    for k in x[4]:
+        if "embeddings" in k:        # the scatter's atomics sum in arrival order
+            assert torch.linalg.norm(x[4][k] - y[4][k]) <= 1e-5 * torch.linalg.norm(x[4][k]), k
+        else:
+            assert torch.equal(x[4][k], y[4][k]), k
+
+
 def test_render_through_the_registered_custom_ops(params_k16, room, room_bitfield, level_table):
     """torch.ops.inr.*: a training-mode render assembled from the registered ops - ray/box test, march, hash-grid
     encode + tiny MLPs (torch), compositing - equals the module path (NeRFNetwork.render) on the same rays: sample

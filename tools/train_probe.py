@@ -14,24 +14,25 @@ ds = SyntheticRoomDataset(dev, num_rays=4096, num_instances=64, sort_pixels=os.e
 net.fused_instance_head = os.environ.get("FUSED_HEAD", "1") == "1"
 net.density_bitfield.copy_(torch.from_numpy(ds.room.density_bitfield(128, 1.0)).to(dev))
 tr = Trainer("probe", None, net, stage="instance", device=dev, iters=1000, update_extra_interval=10 ** 9,
-             use_graph=os.environ.get("USE_GRAPH", "0") == "1")
+             use_graph=os.environ.get("USE_GRAPH", "0") == "1" or os.environ.get("PIPE", "0") == "1",
+             look_ahead=os.environ.get("PIPE", "0") == "1", shade_ahead=os.environ.get("SHADE", "0") == "1", ema_decay=0.95 if os.environ.get("EMA", "1") == "1" else None)
 tr.global_step = 1          # keep the analytic occupancy grid (no update from the untrained NeRF)
 batches = [ds.batch() for _ in range(8)]
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 losses = []
 peak = 0
 for i in range(8):
-    losses.append(float(tr.train_one_step(batches[i % 8], batches[(i + 1) % 8] if os.environ.get('LOOK_AHEAD', '0') == '1' else None)))
+    losses.append(float(tr.train_one_step(batches[i % 8], batches[(i + 1) % 8] if (os.environ.get('LOOK_AHEAD', '0') == '1' or os.environ.get('PIPE', '0') == '1') else None)))
     peak = max(peak, int(net.last_counter[0]))
 # steady state as after an occupancy update: sample buffers sized from mean_count, no host read-back inside a step
 net.mean_count = (int(peak * 1.02) + 127) // 128 * 128
 for i in range(8):
-    tr.train_one_step(batches[i % 8], batches[(i + 1) % 8] if os.environ.get('LOOK_AHEAD', '0') == '1' else None)
+    tr.train_one_step(batches[i % 8], batches[(i + 1) % 8] if (os.environ.get('LOOK_AHEAD', '0') == '1' or os.environ.get('PIPE', '0') == '1') else None)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 n_dev = torch.zeros((), dtype=torch.int64, device=dev)
 for i in range(steps):
-    l = tr.train_one_step(batches[i % 8], batches[(i + 1) % 8] if os.environ.get('LOOK_AHEAD', '0') == '1' else None)
+    l = tr.train_one_step(batches[i % 8], batches[(i + 1) % 8] if (os.environ.get('LOOK_AHEAD', '0') == '1' or os.environ.get('PIPE', '0') == '1') else None)
     n_dev += net.last_counter[0]       # on the device: no host sync inside the loop
 t_host = (time.perf_counter() - t0) / steps      # host time to enqueue a step (== the step time when host-bound)
 torch.cuda.synchronize()
