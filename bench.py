@@ -140,113 +140,6 @@ def cpu_baseline(room, net, frame0=None, chunk=16384, budget_s=12.0, max_chunks=
     return base, parity
 
 
-class SclkSampler:
-    """Shader clock of THIS GPU while the timed region runs (sysfs pp_dpm_sclk of the card with the device's PCI
-    address, one 30-byte read every 10 ms on a side thread), temperatures and the other clocks once after it.  The boxes
-    are GPUs of shared 8-GPU nodes; under this load the clock sits anywhere between ~1.95 and ~2.25 GHz.  Recorded
-    because about one call in three reads 10 % slower on the same build (profiles/r03_NOTES.txt 21) - these numbers
-    turned out NOT to tell the two kinds of call apart, which is worth knowing too."""
-
-    def __init__(self, dev):
-        import glob
-        self.path, self.seen, self._stop, self._thread = None, [], None, None
-        try:
-            pr = torch.cuda.get_device_properties(dev)
-            want = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}."
-            for f in glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"):
-                if want in os.path.realpath(os.path.dirname(f)):
-                    self.path = f
-        except Exception:                                  # noqa: BLE001 - a diagnostic, never a reason to fail
-            self.path = None
-
-    def _read(self):
-        for line in open(self.path).read().splitlines():
-            if line.rstrip().endswith("*"):
-                return int(line.split(":")[1].lower().split("mhz")[0])
-        return None
-
-    def _hwmon(self):
-        """socket power (W) and the temperatures the card's hwmon node reports (deg C), read once after the region"""
-        import glob
-        out = {}
-        base = os.path.dirname(self.path)
-        for f in glob.glob(os.path.join(base, "hwmon", "hwmon*", "power1_average")):
-            out["power_w"] = round(int(open(f).read()) / 1e6, 1)
-        for f in sorted(glob.glob(os.path.join(base, "hwmon", "hwmon*", "temp*_input"))):
-            lab = f.replace("_input", "_label")
-            name = open(lab).read().strip() if os.path.exists(lab) else os.path.basename(f)[:5]
-            out["temp_c_" + name] = round(int(open(f).read()) / 1e3, 1)
-        for clk in ("mclk", "fclk", "socclk"):
-            try:
-                for line in open(os.path.join(base, "pp_dpm_" + clk)).read().splitlines():
-                    if line.rstrip().endswith("*"):
-                        out[clk + "_mhz"] = int(line.split(":")[1].lower().split("mhz")[0])
-            except Exception:                              # noqa: BLE001
-                pass
-        return out
-
-    def start(self):
-        if self.path is None:
-            return
-        import threading
-        self._stop = threading.Event()
-
-        def loop():
-            while not self._stop.is_set():
-                try:
-                    v = self._read()
-                    if v:
-                        self.seen.append(v)
-                except Exception:                          # noqa: BLE001
-                    pass
-                self._stop.wait(0.01)
-        self._thread = threading.Thread(target=loop, daemon=True)
-        self._thread.start()
-
-    def stop(self):
-        if self._thread is None:
-            return None
-        self._stop.set()
-        self._thread.join()
-        v = sorted(self.seen)
-        if not v:
-            return None
-        try:
-            extra = self._hwmon()
-        except Exception:                                  # noqa: BLE001
-            extra = {}
-        return {"sclk_mhz_median": v[len(v) // 2], "sclk_mhz_min": v[0], "sclk_mhz_max": v[-1], "samples": len(v), **extra,
-                "source": "pp_dpm_sclk / hwmon of this GPU, sclk every 10 ms of the timed region; diagnostics for the "
-                          "run-to-run spread of profiles/r03_NOTES.txt 21 (which they do not explain)"}
-
-
-def xcd_map_probe():
-    """On which XCD did workgroup b of a 256 x 512-thread launch on THIS stream land (HW_REG_XCC_ID)?  The field kernels'
-    schedules take b % 8 (for locality only).  A diagnostic from tools/_probe/libxcdmap.so (tools/micro/xcd_map_probe.hip,
-    built by __graft_entry__.build()); None when it is not there."""
-    import ctypes
-    path = os.path.join(ROOT, "tools", "_probe", "libxcdmap.so")
-    if not os.path.exists(path):
-        return None
-    try:
-        lib = ctypes.CDLL(path)
-        lib.xcd_map.restype = ctypes.c_int
-        lib.xcd_map.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int32),
-                                ctypes.c_void_p]
-        blocks = torch.cuda.get_device_properties(0).multi_processor_count
-        out = (ctypes.c_int32 * blocks)()
-        st = torch.cuda.current_stream().cuda_stream
-        if lib.xcd_map(blocks, 512, 44 * 1024, 2000, out, ctypes.c_void_p(st)) != 0:
-            return None
-        ids = [v & 15 for v in out]
-        rot = [(ids[b] - b) % 8 for b in range(blocks)]
-        hist = [ids.count(x) for x in range(8)]
-        return {"xcd_of_block_is_block_mod_8_up_to_rotation": len(set(rot)) == 1, "rotation": rot[0] if len(set(rot)) == 1 else None,
-                "workgroups_per_xcd": hist, "first_16_blocks": ids[:16]}
-    except Exception as e:                                 # noqa: BLE001 - a diagnostic
-        return {"error": f"{type(e).__name__}: {e}"[:120]}
-
-
 def train_probe(dev, rank=0, world=1, red_dev=None, steps=20, warmup=5, stage="instance", mode="eager"):
     """Secondary measurement (not the headline value): instance-field training step, BASELINE configs[2]
     (K=64 logits, 4096 rays/batch per GPU, NeRF frozen): march -> frozen NeRF (fused) -> instance grid encode ->
@@ -766,8 +659,11 @@ def main():
                     help="(default since late round 3; kept for old command lines) measure the same frames through "
                          "FramePipeline (two streams) AFTER the headline's timed region and report them as \"pipelined\"")
     ap.add_argument("--no-pipeline-probe", action="store_true", help="skip the \"pipelined\" object")
-    ap.add_argument("--pipeline", type=int, default=0,
-                    help="1: headline loop through FramePipeline (views alternate on two streams)")
+    ap.add_argument("--diagnostics", action="store_true",
+                    help="record the GPU's clocks during the timed region and the workgroup-to-XCD map (\"clocks\")")
+    ap.add_argument("--pipeline", type=int, default=1,
+                    help="1 (default since round 4): the headline loop is Trainer.render_sequence as Trainer.test runs it "
+                         "- views through FramePipeline, two alternating streams; 0: one view at a time on one stream")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -828,37 +724,35 @@ def main():
     net.forward = timed(net.forward)
     net.forward_table = timed(net.forward_table)      # the entry the fused frame path uses
 
-    pipe = None
-    if args.pipeline:
-        from instance_nerf_amd.nerf.renderer import FramePipeline
-        pipe = FramePipeline(net, dev)
+    # The headline loop is the PRODUCT's view loop: Trainer.render_sequence, what Trainer.test / evaluate_one_epoch
+    # iterate over (round-3 verdict: the fastest multi-view path must be the product path and the headline).  The
+    # loader hands over the H*W rays of a view in row-major pixel order, as upstream's loaders do; the trainer renders
+    # them 4x4-patch by patch and returns every per-ray output in the caller's order.  With --pipeline 1 the views
+    # alternate on the two streams of a FramePipeline (march of view i+1 and compositing of view i-1 under the field
+    # kernel of view i); --pipeline 0 is upstream's one-view-at-a-time loop, reported beside it as "one_stream".
+    from instance_nerf_amd.nerf.utils import Trainer
+    viewer = Trainer("bench_views", None, net, stage="nerf", device=dev, workspace=None, use_checkpoint="scratch", mute=True)
+    viewer.opt = argparse.Namespace(dt_gamma=0, max_steps=1024, T_thresh=1e-4)
+    net.eval()
 
-    def step_pipelined(i):
-        view = (i + rank) % poses_d.shape[0]       # every rank cycles through all views (their sample counts differ by +-25 %)
-        st = pipe.next_stream()
-        with torch.cuda.stream(st):
-            r = get_rays(poses_d[view:view + 1], intr, H, W, patch=4)
-        with torch.no_grad():
-            out = pipe.render(r["rays_o"], r["rays_d"], stream=st, bg_color=1, perturb=False, dt_gamma=0,
-                              max_steps=1024, T_thresh=1e-4)
-        with torch.cuda.stream(st):
-            frame = torch.empty(H * W, 3, device=dev)
-            frame[r["inds"][0]] = out["image"][0]
-        out["frame"] = frame.view(H, W, 3)
-        return out
+    def views(first, n):
+        for i in range(first, first + n):
+            view = (i + rank) % poses_d.shape[0]   # every rank cycles through all views (their sample counts differ by +-25 %)
+            r = get_rays(poses_d[view:view + 1], intr, H, W)
+            yield {"rays_o": r["rays_o"], "rays_d": r["rays_d"], "H": H, "W": W}
 
-    def step(i):
-        if args.pipeline:
-            return step_pipelined(i)
-        view = (i + rank) % poses_d.shape[0]       # every rank cycles through all views (their sample counts differ by +-25 %)
-        r = get_rays(poses_d[view:view + 1], intr, H, W, patch=4)           # same rays, 4x4-patch order
-        with torch.no_grad():
-            out = net.render(r["rays_o"], r["rays_d"], staged=False, bg_color=1, perturb=False, dt_gamma=0,
-                             max_steps=1024, T_thresh=1e-4)
-            frame = torch.empty(H * W, 3, device=dev)
-            frame[r["inds"][0]] = out["image"][0]                           # back to row-major pixels
-        out["frame"] = frame.view(H, W, 3)
-        return out
+    def render_views(first, n, pipeline):
+        """-> (sample counters of the n views, the last view's frame [H,W,3])"""
+        cs, frame = [], None
+        for _, out in viewer.render_sequence(views(first, n), pipeline=pipeline):
+            # samples the field actually evaluated (the early-terminating mode may evaluate fewer than were marched)
+            cs.append(out["num_evaluated"] if "num_evaluated" in out else out["num_samples"])
+            frame = out["image"]
+        return cs, frame.view(H, W, 3)
+
+    def step(i):                                   # one view, one stream (CPU baseline / parity leg)
+        cs, frame = render_views(i, 1, False)
+        return {"frame": frame, "num_samples": cs[0]}
 
     def barrier():
         if world > 1:
@@ -866,21 +760,21 @@ def main():
         torch.cuda.synchronize()
 
     import gc
-    for i in range(args.warmup):
-        step(i)
+    render_views(0, args.warmup, bool(args.pipeline))
     gc.collect()
     gc.disable()               # no collector pause inside the timed region (a frame is 6 ms, a gen-2 pass ~10 ms)
-    sclk = SclkSampler(dev) if rank == 0 else None
+    sclk = None
+    if args.diagnostics and rank == 0:         # opt-in: a sampler thread beside the timed region (tools/bench_diagnostics.py)
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from bench_diagnostics import SclkSampler, xcd_map_probe
+        sclk = SclkSampler(dev)
     barrier()
     ev_pairs.clear()
     counters = []
     if sclk is not None:
         sclk.start()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        out = step(args.warmup + i)
-        # samples the field actually evaluated (the early-terminating mode may evaluate fewer than were marched)
-        counters.append(out["num_evaluated"] if "num_evaluated" in out else out["num_samples"])
+    counters, _ = render_views(args.warmup, args.steps, bool(args.pipeline))
     barrier()
     elapsed = time.perf_counter() - t0
     clocks = sclk.stop() if sclk is not None else None
@@ -927,35 +821,36 @@ def main():
                          "algorithmic_bytes_per_sample": BYTES_PER_SAMPLE},
             "clocks": clocks,
         }
-        if not args.no_pipeline_probe and not args.pipeline:
-            # the same frames with the march of view i+1 under the field kernel of view i (FramePipeline): reported
-            # beside the headline, which stays the one-stream loop the roofline figure is measured in
+        # whole-frame fraction of the roofline: every launch of the loop, not only the field kernel
+        line["end_to_end"] = {"achieved": round(samples_all / world / elapsed_all * BYTES_PER_SAMPLE / 1e9, 1),
+                              "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": round(samples_all / world / elapsed_all * BYTES_PER_SAMPLE / 1e9 / HBM_PEAK_GBS, 4),
+                              "what": "samples x 1024 B over the wall clock of the timed loop, per GPU"}
+        line["loop"] = ("Trainer.render_sequence, FramePipeline (two alternating streams; field kernels serialised)"
+                        if args.pipeline else "Trainer.render_sequence, one view at a time on one stream")
+        if not args.no_pipeline_probe:
+            # the same frames through the OTHER loop, after the headline's timed region
             try:
-                from instance_nerf_amd.nerf.renderer import FramePipeline
-                pipe = FramePipeline(net, dev)
-                n_pipe = min(args.steps, 60)
-                for i in range(5):
-                    step_pipelined(i)
+                other = not args.pipeline
+                n_o = min(args.steps, 60)
+                render_views(0, 4, other)
                 torch.cuda.synchronize()
                 ev_pairs.clear()
-                cs = []
                 t0 = time.perf_counter()
-                for i in range(n_pipe):
-                    o = step_pipelined(5 + i)
-                    cs.append(o["num_evaluated"] if "num_evaluated" in o else o["num_samples"])
+                cs, _ = render_views(4, n_o, other)
                 torch.cuda.synchronize()
                 el = time.perf_counter() - t0
-                pipe.close()
                 ns = int(sum(int(c[0]) for c in cs))
                 kms = sum(a.elapsed_time(b) for a, b, _ in ev_pairs) / max(len(ev_pairs), 1)
-                line["pipelined"] = {"value": round(ns / el / 1e6, 3), "unit": "Msamples/s", "steps": n_pipe,
-                                     "ms_per_step": round(el / n_pipe * 1e3, 3), "field_kernel_ms": round(kms, 4),
-                                     "field_frac_of_hbm_peak": round(ns / n_pipe * BYTES_PER_SAMPLE / (kms / 1e3) / 1e9
-                                                                     / HBM_PEAK_GBS, 4),
-                                     "what": "FramePipeline: views alternate on two streams, field kernels serialised; "
-                                             "march of view i+1 and compositing of view i-1 run under field kernel i"}
+                line["pipelined" if other else "one_stream"] = {
+                    "value": round(ns / el / 1e6, 3), "unit": "Msamples/s", "steps": n_o,
+                    "ms_per_step": round(el / n_o * 1e3, 3), "field_kernel_ms": round(kms, 4),
+                    "field_frac_of_hbm_peak": round(ns / n_o * BYTES_PER_SAMPLE / (kms / 1e3) / 1e9 / HBM_PEAK_GBS, 4),
+                    "what": ("Trainer.render_sequence(pipeline=True): views alternate on two streams, field kernels "
+                             "serialised; march of view i+1 and compositing of view i-1 run under field kernel i") if other
+                    else "Trainer.render_sequence(pipeline=False): upstream's loop, one view at a time on one stream"}
             except Exception as e:                            # noqa: BLE001
-                line["pipelined"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+                line["pipelined" if not args.pipeline else "one_stream"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"], line["parity"] = cpu_baseline(room, net, step(0)["frame"],
                                                                 render_view0=lambda: step(0)["frame"])

@@ -40,10 +40,12 @@ def load_matched_masks(seg_dir, names=None):
 def labels_for_rays(mask, inds, num_instances):
     """mask int32 [H, W], inds int64 [N] flat pixel indices -> int64 [N] CE targets (-1 stays ignore;
     ids >= num_instances are ignored too, they have no logit)."""
-    m = torch.as_tensor(mask).reshape(-1).long()
-    lab = m[inds.cpu()] if torch.is_tensor(inds) else m[torch.as_tensor(inds)]
-    lab = torch.where(lab >= num_instances, torch.full_like(lab, -1), lab)
-    return lab
+    m = torch.as_tensor(mask).reshape(-1)
+    inds = torch.as_tensor(inds)
+    # the gather runs where the mask lives (a loader keeps its masks on the GPU: no host round trip per batch -
+    # round-3 verdict: `inds.cpu()` here put a synchronisation into every training step)
+    lab = m[inds.to(m.device)].long()
+    return torch.where(lab >= num_instances, torch.full_like(lab, -1), lab)
 
 
 # ---------------------------------------------------------------------------------------- png

@@ -183,7 +183,7 @@ class NeRFDataset:
         out["images"] = img[inds.to(img.device)].to(self.device)[None] if self.training else \
             self.images[index].to(self.device)[None]
         if self.masks is not None:
-            lab = labels_for_rays(self.masks[index].cpu(), inds.cpu(), self.num_instances or (1 << 30))
+            lab = labels_for_rays(self.masks[index], inds, self.num_instances or (1 << 30))    # on the masks' device
             out["masks"] = (lab if self.training else lab.view(self.H, self.W)).to(self.device)[None]
         return out
 

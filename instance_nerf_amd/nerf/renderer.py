@@ -264,7 +264,11 @@ class NeRFRenderer(nn.Module):
             if field_gate is not None:
                 field_gate.release()
             if with_instance:
+                if field_gate is not None:       # a gather kernel too: never beside another view's field kernel
+                    field_gate.acquire()
                 results["instance"] = self.instance_render(xyzs, rays, wbuf, normalised=True).view(*prefix, -1)
+                if field_gate is not None:
+                    field_gate.release()
             results["num_samples"] = counter
             results["num_evaluated"] = evaluated
             skipped_frac = (evaluated, int(xyzs.shape[0]), True)        # raw counter, marched total (host), "evaluated"
@@ -298,7 +302,11 @@ class NeRFRenderer(nn.Module):
                 # weights first, then the instance field accumulates w * logits on chip (no [M, K] round trip)
                 weights_sum, depth, image, wbuf = raymarching.composite_rays_patch(sigmas, rgbs, deltas, rays, T_thresh,
                                                                                   return_weights=True, skippable=skippable)
+                if field_gate is not None:       # a gather kernel too: never beside another view's field kernel
+                    field_gate.acquire()
                 results["instance"] = self.instance_render(xyzs, rays, wbuf, normalised=table).view(*prefix, -1)
+                if field_gate is not None:
+                    field_gate.release()
             else:
                 extra = self._instance_for_compositing(xyzs) if with_instance else None
                 out = raymarching.composite_rays_patch(sigmas, rgbs, deltas, rays, T_thresh, extra=extra,
@@ -728,6 +736,10 @@ class FramePipeline:
         self.streams = [torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)]
         self._turn = 0
         self._field_done = None
+        self.open()
+
+    def open(self):
+        """(Re)opens a closed pipeline: overlap placement on.  The two streams live as long as the object."""
         # INR_PIPELINE_PLACEMENT=0: A/B switch (with the hybrid tile schedule the placement is worth 1.3 %, 6.34-6.39
         # against 6.26-6.30 Gsamples/s; with the static deal it was the difference between winning and losing)
         raymarching.set_overlap_placement(os.environ.get("INR_PIPELINE_PLACEMENT", "1") != "0")

@@ -944,6 +944,9 @@ class Trainer:
     def eval_step(self, data):
         """-> (prediction, depth, truth, loss); images may come as [B,N,C] or [B,H,W,C] (upstream), C = 3 or 4."""
         outputs = self._render_view(data, staged=True, bg_color=self.bg_color, perturb=False, **self._render_kwargs())
+        return self._eval_outputs(data, outputs)
+
+    def _eval_outputs(self, data, outputs):
         if self.stage == "nerf":
             images = data["images"]
             flat = images.reshape(images.shape[0], -1, images.shape[-1])
@@ -962,9 +965,70 @@ class Trainer:
     def test_step(self, data, bg_color=None, perturb=False):
         outputs = self._render_view(data, staged=True, bg_color=self.bg_color if bg_color is None else bg_color,
                                     perturb=perturb, **self._render_kwargs())
+        return self._test_outputs(data, outputs)
+
+    def _test_outputs(self, data, outputs):
         inst = outputs.get("instance")
         return (self._as_image(outputs["image"], data), self._as_image(outputs["depth"], data),
                 None if inst is None else self._as_image(inst, data))
+
+    pipeline_views = True      # evaluate / test render view sequences through FramePipeline (two alternating streams)
+
+    @torch.no_grad()
+    def render_sequence(self, loader, pipeline=None, **kwargs):
+        """Yields ``(data, outputs)`` for every view of ``loader`` - what ``evaluate_one_epoch`` and ``test`` (and
+        bench.py's headline loop) iterate over.  With ``cuda_ray`` on a GPU the views alternate on the two streams of a
+        ``FramePipeline``: the ray/box test and march of view i+1 and the compositing of view i-1 run under the field
+        kernel of view i (the field kernels themselves stay one after the other).  A view's outputs are yielded once the
+        NEXT view has been queued and its own stream has finished; frames are bit-identical to ``eval_step`` /
+        ``test_step`` on each view by itself (rays are independent; tests/test_gpu_parity.py).  Upstream renders one view
+        at a time on the default stream; ``pipeline=False`` (or ``Trainer.pipeline_views = False``) does that."""
+        kw = dict(staged=True, bg_color=self.bg_color, perturb=False)
+        kw.update(self._render_kwargs())
+        kw.update(kwargs)
+        use = self.pipeline_views if pipeline is None else bool(pipeline)
+        use = use and getattr(self.model, "cuda_ray", False) and self.device.type == "cuda"
+        if not use:
+            for data in loader:
+                yield data, self._render_view(data, **kw)
+            return
+        from .renderer import FramePipeline
+        # ONE pipeline (two streams) per trainer, reused by every sequence: HIP maps streams onto a handful of hardware
+        # queues, and a fresh pair per call landed on ONE queue - no overlap at all, 5.9 ms per frame instead of 5.0
+        # (kernel trace, profiles/r04_NOTES.txt 3)
+        pipe = self.__dict__.get("_frame_pipe")
+        if pipe is None or pipe.net is not self.model:
+            pipe = self.__dict__["_frame_pipe"] = FramePipeline(self.model, self.device)
+        pipe.open()
+        try:
+            pending = None
+            for data in loader:
+                cur = torch.cuda.current_stream()
+                st = pipe.next_stream()
+                st.wait_stream(cur)
+                for k in ("rays_o", "rays_d"):
+                    if torch.is_tensor(data.get(k)) and data[k].is_cuda:
+                        data[k].record_stream(st)
+                with torch.cuda.stream(st):
+                    out = self._render_view(data, field_gate=pipe, **kw)
+                    done = torch.cuda.Event()
+                    done.record(st)
+                if pending is not None:
+                    yield self._finish_view(*pending)
+                pending = (data, out, done)
+            if pending is not None:
+                yield self._finish_view(*pending)
+        finally:
+            pipe.close()
+
+    @staticmethod
+    def _finish_view(data, out, done):
+        done.synchronize()
+        cur = torch.cuda.current_stream()
+        for v in out.values():                 # allocated on the pipeline's stream, consumed on the caller's
+            if torch.is_tensor(v) and v.is_cuda:
+                v.record_stream(cur)
+        return data, out
 
     # -- loops -------------------------------------------------------------------------------
     # -- captured step ----------------------------------------------------------------------
@@ -1265,8 +1329,8 @@ class Trainer:
             self.ema.store()
             self.ema.copy_to()
         total, n = 0.0, 0
-        for data in loader:
-            pred, _, truth, loss = self.eval_step(data)
+        for data, outputs in self.render_sequence(loader):
+            pred, _, truth, loss = self._eval_outputs(data, outputs)
             for m in meters:
                 m.update(pred, truth)
             total += float(loss)
@@ -1300,8 +1364,8 @@ class Trainer:
         os.makedirs(save_path, exist_ok=True)
         self.model.eval()
         written = []
-        for i, data in enumerate(loader):
-            rgb, depth, inst = self.test_step(data)
+        for i, (data, outputs) in enumerate(self.render_sequence(loader)):
+            rgb, depth, inst = self._test_outputs(data, outputs)
             if rgb.dim() != 4:
                 raise ValueError("test() needs batches that carry the image size ('H', 'W')")
             img = (rgb[0].clamp(0, 1) * 255).byte().cpu().numpy()

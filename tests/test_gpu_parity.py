@@ -1631,6 +1631,44 @@ def test_frame_pipeline_is_bit_identical(params_k16, room, room_bitfield, mode, 
         pipe.render(rays[0]["rays_o"], rays[0]["rays_d"], staged=True)
 
 
+@pytest.mark.parametrize("K", [0, 16])
+def test_trainer_view_loops_go_through_the_frame_pipeline_bit_identically(params_k16, room, room_bitfield, K, tmp_path):
+    """Trainer.evaluate_one_epoch / test / render_sequence render a loader's views through FramePipeline (two alternating
+    streams): every view's image, depth and instance logits carry the bits of eval_step / test_step on that view alone,
+    the metric is the one-stream metric, and the PNG files are the same bytes."""
+    from instance_nerf_amd.nerf.utils import Trainer, get_rays
+    net = _network(params_k16, K=K)
+    net.density_bitfield.copy_(_t(room_bitfield))
+    poses, intr, H, W = room.cameras(n=5, H=64, W=64, focal=32.0)
+    views = []
+    for v in range(5):
+        r = get_rays(_t(poses[v:v + 1]), intr, H, W)              # row-major rays, as upstream's loaders hand them over
+        d = {"rays_o": r["rays_o"], "rays_d": r["rays_d"], "H": H, "W": W}
+        if K:
+            d["masks"] = torch.randint(-1, K, (1, H * W), device=DEV)
+        else:
+            d["images"] = torch.rand(1, H, W, 3, device=DEV)
+        views.append(d)
+    tr = Trainer("seq", None, net, stage="instance" if K else "nerf", device=torch.device(DEV), workspace=str(tmp_path),
+                 use_checkpoint="scratch", mute=True)
+    net.eval()
+    ref = [tr.test_step(d) for d in views]
+    seq = [tr._test_outputs(d, o) for d, o in tr.render_sequence(views)]
+    one = [tr._test_outputs(d, o) for d, o in tr.render_sequence(views, pipeline=False)]
+    for a, b, c in zip(ref, seq, one):
+        for x, y, z in zip(a, b, c):
+            assert (x is None and y is None) or (torch.equal(x, y) and torch.equal(x, z))
+    tr.pipeline_views = True
+    r1 = tr.evaluate_one_epoch(views)
+    files1 = tr.test(views, save_path=str(tmp_path / "a"), name="v")
+    tr.pipeline_views = False
+    r0 = tr.evaluate_one_epoch(views)
+    files0 = tr.test(views, save_path=str(tmp_path / "b"), name="v")
+    assert r1 == r0 and len(files1) == len(files0) == 5
+    for f1, f0 in zip(files1, files0):
+        assert open(f1, "rb").read() == open(f0, "rb").read()
+
+
 def test_instance_head_with_31_classes_runs_on_the_fused_kernels(level_table, room, room_bitfield):
     """K = 31 (the reference's 30 detections + background, run_rcnn.py:75 / match_seg.py:69) is not a multiple of the
     16-channel MFMA tile: the fused kernels run it with a zero-padded output layer.  Nothing padded leaks: logits,
