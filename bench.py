@@ -140,7 +140,50 @@ def cpu_baseline(room, net, frame0=None, chunk=16384, budget_s=12.0, max_chunks=
     return base, parity
 
 
-def train_probe(dev, rank=0, world=1, red_dev=None, steps=20, warmup=5, stage="instance", mode="eager"):
+def collective_record(dev, rank, world, backend, red_dev, table_bytes=6119864 * 2 * 4):
+    """world > 1, EVERY rank calls it: what a reader needs to trust that the collectives of this run crossed N distinct
+    GPUs (round-3 verdict: RCCL has never executed under this repository; the first record must verify itself) - the
+    backend and its version, every rank's device (PCI address + name, all-gathered: N distinct ones, or the run is a
+    dry run and says so), and a 10-iteration all-reduce of one table gradient (48.96 MB fp32) with its bus bandwidth
+    2 (N-1)/N x bytes / time, the figure DESIGN.md section 4 budgets 0.25 ms per step for."""
+    import torch.distributed as dist
+    pr = torch.cuda.get_device_properties(dev)
+    ident = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x} {pr.name}"
+    idents = [None] * world
+    dist.all_gather_object(idents, ident)
+    version = None
+    if backend == "nccl":
+        try:
+            version = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception as e:                                 # noqa: BLE001
+            version = f"unavailable ({type(e).__name__})"
+    n_it = 10 if backend == "nccl" else 2                      # a gloo dry run moves the 49 MB through host memory
+    buf = torch.ones(table_bytes // 4, dtype=torch.float32, device=red_dev)
+    for _ in range(2):
+        dist.all_reduce(buf)
+    dist.barrier()
+    if red_dev.type == "cuda":
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n_it):
+        dist.all_reduce(buf)
+    if red_dev.type == "cuda":
+        torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n_it
+    tm = torch.tensor([dt], dtype=torch.float64, device=red_dev)
+    dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+    dt = float(tm.item())
+    distinct = len(set(idents))
+    return {"backend": backend + (" (RCCL)" if backend == "nccl" else " (dry run: host transport, ranks may share a GPU)"),
+            "rccl_version": version, "ranks": world, "devices": idents, "distinct_devices": distinct,
+            "all_ranks_on_distinct_gpus": distinct == world,
+            "allreduce_table_gradient": {"bytes": table_bytes, "iterations": n_it, "ms": round(dt * 1e3, 4),
+                                         "bus_gb_per_s": round(2 * (world - 1) / world * table_bytes / dt / 1e9, 1),
+                                         "what": "dist.all_reduce of one fp32 table gradient, max over ranks; bus bandwidth = "
+                                                 "2 (N-1)/N x bytes / time (the per-link figure a ring is bound by)"}}
+
+
+def train_probe(dev, rank=0, world=1, red_dev=None, steps=20, warmup=5, stage="instance", mode="eager", schedule=None):
     """Secondary measurement (not the headline value): instance-field training step, BASELINE configs[2]
     (K=64 logits, 4096 rays/batch per GPU, NeRF frozen): march -> frozen NeRF (fused) -> instance grid encode ->
     MLP -> K-channel compositing -> CE -> backward (atomic scatter) -> [gradient all-reduce] -> fused Adam.
@@ -160,6 +203,8 @@ def train_probe(dev, rank=0, world=1, red_dev=None, steps=20, warmup=5, stage="i
     # also holds, forked off before the scatter, the parameter-independent head of the next batch on a second stream
     # (march; in the instance stage also the frozen NeRF's forward and the weight compositing)
     piped = mode == "pipelined" and world == 1
+    if schedule is not None:               # "all_reduce" | "reduce_scatter": how the table gradient crosses the links
+        _grad_sync.schedule = schedule
     tr = Trainer("bench", None, net, stage=stage, device=dev, iters=1000, update_extra_interval=16,
                  local_rank=rank, world_size=world, ema_decay=0.95,     # upstream's main scripts train with the EMA on
                  use_graph=piped, look_ahead=piped, shade_ahead=piped)
@@ -854,6 +899,18 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"], line["parity"] = cpu_baseline(room, net, step(0)["frame"],
                                                                 render_view0=lambda: step(0)["frame"])
+    if world > 1:
+        rec = collective_record(dev, rank, world, backend, red_dev)
+        if rank == 0:
+            line["collective"] = rec
+        if backend == "nccl" and not rec["all_ranks_on_distinct_gpus"]:
+            # an RCCL run whose ranks share GPUs measures nothing about xGMI: fail loudly instead of reporting a curve
+            if rank == 0:
+                line["error"] = f"{rec['distinct_devices']} distinct GPUs for {world} ranks"
+                print(json.dumps(line), flush=True)
+            dist.barrier()
+            dist.destroy_process_group()
+            sys.exit(4)
     if not args.no_train_probe:
         del net                                       # the probe builds its own (instance-head) network
         if world == 1:
@@ -900,8 +957,19 @@ def main():
                 watchdog.daemon = True
                 watchdog.start()
             try:
+                from instance_nerf_amd.nerf.utils import grad_sync as _gs
+                default_schedule = _gs.schedule
                 ts = train_probe(dev, rank, world, red_dev, steps=args.train_steps)   # every rank runs it
                 tn = train_probe(dev, rank, world, red_dev, steps=args.train_steps, stage="nerf")
+                # the other gradient schedule, back to back (same bytes on the links, 7/8 of the
+                # optimiser sweep saved per rank): the xGMI box decides which one becomes the default
+                other = "reduce_scatter" if default_schedule != "reduce_scatter" else "all_reduce"
+                to = train_probe(dev, rank, world, red_dev, steps=args.train_steps, schedule=other)
+                _gs.schedule = default_schedule
+                if rank == 0:
+                    line["train_step_other_schedule"] = {k: to[k] for k in (
+                        "ms_per_step", "ms_per_step_median", "ms_per_step_of_both_timed_regions", "samples_per_step",
+                        "msamples_per_s", "gradient_schedule", "allreduce_mb_per_step", "loss_first", "loss_last") if k in to}
             except Exception as e:                            # noqa: BLE001
                 if rank == 0:
                     line["train_step"] = line["train_step_nerf"] = {"error": f"{type(e).__name__}: {e}"[:300]}

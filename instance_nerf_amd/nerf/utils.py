@@ -247,6 +247,8 @@ class FusedAdam(torch.optim.Optimizer):
                     flat = lambda t: t.view(-1)
                     for piece in pieces:
                         a, n = piece["own"], piece["grad"].numel()
+                        if n == 0:              # a rank beyond the end of a padded slice owns nothing of it
+                            continue
                         jobs.append((flat(p.data)[a:a + n], piece["grad"], flat(st["exp_avg"])[a:a + n],
                                      flat(st["exp_avg_sq"])[a:a + n], g, p, (a, n)))
                     continue
@@ -435,22 +437,31 @@ class _GradSync:
     def active(self):
         return self.enabled and self.world_size > 1 and dist.is_available() and dist.is_initialized()
 
-    def scatter_mode(self, numel):
-        return (self.schedule == "reduce_scatter" and self.sharded_ok and self.world_size > 1
-                and numel % self.world_size == 0)
+    def scatter_mode(self, numel=0):
+        """The reduce-scatter schedule applies - to EVERY slice of a table gradient, whatever its size: a slice that the
+        world size does not divide is padded on the wire and the last ranks' pieces are shorter (round-3 advisor: the
+        mode used to be decided per slice from numel % world_size, so two level ranges of one table could differ - with
+        3 or 6 ranks and T = 6 119 864 rows - and the all-reduced rows were then never updated)."""
+        return self.schedule == "reduce_scatter" and self.sharded_ok and self.world_size > 1
 
     def reduce_async(self, view, param=None, flat_lo=0):
         """Sum ``view`` (a contiguous slice of a table gradient) over the ranks, asynchronously; ``finish()`` waits.
         ``param`` / ``flat_lo`` (the parameter the slice belongs to and the slice's first flat element): with the
         reduce-scatter schedule the rank receives only its 1 / world of the slice, kept as a piece for the optimiser."""
-        if param is not None and self.scatter_mode(view.numel()):
-            n = view.numel() // self.world_size
+        if param is not None and self.scatter_mode():
+            W, numel = self.world_size, view.numel()
+            n = (numel + W - 1) // W                          # elements per rank on the wire
             dt = torch.bfloat16 if self.payload == "bf16" else torch.float32
-            wire = view.reshape(-1).to(dt)                    # fp32: a view, nothing is copied
+            if numel == n * W:
+                wire = view.reshape(-1).to(dt)                # fp32: a view, nothing is copied
+            else:                                             # pad: the tail belongs to nobody
+                wire = torch.zeros(n * W, dtype=dt, device=view.device)
+                wire[:numel] = view.reshape(-1)
             out = torch.empty(n, dtype=dt, device=view.device)
             h = dist.reduce_scatter_tensor(out, wire, async_op=True)
-            piece = {"lo": int(flat_lo), "n": view.numel(), "own": int(flat_lo) + dist.get_rank() * n, "grad": out,
-                     "wire": wire}
+            rank = dist.get_rank()
+            piece = {"lo": int(flat_lo), "n": numel, "own": int(flat_lo) + rank * n, "grad": out, "wire": wire,
+                     "count": max(0, min(n, numel - rank * n)), "stride": n}
             self.pieces.setdefault(param.data_ptr(), []).append(piece)
             self.handles.append((h, None, None))
         elif self.payload == "bf16":
@@ -473,6 +484,8 @@ class _GradSync:
                 piece.pop("wire", None)
                 if piece["grad"].dtype != torch.float32:
                     piece["grad"] = piece["grad"].float()
+                if piece["grad"].numel() != piece["count"]:
+                    piece["grad"] = piece["grad"][:piece["count"]]      # the wire's padding is not a gradient
 
     def reset(self):
         self.finish()
@@ -485,15 +498,26 @@ class _GradSync:
             pieces = self.pieces.pop(p.data_ptr(), None)
             if pieces:
                 p._inr_grad_shards = pieces
-                p._inr_shard_layout = [(q["lo"], q["n"], q["own"], q["grad"].numel()) for q in pieces]
+                p._inr_shard_layout = [(q["lo"], q["n"], q["own"], q["count"], q["stride"]) for q in pieces]
+                # the full-size buffer holds this rank's UNREDUCED gradient: nothing may mistake it for the sum
+                # (clip_grad_norm_, logging); the optimiser takes the pieces
+                p.grad = None
         self.pieces = {}
 
     @staticmethod
     def allgather_pieces(tensor, layout):
         """Every rank's piece (own, count) of each range (lo, n) of the flat ``tensor`` -> all ranks, in place."""
         flat = tensor.view(-1)
-        for lo, n, own, cnt in layout:
-            dist.all_gather_into_tensor(flat[lo:lo + n], flat[own:own + cnt].clone())
+        W = dist.get_world_size()
+        for lo, n, own, cnt, stride in layout:
+            if stride * W == n:
+                dist.all_gather_into_tensor(flat[lo:lo + n], flat[own:own + cnt].clone())
+            else:                                             # padded on the wire: the last pieces are shorter
+                mine = torch.zeros(stride, dtype=flat.dtype, device=flat.device)
+                mine[:cnt] = flat[own:own + cnt]
+                full = torch.empty(stride * W, dtype=flat.dtype, device=flat.device)
+                dist.all_gather_into_tensor(full, mine)
+                flat[lo:lo + n] = full[:n]
 
     def allgather_params(self, params):
         """After the optimiser step of the reduce-scatter schedule: the updated rows of every rank travel to all."""

@@ -71,6 +71,74 @@ def test_allreduce_gradients_world2():
     assert all(r[2] == 2.0 and r[3] == 300.0 for r in res)
 
 
+def _scatter_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from instance_nerf_amd.nerf import utils
+    gs = utils.grad_sync
+    gs.world_size, gs.schedule, gs.enabled = world, "reduce_scatter", True
+    ok = True
+    try:
+        for payload in ("fp32", "bf16"):
+            gs.payload = payload
+            # a "table" of 1001 x 2 (rows the world size does not divide) reduced in two row ranges, as the backward does
+            table = torch.nn.Parameter(torch.zeros(1001, 2))
+            small = torch.nn.Parameter(torch.zeros(7, 3))
+            table._inr_split_row = 400
+            full = [torch.randn(1001, 2, generator=torch.Generator().manual_seed(10 + r)) for r in range(world)]
+            table.grad = full[rank].clone()
+            small.grad = torch.full_like(small, float(rank + 1))
+            want = sum(full)
+            scale = utils.allreduce_gradients([table, small], world, average=False, sharded=True)
+            ok = ok and scale == 1.0 / world
+            pieces = table._inr_grad_shards
+            ok = ok and pieces is not None and len(pieces) == 2 and table.grad is None
+            # this rank's pieces are the matching rows of the sum; all ranks' pieces tile the table exactly once
+            got = torch.full((2002,), float("nan"))
+            cover = torch.zeros(2002)
+            for pc in pieces:
+                a, n = pc["own"], pc["grad"].numel()
+                ok = ok and n == pc["count"]
+                got[a:a + n] = pc["grad"]
+                cover[a:a + n] += 1
+            tol = 1e-6 if payload == "fp32" else 2 ** -6 * float(want.abs().max())
+            mine = cover > 0
+            ok = ok and float((got[mine] - want.reshape(-1)[mine]).abs().max()) <= tol
+            dist.all_reduce(cover)
+            ok = ok and bool((cover == 1).all())
+            ok = ok and torch.equal(small.grad, torch.full_like(small, float(sum(range(1, world + 1)))))
+            # "optimiser": every rank writes its rows, then the rows travel to all (allgather_params)
+            flat = table.data.view(-1)
+            for pc in pieces:
+                flat[pc["own"]:pc["own"] + pc["count"]] = pc["grad"]
+            gs.allgather_params([table])
+            ok = ok and table._inr_grad_shards is None
+            ok = ok and float((table.data - want).abs().max()) <= tol
+    except Exception as e:                                     # noqa: BLE001
+        ok = f"{type(e).__name__}: {e}"
+    dist.barrier()
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_reduce_scatter_schedule_with_rows_the_world_does_not_divide(world):
+    """grad_sync.schedule = "reduce_scatter": every row range of a table gradient is reduce-scattered - padded on the wire
+    when the world size does not divide it (round-3 advisor: with 3 or 6 ranks one of the two level ranges of the
+    BASELINE table fell back to an all-reduce whose rows the optimiser then never saw).  The pieces of all ranks tile
+    the table exactly once, carry the sum, and the updated rows come back whole."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_scatter_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+    assert all(ok is True for _, ok in res), res
+
+
 def test_views_are_sharded_without_overlap():
     """bench.py's view assignment (i + rank) % n: distinct views per rank at every step, and over n steps every rank
     renders every view once (the views' sample counts differ by +-25 %: a rank pinned to one view would make the
@@ -145,13 +213,13 @@ def test_render_sharded_world2(n):
 
 
 def test_bench_diagnostics_never_raise_without_a_gpu(tmp_path):
-    """bench.py's run-to-run diagnostics (`clocks`: shader clock sampled through sysfs, the XCD map of the process) are
-    decoration around the timed region: with no GPU, no sysfs node or no probe library they report nothing instead of
+    """bench.py's opt-in run-to-run diagnostics (--diagnostics, tools/bench_diagnostics.py; `clocks`: shader clock sampled
+    through sysfs, the XCD map of the process) are decoration around the timed region: with no GPU, no sysfs node or no probe library they report nothing instead of
     failing the run; the sysfs parser takes the starred line of a pp_dpm_sclk file."""
     import importlib.util
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "tools", "bench_diagnostics.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
     s = bench.SclkSampler("cpu")

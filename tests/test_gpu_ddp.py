@@ -357,6 +357,15 @@ def test_bench_logic_with_eight_ranks_on_one_gpu():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 8 and line["scaling"] == "weak" and line["value"] > 0 and line["steps"] == 2
     assert line["config"]["rays_per_step"] == 200 * 200 and "8 GPU" in line["config"]["parallelism"]
+    # the self-verifying collective record (round 4): backend, version slot, one device entry per rank, the table-sized
+    # all-reduce probe - on this dry run the eight ranks share ONE GPU and the record says so
+    c = line["collective"]
+    assert c["ranks"] == 8 and len(c["devices"]) == 8 and c["backend"].startswith("gloo")
+    assert c["distinct_devices"] == 1 and c["all_ranks_on_distinct_gpus"] is False and c["rccl_version"] is None
+    assert c["allreduce_table_gradient"]["bytes"] == 6119864 * 8 and c["allreduce_table_gradient"]["bus_gb_per_s"] > 0
+    o = line["train_step_other_schedule"]
+    assert "reduce_scatter" in o["gradient_schedule"] and "all_reduce" in line["train_step"]["gradient_schedule"]
+    assert o["samples_per_step"] > 8 * 50_000 and o["loss_last"] == o["loss_last"]
     for key in ("train_step", "train_step_nerf"):
         t = line[key]
         assert "error" not in t, t
