@@ -183,7 +183,8 @@ def collective_record(dev, rank, world, backend, red_dev, table_bytes=6119864 * 
                                                  "2 (N-1)/N x bytes / time (the per-link figure a ring is bound by)"}}
 
 
-def train_probe(dev, rank=0, world=1, red_dev=None, steps=20, warmup=5, stage="instance", mode="eager", schedule=None):
+def train_probe(dev, rank=0, world=1, red_dev=None, steps=20, warmup=5, stage="instance", mode="eager", schedule=None,
+                fp16=False):
     """Secondary measurement (not the headline value): instance-field training step, BASELINE configs[2]
     (K=64 logits, 4096 rays/batch per GPU, NeRF frozen): march -> frozen NeRF (fused) -> instance grid encode ->
     MLP -> K-channel compositing -> CE -> backward (atomic scatter) -> [gradient all-reduce] -> fused Adam.
@@ -207,7 +208,8 @@ def train_probe(dev, rank=0, world=1, red_dev=None, steps=20, warmup=5, stage="i
         _grad_sync.schedule = schedule
     tr = Trainer("bench", None, net, stage=stage, device=dev, iters=1000, update_extra_interval=16,
                  local_rank=rank, world_size=world, ema_decay=0.95,     # upstream's main scripts train with the EMA on
-                 use_graph=piped, look_ahead=piped, shade_ahead=piped)
+                 use_graph=piped, look_ahead=piped, shade_ahead=piped,
+                 fp16=fp16)             # upstream's -O: the frozen NeRF of the instance stage with -O's numerics
     # Upstream's loop, occupancy update included: every 16 steps update_extra_state() queries the density of 128^3
     # (later 128^3 / 2) cells, refreshes the grid / bitfield and sets mean_count, which sizes the sample buffers of
     # the next 16 steps (no host sync inside a step).  The field is untrained here, so the grid it produces says
@@ -934,6 +936,14 @@ def main():
                     obj["overlapped"]["step_frac_of_hbm_peak"] = ov["roofline"]["step"]["frac"]
                 except Exception as e:                    # noqa: BLE001
                     obj["overlapped"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            if "error" not in ts:
+                # upstream's -O on the instance stage (Trainer(fp16=True)): trained parameters stay fp32, the frozen
+                # NeRF's forward gathers from the fp16 table copy and runs the one-pass fp16 MLP
+                try:
+                    ov = train_probe(dev, rank, world, red_dev, steps=args.train_steps, mode="pipelined", fp16=True)
+                    ts["overlapped_O"] = {k: ov[k] for k in keep if k in ov and k != "ms_of_each_step"}
+                except Exception as e:                    # noqa: BLE001
+                    ts["overlapped_O"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         else:
             # The probe contains collectives: a rank that swallowed an exception would leave the others waiting in
             # all_reduce, so exceptions propagate (non-zero exit, the launcher tears the job down).  Two guards keep

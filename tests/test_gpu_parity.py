@@ -2656,6 +2656,50 @@ def test_shade_ahead_is_bit_identical_to_the_inline_head(room):
             assert torch.equal(x[4][k], y[4][k]), k
 
 
+def test_train_time_O_keeps_the_instance_stage_within_one_percent(room):
+    """Trainer(fp16=True, stage="instance") - upstream's -O for the stage this repository trains with a frozen NeRF: the
+    frozen field's forward runs with -O's numerics (fp16 copy of its table: half the bytes every XCD pulls through its
+    fabric port; single-pass fp16 MLP: inr_nerf_forward_fast) while everything that is TRAINED - instance table, instance
+    MLP, their gradients, Adam's moments - stays fp32 (no GradScaler: nothing trained is ever stored in half precision).
+    50 steps from the same parameters on the same batches: the loss stays within 1 % of the fp32 run at every step."""
+    from instance_nerf_amd.nerf import NeRFNetwork
+    from instance_nerf_amd.nerf.provider import SyntheticRoomDataset
+    from instance_nerf_amd.nerf.utils import Trainer
+    dev = torch.device(DEV)
+    runs = {}
+    for fp16 in (False, True):
+        torch.manual_seed(0)
+        net = NeRFNetwork(cuda_ray=True, bound=1, min_near=0.05, num_instances=16).to(dev)
+        with torch.no_grad():                      # an O(1) NeRF (semi-transparent rays): its rounding matters
+            net.encoder.embeddings.uniform_(-1, 1, generator=torch.Generator(device=DEV).manual_seed(9))
+        ds = SyntheticRoomDataset(dev, num_rays=1024, num_instances=16, seed=5)
+        net.density_bitfield.copy_(_t(ds.room.density_bitfield(128, 1.0)))
+        tr = Trainer("o", None, net, stage="instance", device=dev, iters=200, update_extra_interval=10 ** 9, fp16=fp16,
+                     workspace=None, mute=True)
+        tr.global_step = 1
+        assert net.half_table == fp16 and net.mlp_fp16 == fp16
+        calls = []
+        lib_fast = net._fused_nerf
+
+        def spy(*a, _f=lib_fast, **kw):
+            calls.append(1)
+            return _f(*a, **kw)
+        net._fused_nerf = spy
+        orig = net.render
+        net.render = lambda *a, **kw: orig(*a, **{**kw, "perturb": False, "force_all_rays": True})
+        batches = [ds.batch() for _ in range(5)]
+        losses = [float(tr.train_one_step(batches[i % 5])) for i in range(50)]
+        assert len(calls) == 50                                     # the frozen field ran on the fused no-grad kernel
+        assert all(p.dtype == torch.float32 for p in net.parameters())
+        st = tr.optimizer.state[net.instance_encoder.embeddings]
+        assert st["exp_avg"].dtype == torch.float32 and st["exp_avg_sq"].dtype == torch.float32
+        runs[fp16] = losses
+    a, b = np.asarray(runs[False]), np.asarray(runs[True])
+    assert a[-5:].mean() < 0.5 * a[:5].mean()
+    assert np.abs(a - b).max() <= 0.01 * np.abs(a).max() and (np.abs(a - b) / np.abs(a)).max() < 0.01, (a[-5:], b[-5:])
+    assert np.abs(a - b).max() > 0                                  # it really ran other numerics
+
+
 def test_render_through_the_registered_custom_ops(params_k16, room, room_bitfield, level_table):
     """torch.ops.inr.*: a training-mode render assembled from the registered ops - ray/box test, march, hash-grid
     encode + tiny MLPs (torch), compositing - equals the module path (NeRFNetwork.render) on the same rays: sample
