@@ -64,13 +64,12 @@ def psnr(img, gt):
 
 
 def miou(pred, truth, n_classes=K):
-    """Mean IoU over the classes present in prediction or truth (the product's MIoUMeter rule)."""
+    """Mean IoU over the classes present in the truth (the product's MIoUMeter rule)."""
     ious = []
     for c in range(n_classes):
         p, t = pred == c, truth == c
-        u = np.logical_or(p, t).sum()
-        if u:
-            ious.append(np.logical_and(p, t).sum() / u)
+        if t.sum():
+            ious.append(np.logical_and(p, t).sum() / np.logical_or(p, t).sum())
     return float(np.mean(ious))
 
 
