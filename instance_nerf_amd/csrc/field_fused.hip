@@ -928,10 +928,24 @@ __global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_nerf_fwd(cons
 // out[m] = (mean over D fixed view directions of rgb(x_m, dir), raw density logit h0(x_m)): ONE gather and ONE
 // sigma-net pass per point, then the colour net once per direction with the direction's SH row as a wave-uniform
 // operand (staged in LDS).  Replaces density() + D x color() through the unfused encoder / BLAS path.
+// kLattice (round 4): the points are a [W, L, H] lattice given by its three coordinate axes (x = ax_w[iw], y = ax_l[il],
+// z = ax_h[ih]: exactly the caller's floats, no meshgrid tensor) and a 16-sample tile is a RUN ALONG W at fixed (il, ih).
+// The writer's own order has h fastest; x is the fastest index of the table's rows (dense and hashed levels alike), so
+// 16 consecutive h are 16 different 128-byte lines per level and corner where 16 consecutive w share one or two: the
+// kernel is purely gather-bound (1 or 4 colour-net passes: 2.546 / 2.545 ms) and went 2.55 -> 1.07 ms for 160^3 points
+// on the order alone (tools/extract_order_probe.py, profiles/r04_NOTES.txt 6).  out stays [W, L, H, 4].
+struct LatticeDesc {
+  const float* ax_w;
+  const float* ax_l;
+  const float* ax_h;
+  int W, L, H, Wp;          // Wp = W rounded up to 16: a tile never straddles two (il, ih)
+};
 constexpr int kMaxExtractDirs = 8;
+template <bool kLattice>
 __global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_nerf_fwd_dirs(
     const float* __restrict__ x, int64_t M, float bound, const float2* __restrict__ emb, uint32_t emb_bytes, GridDesc G,
-    const float4* __restrict__ packed, const float* __restrict__ sh_dirs /*[D,16]*/, int D, float4* __restrict__ out) {
+    const float4* __restrict__ packed, const float* __restrict__ sh_dirs /*[D,16]*/, int D, float4* __restrict__ out,
+    LatticeDesc lat) {
   extern __shared__ __attribute__((aligned(16))) float4 wl[];
   constexpr int kStage = kNerfFloats / 4;
   for (int i = threadIdx.x; i < kStage; i += kFieldThreads) wl[i] = packed[i];
@@ -952,10 +966,25 @@ __global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_nerf_fwd_dirs
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)emb, 0, (int)emb_bytes, 0x00020000);
   const float inv_d = 1.0f / (float)D;
   for (int64_t it = 0, tile = sched.tile(0); tile < sched.hi; tile = sched.tile(++it)) {
-    const int64_t m = tile * 16 + j;
-    const bool valid = m < M;
+    int64_t m = tile * 16 + j;
+    bool valid = m < M;
     TileIn me;
-    load_tile_in<false>(x, nullptr, valid ? m : M - 1, bound, rb, 0.0f, me);
+    if constexpr (kLattice) {
+      // traversal index -> (il, ih, iw) with iw fastest; the caller clamps to [-bound, bound] like extract_rgbsigma did
+      const int64_t row = m / lat.Wp;
+      const int iw = (int)(m - row * lat.Wp);
+      const int il = (int)(row / lat.H), ih = (int)(row - (int64_t)il * lat.H);
+      valid = valid && iw < lat.W;
+      const int cw = min(iw, lat.W - 1), cl = min(il, lat.L - 1);
+      me.x0 = to_x01(fminf(fmaxf(lat.ax_w[cw], -bound), bound), bound, rb, 0.0f);
+      me.x1 = to_x01(fminf(fmaxf(lat.ax_l[cl], -bound), bound), bound, rb, 0.0f);
+      me.x2 = to_x01(fminf(fmaxf(lat.ax_h[ih], -bound), bound), bound, rb, 0.0f);
+      me.oob = oob01(me.x0, me.x1, me.x2);
+      if (me.oob) me.x0 = me.x1 = me.x2 = 0.0f;
+      m = ((int64_t)cw * lat.L + cl) * lat.H + ih;      // where the point lives in [W, L, H]
+    } else {
+      load_tile_in<false>(x, nullptr, valid ? m : M - 1, bound, rb, 0.0f, me);
+    }
     f32x4 enc[2];
     {
       Gathered g;
@@ -2147,33 +2176,86 @@ static int grid_for(Kern kern, size_t lds_bytes, int64_t n_tiles) {
 }
 
 // Cursors of the hybrid schedule (TileWalk): a ring of kStealRing sets per device, the next one zeroed on the launch's
-// stream right before the launch - launches on different streams (FramePipeline) never share a set unless more than
-// kStealRing field kernels are in flight at once.
+// stream right before the launch.  Launches on different streams (FramePipeline) never share a set: every set carries
+// the event of the launch that last used it, and a launch that is handed a set whose previous user has not finished
+// (more than kStealRing field kernels pending at once) makes its stream wait for that event first (round-3 advisor: the
+// set used to be re-zeroed under the running kernel - tiles skipped or duplicated without an error).
 constexpr int kStealRing = 16;
-static unsigned long long* steal_cursors(hipStream_t s) {
-  static unsigned long long* ring[64] = {};
+struct StealSet {
+  unsigned long long* cursors = nullptr;
+  int dev = -1, slot = -1;
+};
+struct StealRing {
+  std::atomic<unsigned long long*> base{nullptr};
+  hipEvent_t ev[kStealRing] = {};
+  bool used[kStealRing] = {};
+};
+static StealRing g_steal[64];
+static std::mutex g_steal_mu;
+static bool stream_is_capturing(hipStream_t s) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  return hipStreamIsCapturing(s, &st) == hipSuccess && st != hipStreamCaptureStatusNone;
+}
+static StealSet steal_cursors(hipStream_t s) {
   static std::atomic<unsigned> turn{0};
-  static std::mutex mu;
+  StealSet out;
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-  if (!ring[dev]) {
-    std::lock_guard<std::mutex> lock(mu);
-    if (!ring[dev]) {
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return out;
+  StealRing& R = g_steal[dev];
+  if (!R.base.load(std::memory_order_acquire)) {
+    std::lock_guard<std::mutex> lock(g_steal_mu);
+    if (!R.base.load(std::memory_order_relaxed)) {
       void* p = nullptr;
       if (hipMalloc(&p, (size_t)kStealRing * kStealOwners * sizeof(unsigned long long)) != hipSuccess) {
         set_error("hybrid schedule: hipMalloc of the cursor ring failed");
-        return nullptr;
+        return out;
       }
-      ring[dev] = (unsigned long long*)p;
+      R.base.store((unsigned long long*)p, std::memory_order_release);
     }
   }
-  unsigned long long* p = ring[dev] + (size_t)(turn.fetch_add(1) % kStealRing) * kStealOwners;
+  const int slot = (int)(turn.fetch_add(1) % kStealRing);
+  unsigned long long* p = R.base.load(std::memory_order_acquire) + (size_t)slot * kStealOwners;
+  {
+    std::lock_guard<std::mutex> lock(g_steal_mu);
+    if (R.used[slot] && !stream_is_capturing(s) && hipEventQuery(R.ev[slot]) == hipErrorNotReady &&
+        hipStreamWaitEvent(s, R.ev[slot], 0) != hipSuccess) {
+      set_error("hybrid schedule: hipStreamWaitEvent failed");
+      return out;
+    }
+  }
   if (hipMemsetAsync(p, 0, kStealOwners * sizeof(unsigned long long), s) != hipSuccess) {
     set_error("hybrid schedule: hipMemsetAsync failed");
-    return nullptr;
+    return out;
   }
-  return p;
+  out.cursors = p;
+  out.dev = dev;
+  out.slot = slot;
+  return out;
 }
+// after the launch that draws from the set: its completion event (not inside a stream capture: a captured event says
+// nothing about a replay - captured steps are small launches and never take the hybrid schedule anyway)
+static void steal_release(const StealSet& st, hipStream_t s) {
+  if (!st.cursors || stream_is_capturing(s)) return;
+  std::lock_guard<std::mutex> lock(g_steal_mu);
+  StealRing& R = g_steal[st.dev];
+  if (!R.ev[st.slot] && hipEventCreateWithFlags(&R.ev[st.slot], hipEventDisableTiming) != hipSuccess) return;
+  R.used[st.slot] = hipEventRecord(R.ev[st.slot], s) == hipSuccess;
+}
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: once per (kernel call site, device), not once per
+// process (round-3 advisor: a process that trained on a second GPU launched there without the attribute)
+struct AttrOnce {
+  std::atomic<bool> done[64] = {};
+  template <typename K>
+  bool ensure(K kern, size_t lds) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    if (done[dev].load(std::memory_order_acquire)) return true;
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+    done[dev].store(true, std::memory_order_release);
+    return true;
+  }
+};
 
 }  // namespace inr
 
@@ -2262,11 +2344,12 @@ int inr_nerf_forward(const float* x, const float* d, int64_t M, const int32_t* n
   const uint32_t emb_bytes = (uint32_t)emb_bytes64;
   const int64_t n_tiles = (M + 15) / 16;
   // frames and occupancy sweeps (four rounds of eight 1024-tile chunks and more): hybrid schedule, see TileWalk
-  unsigned long long* steal = nullptr;
+  StealSet steal_set;
   if ((n_tiles >> (kXcdChunkLog2 + 3)) >= 4) {
-    steal = steal_cursors(as_stream(s));
-    if (!steal) return INR_ELAUNCH;
+    steal_set = steal_cursors(as_stream(s));
+    if (!steal_set.cursors) return INR_ELAUNCH;
   }
+  unsigned long long* steal = steal_set.cursors;
   if (rgb) {
     const size_t lds = kNerfFloats * sizeof(float) + kLevelRecBytes;
     const int grid = grid_for(k_nerf_fwd<true>, lds, n_tiles);
@@ -2278,6 +2361,7 @@ int inr_nerf_forward(const float* x, const float* d, int64_t M, const int32_t* n
     k_nerf_fwd<false><<<grid, kFieldThreads, lds, as_stream(s)>>>(x, d, M, n_samples_dev, bound, e, emb_bytes, G, p,
                                                        density_scale, sigma, nullptr, geo_feat, nullptr, nullptr, NerfSave{}, steal);
   }
+  steal_release(steal_set, as_stream(s));
   return check_launch("nerf_forward");
 }
 
@@ -2320,15 +2404,17 @@ static int launch_nerf_table(const float* x01, const int32_t* ray_ids, const flo
                              float density_scale, float* sigma, float* rgb, size_t lds, inr_stream_t s) {
   const int grid = grid_for(k_nerf_fwd<true, true, 0, kHalf, kFast>, lds, (M + 15) / 16);
   // frames (four rounds of eight 1024-tile chunks and more) take the hybrid schedule: its cursors, zeroed on this stream
-  unsigned long long* steal = nullptr;
+  StealSet steal_set;
   if ((((M + 15) / 16) >> (kXcdChunkLog2 + 3)) >= 4) {
-    steal = steal_cursors(as_stream(s));
-    if (!steal) return INR_ELAUNCH;
+    steal_set = steal_cursors(as_stream(s));
+    if (!steal_set.cursors) return INR_ELAUNCH;
   }
+  unsigned long long* steal = steal_set.cursors;
   k_nerf_fwd<true, true, 0, kHalf, kFast><<<grid, kFieldThreads, lds, as_stream(s)>>>(
       x01, nullptr, M, nullptr, bound, reinterpret_cast<const float2*>(embeddings), emb_bytes, G,
       reinterpret_cast<const float4*>(packed), density_scale, sigma, rgb, nullptr, ray_ids,
       reinterpret_cast<const float4*>(sh_table_q), NerfSave{}, steal);
+  steal_release(steal_set, as_stream(s));
   return check_launch("nerf_forward_table");
 }
 }  // extern "C++"
@@ -2374,11 +2460,35 @@ int inr_nerf_forward_dirs(const float* x, int64_t M, float bound, const float* e
   const uint64_t emb_bytes64 = (uint64_t)desc->offsets[desc->num_levels] * 8ull;
   INR_REQUIRE(emb_bytes64 < (1ull << 31), "table larger than 2 GiB is not addressable by the 32-bit gather offsets");
   const size_t lds = kNerfFloats * sizeof(float) + kLevelRecBytes + kMaxExtractDirs * 16 * sizeof(float);
-  const int grid = grid_for(k_nerf_fwd_dirs, lds, (M + 15) / 16);
-  k_nerf_fwd_dirs<<<grid, kFieldThreads, lds, as_stream(s)>>>(x, M, bound, reinterpret_cast<const float2*>(embeddings),
-                                                              (uint32_t)emb_bytes64, G, reinterpret_cast<const float4*>(packed),
-                                                              sh_dirs, n_dirs, reinterpret_cast<float4*>(out));
+  const int grid = grid_for(k_nerf_fwd_dirs<false>, lds, (M + 15) / 16);
+  k_nerf_fwd_dirs<false><<<grid, kFieldThreads, lds, as_stream(s)>>>(
+      x, M, bound, reinterpret_cast<const float2*>(embeddings), (uint32_t)emb_bytes64, G,
+      reinterpret_cast<const float4*>(packed), sh_dirs, n_dirs, reinterpret_cast<float4*>(out), LatticeDesc{});
   return check_launch("nerf_forward_dirs");
+}
+
+int inr_nerf_forward_lattice(const float* ax_w, const float* ax_l, const float* ax_h, int32_t W, int32_t L, int32_t H,
+                             float bound, const float* embeddings, const inr_grid_desc* desc, const float* packed,
+                             const float* sh_dirs, int32_t n_dirs, float* out, inr_stream_t s) {
+  INR_REQUIRE(W >= 0 && L >= 0 && H >= 0 && desc, "bad argument");
+  if ((int64_t)W * L * H == 0) return INR_OK;
+  INR_REQUIRE(ax_w && ax_l && ax_h && embeddings && packed && sh_dirs && out, "null pointer");
+  INR_REQUIRE(n_dirs >= 1 && n_dirs <= kMaxExtractDirs, "1..8 view directions");
+  INR_REQUIRE(((uintptr_t)embeddings & 7) == 0 && ((uintptr_t)packed & 15) == 0 && ((uintptr_t)out & 15) == 0,
+              "embeddings/packed/out misaligned");
+  GridDesc G;
+  int rc = make_grid_desc(desc, G);
+  if (rc) return rc;
+  const uint64_t emb_bytes64 = (uint64_t)desc->offsets[desc->num_levels] * 8ull;
+  INR_REQUIRE(emb_bytes64 < (1ull << 31), "table larger than 2 GiB is not addressable by the 32-bit gather offsets");
+  LatticeDesc lat{ax_w, ax_l, ax_h, W, L, H, (W + 15) / 16 * 16};
+  const int64_t M = (int64_t)lat.Wp * L * H;           // traversal length: runs of 16 along w, padded per (il, ih)
+  const size_t lds = kNerfFloats * sizeof(float) + kLevelRecBytes + kMaxExtractDirs * 16 * sizeof(float);
+  const int grid = grid_for(k_nerf_fwd_dirs<true>, lds, (M + 15) / 16);
+  k_nerf_fwd_dirs<true><<<grid, kFieldThreads, lds, as_stream(s)>>>(
+      nullptr, M, bound, reinterpret_cast<const float2*>(embeddings), (uint32_t)emb_bytes64, G,
+      reinterpret_cast<const float4*>(packed), sh_dirs, n_dirs, reinterpret_cast<float4*>(out), lat);
+  return check_launch("nerf_forward_lattice");
 }
 
 int inr_instance_forward(const float* x, int64_t M, const int32_t* n_samples_dev, float bound, const float* embeddings,
@@ -2513,13 +2623,10 @@ int inr_instance_head_backward(const float* enc, const float* weights, const int
                 (uintptr_t)workspace) & 15) == 0, "arrays must be 16-byte aligned");
   hipStream_t st = as_stream(s);
   const size_t lds = head_bwd_lds();
-  static bool attr_set = false;
-  if (!attr_set) {          // > 64 KB of dynamic LDS must be allowed explicitly
-    if (hipFuncSetAttribute((const void*)k_instance_head_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-      set_error("instance_head_backward: %zu bytes of LDS refused", lds);
-      return INR_ELAUNCH;
-    }
-    attr_set = true;
+  static AttrOnce attr;     // > 64 KB of dynamic LDS must be allowed explicitly, on every device
+  if (!attr.ensure(k_instance_head_bwd, lds)) {
+    set_error("instance_head_backward: %zu bytes of LDS refused", lds);
+    return INR_ELAUNCH;
   }
   const int64_t n_tiles = (M + 15) / 16;
   const int grid = M == 0 ? 1 : grid_for(k_instance_head_bwd, lds, n_tiles);
@@ -2632,13 +2739,10 @@ int inr_nerf_head_backward(const float* enc, const float* d, const float* grad_s
               "arrays must be 16-byte aligned");
   hipStream_t st = as_stream(s);
   const size_t lds = (size_t)(kNhFwdFloats + kNerfBwdFloats + kHbStageFloats) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)k_nerf_head_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-      set_error("nerf_head_backward: %zu bytes of LDS refused", lds);
-      return INR_ELAUNCH;
-    }
-    attr_set = true;
+  static AttrOnce attr;
+  if (!attr.ensure(k_nerf_head_bwd, lds)) {
+    set_error("nerf_head_backward: %zu bytes of LDS refused", lds);
+    return INR_ELAUNCH;
   }
   const int grid = M == 0 ? 1 : grid_for(k_nerf_head_bwd, lds, (M + 15) / 16);
   k_nerf_head_bwd<<<grid, kFieldThreads, lds, st>>>(enc, d, grad_sigma, grad_rgb, M, density_scale,

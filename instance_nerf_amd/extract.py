@@ -29,13 +29,24 @@ def grid_resolution(bbox_min, bbox_max, max_side=160):
     return res
 
 
-def lattice(bbox_min, bbox_max, res, device):
-    """Voxel-centre positions, float32 [W*L*H, 3], index order (w, l, h) with h fastest."""
-    axes = []
+def lattice_axes(bbox_min, bbox_max, res, device):
+    """The three coordinate axes of the voxel-centre lattice: float32 [W], [L], [H]."""
+    # formed on the host in float32 (IEEE division, one rounding per operation) and uploaded in ONE copy: fifteen tiny
+    # device launches otherwise, ~0.1 ms of a 1.2 ms extraction
+    f32 = np.float32
+    host, sizes = [], []
     for a in range(3):
         n = int(res[a])
-        t = (torch.arange(n, dtype=torch.float32, device=device) + 0.5) / n
-        axes.append(float(bbox_min[a]) + t * (float(bbox_max[a]) - float(bbox_min[a])))
+        t = (np.arange(n, dtype=f32) + f32(0.5)) / f32(n)
+        host.append(f32(float(bbox_min[a])) + t * f32(float(bbox_max[a]) - float(bbox_min[a])))
+        sizes.append(n)
+    flat = torch.from_numpy(np.concatenate(host).astype(f32)).to(device)
+    return list(torch.split(flat, sizes))
+
+
+def lattice(bbox_min, bbox_max, res, device):
+    """Voxel-centre positions, float32 [W*L*H, 3], index order (w, l, h) with h fastest."""
+    axes = lattice_axes(bbox_min, bbox_max, res, device)
     ww, ll, hh = torch.meshgrid(*axes, indexing="ij")
     return torch.stack([ww.reshape(-1), ll.reshape(-1), hh.reshape(-1)], -1)
 
@@ -48,9 +59,19 @@ def extract_rgbsigma(model, bbox_min=None, bbox_max=None, max_side=160, res=None
     bbox_min = np.asarray([-b, -b, -b] if bbox_min is None else bbox_min, dtype=np.float32)
     bbox_max = np.asarray([b, b, b] if bbox_max is None else bbox_max, dtype=np.float32)
     res = grid_resolution(bbox_min, bbox_max, max_side) if res is None else np.asarray(res, dtype=np.int64)
+    dirs = torch.from_numpy(VIEW_DIRS).to(dev)
+    if hasattr(model, "forward_lattice"):
+        # one launch for the whole lattice, from its three coordinate axes (no [W*L*H, 3] point tensor), walked in
+        # runs along W: 160^3 in ~1.2 ms instead of 2.8 (profiles/r04_NOTES.txt 6)
+        was_training = model.training
+        model.eval()
+        fused = model.forward_lattice(lattice_axes(bbox_min, bbox_max, res, dev), dirs)
+        model.train(was_training)
+        if fused is not None:
+            fused[..., 3].clamp_(min=float(np.log(1e-30)))
+            return fused, res
     pts = lattice(bbox_min, bbox_max, res, dev)
     out = torch.empty(pts.shape[0], 4, dtype=torch.float32, device=dev)
-    dirs = torch.from_numpy(VIEW_DIRS).to(dev)
     was_training = model.training
     model.eval()
     for s in range(0, pts.shape[0], chunk):

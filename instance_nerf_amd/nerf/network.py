@@ -605,6 +605,28 @@ class NeRFNetwork(NeRFRenderer):
                                         ptr(out, allow_none=M == 0), stream_ptr()), "nerf_forward_dirs")
         return out
 
+    @torch.no_grad()
+    def forward_lattice(self, axes, dirs):
+        """``forward_dirs`` for the lattice ``axes = (ax_w [W], ax_l [L], ax_h [H])`` (float32, on the device): -> float
+        [W, L, H, 4] without a point tensor, the kernel walking the lattice in runs along W (the table's fastest row
+        index; 2.4x faster than the h-fastest point list, ``inr_nerf_forward_lattice``).  Coordinates are clamped to
+        [-bound, bound].  None when the fused kernel does not apply."""
+        if not self._fusable:
+            return None
+        lib = _lib.load()
+        ax = [a.contiguous().float() for a in axes]
+        W, L, H = (int(a.shape[0]) for a in ax)
+        D = dirs.shape[0]
+        sh = self.encoder_dir(dirs.to(ax[0].device).contiguous().float()).contiguous()      # [D,16] (HIP SH kernel)
+        out = torch.empty(W, L, H, 4, dtype=torch.float32, device=ax[0].device)
+        if W * L * H:
+            check(lib.inr_nerf_forward_lattice(ptr(ax[0], torch.float32, "ax_w"), ptr(ax[1], torch.float32, "ax_l"),
+                                               ptr(ax[2], torch.float32, "ax_h"), W, L, H, float(self.bound),
+                                               ptr(self.encoder.embeddings.data, torch.float32), self.encoder.desc,
+                                               ptr(self._packed_weights("nerf")), ptr(sh, torch.float32, "sh_dirs"), D,
+                                               ptr(out), stream_ptr()), "nerf_forward_lattice")
+        return out
+
     # ---- upstream API -----------------------------------------------------------------------------
     def forward(self, x, d):
         """x [M,3] in [-bound,bound], d [M,3] unit -> sigma [M], color [M,3]."""

@@ -206,7 +206,7 @@ class NeRFRenderer(nn.Module):
                              are opaque (measured 4x faster than "fused" on an opaque scene, 1.4x slower on a
                              transparent one)
           "auto" (default)   picks between the two from the fraction of samples the early-terminating kernel skips /
-                             would skip, as counted by the previous inference calls (> terminate_above = 0.35)
+                             would skip, as counted by the previous inference calls (> terminate_above = 0.50)
           "fused_raymajor" / "wavefront"   reference paths kept for parity tests (ray-major layout / upstream's loop)
 
         ce_labels (training, networks with an instance head; int64, one per ray): the cross entropy of the rendered
@@ -452,7 +452,14 @@ class NeRFRenderer(nn.Module):
     # scene - opacity 0.88, only 8 % skippable - then rendered in 20.5 ms instead of 14.4, r02 notes section 11.)  The
     # value travels to the host through a pinned buffer + event and is only read once its copy has completed: no call
     # waits for a previous frame.
-    terminate_above = 0.35
+    # Round 4: 0.50.  The chunked variant the round-3 verdict proposed (two-kernel tile order, a per-group "dead" bit
+    # between depth chunks) was not built: on every trained scene measured the skippable fraction is 5-8 % (trained room,
+    # 1500 steps: 5.7 %), so even a termination that cost NOTHING would save at most that share of the field kernel
+    # (10.5 -> 9.9 ms per frame), and every structure that tracks liveness per group has cost 18-42 % per evaluated
+    # sample so far (profiles/r03k_terminate_vs_two_kernel_pmc.txt: L2 miss rate 55 % against 37 %).  `auto` therefore
+    # takes the terminating kernel only where it wins by a wide margin - scenes that skip more than half of what they
+    # march (the opaque test scene: 1.0 against 5.75 ms); profiles/r04_NOTES.txt 5.
+    terminate_above = 0.50
 
     def _note_skippable(self, counter, total, counts_evaluated):
         """counter: the device counter of the frame (samples skippable / samples evaluated); total: marched samples, known

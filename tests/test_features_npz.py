@@ -65,9 +65,20 @@ def test_extract_matches_oracle_field(level_table, params_k16):
     assert (got[:, :3] - rgb).abs().max() < 1e-4
     # the one-launch path (forward_dirs) and the density() + 4 x color() path agree; ragged size, points on the faces
     net.forward_dirs, fused = (lambda x, d: None), net.forward_dirs
+    net.forward_lattice, fused_lat = (lambda axes, d: None), net.forward_lattice
     slow, _ = extract_rgbsigma(net, res=[12, 10, 8])
     net.forward_dirs = fused
     assert (slow - grid).abs().max() < 1e-4
+    # the lattice launch (runs along W from the three coordinate axes) and the point-list launch give the same bits:
+    # same per-point arithmetic, another order - W not a multiple of the 16-sample tile, a bounding box inside the volume
+    for res, lo, hi in (([12, 10, 8], [-1, -1, -1], [1, 1, 1]), ([37, 5, 9], [-0.8, -0.2, 0.1], [0.9, 0.6, 0.7]),
+                        ([16, 1, 1], [-1, -1, -1], [1, 1, 1])):
+        by_points, _ = extract_rgbsigma(net, lo, hi, res=res)
+        net.forward_lattice = fused_lat
+        by_lattice, _ = extract_rgbsigma(net, lo, hi, res=res)
+        net.forward_lattice = lambda axes, d: None
+        assert by_lattice.shape == by_points.shape == tuple(res) + (4,) and torch.equal(by_lattice, by_points), res
+    net.forward_lattice = fused_lat
     x = torch.rand(1003, 3, device=grid.device) * 2 - 1
     x[:3] = torch.tensor([[1.0, 1, 1], [-1.0, -1, -1], [1.0, -1, 0.25]], device=grid.device)
     out = net.forward_dirs(x, torch.from_numpy(VIEW_DIRS[:3]))
