@@ -21,7 +21,7 @@ NO_UPDATE=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d 
   > $O/train_nerf_probe.txt 2>&1
 cd $R
 bash tools/pmc_bench.sh ${TAG}_pmc > $O/pmc_bench.txt 2>&1
-python tools/traffic_json.py gpurun_out/${TAG}_pmc gpurun_out/${TAG}_pmc.hbm_rd.log $O/r03_traffic.json; echo "traffic rc=$?"
+python tools/traffic_json.py gpurun_out/${TAG}_pmc gpurun_out/${TAG}_pmc.hbm_rd.log $O/r04_traffic.json; echo "traffic rc=$?"
 bash tools/pmc_train.sh ${TAG}_pmct > $O/pmc_train.txt 2>&1; tail -25 $O/pmc_train.txt
 python tools/timed_launches.py $O/trace $O/bench_profiled.json > $O/bench_timed_launches.txt 2>&1
 python tools/step_launches.py $O/trace_inst > $O/launches_inst.txt 2>&1
@@ -29,4 +29,24 @@ python tools/step_launches.py $O/trace_nerf > $O/launches_nerf.txt 2>&1
 ls $O
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; tail -1 $O/smoke.txt
 NO_UPDATE=1 bash tools/pmc_train.sh ${TAG}_pmcn k_grid_bwd tools/train_nerf_probe.py > $O/pmc_train_nerf.txt 2>&1
-python tools/scatter_requests_json.py gpurun_out/${TAG}_pmct 207610 gpurun_out/${TAG}_pmcn 207610 $O/r03_scatter_requests.json > /dev/null; echo "scatter json rc=$?"
+# samples per step of the two probes' timed steps: their last output line ("train step ... ms, N samples/step, ...")
+NI=$(grep -o "[0-9]* samples/step" gpurun_out/${TAG}_pmct.atom2.log | tail -1 | cut -d" " -f1)
+NN=$(grep -o "[0-9]* samples/step" gpurun_out/${TAG}_pmcn.atom2.log | tail -1 | cut -d" " -f1)
+python tools/scatter_requests_json.py gpurun_out/${TAG}_pmct ${NI:-209000} gpurun_out/${TAG}_pmcn ${NN:-209000} $O/r04_scatter_requests.json > /dev/null; echo "scatter json rc=$? ($NI / $NN samples per step)"
+# round 4: timelines of the instance step (eager, captured two-stream pipeline with and without the shaded head)
+export TMPDIR=/tmp
+cd /tmp
+for m in eager pipe pipe_shade; do
+  case $m in eager) E="EMA=1";; pipe) E="PIPE=1 SHADE=0";; pipe_shade) E="PIPE=1 SHADE=1";; esac
+  env $E timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/trace_$m -o t -- python3 $R/tools/train_probe.py 40 > $O/train_probe_$m.txt 2>&1
+done
+cd $R
+for m in eager pipe pipe_shade; do python tools/step_timeline.py $O/trace_$m k_instance_fwd 2 > $O/timeline_$m.txt 2>&1; tail -1 $O/timeline_$m.txt; done
+for m in "EMA=1" "USE_GRAPH=1" "PIPE=1 SHADE=0" "PIPE=1 SHADE=1" "EMA=1" "PIPE=1 SHADE=1"; do echo "== $m: $(env $m python tools/train_probe.py 300 2>&1 | tail -1)"; done > $O/train_probe_modes.txt 2>&1
+# round 4: RoIAlign-3D (PMC of the separable forward, launch-parameter sweep, both implementations) and the extraction
+bash tools/pmc_roialign.sh ${TAG}_pmcr > /dev/null 2>&1
+python tools/pmc_summary.py gpurun_out/${TAG}_pmcr sep_fwd > $O/roialign_pmc.txt 2>&1
+./tools/micro/roialign_bench > $O/roialign_sweep.txt 2>&1
+python tools/roialign_probe.py > $O/roialign_probe.txt 2>&1
+python tools/extract_order_probe.py > $O/extract_order_probe.txt 2>&1
+python -m pytest tests/test_train_twin.py -m gpu -q -s 2>&1 | grep -E "held-out|passed|failed" > $O/train_twin.txt
