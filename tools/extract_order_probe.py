@@ -46,6 +46,18 @@ print(f"4x2x2 bricks:                       {timed(bricks(pts, 4, 2, 2), dirs):.
 print(f"8x8x8 bricks of 4x4x1:              {timed(bricks(pts, 8, 8, 8), dirs):.3f} ms")
 print(f"h fastest, 1 dir:                   {timed(pts, dirs[:1]):.3f} ms")
 print(f"4x4x1 bricks, 1 dir:                {timed(bricks(pts, 4, 4, 1), dirs[:1]):.3f} ms")
+from instance_nerf_amd.extract import lattice_axes               # noqa: E402
+axes = lattice_axes([-1, -1, -1], [1, 1, 1], res, dev)
+for nd in (4, 1):
+    net.forward_lattice(axes, dirs[:nd])
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        net.forward_lattice(axes, dirs[:nd])
+    e1.record()
+    torch.cuda.synchronize()
+    print(f"lattice launch (runs along w, from the axes), {nd} dir(s): {e0.elapsed_time(e1) / 10:.3f} ms")
 with torch.no_grad():
     x = pts.reshape(-1, 3).contiguous()
     d = dirs[:1].expand(x.shape[0], 3).contiguous()
