@@ -89,6 +89,19 @@ def test_trainer_surface():
     m = utils.PSNRMeter()
     m.update(torch.zeros(4, 3), torch.full((4, 3), 0.1))
     assert abs(m.measure() - 20.0) < 1e-4 and "PSNR" in m.report()
+    # mIoU runs over the ids present in the TRUTH (ignore label -1 dropped); a few stray pixels of an id that is not in
+    # the view at all are not a class with IoU 0 (rounds 1-3 counted them: measure(all_predicted=True))
+    truth = torch.tensor([0, 0, 0, 0, 1, 1, 1, 1, -1, -1])
+    pred = torch.tensor([0, 0, 0, 5, 1, 1, 1, 0, 3, 3])
+    mi = utils.MIoUMeter(8)
+    mi.update(pred, truth)
+    assert abs(mi.measure() - (3 / 5 + 3 / 4) / 2) < 1e-9
+    assert abs(mi.measure(all_predicted=True) - (3 / 5 + 3 / 4 + 0.0) / 3) < 1e-9 and "mIoU" in mi.report()
+    # copy_tensors: one fused launch for GPU tensors, plain copies otherwise (CPU tensors here)
+    a, b = torch.zeros(5), torch.arange(5.0)
+    c, d = torch.zeros(3, dtype=torch.int64), torch.tensor([4, 5, 6])
+    utils.copy_tensors([(a, b), (c, d)])
+    assert torch.equal(a, b) and torch.equal(c, d)
 
 
 def test_fused_adam_state_dict_is_the_torch_adam_layout():
