@@ -1122,8 +1122,15 @@ class Trainer:
     # (the grid changed), the last one before an update does not look ahead.
     def _pipe_applies(self, data):
         m = self.model
-        return (self.use_graph and self.look_ahead and m.cuda_ray and m.mean_count > 0 and data["rays_o"].is_cuda
-                and hasattr(m, "march_ahead"))
+        if not (self.use_graph and self.look_ahead and m.cuda_ray and m.mean_count > 0 and data["rays_o"].is_cuda
+                and hasattr(m, "march_ahead")):
+            return False
+        # the persistent buffer sets need the staged wave-per-ray marcher (batches up to 8192 rays, max_steps <= 1024,
+        # march mode not forced to lane-per-ray): other batches take the one-stream captured step
+        from .. import raymarching
+        kw = self._render_kwargs()
+        return bool(_lib.load().inr_march_write_fills_unowned_rows(data["rays_o"].numel() // 3, raymarching.SAMPLE_CAP_TRAIN,
+                                                                    int(kw.get("max_steps", 1024))))
 
     def _pipe_args(self):
         kw = self._render_kwargs()
@@ -1163,6 +1170,20 @@ class Trainer:
         step0 = m.local_step
         side = P["side"]
         g = torch.cuda.CUDAGraph()
+        try:
+            self._pipe_capture_body(g, S, Nx, side, prime, ahead, args)
+        finally:
+            _network._before_scatter.pop("hook", None)       # a failed capture must not leave its fork for an eager backward
+            self._ahead = None
+            m.local_step = step0                # the capture pass launched nothing; undo its bookkeeping
+        G = {"graph": g, "loss": self._pipe_loss}
+        P["graphs"][(turn, prime, ahead)] = G
+        return G
+
+    def _pipe_capture_body(self, g, S, Nx, side, prime, ahead, args):
+        from . import network as _network
+        from .. import raymarching
+        m = self.model
         with torch.cuda.graph(g):
             if prime:
                 S["marched"] = m.march_ahead(S["static"]["rays_o"], S["static"]["rays_d"], stream=None, bufs=S["bufs"],
@@ -1189,10 +1210,7 @@ class Trainer:
             self.optimizer.step_captured()
             if ahead:
                 torch.cuda.current_stream().wait_stream(side)        # join: the graph ends with both branches done
-        m.local_step = step0                    # the capture pass launched nothing; undo its bookkeeping
-        G = {"graph": g, "loss": loss}
-        P["graphs"][(turn, prime, ahead)] = G
-        return G
+        self._pipe_loss = loss
 
     def _pipe_step(self, data, next_data):
         m = self.model
@@ -1474,6 +1492,7 @@ class Trainer:
         Upstream semantics: a file without a 'model' key is a bare model state dict; missing / unexpected keys are
         reported, not fatal; a failing optimizer / scheduler / EMA restore only warns (e.g. an Adam state saved for a
         different set of trained parameters)."""
+        self._pipe = self._graph = None          # captured steps hold buffers sized and primed for the old state
         import glob
         import warnings
         if checkpoint is None:
