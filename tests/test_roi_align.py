@@ -146,3 +146,39 @@ def test_roi_align_channel_tails_and_batches():
                 assert np.abs(out.cpu().numpy() - ref).max() < 1e-5, (C, shape, mode)
     finally:
         _set_mode(0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", list(range(8)))
+def test_roi_align_fuzz_against_the_oracle(seed):
+    """Random volumes (4..11 cells a side, 1..9 channels, 1..3 volumes), output sizes 1..14 a side (all three
+    accumulator widths of the separable forward), scales, and boxes of every kind - inside, straddling a face, larger
+    than the volume (sampling grids > 2: the table path behind the four register taps), thinner than a voxel, outside:
+    both HIP implementations against the oracle, and the backward as the forward's transpose."""
+    from instance_nerf_amd.roi_align.roi_align import roi_align_3d
+    rng = np.random.default_rng(1000 + seed)
+    N, C = int(rng.integers(1, 4)), int(rng.integers(1, 10))
+    shape = tuple(int(v) for v in rng.integers(4, 12, 3))
+    osz = tuple(int(v) for v in rng.integers(1, 15, 3)) if seed % 2 else tuple(int(v) for v in rng.integers(1, 6, 3))
+    scale = float(rng.choice([1.0, 0.5, 0.25, 0.7]))
+    K = 6
+    lo = rng.uniform(-3, max(shape), size=(K, 3)) / scale
+    ext = np.stack([rng.uniform(0.05, 3.0 * max(shape), 3) if k % 3 == 0 else rng.uniform(0.3, 6, 3) for k in range(K)]) / scale
+    rois = np.concatenate([lo, lo + ext], 1).astype(np.float32)
+    rois[-1] = np.asarray([500, 500, 500, 520, 510, 530], np.float32)               # outside
+    inds = rng.integers(0, N, K).astype(np.int32)
+    vol = rng.normal(size=(N, C) + shape).astype(np.float32)
+    ref = roialign.roi_align_3d(vol, rois, inds, *osz, scale)
+    g = torch.randn(ref.shape, device="cuda", generator=torch.Generator(device="cuda").manual_seed(seed))
+    try:
+        for mode in (2, 1):
+            _set_mode(mode)
+            x = torch.tensor(vol, device="cuda", requires_grad=True)
+            out = roi_align_3d(x, torch.tensor(rois, device="cuda"), torch.tensor(inds, device="cuda"), *osz, scale)
+            assert np.abs(out.detach().cpu().numpy() - ref).max() < 2e-5, (mode, N, C, shape, osz, scale)
+            out.backward(g)
+            lhs = (out.detach().double() * g.double()).sum().item()
+            rhs = (x.detach().double() * x.grad.double()).sum().item()
+            assert abs(lhs - rhs) < 1e-4 * max(1.0, abs(lhs)), (mode, lhs, rhs)
+    finally:
+        _set_mode(0)
