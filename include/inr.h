@@ -178,6 +178,16 @@ int inr_composite_rays_patch_forward(const float* sigmas, const float* rgbs, con
                                      uint64_t* skippable /*device, nullable: += samples of steps at which a whole
                                      16-ray group is already below T_thresh - what inr_nerf_render would skip*/,
                                      inr_stream_t s);
+/* No upstream counterpart in the submodule's extension; the counterpart of the reference pipeline's project_3d_masks step
+ * (voxel masks of nerf_rcnn/run_rcnn.py:652-666 projected into the training images that
+ * Mask2Former_sample/match_seg.py:99-102 reads).  For the samples of a patch-interleaved frame (inr_march_rays_patch_write)
+ * and their compositing weights (inr_composite_rays_patch_forward, weights != NULL): out[ray][k_base + i] =
+ * sum over the ray's samples of w * bit_i(mask_words[cell(x)]), i < k_count <= 32; mask_words uint32 [W,L,H], bit i = mask
+ * k_base + i contains the voxel; cell = floor((x - lo) / (hi - lo) * (W,L,H)), samples outside the box contribute nothing;
+ * bbox: HOST array lo[3], hi[3]; out float [N, k_total].                                                               */
+int inr_project_masks_patch(const float* xyzs, const float* weights, const int32_t* rays, int64_t N, int64_t M,
+                            const uint32_t* mask_words, int32_t W, int32_t L, int32_t H, const float* bbox /*host*/,
+                            int32_t k_total, int32_t k_base, int32_t k_count, float* out, inr_stream_t s);
 
 /* ---- inference march/composite (replace raymarching.march_rays / composite_rays, a5) */
 int inr_march_rays(int64_t n_alive, int32_t n_step, const int32_t* rays_alive, const float* rays_t,

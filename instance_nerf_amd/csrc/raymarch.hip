@@ -1615,6 +1615,66 @@ __global__ void __launch_bounds__(kRayBlock) k_composite_patch_extra(const float
   if (lane < K) extra_out[(int64_t)rid * K + lane] = acc;
 }
 
+// NeRF-weighted projection of up to 32 voxel masks along the rays of a patch-interleaved frame (the
+// counterpart of the reference pipeline's project_3d_masks step): out[ray][i] = sum_k w[slot(ray,k)] * bit_i(cell(x)).
+// The masks arrive as ONE 32-bit word per voxel (bit i = mask i contains the voxel), so a sample costs one 4-byte load
+// whatever the number of masks - the tensor-op version gathered a [k, M] float matrix (3.8 GB for a 800x800 frame and
+// 30 masks) and composited it as K extra channels.  One lane per ray, the 16 lanes of a group walk k in lockstep (the
+// slot ranks of k_composite_patch_fwd); the cell is formed with the operations of the tensor-op version, in its order:
+// floor(((x - lo) / (hi - lo)) * res), outside -> no mask.  Same sums in the same order: bit-identical results.
+struct MaskVolume {
+  float lo[3], hi[3], res[3];
+  int W, L, H;
+};
+__global__ void __launch_bounds__(kRayBlock) k_project_masks_patch(const float* __restrict__ xyzs,
+                                                                   const float* __restrict__ wbuf,
+                                                                   const int32_t* __restrict__ rays, int64_t N, int64_t M,
+                                                                   const uint32_t* __restrict__ words, MaskVolume V,
+                                                                   int k_total, int k_base, int k_count,
+                                                                   float* __restrict__ out) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63, g0 = lane & ~(kGroup - 1), rr = lane & (kGroup - 1);
+  const int32_t rid = n < N ? rays[n * 3] : 0;
+  const int off = n < N ? rays[n * 3 + 1] : 0;
+  int cnt = n < N ? rays[n * 3 + 2] : 0;
+  int S = __shfl(off, g0, 64);
+  int gtot = cnt;
+#pragma unroll
+  for (int d = 1; d < kGroup; d <<= 1) gtot += __shfl_xor(gtot, d, 64);
+  if ((int64_t)S + gtot > M) cnt = 0;                      // group was dropped by the writer
+  int maxc = cnt;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) maxc = max(maxc, __shfl_xor(maxc, d, 64));
+  float acc[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) acc[i] = 0.0f;
+  for (int k = 0; k < maxc; ++k) {
+    const bool active = k < cnt;
+    const unsigned field = (unsigned)(__ballot(active) >> g0) & 0xFFFFu;
+    const int64_t slot = (int64_t)S + __popc(field & ((1u << rr) - 1u));
+    S += __popc(field);
+    const float w = active ? wbuf[slot] : 0.0f;
+    if (w != 0.0f) {                                       // (behind a ray's termination point the weights are zero)
+      const float x = xyzs[slot * 3], y = xyzs[slot * 3 + 1], z = xyzs[slot * 3 + 2];
+      const float fx = floorf(((x - V.lo[0]) / (V.hi[0] - V.lo[0])) * V.res[0]);
+      const float fy = floorf(((y - V.lo[1]) / (V.hi[1] - V.lo[1])) * V.res[1]);
+      const float fz = floorf(((z - V.lo[2]) / (V.hi[2] - V.lo[2])) * V.res[2]);
+      const bool inside = fx >= 0.0f && fx < V.res[0] && fy >= 0.0f && fy < V.res[1] && fz >= 0.0f && fz < V.res[2];
+      if (inside) {
+        const uint32_t word = words[((int64_t)(int)fx * V.L + (int)fy) * V.H + (int)fz];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) acc[i] += ((word >> i) & 1u) ? w : 0.0f;
+      }
+    }
+  }
+  if (n < N) {
+    float* dst = out + (int64_t)rid * k_total + k_base;
+#pragma unroll
+    for (int i = 0; i < 32; ++i)
+      if (i < k_count) dst[i] = acc[i];
+  }
+}
+
 static MarchParams make_params(const uint8_t* bits, float bound, float dt_gamma, int max_steps, int C, int H) {
   MarchParams P;
   P.bits = bits;
@@ -1929,6 +1989,23 @@ int inr_composite_rays_patch_forward(const float* sigmas, const float* rgbs, con
     k_composite_patch_extra<<<blocks_for(N * 64, kRayBlock), kRayBlock, 0, st>>>(weights, extra, rays, N, M, K,
                                                                                  extra_out);
   return check_launch("composite_rays_patch_forward");
+}
+
+int inr_project_masks_patch(const float* xyzs, const float* weights, const int32_t* rays, int64_t N, int64_t M,
+                            const uint32_t* mask_words, int32_t W, int32_t L, int32_t H, const float* bbox /*host: lo[3], hi[3]*/,
+                            int32_t k_total, int32_t k_base, int32_t k_count, float* out, inr_stream_t s) {
+  INR_REQUIRE(N >= 0 && M >= 0 && W > 0 && L > 0 && H > 0, "bad sizes");
+  INR_REQUIRE(k_total > 0 && k_base >= 0 && k_count > 0 && k_count <= 32 && k_base + k_count <= k_total, "bad mask range");
+  if (N == 0) return INR_OK;
+  INR_REQUIRE(rays && mask_words && bbox && out, "null pointer");
+  INR_REQUIRE(M == 0 || (xyzs && weights), "null sample arrays");
+  MaskVolume V;
+  for (int a = 0; a < 3; ++a) { V.lo[a] = bbox[a]; V.hi[a] = bbox[3 + a]; }
+  V.res[0] = (float)W; V.res[1] = (float)L; V.res[2] = (float)H;
+  V.W = W; V.L = L; V.H = H;
+  k_project_masks_patch<<<blocks_for(N, kRayBlock), kRayBlock, 0, as_stream(s)>>>(xyzs, weights, rays, N, M, mask_words, V,
+                                                                                 k_total, k_base, k_count, out);
+  return check_launch("project_masks_patch");
 }
 
 int inr_march_rays(int64_t n_alive, int32_t n_step, const int32_t* rays_alive, const float* rays_t,

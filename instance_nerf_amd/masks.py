@@ -101,27 +101,57 @@ def load_3d_masks(path):
             "boxes": boxes.astype(np.float32)}
 
 
+def pack_mask_words(masks, device):
+    """bool [k, W, L, H] -> list of int32 tensors [W, L, H], one per 32 masks: bit i of word j = mask 32 j + i contains
+    the voxel (the layout ``inr_project_masks_patch`` reads; int32 is the storage type, the kernel reads uint32)."""
+    m = torch.as_tensor(masks).to(device).bool()
+    out = []
+    for base in range(0, m.shape[0], 32):
+        chunk = m[base:base + 32].to(torch.int64)
+        shifts = torch.arange(chunk.shape[0], device=device, dtype=torch.int64).view(-1, 1, 1, 1)
+        w = (chunk << shifts).sum(0)
+        w = torch.where(w >= 2 ** 31, w - 2 ** 32, w)                 # the same 32 bits as a signed value
+        out.append(w.to(torch.int32).contiguous())
+    return out
+
+
 @torch.no_grad()
-def soft_project(model, masks, bbox_min, bbox_max, rays_o, rays_d, T_thresh=1e-4, dt_gamma=0, max_steps=1024):
-    """NeRF-weighted projection of k voxel masks along rays.  masks [k, W, L, H]; rays [N, 3].
-    -> (soft [N, k] = sum_s w_s * mask(x_s), weights_sum [N])."""
+def soft_project(model, masks, bbox_min, bbox_max, rays_o, rays_d, T_thresh=1e-4, dt_gamma=0, max_steps=1024, packed=None):
+    """NeRF-weighted projection of k voxel masks along rays.  masks [k, W, L, H] (boolean: non-zero = inside, as
+    ``run_rcnn.py:652-666`` writes them); rays [N, 3].  -> (soft [N, k] = sum_s w_s * mask(x_s), weights_sum [N]).
+    ``packed``: ``(k, pack_mask_words(masks, device))`` from an earlier call (a caller projecting many views packs once).
+
+    March (patch-interleaved frame layout) -> field -> compositing with the per-sample weights kept -> ONE launch per
+    32 masks that walks every ray's samples, looks the sample's voxel up in a 32-bit word per voxel and adds the weight
+    to the accumulators of the masks whose bit is set (``inr_project_masks_patch``; round 4 - until then the mask values
+    of all samples were gathered into a float [M, k] matrix, 3.8 GB for an 800x800 frame and 30 masks, and composited as
+    k extra channels: same sums in the same order, bit-identical)."""
+    from . import _lib
+    from ._lib import check, ptr, stream_ptr
     dev = rays_o.device
-    masks = torch.as_tensor(masks).to(dev).float()
-    k = masks.shape[0]
-    res = torch.tensor(masks.shape[1:], device=dev, dtype=torch.float32)
-    lo = torch.as_tensor(np.asarray(bbox_min, dtype=np.float32)).to(dev)
-    hi = torch.as_tensor(np.asarray(bbox_max, dtype=np.float32)).to(dev)
+    k, words = packed if packed is not None else (len(masks), pack_mask_words(masks, dev))
+    if k == 0:
+        raise ValueError("soft_project: no masks")
+    W, L, H = (int(v) for v in words[0].shape)
+    bbox = torch.tensor([float(v) for v in np.asarray(bbox_min, dtype=np.float32)] +
+                        [float(v) for v in np.asarray(bbox_max, dtype=np.float32)], dtype=torch.float32)
     nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, model.aabb_infer, model.min_near)
     xyzs, dirs, deltas, rays = raymarching.march_rays_patch(rays_o, rays_d, model.bound, model.density_bitfield,
                                                            model.cascade, model.grid_size, nears, fars, dt_gamma, max_steps)
     sigmas, rgbs = model(xyzs, dirs)
     sigmas = sigmas * model.density_scale
-    cell = ((xyzs - lo) / (hi - lo) * res).floor().long()
-    inside = ((cell >= 0) & (cell < res.long())).all(-1)
-    cell = cell.clamp(min=0)
-    cell = torch.minimum(cell, res.long() - 1)
-    vals = masks[:, cell[:, 0], cell[:, 1], cell[:, 2]].t().contiguous() * inside[:, None]     # [M, k]
-    ws, _, _, soft = raymarching.composite_rays_patch(sigmas, rgbs, deltas, rays, T_thresh, extra=vals)
+    ws, _, _, wbuf = raymarching.composite_rays_patch(sigmas, rgbs, deltas, rays, T_thresh, return_weights=True)
+    N, M = rays.shape[0], xyzs.shape[0]
+    soft = torch.empty(N, k, dtype=torch.float32, device=dev)
+    lib = _lib.load()
+    for j, wj in enumerate(words):
+        base = 32 * j
+        check(lib.inr_project_masks_patch(ptr(xyzs, torch.float32, "xyzs", allow_none=M == 0),
+                                          ptr(wbuf, torch.float32, "weights", allow_none=M == 0),
+                                          ptr(rays, torch.int32, "rays", allow_none=N == 0), N, M,
+                                          ptr(wj, torch.int32, "mask_words"), W, L, H,
+                                          _lib.host_ptr(bbox, torch.float32, "bbox"), k, base, min(32, k - base),
+                                          ptr(soft, allow_none=N == 0), stream_ptr()), "project_masks_patch")
     return soft, ws
 
 
@@ -136,9 +166,10 @@ def project_3d_masks(model, masks, bbox_min, bbox_max, poses, intrinsics, H, W, 
     out = np.zeros((poses.shape[0], k, H, W), dtype=bool)
     was_training = model.training
     model.eval()
+    packed = (k, pack_mask_words(masks, dev))          # one 32-bit word per voxel and 32 masks, built once for all views
     for v in range(poses.shape[0]):
         r = get_rays(poses[v:v + 1], intrinsics, H, W, patch=4 if (H % 4 == 0 and W % 4 == 0) else 0)
-        soft, _ = soft_project(model, masks, bbox_min, bbox_max, r["rays_o"][0], r["rays_d"][0])
+        soft, _ = soft_project(model, None, bbox_min, bbox_max, r["rays_o"][0], r["rays_d"][0], packed=packed)
         flat = torch.zeros(H * W, k, device=dev)
         flat[r["inds"][0]] = soft
         out[v] = (flat > thresh).t().reshape(k, H, W).cpu().numpy()

@@ -48,6 +48,31 @@ def test_projector_matches_oracle(tmp_path, room, room_bitfield, level_table, pa
     vals = masks[:, cell[:, 0], cell[:, 1], cell[:, 2]].T
     ref = composite.composite_rays_train(sig, rgb, m["deltas"], m["rays"], 1e-4, extra=vals)
     assert np.abs(soft.cpu().numpy() - ref["extra"].numpy()).max() < 1e-4
+    # the launch that reads one 32-bit word per voxel (round 4) against the tensor-op version it replaced - a float
+    # [M, k] matrix of mask values composited as k extra channels: the same sums in the same order, bit for bit; with
+    # 40 masks (two words per voxel), a bounding box inside the volume and rays that leave it
+    from instance_nerf_amd import raymarching
+    rng = np.random.default_rng(5)
+    many = rng.random((40, 7, 9, 11)) > 0.6
+    lo, hi = [-0.8, -0.9, -0.7], [0.9, 0.6, 0.8]
+    ro_t, rd_t = _t(ro), _t(rd)
+    soft40, ws40 = soft_project(net, many, lo, hi, ro_t, rd_t)
+    with torch.no_grad():
+        nears_t, fars_t = raymarching.near_far_from_aabb(ro_t, rd_t, net.aabb_infer, net.min_near)
+        xyzs, dirs, deltas, rays_t = raymarching.march_rays_patch(ro_t, rd_t, net.bound, net.density_bitfield, net.cascade,
+                                                                 net.grid_size, nears_t, fars_t, 0, 1024)
+        sigmas, rgbs = net(xyzs, dirs)
+        mt = torch.from_numpy(many).to(xyzs.device).float()
+        rs = torch.tensor(many.shape[1:], device=xyzs.device, dtype=torch.float32)
+        lo_t, hi_t = torch.tensor(lo, device=xyzs.device), torch.tensor(hi, device=xyzs.device)
+        cell = ((xyzs - lo_t) / (hi_t - lo_t) * rs).floor().long()
+        inside = ((cell >= 0) & (cell < rs.long())).all(-1)
+        cell = torch.minimum(cell.clamp(min=0), rs.long() - 1)
+        chunks = []
+        for b in range(0, 40, 20):           # the extra-channel compositing takes at most 64 channels
+            vals = mt[b:b + 20, cell[:, 0], cell[:, 1], cell[:, 2]].t().contiguous() * inside[:, None]
+            chunks.append(raymarching.composite_rays_patch(sigmas, rgbs, deltas, rays_t, 1e-4, extra=vals)[3])
+    assert torch.equal(soft40, torch.cat(chunks, 1)) and float(soft40.max()) > 0.05
     # file output contract: <img>_<inst>.png, ids from 1, channel 0 > 0 = foreground
     poses, intr, H, W = room.cameras(n=1, H=32, W=32, focal=16.0)
     out = project_3d_masks(net, masks, [-1, -1, -1], [1, 1, 1], poses, intr, 32, 32, proj_dir=str(tmp_path), thresh=0.02)
