@@ -380,7 +380,7 @@ def main():
             # all_reduce, so exceptions propagate (non-zero exit, the launcher tears the job down).  Two guards keep
             # the headline measurement when that happens: the line is put in a side file first, and a watchdog THREAD
             # on rank 0 (a blocked collective holds the main thread inside C++, where no signal handler runs) prints
-            # the line without the probe's numbers and exits if the probe has not finished after 5 minutes.
+            # the line without the probes' numbers and exits if they have not finished after 7 minutes.
             watchdog = None
             if rank == 0:
                 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
@@ -389,12 +389,12 @@ def main():
                 import threading
 
                 def bail():
-                    line["train_step"] = line["train_step_nerf"] = {"error": "training probe did not finish in 300 s"}
+                    line["train_step"] = line["train_step_nerf"] = {"error": "training probes did not finish in 420 s"}
                     print(json.dumps(line), flush=True)
                     # a hung collective is a FAILED run: non-zero, so that the launcher tears the other ranks down and
                     # the caller sees it (the headline is also in gpurun_out/bench_headline_n<N>.json)
                     os._exit(3)
-                watchdog = threading.Timer(300.0, bail)
+                watchdog = threading.Timer(420.0, bail)      # three probes (two stages + the other gradient schedule)
                 watchdog.daemon = True
                 watchdog.start()
             try:
