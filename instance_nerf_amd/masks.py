@@ -23,17 +23,29 @@ from .nerf.utils import get_rays
 
 
 # ---------------------------------------------------------------------------------------- f3
+HDF5_DATASET = "cp_instance_id_segmaps"       # match_seg.py:142-143
+
+
 def load_matched_masks(seg_dir, names=None):
-    """-> dict {image name: int32 [H, W]} from ``<seg_dir>/<name>.npy``."""
-    files = sorted(f for f in os.listdir(seg_dir) if f.endswith(".npy"))
+    """-> dict {image name: int32 [H, W]} from ``<seg_dir>/<name>.npy`` (match_seg.py:140) and, for images that only
+    have it, from the ``<name>.hdf5`` mirror the reference writes beside it (match_seg.py:142-143: dataset
+    ``cp_instance_id_segmaps``; read without h5py by ``hdf5_lite``).  When both exist the ``.npy`` file is read."""
+    from . import hdf5_lite
+    listing = sorted(os.listdir(seg_dir))
+    stems = {f[:-4]: f for f in listing if f.endswith(".npy")}
+    for f in listing:
+        if f.endswith(".hdf5") and f[:-5] not in stems:
+            stems[f[:-5]] = f
     if names is not None:
-        files = [f for f in files if f[:-4] in set(names)]
+        stems = {k: v for k, v in stems.items() if k in set(names)}
     out = {}
-    for f in files:
-        m = np.load(os.path.join(seg_dir, f))
+    for stem in sorted(stems):
+        f = stems[stem]
+        path = os.path.join(seg_dir, f)
+        m = np.load(path) if f.endswith(".npy") else hdf5_lite.read_dataset(path, HDF5_DATASET)
         if m.ndim != 2:
             raise ValueError(f"{f}: expected an [H, W] instance-id map, got shape {m.shape}")
-        out[f[:-4]] = m.astype(np.int32)
+        out[stem] = m.astype(np.int32)
     return out
 
 
