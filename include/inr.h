@@ -409,11 +409,12 @@ int inr_nerf_forward_dirs(const float* x, int64_t M, float bound, const float* e
 /* The same for a [W, L, H] lattice given by its coordinate axes (x = ax_w[iw], y = ax_l[il], z = ax_h[ih], clamped to
  * [-bound, bound]; the rgb-sigma extraction of SURVEY f1 / BASELINE configs[4]): no point tensor, and the kernel walks the
  * lattice in runs of 16 along W - the table's fastest row index - instead of the writer's h-fastest order (2.4x faster:
- * the kernel is gather-bound).  out float [W, L, H, 4], 16-byte aligned.                                               */
+ * the kernel is gather-bound).  logit_min: lower clamp of the density logit (channel 3; the writer uses log(1e-30),
+ * -INFINITY for none).  out float [W, L, H, 4], 16-byte aligned.                                                        */
 int inr_nerf_forward_lattice(const float* ax_w, const float* ax_l, const float* ax_h, int32_t W, int32_t L, int32_t H,
                              float bound, const float* embeddings, const inr_grid_desc* desc /*host*/,
-                             const float* packed /*device*/, const float* sh_dirs, int32_t n_dirs, float* out,
-                             inr_stream_t s);
+                             const float* packed /*device*/, const float* sh_dirs, int32_t n_dirs, float logit_min,
+                             float* out, inr_stream_t s);
 int inr_instance_forward(const float* x, int64_t M, const int32_t* n_samples_dev, float bound,
                          const float* embeddings, const inr_grid_desc* desc /*host*/,
                          const float* packed /*device*/, int32_t K, float* logits /*[M,K]*/,

@@ -104,7 +104,7 @@ _SIGS = {
     "inr_nerf_forward_fast": (c_int32, [P, P, c_int64, P, c_float, P, POINTER(GridDesc), P, c_float, P, P, P]),
     "inr_nerf_forward_dirs": (c_int32, [P, c_int64, c_float, P, POINTER(GridDesc), P, P, c_int32, P, P]),
     "inr_nerf_forward_lattice": (c_int32, [P, P, P, c_int32, c_int32, c_int32, c_float, P, POINTER(GridDesc), P, P, c_int32,
-                                           P, P]),
+                                           c_float, P, P]),
     "inr_instance_forward": (c_int32, [P, c_int64, P, c_float, P, POINTER(GridDesc), P, c_int32, P, P]),
     "inr_roi_align_3d_set_mode": (c_int32, [c_int32]),
     "inr_roi_align_3d_forward": (c_int32, [P, P, P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int64, c_int32,

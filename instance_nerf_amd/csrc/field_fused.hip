@@ -945,7 +945,7 @@ template <bool kLattice>
 __global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_nerf_fwd_dirs(
     const float* __restrict__ x, int64_t M, float bound, const float2* __restrict__ emb, uint32_t emb_bytes, GridDesc G,
     const float4* __restrict__ packed, const float* __restrict__ sh_dirs /*[D,16]*/, int D, float4* __restrict__ out,
-    LatticeDesc lat) {
+    LatticeDesc lat, float logit_min) {
   extern __shared__ __attribute__((aligned(16))) float4 wl[];
   constexpr int kStage = kNerfFloats / 4;
   for (int i = threadIdx.x; i < kStage; i += kFieldThreads) wl[i] = packed[i];
@@ -1018,7 +1018,7 @@ __global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_nerf_fwd_dirs
       g += __frcp_rn(1.0f + __expf(-o[0][1]));
       b += __frcp_rn(1.0f + __expf(-o[0][2]));
     }
-    if (valid && q == 0) out[m] = make_float4(r * inv_d, g * inv_d, b * inv_d, h2[0][0]);
+    if (valid && q == 0) out[m] = make_float4(r * inv_d, g * inv_d, b * inv_d, fmaxf(h2[0][0], logit_min));
   }
 }
 
@@ -2463,13 +2463,13 @@ int inr_nerf_forward_dirs(const float* x, int64_t M, float bound, const float* e
   const int grid = grid_for(k_nerf_fwd_dirs<false>, lds, (M + 15) / 16);
   k_nerf_fwd_dirs<false><<<grid, kFieldThreads, lds, as_stream(s)>>>(
       x, M, bound, reinterpret_cast<const float2*>(embeddings), (uint32_t)emb_bytes64, G,
-      reinterpret_cast<const float4*>(packed), sh_dirs, n_dirs, reinterpret_cast<float4*>(out), LatticeDesc{});
+      reinterpret_cast<const float4*>(packed), sh_dirs, n_dirs, reinterpret_cast<float4*>(out), LatticeDesc{}, -INFINITY);
   return check_launch("nerf_forward_dirs");
 }
 
 int inr_nerf_forward_lattice(const float* ax_w, const float* ax_l, const float* ax_h, int32_t W, int32_t L, int32_t H,
                              float bound, const float* embeddings, const inr_grid_desc* desc, const float* packed,
-                             const float* sh_dirs, int32_t n_dirs, float* out, inr_stream_t s) {
+                             const float* sh_dirs, int32_t n_dirs, float logit_min, float* out, inr_stream_t s) {
   INR_REQUIRE(W >= 0 && L >= 0 && H >= 0 && desc, "bad argument");
   if ((int64_t)W * L * H == 0) return INR_OK;
   INR_REQUIRE(ax_w && ax_l && ax_h && embeddings && packed && sh_dirs && out, "null pointer");
@@ -2487,7 +2487,7 @@ int inr_nerf_forward_lattice(const float* ax_w, const float* ax_l, const float* 
   const int grid = grid_for(k_nerf_fwd_dirs<true>, lds, (M + 15) / 16);
   k_nerf_fwd_dirs<true><<<grid, kFieldThreads, lds, as_stream(s)>>>(
       nullptr, M, bound, reinterpret_cast<const float2*>(embeddings), (uint32_t)emb_bytes64, G,
-      reinterpret_cast<const float4*>(packed), sh_dirs, n_dirs, reinterpret_cast<float4*>(out), lat);
+      reinterpret_cast<const float4*>(packed), sh_dirs, n_dirs, reinterpret_cast<float4*>(out), lat, logit_min);
   return check_launch("nerf_forward_lattice");
 }
 

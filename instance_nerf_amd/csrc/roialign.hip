@@ -248,6 +248,17 @@ __device__ __forceinline__ bool sep_assign(const SepArgs& A, int* k, int* c0) {
 }
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#ifndef SEP_NT_STORE
+#define SEP_NT_STORE 1
+#endif
+#ifndef SEP_RUN_BARRIER
+#define SEP_RUN_BARRIER 0
+#endif
+#if SEP_NT_STORE
+#define SEP_STORE(p, v) __builtin_nontemporal_store((v), (p))
+#else
+#define SEP_STORE(p, v) (*(p) = (v))
+#endif
 
 __device__ __forceinline__ void fma4(f32x4& a, float w, const f32x4 v) {
   a.x = __builtin_fmaf(w, v.x, a.x);
@@ -436,19 +447,25 @@ __global__ void __launch_bounds__(SEP_THREADS) k_roi_align3d_sep_fwd(const float
       // no barrier here: the next slab's pass 1 writes tmp1 only, and its barrier orders the writes of tmp2 behind
       // these reads
     }
+    // streaming stores (SEP_NT_STORE): the 262 MB of a configs[4] call would otherwise walk through the L2 and push out
+    // the few channels of the volume its workgroups keep re-reading
 #pragma unroll
     for (int i = 0; i < NOUT; ++i) {
       const int o = t + i * SEP_THREADS;
       if (o < nout) {
         float* dst = obase + (int64_t)c * nout + o;
-        dst[0] = acc[i].x * inv_count;
-        if (c + 1 < cend) dst[nout] = acc[i].y * inv_count;
-        if (c + 2 < cend) dst[2 * (int64_t)nout] = acc[i].z * inv_count;
-        if (c + 3 < cend) dst[3 * (int64_t)nout] = acc[i].w * inv_count;
+        SEP_STORE(dst, acc[i].x * inv_count);
+        if (c + 1 < cend) SEP_STORE(dst + nout, acc[i].y * inv_count);
+        if (c + 2 < cend) SEP_STORE(dst + 2 * (int64_t)nout, acc[i].z * inv_count);
+        if (c + 3 < cend) SEP_STORE(dst + 3 * (int64_t)nout, acc[i].w * inv_count);
       }
     }
-    __syncthreads();   // keeps the channel runs apart: a fast wave of a small RoI must not write tmp1 / tmp2 of the
-                       // next run while a slow one still reads this run's
+#if SEP_RUN_BARRIER
+    __syncthreads();
+#endif
+    // no barrier between channel runs: the next run's pass 1 writes tmp1, which nobody reads any more (every wave left
+    // this run's pass 2 through the barrier behind it), and its pass 2 writes tmp2 only behind the NEXT barrier, which
+    // a wave reaches after it has finished this run's pass 3
   }
 }
 

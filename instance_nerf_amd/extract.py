@@ -44,6 +44,21 @@ def lattice_axes(bbox_min, bbox_max, res, device):
     return list(torch.split(flat, sizes))
 
 
+_AXES_CACHE = {}
+
+
+def _cached_axes(bbox_min, bbox_max, res, device):
+    """``lattice_axes`` kept per (box, resolution, device): a scene is extracted with one lattice, and the upload of a
+    fresh one is a synchronous host-to-device copy in front of every extraction."""
+    key = (tuple(float(v) for v in bbox_min), tuple(float(v) for v in bbox_max), tuple(int(v) for v in res), str(device))
+    hit = _AXES_CACHE.get(key)
+    if hit is None:
+        if len(_AXES_CACHE) > 16:
+            _AXES_CACHE.clear()
+        hit = _AXES_CACHE[key] = lattice_axes(bbox_min, bbox_max, res, device)
+    return hit
+
+
 def lattice(bbox_min, bbox_max, res, device):
     """Voxel-centre positions, float32 [W*L*H, 3], index order (w, l, h) with h fastest."""
     axes = lattice_axes(bbox_min, bbox_max, res, device)
@@ -59,16 +74,21 @@ def extract_rgbsigma(model, bbox_min=None, bbox_max=None, max_side=160, res=None
     bbox_min = np.asarray([-b, -b, -b] if bbox_min is None else bbox_min, dtype=np.float32)
     bbox_max = np.asarray([b, b, b] if bbox_max is None else bbox_max, dtype=np.float32)
     res = grid_resolution(bbox_min, bbox_max, max_side) if res is None else np.asarray(res, dtype=np.int64)
-    dirs = torch.from_numpy(VIEW_DIRS).to(dev)
+    cached = getattr(model, "_view_dirs_dev", None)     # the four fixed directions and their SH rows, uploaded once
+    if cached is None or cached[0].device != dev:
+        d = torch.from_numpy(VIEW_DIRS).to(dev)
+        cached = model._view_dirs_dev = (d, model.encoder_dir(d).contiguous() if hasattr(model, "encoder_dir") else None)
+    dirs = cached[0]
     if hasattr(model, "forward_lattice"):
         # one launch for the whole lattice, from its three coordinate axes (no [W*L*H, 3] point tensor), walked in
         # runs along W: 160^3 in ~1.2 ms instead of 2.8 (profiles/r04_NOTES.txt 6)
         was_training = model.training
         model.eval()
-        fused = model.forward_lattice(lattice_axes(bbox_min, bbox_max, res, dev), dirs)
+        sh = cached[1]
+        # the density logit's lower clamp (log 1e-30, as on the point-list path) is applied inside the launch
+        fused = model.forward_lattice(_cached_axes(bbox_min, bbox_max, res, dev), dirs, logit_min=float(np.log(1e-30)), sh=sh)
         model.train(was_training)
         if fused is not None:
-            fused[..., 3].clamp_(min=float(np.log(1e-30)))
             return fused, res
     pts = lattice(bbox_min, bbox_max, res, dev)
     out = torch.empty(pts.shape[0], 4, dtype=torch.float32, device=dev)

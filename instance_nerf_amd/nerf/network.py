@@ -606,25 +606,27 @@ class NeRFNetwork(NeRFRenderer):
         return out
 
     @torch.no_grad()
-    def forward_lattice(self, axes, dirs):
+    def forward_lattice(self, axes, dirs, logit_min=float("-inf"), sh=None):
         """``forward_dirs`` for the lattice ``axes = (ax_w [W], ax_l [L], ax_h [H])`` (float32, on the device): -> float
         [W, L, H, 4] without a point tensor, the kernel walking the lattice in runs along W (the table's fastest row
         index; 2.4x faster than the h-fastest point list, ``inr_nerf_forward_lattice``).  Coordinates are clamped to
-        [-bound, bound].  None when the fused kernel does not apply."""
+        [-bound, bound]; ``logit_min`` clamps the density logit from below inside the launch; ``sh``: the directions' SH
+        rows [D,16] when the caller has them already.  None when the fused kernel does not apply."""
         if not self._fusable:
             return None
         lib = _lib.load()
         ax = [a.contiguous().float() for a in axes]
         W, L, H = (int(a.shape[0]) for a in ax)
         D = dirs.shape[0]
-        sh = self.encoder_dir(dirs.to(ax[0].device).contiguous().float()).contiguous()      # [D,16] (HIP SH kernel)
+        if sh is None:
+            sh = self.encoder_dir(dirs.to(ax[0].device).contiguous().float()).contiguous()  # [D,16] (HIP SH kernel)
         out = torch.empty(W, L, H, 4, dtype=torch.float32, device=ax[0].device)
         if W * L * H:
             check(lib.inr_nerf_forward_lattice(ptr(ax[0], torch.float32, "ax_w"), ptr(ax[1], torch.float32, "ax_l"),
                                                ptr(ax[2], torch.float32, "ax_h"), W, L, H, float(self.bound),
                                                ptr(self.encoder.embeddings.data, torch.float32), self.encoder.desc,
                                                ptr(self._packed_weights("nerf")), ptr(sh, torch.float32, "sh_dirs"), D,
-                                               ptr(out), stream_ptr()), "nerf_forward_lattice")
+                                               float(logit_min), ptr(out), stream_ptr()), "nerf_forward_lattice")
         return out
 
     # ---- upstream API -----------------------------------------------------------------------------

@@ -65,7 +65,7 @@ def test_extract_matches_oracle_field(level_table, params_k16):
     assert (got[:, :3] - rgb).abs().max() < 1e-4
     # the one-launch path (forward_dirs) and the density() + 4 x color() path agree; ragged size, points on the faces
     net.forward_dirs, fused = (lambda x, d: None), net.forward_dirs
-    net.forward_lattice, fused_lat = (lambda axes, d: None), net.forward_lattice
+    net.forward_lattice, fused_lat = (lambda *a, **k: None), net.forward_lattice
     slow, _ = extract_rgbsigma(net, res=[12, 10, 8])
     net.forward_dirs = fused
     assert (slow - grid).abs().max() < 1e-4
@@ -76,7 +76,7 @@ def test_extract_matches_oracle_field(level_table, params_k16):
         by_points, _ = extract_rgbsigma(net, lo, hi, res=res)
         net.forward_lattice = fused_lat
         by_lattice, _ = extract_rgbsigma(net, lo, hi, res=res)
-        net.forward_lattice = lambda axes, d: None
+        net.forward_lattice = lambda *a, **k: None
         assert by_lattice.shape == by_points.shape == tuple(res) + (4,) and torch.equal(by_lattice, by_points), res
     net.forward_lattice = fused_lat
     x = torch.rand(1003, 3, device=grid.device) * 2 - 1
