@@ -81,7 +81,7 @@ def extract_rgbsigma(model, bbox_min=None, bbox_max=None, max_side=160, res=None
     dirs = cached[0]
     if hasattr(model, "forward_lattice"):
         # one launch for the whole lattice, from its three coordinate axes (no [W*L*H, 3] point tensor), walked in
-        # runs along W: 160^3 in ~1.2 ms instead of 2.8 (profiles/r04_NOTES.txt 6)
+        # runs along W: 160^3 in 1.4 ms instead of 2.8 (profiles/r04_NOTES.txt 6)
         was_training = model.training
         model.eval()
         sh = cached[1]
