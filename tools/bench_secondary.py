@@ -377,6 +377,33 @@ def instance_render_probe(dev, frames=8):
            "ms_per_frame": round(dt / frames * 1e3, 3), "value": round(n / dt / 1e6, 1), "unit": "Msamples/s",
            "algorithmic_bytes_per_sample": 2 * BYTES_PER_SAMPLE,
            "frac_of_hbm_peak": round(n * 2 * BYTES_PER_SAMPLE / dt / 1e9 / HBM_PEAK_GBS, 4)}
+    # the product's view loop for this network (Trainer.test of the instance stage): row-major rays from the loader, views
+    # alternating on the two streams of the trainer's FramePipeline, the instance render behind the field gate too
+    try:
+        from instance_nerf_amd.nerf.utils import Trainer
+        tr = Trainer("bench_inst_views", None, net, stage="instance", device=dev, workspace=None, use_checkpoint="scratch",
+                     mute=True)
+        for q in net.parameters():
+            q.requires_grad_(False)
+        net.eval()
+
+        def loader(k):
+            for v in range(k):
+                r = get_rays(pd[v % pd.shape[0]:v % pd.shape[0] + 1], intr, H, W)
+                yield {"rays_o": r["rays_o"], "rays_d": r["rays_d"], "H": H, "W": W}
+        for _ in tr.render_sequence(loader(3), infer_mode="fused"):
+            pass
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        cs = [o["num_samples"] for _, o in tr.render_sequence(loader(frames), infer_mode="fused")]
+        torch.cuda.synchronize()
+        dt_p = time.perf_counter() - t0
+        n_p = sum(int(c[0]) for c in cs)
+        out["pipelined"] = {"ms_per_frame": round(dt_p / frames * 1e3, 3), "value": round(n_p / dt_p / 1e6, 1),
+                            "frac_of_hbm_peak": round(n_p * 2 * BYTES_PER_SAMPLE / dt_p / 1e9 / HBM_PEAK_GBS, 4),
+                            "what": "Trainer.render_sequence (FramePipeline), the loop Trainer.test runs"}
+    except Exception as e:                                    # noqa: BLE001
+        out["pipelined"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     # the same frames with upstream's -O numerics on BOTH fields (opt-in: fp16 table copies, single-pass fp16 MLPs)
     ref = frame(0)
     net.half_table = net.mlp_fp16 = True
