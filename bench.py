@@ -332,11 +332,36 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"], line["parity"] = cpu_baseline(room, net, step(0)["frame"],
                                                                 render_view0=lambda: step(0)["frame"])
+    watchdog = None
     if world > 1:
-        rec = collective_record(dev, rank, world, backend, red_dev)
+        # Everything from here on contains collectives: a rank that dies or hangs in one leaves the others waiting.  Two
+        # guards keep the headline measurement when that happens: the line is put in a side file first, and a watchdog
+        # THREAD on rank 0 (a blocked collective holds the main thread inside C++, where no signal handler runs) prints
+        # the line as far as it got and exits non-zero if the collective record and the probes have not finished after
+        # 7 minutes.
+        if rank == 0:
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", f"bench_headline_n{world}.json"), "w") as f:
+                f.write(json.dumps(line) + "\n")
+            import threading
+
+            def bail():
+                line.setdefault("train_step", {"error": "collectives / training probes did not finish in 420 s"})
+                line.setdefault("train_step_nerf", line["train_step"])
+                print(json.dumps(line), flush=True)
+                # a hung collective is a FAILED run: non-zero, so that the launcher tears the other ranks down and the
+                # caller sees it (the headline is also in gpurun_out/bench_headline_n<N>.json)
+                os._exit(3)
+            watchdog = threading.Timer(420.0, bail)
+            watchdog.daemon = True
+            watchdog.start()
+        try:
+            rec = collective_record(dev, rank, world, backend, red_dev)
+        except Exception as e:                                # noqa: BLE001 - reported; the same code path on every rank
+            rec = {"error": f"{type(e).__name__}: {e}"[:300], "all_ranks_on_distinct_gpus": None}
         if rank == 0:
             line["collective"] = rec
-        if backend == "nccl" and not rec["all_ranks_on_distinct_gpus"]:
+        if backend == "nccl" and rec.get("all_ranks_on_distinct_gpus") is False:
             # an RCCL run whose ranks share GPUs measures nothing about xGMI: fail loudly instead of reporting a curve
             if rank == 0:
                 line["error"] = f"{rec['distinct_devices']} distinct GPUs for {world} ranks"
@@ -344,6 +369,8 @@ def main():
             dist.barrier()
             dist.destroy_process_group()
             sys.exit(4)
+    if args.no_train_probe and watchdog is not None:
+        watchdog.cancel()
     if not args.no_train_probe:
         del net                                       # the probe builds its own (instance-head) network
         if world == 1:
@@ -376,27 +403,9 @@ def main():
                 except Exception as e:                    # noqa: BLE001
                     ts["overlapped_O"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         else:
-            # The probe contains collectives: a rank that swallowed an exception would leave the others waiting in
-            # all_reduce, so exceptions propagate (non-zero exit, the launcher tears the job down).  Two guards keep
-            # the headline measurement when that happens: the line is put in a side file first, and a watchdog THREAD
-            # on rank 0 (a blocked collective holds the main thread inside C++, where no signal handler runs) prints
-            # the line without the probes' numbers and exits if they have not finished after 7 minutes.
-            watchdog = None
-            if rank == 0:
-                os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-                with open(os.path.join(ROOT, "gpurun_out", f"bench_headline_n{world}.json"), "w") as f:
-                    f.write(json.dumps(line) + "\n")
-                import threading
-
-                def bail():
-                    line["train_step"] = line["train_step_nerf"] = {"error": "training probes did not finish in 420 s"}
-                    print(json.dumps(line), flush=True)
-                    # a hung collective is a FAILED run: non-zero, so that the launcher tears the other ranks down and
-                    # the caller sees it (the headline is also in gpurun_out/bench_headline_n<N>.json)
-                    os._exit(3)
-                watchdog = threading.Timer(420.0, bail)      # three probes (two stages + the other gradient schedule)
-                watchdog.daemon = True
-                watchdog.start()
+            # The probes contain collectives: a rank that swallowed an exception would leave the others waiting in
+            # all_reduce, so exceptions propagate (non-zero exit, the launcher tears the job down); the watchdog started
+            # above covers them.
             try:
                 from instance_nerf_amd.nerf.utils import grad_sync as _gs
                 default_schedule = _gs.schedule
