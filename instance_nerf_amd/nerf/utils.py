@@ -1220,7 +1220,9 @@ class Trainer:
         P = self._pipe
         t = P["turn"]
         S, Nx = P["sets"][t], P["sets"][t ^ 1]
-        prime = not (P["primed"] and P["expect"] is data["rays_o"])
+        # the prefetched head is this batch's only if it was marched for these tensors through the occupancy grid as it is
+        # NOW (an update between the two steps - the trainer's own never falls there, a caller's may - bumps iter_density)
+        prime = not (P["primed"] and P["expect"] is data["rays_o"] and P.get("grid_state") == getattr(m, "iter_density", 0))
         pairs = []
         if prime:
             pairs += [(S["static"][k], v) for k, v in data.items() if torch.is_tensor(v)]
@@ -1248,6 +1250,7 @@ class Trainer:
         if self.ema is not None:
             self.ema.update()
         P["primed"], P["expect"] = ahead, (next_data["rays_o"] if ahead else None)
+        P["grid_state"] = getattr(m, "iter_density", 0)
         P["turn"] = t ^ 1
         return G["loss"].detach()
 
