@@ -232,7 +232,9 @@ class NeRFRenderer(nn.Module):
         N = rays_o.shape[0]
         device = rays_o.device
         aabb = self.aabb_train if self.training else self.aabb_infer
-        if marched is not None and not (self.training and marched["n_rays"] == N):
+        if marched is not None and not (self.training and marched["n_rays"] == N
+                                        and marched.get("grid_state", self.iter_density) == self.iter_density):
+            self.drop_ahead(marched)         # other rays, or marched through an occupancy grid that has been updated since
             marched = None
         if marched is not None:
             marched["consume"]()
@@ -608,7 +610,7 @@ class NeRFRenderer(nn.Module):
         out = {"n_rays": N, "key": (rays_o.data_ptr(), rays_d.data_ptr(), N), "rays_o": rays_o_in, "rays_d": rays_d_in,
                "nears": nears, "fars": fars, "xyzs": xyzs, "dirs": dirs, "deltas": deltas, "rays": rays, "counter": counter,
                "shaded": shaded, "T_thresh": float(T_thresh), "density_scale": float(self.density_scale),
-               "slot_taken": slot_taken}
+               "slot_taken": slot_taken, "grid_state": self.iter_density}
 
         def consume():
             cur = torch.cuda.current_stream()
