@@ -1192,6 +1192,9 @@ class Trainer:
                     raise RuntimeError("pipeline: march_ahead refused the batch (not the steady state / staged marcher)")
             marched = dict(S["marched"])
             marched["consume"] = lambda: None        # same graph or an earlier replay on the same stream: ordered already
+            # (the dict may come from an earlier capture; whether the buffers' CONTENT is current is _pipe_step's business
+            # at every replay, so the renderer's own staleness check must not refuse it while the graph is captured)
+            marched["grid_state"] = getattr(m, "iter_density", 0)
             self._ahead = marched
 
             def hook():
