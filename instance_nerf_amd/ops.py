@@ -13,6 +13,8 @@ Ops (names follow upstream's extension modules):
   inr::composite_rays_train     raymarching.composite_rays_train, differentiable        (a12)
   inr::grid_encode              gridencoder forward, differentiable w.r.t. the table    (a7 / a8)
   inr::nerf_forward             NeRFNetwork.forward without autograd (fused kernel)     (a9, a10, a11)
+  inr::roi_align_3d             roi_align.roi_align.roi_align_3d, differentiable w.r.t. input  (f2; the reference's one
+                                in-tree FFI call, /root/reference/nerf_rcnn/model/utils.py:608)
 The level table of a hash grid travels as plain integer / float lists (``GridEncoder.table``): a custom-op schema
 knows tensors, numbers and lists of numbers, not ctypes structures.
 """
@@ -219,3 +221,62 @@ def _(x, d, embeddings, sigma_w0, sigma_w1, color_w0, color_w1, color_w2, bound,
 
 OPS = ("near_far_from_aabb", "march_rays_train", "composite_rays_train", "composite_rays_train_backward", "grid_encode",
        "grid_encode_backward", "nerf_forward")
+
+
+# ------------------------------------------------------------------------------------------------ 3-D RoIAlign
+@torch.library.custom_op("inr::roi_align_3d", mutates_args=())
+def roi_align_3d(input: Tensor, rois: Tensor, roi_inds: Tensor, out_w: int, out_l: int, out_h: int,
+                 spatial_scale: float) -> Tensor:
+    """input [N,C,W,L,H], rois [K,6], roi_inds int [K] -> [K,C,out_w,out_l,out_h] (torchvision roi_align semantics on
+    three axes; the separable HIP kernels of csrc/roialign.hip)."""
+    lib = _lib.load()
+    input, rois = input.contiguous().float(), rois.contiguous().float()
+    roi_inds = roi_inds.contiguous().to(I32)
+    N, C, W, L, H = input.shape
+    K = rois.shape[0]
+    out = torch.empty(K, C, out_w, out_l, out_h, dtype=F32, device=input.device)
+    check(lib.inr_roi_align_3d_forward(ptr(input, F32, "input", allow_none=input.numel() == 0),
+                                       ptr(rois, F32, "rois", allow_none=K == 0), ptr(roi_inds, I32, "roi_inds", allow_none=K == 0),
+                                       N, C, W, L, H, K, out_w, out_l, out_h, float(spatial_scale),
+                                       ptr(out, allow_none=K == 0), stream_ptr()), "roi_align_3d_forward")
+    return out
+
+
+@roi_align_3d.register_fake
+def _(input, rois, roi_inds, out_w, out_l, out_h, spatial_scale):
+    return input.new_empty(rois.shape[0], input.shape[1], out_w, out_l, out_h, dtype=F32)
+
+
+@torch.library.custom_op("inr::roi_align_3d_backward", mutates_args=())
+def roi_align_3d_backward(grad_out: Tensor, rois: Tensor, roi_inds: Tensor, N: int, W: int, L: int, H: int,
+                          spatial_scale: float) -> Tensor:
+    """dL/d(input) [N,C,W,L,H] of roi_align_3d: the transposed separable passes, one atomic per touched cell."""
+    lib = _lib.load()
+    grad_out, rois = grad_out.contiguous().float(), rois.contiguous().float()
+    roi_inds = roi_inds.contiguous().to(I32)
+    K, C, ow, ol, oh = grad_out.shape
+    gin = torch.zeros(N, C, W, L, H, dtype=F32, device=grad_out.device)
+    check(lib.inr_roi_align_3d_backward(ptr(grad_out, allow_none=K == 0), ptr(rois, allow_none=K == 0),
+                                        ptr(roi_inds, allow_none=K == 0), N, C, W, L, H, K, ow, ol, oh, float(spatial_scale),
+                                        ptr(gin, allow_none=gin.numel() == 0), stream_ptr()), "roi_align_3d_backward")
+    return gin
+
+
+@roi_align_3d_backward.register_fake
+def _(grad_out, rois, roi_inds, N, W, L, H, spatial_scale):
+    return grad_out.new_empty(N, grad_out.shape[1], W, L, H, dtype=F32)
+
+
+def _roi_setup(ctx, inputs, output):
+    input, rois, roi_inds, out_w, out_l, out_h, spatial_scale = inputs
+    ctx.save_for_backward(rois, roi_inds)
+    ctx.args = (input.shape[0], input.shape[2], input.shape[3], input.shape[4], spatial_scale)
+
+
+def _roi_backward(ctx, grad):
+    rois, roi_inds = ctx.saved_tensors
+    N, W, L, H, scale = ctx.args
+    return torch.ops.inr.roi_align_3d_backward(grad, rois, roi_inds, N, W, L, H, scale), None, None, None, None, None, None
+
+
+roi_align_3d.register_autograd(_roi_backward, setup_context=_roi_setup)

@@ -182,3 +182,26 @@ def test_roi_align_fuzz_against_the_oracle(seed):
             assert abs(lhs - rhs) < 1e-4 * max(1.0, abs(lhs)), (mode, lhs, rhs)
     finally:
         _set_mode(0)
+
+
+@pytest.mark.gpu
+def test_registered_custom_op_equals_the_module_function():
+    """torch.ops.inr.roi_align_3d (schema + fake implementation + autograd formula over the same C ABI) gives the module
+    function's output and gradient bit for bit, and torch.library's opcheck accepts its registration."""
+    from instance_nerf_amd import ops  # noqa: F401
+    from instance_nerf_amd.roi_align.roi_align import roi_align_3d
+    rng = np.random.default_rng(2)
+    vol = torch.tensor(rng.normal(size=(2, 5, 8, 7, 9)).astype(np.float32), device="cuda")
+    rois = torch.tensor([[0.5, 1, 2, 12, 11, 14], [3, 2, 1, 9, 9, 9], [-4, 0, 0, 30, 5, 5]], dtype=torch.float32, device="cuda")
+    inds = torch.tensor([0, 1, 1], dtype=torch.int32, device="cuda")
+    a = vol.clone().requires_grad_(True)
+    b = vol.clone().requires_grad_(True)
+    ya = roi_align_3d(a, rois, inds, 4, 3, 5, 0.5)
+    yb = torch.ops.inr.roi_align_3d(b, rois, inds, 4, 3, 5, 0.5)
+    assert torch.equal(ya, yb)
+    g = torch.randn_like(ya)
+    ya.backward(g)
+    yb.backward(g)
+    assert torch.allclose(a.grad, b.grad, rtol=1e-6, atol=1e-6)          # atomics: summation order
+    torch.library.opcheck(torch.ops.inr.roi_align_3d.default, (vol, rois, inds, 4, 3, 5, 0.5),
+                          test_utils=("test_schema", "test_faketensor"))
