@@ -327,6 +327,13 @@ def main():
                     "what": ("Trainer.render_sequence(pipeline=True): views alternate on two streams, field kernels "
                              "serialised; march of view i+1 and compositing of view i-1 run under field kernel i") if other
                     else "Trainer.render_sequence(pipeline=False): upstream's loop, one view at a time on one stream"}
+                if not other:
+                    # the dominant kernel with the chip to itself, beside the figure of the timed (pipelined) region where
+                    # it shares the CUs with the next view's marchers
+                    line["roofline"]["kernel_alone"] = {
+                        "avg_launch_ms": round(kms, 4),
+                        "frac": round(ns / n_o * BYTES_PER_SAMPLE / (kms / 1e3) / 1e9 / HBM_PEAK_GBS, 4),
+                        "what": "the same launches in the one-stream loop of the \"one_stream\" object"}
             except Exception as e:                            # noqa: BLE001
                 line["pipelined" if not args.pipeline else "one_stream"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         if world == 1 and not args.no_cpu_baseline:
