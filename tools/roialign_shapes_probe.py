@@ -1,4 +1,4 @@
-"""Separable vs lane-per-output RoIAlign-3D over the shapes a feature pyramid produces (levels of 80^3 .. 5^3, 7 / 10 / 14
+"""Separable vs lane-per-output RoIAlign-3D over the shapes a feature pyramid produces (levels of 80^3 .. 5^3, 5 / 5 / 7 / 10 / 14
 bins, 64 .. 512 boxes): no shape may be slower on the default (separable) kernels.  python tools/roialign_shapes_probe.py"""
 import os
 import sys
@@ -33,7 +33,7 @@ for C, S in ((256, 80), (256, 40), (256, 20), (256, 10), (256, 5), (64, 40), (16
         lo = torch.rand(K, 3, device=dev, generator=gen) * 0.6 * S
         rois = torch.cat([lo, lo + 1 + torch.rand(K, 3, device=dev, generator=gen) * 0.4 * S], 1)
         inds = torch.zeros(K, dtype=torch.int32, device=dev)
-        for o in (7, 10, 14):
+        for o in (5, 7, 10, 14):
             ts = []
             for mode in (2, 1):
                 lib.inr_roi_align_3d_set_mode(mode)
