@@ -1071,6 +1071,19 @@ class Trainer:
     GRAPH_ALIGN = 16384        # buffer sizes are rounded up to this many samples so that a graph survives the
                                # small changes of mean_count at every occupancy update
 
+    def _graph_capacity(self, mean_count):
+        """Sample-buffer size of the captured step for a measured ``mean_count``: rounded up to GRAPH_ALIGN, and the size
+        already captured for is kept while it still holds the batch and is at most max(2 units, 1/8) too large - the
+        16-step mean of a converged scene wanders by a few thousand samples, and every change of the size is a new set
+        of graphs (tools/pipeline_convergence_probe.py: without the hold, 84 captures in 31 updates)."""
+        a = self.GRAPH_ALIGN
+        need = (mean_count + a - 1) // a * a
+        held = getattr(self, "_held_capacity", 0)
+        if need <= held <= need + max(2 * a, need // 8):
+            need = held
+        self._held_capacity = need
+        return need
+
     def _graph_key(self, data):
         return (self.model.mean_count, self.stage) + tuple((k, tuple(v.shape)) for k, v in sorted(data.items())
                                                             if torch.is_tensor(v))
@@ -1284,8 +1297,7 @@ class Trainer:
         if self.model.cuda_ray and self.global_step % self.update_extra_interval == 0:
             self.model.update_extra_state()
             if self.use_graph and self.model.mean_count > 0:
-                a = self.GRAPH_ALIGN
-                self.model.mean_count = (self.model.mean_count + a - 1) // a * a
+                self.model.mean_count = self._graph_capacity(self.model.mean_count)
         self.global_step += 1
         if self._pipe_applies(data):
             return self._pipe_step(data, next_data)

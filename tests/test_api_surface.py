@@ -251,3 +251,21 @@ def test_registered_custom_ops():
         ws, depth, image = torch.ops.inr.composite_rays_train(torch.empty(4096, requires_grad=True), torch.empty(4096, 3), dl,
                                                              rays, 1e-4)
         assert ws.shape == depth.shape == (40,) and image.shape == (40, 3) and image.requires_grad
+
+
+def test_captured_step_buffer_size_holds_across_small_changes():
+    """Trainer._graph_capacity: sizes of the captured step's sample buffers - up to GRAPH_ALIGN, kept while the held size
+    still fits and is not more than max(2 units, 1/8) too large (every change re-captures the step's graphs)."""
+    from instance_nerf_amd.nerf.utils import Trainer
+    t = Trainer.__new__(Trainer)
+    a = Trainer.GRAPH_ALIGN
+    assert t._graph_capacity(1) == a and t._graph_capacity(a) == a
+    assert t._graph_capacity(30 * a - 5) == 30 * a
+    assert t._graph_capacity(29 * a - 7) == 30 * a               # wandered down a unit: held
+    assert t._graph_capacity(30 * a - 9) == 30 * a
+    assert t._graph_capacity(30 * a + 1) == 31 * a               # no longer fits: grows at once
+    assert t._graph_capacity(28 * a) == 31 * a                   # 3 units under, 1/8 of 28 units = 3.5: held
+    assert t._graph_capacity(20 * a) == 20 * a                   # the scene emptied: shrinks
+    assert t._graph_capacity(4 * a) == 4 * a
+    assert t._graph_capacity(2 * a + 1) == 4 * a                 # small sizes: two units of slack
+    assert t._graph_capacity(a) == a
