@@ -49,8 +49,8 @@ def measured_traffic_bytes_per_sample(res):
 
 
 sys.path.insert(0, os.path.join(ROOT, "tools"))
-from bench_secondary import (build_network, collective_record, config5_probe, half_table_probe,  # noqa: E402
-                             instance_render_probe, train_probe, trained_scene_probe)
+from bench_secondary import (bound_render_probe, build_network, collective_record, config5_probe,  # noqa: E402
+                             half_table_probe, instance_render_probe, train_probe, trained_scene_probe)
 
 
 def cpu_baseline(room, net, frame0=None, chunk=16384, budget_s=12.0, max_chunks=40, render_view0=None):
@@ -454,6 +454,23 @@ def main():
                 line["render_fast"] = half_table_probe(dev, mlp_fp16=True)
             except Exception as e:                            # noqa: BLE001
                 line["render_fast"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            # off the tuned configuration (round-4 verdict item 1): bound 2 and 4 (cascades, finer level tables), the
+            # render with growing and with constant steps, and both training stages at bound 4
+            for key, kw in (("render_bound2", dict(bound=2, dt_gamma=1.0 / 128)), ("render_bound4", dict(bound=4, dt_gamma=1.0 / 128)),
+                            ("render_bound4_constant_steps", dict(bound=4, dt_gamma=0.0))):
+                try:
+                    line[key] = bound_render_probe(dev, **kw)
+                except Exception as e:                        # noqa: BLE001
+                    line[key] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            if world == 1:
+                drop = ("ms_of_each_step", "ms_per_step_of_both_timed_regions", "graphs_captured", "allreduce_mb_per_step",
+                        "gradient_schedule", "n_gpus")
+                for key, st in (("train_step_bound4", "instance"), ("train_step_nerf_bound4", "nerf")):
+                    try:
+                        o = train_probe(dev, rank, world, red_dev, steps=args.train_steps, stage=st, bound=4, dt_gamma=1.0 / 128)
+                        line[key] = {k: v for k, v in o.items() if k not in drop}
+                    except Exception as e:                    # noqa: BLE001
+                        line[key] = {"error": f"{type(e).__name__}: {e}"[:300]}
             if world == 1 and not args.no_trained_scene:
                 try:
                     line["trained_scene"] = trained_scene_probe(dev, with_oracle=not args.no_cpu_baseline)

@@ -14,10 +14,10 @@ from .utils import get_rays
 
 class SyntheticRoomDataset:
     def __init__(self, device, H=800, W=800, n_views=8, num_rays=4096, training=True, ignore_frac=0.1, seed=2,
-                 num_instances=64, rank=0, sort_pixels=False):
+                 num_instances=64, rank=0, sort_pixels=False, scale=1.0):
         self.device, self.H, self.W, self.num_rays, self.training = device, H, W, num_rays, training
         self.sort_pixels = sort_pixels      # the batch's random pixels in image order (same set of rays per batch)
-        self.room = RoomScene()
+        self.room = RoomScene(scale=scale)      # scale s: the room enlarged s times (train it with bound = s)
         poses, self.intrinsics, _, _ = self.room.cameras(n=n_views, H=H, W=W, focal=W / 2.0)
         self.poses = torch.from_numpy(poses).to(device)
         self.rng = np.random.default_rng(seed + 1000 * rank)

@@ -7,6 +7,11 @@ axis-aligned boxes (centres U(-0.7,0.7), half extents U(0.05,0.25),
 Cameras: 800x800, fx = fy = 400, cx = cy = 400; 8 poses (seed 1) with the eye
 in U(-0.5,0.5)^3 looking at the origin, up = +z.
 
+``RoomScene(scale=s)`` is the same room enlarged s times about the origin (walls at
+s * [0.90, 0.94], cameras in s * U(-0.5,0.5)^3): with ``bound = s`` it fills a torch-ngp volume of
+1 + ceil(log2 s) occupancy cascades the way a real 3D-FRONT room trained at bound 2-8 does, and
+``density_bitfield(H, bound)`` then returns all cascades (cascade c covers [-min(2^c, bound), ..]^3).
+
 This is data generation, not part of the render algorithm; both the product
 code (bench) and the tests use it.  numpy only.
 """
@@ -17,19 +22,21 @@ WALL_IN, WALL_OUT = 0.90, 0.94
 
 
 class RoomScene:
-    def __init__(self, n_boxes=12, seed=0):
+    def __init__(self, n_boxes=12, seed=0, scale=1.0):
         rng = np.random.default_rng(seed)
-        self.centres = rng.uniform(-0.7, 0.7, size=(n_boxes, 3))
-        self.halves = rng.uniform(0.05, 0.25, size=(n_boxes, 3))
-        self.lo = np.maximum(self.centres - self.halves, -WALL_IN)
-        self.hi = np.minimum(self.centres + self.halves, WALL_IN)
+        self.scale = float(scale)
+        self.wall_in, self.wall_out = WALL_IN * self.scale, WALL_OUT * self.scale
+        self.centres = rng.uniform(-0.7, 0.7, size=(n_boxes, 3)) * self.scale
+        self.halves = rng.uniform(0.05, 0.25, size=(n_boxes, 3)) * self.scale
+        self.lo = np.maximum(self.centres - self.halves, -self.wall_in)
+        self.hi = np.minimum(self.centres + self.halves, self.wall_in)
         pal = np.random.default_rng(seed + 100).uniform(0.15, 0.95, size=(n_boxes + 1, 3))
         pal[0] = (0.8, 0.8, 0.75)
         self.palette = pal.astype(F32)
 
     # ------------------------------------------------------------------ occupancy
     def occupancy_grid(self, H=128, bound=1.0):
-        """bool[H,H,H] indexed [x,y,z]: cell overlaps geometry (cascade 0 only)."""
+        """bool[H,H,H] indexed [x,y,z]: cell of the grid over [-bound, bound]^3 overlaps geometry (one cascade)."""
         edges = -bound + 2.0 * bound * np.arange(H + 1) / H
         lo_e, hi_e = edges[:-1], edges[1:]
 
@@ -37,8 +44,8 @@ class RoomScene:
             return (hi_e > a) & (lo_e < b)
 
         occ = np.zeros((H, H, H), dtype=bool)
-        inside = overlap(-WALL_OUT, WALL_OUT)
-        wall = overlap(WALL_IN, WALL_OUT) | overlap(-WALL_OUT, -WALL_IN)
+        inside = overlap(-self.wall_out, self.wall_out)
+        wall = overlap(self.wall_in, self.wall_out) | overlap(-self.wall_out, -self.wall_in)
         ix, iy, iz = inside[:, None, None], inside[None, :, None], inside[None, None, :]
         occ |= wall[:, None, None] & iy & iz
         occ |= wall[None, :, None] & ix & iz
@@ -49,8 +56,16 @@ class RoomScene:
         return occ
 
     def density_bitfield(self, H=128, bound=1.0):
-        """u8[H^3/8] in Morton order (bit i of byte k = cell with morton code 8k+i)."""
-        occ = self.occupancy_grid(H, bound)
+        """u8[C*H^3/8], C = 1 + ceil(log2 bound) cascades one after the other, each in Morton order (bit i of byte k =
+        cell with morton code 8k+i); cascade c is the grid over [-min(2^c, bound), min(2^c, bound)]^3."""
+        C = 1 + int(np.ceil(np.log2(max(bound, 1.0))))
+        if C > 1:
+            return np.concatenate([self._bitfield_of(self.occupancy_grid(H, min(2.0 ** c, bound))) for c in range(C)])
+        return self._bitfield_of(self.occupancy_grid(H, bound))
+
+    @staticmethod
+    def _bitfield_of(occ):
+        H = occ.shape[0]
         r = np.arange(H, dtype=np.uint32)
 
         def ex(v):
@@ -83,7 +98,7 @@ class RoomScene:
 
     def cameras(self, n=8, seed=1, H=800, W=800, focal=400.0):
         rng = np.random.default_rng(seed)
-        eyes = rng.uniform(-0.5, 0.5, size=(n, 3))
+        eyes = rng.uniform(-0.5, 0.5, size=(n, 3)) * self.scale
         poses = np.stack([self.look_at(e) for e in eyes])
         return poses, (focal, focal, W / 2.0, H / 2.0), H, W
 
@@ -95,10 +110,11 @@ class RoomScene:
         with np.errstate(divide="ignore", invalid="ignore"):
             rd = 1.0 / d
             # walls: exit point of the inner room box [-WALL_IN, WALL_IN]^3
-            t_exit = np.min(np.where(d > 0, (WALL_IN - o) * rd, (-WALL_IN - o) * rd), axis=1)
+            wi = self.wall_in
+            t_exit = np.min(np.where(d > 0, (wi - o) * rd, (-wi - o) * rd), axis=1)
             best_t = t_exit.copy()
             best_id = np.zeros(o.shape[0], dtype=np.int64)
-            axis_hit = np.argmin(np.where(d > 0, (WALL_IN - o) * rd, (-WALL_IN - o) * rd), axis=1)
+            axis_hit = np.argmin(np.where(d > 0, (wi - o) * rd, (-wi - o) * rd), axis=1)
             for b, (lo, hi) in enumerate(zip(self.lo, self.hi)):
                 t0 = (lo - o) * rd
                 t1 = (hi - o) * rd

@@ -306,7 +306,13 @@ def test_grid_encoder_fuzz_against_the_c_oracle(seed):
     go = torch.randn(3000, 2 * L, generator=gen)
     out.backward(go.to(DEV))
     g_ref = hashgrid.encode_backward_table(x, go, bound, tb)
-    assert torch.allclose(enc.embeddings.grad.cpu(), g_ref, atol=5e-5, rtol=1e-4)
+    # fp32 atomics land in any order: a row of a coarse level collects hundreds of O(1) terms of both signs, so the
+    # rounding of its sum is bounded by (terms x eps x sum |term|), not by the (cancelled) sum itself - compare against
+    # the row's absolute mass (seed 2: 5 levels from resolution 4, ~190 terms per coarse row, failed 5e-5 absolute once
+    # in round 5 with unchanged kernels)
+    mass = hashgrid.encode_backward_table(x, go.abs(), bound, tb)
+    err = (enc.embeddings.grad.cpu() - g_ref).abs()
+    assert bool((err <= 2e-5 + 2e-6 * mass).all()), float((err / (2e-5 + 2e-6 * mass)).max())
 
 
 def test_grid_encode_input_gradient(level_table, params_k16):
@@ -1184,6 +1190,68 @@ def test_full_size_frame_against_the_c_oracle(rm, params_k16, room, room_bitfiel
     assert np.abs(out["depth"][0].cpu().numpy() - c["depth"]).max() < 1e-4
 
 
+def test_full_size_frame_at_bound4_against_the_c_oracle(rm):
+    """The BASELINE-size job off the tuned configuration (round-4 verdict item 1b): the synthetic room enlarged 4x in a
+    bound-4 volume - THREE occupancy cascades, finest level 8192 (12 of the 16 levels hashed), steps growing with the
+    distance (dt_gamma = 1/128, torch-ngp's setting for bound > 1) - 800x800 = 640 000 rays against the scalar C
+    restatement: every ray's sample count and offset bit-exact, the sample positions of the first 20 000 rays bit-exact,
+    and the whole frame (table U(-1,1), O(1) outputs) within 1e-4.  A second view with constant steps (dt_gamma = 0:
+    ~190 samples per ray, rays that cross all three cascades) on 30 000 random pixels."""
+    from instance_nerf_amd.nerf.utils import get_rays
+    from instance_nerf_amd.scene import RoomScene
+    from oracle import c_port, field, hashgrid
+    bound, C, H = 4.0, 3, 128
+    big = RoomScene(scale=bound)
+    bits = big.density_bitfield(H, bound)
+    assert bits.shape[0] == C * H ** 3 // 8
+    table = hashgrid.level_table(desired_resolution=int(2048 * bound))
+    assert int(table["hashed"].sum()) == 12
+    p = field.init_params(seed=3, table=table, table_std=1.0, K=0)
+    net = _network(p, K=0, bound=int(bound)).eval()
+    assert net.cascade == C and (net.encoder.table["offsets"] == table["offsets"]).all()
+    net.density_bitfield.copy_(_t(bits))
+    net.density_scale = 0.25            # table U(-1,1) at 4x the path length: keep the rays semi-transparent
+    poses, intr, Hi, Wi = big.cameras()
+    aabb = [-bound] * 3 + [bound] * 3
+    r = get_rays(_t(poses[2:3]), intr, Hi, Wi)
+    ro, rd = r["rays_o"][0], r["rays_d"][0]
+    nears, fars = rm.near_far_from_aabb(ro, rd, _t(np.asarray(aabb, np.float32)), 0.05)
+    xyzs, dirs, deltas, rays = rm.march_rays_train(ro, rd, bound, _t(bits), C, H, nears, fars, force_all_rays=True,
+                                                   dt_gamma=1 / 128)
+    cn, cf = c_port.near_far_from_aabb(ro.cpu().numpy(), rd.cpu().numpy(), aabb, 0.05)
+    assert (cn == nears.cpu().numpy()).all() and (cf == fars.cpu().numpy()).all()
+    ref = c_port.march_rays_train(ro.cpu().numpy(), rd.cpu().numpy(), bits, bound, C, H, cn, cf, dt_gamma=1 / 128)
+    assert ref["total"] > 10_000_000
+    assert (rays.cpu().numpy() == ref["rays"]).all()
+    m = int(ref["rays"][20000, 1])
+    assert (xyzs[:m].cpu().numpy() == ref["xyzs"][:m]).all() and (deltas[:m].cpu().numpy() == ref["deltas"][:m]).all()
+    # every cascade is really used: samples outside [-1,1]^3 and outside [-2,2]^3
+    far_out = np.abs(ref["xyzs"]).max(1)
+    assert (far_out > 2).mean() > 0.05 and ((far_out > 1) & (far_out <= 2)).mean() > 0.05 and (far_out <= 1).mean() > 0.05
+    del xyzs, dirs, deltas, ref
+    r = get_rays(_t(poses[2:3]), intr, Hi, Wi, patch=4)
+    with torch.no_grad():
+        out = net.render(r["rays_o"], r["rays_d"], bg_color=1, infer_mode="fused", dt_gamma=1 / 128)
+    c = c_port.render(r["rays_o"][0].cpu().numpy(), r["rays_d"][0].cpu().numpy(), p, table, bits, bound=bound, cascade=C,
+                      H=H, min_near=0.05, dt_gamma=1 / 128, density_scale=0.25, absolute_depth=True)
+    assert int(out["num_samples"][0]) == c["total"] > 10_000_000
+    assert 0.2 < float(c["weights_sum"].mean()) < 0.98
+    assert np.abs(out["image"][0].cpu().numpy() - c["image"]).max() < 1e-4
+    assert np.abs(out["weights_sum"][0].cpu().numpy() - c["weights_sum"]).max() < 1e-4
+    assert np.abs(out["depth"][0].cpu().numpy() - c["depth"]).max() < 1e-4
+    # constant steps, another view, the early-terminating kernel as well
+    pick = torch.from_numpy(np.sort(np.random.default_rng(23).choice(Hi * Wi, size=30000, replace=False))).to(DEV)
+    r = get_rays(_t(poses[5:6]), intr, Hi, Wi, inds=pick)
+    c = c_port.render(r["rays_o"][0].cpu().numpy(), r["rays_d"][0].cpu().numpy(), p, table, bits, bound=bound, cascade=C,
+                      H=H, min_near=0.05, dt_gamma=0.0, density_scale=0.25, absolute_depth=True)
+    for mode in ("fused", "fused_terminate"):
+        with torch.no_grad():
+            out = net.render(r["rays_o"], r["rays_d"], bg_color=1, infer_mode=mode, dt_gamma=0)
+        assert int(out["num_samples"][0]) == c["total"] > 3_000_000, mode
+        assert np.abs(out["image"][0].cpu().numpy() - c["image"]).max() < 1e-4, mode
+        assert np.abs(out["depth"][0].cpu().numpy() - c["depth"]).max() < 1e-4, mode
+
+
 def test_generic_sampler_without_cuda_ray(params_k16, room, level_table):
     """NeRFNetwork(cuda_ray=False).render(): upstream's default sampler (128 uniform + 128 importance samples, no
     occupancy grid) as tensor-op glue around the HIP ray/box test and field kernels, against the oracle's ray-by-ray
@@ -1245,41 +1313,57 @@ def test_composite_fuzz_against_the_c_oracle(rm, seed):
         assert float(out[0][int(rays[-1, 0])]) == 0.0                          # the dropped ray composites to nothing
 
 
-@pytest.mark.parametrize("seed", _seeds(10))
-def test_render_fuzz_against_the_c_oracle(level_table, seed):
-    """Whole renders on random set-ups - occupancy from empty to full, 1..700 rays (ragged 16-ray groups), K = 0 / 16 /
-    48 / 64 instance logits, opaque and transparent densities, constant and growing steps, every inference mode and
-    the training-mode path - against the scalar C restatement: sample totals exact, image / opacity / depth / rendered
-    logits within 1e-4 / 1e-3."""
+def _fuzz_volume(rng, varied):
+    """The volume a fuzz case renders in.  varied=False: the configuration every kernel was tuned on (bound 1, one
+    128^3 cascade, the default level table).  varied=True (round-4 verdict item 1): bound 1 / 2 / 4 (1-3 occupancy
+    cascades of 64^3 or 128^3 cells), hash tables of 2^15 .. 2^19 rows per level, finest resolutions from 512 to
+    2048 * bound (so between 2 and 13 of the 16 levels are hashed) and, one case in four, 12 levels (the composable
+    path: HIP encoder + BLAS layers).  -> (bound, cascades, grid H, oracle level table, encoder_kwargs)."""
+    from oracle import hashgrid
+    if not varied:
+        return 1.0, 1, 128, hashgrid.level_table(), {}
+    bound = float(rng.choice([1.0, 2.0, 2.0, 4.0, 4.0]))
+    C = 1 + int(np.ceil(np.log2(bound)))
+    H = int(rng.choice([64, 128]))
+    kw = {"num_levels": int(rng.choice([16, 16, 16, 12])), "log2_hashmap_size": int(rng.choice([15, 17, 19])),
+          "desired_resolution": int(rng.choice([512, 2048, 2048 * bound, 2048 * bound]))}
+    return bound, C, H, hashgrid.level_table(**kw), kw
+
+
+def _render_fuzz_case(seed, varied):
     from oracle import c_port, field
-    rng = np.random.default_rng(4000 + seed)
+    rng = np.random.default_rng((14000 if varied else 4000) + seed)
+    bound, C, H, table, enc_kw = _fuzz_volume(rng, varied)
     K = int(rng.choice([0, 5, 16, 31, 48, 64]))              # 31 = the reference's 30 detections + background
-    p = field.init_params(seed=seed, table=level_table, table_std=1.0, K=K)
+    p = field.init_params(seed=seed, table=table, table_std=1.0, K=K)
     fill = float(rng.choice([0.0, 0.002, 0.05, 0.5, 1.0]))
-    bits = (rng.random(128 ** 3 // 8) < fill).astype(np.uint8) * rng.integers(1, 256, 128 ** 3 // 8).astype(np.uint8)
+    nb = C * H ** 3 // 8
+    bits = (rng.random(nb) < fill).astype(np.uint8) * rng.integers(1, 256, nb).astype(np.uint8)
     if fill == 1.0:
         bits[:] = 255
     n = int(rng.choice([1, 7, 16, 100, 700]))
-    ro = rng.uniform(-0.9, 0.9, size=(n, 3)).astype(np.float32)
+    ro = (rng.uniform(-0.9, 0.9, size=(n, 3)) * bound).astype(np.float32)
     rd = rng.normal(size=(n, 3)).astype(np.float32)
     rd /= np.linalg.norm(rd, axis=1, keepdims=True)
     if n > 2:
-        ro[0], rd[0] = [4, 4, 4], [1, 0, 0]                        # misses the box
+        ro[0], rd[0] = [4 * bound, 4 * bound, 4 * bound], [1, 0, 0]          # misses the box
     scale = float(rng.choice([1.0, 30.0, 1000.0])) if fill < 0.5 else float(rng.choice([0.05, 1.0]))
     gamma = float(rng.choice([0.0, 1.0 / 128]))
     steps = int(rng.choice([64, 1024])) if fill < 0.5 else 64
-    net = _network(p, K=K).eval()
+    net = _network(p, K=K, bound=int(bound), grid_size=H, encoder_kwargs=enc_kw).eval()
+    assert net.cascade == C and (net.encoder.table["offsets"] == table["offsets"]).all()
     net.density_bitfield.copy_(_t(bits))
     net.density_scale = scale
-    ref = c_port.render(ro, rd, p, level_table, bits, min_near=0.05, dt_gamma=gamma, max_steps=steps,
-                        with_instance=K > 0, density_scale=scale, absolute_depth=True)       # inference semantics
-    ref_train = c_port.render(ro, rd, p, level_table, bits, min_near=0.05, dt_gamma=gamma, max_steps=steps,
-                              with_instance=K > 0, density_scale=scale)
+    vol = dict(bound=bound, cascade=C, H=H)
+    ref = c_port.render(ro, rd, p, table, bits, min_near=0.05, dt_gamma=gamma, max_steps=steps,
+                        with_instance=K > 0, density_scale=scale, absolute_depth=True, **vol)       # inference semantics
+    ref_train = c_port.render(ro, rd, p, table, bits, min_near=0.05, dt_gamma=gamma, max_steps=steps,
+                              with_instance=K > 0, density_scale=scale, **vol)
     modes = ["fused", "fused_terminate", "fused_raymajor", "auto"] + (["wavefront"] if n <= 100 and steps == 64 else [])
     for mode in modes:
         with torch.no_grad():
             out = net.render(_t(ro)[None], _t(rd)[None], bg_color=1, dt_gamma=gamma, max_steps=steps, infer_mode=mode)
-        tag = (mode, K, fill, n, scale, gamma, steps)
+        tag = (mode, K, fill, n, scale, gamma, steps, bound, H, tuple(enc_kw.items()))
         if "num_samples" in out:
             assert int(out["num_samples"][0]) == ref["total"], tag
         # upstream's alive-ray loop advances `step` by n_step = clamp(N // n_alive, 1, 8) per iteration, so a ray that
@@ -1305,27 +1389,43 @@ def test_render_fuzz_against_the_c_oracle(level_table, seed):
         assert np.abs(out["instance"][0].cpu().numpy() - ref["instance"]).max() < 2e-3 * max(1.0, float(np.abs(ref["instance"]).max()))
 
 
-@pytest.mark.parametrize("seed", _seeds(8))
-def test_training_gradients_fuzz_against_the_oracle(level_table, seed):
-    """Both training stages on random set-ups (occupancy, density scale, ray count, K, growing / constant steps, a
-    sample buffer that drops the last rays): loss and ALL gradients - table, sigma / colour nets or instance nets -
-    of the fused training kernels against torch autograd through the numpy/torch oracle."""
+@pytest.mark.parametrize("seed", _seeds(10))
+def test_render_fuzz_against_the_c_oracle(seed):
+    """Whole renders on random set-ups - occupancy from empty to full, 1..700 rays (ragged 16-ray groups), K = 0 / 16 /
+    48 / 64 instance logits, opaque and transparent densities, constant and growing steps, every inference mode and
+    the training-mode path - against the scalar C restatement: sample totals exact, image / opacity / depth / rendered
+    logits within 1e-4 / 1e-3."""
+    _render_fuzz_case(seed, varied=False)
+
+
+@pytest.mark.parametrize("seed", _seeds(12))
+def test_render_fuzz_over_bounds_and_level_tables_against_the_c_oracle(seed):
+    """The same whole-render fuzz off the tuned configuration (``_fuzz_volume(varied=True)``): bound 1 / 2 / 4 with their
+    occupancy cascades, 64^3 and 128^3 grids, table sizes 2^15 .. 2^19, finest resolutions 512 .. 8192, 12 and 16
+    levels."""
+    _render_fuzz_case(seed, varied=True)
+
+
+def _gradient_fuzz_case(seed, varied):
     from oracle import field, render
-    rng = np.random.default_rng(9000 + seed)
+    rng = np.random.default_rng((19000 if varied else 9000) + seed)
+    bound, C, H, level_table, enc_kw = _fuzz_volume(rng, varied)
     # (stage, K) by seed: the two are independent of each other (round 2 took K from seed % 5 and the stage from
     # seed % 2, so K = 64 only ever met the NeRF stage); 31 = the reference's 30 detections + background
     stage = "nerf" if seed % 2 == 0 else "instance"
     K = [64, 31, 16, 5][(seed // 2) % 4]
     p = field.init_params(seed=seed, table=level_table, table_std=1.0, K=K)
     fill = float(rng.choice([0.02, 0.2]))
-    bits = (rng.random(128 ** 3 // 8) < fill).astype(np.uint8) * rng.integers(1, 256, 128 ** 3 // 8).astype(np.uint8)
+    nb = C * H ** 3 // 8
+    bits = (rng.random(nb) < fill).astype(np.uint8) * rng.integers(1, 256, nb).astype(np.uint8)
     n = int(rng.choice([33, 90, 150]))
-    ro = rng.uniform(-0.8, 0.8, size=(n, 3)).astype(np.float32)
+    ro = (rng.uniform(-0.8, 0.8, size=(n, 3)) * bound).astype(np.float32)
     rd = rng.normal(size=(n, 3)).astype(np.float32)
     rd /= np.linalg.norm(rd, axis=1, keepdims=True)
     scale = float(rng.choice([0.3, 3.0]))
     gamma = float(rng.choice([0.0, 1.0 / 128]))
-    net = _network({k: v.clone() for k, v in p.items()}, K=K).train()
+    net = _network({k: v.clone() for k, v in p.items()}, K=K, bound=int(bound), grid_size=H, encoder_kwargs=enc_kw).train()
+    assert net.cascade == C
     net.density_bitfield.copy_(_t(bits))
     net.density_scale = scale
     trained = ("embeddings", "sigma_w0", "sigma_w1", "color_w0", "color_w1", "color_w2") if stage == "nerf" else \
@@ -1340,8 +1440,8 @@ def test_training_gradients_fuzz_against_the_oracle(level_table, seed):
         for q in list(net.instance_encoder.parameters()) + list(net.instance_net.parameters()):
             q.requires_grad_(False)
     q = {k: v.clone().requires_grad_(k in trained) for k, v in p.items()}
-    ref = render.render_train(ro, rd, q, level_table, bits, min_near=0.05, dt_gamma=gamma, max_steps=256,
-                              with_instance=stage == "instance", density_scale=scale)
+    ref = render.render_train(ro, rd, q, level_table, bits, bound=bound, cascade=C, H=H, min_near=0.05, dt_gamma=gamma,
+                              max_steps=256, with_instance=stage == "instance", density_scale=scale)
     out = net.render(_t(ro)[None], _t(rd)[None], bg_color=1, perturb=False, force_all_rays=True, dt_gamma=gamma,
                      max_steps=256)
     assert int(out["num_samples"][0]) == ref["total"] > 0
@@ -1368,6 +1468,21 @@ def test_training_gradients_fuzz_against_the_oracle(level_table, seed):
     for k in set(names) - set(trained):
         if names[k] in params:
             assert params[names[k]].grad is None, k
+
+
+@pytest.mark.parametrize("seed", _seeds(8))
+def test_training_gradients_fuzz_against_the_oracle(seed):
+    """Both training stages on random set-ups (occupancy, density scale, ray count, K, growing / constant steps, a
+    sample buffer that drops the last rays): loss and ALL gradients - table, sigma / colour nets or instance nets -
+    of the fused training kernels against torch autograd through the numpy/torch oracle."""
+    _gradient_fuzz_case(seed, varied=False)
+
+
+@pytest.mark.parametrize("seed", _seeds(8))
+def test_training_gradients_fuzz_over_bounds_and_level_tables(seed):
+    """The gradient fuzz off the tuned configuration (``_fuzz_volume(varied=True)``: bound 1 / 2 / 4, cascades, table
+    sizes, finest resolutions, 12 or 16 levels)."""
+    _gradient_fuzz_case(seed, varied=True)
 
 
 def test_training_batch_that_misses_the_volume(params_k16, room_bitfield):

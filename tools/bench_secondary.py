@@ -91,22 +91,25 @@ def collective_record(dev, rank, world, backend, red_dev, table_bytes=6119864 * 
 
 
 def train_probe(dev, rank=0, world=1, red_dev=None, steps=20, warmup=5, stage="instance", mode="eager", schedule=None,
-                fp16=False):
+                fp16=False, bound=1, dt_gamma=0.0):
     """Secondary measurement (not the headline value): instance-field training step, BASELINE configs[2]
     (K=64 logits, 4096 rays/batch per GPU, NeRF frozen): march -> frozen NeRF (fused) -> instance grid encode ->
     MLP -> K-channel compositing -> CE -> backward (atomic scatter) -> [gradient all-reduce] -> fused Adam.
     With world > 1 this is configs[3]: every rank draws its own rays, parameters are replicated and the
     gradients (49 MB hash table + MLP) are all-reduced over RCCL each step; all ranks must call it.
-    stage="nerf": the same loop for the NeRF itself (MSE on rgb; table + sigma/colour nets trained)."""
+    stage="nerf": the same loop for the NeRF itself (MSE on rgb; table + sigma/colour nets trained).
+    bound > 1 (round 5): the room enlarged `bound` times in a volume of 1 + log2(bound) occupancy cascades, level table up
+    to 2048 * bound, steps growing with dt_gamma - the configuration a real 3D-FRONT scene trains at under torch-ngp."""
+    import argparse
     import torch.distributed as dist
     from instance_nerf_amd.nerf import NeRFNetwork
     from instance_nerf_amd.nerf.provider import SyntheticRoomDataset
     from instance_nerf_amd.nerf.utils import Trainer, grad_sync as _grad_sync
     torch.manual_seed(0)                   # replicated initial parameters
-    net = NeRFNetwork(cuda_ray=True, bound=1, min_near=0.05, density_thresh=10,
+    net = NeRFNetwork(cuda_ray=True, bound=bound, min_near=0.05, density_thresh=10,
                       num_instances=64 if stage == "instance" else 0).to(dev)
-    ds = SyntheticRoomDataset(dev, num_rays=4096, num_instances=64, rank=rank)
-    net.density_bitfield.copy_(torch.from_numpy(ds.room.density_bitfield(128, 1.0)).to(dev))
+    ds = SyntheticRoomDataset(dev, num_rays=4096, num_instances=64, rank=rank, scale=float(bound))
+    net.density_bitfield.copy_(torch.from_numpy(ds.room.density_bitfield(128, float(bound))).to(dev))
     # mode "pipelined" (one process): Trainer(use_graph=True, look_ahead=True) - every step is ONE hipGraph replay that
     # also holds, forked off before the scatter, the parameter-independent head of the next batch on a second stream
     # (march; in the instance stage also the frozen NeRF's forward and the weight compositing)
@@ -117,6 +120,8 @@ def train_probe(dev, rank=0, world=1, red_dev=None, steps=20, warmup=5, stage="i
                  local_rank=rank, world_size=world, ema_decay=0.95,     # upstream's main scripts train with the EMA on
                  use_graph=piped, look_ahead=piped, shade_ahead=piped,
                  fp16=fp16)             # upstream's -O: the frozen NeRF of the instance stage with -O's numerics
+    if dt_gamma:
+        tr.opt = argparse.Namespace(dt_gamma=float(dt_gamma), max_steps=1024, T_thresh=1e-4)
     # Upstream's loop, occupancy update included: every 16 steps update_extra_state() queries the density of 128^3
     # (later 128^3 / 2) cells, refreshes the grid / bitfield and sets mean_count, which sizes the sample buffers of
     # the next 16 steps (no host sync inside a step).  The field is untrained here, so the grid it produces says
@@ -263,6 +268,9 @@ def train_probe(dev, rank=0, world=1, red_dev=None, steps=20, warmup=5, stage="i
     what = ("instance-field training step, K=64, 4096 rays/batch per GPU, NeRF frozen, parameter EMA 0.95 "
             f"(BASELINE configs[{2 if world == 1 else 3}])") if stage == "instance" else \
         "NeRF training step (MSE on rgb: hash table + sigma/colour nets, parameter EMA 0.95), 4096 rays/batch per GPU"
+    if bound != 1:
+        what += (f"; bound {bound}: room enlarged {bound}x, {net.cascade} occupancy cascades, finest level {2048 * bound}, "
+                 f"dt_gamma {dt_gamma:g}")
     return {"workload": what,
             "n_gpus": world, "ms_per_step": round(dt * 1e3, 3),
             # median / max of the steps' device-side times: one stalled step (a host hiccup, an allocator slow path, the
@@ -419,6 +427,59 @@ def instance_render_probe(dev, frames=8):
                          "max_abs_diff_logits": float((fast["instance"] - ref["instance"]).abs().max()),
                          "max_abs_logit": float(ref["instance"].abs().max())}
     return out
+
+
+def bound_render_probe(dev, bound=4, dt_gamma=1.0 / 128, frames=8):
+    """Secondary measurement (round-4 verdict item 1): the headline render off its tuned configuration - the synthetic
+    room enlarged `bound` times inside a bound-`bound` volume: 1 + log2(bound) occupancy cascades, level table up to
+    2048 * bound (13 of 16 levels hashed at bound 8), steps growing with the distance (dt_gamma) or constant (0).
+    Same loop as the headline's one-stream leg: 800x800 views through net.render (fused), events around the field kernel
+    on its stream.  Upstream init U(-1e-4, 1e-4) (transparent field: every marched sample is evaluated)."""
+    from instance_nerf_amd.nerf import NeRFNetwork
+    from instance_nerf_amd.nerf.utils import get_rays
+    from instance_nerf_amd.scene import RoomScene
+    torch.manual_seed(0)
+    net = NeRFNetwork(cuda_ray=True, bound=bound, min_near=0.05, density_thresh=10).to(dev).eval()
+    room = RoomScene(scale=float(bound))
+    net.density_bitfield.copy_(torch.from_numpy(room.density_bitfield(128, float(bound))).to(dev))
+    poses, intr, H, W = room.cameras()
+    pd = torch.from_numpy(poses).to(dev)
+    ev = []
+    inner = net.forward_table
+
+    def timed(*a, **kw):
+        st = torch.cuda.current_stream()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        out = inner(*a, **kw)
+        e1.record(st)
+        ev.append((e0, e1))
+        return out
+    net.forward_table = timed
+
+    def frame(v):
+        r = get_rays(pd[v:v + 1], intr, H, W, patch=4)
+        with torch.no_grad():
+            return net.render(r["rays_o"], r["rays_d"], bg_color=1, infer_mode="fused", dt_gamma=dt_gamma)
+    frame(0)
+    frame(1)
+    torch.cuda.synchronize()
+    ev.clear()
+    t0 = time.perf_counter()
+    counts = [frame(v % pd.shape[0])["num_samples"] for v in range(frames)]
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    n = sum(int(c[0]) for c in counts)
+    kms = sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1)
+    tb = net.encoder.table
+    return {"workload": f"render 800x800, sigma+rgb, room enlarged {bound}x in a bound-{bound} volume: {net.cascade} occupancy "
+                        f"cascades, levels 16 .. {int(tb['resolutions'][-1])} ({int(tb['hashed'].sum())} of 16 hashed, "
+                        f"T = {tb['total_rows']}), dt_gamma {dt_gamma:g}",
+            "ms_per_frame": round(dt / frames * 1e3, 3), "value": round(n / dt / 1e6, 1), "unit": "Msamples/s",
+            "samples_per_frame": n // frames, "field_kernel_ms": round(kms, 4),
+            "algorithmic_bytes_per_sample": BYTES_PER_SAMPLE,
+            "field_frac_of_hbm_peak": round(n / frames * BYTES_PER_SAMPLE / (kms / 1e3) / 1e9 / HBM_PEAK_GBS, 4),
+            "end_to_end_frac_of_hbm_peak": round(n * BYTES_PER_SAMPLE / dt / 1e9 / HBM_PEAK_GBS, 4)}
 
 
 def half_table_probe(dev, frames=8, mlp_fp16=False):
