@@ -202,7 +202,7 @@ __device__ __forceinline__ void wait_vmcnt() {
   if constexpr (N >= 0) __builtin_amdgcn_s_waitcnt((N & 0xF) | (0x7 << 4) | (0xF << 8) | ((N >> 4) << 14));
 }
 
-template <bool kFineHashed, bool kHalf = false, bool kPre = false>
+template <bool kFineHashed, bool kHalf = false>
 __device__ __forceinline__ void issue_gathers_impl(const LevelRec* __restrict__ my_recs, __amdgpu_buffer_rsrc_t rsrc,
                                                    float x0, float x1, float x2, Gathered& g) {
   const int q = (threadIdx.x >> 4) & 3;
@@ -229,7 +229,6 @@ __device__ __forceinline__ void issue_gathers_impl(const LevelRec* __restrict__ 
       g.c[li][k] = gather_row<kHalf>(rsrc, base + idx * 8u);
     }
   }
-  if constexpr (kPre) return;            // the fine levels arrive precomputed (k_grid_fine_slices)
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const LevelRec* rec = pair_recs + (i >> 1) * 4 + 2 + (i & 1);    // level 8 + 4p + i
@@ -264,11 +263,10 @@ __device__ __forceinline__ void issue_gathers_impl(const LevelRec* __restrict__ 
   }
 }
 
-template <bool kHalf = false, bool kPre = false>
+template <bool kHalf = false>
 __device__ __forceinline__ void issue_gathers(const LevelRec* __restrict__ my_recs, const bool (&all_hashed)[4],
                                               __amdgpu_buffer_rsrc_t rsrc, float x0, float x1, float x2, Gathered& g) {
-  if constexpr (kPre) issue_gathers_impl<true, kHalf, true>(my_recs, rsrc, x0, x1, x2, g);
-  else if (all_hashed[2] && all_hashed[3]) issue_gathers_impl<true, kHalf>(my_recs, rsrc, x0, x1, x2, g);
+  if (all_hashed[2] && all_hashed[3]) issue_gathers_impl<true, kHalf>(my_recs, rsrc, x0, x1, x2, g);
   else issue_gathers_impl<false, kHalf>(my_recs, rsrc, x0, x1, x2, g);
 }
 
@@ -287,7 +285,7 @@ __device__ __forceinline__ f32x2 row2(const u32x2 v) {
 // trilinear blend: weight = (wx*wy)*wz, accumulated with fma - coarse levels in corner order 0..7, fine levels as
 // (this side's corners in yz order) and then x side 0 + x side 1.
 // out[s], s = 0..7 <-> feature 16*(s>>2) + 4q + (s&3).
-template <bool kHalf = false, bool kPre = false>
+template <bool kHalf = false>
 __device__ __forceinline__ void blend(const Gathered& g, f32x4& lo, f32x4& hi) {
 #pragma unroll
   for (int li = 0; li < 2; ++li) {
@@ -304,7 +302,6 @@ __device__ __forceinline__ void blend(const Gathered& g, f32x4& lo, f32x4& hi) {
     lo[2 * li] = acc.x;
     lo[2 * li + 1] = acc.y;
   }
-  if constexpr (kPre) return;            // hi: the caller's precomputed fine features
   f32x2 part[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -764,10 +761,7 @@ struct NerfSave {
   float *enc, *h1, *so, *cin, *c1, *c2;
 };
 
-// kPre (table feed only; round 5, "XCD-sliced" frame path): the eight fine levels were evaluated by k_grid_fine_slices,
-// one level per XCD; `d` (unused by the table feed) then points to their features, float2 [8][m_pad], m_pad = M rounded
-// up to 32, and this kernel gathers the coarse slots only.
-template <bool kColor, bool kTable = false, int kSave = 0, bool kHalf = false, bool kFast = false, bool kPre = false>
+template <bool kColor, bool kTable = false, int kSave = 0, bool kHalf = false, bool kFast = false>
 __global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_nerf_fwd(const float* __restrict__ x, const float* __restrict__ d,
                                                                int64_t M, const int32_t* __restrict__ n_dev, float bound,
                                                                const float2* __restrict__ emb, uint32_t emb_bytes, GridDesc G,
@@ -830,23 +824,10 @@ __global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_nerf_fwd(cons
       Gathered g;
       uint32_t rec_off = (uint32_t)q * 4u * (uint32_t)sizeof(LevelRec);
       asm volatile("" : "+v"(rec_off));    // opaque per tile: keeps the records in LDS, not hoisted into VGPRs
-      float2 fine_a = make_float2(0.f, 0.f), fine_b = fine_a;
-      if constexpr (kPre) {                // lane q's fine levels 8+2q, 9+2q = slices 2q, 2q+1: two coalesced 8-byte loads
-        static_assert(!kPre || kTable, "the sliced feed is a variant of the table feed");
-        const float2* pre = reinterpret_cast<const float2*>(d);
-        const int64_t m_pad = (M + 31) & ~(int64_t)31, mm = valid ? m : n - 1;
-        typedef float v2f __attribute__((ext_vector_type(2)));
-        const v2f* prev = reinterpret_cast<const v2f*>(pre);
-        const v2f a = __builtin_nontemporal_load(prev + (int64_t)(2 * q) * m_pad + mm);
-        const v2f b = __builtin_nontemporal_load(prev + (int64_t)(2 * q + 1) * m_pad + mm);
-        fine_a = make_float2(a.x, a.y);
-        fine_b = make_float2(b.x, b.y);
-      }
-      issue_gathers<kHalf, kPre>(reinterpret_cast<const LevelRec*>(reinterpret_cast<const char*>(recs) + rec_off), all_hashed,
-                                 rsrc, me.x0, me.x1, me.x2, g);
+      issue_gathers<kHalf>(reinterpret_cast<const LevelRec*>(reinterpret_cast<const char*>(recs) + rec_off), all_hashed, rsrc,
+                           me.x0, me.x1, me.x2, g);
       __builtin_amdgcn_sched_barrier(0);   // all 32 gathers in flight before the first blend waits
-      blend<kHalf, kPre>(g, enc[0], enc[1]);
-      if constexpr (kPre) enc[1] = f32x4{fine_a.x, fine_a.y, fine_b.x, fine_b.y};
+      blend<kHalf>(g, enc[0], enc[1]);
     }
     if constexpr (!kTable) {               // the table feed comes from the marcher, which clamps to the volume
       if (me.oob) enc[0] = enc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -941,124 +922,6 @@ __global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_nerf_fwd(cons
     if (threadIdx.x == 0) dbg[2 * blockIdx.x] = probe_t0;
   }
 #endif
-}
-
-// ---- XCD-sliced fine levels (round 5) ---------------------------------------------------------------------------
-// Why: a hashed level is 2^19 rows x 8 B = 4 MiB - exactly one XCD's L2.  On the fine levels no two samples of a frame
-// share a cell, so each (sample, level) costs four 128-byte lines whatever the sample order, and the only cache that can
-// serve them is one that holds the WHOLE level.  The fused kernel lets every workgroup touch all 16 levels: up to 48 MB of
-// hashed levels behind each XCD's 4 MB, so at bound 4 (finest level 8192: even neighbouring pixels are cells apart on
-// ten levels) 12.4 of its 22 L2 requests per sample miss and the launch runs at the Infinity Cache's line rate - 58 G
-// lines/s of the 69 G/s tools/micro/level_xcd_bench.hip measures for random lines over eight levels, against 259 G/s when
-// every XCD gathers from ONE level (profiles/r05_NOTES.txt 1).  So the eight fine levels are evaluated by a pre-pass in
-// which workgroup b serves level 8 + (b & 7) for ALL samples (workgroup b runs on XCD b % 8), and the fused kernel
-// (k_nerf_fwd<.., kPre>) reads the 64 bytes per sample it leaves - streamed, coalesced - instead of issuing 16 of its 32
-// gathers.  Placement is speed only: any workgroup-to-XCD map gives the same numbers.
-// Lanes 2i, 2i+1 of a wave are the two x sides of sample i (the x-neighbour rows of a cell sit in one line 15 times
-// out of 16 and are requested by ONE instruction: one look-up).  Arithmetic = the fused kernel's fine slots, operation by
-// operation: weight (wy * wx) * wz, this side's four corners accumulated by fma in yz order, then side 0 + side 1.
-constexpr int kSliceThreads = 256;
-#ifndef INR_SLICE_TILES
-#define INR_SLICE_TILES 4
-#endif
-constexpr int kSliceTilesPerIter = INR_SLICE_TILES;     // 32-sample tiles a wave has in flight (4 loads per lane each)
-#ifndef INR_SLICE_ABL
-#define INR_SLICE_ABL 0          // profiling builds only (tools/build_probe.py): 1 = no stores, 4 = no nt hints
-#endif
-struct SliceX {
-  float x0, x1, x2;
-};
-__device__ __forceinline__ SliceX slice_load_x(const float* __restrict__ x01, int64_t m, int64_t M) {
-  const int64_t mm = m < M ? m : M - 1;
-  const float* p = x01 + mm * 3;
-#if INR_SLICE_ABL & 4
-  return SliceX{p[0], p[1], p[2]};
-#else
-  return SliceX{__builtin_nontemporal_load(p), __builtin_nontemporal_load(p + 1), __builtin_nontemporal_load(p + 2)};
-#endif
-}
-__global__ void __launch_bounds__(kSliceThreads) k_grid_fine_slices(const float* __restrict__ x01, int64_t M,
-                                                                    const float2* __restrict__ emb, uint32_t emb_bytes,
-                                                                    GridDesc G, float* __restrict__ pre) {
-  const int slice = blockIdx.x & 7, local = blockIdx.x >> 3, per = gridDim.x >> 3;
-  const int l = 8 + slice;
-  const float sc = G.scales[l];
-  const uint32_t m_ = G.mask[l], res1 = G.res1[l];
-  const bool h = m_ != 0;
-  const uint32_t base = G.offsets[l] * 8u, pa = h ? 2654435761u : res1, pb = h ? 805459861u : res1 * res1;
-  const uint32_t mask = h ? m_ : 0xFFFFFFFFu;
-  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)emb, 0, (int)emb_bytes, 0x00020000);
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const uint32_t side = (uint32_t)(lane & 1);
-  constexpr int kWaves = kSliceThreads / 64;
-  constexpr int kT = kSliceTilesPerIter;
-  const int64_t m_pad = (M + 31) & ~(int64_t)31;
-  const int64_t n_iter = (M + 32 * kT - 1) / (32 * kT);
-  const int64_t stride = (int64_t)per * kWaves;
-  float* __restrict__ out = pre + (int64_t)slice * m_pad * 2;
-  int64_t it = (int64_t)local * kWaves + w;
-  if (it >= n_iter) return;
-  // the NEXT iteration's coordinates are requested before this iteration's gathers go out: a wave never sits behind
-  // two memory round trips in a row (x01 comes from HBM / the Infinity Cache: it is streamed, 8 times - once per XCD)
-  SliceX cur[kT], nxt[kT];
-#pragma unroll
-  for (int t = 0; t < kT; ++t) cur[t] = slice_load_x(x01, (it * kT + t) * 32 + (lane >> 1), M);
-  for (; it < n_iter; it += stride) {
-    const bool more = it + stride < n_iter;
-    if (more) {
-#pragma unroll
-      for (int t = 0; t < kT; ++t) nxt[t] = slice_load_x(x01, ((it + stride) * kT + t) * 32 + (lane >> 1), M);
-    }
-    u32x2 rows[kT][4];
-    float wx[kT], fy[kT], fz[kT];
-#pragma unroll
-    for (int t = 0; t < kT; ++t) {
-      const float px = cur[t].x0 * sc + 0.5f, py = cur[t].x1 * sc + 0.5f, pz = cur[t].x2 * sc + 0.5f;   // mul, add: not fused
-      const float fx = __builtin_amdgcn_fractf(px);
-      wx[t] = side ? fx : 1.0f - fx;
-      fy[t] = __builtin_amdgcn_fractf(py); fz[t] = __builtin_amdgcn_fractf(pz);
-      const uint32_t c = (uint32_t)px + side, cy = (uint32_t)py, cz = (uint32_t)pz;
-      const uint32_t hy0 = cy * pa, hy1 = hy0 + pa;
-      const uint32_t hz0 = cz * pb, hz1 = hz0 + pb;
-      const uint32_t yz[4] = {h ? (hy0 ^ hz0) : (hy0 + hz0), h ? (hy1 ^ hz0) : (hy1 + hz0),
-                              h ? (hy0 ^ hz1) : (hy0 + hz1), h ? (hy1 ^ hz1) : (hy1 + hz1)};
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const uint32_t idx = (h ? (c ^ yz[k]) : (c + yz[k])) & mask;
-#if INR_SLICE_ABL & 8
-        const float2 gv = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(emb) + (size_t)(base + idx * 8u));
-        rows[t][k][0] = __float_as_uint(gv.x); rows[t][k][1] = __float_as_uint(gv.y);
-#else
-        rows[t][k] = gather_row<false>(rsrc, base + idx * 8u);
-#endif
-      }
-    }
-#pragma unroll
-    for (int t = 0; t < kT; ++t) {
-      const f32x2 wy = {1.0f - fy[t], fy[t]};
-      const f32x2 xy = wy * wx[t];
-      const f32x2 w0 = xy * (1.0f - fz[t]), w1 = xy * fz[t];
-      f32x2 acc = {0.f, 0.f};
-      acc = __builtin_elementwise_fma(w0.xx, row2<false>(rows[t][0]), acc);
-      acc = __builtin_elementwise_fma(w0.yy, row2<false>(rows[t][1]), acc);
-      acc = __builtin_elementwise_fma(w1.xx, row2<false>(rows[t][2]), acc);
-      acc = __builtin_elementwise_fma(w1.yy, row2<false>(rows[t][3]), acc);
-      const float ox = __shfl_xor(acc.x, 1), oy = __shfl_xor(acc.y, 1);
-      const float v = side ? acc.y + oy : acc.x + ox;          // both lanes hold side 0 + side 1; lane `side` stores feature `side`
-      const int64_t m = (it * kT + t) * 32 + (lane >> 1);
-#if INR_SLICE_ABL & 1
-      if (m < M && v == 12345.678f) out[m * 2 + side] = v;
-#elif INR_SLICE_ABL & 4
-      if (m < M) out[m * 2 + side] = v;
-#else
-      if (m < M) __builtin_nontemporal_store(v, out + m * 2 + side);
-#endif
-    }
-    if (more) {
-#pragma unroll
-      for (int t = 0; t < kT; ++t) cur[t] = nxt[t];
-    }
-  }
 }
 
 // ---- rgb-sigma lattice extraction (BASELINE configs[4]) ---------------------------------------
@@ -2333,6 +2196,9 @@ static bool stream_is_capturing(hipStream_t s) {
   hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
   return hipStreamIsCapturing(s, &st) == hipSuccess && st != hipStreamCaptureStatusNone;
 }
+// Never called while `s` is capturing (round-4 advisor): a graph would bake ONE ring slot and its memset into every
+// replay, with no event protection - an eager launch on another stream that draws the same slot could re-zero the cursors
+// under the running replay (tiles skipped or duplicated, no error).  Captured launches take the static deal instead.
 static StealSet steal_cursors(hipStream_t s) {
   static std::atomic<unsigned> turn{0};
   StealSet out;
@@ -2482,7 +2348,7 @@ int inr_nerf_forward(const float* x, const float* d, int64_t M, const int32_t* n
   const int64_t n_tiles = (M + 15) / 16;
   // frames and occupancy sweeps (four rounds of eight 1024-tile chunks and more): hybrid schedule, see TileWalk
   StealSet steal_set;
-  if ((n_tiles >> (kXcdChunkLog2 + 3)) >= 4) {
+  if ((n_tiles >> (kXcdChunkLog2 + 3)) >= 4 && !stream_is_capturing(as_stream(s))) {   // captured: static deal, see steal_cursors
     steal_set = steal_cursors(as_stream(s));
     if (!steal_set.cursors) return INR_ELAUNCH;
   }
@@ -2542,7 +2408,7 @@ static int launch_nerf_table(const float* x01, const int32_t* ray_ids, const flo
   const int grid = grid_for(k_nerf_fwd<true, true, 0, kHalf, kFast>, lds, (M + 15) / 16);
   // frames (four rounds of eight 1024-tile chunks and more) take the hybrid schedule: its cursors, zeroed on this stream
   StealSet steal_set;
-  if ((((M + 15) / 16) >> (kXcdChunkLog2 + 3)) >= 4) {
+  if ((((M + 15) / 16) >> (kXcdChunkLog2 + 3)) >= 4 && !stream_is_capturing(as_stream(s))) {
     steal_set = steal_cursors(as_stream(s));
     if (!steal_set.cursors) return INR_ELAUNCH;
   }
@@ -2581,128 +2447,6 @@ static int nerf_forward_table_impl(const float* x01, const int32_t* ray_ids, con
   return half ? INR_TABLE_LAUNCH(true, false) : INR_TABLE_LAUNCH(false, false);
 #endif
 #undef INR_TABLE_LAUNCH
-}
-
-// ---- XCD-sliced frame path: pre-pass over the fine levels + fused kernel on the coarse ones --------------------------
-int64_t inr_nerf_forward_table_sliced_workspace_bytes(int64_t M) {
-  return M < 0 ? -1 : 8 * ((M + 31) & ~(int64_t)31) * (int64_t)sizeof(float2);
-}
-
-// side stream + events of the chunked schedule, one set per device, created on first use
-struct SliceSide {
-  hipStream_t side = nullptr;
-  hipEvent_t fork = nullptr, pre_done[2] = {nullptr, nullptr}, fused_done[2] = {nullptr, nullptr};
-  bool ok = false;
-};
-static SliceSide g_slice_side[64];
-static std::mutex g_slice_mu;
-static SliceSide* slice_side() {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-  std::lock_guard<std::mutex> lock(g_slice_mu);
-  SliceSide& S = g_slice_side[dev];
-  if (!S.ok) {
-    bool ok = hipStreamCreateWithFlags(&S.side, hipStreamNonBlocking) == hipSuccess &&
-              hipEventCreateWithFlags(&S.fork, hipEventDisableTiming) == hipSuccess;
-    for (int i = 0; i < 2 && ok; ++i)
-      ok = hipEventCreateWithFlags(&S.pre_done[i], hipEventDisableTiming) == hipSuccess &&
-           hipEventCreateWithFlags(&S.fused_done[i], hipEventDisableTiming) == hipSuccess;
-    if (!ok) {
-      set_error("sliced frame path: could not create the side stream / events");
-      return nullptr;
-    }
-    S.ok = true;
-  }
-  return &S;
-}
-
-static int g_slice_default_chunks = 1;
-
-int inr_nerf_forward_table_sliced(const float* x01, const int32_t* ray_ids, const float* sh_table_q, int64_t M, float bound,
-                                  const float* embeddings, const inr_grid_desc* desc, const float* packed,
-                                  float density_scale, float* sigma, float* rgb, float* fine_ws, int32_t n_chunks,
-                                  inr_stream_t s) {
-  INR_REQUIRE(M >= 0 && desc && n_chunks >= 0, "bad argument");
-  if (M == 0) return INR_OK;
-  INR_REQUIRE(x01 && ray_ids && sh_table_q && embeddings && packed && sigma && rgb && fine_ws, "null pointer");
-  INR_REQUIRE(((uintptr_t)embeddings & 7) == 0 && ((uintptr_t)packed & 15) == 0 && ((uintptr_t)sh_table_q & 15) == 0 &&
-              ((uintptr_t)fine_ws & 7) == 0, "embeddings/packed/sh_table_q/fine_ws misaligned");
-  INR_REQUIRE(desc->num_levels == 16, "the sliced frame path needs the 16-level table (fine slots = levels 8..15)");
-  GridDesc G;
-  int rc = make_grid_desc(desc, G);
-  if (rc) return rc;
-  const uint64_t emb_bytes64 = (uint64_t)desc->offsets[desc->num_levels] * 8ull;
-  INR_REQUIRE(emb_bytes64 < (1ull << 31), "table larger than 2 GiB is not addressable by the 32-bit gather offsets");
-  const uint32_t eb = (uint32_t)emb_bytes64;
-  const float2* e = reinterpret_cast<const float2*>(embeddings);
-  const size_t lds = std::max(kNerfFloats * sizeof(float) + kLevelRecBytes, (size_t)g_field_lds_min);
-  hipStream_t st = as_stream(s);
-  if (n_chunks == 0) n_chunks = g_slice_default_chunks;
-  // chunk boundaries on multiples of 32 samples: a chunk's slices are then a contiguous run of every level's array
-  const int64_t per = ((M + n_chunks - 1) / n_chunks + 1023) & ~(int64_t)1023;
-  const int chunks = (int)((M + per - 1) / per);
-  const bool overlap = chunks > 1 && !stream_is_capturing(st);
-  SliceSide* S = overlap ? slice_side() : nullptr;
-  if (overlap && !S) return INR_ELAUNCH;
-  const int64_t m_pad = (M + 31) & ~(int64_t)31;
-  const int cus = cu_count();
-
-  auto pre_pass = [&](int64_t lo, int64_t n, hipStream_t on) {
-    // the chunk's rows of all eight level arrays: the kernel indexes slices by ITS m_pad = n rounded up, so a chunk gets
-    // its own compact [8][n_pad] block of the workspace (block k starts at 8 * lo: the blocks of earlier chunks are full)
-    const int64_t want = (n + 32 * kSliceTilesPerIter * (kSliceThreads / 64) - 1) / (32 * kSliceTilesPerIter * (kSliceThreads / 64));
-    static int fit = 0;                    // resident workgroups per CU (a constant of the build)
-    if (fit < 1 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, k_grid_fine_slices, kSliceThreads, 0) != hipSuccess || fit < 1))
-      fit = 4;
-    static const int env_per_cu = getenv("INR_SLICE_PRE_PER_CU") ? atoi(getenv("INR_SLICE_PRE_PER_CU")) : 0;
-    const int per_cu = overlap ? (env_per_cu > 0 ? std::min(env_per_cu, fit) : std::min(3, fit)) : fit;
-    // a multiple of 8: workgroup b serves level 8 + (b & 7); every level gets the same number of workgroups
-    // chunked schedule: the pre-pass shares every CU with one workgroup of the fused kernel (8 waves, <= 112 VGPRs each:
-    // 224 of a SIMD's 512) - three workgroups of four waves (76 VGPRs) fit beside it, a full house would lock it out
-    const int grid = (int)std::max<int64_t>(8, std::min<int64_t>(want * 8, (int64_t)cus * per_cu / 8 * 8));
-    k_grid_fine_slices<<<grid, kSliceThreads, 0, on>>>(x01 + lo * 3, n, e, eb, G, fine_ws + 8 * lo * 2);
-  };
-  auto fused = [&](int64_t lo, int64_t n) -> int {
-    const int grid = grid_for(k_nerf_fwd<true, true, 0, false, false, true>, lds, (n + 15) / 16);
-    StealSet steal_set;
-    if ((((n + 15) / 16) >> (kXcdChunkLog2 + 3)) >= 4 && !stream_is_capturing(st)) {
-      steal_set = steal_cursors(st);
-      if (!steal_set.cursors) return INR_ELAUNCH;
-    }
-    k_nerf_fwd<true, true, 0, false, false, true><<<grid, kFieldThreads, lds, st>>>(
-        x01 + lo * 3, fine_ws + 8 * lo * 2, n, nullptr, bound, e, eb, G, reinterpret_cast<const float4*>(packed),
-        density_scale, sigma + lo, rgb + lo * 3, nullptr, ray_ids + lo, reinterpret_cast<const float4*>(sh_table_q), NerfSave{},
-        steal_set.cursors);
-    steal_release(steal_set, st);
-    return (int)INR_OK;
-  };
-  (void)m_pad;
-  if (!overlap) {
-    for (int c = 0; c < chunks; ++c) {
-      const int64_t lo = (int64_t)c * per, n = std::min(per, M - lo);
-      pre_pass(lo, n, st);
-      if ((rc = fused(lo, n)) != INR_OK) return rc;
-    }
-    return check_launch("nerf_forward_table_sliced");
-  }
-  // chunked: pre-pass k+1 on the side stream beside fused kernel k.  The side stream starts behind everything queued on
-  // `s` so far (fork), every fused kernel waits for its chunk's pre-pass, and `s` ends behind the last one: to the caller
-  // the call is ordered on `s` like any other launch.  Each chunk has its own block of the workspace, so nothing is
-  // overwritten while it may still be read.
-  if (hipEventRecord(S->fork, st) != hipSuccess || hipStreamWaitEvent(S->side, S->fork, 0) != hipSuccess) {
-    set_error("sliced frame path: fork failed");
-    return INR_ELAUNCH;
-  }
-  for (int c = 0; c < chunks; ++c) {
-    const int64_t lo = (int64_t)c * per, n = std::min(per, M - lo);
-    pre_pass(lo, n, S->side);
-    if (hipEventRecord(S->pre_done[c & 1], S->side) != hipSuccess || hipStreamWaitEvent(st, S->pre_done[c & 1], 0) != hipSuccess) {
-      set_error("sliced frame path: join failed");
-      return INR_ELAUNCH;
-    }
-    if ((rc = fused(lo, n)) != INR_OK) return rc;
-  }
-  return check_launch("nerf_forward_table_sliced");
 }
 
 int inr_nerf_forward_dirs(const float* x, int64_t M, float bound, const float* embeddings, const inr_grid_desc* desc,

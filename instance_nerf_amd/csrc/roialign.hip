@@ -251,6 +251,9 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #ifndef SEP_NT_STORE
 #define SEP_NT_STORE 1
 #endif
+#ifndef SEP_BWD_PROBE
+#define SEP_BWD_PROBE 0
+#endif
 #ifndef SEP_RUN_BARRIER
 #define SEP_RUN_BARRIER 0
 #endif
@@ -588,10 +591,16 @@ __global__ void __launch_bounds__(SEP_THREADS) k_roi_align3d_sep_bwd(const float
           a.x += w * v.x; a.y += w * v.y; a.z += w * v.z; a.w += w * v.w;
         }
         float* dst = vol0 + (int64_t)c * WLH + ((x0 + xs + x) * L + (y0 + y)) * H + cell;
+#if SEP_BWD_PROBE == 1       // profiling builds only: plain stores (wrong results) - what do the atomics cost?
+        dst[0] = a.x; dst[WLH] = a.y; dst[2 * WLH] = a.z; dst[3 * WLH] = a.w;
+#elif SEP_BWD_PROBE == 2     // no global writes at all
+        if (a.x == 12345.678f) dst[0] = a.x + a.y + a.z + a.w;
+#else
         atomicAdd(dst, a.x);
         if (c + 1 < cend) atomicAdd(dst + WLH, a.y);
         if (c + 2 < cend) atomicAdd(dst + 2 * WLH, a.z);
         if (c + 3 < cend) atomicAdd(dst + 3 * WLH, a.w);
+#endif
       }
       // t2 is rewritten by the next slab's first pass while slow waves may still read t1 here, never t2: fine; t1 is
       // rewritten after that pass's barrier

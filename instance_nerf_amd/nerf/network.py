@@ -465,9 +465,6 @@ class NeRFNetwork(NeRFRenderer):
         # activations rounded to fp16, fp32 accumulation) instead of the three-pass bf16 split that keeps the default
         # fp32-class.  Outputs within a few 1e-3 of the default's; training and every other path are unaffected.
         self.mlp_fp16 = False
-        # Frame path: 0 = the one-kernel fused field; n >= 1 = XCD-sliced (fine levels by a per-XCD pre-pass, n chunks with
-        # the pre-pass of chunk k+1 beside the fused kernel of chunk k); see inr_nerf_forward_table_sliced
-        self.frame_slices = int(__import__("os").environ.get("INR_FRAME_SLICES", "0"))
 
     # ---- packed MFMA weights (cached until a weight tensor changes) ------------------------------
     def _packed_weights(self, which):
@@ -611,16 +608,6 @@ class NeRFNetwork(NeRFRenderer):
                                                   self.encoder.desc, ptr(self._packed_weights("nerf")), 1.0,
                                                   ptr(sigma, allow_none=M == 0), ptr(rgb, allow_none=M == 0), stream_ptr()),
                   "nerf_forward_table_half")
-            return sigma, rgb
-        if self.frame_slices and M and int(self.encoder.desc.num_levels) == 16:
-            # XCD-sliced frame path (round 5): the eight fine levels by a pre-pass in which every XCD serves one level
-            # (its L2 then holds that level whole), the fused kernel on the coarse levels; same numbers bit for bit
-            ws = torch.empty(lib.inr_nerf_forward_table_sliced_workspace_bytes(M) // 4, dtype=torch.float32, device=dev)
-            check(lib.inr_nerf_forward_table_sliced(ptr(x01, torch.float32, "x01"), ptr(ray_ids, torch.int32, "ray_ids"),
-                                                    ptr(shq), M, float(self.bound),
-                                                    ptr(self.encoder.embeddings.data, torch.float32), self.encoder.desc,
-                                                    ptr(self._packed_weights("nerf")), 1.0, ptr(sigma), ptr(rgb), ptr(ws),
-                                                    int(self.frame_slices), stream_ptr()), "nerf_forward_table_sliced")
             return sigma, rgb
         check(lib.inr_nerf_forward_table(ptr(x01, torch.float32, "x01", allow_none=M == 0),
                                          ptr(ray_ids, torch.int32, "ray_ids", allow_none=M == 0), ptr(shq), M,

@@ -1210,7 +1210,7 @@ def test_full_size_frame_at_bound4_against_the_c_oracle(rm):
     net = _network(p, K=0, bound=int(bound)).eval()
     assert net.cascade == C and (net.encoder.table["offsets"] == table["offsets"]).all()
     net.density_bitfield.copy_(_t(bits))
-    net.density_scale = 0.25            # table U(-1,1) at 4x the path length: keep the rays semi-transparent
+    net.density_scale = 1.0             # table U(-1,1), steps growing with t: mean opacity ~0.4 (semi-transparent rays)
     poses, intr, Hi, Wi = big.cameras()
     aabb = [-bound] * 3 + [bound] * 3
     r = get_rays(_t(poses[2:3]), intr, Hi, Wi)
@@ -1233,9 +1233,9 @@ def test_full_size_frame_at_bound4_against_the_c_oracle(rm):
     with torch.no_grad():
         out = net.render(r["rays_o"], r["rays_d"], bg_color=1, infer_mode="fused", dt_gamma=1 / 128)
     c = c_port.render(r["rays_o"][0].cpu().numpy(), r["rays_d"][0].cpu().numpy(), p, table, bits, bound=bound, cascade=C,
-                      H=H, min_near=0.05, dt_gamma=1 / 128, density_scale=0.25, absolute_depth=True)
+                      H=H, min_near=0.05, dt_gamma=1 / 128, density_scale=1.0, absolute_depth=True)
     assert int(out["num_samples"][0]) == c["total"] > 10_000_000
-    assert 0.2 < float(c["weights_sum"].mean()) < 0.98
+    assert 0.15 < float(c["weights_sum"].mean()) < 0.98
     assert np.abs(out["image"][0].cpu().numpy() - c["image"]).max() < 1e-4
     assert np.abs(out["weights_sum"][0].cpu().numpy() - c["weights_sum"]).max() < 1e-4
     assert np.abs(out["depth"][0].cpu().numpy() - c["depth"]).max() < 1e-4
@@ -1243,7 +1243,7 @@ def test_full_size_frame_at_bound4_against_the_c_oracle(rm):
     pick = torch.from_numpy(np.sort(np.random.default_rng(23).choice(Hi * Wi, size=30000, replace=False))).to(DEV)
     r = get_rays(_t(poses[5:6]), intr, Hi, Wi, inds=pick)
     c = c_port.render(r["rays_o"][0].cpu().numpy(), r["rays_d"][0].cpu().numpy(), p, table, bits, bound=bound, cascade=C,
-                      H=H, min_near=0.05, dt_gamma=0.0, density_scale=0.25, absolute_depth=True)
+                      H=H, min_near=0.05, dt_gamma=0.0, density_scale=1.0, absolute_depth=True)
     for mode in ("fused", "fused_terminate"):
         with torch.no_grad():
             out = net.render(r["rays_o"], r["rays_d"], bg_color=1, infer_mode=mode, dt_gamma=0)

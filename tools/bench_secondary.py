@@ -429,6 +429,25 @@ def instance_render_probe(dev, frames=8):
     return out
 
 
+BOUND_TRAFFIC_JSON = os.path.join("profiles", "r05_bound_traffic.json")
+
+
+def bound_traffic(bound, dt_gamma):
+    """Fabric read requests per sample of the fused field kernel at this configuration, from the committed PMC profile
+    (profiles/r05_bound_traffic.json: tools/pmc_bound.sh + tools/bound_traffic_json.py); quoted only for the kernel sources
+    it was measured on.  -> (record of the configuration, random-line rate of the fabric in requests/s) or None."""
+    from instance_nerf_amd import build
+    path = os.path.join(ROOT, BOUND_TRAFFIC_JSON)
+    if not os.path.exists(path):
+        return None
+    t = json.load(open(path))
+    if t.get("source_sha") != build.source_sha():
+        return None
+    key = f"{bound}:{bound}:{int(round(1 / dt_gamma)) if dt_gamma else 0}:0:0"
+    rec = t["configs"].get(key)
+    return None if rec is None else (rec, float(t["random_line_rate_of_the_fabric_g_per_s"]) * 1e9)
+
+
 def bound_render_probe(dev, bound=4, dt_gamma=1.0 / 128, frames=8):
     """Secondary measurement (round-4 verdict item 1): the headline render off its tuned configuration - the synthetic
     room enlarged `bound` times inside a bound-`bound` volume: 1 + log2(bound) occupancy cascades, level table up to
@@ -472,7 +491,21 @@ def bound_render_probe(dev, bound=4, dt_gamma=1.0 / 128, frames=8):
     n = sum(int(c[0]) for c in counts)
     kms = sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1)
     tb = net.encoder.table
-    return {"workload": f"render 800x800, sigma+rgb, room enlarged {bound}x in a bound-{bound} volume: {net.cascade} occupancy "
+    # what binds the kernel off the tuned configuration is not the algorithmic byte count but the number of 128-byte
+    # fabric requests its L2 misses cause (profiles/r05_NOTES.txt 1-2): both fractions side by side
+    fabric = None
+    bt = bound_traffic(bound, dt_gamma)
+    if bt is not None and kms > 0:
+        rec, ceiling = bt
+        req_s = rec["fabric_read_requests_per_sample"] * (n / frames) / (kms / 1e3)
+        fabric = {"requests_per_sample": rec["fabric_read_requests_per_sample"], "bytes_per_sample": rec["fabric_read_bytes_per_sample"],
+                  "l2_hit_rate": rec["l2_hit_rate"], "achieved_g_requests_per_s": round(req_s / 1e9, 1),
+                  "traffic_gb_per_s": round(req_s * 128 / 1e9, 1), "ceiling_g_requests_per_s": round(ceiling / 1e9, 1),
+                  "frac": round(req_s / ceiling, 4),
+                  "source": BOUND_TRAFFIC_JSON + " (rocprofv3 PMC on these kernel sources, view 0; ceiling: random 128-byte lines "
+                                                 "over eight 4 MiB levels, tools/micro/level_xcd_bench.hip)"}
+    return {"fabric_requests": fabric,
+            "workload": f"render 800x800, sigma+rgb, room enlarged {bound}x in a bound-{bound} volume: {net.cascade} occupancy "
                         f"cascades, levels 16 .. {int(tb['resolutions'][-1])} ({int(tb['hashed'].sum())} of 16 hashed, "
                         f"T = {tb['total_rows']}), dt_gamma {dt_gamma:g}",
             "ms_per_frame": round(dt / frames * 1e3, 3), "value": round(n / dt / 1e6, 1), "unit": "Msamples/s",

@@ -5,7 +5,7 @@ TAG=${1:-pmcbound}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 export TMPDIR=/tmp
 cd /tmp
-for CFG in 1:1:0:0:0 4:4:0:0:0 4:4:128:0:0; do
+for CFG in 1:1:0:0:0 2:2:128:0:0 4:4:0:0:0 4:4:128:0:0; do
   D=$R/gpurun_out/$TAG/$(echo $CFG | tr ':' '_')
   run() {
     name=$1; shift
@@ -21,3 +21,4 @@ for CFG in 1:1:0:0:0 4:4:0:0:0 4:4:128:0:0; do
   echo "== $CFG"; grep -h "field" $D.tcc.log | tail -1
   python3 $R/tools/pmc_summary.py $D k_nerf_fwd
 done
+python3 $R/tools/bound_traffic_json.py $R/gpurun_out/$TAG $R/gpurun_out/$TAG.bound_traffic.json > /dev/null
