@@ -335,6 +335,20 @@ __global__ void __launch_bounds__(SEP_THREADS) k_roi_align3d_sep_fwd(const float
 #pragma unroll
   for (int j = 0; j < 4; ++j) wz[j] = (jz + j >= fz && jz + j <= lz) ? T[2][ph1 * H + jz + j] : 0.0f;
   const bool morez = lz >= jz + 4;
+  // Round-4 advisor: a window cell that NO sample of this RoI touches (before z0 when the window is pulled back from the
+  // end of the row, behind z1 for the last output index) was multiplied by a zero weight - 0 x Inf = NaN where the
+  // lane-per-output kernel, the oracle and torchvision never read the voxel.  Such cells are masked to +0 before the
+  // multiply (four ANDs per row and channel, taken only by the threads whose window leaves [z0, z1]); cells INSIDE
+  // the sampled region still meet zero weights of the output indices that do not reach them: a non-finite voxel inside
+  // a RoI's region poisons that RoI's outputs along the row, as it poisons the ones that sample it anyway.
+  uint32_t zm[4];
+  bool maskz = false;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const bool in = jz + j >= z0 && jz + j <= R->hi[2];
+    zm[j] = in ? 0xFFFFFFFFu : 0u;
+    maskz = maskz || !in;
+  }
 
   // ---- y role: (pl, ph), plane slot
   const int NS2 = SEP_THREADS / olh;
@@ -394,6 +408,10 @@ __global__ void __launch_bounds__(SEP_THREADS) k_roi_align3d_sep_fwd(const float
         u32x4 q[SEP_CH];
 #pragma unroll
         for (int ch = 0; ch < SEP_CH; ++ch) q[ch] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff[ch], 0);
+        if (maskz) {
+#pragma unroll
+          for (int ch = 0; ch < SEP_CH; ++ch) { q[ch].x &= zm[0]; q[ch].y &= zm[1]; q[ch].z &= zm[2]; q[ch].w &= zm[3]; }
+        }
         f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
         fma4(a, wz[0], f32x4{__uint_as_float(q[0].x), __uint_as_float(q[1].x), __uint_as_float(q[2].x), __uint_as_float(q[3].x)});
         fma4(a, wz[1], f32x4{__uint_as_float(q[0].y), __uint_as_float(q[1].y), __uint_as_float(q[2].y), __uint_as_float(q[3].y)});
@@ -531,20 +549,59 @@ __global__ void __launch_bounds__(SEP_THREADS) k_roi_align3d_sep_bwd(const float
   XB = max(1, min(XB, sx));
   lfloat4* t2 = go + nout;
   lfloat4* t1 = t2 + XB * olh;
-  const float inv_oh = 1.0f / (float)oh, inv_sy = 1.0f / (float)sy, inv_olh = 1.0f / (float)olh,
-              inv_sz = 1.0f / (float)sz;
+  // integer division in the index decodes below (round-4 advisor: the float-reciprocal fdiv() is exact only for small
+  // operands, and nothing bounds the extents here - L, H up to what the LDS window holds)
   const float* gbase = gout + ((int64_t)k * A.C) * nout;
   float* vol0 = gin + ((int64_t)roi_inds[k] * A.C) * WLH;
 
-  for (int c = c0; c < cend; c += SEP_CH) {
-    for (int o = t; o < nout; o += SEP_THREADS) {
+  // The gout values of the NEXT channel run are requested before this run's passes (round 5): the kernel is a chain of
+  // dependent steps per run - global read, barrier, three LDS passes - and the read used to start only when the
+  // previous run had finished.  Up to GOP elements per thread ride in registers (outputs up to 1024 elements: 10^3); larger
+  // outputs read in place as before.
+  constexpr int GOP = 4;
+  const bool pre_ok = nout <= GOP * SEP_THREADS;
+  f32x4 gnext[GOP];
+  auto go_request = [&](int c) {
+#pragma unroll
+    for (int i = 0; i < GOP; ++i) {
+      const int o = min(t + i * SEP_THREADS, nout - 1);
       const float* src = gbase + (int64_t)c * nout + o;
       f32x4 g;
-      g.x = src[0] * inv_count;
-      g.y = c + 1 < cend ? src[nout] * inv_count : 0.0f;
-      g.z = c + 2 < cend ? src[2 * (int64_t)nout] * inv_count : 0.0f;
-      g.w = c + 3 < cend ? src[3 * (int64_t)nout] * inv_count : 0.0f;
-      go[o] = g;
+      g.x = src[0];
+      g.y = src[(int64_t)min(1, cend - 1 - c) * nout];
+      g.z = src[(int64_t)min(2, cend - 1 - c) * nout];
+      g.w = src[(int64_t)min(3, cend - 1 - c) * nout];
+      gnext[i] = g;
+      if ((i + 1) * SEP_THREADS >= nout) break;
+    }
+  };
+  if (pre_ok) go_request(c0);
+  for (int c = c0; c < cend; c += SEP_CH) {
+    if (pre_ok) {
+#pragma unroll
+      for (int i = 0; i < GOP; ++i) {
+        const int o = t + i * SEP_THREADS;
+        if (o < nout) {
+          f32x4 g = gnext[i];
+          g.x *= inv_count;
+          g.y = c + 1 < cend ? g.y * inv_count : 0.0f;
+          g.z = c + 2 < cend ? g.z * inv_count : 0.0f;
+          g.w = c + 3 < cend ? g.w * inv_count : 0.0f;
+          go[o] = g;
+        }
+        if ((i + 1) * SEP_THREADS >= nout) break;
+      }
+      if (c + SEP_CH < cend) go_request(c + SEP_CH);
+    } else {
+      for (int o = t; o < nout; o += SEP_THREADS) {
+        const float* src = gbase + (int64_t)c * nout + o;
+        f32x4 g;
+        g.x = src[0] * inv_count;
+        g.y = c + 1 < cend ? src[nout] * inv_count : 0.0f;
+        g.z = c + 2 < cend ? src[2 * (int64_t)nout] * inv_count : 0.0f;
+        g.w = c + 3 < cend ? src[3 * (int64_t)nout] * inv_count : 0.0f;
+        go[o] = g;
+      }
     }
     __syncthreads();
     for (int xs = 0; xs < sx; xs += XB) {
@@ -552,7 +609,7 @@ __global__ void __launch_bounds__(SEP_THREADS) k_roi_align3d_sep_bwd(const float
       // ---- x^T: t2[x][pl][ph] = sum_pw Tx[pw][x] * go[pw][pl][ph]
       const int n2 = nx * olh;
       for (int item = t; item < n2; item += SEP_THREADS) {
-        const int x = fdiv(item, inv_olh), r = item - x * olh;
+        const int x = item / olh, r = item - x * olh;
         const int cell = x0 + xs + x;
         f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int p = pfirst[0][cell]; p <= plast[0][cell]; ++p) {
@@ -566,8 +623,8 @@ __global__ void __launch_bounds__(SEP_THREADS) k_roi_align3d_sep_bwd(const float
       // ---- y^T: t1[x][y][ph] = sum_pl Ty[pl][y] * t2[x][pl][ph]
       const int n1 = nx * sy * oh;
       for (int item = t; item < n1; item += SEP_THREADS) {
-        const int row = fdiv(item, inv_oh), ph = item - row * oh;
-        const int x = fdiv(row, inv_sy), y = row - x * sy;
+        const int row = item / oh, ph = item - row * oh;
+        const int x = row / sy, y = row - x * sy;
         const int cell = y0 + y;
         f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int p = pfirst[1][cell]; p <= plast[1][cell]; ++p) {
@@ -581,8 +638,8 @@ __global__ void __launch_bounds__(SEP_THREADS) k_roi_align3d_sep_bwd(const float
       // ---- z^T: grad_input[x][y][z] += sum_ph Tz[ph][z] * t1[x][y][ph]
       const int n0 = nx * sy * sz;
       for (int item = t; item < n0; item += SEP_THREADS) {
-        const int row = fdiv(item, inv_sz), z = item - row * sz;
-        const int x = fdiv(row, inv_sy), y = row - x * sy;
+        const int row = item / sz, z = item - row * sz;
+        const int x = row / sy, y = row - x * sy;
         const int cell = z0 + z;
         f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int p = pfirst[2][cell]; p <= plast[2][cell]; ++p) {
