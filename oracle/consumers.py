@@ -69,3 +69,67 @@ def level_mapper(boxes, k_min, k_max, canonical_scale=160, canonical_level=4, ep
     s = np.power((b[:, 3] - b[:, 0]) * (b[:, 4] - b[:, 1]) * (b[:, 5] - b[:, 2]), np.float32(1.0 / 3.0), dtype=np.float32)
     lvl = np.floor(np.float32(canonical_level) + np.log2(s / np.float32(canonical_scale), dtype=np.float32) + np.float32(eps))
     return (np.clip(lvl, k_min, k_max).astype(np.int64) - k_min)
+
+
+# ---- 2-D mask matching (the step between project_3d_masks and the instance-field trainer) ---------------------------
+# /root/reference/Mask2Former_sample/match_seg.py.  Pinned: tests/golden/make_match_seg_golden.py runs the reference's own
+# `match_seg()` (real h5py / matplotlib / tqdm; cv2 - absent from the image - replaced by three PIL-backed calls) on
+# inputs written by this repository's PNG writer, and tests/test_match_seg_oracle.py checks these restatements against
+# its outputs.
+# category (b) constant tables of the reference (match_seg.py:17-47): COCO class name -> NYU40 id; 40 = background,
+# everything not listed = 39 ("others")
+COCO_THINGS_TO_NYU40 = {"chair": 5, "couch": 6, "bed": 4, "dining table": 7}
+COCO_STUFF_TO_NYU40 = {
+    "chair": 5, "couch": 6, "bed": 4, "dining table": 7, "curtain": 40, "door-stuff": 40, "floor-wood": 40, "light": 35,
+    "shelf": 10, "stairs": 40, "wall-brick": 40, "wall-stone": 40, "wall-tile": 40, "wall-wood": 40, "window-blind": 40,
+    "window-other": 40, "ceiling-merged": 40, "cabinet-merged": 3, "table-merged": 7, "floor-other-merged": 40,
+    "building-other-merged": 40, "wall-other-merged": 40,
+}
+
+
+def convert_seg(panoptic_seg, segments_info):
+    """match_seg.py:65-91.  panoptic_seg int [H,W] (0 = unlabeled), segments_info: dicts with ``id`` (> 0), ``isthing``
+    and ``name`` (the COCO class name the reference looks up from ``category_id`` through coco_id_to_name.json).
+    -> int32 [H,W]: -1 unlabeled, 0 background (NYU40 id 40), otherwise the segment's own id."""
+    seg = np.asarray(panoptic_seg).astype(np.int32)
+    assert seg.min() >= 0
+    out = np.zeros_like(seg)
+    out[seg == 0] = -1
+    for s in segments_info:
+        assert s["id"] > 0
+        table = COCO_THINGS_TO_NYU40 if s["isthing"] else COCO_STUFF_TO_NYU40
+        nyu40 = table.get(s["name"], 39)
+        out[seg == s["id"]] = 0 if nyu40 == 40 else s["id"]
+    return out
+
+
+def match_seg(seg_map, proj_masks, instance_ids, iou_thresh=0.05):
+    """match_seg.py:111-138, one image.  seg_map: ``convert_seg`` output; proj_masks: list of bool [H,W] (channel 0 > 0
+    of ``<img>_<inst>.png``, files ``*_0.png`` already dropped, in the reference's sorted-file-name order);
+    instance_ids: their ``<inst>`` numbers.  Every segment id > 0 takes the instance id of the projected mask with the
+    largest IoU (first one on ties: np.argmax) if that IoU exceeds ``iou_thresh``, else -1; without projections every
+    segment becomes -1.  -> int32 [H,W] (-1 ignore, 0 background, > 0 instance id)."""
+    seg_map = np.asarray(seg_map)
+    out = np.copy(seg_map)
+    if len(proj_masks) == 0:
+        out[seg_map > 0] = -1
+        return out
+    for sid in np.unique(seg_map):
+        if sid <= 0:
+            continue
+        sel = seg_map == sid
+        iou = np.zeros(len(proj_masks))
+        for j, m in enumerate(proj_masks):
+            iou[j] = np.sum(sel & m) / np.sum(sel | m)
+        j = int(np.argmax(iou))
+        out[sel] = instance_ids[j] if iou[j] > iou_thresh else -1
+    return out
+
+
+def projections_of(files, img_idx):
+    """The reference's file selection (match_seg.py:99-102,117-119): ``*.png`` with an underscore whose part after the
+    FIRST underscore is not ``0.png``, sorted by name, belonging to the image whose name they START with.
+    -> (file names, instance ids)."""
+    keep = sorted(f for f in files if f.endswith(".png") and "_" in f and f.split("_")[1] != "0.png")
+    mine = [f for f in keep if f.startswith(img_idx)]
+    return mine, [int(f.split("_")[1].split(".")[0]) for f in mine]
