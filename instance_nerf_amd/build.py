@@ -34,8 +34,9 @@ LIB_FP32 = os.path.join(CSRC, "libinr_hip_fp32.so")
 
 def build_fp32(force=False, verbose=True):
     """The exact-fp32 A/B library: the same sources with -DINR_MLP_FP32=1 (MLP GEMMs on v_mfma_f32_16x16x4_f32 instead
-    of the 3-term bf16 split).  Inference entry points only (the device-side weight packers of the training paths
-    refuse that layout); tests/test_gpu_parity.py::test_exact_fp32_mlp_build loads it in a child process."""
+    of the 3-term bf16 split).  Inference AND training entry points since round 5 (the device-side weight packers write
+    the fp32 fragment layout there); only the opt-in -O variants (`*_fast`) are absent.  Loaded in child processes by
+    tests/test_gpu_parity.py::test_exact_fp32_mlp_build / ::test_training_gradients_under_the_exact_fp32_build."""
     deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
     if not force and os.path.exists(LIB_FP32) and all(os.path.getmtime(d) <= os.path.getmtime(LIB_FP32) for d in deps):
         return LIB_FP32

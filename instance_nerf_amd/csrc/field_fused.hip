@@ -1768,10 +1768,17 @@ __global__ void __launch_bounds__(256) k_pack_weights(PackJobs jobs, float* __re
       if (!J.transpose) v = J.W[(size_t)row * J.w_cols + col];
       else if (row >= J.row_min) v = J.W[(size_t)col * J.w_cols + row + J.row_shift];
     }
+#if INR_MLP_FP32
+    // exact-fp32 build (round 5: the training entry points too): the fragment order of pack_section_f32 - k-step
+    // ks = 4 (2 st + (e >> 2)) + (e & 3) of the bf16 layout's element (st, e), value (mt, ks, lane) at frag_pos()
+    (void)dst;
+    base[frag_pos(mt, 4 * (2 * st + (e >> 2)) + (e & 3), lane, 8 * J.n_s)] = v;
+#else
     const uint16_t hi = bf16_rne_dev(v);
     const uint16_t lo = bf16_rne_dev(v - __uint_as_float((uint32_t)hi << 16));
     dst[((((size_t)(mt * J.n_s + st) * 2 + 0) * 64 + lane) * 8) + e] = hi;
     dst[((((size_t)(mt * J.n_s + st) * 2 + 1) * 64 + lane) * 8) + e] = lo;
+#endif
   }
 }
 
@@ -2527,10 +2534,6 @@ int64_t inr_instance_bwd_packed_floats(void) { return kBwdFloats; }
 
 int inr_instance_pack_weights_device(const float* w0, const float* w1, const float* w2, int32_t K, float* packed_fwd,
                                      float* packed_bwd, inr_stream_t s) {
-#if INR_MLP_FP32
-  set_error("instance_pack_weights_device: built with INR_MLP_FP32 (no device packer for the fp32 layout)");
-  return INR_EINVAL;
-#else
   INR_REQUIRE(w0 && w1 && w2 && packed_fwd && packed_bwd, "null pointer");
   INR_REQUIRE(K > 0 && K <= 64 && K % 16 == 0, "K must be 16, 32, 48 or 64");
   INR_REQUIRE(((uintptr_t)packed_fwd & 15) == 0 && ((uintptr_t)packed_bwd & 15) == 0, "packed buffers misaligned");
@@ -2544,7 +2547,6 @@ int inr_instance_pack_weights_device(const float* w0, const float* w1, const flo
   jobs.j[5] = {w0, 64, 32, 32, 64, 2, 2, 1, kBwd0, 0, 0, 0, 1};
   k_pack_weights<<<dim3(8, 6), 256, 0, as_stream(s)>>>(jobs, packed_fwd, packed_bwd);
   return check_launch("instance_pack_weights_device");
-#endif
 }
 
 int inr_instance_forward_train(const float* x, int64_t M, float bound, const float* embeddings, const inr_grid_desc* desc,
@@ -2662,10 +2664,6 @@ int64_t inr_nerf_bwd_packed_floats(void) { return kNerfBwdFloats; }
 int inr_nerf_pack_weights_device(const float* sigma_w0, const float* sigma_w1, const float* color_w0,
                                  const float* color_w1, const float* color_w2, float* packed_fwd, float* packed_bwd,
                                  inr_stream_t s) {
-#if INR_MLP_FP32
-  set_error("nerf_pack_weights_device: built with INR_MLP_FP32 (no device packer for the fp32 layout)");
-  return INR_EINVAL;
-#else
   INR_REQUIRE(sigma_w0 && sigma_w1 && color_w0 && color_w1 && color_w2 && packed_fwd && packed_bwd, "null pointer");
   INR_REQUIRE(((uintptr_t)packed_fwd & 15) == 0 && ((uintptr_t)packed_bwd & 15) == 0, "packed buffers misaligned");
   PackJobs jobs;
@@ -2682,7 +2680,6 @@ int inr_nerf_pack_weights_device(const float* sigma_w0, const float* sigma_w1, c
   jobs.j[9] = {sigma_w0, 64, 32, 32, 64, 2, 2, 1, kNbS0, 0, 0, 0, 1};
   k_pack_weights<<<dim3(8, 10), 256, 0, as_stream(s)>>>(jobs, packed_fwd, packed_bwd);
   return check_launch("nerf_pack_weights_device");
-#endif
 }
 
 int inr_nerf_forward_train(const float* x, const float* d, int64_t M, float bound, const float* embeddings,

@@ -661,6 +661,46 @@ print("ERR", float(np.abs(sigma.cpu().numpy() / g["sigma"] - 1).max()), float(np
     assert errs["bf16x3"][0] < 1e-4 and errs["bf16x3"][1] < 1e-5 and errs["bf16x3"][2] < 1e-4, errs
 
 
+def test_training_gradients_under_the_exact_fp32_build():
+    """Round-4 verdict item 5: the -DINR_MLP_FP32=1 build now covers the TRAINING entry points (device weight packers,
+    k_nerf_head_bwd, k_instance_head_bwd on v_mfma_f32_16x16x4_f32), so the gradient fuzz can say which part of its
+    2e-2 norm-wise tolerance belongs to the split-bf16 MLP: the same eight set-ups (both stages, K = 64 / 31 / 16 / 5)
+    (plus the eight off the tuned configuration: bound 1 / 2 / 4, table sizes, 12 / 16 levels) through both libraries,
+    each in a child process (a process binds one library).  Exact fp32: every gradient tensor within 1e-4 norm-wise of
+    torch autograd through the oracle (measured: 4e-6 worst) - what is left is fp32 summation order, the
+    trunc-exp / sigmoid hardware approximations (1e-7 class) and the rare ReLU pre-activation that fp32 rounding itself
+    puts on the other side of zero.  The default build on the SAME inputs is reported next to it."""
+    import json
+    import subprocess
+    import sys
+    from instance_nerf_amd import build
+    assert os.path.exists(build.LIB_FP32), "libinr_hip_fp32.so is built by __graft_entry__.build()"
+    code = f"""
+import json, os, sys
+sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r}); sys.path.insert(0, {os.path.dirname(os.path.abspath(__file__))!r})
+from test_gpu_parity import _gradient_fuzz_case
+out = {{}}
+for varied in (False, True):
+    for seed in range(8):
+        got = {{}}
+        _gradient_fuzz_case(seed, varied=varied, collect=got)
+        out.update({{f"{{'v' if varied else 't'}}{{seed}}:{{st}}:{{k}}": v for (st, k), v in got.items()}})
+print("ERRS", json.dumps(out))
+"""
+    errs = {}
+    for name, path in (("fp32", build.LIB_FP32), ("bf16x3", build.LIB)):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, INR_LIB_PATH=path), capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        errs[name] = json.loads([l for l in r.stdout.splitlines() if l.startswith("ERRS")][-1][5:])
+    worst = {n: max(v[0] for v in e.values()) for n, e in errs.items()}
+    print("worst norm-wise gradient error per build:", worst)
+    print({k: (errs["fp32"][k][0], errs["bf16x3"][k][0], errs["fp32"][k][1]) for k in sorted(errs["fp32"])})
+    assert len(errs["fp32"]) == 2 * (4 * 6 + 4 * 4)                # tuned + varied: four NeRF-stage set-ups x 6 tensors, four instance x 4
+    assert worst["fp32"] < 1e-4, {k: v for k, v in errs["fp32"].items() if v[0] >= 1e-4}
+    assert worst["bf16x3"] < 2e-2
+
+
 def test_fused_equals_unfused_and_ragged_sizes(params_k16):
     """The MFMA path and the encoder+rocBLAS path agree; sizes that are not tile multiples work."""
     net = _network(params_k16)
@@ -1406,7 +1446,9 @@ def test_render_fuzz_over_bounds_and_level_tables_against_the_c_oracle(seed):
     _render_fuzz_case(seed, varied=True)
 
 
-def _gradient_fuzz_case(seed, varied):
+def _gradient_fuzz_case(seed, varied, collect=None):
+    """collect: a dict that receives {(stage, tensor): (norm-wise relative error, samples)} INSTEAD of the tolerance
+    assertion (the exact-fp32 A/B test reads the errors of both builds)."""
     from oracle import field, render
     rng = np.random.default_rng((19000 if varied else 9000) + seed)
     bound, C, H, level_table, enc_kw = _fuzz_volume(rng, varied)
@@ -1460,10 +1502,17 @@ def _gradient_fuzz_case(seed, varied):
     for k in trained:
         got, want = params[names[k]].grad.cpu(), q[k].grad
         assert want.abs().sum() > 0, k
-        # norm-wise: a ReLU pre-activation within rounding of zero may fall on either side (split-bf16 forward vs fp32
-        # oracle) - one flipped unit of one sample is ~1 % of the whole gradient when a set-up has only ~100 samples
-        # (seed 31 of an INR_FUZZ_SEEDS sweep: 128 samples, 85 of 13746 touched rows differ, composable path 3e-6)
-        tol = 2e-2 if ref["total"] >= 1000 else 1e-1
+        # norm-wise, at north_star's 1e-3 (round 5; 2e-2 / 1e-1 until then).  Measured on these sixteen set-ups
+        # (test_training_gradients_under_the_exact_fp32_build): 2.7e-5 worst for the default split-bf16 build, 4e-6 for
+        # the exact-fp32 one.  What the old tolerance allowed for is a RARE event, not a level: a ReLU pre-activation
+        # within rounding of zero falling on the other side in the split-bf16 forward - one flipped unit of one sample is
+        # ~1 % of the whole gradient when a set-up has only ~100 samples (seed 31 of an INR_FUZZ_SEEDS sweep in round 3:
+        # 128 samples, 85 of 13746 touched rows differ, composable path 3e-6).  A sweep that hits one shows it as a
+        # single failing seed that passes under INR_LIB_PATH=libinr_hip_fp32.so.
+        tol = 1e-3
+        if collect is not None:
+            collect[(stage, k)] = (float(torch.linalg.norm(got - want) / torch.linalg.norm(want)), int(ref["total"]))
+            continue
         assert torch.linalg.norm(got - want) < tol * torch.linalg.norm(want), (stage, k, ref["total"])
     for k in set(names) - set(trained):
         if names[k] in params:
