@@ -586,8 +586,10 @@ class NeRFRenderer(nn.Module):
             b = own[self._ahead_turn]
             self._ahead_turn ^= 1
         slot_taken = counter is None
+        slot_index = -1
         if counter is None:
-            counter = self.step_counter[self.local_step % 16]
+            slot_index = self.local_step % 16
+            counter = self.step_counter[slot_index]
             self.local_step += 1
         with torch.cuda.stream(side):
             nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, self.aabb_train, self.min_near,
@@ -610,7 +612,7 @@ class NeRFRenderer(nn.Module):
         out = {"n_rays": N, "key": (rays_o.data_ptr(), rays_d.data_ptr(), N), "rays_o": rays_o_in, "rays_d": rays_d_in,
                "nears": nears, "fars": fars, "xyzs": xyzs, "dirs": dirs, "deltas": deltas, "rays": rays, "counter": counter,
                "shaded": shaded, "T_thresh": float(T_thresh), "density_scale": float(self.density_scale),
-               "slot_taken": slot_taken, "grid_state": self.iter_density}
+               "slot_taken": slot_taken, "slot_index": slot_index, "grid_state": self.iter_density}
 
         def consume():
             cur = torch.cuda.current_stream()
@@ -621,9 +623,13 @@ class NeRFRenderer(nn.Module):
 
     def drop_ahead(self, marched):
         """A prefetched march that no render will consume: give its ``step_counter`` slot back (it would otherwise count
-        as a step of its own in the next ``mean_count``)."""
+        as a step of its own in the next ``mean_count``) - but only while it is still the MOST RECENT slot (round-4
+        advisor: if another training render took a slot in between, stepping back would make the next render overwrite
+        that real step's counter).  An orphaned slot further back is left alone: it holds the sample total of a real
+        march of a real batch, a valid sample of what ``mean_count`` averages."""
         if marched is not None and marched.get("slot_taken") and self.local_step > 0:
-            self.local_step -= 1
+            if marched.get("slot_index", -1) == (self.local_step - 1) % 16:
+                self.local_step -= 1
             marched["slot_taken"] = False
 
     @torch.no_grad()        # as upstream's: without it the NeRF stage's update ran the density query through the

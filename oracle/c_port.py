@@ -13,7 +13,9 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SRC = os.path.join(_HERE, "c", "inr_oracle.c")
-LIB_PATH = os.path.join(_HERE, "c", "liborc.so")
+# INR_ORACLE_LIB: another build of the same source (tests/test_oracle_c.py::test_ubsan_build points it at the
+# -fsanitize=undefined library in a child process)
+LIB_PATH = os.environ.get("INR_ORACLE_LIB") or os.path.join(_HERE, "c", "liborc.so")
 _lib = None
 
 F32, I32, U8 = np.float32, np.int32, np.uint8
@@ -33,6 +35,8 @@ class _Inst(ctypes.Structure):
 
 
 def build(force=False):
+    if os.environ.get("INR_ORACLE_LIB"):
+        return LIB_PATH                                  # an explicitly chosen build: never rebuilt here
     if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(_SRC):
         subprocess.check_call(["make", "-s", "-B", "-C", os.path.join(_HERE, "c"), "liborc.so"])
     return LIB_PATH

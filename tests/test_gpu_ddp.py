@@ -366,6 +366,16 @@ def test_bench_logic_with_eight_ranks_on_one_gpu():
     o = line["train_step_other_schedule"]
     assert "reduce_scatter" in o["gradient_schedule"] and "all_reduce" in line["train_step"]["gradient_schedule"]
     assert o["samples_per_step"] > 8 * 50_000 and o["loss_last"] == o["loss_last"]
+    # round 5: the strong-scaling figure beside the weak one, and configs[4] as "N scenes, one per GPU"
+    rs = line["render_sharded"]
+    assert rs["scaling"] == "strong" and rs["n_gpus"] == 8 and rs["value"] > 0
+    assert rs["rays_of_rank_0"] == 5120                   # 40 chunks of 1024 rays of the 200x200 dry-run frame, five per rank
+    assert rs["with_gather"].get("full_frame_on_every_rank") is True, rs["with_gather"]
+    ex = line["extract_roialign"]
+    assert "error" not in ex, ex
+    assert ex["n_gpus"] == 8 and len(ex["per_rank"]) == 8
+    assert abs(ex["extract_mvoxels_per_s"] - sum(o["extract_mvoxels_per_s"] for o in ex["per_rank"])) < 1.0
+    assert ex["roi_align_backward_ms_max_over_ranks"] == max(o["roi_align_backward_ms"] for o in ex["per_rank"])
     for key in ("train_step", "train_step_nerf"):
         t = line[key]
         assert "error" not in t, t

@@ -2312,6 +2312,32 @@ def test_composite_backward_writes_every_row_when_given_the_total(rm, room, bits
     assert (gs_b[~owned] == 0).all() and (gc_b[~owned] == 0).all() and gs_b[owned].abs().sum() > 0
 
 
+def test_dropping_a_prefetched_march_never_steps_over_a_later_slot(room):
+    """Round-4 advisor (renderer.py: drop_ahead): a prefetched march that is dropped gives its step_counter slot back
+    only while it is still the most recent one; with another training render in between the counter position stays,
+    so the next render cannot overwrite that real step's sample total."""
+    from instance_nerf_amd.nerf import NeRFNetwork
+    net = NeRFNetwork(cuda_ray=True, num_instances=0, min_near=0.05).to(DEV).train()
+    net.density_bitfield.copy_(_t(room.density_bitfield(128, 1.0)))
+    net.mean_count = 60000
+    ro, rd = (_t(a)[None] for a in scene_rays(room, 512, seed=3))
+    ro2, rd2 = (_t(a)[None] for a in scene_rays(room, 512, seed=4))
+    a = net.march_ahead(ro, rd)
+    assert a is not None and a["slot_taken"] and a["slot_index"] == 0 and net.local_step == 1
+    net.drop_ahead(a)                                   # still the newest slot: handed back
+    assert net.local_step == 0
+    a = net.march_ahead(ro, rd)                         # slot 0 again
+    with torch.no_grad():
+        net.render(ro2, rd2, bg_color=1, perturb=False)  # an unrelated training render takes slot 1
+    assert net.local_step == 2
+    total_1 = int(net.step_counter[1, 0])
+    net.drop_ahead(a)                                   # NOT the newest slot any more: nothing moves
+    assert net.local_step == 2 and not a["slot_taken"]
+    with torch.no_grad():
+        net.render(ro, rd, bg_color=1, perturb=False)    # goes to slot 2
+    assert net.local_step == 3 and int(net.step_counter[1, 0]) == total_1 > 0
+
+
 def test_look_ahead_march_changes_nothing_but_the_schedule(room):
     """Trainer.train_one_step(data, next_data): the next batch's ray/box test and march are queued on a side stream
     under this step's backward.  Same seeds, same batches, occupancy updates every 4 steps (no look-ahead across an

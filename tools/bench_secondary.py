@@ -515,6 +515,73 @@ def bound_render_probe(dev, bound=4, dt_gamma=1.0 / 128, frames=8):
             "end_to_end_frac_of_hbm_peak": round(n * BYTES_PER_SAMPLE / dt / 1e9 / HBM_PEAK_GBS, 4)}
 
 
+def render_sharded_probe(dev, rank, world, red_dev, frames=8):
+    """world > 1, EVERY rank calls it.  STRONG scaling of the render path (round-4 verdict item 7; the headline is weak
+    scaling: one whole view per rank): ONE 800x800 view at a time, split over the ranks the way the product splits it
+    (`nerf/utils.py::shard_indices`: 1024-ray chunks of the 4x4-patch-ordered ray list dealt round robin - contiguous
+    ranges are as unbalanced as the frame's rows), parameters and bitfield replicated, no collective on the critical
+    path.  Time per frame = max over ranks (barrier before and after), samples = sum over ranks; then the
+    product's `render_sharded` itself, which also all-gathers image / depth / opacity onto every rank."""
+    import torch.distributed as dist
+    from instance_nerf_amd.nerf.utils import get_rays, render_sharded, shard_indices
+    net, room = build_network(dev)
+    poses, intr, H, W = room.cameras()
+    pd = torch.from_numpy(poses).to(dev)
+    mine_idx = shard_indices(H * W, rank, world, dev)
+
+    def rays(v):
+        r = get_rays(pd[v:v + 1], intr, H, W, patch=4)
+        return r["rays_o"], r["rays_d"]
+
+    def shard(v):
+        ro, rd = rays(v)
+        with torch.no_grad():
+            return net.render(ro[:, mine_idx].contiguous(), rd[:, mine_idx].contiguous(), bg_color=1, infer_mode="fused")
+
+    def barrier():
+        dist.barrier()
+        torch.cuda.synchronize()
+    shard(0)
+    shard(1)
+    barrier()
+    t0 = time.perf_counter()
+    counts = [shard(v % pd.shape[0])["num_samples"] for v in range(frames)]
+    barrier()
+    el = time.perf_counter() - t0
+    mine = float(sum(int(c[0]) for c in counts))
+    t = torch.tensor([el, mine], dtype=torch.float64, device=red_dev)
+    tm, ts = t[:1].clone(), t[1:].clone()
+    dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+    dist.all_reduce(ts, op=dist.ReduceOp.SUM)
+    el, total = float(tm[0]), float(ts[0])
+    out = {"workload": f"render 800x800, one view at a time, the view's rays dealt to {world} ranks in 1024-ray chunks "
+                       "(nerf/utils.py::shard_indices), replicated parameters",
+           "scaling": "strong", "n_gpus": world, "frames": frames, "rays_of_rank_0": int(mine_idx.numel()),
+           "ms_per_frame": round(el / frames * 1e3, 3), "value": round(total / el / 1e6, 1), "unit": "Msamples/s"}
+    # the product's entry point: the same shards + the all-gather of every per-ray result
+    try:
+        ro, rd = rays(0)
+        render_sharded(net, ro, rd, rank, world, bg_color=1, infer_mode="fused")
+        barrier()
+        t0 = time.perf_counter()
+        for v in range(frames):
+            ro, rd = rays(v % pd.shape[0])
+            full = render_sharded(net, ro, rd, rank, world, bg_color=1, infer_mode="fused")
+        barrier()
+        el_g = time.perf_counter() - t0
+        tg = torch.tensor([el_g], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+        el_g = float(tg[0])
+        out["with_gather"] = {"ms_per_frame": round(el_g / frames * 1e3, 3), "value": round(total / el_g / 1e6, 1),
+                              "bytes_gathered_per_frame": H * W * 20,
+                              "full_frame_on_every_rank": list(full["image"].shape) == [1, H * W, 3],
+                              "what": "nerf/utils.py::render_sharded: image, depth and opacity all-gathered onto every rank"}
+        ok = 1.0
+    except Exception as e:                                    # noqa: BLE001 - the same code on every rank: all fail together
+        out["with_gather"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    return out
+
+
 def half_table_probe(dev, frames=8, mlp_fp16=False):
     """Secondary measurement: the headline frames with the OPT-IN half-precision table copy (NeRFNetwork.half_table;
     upstream's -O / fp16 storage): 512 B of algorithmic table traffic per sample.  Not the headline: its outputs differ
@@ -567,6 +634,59 @@ def half_table_probe(dev, frames=8, mlp_fp16=False):
     return out
 
 
+def timed_trained_steps(tr, net, ds, stage, n=48):
+    """Steady-state training steps of a Trainer whose scene is already TRAINED (opaque surfaces, learned occupancy grid:
+    2.4x the samples per step of the untrained bench scene), eager loop: ms per step from device events, samples per
+    step from the march's device counter, and the table-gradient scatter's share with its request-rate roofline
+    (round-4 verdict item 2c).  -> the "train_step" object of the trained scene for this stage."""
+    from instance_nerf_amd.nerf import network as _network_mod
+    ev = []
+    real = _network_mod._table_backward
+
+    def timed(*a, **kw):
+        st = torch.cuda.current_stream()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        out = real(*a, **kw)
+        e1.record(st)
+        ev.append((e0, e1))
+        return out
+    batches = [ds.batch() for _ in range(8)]        # traced on the host (numpy): not inside the timed loop
+    for i in range(8):
+        tr.train_one_step(batches[i])
+    _network_mod._table_backward = timed
+    try:
+        per = torch.zeros(n, dtype=torch.int32, device=tr.device)
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+        torch.cuda.synchronize()
+        marks[0].record()
+        for i in range(n):
+            tr.train_one_step(batches[i % 8])
+            torch.clamp(net.last_counter[0], max=max(int(net.mean_count), 1), out=per[i])
+            marks[i + 1].record()
+        torch.cuda.synchronize()
+    finally:
+        _network_mod._table_backward = real
+    ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(n)]
+    sc = sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1)
+    samples = float(per.sum().item()) / n
+    out = {"ms_per_step": round(float(np.mean(ms)), 3), "ms_per_step_median": round(float(np.median(ms)), 3),
+           "samples_per_step": int(samples), "msamples_per_s": round(samples / (float(np.mean(ms)) * 1e-3) / 1e6, 1),
+           "scatter_ms": round(sc, 4), "scatter_share_of_step": round(sc / float(np.mean(ms)), 3),
+           "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                        "kernel": "k_grid_bwd (table-gradient scatter)", "algorithmic_bytes_per_sample": 2048,
+                        "achieved": round(2048 * samples / (sc / 1e3) / 1e9, 1) if sc > 0 else None,
+                        "frac": round(2048 * samples / (sc / 1e3) / 1e9 / HBM_PEAK_GBS, 4) if sc > 0 else None,
+                        "atomic_unit": None}}
+    sr = scatter_requests(stage)
+    if sr is not None and sc > 0:
+        req = sr[0] * samples
+        out["roofline"]["atomic_unit"] = {"requests_per_sample": sr[0], "achieved_g_requests_per_s": round(req / (sc / 1e3) / 1e9, 2),
+                                          "peak_g_requests_per_s": round(sr[1] / 1e9, 1), "frac": round(req / (sc / 1e3) / sr[1], 4),
+                                          "source": SCATTER_JSON + " (requests per sample measured on the UNTRAINED bench scene)"}
+    return out
+
+
 def trained_scene_probe(dev, steps=1500, with_oracle=True):
     """Secondary measurement: rendering a TRAINED scene.  The headline scene is an untrained (transparent) field, so no
     ray of it ever terminates; a trained 3D-FRONT room is opaque.  Here the NeRF of the synthetic room is trained for
@@ -586,6 +706,10 @@ def trained_scene_probe(dev, steps=1500, with_oracle=True):
         tr.train_one_step(ds.batch())
     torch.cuda.synchronize()
     train_s = time.perf_counter() - t0
+    try:
+        step_nerf = timed_trained_steps(tr, net, ds, "nerf")
+    except Exception as e:                                    # noqa: BLE001
+        step_nerf = {"error": f"{type(e).__name__}: {e}"[:300]}
     net.eval()
     poses, intr, H, W = ds.room.cameras()
     pd = torch.from_numpy(poses).to(dev)
@@ -605,7 +729,9 @@ def trained_scene_probe(dev, steps=1500, with_oracle=True):
     net.nerf_render = timed(net.nerf_render)
     out = {"workload": f"NeRF of the synthetic room trained {steps} steps (4096 rays, 400x400 views, learned occupancy "
                        "grid), then the 8 bench views at 800x800", "train_seconds": round(train_s, 1),
-           "occupied_cells": round(float((net.density_grid > min(net.mean_density, net.density_thresh)).float().mean()), 4)}
+           "occupied_cells": round(float((net.density_grid > min(net.mean_density, net.density_thresh)).float().mean()), 4),
+           "train_step": {"what": "steady-state eager training steps ON the trained scene (48 steps after the training run): "
+                                  "4096 rays per batch, learned occupancy grid", "nerf_stage": step_nerf}}
     frame0 = frame0_fast = None
     # "fused_O": the two-kernel path with both opt-in halves of upstream's -O (fp16 table copy + single-pass fp16 MLP)
     for mode in ("fused", "fused_terminate", "auto", "fused_O"):
@@ -684,6 +810,10 @@ def trained_scene_probe(dev, steps=1500, with_oracle=True):
                   for i in range(n_inst)]
             torch.cuda.synchronize()
             inst_s = time.perf_counter() - t0
+            try:
+                out["train_step"]["instance_stage"] = timed_trained_steps(tr2, net2, ds2, "instance")
+            except Exception as e:                            # noqa: BLE001
+                out["train_step"]["instance_stage"] = {"error": f"{type(e).__name__}: {e}"[:300]}
             net2.eval()
 
             def score(pose):
@@ -694,11 +824,13 @@ def trained_scene_probe(dev, steps=1500, with_oracle=True):
                 truth = torch.from_numpy(ids % K)
                 m = MIoUMeter(K)
                 m.update(pred, truth)
-                return {"miou": round(m.measure(), 3), "pixel_accuracy": round(float((pred == truth).float().mean()), 4),
-                        "ids_in_view": int((m.truth > 0).sum()),
-                        # the figure of rounds 1-3: ids that only the prediction contains (a few stray pixels) count as
-                        # classes with IoU 0 - tools/miou_probe.py, profiles/r04_NOTES.txt 4
-                        "miou_counting_ids_only_predicted": round(m.measure(all_predicted=True), 3)}
+                both = m.measure_both()
+                # two definitions under distinct names (round-4 advisor): over the ids present in the ground truth, and
+                # over every id with a non-empty union - the figure of rounds 1-3, where ids that only the prediction
+                # contains (a few stray pixels) count as classes with IoU 0 (tools/miou_probe.py, r04_NOTES 4)
+                return {"miou_gt_ids": round(both["miou_gt_ids"], 3), "miou_all_ids": round(both["miou_all_ids"], 3),
+                        "pixel_accuracy": round(float((pred == truth).float().mean()), 4),
+                        "ids_in_view": int((m.truth > 0).sum())}
             out["instance_miou_vs_ground_truth"] = {"training_view_0_at_400": score(ds.poses[:1]),
                                                     "held_out_pose_at_400": score(held), "classes": K, "steps": n_inst,
                                                     "ce_first": round(ce[0], 4), "ce_last": round(ce[-1], 4),
