@@ -443,13 +443,8 @@ def main():
                     line["train_step_other_schedule"] = {k: to[k] for k in (
                         "ms_per_step", "ms_per_step_median", "ms_per_step_of_both_timed_regions", "samples_per_step",
                         "msamples_per_s", "gradient_schedule", "allreduce_mb_per_step", "loss_first", "loss_last") if k in to}
-            except Exception as e:                            # noqa: BLE001
-                if rank == 0:
-                    line["train_step"] = line["train_step_nerf"] = {"error": f"{type(e).__name__}: {e}"[:300]}
-                    print(json.dumps(line), flush=True)
-                raise
                 # strong scaling beside the headline's weak scaling: one frame over all ranks (every rank calls it)
-                rs = render_sharded_probe(dev, rank, world, red_dev)
+                rs = render_sharded_probe(dev, rank, world, red_dev, res=args.res)
                 if rank == 0:
                     line["render_sharded"] = rs
                 # BASELINE configs[4] as the metric states it: N scenes, one per GPU, no collective on the data path -
@@ -472,6 +467,11 @@ def main():
                         "roi_align_backward_ms_max_over_ranks": max(o["roi_align_backward_ms"] for o in ok),
                         "per_rank": [{k: o[k] for k in ("extract_ms", "extract_mvoxels_per_s", "roi_align_forward_ms",
                                                         "roi_align_backward_ms")} for o in ok]}
+            except Exception as e:                            # noqa: BLE001
+                if rank == 0:
+                    line["train_step"] = line["train_step_nerf"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+                    print(json.dumps(line), flush=True)
+                raise
             finally:
                 if watchdog is not None:
                     watchdog.cancel()

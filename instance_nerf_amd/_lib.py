@@ -77,6 +77,8 @@ _SIGS = {
     "inr_nerf_forward_table": (c_int32, [P, P, P, c_int64, c_float, P, POINTER(GridDesc), P, c_float, P, P, P]),
     "inr_nerf_forward_table_half": (c_int32, [P, P, P, c_int64, c_float, P, POINTER(GridDesc), P, c_float, P, P, P]),
     "inr_nerf_forward_table_fast": (c_int32, [P, P, P, c_int64, c_float, P, c_int32, POINTER(GridDesc), P, c_float, P, P, P]),
+    "inr_nerf_forward_table_sliced_workspace_bytes": (c_int64, [c_int64]),
+    "inr_nerf_forward_table_sliced": (c_int32, [P, P, P, c_int64, c_float, P, POINTER(GridDesc), P, c_float, P, P, P, c_int32, P]),
     "inr_nerf_pack_weights_f16": (c_int32, [P, P, P, P, P, P]),
     "inr_composite_rays_patch_forward": (c_int32, [P, P, P, P, c_int64, c_int64, c_float, P, c_int32, P, P, P, P, P, P, P]),
     "inr_project_masks_patch": (c_int32, [P, P, P, c_int64, c_int64, P, c_int32, c_int32, c_int32, P, c_int32, c_int32, c_int32,
@@ -124,7 +126,7 @@ _SIGS = {
 }
 EXPORTS = tuple(_SIGS)
 
-ABI_VERSION = 6          # include/inr.h INR_ABI_VERSION this binding was written against
+ABI_VERSION = 7          # include/inr.h INR_ABI_VERSION this binding was written against
 _lib = None
 
 

@@ -465,6 +465,13 @@ class NeRFNetwork(NeRFRenderer):
         # activations rounded to fp16, fp32 accumulation) instead of the three-pass bf16 split that keeps the default
         # fp32-class.  Outputs within a few 1e-3 of the default's; training and every other path are unaffected.
         self.mlp_fp16 = False
+        # Frame path of the fused field: False = one kernel; True = XCD-sliced (inr_nerf_forward_table_sliced: the four
+        # finest levels by a per-XCD pre-pass, `frame_slice_chunks` chunks pipelined on a side stream); "auto" (the
+        # default) = measure both on the first frames of this network and keep the faster - the sliced path pays where
+        # the finest levels have no locality at all (a scene filling a bound >= 4 volume), the fused kernel elsewhere
+        self.frame_slices = __import__("os").environ.get("INR_FRAME_SLICES", "auto")
+        self.frame_slice_chunks = 8
+        self._slice_probe = None
 
     # ---- packed MFMA weights (cached until a weight tensor changes) ------------------------------
     def _packed_weights(self, which):
@@ -562,6 +569,54 @@ class NeRFNetwork(NeRFRenderer):
               "nerf_forward")
         return sigma, rgb, geo
 
+    def _use_slices(self, M):
+        """Which frame path this call takes (see ``frame_slices``).  "auto": frames of >= 2^21 samples on the 16-level
+        table with hashed fine levels are timed with events on their stream - two calls on each path, alternating,
+        nothing waits for them - and once all four timings have landed the faster path is kept for this network."""
+        mode = self.frame_slices
+        if mode in (False, 0, "0", "off", "False"):
+            return False
+        tb = self.encoder.table
+        if not (M > 0 and int(tb["num_levels"]) == 16 and bool(tb["hashed"][8:].all())):
+            return False
+        if mode in (True, 1, "1", "on", "True"):
+            return True
+        if M < (1 << 21):                         # "auto": frames only (a batch has nothing to pipeline)
+            return False
+        # "auto" only ever probes where the sliced path has a chance: a finest level of 8192+ (bound >= 4 under upstream's
+        # 2048 x bound rule).  Below that the fused kernel won every measurement (bound 1: 5.1 vs 6.4 ms, bound 2: 3.2 vs
+        # 3.8 ms, profiles/r05_NOTES.txt 6) and a probe would put two slower frames into somebody's loop for nothing.
+        if int(tb["resolutions"][-1]) < 8192:
+            return False
+        p = self._slice_probe
+        if p is None:
+            p = self._slice_probe = {"calls": 0, "pending": [], "ms": {False: [], True: []}, "choice": None}
+        if p["choice"] is not None:
+            return p["choice"]
+        for rec in list(p["pending"]):
+            if rec[1].query():
+                p["ms"][rec[2]].append(rec[0].elapsed_time(rec[1]) / max(rec[3], 1))
+                p["pending"].remove(rec)
+        if len(p["ms"][False]) >= 2 and len(p["ms"][True]) >= 2:
+            p["choice"] = min(p["ms"][True]) < 0.97 * min(p["ms"][False])     # (3 % margin: the fused kernel on a tie)
+            return p["choice"]
+        if p["calls"] >= 8:                       # timings never landed (a stream nobody synchronises): stay fused
+            return False
+        use = bool(p["calls"] % 2)
+        p["calls"] += 1
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        p["open"] = (e0, use, M)
+        return use
+
+    def _close_slice_probe(self):
+        p = self._slice_probe
+        if p and p.get("open") is not None:
+            e0, use, M = p.pop("open")
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            p["pending"].append((e0, e1, use, M))
+
     @torch.no_grad()
     def sh_table(self, rays_d):
         """Per-ray direction table [N,16] of ``forward_table`` (degree-4 SH in the lane order of the fused kernel)."""
@@ -609,12 +664,24 @@ class NeRFNetwork(NeRFRenderer):
                                                   ptr(sigma, allow_none=M == 0), ptr(rgb, allow_none=M == 0), stream_ptr()),
                   "nerf_forward_table_half")
             return sigma, rgb
+        if self._use_slices(M):
+            # XCD-sliced frame path (round 5): the four finest levels by a pre-pass in which every XCD serves one level
+            # (its L2 then holds that level whole), the fused kernel on the other twelve; same numbers bit for bit
+            ws = torch.empty(lib.inr_nerf_forward_table_sliced_workspace_bytes(M) // 4, dtype=torch.float32, device=dev)
+            check(lib.inr_nerf_forward_table_sliced(ptr(x01, torch.float32, "x01"), ptr(ray_ids, torch.int32, "ray_ids"),
+                                                    ptr(shq), M, float(self.bound),
+                                                    ptr(self.encoder.embeddings.data, torch.float32), self.encoder.desc,
+                                                    ptr(self._packed_weights("nerf")), 1.0, ptr(sigma), ptr(rgb), ptr(ws),
+                                                    int(self.frame_slice_chunks), stream_ptr()), "nerf_forward_table_sliced")
+            self._close_slice_probe()
+            return sigma, rgb
         check(lib.inr_nerf_forward_table(ptr(x01, torch.float32, "x01", allow_none=M == 0),
                                          ptr(ray_ids, torch.int32, "ray_ids", allow_none=M == 0), ptr(shq), M,
                                          float(self.bound), ptr(self.encoder.embeddings.data, torch.float32),
                                          self.encoder.desc, ptr(self._packed_weights("nerf")), 1.0,
                                          ptr(sigma, allow_none=M == 0), ptr(rgb, allow_none=M == 0), stream_ptr()),
               "nerf_forward_table")
+        self._close_slice_probe()
         return sigma, rgb
 
     @torch.no_grad()

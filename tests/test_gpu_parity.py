@@ -1292,6 +1292,53 @@ def test_full_size_frame_at_bound4_against_the_c_oracle(rm):
         assert np.abs(out["depth"][0].cpu().numpy() - c["depth"]).max() < 1e-4, mode
 
 
+def test_xcd_sliced_frame_path_is_bit_identical():
+    """Round 5: the XCD-sliced frame path (``NeRFNetwork.frame_slices``: the four finest levels evaluated by a pre-pass in
+    which every XCD serves one level, the fused kernel on the other twelve, chunks pipelined on an internal side stream)
+    returns the fused kernel's numbers bit for bit - table U(-1,1), a bound-4 frame of 800x800 rays and ragged small
+    batches, 1 / 3 / 8 chunks - and through ``render`` the same image; "auto" never probes below a finest level of 8192."""
+    from instance_nerf_amd import raymarching as rmod
+    from instance_nerf_amd.nerf.utils import get_rays
+    from instance_nerf_amd.scene import RoomScene
+    from oracle import field, hashgrid
+    bound = 4
+    big = RoomScene(scale=float(bound))
+    table = hashgrid.level_table(desired_resolution=2048 * bound)
+    p = field.init_params(seed=11, table=table, table_std=1.0, K=0)
+    net = _network(p, K=0, bound=bound).eval()
+    net.density_bitfield.copy_(_t(big.density_bitfield(128, float(bound))))
+    poses, intr, H, W = big.cameras()
+    r = get_rays(_t(poses[1:2]), intr, H, W, patch=4)
+    ro, rd = r["rays_o"].view(-1, 3), r["rays_d"].view(-1, 3)
+    nears, fars = rmod.near_far_from_aabb(ro, rd, net.aabb_infer, net.min_near)
+    xyzs, ids, deltas, rays = rmod.march_rays_patch(ro, rd, bound, net.density_bitfield, net.cascade, 128, nears, fars,
+                                                    1 / 128, 1024, table=True)
+    assert xyzs.shape[0] > 10_000_000
+    with torch.no_grad():
+        shq = net.sh_table(rd)
+        for M in (xyzs.shape[0], 1, 17, 1000, 70001):
+            net.frame_slices = False
+            ref = net.forward_table(xyzs[:M].contiguous(), ids[:M].contiguous(), rd, shq=shq)
+            for chunks in (1, 3, 8):
+                net.frame_slices, net.frame_slice_chunks = True, chunks
+                got = net.forward_table(xyzs[:M].contiguous(), ids[:M].contiguous(), rd, shq=shq)
+                assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), (M, chunks)
+        net.frame_slices, net.frame_slice_chunks = False, 8
+        a = net.render(r["rays_o"], r["rays_d"], bg_color=1, infer_mode="fused", dt_gamma=1 / 128)
+        net.frame_slices = True
+        b = net.render(r["rays_o"], r["rays_d"], bg_color=1, infer_mode="fused", dt_gamma=1 / 128)
+        assert torch.equal(a["image"], b["image"]) and torch.equal(a["depth"], b["depth"])
+        # auto: decides by measurement at bound 4 (either answer is legal), never leaves the fused kernel at bound 1
+        net.frame_slices = "auto"
+        net._slice_probe = None
+        for _ in range(8):
+            c = net.render(r["rays_o"], r["rays_d"], bg_color=1, infer_mode="fused", dt_gamma=1 / 128)
+            torch.cuda.synchronize()
+        assert torch.equal(a["image"], c["image"]) and net._slice_probe["choice"] in (True, False)
+    small = _network(field.init_params(seed=1, table=hashgrid.level_table(), table_std=1.0, K=0), K=0).eval()
+    assert small.frame_slices == "auto" and small._use_slices(1 << 24) is False and small._slice_probe is None
+
+
 def test_generic_sampler_without_cuda_ray(params_k16, room, level_table):
     """NeRFNetwork(cuda_ray=False).render(): upstream's default sampler (128 uniform + 128 importance samples, no
     occupancy grid) as tensor-op glue around the HIP ray/box test and field kernels, against the oracle's ray-by-ray

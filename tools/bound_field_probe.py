@@ -25,6 +25,8 @@ reps = int(args[0]) if args else 5
 configs = args[1:] or ["1:1:0:0:0", "2:2:128:0:0", "4:4:128:0:0", "4:4:0:0:0"]
 dev = torch.device("cuda", 0)
 VIEW = int(os.environ.get("PROBE_VIEW", "0"))
+# frame paths to run: fused | sliced[:chunks] | auto (NeRFNetwork.frame_slices)
+MODES = os.environ.get("PROBE_MODES", "fused").split(",")
 
 
 def one(cfg):
@@ -49,20 +51,34 @@ def one(cfg):
                                                             1024, table=True)
     M = xyzs.shape[0]
     tb = net.encoder.table
-    with torch.no_grad():
-        shq = net.sh_table(rd)
-        net.forward_table(xyzs, dirs, rd, shq=shq)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            net.forward_table(xyzs, dirs, rd, shq=shq)
-        e1.record()
-        torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / reps
-    print(f"{cfg:22s} bound {bound} scene x{s:g} dt_gamma {gamma:.5f} levels..{int(tb['resolutions'][-1])} "
-          f"hashed {int(tb['hashed'].sum())} T {tb['total_rows']}  M={M}  field {ms:.3f} ms  "
-          f"{M / ms / 1e6:.3f} Gsamples/s  frac {M * 1024 / (ms * 1e-3) / 8e12:.4f}", flush=True)
+    ref = None
+    for mode in MODES:
+        net.frame_slices = {"fused": False, "sliced": True}.get(mode.split(":")[0], "auto")
+        if ":" in mode:
+            net.frame_slice_chunks = int(mode.split(":")[1])
+        net._slice_probe = None
+        with torch.no_grad():
+            shq = net.sh_table(rd)
+            for _ in range(10 if mode == "auto" else 1):      # auto: four timed calls + the decision before the clock
+                out = net.forward_table(xyzs, dirs, rd, shq=shq)
+                torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                net.forward_table(xyzs, dirs, rd, shq=shq)
+            e1.record()
+            torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        same = ""
+        if ref is None:
+            ref = out
+        else:
+            same = "  bit-identical to the first mode: " + str(bool(torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1])))
+        if mode == "auto":
+            same += f"  auto chose {'sliced' if (net._slice_probe or {}).get('choice') else 'fused'}"
+        print(f"{cfg:22s} {mode:10s} bound {bound} scene x{s:g} dt_gamma {gamma:.5f} levels..{int(tb['resolutions'][-1])} "
+              f"hashed {int(tb['hashed'].sum())} T {tb['total_rows']}  M={M}  field {ms:.3f} ms  "
+              f"{M / ms / 1e6:.3f} Gsamples/s  frac {M * 1024 / (ms * 1e-3) / 8e12:.4f}{same}", flush=True)
     del net, xyzs, dirs, deltas, rays
 
 
