@@ -329,20 +329,19 @@ int inr_nerf_forward_table_fast(const float* x01, const int32_t* ray_ids, const 
                                 float bound, const void* embeddings, int32_t table_is_half,
                                 const inr_grid_desc* desc /*host*/, const float* packed /*device*/,
                                 float density_scale, float* sigma, float* rgb, inr_stream_t s);
-/* XCD-sliced variant of inr_nerf_forward_table (round 5; same results bit for bit; fp32 table, 16 levels, hashed fine
- * levels): the four finest levels (12..15) are evaluated first by a pre-pass in which every XCD serves ONE level - a
- * hashed level is 4 MiB, exactly one XCD's L2, and where those levels are finer than the spacing of a frame's samples
- * nothing but a cache that holds the whole level can serve their gathers (tools/micro/level_xcd_bench.hip: 259 against
- * 69 G lines/s) - into `fine_ws` (device, caller-owned, >= inr_nerf_forward_table_sliced_workspace_bytes(M) bytes: 32
- * bytes per sample); the fused kernel then gathers the other twelve levels.  n_chunks > 1: the samples go through in
- * that many chunks, the pre-pass of chunk k+1 on an internal side stream beside the fused kernel of chunk k (fork / join
- * by events: to the caller everything is ordered on `s`); 0 = the library's default (8).  Pays where the finest levels
- * have no locality at all (bound >= 4); NeRFNetwork.frame_slices = "auto" measures both paths and keeps the faster.   */
+/* Sliced variant of inr_nerf_forward_table (round 5; same results bit for bit; fp32 table, 16 levels, hashed fine
+ * levels): the three finest levels (13..15) are evaluated first, one level at a time over all samples - a hashed level
+ * is 4 MiB, exactly one XCD's L2, and where those levels are finer than the spacing of a frame's samples nothing but a
+ * cache that holds the whole level can serve their gathers (tools/micro/level_xcd_bench.hip: 259 against 69 G lines/s)
+ * - into `fine_ws` (device, caller-owned, >= inr_nerf_forward_table_sliced_workspace_bytes(M) bytes: 24 bytes per
+ * sample); the fused kernel then gathers the other thirteen levels.  Two launches on `s`.  Pays where the finest levels
+ * have no locality at all (a scene filling a bound >= 4 volume: 30.2 -> 27.5 ms per 141 M samples); slower elsewhere -
+ * NeRFNetwork.frame_slices = "auto" measures both paths and keeps the faster.                                          */
 int64_t inr_nerf_forward_table_sliced_workspace_bytes(int64_t M);
 int inr_nerf_forward_table_sliced(const float* x01, const int32_t* ray_ids, const float* sh_table_q, int64_t M,
                                   float bound, const float* embeddings, const inr_grid_desc* desc /*host*/,
                                   const float* packed /*device*/, float density_scale, float* sigma, float* rgb,
-                                  float* fine_ws, int32_t n_chunks, inr_stream_t s);
+                                  float* fine_ws, inr_stream_t s);
 /* Training path of the NeRF field (a9 under autograd): device-packed weights (forward layout of
  * inr_nerf_pack_weights + the transposed sections of the backward), a forward that also stores the activations
  * (enc [M,32], h1 [M,64], so [M,16] = raw sigma-net output, cin [M,32] = colour-net input with a zero pad column,

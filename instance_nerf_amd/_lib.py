@@ -78,7 +78,7 @@ _SIGS = {
     "inr_nerf_forward_table_half": (c_int32, [P, P, P, c_int64, c_float, P, POINTER(GridDesc), P, c_float, P, P, P]),
     "inr_nerf_forward_table_fast": (c_int32, [P, P, P, c_int64, c_float, P, c_int32, POINTER(GridDesc), P, c_float, P, P, P]),
     "inr_nerf_forward_table_sliced_workspace_bytes": (c_int64, [c_int64]),
-    "inr_nerf_forward_table_sliced": (c_int32, [P, P, P, c_int64, c_float, P, POINTER(GridDesc), P, c_float, P, P, P, c_int32, P]),
+    "inr_nerf_forward_table_sliced": (c_int32, [P, P, P, c_int64, c_float, P, POINTER(GridDesc), P, c_float, P, P, P, P]),
     "inr_nerf_pack_weights_f16": (c_int32, [P, P, P, P, P, P]),
     "inr_composite_rays_patch_forward": (c_int32, [P, P, P, P, c_int64, c_int64, c_float, P, c_int32, P, P, P, P, P, P, P]),
     "inr_project_masks_patch": (c_int32, [P, P, P, c_int64, c_int64, P, c_int32, c_int32, c_int32, P, c_int32, c_int32, c_int32,

@@ -194,6 +194,7 @@ struct Gathered {
 // of the 16 coarse loads have landed and each later fine level waits until at most 4 loads are outstanding.  The
 // kernel is throughput-bound (look-ups, VALU issue), not latency-bound, and fewer lines in flight per wave leave
 // more of the 32 KB L1 to the other seven waves of the CU.  (-1 = no wait.)
+constexpr int kSliceLevels = 3;           // XCD-sliced frame path (k_grid_fine_slices): levels 13..15 arrive precomputed
 constexpr int kWaitAfterCoarse = 8;
 constexpr int kWaitBetweenFine = 4;
 // s_waitcnt vmcnt(N) only (gfx9 encoding: vmcnt[3:0] | expcnt 7 << 4 | lgkmcnt 15 << 8 | vmcnt[5:4] << 14)
@@ -246,9 +247,10 @@ __device__ __forceinline__ void issue_gathers_impl(const LevelRec* __restrict__ 
     if (i == 0) wait_vmcnt<kWaitAfterCoarse>();
     else wait_vmcnt<kWaitBetweenFine>();
     if constexpr (kPre) {
-      // sliced feed: levels 12..15 (pair 1) arrive precomputed; its lanes ask for row 0 of the table instead (all of them
-      // the SAME line: one look-up per instruction, no divergence) and the caller overwrites their features
-      const uint32_t keep = (q >> 1) ? 0u : 0xFFFFFFFFu;
+      // sliced feed: the finest kSliceLevels levels (of pair 1's 12..15) arrive precomputed; its lanes ask for row 0 of
+      // the table instead (all of them the SAME line: one look-up per instruction, no divergence) and the caller
+      // overwrites those features
+      const uint32_t keep = ((q >> 1) && i >= 4 - kSliceLevels) ? 0u : 0xFFFFFFFFu;
       g.f[i][0] = gather_row<kHalf>(rsrc, (base + ((c ^ (hy0 ^ hz0)) & mask) * 8u) & keep);
       g.f[i][1] = gather_row<kHalf>(rsrc, (base + ((c ^ (hy1 ^ hz0)) & mask) * 8u) & keep);
       g.f[i][2] = gather_row<kHalf>(rsrc, (base + ((c ^ (hy0 ^ hz1)) & mask) * 8u) & keep);
@@ -770,9 +772,9 @@ struct NerfSave {
   float *enc, *h1, *so, *cin, *c1, *c2;
 };
 
-// kPre (table feed only; round 5, "XCD-sliced" frame path): the four FINEST levels (12..15, the fine slots of lanes q = 2, 3)
-// were evaluated by k_grid_fine_slices, one level per XCD pair; `d` (unused by the table feed) then points to their
-// features, float2 [4][m_pad], m_pad = M rounded up to 32; lanes q = 2, 3 read theirs from there.
+// kPre (table feed only; round 5, sliced frame path): the three FINEST levels (13..15, fine slots of lanes q = 2, 3) were
+// evaluated by k_grid_fine_slices; `d` (unused by the table feed) then points to their features, float2 [3][m_pad],
+// m_pad = M rounded up to 32; lanes q = 2, 3 read theirs from there and gather level 12 themselves.
 template <bool kColor, bool kTable = false, int kSave = 0, bool kHalf = false, bool kFast = false, bool kPre = false>
 __global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_nerf_fwd(const float* __restrict__ x, const float* __restrict__ d,
                                                                int64_t M, const int32_t* __restrict__ n_dev, float bound,
@@ -838,11 +840,12 @@ __global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_nerf_fwd(cons
       asm volatile("" : "+v"(rec_off));    // opaque per tile: keeps the records in LDS, not hoisted into VGPRs
       typedef float v2f __attribute__((ext_vector_type(2)));
       v2f fine_a = {0.f, 0.f}, fine_b = {0.f, 0.f};
-      if constexpr (kPre) {                // lanes q = 2, 3: levels 12 + 2(q-2), 13 + 2(q-2) = slices 2(q-2), 2(q-2)+1
+      if constexpr (kPre) {                // lane q = 2: levels 12 (own gathers), 13 (slice 0); q = 3: 14, 15 (slices 1, 2)
         static_assert(!kPre || kTable, "the sliced feed is a variant of the table feed");
+        static_assert(kSliceLevels == 3, "lane map below");
         const v2f* pre = reinterpret_cast<const v2f*>(d);
         const int64_t m_pad = (M + 31) & ~(int64_t)31, mm = valid ? m : n - 1;
-        const int sl = 2 * (q & 1);        // (lanes q = 0, 1 load the same rows: their values are not used)
+        const int sl = (q & 1) ? 1 : 0;    // (lanes q = 0, 1 load the same rows: their values are not used)
         fine_a = __builtin_nontemporal_load(pre + (int64_t)sl * m_pad + mm);
         fine_b = __builtin_nontemporal_load(pre + (int64_t)(sl + 1) * m_pad + mm);
       }
@@ -851,7 +854,8 @@ __global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_nerf_fwd(cons
       __builtin_amdgcn_sched_barrier(0);   // all 32 gathers in flight before the first blend waits
       blend<kHalf>(g, enc[0], enc[1]);
       if constexpr (kPre) {
-        if (q >> 1) enc[1] = f32x4{fine_a.x, fine_a.y, fine_b.x, fine_b.y};
+        if (q == 2) enc[1] = f32x4{enc[1][0], enc[1][1], fine_a.x, fine_a.y};          // level 12 gathered here, 13 precomputed
+        else if (q == 3) enc[1] = f32x4{fine_a.x, fine_a.y, fine_b.x, fine_b.y};       // 14, 15
       }
     }
     if constexpr (!kTable) {               // the table feed comes from the marcher, which clamps to the volume
@@ -949,23 +953,22 @@ __global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_nerf_fwd(cons
 #endif
 }
 
-// ---- XCD-sliced finest levels (round 5) ---------------------------------------------------------------------------
+// ---- sliced frame path: the finest levels level by level (round 5) ---------------------------------------------------
 // A hashed level is 2^19 rows x 8 B = 4 MiB - exactly one XCD's L2.  Where the finest levels are finer than the spacing
-// of the frame's samples (bound >= 4: finest level 8192), no two samples share a cell on them: each (sample, level)
-// costs four 128-byte lines whatever the order, and the only cache that can serve them is one that holds the WHOLE level.
-// The fused kernel lets every workgroup touch all 16 levels, so exactly those levels miss the L2 altogether - PMC at
-// bound 4: 12.35 fabric requests per sample = 3 levels x 4 lines, 58 G requests/s against the 69 G random lines/s the
-// XCD fabric ports deliver (profiles/r05_NOTES.txt 1-2).  Here the FOUR finest levels (12..15 - the fine slots of the
-// lane pair q = 2, 3) are evaluated by a pre-pass in which workgroup b serves level 12 + (b & 3) for half of the samples
-// (b >> 2 & 1): workgroup b runs on XCD b % 8, so an XCD's L2 holds ONE level (tools/micro/level_xcd_bench.hip: 259
-// against 69 G lines/s), and k_nerf_fwd<.., kPre> reads the 32 bytes per sample it leaves instead of missing 12 times.
-// (The first cut sliced all eight fine levels: the pre-pass then pays the L1-fill cost of levels the fused kernel gets
-// out of its L2 under its own MLP for free - 22 + 14.5 ms against 30 ms fused; notes 3.)  Placement is speed only: any
-// workgroup-to-XCD map gives the same numbers.  Lanes 2i, 2i+1 of a wave are the two x sides of sample i (one look-up
-// for the x-neighbour rows).  Arithmetic = the fused kernel's fine slots, operation by operation.
+// of the frame's samples (a scene that fills a bound >= 4 volume: finest level 8192), no two samples share a cell on
+// them: each (sample, level) costs four 128-byte lines whatever the order, and the only cache that can serve them is
+// one that holds the WHOLE level.  The fused kernel touches all 16 levels in every tile, so exactly those levels miss
+// the L2 altogether - PMC at bound 4: 12.35 fabric requests per sample = 3 levels x 4 lines, 58 G requests/s against
+// the 69 G random lines/s the XCD fabric ports deliver (profiles/r05_NOTES.txt 1-2).  This pre-pass evaluates the THREE
+// finest levels (13..15) one level at a time over all samples - the level is the slow index of the launch, so at any
+// moment every XCD's L2 holds the one level the chip is working on (tools/micro/level_xcd_bench.hip: 259 against 69 G
+// lines/s; the kernel reaches 200) - and leaves 24 bytes per sample for k_nerf_fwd<.., kPre>, which gathers the other
+// thirteen levels and reads these back, streamed.  2.8 ms per level and 141 M samples against 3.7 ms inside the fused
+// kernel; level 12 costs 0.7 ms inside and stays there (history of the cut, from all eight fine levels on their own XCDs
+// down to this: notes 3).  Lanes 2i, 2i+1 of a wave are the two x sides of sample i (one look-up for the x-neighbour
+// rows).  Arithmetic = the fused kernel's fine slots, operation by operation: results are bit-identical.
 constexpr int kSliceThreads = 256;
 constexpr int kSliceTilesPerIter = 4;     // 32-sample tiles a wave has in flight (4 loads per lane each)
-constexpr int kSliceLevels = 4;           // levels 12..15
 struct SliceX {
   float x0, x1, x2;
 };
@@ -974,10 +977,12 @@ __device__ __forceinline__ SliceX slice_load_x(const float* __restrict__ x01, in
   const float* p = x01 + mm * 3;
   return SliceX{__builtin_nontemporal_load(p), __builtin_nontemporal_load(p + 1), __builtin_nontemporal_load(p + 2)};
 }
+// grid (workgroups per level, kSliceLevels): the level is the SLOW index of the launch, so the chip sweeps the chunk's
+// samples level by level and at any time (nearly) all workgroups of every XCD gather from the same 4 MiB
 __global__ void __launch_bounds__(kSliceThreads) k_grid_fine_slices(const float* __restrict__ x01, int64_t M,
                                                                     const float2* __restrict__ emb, uint32_t emb_bytes,
                                                                     GridDesc G, float* __restrict__ pre) {
-  const int slice = blockIdx.x & 3, half = (blockIdx.x >> 2) & 1, local = blockIdx.x >> 3, per = gridDim.x >> 3;
+  const int slice = blockIdx.y;
   const int l = 16 - kSliceLevels + slice;
   const float sc = G.scales[l];
   const uint32_t m_ = G.mask[l], res1 = G.res1[l];
@@ -992,8 +997,7 @@ __global__ void __launch_bounds__(kSliceThreads) k_grid_fine_slices(const float*
   const int64_t m_pad = (M + 31) & ~(int64_t)31;
   const int64_t n_iter = (M + 32 * kT - 1) / (32 * kT);
   float* __restrict__ out = pre + (int64_t)slice * m_pad * 2;
-  // this workgroup's iterations: those of its half (even / odd), dealt over the workgroups of the (level, half)
-  for (int64_t it = 2 * ((int64_t)local * kWaves + w) + half; it < n_iter; it += 2 * (int64_t)per * kWaves) {
+  for (int64_t it = (int64_t)blockIdx.x * kWaves + w; it < n_iter; it += (int64_t)gridDim.x * kWaves) {
     u32x2 rows[kT][4];
     float wx[kT], fy[kT], fz[kT];
 #pragma unroll
@@ -2564,41 +2568,15 @@ static int nerf_forward_table_impl(const float* x01, const int32_t* ray_ids, con
 #undef INR_TABLE_LAUNCH
 }
 
-// ---- XCD-sliced frame path: pre-pass over the four finest levels + fused kernel on the rest ----------------------------
+// ---- sliced frame path: level-major pre-pass over the three finest levels + fused kernel on the other thirteen ------
 int64_t inr_nerf_forward_table_sliced_workspace_bytes(int64_t M) {
   return M < 0 ? -1 : kSliceLevels * ((M + 31) & ~(int64_t)31) * (int64_t)sizeof(float2);
 }
 
-// side stream + events of the chunked schedule, one set per device, created on first use
-struct SliceSide {
-  hipStream_t side = nullptr;
-  hipEvent_t fork = nullptr, pre_done = nullptr;
-  bool ok = false;
-};
-static SliceSide g_slice_side[64];
-static std::mutex g_slice_mu;
-static SliceSide* slice_side() {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-  std::lock_guard<std::mutex> lock(g_slice_mu);
-  SliceSide& S = g_slice_side[dev];
-  if (!S.ok) {
-    if (hipStreamCreateWithFlags(&S.side, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&S.fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&S.pre_done, hipEventDisableTiming) != hipSuccess) {
-      set_error("sliced frame path: could not create the side stream / events");
-      return nullptr;
-    }
-    S.ok = true;
-  }
-  return &S;
-}
-
 int inr_nerf_forward_table_sliced(const float* x01, const int32_t* ray_ids, const float* sh_table_q, int64_t M, float bound,
                                   const float* embeddings, const inr_grid_desc* desc, const float* packed,
-                                  float density_scale, float* sigma, float* rgb, float* fine_ws, int32_t n_chunks,
-                                  inr_stream_t s) {
-  INR_REQUIRE(M >= 0 && desc && n_chunks >= 0, "bad argument");
+                                  float density_scale, float* sigma, float* rgb, float* fine_ws, inr_stream_t s) {
+  INR_REQUIRE(M >= 0 && desc, "bad argument");
   if (M == 0) return INR_OK;
   INR_REQUIRE(x01 && ray_ids && sh_table_q && embeddings && packed && sigma && rgb && fine_ws, "null pointer");
   INR_REQUIRE(((uintptr_t)embeddings & 7) == 0 && ((uintptr_t)packed & 15) == 0 && ((uintptr_t)sh_table_q & 15) == 0 &&
@@ -2614,65 +2592,26 @@ int inr_nerf_forward_table_sliced(const float* x01, const int32_t* ray_ids, cons
   const float2* e = reinterpret_cast<const float2*>(embeddings);
   const size_t lds = std::max(kNerfFloats * sizeof(float) + kLevelRecBytes, (size_t)g_field_lds_min);
   hipStream_t st = as_stream(s);
-  if (n_chunks == 0) n_chunks = 8;
-  // chunk boundaries on multiples of 1024 samples: a chunk owns a compact [4][n_pad] block of the workspace
-  const int64_t per = ((M + n_chunks - 1) / n_chunks + 1023) & ~(int64_t)1023;
-  const int chunks = (int)((M + per - 1) / per);
-  const bool overlap = chunks > 1 && !stream_is_capturing(st);
-  SliceSide* S = overlap ? slice_side() : nullptr;
-  if (overlap && !S) return INR_ELAUNCH;
-  const int cus = cu_count();
   static int fit = 0;                      // resident pre-pass workgroups per CU (a constant of the build)
   if (fit < 1 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, k_grid_fine_slices, kSliceThreads, 0) != hipSuccess || fit < 1))
     fit = 4;
-  static const int env_per_cu = getenv("INR_SLICE_PRE_PER_CU") ? atoi(getenv("INR_SLICE_PRE_PER_CU")) : 0;
-  // chunked schedule: the pre-pass of chunk k+1 shares every CU with one workgroup of the fused kernel of chunk k
-  const int per_cu = overlap ? (env_per_cu > 0 ? std::min(env_per_cu, fit) : std::min(4, fit)) : fit;
-
-  auto pre_pass = [&](int64_t lo, int64_t n, hipStream_t on) {
-    const int64_t want = (n + 32 * kSliceTilesPerIter * (kSliceThreads / 64) - 1) / (32 * kSliceTilesPerIter * (kSliceThreads / 64));
-    // a multiple of 8: workgroup b serves level 12 + (b & 3), half (b >> 2) & 1
-    const int grid = (int)std::max<int64_t>(8, std::min<int64_t>((want + 1) / 2 * 8, (int64_t)cus * per_cu / 8 * 8));
-    k_grid_fine_slices<<<grid, kSliceThreads, 0, on>>>(x01 + lo * 3, n, e, eb, G, fine_ws + kSliceLevels * lo * 2);
-  };
-  auto fused = [&](int64_t lo, int64_t n) -> int {
-    const int grid = grid_for(k_nerf_fwd<true, true, 0, false, false, true>, lds, (n + 15) / 16);
-    StealSet steal_set;
-    if ((((n + 15) / 16) >> (kXcdChunkLog2 + 3)) >= 4 && !stream_is_capturing(st)) {
-      steal_set = steal_cursors(st);
-      if (!steal_set.cursors) return INR_ELAUNCH;
-    }
-    k_nerf_fwd<true, true, 0, false, false, true><<<grid, kFieldThreads, lds, st>>>(
-        x01 + lo * 3, fine_ws + kSliceLevels * lo * 2, n, nullptr, bound, e, eb, G, reinterpret_cast<const float4*>(packed),
-        density_scale, sigma + lo, rgb + lo * 3, nullptr, ray_ids + lo, reinterpret_cast<const float4*>(sh_table_q), NerfSave{},
-        steal_set.cursors);
-    steal_release(steal_set, st);
-    return (int)INR_OK;
-  };
-  if (!overlap) {
-    for (int c = 0; c < chunks; ++c) {
-      const int64_t lo = (int64_t)c * per, n = std::min(per, M - lo);
-      pre_pass(lo, n, st);
-      if ((rc = fused(lo, n)) != INR_OK) return rc;
-    }
-    return check_launch("nerf_forward_table_sliced");
+  // pre-pass: a full house of persistent workgroups per level; dispatch order (x fast, level slow) is the temporal order.
+  // (Measured and not kept, profiles/r05_NOTES.txt 3: the frame in chunks with the pre-pass of chunk k+1 on a side stream
+  //  beside the fused kernel of chunk k - the fused kernel's traffic then walks through the L2 the pre-pass lives on:
+  //  27.3-27.9 ms against 27.5 ms one after the other, 4.2-4.4 against 4.07 ms with growing steps.)
+  const int64_t per_wg = 32 * kSliceTilesPerIter * (kSliceThreads / 64);
+  const int gx = (int)std::max<int64_t>(1, std::min<int64_t>((M + per_wg - 1) / per_wg, (int64_t)cu_count() * fit));
+  k_grid_fine_slices<<<dim3(gx, kSliceLevels), kSliceThreads, 0, st>>>(x01, M, e, eb, G, fine_ws);
+  const int grid = grid_for(k_nerf_fwd<true, true, 0, false, false, true>, lds, (M + 15) / 16);
+  StealSet steal_set;
+  if ((((M + 15) / 16) >> (kXcdChunkLog2 + 3)) >= 4 && !stream_is_capturing(st)) {
+    steal_set = steal_cursors(st);
+    if (!steal_set.cursors) return INR_ELAUNCH;
   }
-  // chunked: pre-pass k+1 on the side stream beside fused kernel k.  The side stream starts behind everything queued on
-  // `s` so far (fork), every fused kernel waits for its chunk's pre-pass, and `s` ends behind the last one: to the caller
-  // the call is ordered on `s` like any other launch.  Each chunk has its own block of the workspace.
-  if (hipEventRecord(S->fork, st) != hipSuccess || hipStreamWaitEvent(S->side, S->fork, 0) != hipSuccess) {
-    set_error("sliced frame path: fork failed");
-    return INR_ELAUNCH;
-  }
-  for (int c = 0; c < chunks; ++c) {
-    const int64_t lo = (int64_t)c * per, n = std::min(per, M - lo);
-    pre_pass(lo, n, S->side);
-    if (hipEventRecord(S->pre_done, S->side) != hipSuccess || hipStreamWaitEvent(st, S->pre_done, 0) != hipSuccess) {
-      set_error("sliced frame path: join failed");
-      return INR_ELAUNCH;
-    }
-    if ((rc = fused(lo, n)) != INR_OK) return rc;
-  }
+  k_nerf_fwd<true, true, 0, false, false, true><<<grid, kFieldThreads, lds, st>>>(
+      x01, fine_ws, M, nullptr, bound, e, eb, G, reinterpret_cast<const float4*>(packed), density_scale, sigma, rgb, nullptr,
+      ray_ids, reinterpret_cast<const float4*>(sh_table_q), NerfSave{}, steal_set.cursors);
+  steal_release(steal_set, st);
   return check_launch("nerf_forward_table_sliced");
 }
 

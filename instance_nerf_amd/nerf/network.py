@@ -465,12 +465,11 @@ class NeRFNetwork(NeRFRenderer):
         # activations rounded to fp16, fp32 accumulation) instead of the three-pass bf16 split that keeps the default
         # fp32-class.  Outputs within a few 1e-3 of the default's; training and every other path are unaffected.
         self.mlp_fp16 = False
-        # Frame path of the fused field: False = one kernel; True = XCD-sliced (inr_nerf_forward_table_sliced: the four
-        # finest levels by a per-XCD pre-pass, `frame_slice_chunks` chunks pipelined on a side stream); "auto" (the
-        # default) = measure both on the first frames of this network and keep the faster - the sliced path pays where
-        # the finest levels have no locality at all (a scene filling a bound >= 4 volume), the fused kernel elsewhere
+        # Frame path of the fused field: False = one kernel; True = sliced (inr_nerf_forward_table_sliced: the three finest
+        # levels by a level-major pre-pass); "auto" (the default) = measure both on the first frames of this network and
+        # keep the faster - the sliced path pays where the finest levels have no locality at all (a scene filling a
+        # bound >= 4 volume), the fused kernel elsewhere
         self.frame_slices = __import__("os").environ.get("INR_FRAME_SLICES", "auto")
-        self.frame_slice_chunks = 8
         self._slice_probe = None
 
     # ---- packed MFMA weights (cached until a weight tensor changes) ------------------------------
@@ -665,14 +664,19 @@ class NeRFNetwork(NeRFRenderer):
                   "nerf_forward_table_half")
             return sigma, rgb
         if self._use_slices(M):
-            # XCD-sliced frame path (round 5): the four finest levels by a pre-pass in which every XCD serves one level
-            # (its L2 then holds that level whole), the fused kernel on the other twelve; same numbers bit for bit
-            ws = torch.empty(lib.inr_nerf_forward_table_sliced_workspace_bytes(M) // 4, dtype=torch.float32, device=dev)
+            # sliced frame path (round 5): the three finest levels by a level-major pre-pass (every XCD's L2 then holds
+            # the one level the chip is working on), the fused kernel on the other thirteen; same numbers bit for bit
+            need = lib.inr_nerf_forward_table_sliced_workspace_bytes(M) // 4
+            ws = self.__dict__.get("_slice_ws")
+            if ws is None or ws.numel() < need or ws.device != dev:
+                # kept between frames (24 bytes per sample: 3.4 GB for a 141 M-sample frame - a fresh block of that size
+                # per call cost tens of milliseconds in the allocator on the first frames); consumers run in stream order
+                ws = self.__dict__["_slice_ws"] = torch.empty(int(need * 1.25), dtype=torch.float32, device=dev)
             check(lib.inr_nerf_forward_table_sliced(ptr(x01, torch.float32, "x01"), ptr(ray_ids, torch.int32, "ray_ids"),
                                                     ptr(shq), M, float(self.bound),
                                                     ptr(self.encoder.embeddings.data, torch.float32), self.encoder.desc,
                                                     ptr(self._packed_weights("nerf")), 1.0, ptr(sigma), ptr(rgb), ptr(ws),
-                                                    int(self.frame_slice_chunks), stream_ptr()), "nerf_forward_table_sliced")
+                                                    stream_ptr()), "nerf_forward_table_sliced")
             self._close_slice_probe()
             return sigma, rgb
         check(lib.inr_nerf_forward_table(ptr(x01, torch.float32, "x01", allow_none=M == 0),

@@ -1293,10 +1293,10 @@ def test_full_size_frame_at_bound4_against_the_c_oracle(rm):
 
 
 def test_xcd_sliced_frame_path_is_bit_identical():
-    """Round 5: the XCD-sliced frame path (``NeRFNetwork.frame_slices``: the four finest levels evaluated by a pre-pass in
-    which every XCD serves one level, the fused kernel on the other twelve, chunks pipelined on an internal side stream)
-    returns the fused kernel's numbers bit for bit - table U(-1,1), a bound-4 frame of 800x800 rays and ragged small
-    batches, 1 / 3 / 8 chunks - and through ``render`` the same image; "auto" never probes below a finest level of 8192."""
+    """Round 5: the sliced frame path (``NeRFNetwork.frame_slices``: the three finest levels evaluated level by level by a
+    pre-pass, the fused kernel on the other thirteen) returns the fused kernel's numbers bit for bit - table U(-1,1), a
+    bound-4 frame of 800x800 rays and ragged small batches - and through ``render`` the same image; "auto" never probes
+    below a finest level of 8192."""
     from instance_nerf_amd import raymarching as rmod
     from instance_nerf_amd.nerf.utils import get_rays
     from instance_nerf_amd.scene import RoomScene
@@ -1319,11 +1319,10 @@ def test_xcd_sliced_frame_path_is_bit_identical():
         for M in (xyzs.shape[0], 1, 17, 1000, 70001):
             net.frame_slices = False
             ref = net.forward_table(xyzs[:M].contiguous(), ids[:M].contiguous(), rd, shq=shq)
-            for chunks in (1, 3, 8):
-                net.frame_slices, net.frame_slice_chunks = True, chunks
-                got = net.forward_table(xyzs[:M].contiguous(), ids[:M].contiguous(), rd, shq=shq)
-                assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), (M, chunks)
-        net.frame_slices, net.frame_slice_chunks = False, 8
+            net.frame_slices = True
+            got = net.forward_table(xyzs[:M].contiguous(), ids[:M].contiguous(), rd, shq=shq)
+            assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), M
+        net.frame_slices = False
         a = net.render(r["rays_o"], r["rays_d"], bg_color=1, infer_mode="fused", dt_gamma=1 / 128)
         net.frame_slices = True
         b = net.render(r["rays_o"], r["rays_d"], bg_color=1, infer_mode="fused", dt_gamma=1 / 128)

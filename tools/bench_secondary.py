@@ -511,8 +511,8 @@ def bound_render_probe(dev, bound=4, dt_gamma=1.0 / 128, frames=8):
                            "probed_ms_per_msample": {k: [round(v * 1e6, 4) for v in vs] for k, vs in
                                                      (("fused", probe.get("ms", {}).get(False, [])),
                                                       ("sliced", probe.get("ms", {}).get(True, [])))},
-                           "what": "fused = one kernel; sliced = the four finest levels by a per-XCD pre-pass, pipelined in "
-                                   "chunks beside the fused kernel (inr_nerf_forward_table_sliced); auto keeps the faster"},
+                           "what": "fused = one kernel; sliced = the three finest levels by a level-major pre-pass, then the "
+                                   "fused kernel on the other thirteen (inr_nerf_forward_table_sliced); auto keeps the faster"},
             "workload": f"render 800x800, sigma+rgb, room enlarged {bound}x in a bound-{bound} volume: {net.cascade} occupancy "
                         f"cascades, levels 16 .. {int(tb['resolutions'][-1])} ({int(tb['hashed'].sum())} of 16 hashed, "
                         f"T = {tb['total_rows']}), dt_gamma {dt_gamma:g}",

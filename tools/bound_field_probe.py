@@ -25,7 +25,7 @@ reps = int(args[0]) if args else 5
 configs = args[1:] or ["1:1:0:0:0", "2:2:128:0:0", "4:4:128:0:0", "4:4:0:0:0"]
 dev = torch.device("cuda", 0)
 VIEW = int(os.environ.get("PROBE_VIEW", "0"))
-# frame paths to run: fused | sliced[:chunks] | auto (NeRFNetwork.frame_slices)
+# frame paths to run: fused | sliced | auto (NeRFNetwork.frame_slices)
 MODES = os.environ.get("PROBE_MODES", "fused").split(",")
 
 
@@ -53,9 +53,7 @@ def one(cfg):
     tb = net.encoder.table
     ref = None
     for mode in MODES:
-        net.frame_slices = {"fused": False, "sliced": True}.get(mode.split(":")[0], "auto")
-        if ":" in mode:
-            net.frame_slice_chunks = int(mode.split(":")[1])
+        net.frame_slices = {"fused": False, "sliced": True}.get(mode, "auto")
         net._slice_probe = None
         with torch.no_grad():
             shq = net.sh_table(rd)
