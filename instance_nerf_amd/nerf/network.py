@@ -672,6 +672,7 @@ class NeRFNetwork(NeRFRenderer):
                 # kept between frames (24 bytes per sample: 3.4 GB for a 141 M-sample frame - a fresh block of that size
                 # per call cost tens of milliseconds in the allocator on the first frames); consumers run in stream order
                 ws = self.__dict__["_slice_ws"] = torch.empty(int(need * 1.25), dtype=torch.float32, device=dev)
+            ws.record_stream(torch.cuda.current_stream())      # FramePipeline: views on two streams share it (inside the gate)
             check(lib.inr_nerf_forward_table_sliced(ptr(x01, torch.float32, "x01"), ptr(ray_ids, torch.int32, "ray_ids"),
                                                     ptr(shq), M, float(self.bound),
                                                     ptr(self.encoder.embeddings.data, torch.float32), self.encoder.desc,

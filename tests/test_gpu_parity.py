@@ -1841,6 +1841,41 @@ def test_frame_pipeline_is_bit_identical(params_k16, room, room_bitfield, mode, 
         pipe.render(rays[0]["rays_o"], rays[0]["rays_d"], staged=True)
 
 
+def test_sliced_frames_through_the_frame_pipeline():
+    """The sliced frame path under FramePipeline: views alternate on two streams and share the network's ONE workspace of
+    precomputed fine-level features - both launches of a view sit inside the field gate, so view i+1's pre-pass cannot
+    overwrite what view i's fused kernel still reads.  Nine views of three sizes (the workspace is reused and regrown),
+    bit-identical to the fused kernel view by view."""
+    from instance_nerf_amd.nerf.renderer import FramePipeline
+    from instance_nerf_amd.nerf.utils import get_rays
+    from instance_nerf_amd.scene import RoomScene
+    from oracle import field, hashgrid
+    bound = 4
+    big = RoomScene(scale=float(bound))
+    p = field.init_params(seed=2, table=hashgrid.level_table(desired_resolution=2048 * bound), table_std=1.0, K=0)
+    net = _network(p, K=0, bound=bound).eval()
+    net.density_bitfield.copy_(_t(big.density_bitfield(128, float(bound))))
+    sizes = (160, 96, 240)
+    rays = []
+    for v, S in enumerate(sizes):
+        poses, intr, H, W = big.cameras(n=3, H=S, W=S, focal=S / 2.0)
+        rays.append(get_rays(_t(poses[v:v + 1]), intr, S, S, patch=4))
+    net.frame_slices = False
+    with torch.no_grad():
+        ref = [net.render(r["rays_o"], r["rays_d"], bg_color=1, infer_mode="fused", dt_gamma=1 / 128) for r in rays]
+    torch.cuda.synchronize()
+    net.frame_slices = True
+    pipe = FramePipeline(net)
+    with torch.no_grad():
+        outs = [pipe.render(rays[k % 3]["rays_o"], rays[k % 3]["rays_d"], bg_color=1, infer_mode="fused", dt_gamma=1 / 128)
+                for k in range(9)]
+    pipe.close()
+    assert net.__dict__.get("_slice_ws") is not None
+    for k, o in enumerate(outs):
+        for key in ("image", "depth", "weights_sum"):
+            assert torch.equal(o[key], ref[k % 3][key]), (k, key)
+
+
 @pytest.mark.parametrize("K", [0, 16])
 def test_trainer_view_loops_go_through_the_frame_pipeline_bit_identically(params_k16, room, room_bitfield, K, tmp_path):
     """Trainer.evaluate_one_epoch / test / render_sequence render a loader's views through FramePipeline (two alternating
