@@ -277,7 +277,7 @@ __device__ __forceinline__ void fma4(f32x4& a, float w, const f32x4 v) {
 // The kernel is bound by vector-instruction issue (PMC, profiles/r04_roialign_pmc.txt: a wave64 instruction holds a
 // SIMD for four cycles), so instructions per element are what is trimmed: buffer loads (one 32-bit offset per row
 // for all four channels, the channel in the scalar offset), explicit fma, no index decoding in the inner loops.
-template <int NOUT>   // output elements per thread: ow*ol*oh <= NOUT * SEP_THREADS
+template <int NOUT, bool kMulti>   // NOUT output elements per thread; kMulti: outputs beyond NOUT * SEP_THREADS, in chunks
 __global__ void __launch_bounds__(SEP_THREADS) k_roi_align3d_sep_fwd(const float* __restrict__ in,
                                                                      const float* __restrict__ rois,
                                                                      const int32_t* __restrict__ roi_inds, SepArgs A,
@@ -330,7 +330,11 @@ __global__ void __launch_bounds__(SEP_THREADS) k_roi_align3d_sep_fwd(const float
   // the taps of an output index are consecutive cells: ONE 16-byte load per channel covers four of them (the vector
   // memory path charges a gather per 128-byte line an INSTRUCTION touches: four one-tap loads touched the same lines
   // four times); the window is pulled back from the end of the row, cells outside [fz, lz] get weight zero
-  const int jz = min(min(fz, H - 1), H - 4);
+  // (round 5: pulled back from the end of the RoI's sampled REGION where that has four cells - the window then never
+  //  holds a cell no sample of this RoI touches, see the mask below - and from the end of the volume otherwise)
+  const int z1r = R->hi[2];
+  const bool tiny_z = sz < 4;                                    // RoI-uniform
+  const int jz = tiny_z ? min(min(fz, H - 1), H - 4) : min(fz <= lz ? fz : z0, z1r - 3);
   float wz[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) wz[j] = (jz + j >= fz && jz + j <= lz) ? T[2][ph1 * H + jz + j] : 0.0f;
@@ -338,17 +342,17 @@ __global__ void __launch_bounds__(SEP_THREADS) k_roi_align3d_sep_fwd(const float
   // Round-4 advisor: a window cell that NO sample of this RoI touches (before z0 when the window is pulled back from the
   // end of the row, behind z1 for the last output index) was multiplied by a zero weight - 0 x Inf = NaN where the
   // lane-per-output kernel, the oracle and torchvision never read the voxel.  Such cells are masked to +0 before the
-  // multiply (four ANDs per row and channel, taken only by the threads whose window leaves [z0, z1]); cells INSIDE
+  // multiply (four ANDs per row and channel, only in RoIs whose region is thinner than the window along z); cells INSIDE
   // the sampled region still meet zero weights of the output indices that do not reach them: a non-finite voxel inside
   // a RoI's region poisons that RoI's outputs along the row, as it poisons the ones that sample it anyway.
   uint32_t zm[4];
-  bool maskz = false;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const bool in = jz + j >= z0 && jz + j <= R->hi[2];
-    zm[j] = in ? 0xFFFFFFFFu : 0u;
-    maskz = maskz || !in;
-  }
+  for (int j = 0; j < 4; ++j) zm[j] = (jz + j >= z0 && jz + j <= z1r) ? 0xFFFFFFFFu : 0u;
+#ifdef SEP_NO_ZMASK
+  const bool maskz = false;
+#else
+  const bool maskz = tiny_z;      // only regions thinner than the window can leave it: one uniform branch per row otherwise
+#endif
 
   // ---- y role: (pl, ph), plane slot
   const int NS2 = SEP_THREADS / olh;
@@ -365,13 +369,13 @@ __global__ void __launch_bounds__(SEP_THREADS) k_roi_align3d_sep_fwd(const float
 
   // ---- x role: the output elements this thread owns
   // (the taps themselves stay in LDS as one 16-byte record per pw: sixteen more live registers cost a wave per SIMD)
+  // Outputs beyond NOUT * SEP_THREADS (14 bins: 2744 elements) are handled in CHUNKS of whole pw planes (round 5): a chunk
+  // is a smaller problem of its own - its pw planes tap a sub-range of the x cells, passes 1 and 2 run over that
+  // sub-range only (one or two cells shared with the neighbouring chunk) - so the accumulators stay at NOUT per thread.
+  // The round-4 kernel carried 8 or 16 outputs per thread instead: 184 / 256 VGPRs, two / ONE wave per SIMD, and 14 bins
+  // cost 3.3-5x the 10-bin time for 2.7x the outputs (profiles/r04_NOTES.txt 11).
+  const int pch = max(1, min(ow, (NOUT * SEP_THREADS) / olh));     // pw planes per chunk
   int orr[NOUT], opw[NOUT];
-#pragma unroll
-  for (int i = 0; i < NOUT; ++i) {
-    const int o = t + i * SEP_THREADS;
-    opw[i] = o < nout ? fdiv(o, 1.0f / (float)olh) : 0;
-    orr[i] = o < nout ? o - opw[i] * olh : 0;
-  }
   bool morex = false;
   if (t < ow) {
     const int f = first[0][t], l = last[0][t];
@@ -389,17 +393,42 @@ __global__ void __launch_bounds__(SEP_THREADS) k_roi_align3d_sep_fwd(const float
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(in + (int64_t)roi_inds[k] * A.C * WLH), 0, (int)((int64_t)A.C * WLH * 4), 0x00020000);
 
+  // the chunk's outputs and x cells (rows start and end monotonically in pw; rows without taps were pointed at x0 above)
+  constexpr bool multi = kMulti;
+  int o_lo = 0, o_hi = nout, cx0 = x0, cx1 = x0 + sx - 1;
+  auto chunk_setup = [&](int p0) {
+    const int p1 = min(p0 + pch, ow);
+    o_lo = p0 * olh;
+    o_hi = p1 * olh;
+    cx0 = x0 + sx;
+    cx1 = x0 - 1;
+    for (int pp = p0; pp < p1; ++pp) {
+      const int l = last[0][pp];
+      if (l >= first[0][pp]) { cx0 = min(cx0, (int)first[0][pp]); cx1 = max(cx1, l); }
+    }
+    cx0 = max(cx0, x0);
+    cx1 = min(cx1, x0 + sx - 1);
+#pragma unroll
+    for (int i = 0; i < NOUT; ++i) {
+      const int o = o_lo + t + i * SEP_THREADS;
+      opw[i] = o < o_hi ? fdiv(o, 1.0f / (float)olh) : p0;
+      orr[i] = o < o_hi ? o - opw[i] * olh : 0;
+    }
+  };
+  if (!multi) chunk_setup(0);
   for (int c = c0; c < cend; c += SEP_CH) {
     // a run shorter than SEP_CH re-reads its last channel and skips the stores
     int soff[SEP_CH];
 #pragma unroll
     for (int ch = 0; ch < SEP_CH; ++ch) soff[ch] = min(c + ch, A.C - 1) * WLH * 4;
+   for (int p0 = 0; p0 < (kMulti ? ow : 1); p0 += pch) {
+    if constexpr (kMulti) chunk_setup(p0);   // (a single chunk - every output up to 10 bins - was set up once, above)
     f32x4 acc[NOUT];
 #pragma unroll
     for (int i = 0; i < NOUT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int xs = 0; xs < sx; xs += XB) {
-      const int nx = min(XB, sx - xs);
+    for (int xs = cx0 - x0; xs <= cx1 - x0; xs += XB) {
+      const int nx = min(XB, cx1 - x0 + 1 - xs);
       // ---- pass 1 (z): tmp1[x][y][ph] = sum_z Tz[ph][z] * in[x0+xs+x][y0+y][z]
       const int nrows = act1 ? nx * sy : 0;
       for (int r = slot1; r < nrows; r += NS1) {
@@ -459,7 +488,7 @@ __global__ void __launch_bounds__(SEP_THREADS) k_roi_align3d_sep_fwd(const float
       if (morex) {        // rows longer than the four register taps (sampling grid > 2): the rest from the table
 #pragma unroll
         for (int i = 0; i < NOUT; ++i) {
-          if (t + i * SEP_THREADS >= nout) continue;
+          if (o_lo + t + i * SEP_THREADS >= o_hi) continue;
           const int pw = opw[i], lx = last[0][pw];
           const lfloat4* src = tmp2 + orr[i] - xlo * olh;
           for (int xx = max(first[0][pw] + 4, xlo); xx <= min(lx, xhi); ++xx) fma4(acc[i], T[0][pw * W + xx], src[xx * olh]);
@@ -472,8 +501,8 @@ __global__ void __launch_bounds__(SEP_THREADS) k_roi_align3d_sep_fwd(const float
     // the few channels of the volume its workgroups keep re-reading
 #pragma unroll
     for (int i = 0; i < NOUT; ++i) {
-      const int o = t + i * SEP_THREADS;
-      if (o < nout) {
+      const int o = o_lo + t + i * SEP_THREADS;
+      if (o < o_hi) {
         float* dst = obase + (int64_t)c * nout + o;
         SEP_STORE(dst, acc[i].x * inv_count);
         if (c + 1 < cend) SEP_STORE(dst + nout, acc[i].y * inv_count);
@@ -481,6 +510,9 @@ __global__ void __launch_bounds__(SEP_THREADS) k_roi_align3d_sep_fwd(const float
         if (c + 3 < cend) SEP_STORE(dst + 3 * (int64_t)nout, acc[i].w * inv_count);
       }
     }
+    // (no barrier between chunks either: the next chunk's pass 1 writes tmp1 only, and its first barrier is reached by
+    //  a wave after it has finished this chunk's pass 3)
+   }
 #if SEP_RUN_BARRIER
     __syncthreads();
 #endif
@@ -737,12 +769,11 @@ int inr_roi_align_3d_forward(const float* input, const float* rois, const int32_
     A.K = (int)K;
     A.tmp_floats = tmp_floats;
     const unsigned grid = 8u * (unsigned)K * (unsigned)((A.ngroups + 7) / 8);
+    // four outputs per thread; larger outputs (11 bins and up) in chunks of whole pw planes inside the kernel
     if (nout <= 4 * SEP_THREADS)
-      k_roi_align3d_sep_fwd<4><<<grid, SEP_THREADS, lds, as_stream(s)>>>(input, rois, roi_inds, A, out);
-    else if (nout <= 8 * SEP_THREADS)
-      k_roi_align3d_sep_fwd<8><<<grid, SEP_THREADS, lds, as_stream(s)>>>(input, rois, roi_inds, A, out);
+      k_roi_align3d_sep_fwd<4, false><<<grid, SEP_THREADS, lds, as_stream(s)>>>(input, rois, roi_inds, A, out);
     else
-      k_roi_align3d_sep_fwd<16><<<grid, SEP_THREADS, lds, as_stream(s)>>>(input, rois, roi_inds, A, out);
+      k_roi_align3d_sep_fwd<4, true><<<grid, SEP_THREADS, lds, as_stream(s)>>>(input, rois, roi_inds, A, out);
     return check_launch("roi_align_3d_forward (separable)");
   }
   k_roi_align3d_fwd<<<blocks_for(total, 256), 256, 0, as_stream(s)>>>(input, rois, roi_inds, C, W, L, H, total, out_w,

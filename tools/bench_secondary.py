@@ -352,7 +352,7 @@ def config5_probe(dev):
             "roi_align_roofline": {"bound": "hbm", "achieved": round(roi_bytes / t_roi / 1e9, 1), "peak": 8000.0,
                                    "unit": "GB/s", "frac": round(roi_bytes / t_roi / 8e12, 4),
                                    "compulsory_mb": round(roi_bytes / 1e6, 1),
-                                   "kernel": "k_roi_align3d_sep_fwd<4> (separable; events on the launch stream, 20 launches)",
+                                   "kernel": "k_roi_align3d_sep_fwd<4, false> (separable; events on the launch stream, 20 launches)",
                                    "backward_note": "k_roi_align3d_sep_bwd + the 65.5 MB zero fill of grad_input"}}
 
 

@@ -50,9 +50,9 @@ int main(int argc, char** argv) {
     printf("separable %-28s cpb %2d tmp %5d floats (lds %6d B): %.4f ms\n", what, cpb, tmp, lds, best);
     return 0;
   };
-  if (only_full) { run(k_roi_align3d_sep_fwd<4>, "full", 16, 10240); return 0; }
+  if (only_full) { run(k_roi_align3d_sep_fwd<4, false>, "full", 16, 10240); return 0; }
   for (int cpb : {8, 16, 32})
-    for (int tmp : {6144, 8192, 10240}) run(k_roi_align3d_sep_fwd<4>, "full", cpb, tmp);
+    for (int tmp : {6144, 8192, 10240}) run(k_roi_align3d_sep_fwd<4, false>, "full", cpb, tmp);
   {
     float best = 1e9f;
     const int64_t total = (int64_t)nout;
