@@ -29,12 +29,12 @@ HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BYTES_PER_SAMPLE = 1024         # 16 levels x 8 corners x 2 features x 4 B
 
 
-TRAFFIC_JSON = os.path.join("profiles", "r04_traffic.json")
+TRAFFIC_JSON = os.path.join("profiles", "r05_traffic.json")
 
 
 def measured_traffic_bytes_per_sample(res):
     """HBM-side bytes per sample of the fused field kernel from the committed PMC profile
-    (profiles/r04_traffic.json: FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc passes, gfx950 x2
+    (profiles/r05_traffic.json: FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc passes, gfx950 x2
     read correction; written by tools/traffic_json.py from a tools/pmc_bench.sh run).  PMC counters cannot be
     collected from inside this process, so the figure is only quoted for the kernel sources it was measured on (the
     file carries their sha): None if the profile is absent, belongs to other sources, or the workload differs."""

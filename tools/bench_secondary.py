@@ -20,12 +20,12 @@ HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BYTES_PER_SAMPLE = 1024         # 16 levels x 8 corners x 2 features x 4 B
 
 
-SCATTER_JSON = os.path.join("profiles", "r04_scatter_requests.json")
+SCATTER_JSON = os.path.join("profiles", "r05_scatter_requests.json")
 
 
 def scatter_requests(stage):
     """Memory-side atomic requests per sample of the table-gradient scatter and the unit's measured rate, from the
-    committed PMC profile (profiles/r04_scatter_requests.json, tools/pmc_train.sh + tools/scatter_requests_json.py);
+    committed PMC profile (profiles/r05_scatter_requests.json, tools/pmc_train.sh + tools/scatter_requests_json.py);
     quoted only for the kernel sources it was measured on.  -> (requests per sample, unit rate in requests/s) or None."""
     from instance_nerf_amd import build
     path = os.path.join(ROOT, SCATTER_JSON)
@@ -432,8 +432,8 @@ def instance_render_probe(dev, frames=8):
 BOUND_TRAFFIC_JSON = os.path.join("profiles", "r05_bound_traffic.json")
 
 
-def bound_traffic(bound, dt_gamma):
-    """Fabric read requests per sample of the fused field kernel at this configuration, from the committed PMC profile
+def bound_traffic(bound, dt_gamma, path="fused"):
+    """Fabric read requests per sample of the frame path taken (fused kernel | pre-pass + kernel) at this configuration, from the committed PMC profile
     (profiles/r05_bound_traffic.json: tools/pmc_bound.sh + tools/bound_traffic_json.py); quoted only for the kernel sources
     it was measured on.  -> (record of the configuration, random-line rate of the fabric in requests/s) or None."""
     from instance_nerf_amd import build
@@ -443,7 +443,7 @@ def bound_traffic(bound, dt_gamma):
     t = json.load(open(path))
     if t.get("source_sha") != build.source_sha():
         return None
-    key = f"{bound}:{bound}:{int(round(1 / dt_gamma)) if dt_gamma else 0}:0:0"
+    key = f"{bound}:{bound}:{int(round(1 / dt_gamma)) if dt_gamma else 0}:0:0" + ("-sliced" if path == "sliced" else "")
     rec = t["configs"].get(key)
     return None if rec is None else (rec, float(t["random_line_rate_of_the_fabric_g_per_s"]) * 1e9)
 
@@ -496,11 +496,11 @@ def bound_render_probe(dev, bound=4, dt_gamma=1.0 / 128, frames=8):
     # what binds the kernel off the tuned configuration is not the algorithmic byte count but the number of 128-byte
     # fabric requests its L2 misses cause (profiles/r05_NOTES.txt 1-2): both fractions side by side
     fabric = None
-    bt = bound_traffic(bound, dt_gamma)
+    bt = bound_traffic(bound, dt_gamma, path)
     if bt is not None and kms > 0:
         rec, ceiling = bt
         req_s = rec["fabric_read_requests_per_sample"] * (n / frames) / (kms / 1e3)
-        fabric = {"requests_per_sample": rec["fabric_read_requests_per_sample"], "bytes_per_sample": rec["fabric_read_bytes_per_sample"],
+        fabric = {"frame_path": path, "requests_per_sample": rec["fabric_read_requests_per_sample"], "bytes_per_sample": rec["fabric_read_bytes_per_sample"],
                   "l2_hit_rate": rec["l2_hit_rate"], "achieved_g_requests_per_s": round(req_s / 1e9, 1),
                   "traffic_gb_per_s": round(req_s * 128 / 1e9, 1), "ceiling_g_requests_per_s": round(ceiling / 1e9, 1),
                   "frac": round(req_s / ceiling, 4),

@@ -26,20 +26,25 @@ for sub in sorted(glob.glob(os.path.join(d, "*_*_*_*_*"))):
     if not m:
         continue
     M, ms = int(m.group(1)), float(m.group(2))
-    tot = defaultdict(lambda: defaultdict(float))
-    for f in glob.glob(os.path.join(sub, "*counter_collection.csv")):
-        for row in csv.DictReader(open(f)):
-            if "k_nerf_fwd" in row["Kernel_Name"]:
-                tot[row["Counter_Name"]][row["Dispatch_Id"]] += float(row["Counter_Value"])
-    mean = {k: sum(v.values()) / len(v) for k, v in tot.items()}
-    res[cfg] = {"samples": M, "field_ms_under_the_profiler": ms,
+    # per kernel of the frame path (the sliced path: the level-major pre-pass + the field kernel on thirteen levels):
+    # mean over its dispatches; the frame's figure is the sum over the kernels
+    mean = defaultdict(float)
+    for kern in ("k_nerf_fwd", "k_grid_fine_slices"):
+        tot = defaultdict(lambda: defaultdict(float))
+        for f in glob.glob(os.path.join(sub, "*counter_collection.csv")):
+            for row in csv.DictReader(open(f)):
+                if kern in row["Kernel_Name"]:
+                    tot[row["Counter_Name"]][row["Dispatch_Id"]] += float(row["Counter_Value"])
+        for k, v in tot.items():
+            mean[k] += sum(v.values()) / len(v)
+    res[cfg] = {"frame_path": "sliced" if cfg.endswith("-sliced") else "fused", "samples": M, "field_ms_under_the_profiler": ms,
                 "l1_lookups_per_sample": round(mean["TCP_TOTAL_CACHE_ACCESSES_sum"] / M, 2),
                 "l2_requests_per_sample": round(mean["TCP_TCC_READ_REQ_sum"] / M, 2),
                 "l2_misses_per_sample": round(mean["TCC_MISS_sum"] / M, 2),
                 "l2_hit_rate": round(mean["TCC_HIT_sum"] / (mean["TCC_HIT_sum"] + mean["TCC_MISS_sum"]), 4),
                 "fabric_read_requests_per_sample": round(mean["TCC_EA0_RDREQ_sum"] / M, 3),
                 "fabric_read_bytes_per_sample": round(mean["TCC_EA0_RDREQ_sum"] * 128 / M, 1)}
-json.dump({"kernel": "k_nerf_fwd<true,true>", "source_sha": build.source_sha(),
+json.dump({"kernel": "k_nerf_fwd<true,true> (fused) | k_grid_fine_slices + k_nerf_fwd<.., kPre> (sliced)", "source_sha": build.source_sha(),
            "source": f"{d} (rocprofv3 --pmc, separate passes, tools/pmc_bound.sh; one 800x800 view per configuration)",
            "fabric_request_bytes": 128,
            "random_line_rate_of_the_fabric_g_per_s": 69.0,
