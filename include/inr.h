@@ -37,7 +37,7 @@ extern "C" {
 /* Bumped whenever an existing prototype changes or an entry point is removed (round 2 changed four argument lists
  * without a bump: a stale library or an external caller built against the old header was only rejected by accident).
  * instance_nerf_amd/_lib.py refuses a library whose version differs from the one it was written against. */
-#define INR_ABI_VERSION 7
+#define INR_ABI_VERSION 8
 #define INR_MAX_LEVELS 16
 
 enum {
@@ -84,6 +84,13 @@ int inr_get_rays(const float* poses, int64_t B, float fx, float fy, float cx, fl
 
 int inr_near_far_from_aabb(const float* rays_o, const float* rays_d, const float* aabb /*[6]*/,
                            int64_t N, float min_near, float* nears, float* fars, inr_stream_t s);
+/* The same with per-ray labels (int64 [N]): a ray whose label equals `ignore_index` is reported as a miss (near = far =
+ * FLT_MAX), so the training march gives it no samples.  No upstream counterpart: upstream marches and evaluates the
+ * rays its mask loss then ignores (cross entropy with ignore_index -1 over matched masks,
+ * /root/reference/Mask2Former_sample/match_seg.py:111-138 writes the -1s).  Used by Trainer(stage="instance").          */
+int inr_near_far_from_aabb_skip(const float* rays_o, const float* rays_d, const float* aabb /*[6]*/, int64_t N,
+                                float min_near, const int64_t* labels, int64_t ignore_index, float* nears, float* fars,
+                                inr_stream_t s);
 
 /* ---- occupancy helpers (replace raymarching.morton3D / morton3D_invert / packbits, a3) */
 int inr_morton3D(const int32_t* coords /*[N,3]*/, int64_t N, int32_t* indices, inr_stream_t s);

@@ -32,6 +32,7 @@ _SIGS = {
     "inr_device_info": (c_int32, [c_int32, POINTER(c_int64)]),
     "inr_get_rays": (c_int32, [P, c_int64, c_float, c_float, c_float, c_float, c_int32, P, c_int64, P, P, P]),
     "inr_near_far_from_aabb": (c_int32, [P, P, P, c_int64, c_float, P, P, P]),
+    "inr_near_far_from_aabb_skip": (c_int32, [P, P, P, c_int64, c_float, P, c_int64, P, P, P]),
     "inr_morton3D": (c_int32, [P, c_int64, P, P]),
     "inr_morton3D_invert": (c_int32, [P, c_int64, P, P]),
     "inr_packbits": (c_int32, [P, c_int64, c_float, P, P]),
@@ -126,7 +127,7 @@ _SIGS = {
 }
 EXPORTS = tuple(_SIGS)
 
-ABI_VERSION = 7          # include/inr.h INR_ABI_VERSION this binding was written against
+ABI_VERSION = 8          # include/inr.h INR_ABI_VERSION this binding was written against
 _lib = None
 
 

@@ -27,11 +27,13 @@ __global__ void __launch_bounds__(kRayBlock) k_near_far(const float* __restrict_
                                                         const float* __restrict__ rays_d,
                                                         const float* __restrict__ aabb, int64_t N,
                                                         float min_near, float* __restrict__ nears,
-                                                        float* __restrict__ fars) {
+                                                        float* __restrict__ fars,
+                                                        const int64_t* __restrict__ labels, int64_t ignore) {
   const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
   float near = -INFINITY, far = INFINITY;
-  bool miss = false;
+  // a ray whose label is the ignored one is reported as a miss: it is never marched (inr_near_far_from_aabb_skip)
+  bool miss = labels != nullptr && labels[n] == ignore;
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
     const float o = rays_o[n * 3 + a];
@@ -1737,8 +1739,20 @@ int inr_near_far_from_aabb(const float* rays_o, const float* rays_d, const float
   INR_REQUIRE(N >= 0, "negative N");
   if (N == 0) return INR_OK;
   INR_REQUIRE(rays_o && rays_d && aabb && nears && fars, "null pointer");
-  k_near_far<<<blocks_for(N, kRayBlock), kRayBlock, 0, as_stream(s)>>>(rays_o, rays_d, aabb, N, min_near, nears, fars);
+  k_near_far<<<blocks_for(N, kRayBlock), kRayBlock, 0, as_stream(s)>>>(rays_o, rays_d, aabb, N, min_near, nears, fars,
+                                                                       nullptr, 0);
   return check_launch("near_far_from_aabb");
+}
+
+int inr_near_far_from_aabb_skip(const float* rays_o, const float* rays_d, const float* aabb, int64_t N,
+                                float min_near, const int64_t* labels, int64_t ignore_index, float* nears,
+                                float* fars, inr_stream_t s) {
+  INR_REQUIRE(N >= 0, "negative N");
+  if (N == 0) return INR_OK;
+  INR_REQUIRE(rays_o && rays_d && aabb && nears && fars && labels, "null pointer");
+  k_near_far<<<blocks_for(N, kRayBlock), kRayBlock, 0, as_stream(s)>>>(rays_o, rays_d, aabb, N, min_near, nears, fars,
+                                                                       labels, ignore_index);
+  return check_launch("near_far_from_aabb_skip");
 }
 
 int inr_morton3D(const int32_t* coords, int64_t N, int32_t* indices, inr_stream_t s) {

@@ -197,7 +197,7 @@ class NeRFRenderer(nn.Module):
 
     def run_cuda(self, rays_o, rays_d, dt_gamma=0, bg_color=None, perturb=False, force_all_rays=False,
                  max_steps=1024, T_thresh=1e-4, infer_mode="auto", noises=None, field_gate=None, ce_labels=None,
-                 ce_ignore_index=-1, mse_target=None, marched=None, **kwargs):
+                 ce_ignore_index=-1, mse_target=None, marched=None, ce_prune=False, **kwargs):
         """rays_o, rays_d [B,N,3] -> dict(image [B,N,3], depth [B,N], weights_sum [B,N] (, instance [B,N,K])).
 
         infer_mode (eval only; all modes render the same image):
@@ -213,6 +213,10 @@ class NeRFRenderer(nn.Module):
         instance logits against them (``ce_ignore_index`` rows skipped) is returned as ``results["instance_ce"]`` when
         the one-node instance head applies (``instance_head_available``); otherwise the key is absent and the caller
         computes the loss from ``results["instance"]`` as usual.
+        ce_prune (training, with ce_labels): rays labelled ``ce_ignore_index`` are not marched at all - they carry no
+        loss and no gradient, so loss and gradients are unchanged; their image / depth / instance rows come back as
+        those of a ray that misses the volume (background, zeros).  Trainer(stage="instance") asks for it; a caller
+        that wants the rendered rows of ignored rays leaves it off.
 
         marched (training): the result of ``march_ahead`` for exactly these rays - the ray/box test and the march were
         queued earlier (on a side stream, under the previous step's backward) and are not repeated here.
@@ -239,6 +243,9 @@ class NeRFRenderer(nn.Module):
         if marched is not None:
             marched["consume"]()
             nears, fars = marched["nears"], marched["fars"]
+        elif self.training and ce_prune and ce_labels is not None:
+            nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, aabb, self.min_near, skip_labels=ce_labels,
+                                                         ignore_index=ce_ignore_index)
         else:
             nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, aabb, self.min_near)
         if bg_color is None:
@@ -536,7 +543,7 @@ class NeRFRenderer(nn.Module):
 
     @torch.no_grad()
     def march_ahead(self, rays_o, rays_d, dt_gamma=0, perturb=False, max_steps=1024, stream=None, shade=False,
-                    T_thresh=1e-4, bufs=None, counter=None):
+                    T_thresh=1e-4, bufs=None, counter=None, skip_labels=None, ignore_index=-1):
         """The parameter-independent head of a TRAINING render - ray/box test, jitter, march (count, scan, write) - queued
         now, on ``stream`` (a side stream: it then runs beside whatever the current stream is busy with - the previous
         step's backward, whose table-gradient scatter leaves the CUs idle; measured: ~47 of its ~60 us hide), for a
@@ -550,7 +557,8 @@ class NeRFRenderer(nn.Module):
         the march, into the same persistent buffer set - ~165 us of the instance stage's ~0.83 ms step that can run
         beside the atomic-bound scatter.  ``bufs`` / ``counter``: a caller-owned buffer set
         (``raymarching.march_train_buffers(shade=...)``) and sample counter (int32 [2]) instead of the renderer's two
-        alternating sets and its ``step_counter`` slot - the captured pipeline of ``Trainer`` owns both."""
+        alternating sets and its ``step_counter`` slot - the captured pipeline of ``Trainer`` owns both.
+        ``skip_labels`` (int64, one per ray): rays labelled ``ignore_index`` are not marched (``render(ce_prune=True)``)."""
         if not (self.cuda_ray and self.training and self.mean_count > 0 and rays_o.is_cuda):
             return None
         rays_o_in, rays_d_in = rays_o, rays_d
@@ -593,7 +601,8 @@ class NeRFRenderer(nn.Module):
             self.local_step += 1
         with torch.cuda.stream(side):
             nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, self.aabb_train, self.min_near,
-                                                         out=(b["nears"], b["fars"]))
+                                                         out=(b["nears"], b["fars"]), skip_labels=skip_labels,
+                                                         ignore_index=ignore_index)
             xyzs, dirs, deltas, rays = raymarching.march_rays_train(
                 rays_o, rays_d, self.bound, self.density_bitfield, self.cascade, self.grid_size, nears, fars,
                 counter, self.mean_count, perturb, 128, False, dt_gamma, max_steps, out=b)

@@ -802,7 +802,7 @@ class Trainer:
                  workspace="workspace", best_mode="min", use_loss_as_metric=True, report_metric_at_train=False,
                  use_checkpoint="latest", use_tensorboardX=True, scheduler_update_every_step=False, *,
                  lr=1e-2, iters=30000, fused_adam=True, stage="nerf", update_extra_interval=None, use_graph=False,
-                 look_ahead=False, shade_ahead=None):
+                 look_ahead=False, shade_ahead=None, prune_ignored=True):
         self.name, self.opt, self.model = name, opt, model
         self.world_size, self.local_rank = world_size, local_rank
         grad_sync.world_size = world_size
@@ -860,6 +860,10 @@ class Trainer:
         # that; in the eager look-ahead it only adds host work)
         self.shade_ahead = bool(use_graph and look_ahead) if shade_ahead is None else bool(shade_ahead)
         self.pipe_fork = os.environ.get("INR_PIPE_FORK", "scatter")     # probe switch: where the captured step forks
+        # instance stage: rays whose matched-mask label is -1 carry neither loss nor gradient (cross entropy with
+        # ignore_index -1), so they are reported to the marcher as misses and cost nothing (render(ce_prune=True)):
+        # same loss, same gradients; the step's `pred` rows of those rays are zeros instead of rendered logits
+        self.prune_ignored = bool(prune_ignored)
         self.iters = iters
         # upstream: lr_scheduler = lambda optimizer: LambdaLR(optimizer, lambda it: 0.1 ** min(it / opt.iters, 1)),
         # stepped after every optimiser step; without one, exactly that rule is applied to the param groups
@@ -928,6 +932,7 @@ class Trainer:
         extra = {}
         if self.stage == "instance" and getattr(self.model, "cuda_ray", False) and data["rays_o"].is_cuda:
             extra["ce_labels"] = data["masks"]      # the renderer may form the mask loss inside its compositing launch
+            extra["ce_prune"] = self.prune_ignored  # rays labelled -1 carry no loss: never marched
         if (self.stage == "nerf" and self._default_criterion and getattr(self.model, "cuda_ray", False)
                 and data["rays_o"].is_cuda):
             extra["mse_target"] = gt                # the renderer may fold blend + loss + gradients into one launch
@@ -1158,6 +1163,10 @@ class Trainer:
         return dict(dt_gamma=kw.get("dt_gamma", 0), perturb=True, max_steps=kw.get("max_steps", 1024),
                     shade=self.stage == "instance" and self.shade_ahead, T_thresh=kw.get("T_thresh", 1e-4))
 
+    def _skip_labels(self, data):
+        """The labels whose ignored rays the march leaves out (instance stage, ``prune_ignored``), or None."""
+        return data["masks"] if (self.stage == "instance" and self.prune_ignored and "masks" in data) else None
+
     def _pipe_init(self, data):
         from .. import raymarching
         m, dev = self.model, data["rays_o"].device
@@ -1208,7 +1217,7 @@ class Trainer:
         with torch.cuda.graph(g):
             if prime:
                 S["marched"] = m.march_ahead(S["static"]["rays_o"], S["static"]["rays_d"], stream=None, bufs=S["bufs"],
-                                             counter=S["counter"], **args)
+                                             counter=S["counter"], skip_labels=self._skip_labels(S["static"]), **args)
                 if S["marched"] is None:
                     raise RuntimeError("pipeline: march_ahead refused the batch (not the steady state / staged marcher)")
             marched = dict(S["marched"])
@@ -1220,7 +1229,7 @@ class Trainer:
 
             def hook():
                 Nx["marched"] = m.march_ahead(Nx["static"]["rays_o"], Nx["static"]["rays_d"], stream=side, bufs=Nx["bufs"],
-                                              counter=Nx["counter"], **args)
+                                              counter=Nx["counter"], skip_labels=self._skip_labels(Nx["static"]), **args)
             if ahead and self.pipe_fork == "start":
                 hook()                               # fork right away: beside the whole step
             elif ahead:
@@ -1295,7 +1304,8 @@ class Trainer:
             return                                   # the buffers marched from must be the ones render() will see
         self._ahead = m.march_ahead(ro, rd, dt_gamma=kw.get("dt_gamma", 0), perturb=True,
                                     max_steps=kw.get("max_steps", 1024), stream=self._side_stream,
-                                    shade=self.stage == "instance" and self.shade_ahead, T_thresh=kw.get("T_thresh", 1e-4))
+                                    shade=self.stage == "instance" and self.shade_ahead, T_thresh=kw.get("T_thresh", 1e-4),
+                                    skip_labels=self._skip_labels(next_data))
 
     def train_one_step(self, data, next_data=None):
         """One optimisation step on ``data``.  ``next_data`` (optional): the batch the NEXT call will get - its ray/box

@@ -49,8 +49,9 @@ def set_march_mode(mode):
     check(_lib.load().inr_set_march_mode(code), "set_march_mode")
 
 
-def near_far_from_aabb(rays_o, rays_d, aabb, min_near=0.2, out=None):
-    """rays_o, rays_d [N,3]; aabb [6] -> nears, fars [N] (written into ``out = (nears, fars)`` when given)."""
+def near_far_from_aabb(rays_o, rays_d, aabb, min_near=0.2, out=None, skip_labels=None, ignore_index=-1):
+    """rays_o, rays_d [N,3]; aabb [6] -> nears, fars [N] (written into ``out = (nears, fars)`` when given).
+    skip_labels (int64 [N]): rays labelled ``ignore_index`` come back as misses - the march gives them no samples."""
     lib = _lib.load()
     rays_o, rays_d, aabb = _f(rays_o).view(-1, 3), _f(rays_d).view(-1, 3), _f(aabb)
     N = rays_o.shape[0]
@@ -59,6 +60,15 @@ def near_far_from_aabb(rays_o, rays_d, aabb, min_near=0.2, out=None):
     else:
         nears = torch.empty(N, dtype=F32, device=rays_o.device)
         fars = torch.empty(N, dtype=F32, device=rays_o.device)
+    if skip_labels is not None:
+        labels = skip_labels.reshape(-1).contiguous()
+        if labels.shape[0] != N:
+            raise RuntimeError(f"near_far_from_aabb: {labels.shape[0]} labels for {N} rays")
+        check(lib.inr_near_far_from_aabb_skip(ptr(rays_o, F32, "rays_o"), ptr(rays_d, F32, "rays_d"), ptr(aabb, F32, "aabb"),
+                                              N, float(min_near), ptr(labels, torch.int64, "skip_labels"),
+                                              int(ignore_index), ptr(nears), ptr(fars), stream_ptr()),
+              "near_far_from_aabb_skip")
+        return nears, fars
     check(lib.inr_near_far_from_aabb(ptr(rays_o, F32, "rays_o"), ptr(rays_d, F32, "rays_d"), ptr(aabb, F32, "aabb"),
                                      N, float(min_near), ptr(nears), ptr(fars), stream_ptr()), "near_far_from_aabb")
     return nears, fars

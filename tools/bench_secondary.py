@@ -283,6 +283,10 @@ def train_probe(dev, rank=0, world=1, red_dev=None, steps=20, warmup=5, stage="i
             "host_enqueue_ms_per_step": round(host_s / steps * 1e3, 3),     # a busy host shows here first
             "samples_per_step": int(n_all) // steps,
             "msamples_per_s": round(n_all / steps / dt / 1e6, 2),
+            # instance stage: rays whose mask label is -1 (10 % of the synthetic loader's, as unmatched segments are in
+            # match_seg.py's output) carry no loss; Trainer(prune_ignored=True) never marches them
+            "ignored_rays": ({"fraction_of_the_batch": round(float(np.mean([float((b["masks"] < 0).float().mean()) for b in batches])), 4),
+                              "marched": not tr.prune_ignored} if stage == "instance" else None),
             "allreduce_mb_per_step": round(reduced / 1e6, 1) if world > 1 else 0.0,
             "gradient_schedule": (f"{_grad_sync.schedule}, payload {_grad_sync.payload}, "
                                   f"{'started inside the backward' if _grad_sync.enabled else 'after the backward'}") if world > 1 else None,

@@ -15,7 +15,7 @@ net, _ = build_network(dev)
 res = extract.grid_resolution([-1, -1, -1], [1, 1, 1], 160)
 axes = extract.lattice_axes(np.asarray([-1, -1, -1], np.float32), np.asarray([1, 1, 1], np.float32), res, dev)
 dirs = torch.from_numpy(extract.VIEW_DIRS).to(dev)
-for D in (1, 2, 4):
+for D in ([int(os.environ["PROBE_DIRS"])] if os.environ.get("PROBE_DIRS") else (1, 2, 4)):
     d = dirs[:D].contiguous()
     net.forward_lattice(axes, d)
     torch.cuda.synchronize()
