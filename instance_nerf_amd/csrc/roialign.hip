@@ -525,6 +525,13 @@ __global__ void __launch_bounds__(SEP_THREADS) k_roi_align3d_sep_fwd(const float
 // Backward = the transpose, pass by pass: gout [ow][ol][oh] -(x^T)-> [sx][ol][oh] -(y^T)-> [sx][sy][oh] -(z^T)->
 // [sx][sy][sz], added into grad_input with one atomic per touched cell and channel (the lane-per-output kernel
 // issues 8 g^3 per output element); lanes run along z, so the atomics of a wave hit adjacent addresses.
+// What bounds it (round 5, tools/micro/roialign_bench bwd, configs[4]): with the fixed roles below the three passes take
+// 0.13-0.16 ms (plain stores instead of atomics: 0.16; the first version: 0.40 / 0.45) and the launch still takes 0.58 ms
+// whatever the channels per workgroup (8..32) or the LDS budget (2..5 workgroups per CU): a region row along z is
+// ~10 floats = 1.56 64-byte segments per (x, y, channel), 10.7 M atomic requests per call, and the memory-side atomic
+// unit takes ~21 G requests/s whatever their width (profiles/r03_NOTES.txt 1) = 0.51 ms.  Fewer requests need another
+// layout of the accumulation target (channels fastest: one 64-byte request per voxel and 16 channels, 2.4x fewer, plus a
+// transposing copy into grad_input) - priced in profiles/r05_NOTES.txt 5, not built.
 __global__ void __launch_bounds__(SEP_THREADS) k_roi_align3d_sep_bwd(const float* __restrict__ gout,
                                                                      const float* __restrict__ rois,
                                                                      const int32_t* __restrict__ roi_inds, SepArgs A,
@@ -586,6 +593,47 @@ __global__ void __launch_bounds__(SEP_THREADS) k_roi_align3d_sep_bwd(const float
   const float* gbase = gout + ((int64_t)k * A.C) * nout;
   float* vol0 = gin + ((int64_t)roi_inds[k] * A.C) * WLH;
 
+  // ---- roles (round 5).  The first version of this kernel decoded (x, y, z) from a flat item index in every pass - two
+  // integer divisions per item, ~60 vector instructions around ~20 useful ones - and read taps and tap ranges from the
+  // tables per item.  Now a thread's role is fixed for the whole RoI, as in the forward: (pl, ph) in the x^T pass, cell y
+  // and ph in the y^T pass, cell z in the z^T pass; the taps of its cell (first output index + four weights; longer
+  // ranges - boxes thinner than the output - take the rest from the table) sit in registers and the loops run over
+  // x planes / (x, y) rows with a carried increment.  Needs ol*oh, sy*oh and sz within the workgroup (every RoI up to
+  // 25 cells across at 10 bins); other RoIs take the generic loops below.
+  const bool fast = olh <= SEP_THREADS && sy * oh <= SEP_THREADS && sz <= SEP_THREADS;      // RoI-uniform
+  int NSA = 1, slotA = 0, rA = 0, NSB = 1, slotB = 0, yB = 0, phB = 0, pfB = 0, plB = -1, nB = 0;
+  int NSC = 1, slotC = 0, zC = 0, pfC = 0, plC = -1, nC = 0, xC0 = 0, yC0 = 0, dxC = 0, dyC = 0;
+  bool actA = false, actB = false, actC = false, moreB = false, moreC = false;
+  float wB[4] = {0.f, 0.f, 0.f, 0.f}, wC[4] = {0.f, 0.f, 0.f, 0.f};
+  if (fast) {
+    NSA = SEP_THREADS / olh; slotA = t / olh; rA = t - slotA * olh; actA = slotA < NSA;
+    const int syoh = sy * oh;
+    NSB = SEP_THREADS / syoh; slotB = t / syoh;
+    const int rB = t - slotB * syoh;
+    yB = rB / oh; phB = rB - yB * oh; actB = slotB < NSB;
+    {
+      const int cell = y0 + yB;
+      const int pf = pfirst[1][cell], pl = plast[1][cell];
+      pfB = pf <= pl ? pf : 0; plB = pf <= pl ? pl : -1;
+      nB = max(plB - pfB, 0);                  // tap j reads output index pfB + min(j, nB): always one that reaches the cell
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wB[j] = (pfB + j <= plB) ? T[1][(pfB + j) * L + cell] : 0.0f;
+      moreB = plB >= pfB + 4;
+    }
+    NSC = SEP_THREADS / sz; slotC = t / sz; zC = t - slotC * sz; actC = slotC < NSC;
+    {
+      const int cell = z0 + zC;
+      const int pf = pfirst[2][cell], pl = plast[2][cell];
+      pfC = pf <= pl ? pf : 0; plC = pf <= pl ? pl : -1;
+      nC = max(plC - pfC, 0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wC[j] = (pfC + j <= plC) ? T[2][(pfC + j) * H + cell] : 0.0f;
+      moreC = plC >= pfC + 4;
+    }
+    xC0 = slotC / sy; yC0 = slotC - xC0 * sy;     // row = x * sy + y, rows slotC, slotC + NSC, ...
+    dxC = NSC / sy; dyC = NSC - dxC * sy;
+  }
+
   // The gout values of the NEXT channel run are requested before this run's passes (round 5): the kernel is a chain of
   // dependent steps per run - global read, barrier, three LDS passes - and the read used to start only when the
   // previous run had finished.  Up to GOP elements per thread ride in registers (outputs up to 1024 elements: 10^3); larger
@@ -636,6 +684,59 @@ __global__ void __launch_bounds__(SEP_THREADS) k_roi_align3d_sep_bwd(const float
       }
     }
     __syncthreads();
+    if (fast) {
+    // ---- fixed roles (round 5): no index decoding and no table look-ups in the inner loops (see the roles above)
+    for (int xs = 0; xs < sx; xs += XB) {
+      const int nx = min(XB, sx - xs);
+      // ---- x^T: t2[x][pl][ph] = sum_pw Tx[pw][x] * go[pw][pl][ph]       (x is wave-uniform up to the slot: broadcasts)
+      const int nxA = actA ? nx : 0;
+      for (int x = slotA; x < nxA; x += NSA) {
+        const int cell = x0 + xs + x;
+        const int pf = pfirst[0][cell], pl = plast[0][cell];
+        f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int p = pf; p <= pl; ++p) fma4(a, T[0][p * W + cell], go[p * olh + rA]);
+        t2[x * olh + rA] = a;
+      }
+      __syncthreads();
+      // ---- y^T: t1[x][y][ph] = sum_pl Ty[pl][y] * t2[x][pl][ph]        (taps of cell y in registers)
+      const int nxB = actB ? nx : 0;
+      for (int x = slotB; x < nxB; x += NSB) {
+        const lfloat4* src = t2 + (x * ol + pfB) * oh + phB;
+        f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fma4(a, wB[j], src[min(j, nB) * oh]);
+        if (moreB)
+          for (int p = pfB + 4; p <= plB; ++p) fma4(a, T[1][p * L + y0 + yB], src[(p - pfB) * oh]);
+        t1[(x * sy + yB) * oh + phB] = a;
+      }
+      __syncthreads();
+      // ---- z^T: grad_input[x][y][z] += sum_ph Tz[ph][z] * t1[x][y][ph]   (taps of cell z in registers; lanes along z)
+      const int nrowsC = actC ? nx * sy : 0;
+      int x = xC0, y = yC0;
+      for (int row = slotC; row < nrowsC; row += NSC) {
+        const lfloat4* src = t1 + row * oh + pfC;
+        f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fma4(a, wC[j], src[min(j, nC)]);
+        if (moreC)
+          for (int p = pfC + 4; p <= plC; ++p) fma4(a, T[2][p * H + z0 + zC], src[p - pfC]);
+        float* dst = vol0 + (int64_t)c * WLH + ((x0 + xs + x) * L + (y0 + y)) * H + z0 + zC;
+#if SEP_BWD_PROBE == 1       // profiling builds only: plain stores (wrong results) - what do the atomics cost?
+        dst[0] = a.x; dst[WLH] = a.y; dst[2 * WLH] = a.z; dst[3 * WLH] = a.w;
+#elif SEP_BWD_PROBE == 2     // no global writes at all
+        if (a.x == 12345.678f) dst[0] = a.x + a.y + a.z + a.w;
+#else
+        atomicAdd(dst, a.x);
+        if (c + 1 < cend) atomicAdd(dst + WLH, a.y);
+        if (c + 2 < cend) atomicAdd(dst + 2 * WLH, a.z);
+        if (c + 3 < cend) atomicAdd(dst + 3 * WLH, a.w);
+#endif
+        y += dyC; x += dxC;
+        if (y >= sy) { y -= sy; ++x; }
+      }
+    }
+    } else {
+    // ---- any extents: every item decodes its indices and reads its taps from the tables
     for (int xs = 0; xs < sx; xs += XB) {
       const int nx = min(XB, sx - xs);
       // ---- x^T: t2[x][pl][ph] = sum_pw Tx[pw][x] * go[pw][pl][ph]
@@ -693,6 +794,7 @@ __global__ void __launch_bounds__(SEP_THREADS) k_roi_align3d_sep_bwd(const float
       }
       // t2 is rewritten by the next slab's first pass while slow waves may still read t1 here, never t2: fine; t1 is
       // rewritten after that pass's barrier
+    }
     }
     __syncthreads();   // go is reloaded
   }

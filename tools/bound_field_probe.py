@@ -67,6 +67,17 @@ def one(cfg):
             e1.record()
             torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / reps
+        if os.environ.get("PROBE_EACH"):
+            # every launch on its own clock, back to back: does the time of ONE kernel depend on how long the device has
+            # been busy (clock ramp after the host-paced start)?
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(41)]
+            with torch.no_grad():
+                evs[0].record()
+                for i in range(40):
+                    net.forward_table(xyzs, dirs, rd, shq=shq)
+                    evs[i + 1].record()
+            torch.cuda.synchronize()
+            print("   each of 40 back-to-back launches (ms):", " ".join(f"{evs[i].elapsed_time(evs[i + 1]):.2f}" for i in range(40)))
         same = ""
         if ref is None:
             ref = out

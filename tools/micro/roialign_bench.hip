@@ -4,6 +4,7 @@
 #include "../../instance_nerf_amd/csrc/roialign.hip"
 
 #include <random>
+#include <string>
 #include <vector>
 
 namespace inr {
@@ -50,6 +51,34 @@ int main(int argc, char** argv) {
     printf("separable %-28s cpb %2d tmp %5d floats (lds %6d B): %.4f ms\n", what, cpb, tmp, lds, best);
     return 0;
   };
+  if (argc > 1 && std::string(argv[1]) == "bwd") {
+    // the backward's launch parameters: channels per workgroup x LDS budget of the slab intermediates (gout rides on top);
+    // `out` holds the output gradient (whatever the forward sweep left there or zeros), gin is accumulated into, never read
+    float* gin;
+    CK(hipMalloc(&gin, hin.size() * 4));
+    CK(hipMemset(gin, 0, hin.size() * 4));
+    CK(hipMemset(out, 0, nout * 4));
+    for (int cpb : {8, 16, 32, 64})
+      for (int tmp : {2048, 3072, 4096, 6144, 10240}) {
+        SepArgs A;
+        A.C = C; A.W = W; A.L = L; A.H = H; A.ow = o; A.ol = o; A.oh = o; A.scale = 0.25f; A.cpb = cpb;
+        A.ngroups = (C + cpb - 1) / cpb; A.K = K; A.tmp_floats = tmp + SEP_CH * o * o * o;
+        const int lds = (o * W * 3 + 6 * o + 2 * (W + L + H)) * 4 + (int)sizeof(SepRoi) + 16 + A.tmp_floats * 4;
+        const unsigned grid = 8u * K * ((A.ngroups + 7) / 8);
+        float best = 1e9f;
+        for (int it = 0; it < 6; ++it) {
+          CK(hipEventRecord(e0));
+          k_roi_align3d_sep_bwd<<<grid, SEP_THREADS, lds>>>(out, rois, inds, A, gin);
+          CK(hipEventRecord(e1));
+          CK(hipEventSynchronize(e1));
+          float ms;
+          CK(hipEventElapsedTime(&ms, e0, e1));
+          if (it) best = std::min(best, ms);
+        }
+        printf("separable backward cpb %2d slab budget %5d floats (lds %6d B): %.4f ms (without the zero fill)\n", cpb, tmp, lds, best);
+      }
+    return 0;
+  }
   if (only_full) { run(k_roi_align3d_sep_fwd<4, false>, "full", 16, 10240); return 0; }
   for (int cpb : {8, 16, 32})
     for (int tmp : {6144, 8192, 10240}) run(k_roi_align3d_sep_fwd<4, false>, "full", cpb, tmp);

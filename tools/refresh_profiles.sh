@@ -10,6 +10,19 @@ O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
 python -m pytest tests -x -q -m gpu > $O/pytest.txt 2>&1; tail -2 $O/pytest.txt
+# the PMC passes first: the three sha-keyed json files are installed under profiles/ ON THE BOX before the bench runs, so
+# that the bench line of this very call carries `traffic`, `atomic_unit` and `fabric_requests` (copy them into the
+# repository's profiles/ afterwards - they describe exactly these kernel sources)
+bash tools/pmc_bench.sh ${TAG}_pmc > $O/pmc_bench.txt 2>&1
+python tools/traffic_json.py gpurun_out/${TAG}_pmc gpurun_out/${TAG}_pmc.hbm_rd.log $O/r05_traffic.json > /dev/null; echo "traffic rc=$?"
+bash tools/pmc_train.sh ${TAG}_pmct > $O/pmc_train.txt 2>&1
+NO_UPDATE=1 bash tools/pmc_train.sh ${TAG}_pmcn k_grid_bwd tools/train_nerf_probe.py > $O/pmc_train_nerf.txt 2>&1
+# samples per step of the two probes' timed steps: their last output line ("train step ... ms, N samples/step, ...")
+NI=$(grep -o "[0-9]* samples/step" gpurun_out/${TAG}_pmct.atom2.log | tail -1 | cut -d" " -f1)
+NN=$(grep -o "[0-9]* samples/step" gpurun_out/${TAG}_pmcn.atom2.log | tail -1 | cut -d" " -f1)
+python tools/scatter_requests_json.py gpurun_out/${TAG}_pmct ${NI:-209000} gpurun_out/${TAG}_pmcn ${NN:-209000} $O/r05_scatter_requests.json > /dev/null; echo "scatter json rc=$? ($NI / $NN samples per step)"
+bash tools/pmc_bound.sh ${TAG}_pmcb > $O/bound_pmc.txt 2>&1; cp gpurun_out/${TAG}_pmcb.bound_traffic.json $O/r05_bound_traffic.json
+cp $O/r05_traffic.json $O/r05_scatter_requests.json $O/r05_bound_traffic.json $R/profiles/
 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
 export TMPDIR=/tmp
 cd /tmp
@@ -20,19 +33,11 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_ins
 NO_UPDATE=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_nerf -o nerf -- python3 $R/tools/train_nerf_probe.py 40 \
   > $O/train_nerf_probe.txt 2>&1
 cd $R
-bash tools/pmc_bench.sh ${TAG}_pmc > $O/pmc_bench.txt 2>&1
-python tools/traffic_json.py gpurun_out/${TAG}_pmc gpurun_out/${TAG}_pmc.hbm_rd.log $O/r05_traffic.json; echo "traffic rc=$?"
-bash tools/pmc_train.sh ${TAG}_pmct > $O/pmc_train.txt 2>&1; tail -25 $O/pmc_train.txt
 python tools/timed_launches.py $O/trace $O/bench_profiled.json > $O/bench_timed_launches.txt 2>&1
 python tools/step_launches.py $O/trace_inst > $O/launches_inst.txt 2>&1
 python tools/step_launches.py $O/trace_nerf > $O/launches_nerf.txt 2>&1
 ls $O
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; tail -1 $O/smoke.txt
-NO_UPDATE=1 bash tools/pmc_train.sh ${TAG}_pmcn k_grid_bwd tools/train_nerf_probe.py > $O/pmc_train_nerf.txt 2>&1
-# samples per step of the two probes' timed steps: their last output line ("train step ... ms, N samples/step, ...")
-NI=$(grep -o "[0-9]* samples/step" gpurun_out/${TAG}_pmct.atom2.log | tail -1 | cut -d" " -f1)
-NN=$(grep -o "[0-9]* samples/step" gpurun_out/${TAG}_pmcn.atom2.log | tail -1 | cut -d" " -f1)
-python tools/scatter_requests_json.py gpurun_out/${TAG}_pmct ${NI:-209000} gpurun_out/${TAG}_pmcn ${NN:-209000} $O/r05_scatter_requests.json > /dev/null; echo "scatter json rc=$? ($NI / $NN samples per step)"
 # round 4: timelines of the instance step (eager, captured two-stream pipeline with and without the shaded head)
 export TMPDIR=/tmp
 cd /tmp
@@ -52,8 +57,9 @@ python tools/extract_order_probe.py > $O/extract_order_probe.txt 2>&1
 python -m pytest tests/test_train_twin.py -m gpu -q -s 2>&1 | grep -E "held-out|passed|failed" > $O/train_twin.txt
 # round 5: the field kernel off its tuned configuration (PMC per configuration -> bound traffic json), both frame paths,
 # the RoIAlign shapes (incl. the GT-mask crop call) and the extraction's direction sweep
-bash tools/pmc_bound.sh ${TAG}_pmcb > $O/bound_pmc.txt 2>&1; cp gpurun_out/${TAG}_pmcb.bound_traffic.json $O/r05_bound_traffic.json
 PROBE_MODES=fused,sliced,auto python tools/bound_field_probe.py 5 1:1:0:0:0 2:2:128:0:0 4:4:0:0:0 4:4:128:0:0 8:8:128:0:0 2>&1 | grep -v amdgpu.ids > $O/frame_paths.txt
 python tools/roialign_shapes_probe.py 2>&1 | grep -v amdgpu > $O/roialign_shapes.txt
 python tools/extract_dirs_probe.py 2>&1 | grep -v amdgpu > $O/extract_dirs_probe.txt
+bash tools/pmc_extract.sh ${TAG}_pmcx > $O/extract_pmc.txt 2>&1
+./tools/micro/roialign_bench bwd > $O/roialign_bwd_sweep.txt 2>&1
 ./tools/micro/level_xcd_bench 19 > $O/level_xcd_bench.txt 2>&1
