@@ -1615,6 +1615,29 @@ def test_rays_missing_the_volume(rm, bits_dev):
     assert ws.tolist() == [0.0, 0.0, 0.0]
 
 
+def test_ray_box_test_with_ignored_labels(rm, room, bits_dev):
+    """inr_near_far_from_aabb_skip: rays whose label is the ignored one come back exactly as rays that miss the volume do
+    (near = far = FLT_MAX: the marchers give them no samples), every other ray as from the plain test - bit for bit; any
+    ignore value, not only -1."""
+    poses, intr, H, W = room.cameras(H=64, W=64, focal=32.0)
+    r = __import__("instance_nerf_amd.nerf.utils", fromlist=["get_rays"]).get_rays(_t(poses[:1]), intr, H, W)
+    ro, rd = r["rays_o"].view(-1, 3), r["rays_d"].view(-1, 3)
+    aabb = _t(np.asarray([-1, -1, -1, 1, 1, 1], np.float32))
+    labels = torch.randint(-1, 5, (ro.shape[0],), device=DEV, generator=torch.Generator(device=DEV).manual_seed(1))
+    n0, f0 = rm.near_far_from_aabb(ro, rd, aabb, 0.05)
+    for ignore in (-1, 3):
+        n1, f1 = rm.near_far_from_aabb(ro, rd, aabb, 0.05, skip_labels=labels, ignore_index=ignore)
+        keep = labels != ignore
+        assert 0 < int(keep.sum()) < keep.numel()
+        assert torch.equal(n1[keep], n0[keep]) and torch.equal(f1[keep], f0[keep])
+        big = torch.finfo(torch.float32).max
+        assert bool((n1[~keep] == big).all()) and bool((f1[~keep] == big).all())
+        x, d, dl, rays = rm.march_rays_patch(ro, rd, 1.0, bits_dev, 1, 128, n1, f1)
+        assert int(rays[~keep, 2].sum()) == 0 and int(rays[keep, 2].sum()) > 0
+    with pytest.raises(RuntimeError):
+        rm.near_far_from_aabb(ro, rd, aabb, 0.05, skip_labels=labels[:-1])
+
+
 @pytest.mark.parametrize("cap", [0, 40, 256, 1024])
 def test_capture_replay_is_bit_identical(rm, room, room_bitfield, bits_dev, cap, monkeypatch, request):
     """The write pass replaying the recorded candidate bit mask, re-marching rays that outrun the mask, or

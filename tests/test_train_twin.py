@@ -52,7 +52,11 @@ def test_twin_golden_is_what_the_oracle_does(twin, level_table):
 
 
 @pytest.mark.gpu
-def test_hip_trainer_lands_where_the_oracle_trained_twin_does(twin, level_table):
+@pytest.mark.parametrize("prune", [False, True])
+def test_hip_trainer_lands_where_the_oracle_trained_twin_does(twin, level_table, prune):
+    """prune: Trainer(prune_ignored=...) of the instance stage.  The oracle twin marches every ray, so the step-by-step
+    sample totals are compared with pruning off; with it on (the product's default) the rays labelled -1 are never
+    marched - fewer samples per step, the same losses and the same place to land."""
     import make_train_twin_golden as mk
     from instance_nerf_amd.nerf import NeRFNetwork
     from instance_nerf_amd.nerf.utils import MIoUMeter, PSNRMeter, Trainer, get_rays
@@ -77,7 +81,7 @@ def test_hip_trainer_lands_where_the_oracle_trained_twin_does(twin, level_table)
         for q in net.parameters():
             q.requires_grad_(True)
         tr = Trainer("twin", None, net, stage=stage, device=dev, lr=mk.LR, iters=mk.ITERS, update_extra_interval=10 ** 9,
-                     workspace=None, mute=True)
+                     workspace=None, mute=True, prune_ignored=prune)
         tr.global_step = 1
         for s in range(n0, n1):
             view, inds = cfg["steps"][s]
@@ -91,7 +95,12 @@ def test_hip_trainer_lands_where_the_oracle_trained_twin_does(twin, level_table)
             losses.append(float(tr.train_one_step(data)))
             totals.append(int(net.step_counter[(net.local_step - 1) % 16, 0]))
     # same rays, no jitter, same occupancy grid: the marchers agree on every step's sample total
-    assert totals == twin["totals"].tolist()
+    if prune:
+        assert totals[:n_nerf] == twin["totals"][:n_nerf].tolist()
+        assert all(a <= b for a, b in zip(totals[n_nerf:], twin["totals"][n_nerf:].tolist()))
+        assert sum(totals[n_nerf:]) < 0.97 * int(twin["totals"][n_nerf:].sum())
+    else:
+        assert totals == twin["totals"].tolist()
     # the curves run together (the step-by-step tie of 6 steps is tests/test_gpu_parity.py's; here 200 steps of drift)
     ref = twin["losses"]
     rel = np.abs(np.asarray(losses) - ref) / np.maximum(np.abs(ref), 1e-3)

@@ -436,7 +436,7 @@ def instance_render_probe(dev, frames=8):
 BOUND_TRAFFIC_JSON = os.path.join("profiles", "r05_bound_traffic.json")
 
 
-def bound_traffic(bound, dt_gamma, path="fused"):
+def bound_traffic(bound, dt_gamma, frame_path="fused"):
     """Fabric read requests per sample of the frame path taken (fused kernel | pre-pass + kernel) at this configuration, from the committed PMC profile
     (profiles/r05_bound_traffic.json: tools/pmc_bound.sh + tools/bound_traffic_json.py); quoted only for the kernel sources
     it was measured on.  -> (record of the configuration, random-line rate of the fabric in requests/s) or None."""
@@ -447,7 +447,7 @@ def bound_traffic(bound, dt_gamma, path="fused"):
     t = json.load(open(path))
     if t.get("source_sha") != build.source_sha():
         return None
-    key = f"{bound}:{bound}:{int(round(1 / dt_gamma)) if dt_gamma else 0}:0:0" + ("-sliced" if path == "sliced" else "")
+    key = f"{bound}:{bound}:{int(round(1 / dt_gamma)) if dt_gamma else 0}:0:0" + ("-sliced" if frame_path == "sliced" else "")
     rec = t["configs"].get(key)
     return None if rec is None else (rec, float(t["random_line_rate_of_the_fabric_g_per_s"]) * 1e9)
 
@@ -508,6 +508,9 @@ def bound_render_probe(dev, bound=4, dt_gamma=1.0 / 128, frames=8):
                   "l2_hit_rate": rec["l2_hit_rate"], "achieved_g_requests_per_s": round(req_s / 1e9, 1),
                   "traffic_gb_per_s": round(req_s * 128 / 1e9, 1), "ceiling_g_requests_per_s": round(ceiling / 1e9, 1),
                   "frac": round(req_s / ceiling, 4),
+                  "note": ("behind the level-major pre-pass the fabric is no longer the limit (most fine-level lines come from "
+                           "the L2 the level fits in); the gather is then bound by L1 fills (profiles/r05_NOTES.txt 3)")
+                  if path == "sliced" else "the fused kernel off the tuned configuration is bound by this request rate",
                   "source": BOUND_TRAFFIC_JSON + " (rocprofv3 PMC on these kernel sources, view 0; ceiling: random 128-byte lines "
                                                  "over eight 4 MiB levels, tools/micro/level_xcd_bench.hip)"}
     return {"fabric_requests": fabric,
