@@ -37,7 +37,7 @@ extern "C" {
 /* Bumped whenever an existing prototype changes or an entry point is removed (round 2 changed four argument lists
  * without a bump: a stale library or an external caller built against the old header was only rejected by accident).
  * instance_nerf_amd/_lib.py refuses a library whose version differs from the one it was written against. */
-#define INR_ABI_VERSION 8
+#define INR_ABI_VERSION 9
 #define INR_MAX_LEVELS 16
 
 enum {
@@ -447,7 +447,8 @@ int inr_instance_forward(const float* x, int64_t M, const int32_t* n_samples_dev
  * out [K,C,out_w,out_l,out_h].  backward ACCUMULATES into grad_input (caller zeroes it).          */
 /* No reference counterpart.  Which kernels the two calls below use: 0 (default) the separable ones (per-axis weight
  * tables built once per RoI in LDS, z -> y -> x contraction, 4 channels per lane) whenever the tables fit the LDS
- * window, 1 one lane per output element (the torchvision kernel shape; also the fallback), 2 separable or INR_EINVAL.
+ * window, 1 one lane per output element (the torchvision kernel shape; also the fallback), 2 separable or INR_EINVAL,
+ * 3 separable without the workspace form of the backward (below).
  * Same sample geometry in both; sums differ by fp32 rounding.  Process-wide.                                        */
 int inr_roi_align_3d_set_mode(int32_t mode);
 int inr_roi_align_3d_forward(const float* input, const float* rois, const int32_t* roi_inds, int32_t N,
@@ -457,6 +458,21 @@ int inr_roi_align_3d_backward(const float* grad_out, const float* rois, const in
                               int32_t C, int32_t W, int32_t L, int32_t H, int64_t K, int32_t out_w,
                               int32_t out_l, int32_t out_h, float spatial_scale, float* grad_input,
                               inr_stream_t s);
+
+/* No reference counterpart.  The backward with a caller-owned workspace: the separable backward is bound by the
+ * memory-side atomic unit (requests of up to 64 bytes, ~21 G/s whatever they carry), and a region row of the gradient's
+ * own layout fills a request with ~6 floats.  This form accumulates into a channels-fastest scratch volume
+ * (workspace: N*C*W*L*H floats, zeroed by the call) - one full 64-byte request per voxel and 16 channels - and writes
+ * grad_input with a transposing copy: grad_input is OVERWRITTEN (no zero fill by the caller, no accumulation).
+ * _workspace_bytes returns 0 where the form does not apply (C not a multiple of 16, out_l*out_h > 256, tables beyond
+ * the LDS window, modes 1 and 3 of inr_roi_align_3d_set_mode): the caller then uses inr_roi_align_3d_backward.
+ * Mode 3 (added with it) = separable kernels, accumulation in place (the round-4 form) - for A/B tests.             */
+int64_t inr_roi_align_3d_backward_workspace_bytes(int32_t N, int32_t C, int32_t W, int32_t L, int32_t H, int64_t K,
+                                                  int32_t out_w, int32_t out_l, int32_t out_h);
+int inr_roi_align_3d_backward_ws(const float* grad_out, const float* rois, const int32_t* roi_inds, int32_t N,
+                                 int32_t C, int32_t W, int32_t L, int32_t H, int64_t K, int32_t out_w,
+                                 int32_t out_l, int32_t out_h, float spatial_scale, float* grad_input,
+                                 void* workspace, int64_t workspace_bytes, inr_stream_t s);
 
 /* Whole-ray rendering with early termination (inference, patch-interleaved layout): field evaluation and alpha
  * compositing in one launch; a 16-ray group stops being evaluated once all its rays are below T_thresh (what the

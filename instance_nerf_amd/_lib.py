@@ -114,6 +114,10 @@ _SIGS = {
                                            c_int32, c_int32, c_float, P, P]),
     "inr_roi_align_3d_backward": (c_int32, [P, P, P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int64, c_int32,
                                             c_int32, c_int32, c_float, P, P]),
+    "inr_roi_align_3d_backward_workspace_bytes": (c_int64, [c_int32, c_int32, c_int32, c_int32, c_int32, c_int64, c_int32,
+                                                            c_int32, c_int32]),
+    "inr_roi_align_3d_backward_ws": (c_int32, [P, P, P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int64, c_int32,
+                                               c_int32, c_int32, c_float, P, P, c_int64, P]),
     "inr_nerf_render": (c_int32, [P, P, P, P, c_int64, c_int64, c_float, P, POINTER(GridDesc), P, c_float, c_float,
                                   P, P, P, P, P, c_int32, P]),
     "inr_nerf_render_fast": (c_int32, [P, P, P, P, c_int64, c_int64, c_float, P, POINTER(GridDesc), P, c_float, c_float,
@@ -127,7 +131,7 @@ _SIGS = {
 }
 EXPORTS = tuple(_SIGS)
 
-ABI_VERSION = 8          # include/inr.h INR_ABI_VERSION this binding was written against
+ABI_VERSION = 9          # include/inr.h INR_ABI_VERSION this binding was written against
 _lib = None
 
 

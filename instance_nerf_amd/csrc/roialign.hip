@@ -530,8 +530,9 @@ __global__ void __launch_bounds__(SEP_THREADS) k_roi_align3d_sep_fwd(const float
 // whatever the channels per workgroup (8..32) or the LDS budget (2..5 workgroups per CU): a region row along z is
 // ~10 floats = 1.56 64-byte segments per (x, y, channel), 10.7 M atomic requests per call, and the memory-side atomic
 // unit takes ~21 G requests/s whatever their width (profiles/r03_NOTES.txt 1) = 0.51 ms.  Fewer requests need another
-// layout of the accumulation target (channels fastest: one 64-byte request per voxel and 16 channels, 2.4x fewer, plus a
-// transposing copy into grad_input) - priced in profiles/r05_NOTES.txt 5, not built.
+// layout of the accumulation target: k_roi_align3d_sep_bwd_cl below (channels fastest: one 64-byte request per voxel and
+// 16 channels, plus a transposing copy into grad_input; 0.34 ms for the whole call) is what inr_roi_align_3d_backward_ws
+// runs; this kernel stays behind inr_roi_align_3d_backward (no workspace, accumulates in place, any channel count).
 __global__ void __launch_bounds__(SEP_THREADS) k_roi_align3d_sep_bwd(const float* __restrict__ gout,
                                                                      const float* __restrict__ rois,
                                                                      const int32_t* __restrict__ roi_inds, SepArgs A,
@@ -800,6 +801,190 @@ __global__ void __launch_bounds__(SEP_THREADS) k_roi_align3d_sep_bwd(const float
   }
 }
 
+// ---- backward with a channels-fastest accumulation target (round 5) ---------------------------------------------------
+// The backward above is bound by the memory-side atomic unit, which takes ~21 G requests of up to 64 bytes per second
+// whatever they carry: a region row along z of the gradient's own [C][W][L][H] layout is ~10 floats in 1.56 segments.
+// Accumulating into a scratch volume laid out [W][L][H][C] lets one instruction cover the 16 channels of a workgroup at
+// a voxel with ONE full 64-byte request (tools/micro/atomic_layout_bench.hip: the atomics of a configs[4] call alone
+// 0.64 -> 0.30 ms, 0.25 being the floor of packed requests); a transposing copy then writes grad_input once (no zero
+// fill of grad_input, no accumulation into it: the call OVERWRITES it).  configs[4]: 0.293 ms + 0.015 (zero fill of the
+// scratch) + 0.030 (copy) = 0.34 ms against 0.58 + 0.02 in place.  The passes are the ones above with 16 channels
+// in flight per slab instead of 4: x^T reads the output gradient straight from global memory (its 64 KB per workgroup
+// do not fit beside the slabs), y^T as above, z^T with one channel per lane (16 lanes = the 16 channels of a voxel).
+__global__ void __launch_bounds__(SEP_THREADS) k_roi_align3d_sep_bwd_cl(const float* __restrict__ gout,
+                                                                        const float* __restrict__ rois,
+                                                                        const int32_t* __restrict__ roi_inds, SepArgs A,
+                                                                        float* __restrict__ gt) {
+  extern __shared__ f32x4 lds4[];
+  int k, c0;
+  if (!sep_assign(A, &k, &c0)) return;
+  lfloat* lds = (lfloat*)lds4;
+  const int t = threadIdx.x;
+  const int W = A.W, L = A.L, H = A.H, ow = A.ow, ol = A.ol, oh = A.oh;
+  lfloat* T[3];
+  lint* first[3];
+  lint* last[3];
+  T[0] = lds; T[1] = T[0] + ow * W; T[2] = T[1] + ol * L;
+  lint* ip = (lint*)(T[2] + oh * H);
+  first[0] = ip; last[0] = first[0] + ow; first[1] = last[0] + ow; last[1] = first[1] + ol;
+  first[2] = last[1] + ol; last[2] = first[2] + oh;
+  lint* pfirst[3];
+  lint* plast[3];
+  pfirst[0] = last[2] + oh; plast[0] = pfirst[0] + W; pfirst[1] = plast[0] + W; plast[1] = pfirst[1] + L;
+  pfirst[2] = plast[1] + L; plast[2] = pfirst[2] + H;
+  lSepRoi* R = (lSepRoi*)(plast[2] + H);
+  const int fixed_words = ow * W + ol * L + oh * H + 2 * (ow + ol + oh) + 2 * (W + L + H) + (int)(sizeof(SepRoi) / 4);
+  lfloat* tmpbase = lds + ((fixed_words + 3) & ~3);
+
+  sep_build_tables(rois + (int64_t)k * 6, A, R, T, first, last);
+  {
+    const int o[3] = {ow, ol, oh};
+    for (int r = t; r < W + L + H; r += SEP_THREADS) {
+      const int a = r < W ? 0 : (r < W + L ? 1 : 2);
+      const int cell = r - (a == 0 ? 0 : (a == 1 ? W : W + L));
+      int f = o[a], l = -1;
+      for (int p = 0; p < o[a]; ++p)
+        if (first[a][p] <= cell && cell <= last[a][p]) { f = min(f, p); l = max(l, p); }
+      pfirst[a][cell] = f;
+      plast[a][cell] = l;
+    }
+  }
+  __syncthreads();
+
+  constexpr int RUNS = 4;                       // channel runs of SEP_CH in flight: cpb = 16 channels per workgroup
+  const int olh = ol * oh, nout = ow * olh;
+  const int64_t WLH = (int64_t)W * L * H;
+  const int x0 = R->lo[0], y0 = R->lo[1], z0 = R->lo[2];
+  const int sx = R->hi[0] - x0 + 1, sy = R->hi[1] - y0 + 1, sz = R->hi[2] - z0 + 1;
+  if (sx <= 0 || sy <= 0 || sz <= 0) return;
+  const float inv_count = R->inv_count;
+  const int syoh = sy * oh;
+  int XB = A.tmp_floats / (SEP_CH * RUNS * (olh + syoh));
+  XB = max(1, min(XB, sx));
+  lfloat4* t2 = (lfloat4*)tmpbase;              // [RUNS][XB][ol][oh]
+  lfloat4* t1 = t2 + RUNS * XB * olh;           // [RUNS][XB][sy][oh]
+  const float* gbase = gout + ((int64_t)k * A.C + c0) * nout;
+  float* vol = gt + ((int64_t)roi_inds[k] * WLH) * A.C + c0;
+
+  // x^T role: (pl, ph) fixed, slots over x (host: ol * oh <= SEP_THREADS)
+  const int NSA = SEP_THREADS / olh, slotA = t / olh, rA = t - slotA * olh;
+  const bool actA = slotA < NSA;
+  // y^T roles: (y, ph); one per thread with slots over (run, x) when sy * oh fits the workgroup, else several per thread
+  const bool oneB = syoh <= SEP_THREADS;
+  const int NSB = oneB ? SEP_THREADS / syoh : 1, slotB = oneB ? t / syoh : 0, roleB0 = oneB ? t - slotB * syoh : t;
+  const bool actB = slotB < NSB;
+  // z^T role: channel (16 lanes = the workgroup's 16 channels), z slot
+  const int chC = t & 15, runC = chC >> 2, compC = chC & 3;
+
+  for (int xs = 0; xs < sx; xs += XB) {
+    const int nx = min(XB, sx - xs);
+    // ---- x^T: t2[run][x][pl][ph] = sum_pw Tx[pw][x] * gout[run][pw][pl][ph] / count     (gout from global memory)
+    if (actA) {
+      for (int x = slotA; x < nx; x += NSA) {
+        const int cell = x0 + xs + x;
+        const int pf0 = pfirst[0][cell], pl0 = plast[0][cell];
+        const int pf = pf0 <= pl0 ? pf0 : 0, pl = pf0 <= pl0 ? pl0 : -1, np = max(pl - pf, 0);
+        float w[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] = (pf + j <= pl) ? T[0][(pf + j) * W + cell] * inv_count : 0.0f;
+#pragma unroll
+        for (int run = 0; run < RUNS; ++run) {
+          const float* src = gbase + (int64_t)(run * SEP_CH) * nout + rA;
+          float g[4][SEP_CH];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int po = (pf + min(j, np)) * olh;          // tap j reads an output index that reaches the cell
+#pragma unroll
+            for (int ch = 0; ch < SEP_CH; ++ch) g[j][ch] = src[(int64_t)ch * nout + po];
+          }
+          f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) fma4(a, w[j], f32x4{g[j][0], g[j][1], g[j][2], g[j][3]});
+          for (int p = pf + 4; p <= pl; ++p) {
+            const float wp = T[0][p * W + cell] * inv_count;
+            fma4(a, wp, f32x4{src[p * olh], src[(int64_t)nout + p * olh], src[2 * (int64_t)nout + p * olh],
+                              src[3 * (int64_t)nout + p * olh]});
+          }
+          t2[(run * XB + x) * olh + rA] = a;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- y^T: t1[run][x][y][ph] = sum_pl Ty[pl][y] * t2[run][x][pl][ph]
+    if (actB) {
+      for (int role = roleB0; role < syoh; role += SEP_THREADS) {
+        const int yB = role / oh, phB = role - yB * oh;
+        const int cell = y0 + yB;
+        const int pf0 = pfirst[1][cell], pl0 = plast[1][cell];
+        const int pf = pf0 <= pl0 ? pf0 : 0, pl = pf0 <= pl0 ? pl0 : -1, np = max(pl - pf, 0);
+        float w[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] = (pf + j <= pl) ? T[1][(pf + j) * L + cell] : 0.0f;
+        for (int q = slotB; q < RUNS * nx; q += NSB) {
+          const int run = q / nx, x = q - run * nx;
+          const lfloat4* src = t2 + ((run * XB + x) * ol + pf) * oh + phB;
+          f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) fma4(a, w[j], src[min(j, np) * oh]);
+          for (int p = pf + 4; p <= pl; ++p) fma4(a, T[1][p * L + cell], src[(p - pf) * oh]);
+          t1[((run * XB + x) * sy + yB) * oh + phB] = a;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- z^T: scratch[x][y][z][c] += sum_ph Tz[ph][z] * t1[run(c)][x][y][ph][c & 3]     (one 64-byte request per voxel)
+    for (int z = t >> 4; z < sz; z += SEP_THREADS / 16) {
+      const int cell = z0 + z;
+      const int pf0 = pfirst[2][cell], pl0 = plast[2][cell];
+      const int pf = pf0 <= pl0 ? pf0 : 0, pl = pf0 <= pl0 ? pl0 : -1, np = max(pl - pf, 0);
+      float w[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) w[j] = (pf + j <= pl) ? T[2][(pf + j) * H + cell] : 0.0f;
+      const lfloat* src0 = (const lfloat*)(t1 + runC * XB * syoh) + compC + 4 * pf;
+      const int o1 = 4 * min(1, np), o2 = 4 * min(2, np), o3 = 4 * min(3, np);
+      for (int x = 0; x < nx; ++x) {
+        float* dst = vol + ((int64_t)((x0 + xs + x) * L + y0) * H + cell) * A.C + chC;
+        const lfloat* src = src0 + 4 * (x * syoh);
+        for (int y = 0; y < sy; ++y) {
+          float a = w[0] * src[0];
+          a = __builtin_fmaf(w[1], src[o1], a);
+          a = __builtin_fmaf(w[2], src[o2], a);
+          a = __builtin_fmaf(w[3], src[o3], a);
+          for (int p = pf + 4; p <= pl; ++p) a = __builtin_fmaf(T[2][p * H + cell], src[4 * (p - pf)], a);
+          atomicAdd(dst, a);
+          src += 4 * oh;
+          dst += (int64_t)H * A.C;
+        }
+      }
+    }
+    // the next slab's x^T pass writes t2 only; its barrier orders the rewrite of t1 behind these reads
+  }
+}
+
+// scratch [N][V][C] -> grad_input [N][C][V] (V = W*L*H): 32 x 32 tiles through LDS, both sides 128-byte rows
+__global__ void __launch_bounds__(256) k_channels_last_to_planes(const float* __restrict__ src, float* __restrict__ dst,
+                                                                 int64_t V, int C) {
+  __shared__ float tile[32][33];
+  const int64_t v0 = (int64_t)blockIdx.x * 32;
+  const int c0 = blockIdx.y * 32;
+  const float* s = src + (int64_t)blockIdx.z * V * C;
+  float* d = dst + (int64_t)blockIdx.z * V * C;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t v = v0 + ty + 8 * i;
+    const int c = c0 + tx;
+    tile[ty + 8 * i][tx] = (v < V && c < C) ? s[v * C + c] : 0.0f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 8 * i;
+    const int64_t v = v0 + tx;
+    if (v < V && c < C) d[(int64_t)c * V + v] = tile[tx][ty + 8 * i];
+  }
+}
+
 static int g_roi_mode = 0;   // 0 auto, 1 one lane per output element, 2 separable (error if it does not fit)
 
 // LDS bytes of the separable kernels for these extents (0: does not fit the device's 64 KB default window)
@@ -842,8 +1027,8 @@ using namespace inr;
 extern "C" {
 
 int inr_roi_align_3d_set_mode(int32_t mode) {
-  if (mode < 0 || mode > 2) {
-    set_error("inr_roi_align_3d_set_mode: mode must be 0 (auto), 1 (lane per output) or 2 (separable)");
+  if (mode < 0 || mode > 3) {
+    set_error("inr_roi_align_3d_set_mode: mode must be 0 (auto), 1 (lane per output), 2 (separable) or 3 (separable, no workspace)");
     return INR_EINVAL;
   }
   g_roi_mode = mode;
@@ -909,6 +1094,75 @@ int inr_roi_align_3d_backward(const float* grad_out, const float* rois, const in
   k_roi_align3d_bwd<<<blocks_for(total, 256), 256, 0, as_stream(s)>>>(grad_out, rois, roi_inds, C, W, L, H, total,
                                                                       out_w, out_l, out_h, spatial_scale, grad_input);
   return check_launch("roi_align_3d_backward");
+}
+
+// LDS of the channels-last backward: the backward's tables + the two slab intermediates for 16 channels (no staged gout)
+static int sep_cl_lds_bytes(int W, int L, int H, int ow, int ol, int oh, int* tmp_floats) {
+  const int64_t tab = (int64_t)ow * W + (int64_t)ol * L + (int64_t)oh * H;
+  const int64_t ints = 2 * (int64_t)(ow + ol + oh) + 2 * (int64_t)(W + L + H);
+  const int64_t fixed = (tab + ints) * 4 + (int64_t)sizeof(SepRoi) + 16;
+  const int64_t need = 4 * (int64_t)SEP_CH * ((int64_t)L * oh + (int64_t)ol * oh);     // one x plane of the widest region
+  // 8192 floats of slabs: ~39 KB in all, four workgroups per CU (tools/micro/roialign_bench bwd: 0.33 ms against 0.35 at
+  // 10240 and 0.37-0.39 at 6144 / 4096, where the slabs get thin)
+  int64_t tmp = std::max<int64_t>(need, 8192);
+  if (fixed + tmp * 4 > 64 * 1024) {
+    tmp = need;
+    if (fixed + tmp * 4 > 64 * 1024) return 0;
+  }
+  *tmp_floats = (int)tmp;
+  return (int)(fixed + tmp * 4);
+}
+
+int64_t inr_roi_align_3d_backward_workspace_bytes(int32_t N, int32_t C, int32_t W, int32_t L, int32_t H, int64_t K,
+                                                  int32_t out_w, int32_t out_l, int32_t out_h) {
+  if (N <= 0 || C <= 0 || W <= 0 || L <= 0 || H <= 0 || K <= 0 || out_w <= 0 || out_l <= 0 || out_h <= 0) return 0;
+  if (g_roi_mode == 1 || g_roi_mode == 3) return 0;
+  int tmp_floats = 0;
+  const int64_t V = (int64_t)W * L * H;
+  // 16 channels per workgroup = one 64-byte request per voxel; every output column (pl, ph) needs a thread in the x^T pass
+  if (C % 16 != 0 || (int64_t)out_l * out_h > SEP_THREADS || V >= (1ll << 30) || (V + 31) / 32 >= (1ll << 31) ||
+      (C + 31) / 32 > 65535 || N > 65535 || K >= (1 << 24) || 8 * K * (((int64_t)C / 16 + 7) / 8) >= (1ll << 31))
+    return 0;
+  if (sep_cl_lds_bytes(W, L, H, out_w, out_l, out_h, &tmp_floats) == 0) return 0;
+  return (int64_t)N * C * V * 4;
+}
+
+int inr_roi_align_3d_backward_ws(const float* grad_out, const float* rois, const int32_t* roi_inds, int32_t N, int32_t C,
+                                 int32_t W, int32_t L, int32_t H, int64_t K, int32_t out_w, int32_t out_l, int32_t out_h,
+                                 float spatial_scale, float* grad_input, void* workspace, int64_t workspace_bytes,
+                                 inr_stream_t s) {
+  INR_REQUIRE(K >= 0 && N >= 0 && C > 0 && W > 0 && L > 0 && H > 0 && out_w > 0 && out_l > 0 && out_h > 0, "bad sizes");
+  INR_REQUIRE(grad_input || N == 0, "null pointer");
+  const int64_t V = (int64_t)W * L * H;
+  if (N == 0) return INR_OK;
+  if (K == 0) {                                    // the call overwrites grad_input: nothing pooled, nothing flows back
+    const hipError_t e = hipMemsetAsync(grad_input, 0, (size_t)N * C * V * 4, as_stream(s));
+    INR_REQUIRE(e == hipSuccess, "hipMemsetAsync failed");
+    return INR_OK;
+  }
+  INR_REQUIRE(grad_out && rois && roi_inds, "null pointer");
+  const int64_t need = inr_roi_align_3d_backward_workspace_bytes(N, C, W, L, H, K, out_w, out_l, out_h);
+  INR_REQUIRE(need > 0, "inr_roi_align_3d_backward_ws: not available for these extents / this mode (workspace_bytes == 0: "
+                        "call inr_roi_align_3d_backward)");
+  INR_REQUIRE(workspace && workspace_bytes >= need, "workspace too small");
+  int tmp_floats = 0;
+  const int lds = sep_cl_lds_bytes(W, L, H, out_w, out_l, out_h, &tmp_floats);
+  float* gt = static_cast<float*>(workspace);
+  const hipError_t e = hipMemsetAsync(gt, 0, (size_t)need, as_stream(s));
+  INR_REQUIRE(e == hipSuccess, "hipMemsetAsync failed");
+  SepArgs A;
+  A.C = C; A.W = W; A.L = L; A.H = H; A.ow = out_w; A.ol = out_l; A.oh = out_h; A.scale = spatial_scale;
+  A.cpb = 16;
+  A.ngroups = C / 16;
+  A.K = (int)K;
+  A.tmp_floats = tmp_floats;
+  const unsigned grid = 8u * (unsigned)K * (unsigned)((A.ngroups + 7) / 8);
+  k_roi_align3d_sep_bwd_cl<<<grid, SEP_THREADS, lds, as_stream(s)>>>(grad_out, rois, roi_inds, A, gt);
+  const int rc = check_launch("roi_align_3d_backward (separable, channels-last accumulation)");
+  if (rc != INR_OK) return rc;
+  const dim3 tg((unsigned)((V + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)N);
+  k_channels_last_to_planes<<<tg, 256, 0, as_stream(s)>>>(gt, grad_input, V, C);
+  return check_launch("roi_align_3d_backward (transposing copy)");
 }
 
 }  // extern "C"

@@ -6,6 +6,23 @@ from .. import _lib
 from .._lib import check, ptr, stream_ptr
 
 
+_WS = {}
+
+
+def _workspace(device, nbytes):
+    """Grow-only scratch of the backward's workspace form, one per device and stream (the call zeroes what it uses; a
+    buffer shared between streams would race)."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = _WS[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    return buf
+
+
+def gin_numel(N, C, W, L, H):
+    return N * C * W * L * H
+
+
 class _RoIAlign3D(torch.autograd.Function):
     @staticmethod
     def forward(ctx, input, rois, roi_inds, out_w, out_l, out_h, spatial_scale):
@@ -36,6 +53,15 @@ class _RoIAlign3D(torch.autograd.Function):
         ow, ol, oh, scale = ctx.cfg
         K = rois.shape[0]
         grad = grad.contiguous().float()
+        # the workspace form (channels-fastest accumulation + transposing copy, fewer and fuller atomic requests) where the
+        # library offers it for these extents; it OVERWRITES grad_input, so no zero fill here
+        need = int(lib.inr_roi_align_3d_backward_workspace_bytes(N, C, W, L, H, K, ow, ol, oh)) if K > 0 and gin_numel(N, C, W, L, H) else 0
+        if need > 0:
+            gin = torch.empty(N, C, W, L, H, dtype=torch.float32, device=grad.device)
+            ws = _workspace(grad.device, need)
+            check(lib.inr_roi_align_3d_backward_ws(ptr(grad), ptr(rois), ptr(roi_inds), N, C, W, L, H, K, ow, ol, oh, scale,
+                                                   ptr(gin), ws.data_ptr(), need, stream_ptr()), "roi_align_3d_backward_ws")
+            return gin, None, None, None, None, None, None
         gin = torch.zeros(N, C, W, L, H, dtype=torch.float32, device=grad.device)
         check(lib.inr_roi_align_3d_backward(ptr(grad, allow_none=K == 0), ptr(rois, allow_none=K == 0),
                                             ptr(roi_inds, allow_none=K == 0), N, C, W, L, H, K, ow, ol, oh, scale,

@@ -105,7 +105,7 @@ def test_roi_align_at_baseline_config4_size():
     outs, grads = {}, {}
     g = torch.randn(256, 256, 10, 10, 10, device=dev, generator=torch.Generator(device=dev).manual_seed(6))
     try:
-        for mode in (2, 1):
+        for mode in (2, 3, 1):       # separable (backward: workspace form), separable accumulating in place, lane per output
             _set_mode(mode)
             x = feat.clone().requires_grad_(True)
             out = roi_align_3d(x, rois, inds, 10, 10, 10, 0.25)
@@ -117,6 +117,7 @@ def test_roi_align_at_baseline_config4_size():
         _set_mode(0)
     assert (outs[2] - outs[1]).abs().max().item() < 2e-5
     assert (grads[2] - grads[1]).abs().max().item() < 1e-3 * grads[1].abs().max().item()
+    assert (grads[3] - grads[1]).abs().max().item() < 1e-3 * grads[1].abs().max().item()
     assert outs[2][2].abs().max().item() == 0.0          # the box outside the volume pools nothing
     rng = np.random.default_rng(7)
     pts = np.stack([rng.integers(0, n, 2000) for n in (256, 256, 10, 10, 10)], 1)
@@ -211,6 +212,58 @@ def test_backward_of_regions_wider_than_the_fixed_roles():
     finally:
         _set_mode(0)
     assert (grads[2] - grads[1]).abs().max().item() < 1e-4 * grads[1].abs().max().item()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [0, 1, 2, 3])
+def test_backward_workspace_form(case):
+    """inr_roi_align_3d_backward_ws (channel counts that are multiples of 16): accumulation into a channels-fastest scratch
+    volume + transposing copy.  Several volumes, non-cubic levels, boxes inside / straddling a face / larger than the volume /
+    thinner than a voxel / outside, regions wider than one role per thread (case 1), a cell no box reaches (grad exactly 0,
+    although the call gets an uninitialised grad_input): against the lane-per-output kernel, the in-place separable
+    kernel, and as the forward's transpose; the library refuses the form where it does not apply."""
+    from instance_nerf_amd import _lib
+    from instance_nerf_amd.roi_align.roi_align import roi_align_3d
+    N, C, shape, osz, scale = [(2, 16, (12, 9, 11), (5, 4, 6), 0.5), (1, 32, (30, 30, 30), (12, 12, 12), 1.0),
+                               (3, 48, (6, 6, 6), (1, 2, 3), 0.7), (1, 64, (16, 20, 12), (7, 7, 7), 0.25)][case]
+    rng = np.random.default_rng(50 + case)
+    K = 9
+    lo = rng.uniform(-3, max(shape), size=(K, 3)) / scale
+    ext = np.stack([rng.uniform(0.05, 3.0 * max(shape), 3) if k % 3 == 0 else rng.uniform(0.3, 6, 3) for k in range(K)]) / scale
+    rois = np.concatenate([lo, lo + ext], 1).astype(np.float32)
+    rois[-1] = np.asarray([500, 500, 500, 520, 510, 530], np.float32)               # outside
+    rois[0] = np.asarray([0, 0, 0] + [s / scale for s in shape], np.float32)         # the whole volume (widest region)
+    inds = rng.integers(0, N, K).astype(np.int32)
+    inds[0] = 0
+    dev = "cuda"
+    lib = _lib.load()
+    assert lib.inr_roi_align_3d_backward_workspace_bytes(N, C, *shape, K, *osz) == N * C * int(np.prod(shape)) * 4
+    assert lib.inr_roi_align_3d_backward_workspace_bytes(N, C + 3, *shape, K, *osz) == 0
+    assert lib.inr_roi_align_3d_backward_workspace_bytes(N, C, *shape, K, 4, 20, 20) == 0
+    vol = torch.tensor(rng.normal(size=(N, C) + shape).astype(np.float32), device=dev)
+    g = torch.randn((K, C) + osz, device=dev, generator=torch.Generator(device=dev).manual_seed(case))
+    grads = {}
+    try:
+        for mode in (2, 3, 1):
+            _set_mode(mode)
+            x = vol.clone().requires_grad_(True)
+            torch.empty(N * C * int(np.prod(shape)), device=dev).fill_(float("nan"))   # what a recycled block may hold
+            out = roi_align_3d(x, torch.tensor(rois, device=dev), torch.tensor(inds, device=dev), *osz, scale)
+            out.backward(g)
+            grads[mode] = x.grad
+            lhs, rhs = (out.detach().double() * g.double()).sum().item(), (vol.double() * x.grad.double()).sum().item()
+            assert abs(lhs - rhs) < 1e-5 * max(1.0, abs(lhs)), (mode, lhs, rhs)
+            assert lib.inr_roi_align_3d_backward_workspace_bytes(N, C, *shape, K, *osz) == (N * C * int(np.prod(shape)) * 4 if mode == 2 else 0)
+    finally:
+        _set_mode(0)
+    tol = 1e-4 * grads[1].abs().max().item()
+    assert (grads[2] - grads[1]).abs().max().item() < tol and (grads[3] - grads[1]).abs().max().item() < tol
+    assert bool(torch.isfinite(grads[2]).all())
+    assert torch.equal(grads[2] == 0, grads[1] == 0) or ((grads[2] == 0) ^ (grads[1] == 0)).float().mean().item() < 1e-3
+    if N > 1:                                            # volumes no box points at: exactly zero
+        unused = [n for n in range(N) if n not in set(inds[:-1].tolist())]
+        for n in unused:
+            assert float(grads[2][n].abs().max()) == 0.0
 
 
 @pytest.mark.gpu

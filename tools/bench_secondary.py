@@ -357,7 +357,9 @@ def config5_probe(dev):
                                    "unit": "GB/s", "frac": round(roi_bytes / t_roi / 8e12, 4),
                                    "compulsory_mb": round(roi_bytes / 1e6, 1),
                                    "kernel": "k_roi_align3d_sep_fwd<4, false> (separable; events on the launch stream, 20 launches)",
-                                   "backward_note": "k_roi_align3d_sep_bwd + the 65.5 MB zero fill of grad_input"}}
+                                   "backward_note": "the autograd backward: inr_roi_align_3d_backward_ws = zero fill of the 65.5 MB channels-fastest "
+                                                    "scratch + k_roi_align3d_sep_bwd_cl + transposing copy into grad_input "
+                                                    "(in place, round 4: k_roi_align3d_sep_bwd + zero fill, 0.58-0.60 ms)"}}
 
 
 def instance_render_probe(dev, frames=8):

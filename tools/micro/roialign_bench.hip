@@ -77,6 +77,37 @@ int main(int argc, char** argv) {
         }
         printf("separable backward cpb %2d slab budget %5d floats (lds %6d B): %.4f ms (without the zero fill)\n", cpb, tmp, lds, best);
       }
+    {   // the workspace form: channels-fastest scratch (zero fill timed with it) + transposing copy
+      float* gt;
+      CK(hipMalloc(&gt, hin.size() * 4));
+      SepArgs A;
+      A.C = C; A.W = W; A.L = L; A.H = H; A.ow = o; A.ol = o; A.oh = o; A.scale = 0.25f; A.cpb = 16;
+      A.ngroups = C / 16; A.K = K;
+      for (int tmp : {4096, 6144, 8192, 10240}) {
+        A.tmp_floats = tmp;
+        const int lds = (o * W * 3 + 6 * o + 2 * (W + L + H)) * 4 + (int)sizeof(SepRoi) + 16 + tmp * 4;
+        const unsigned grid = 8u * K * ((A.ngroups + 7) / 8);
+        float best = 1e9f, best_k = 1e9f;
+        hipEvent_t ea, eb;
+        CK(hipEventCreate(&ea)); CK(hipEventCreate(&eb));
+        for (int it = 0; it < 6; ++it) {
+          CK(hipEventRecord(e0));
+          CK(hipMemsetAsync(gt, 0, hin.size() * 4));
+          CK(hipEventRecord(ea));
+          k_roi_align3d_sep_bwd_cl<<<grid, SEP_THREADS, lds>>>(out, rois, inds, A, gt);
+          CK(hipEventRecord(eb));
+          k_channels_last_to_planes<<<dim3((unsigned)((W * L * H + 31) / 32), C / 32, 1), 256>>>(gt, gin, (int64_t)W * L * H, C);
+          CK(hipEventRecord(e1));
+          CK(hipEventSynchronize(e1));
+          float ms, mk;
+          CK(hipEventElapsedTime(&ms, e0, e1));
+          CK(hipEventElapsedTime(&mk, ea, eb));
+          if (it) { best = std::min(best, ms); best_k = std::min(best_k, mk); }
+        }
+        printf("workspace form (16 channels per workgroup) slab budget %5d floats (lds %6d B): %.4f ms, of which the kernel %.4f\n",
+               tmp, lds, best, best_k);
+      }
+    }
     return 0;
   }
   if (only_full) { run(k_roi_align3d_sep_fwd<4, false>, "full", 16, 10240); return 0; }
