@@ -250,16 +250,13 @@ def _(input, rois, roi_inds, out_w, out_l, out_h, spatial_scale):
 @torch.library.custom_op("inr::roi_align_3d_backward", mutates_args=())
 def roi_align_3d_backward(grad_out: Tensor, rois: Tensor, roi_inds: Tensor, N: int, W: int, L: int, H: int,
                           spatial_scale: float) -> Tensor:
-    """dL/d(input) [N,C,W,L,H] of roi_align_3d: the transposed separable passes, one atomic per touched cell."""
-    lib = _lib.load()
+    """dL/d(input) [N,C,W,L,H] of roi_align_3d: the transposed separable passes + atomics (through the channels-fastest
+    workspace form where it applies)."""
+    from .roi_align.roi_align import roi_align_3d_grad_input
     grad_out, rois = grad_out.contiguous().float(), rois.contiguous().float()
     roi_inds = roi_inds.contiguous().to(I32)
     K, C, ow, ol, oh = grad_out.shape
-    gin = torch.zeros(N, C, W, L, H, dtype=F32, device=grad_out.device)
-    check(lib.inr_roi_align_3d_backward(ptr(grad_out, allow_none=K == 0), ptr(rois, allow_none=K == 0),
-                                        ptr(roi_inds, allow_none=K == 0), N, C, W, L, H, K, ow, ol, oh, float(spatial_scale),
-                                        ptr(gin, allow_none=gin.numel() == 0), stream_ptr()), "roi_align_3d_backward")
-    return gin
+    return roi_align_3d_grad_input(grad_out, rois, roi_inds, (N, C, W, L, H), (ow, ol, oh, float(spatial_scale)))
 
 
 @roi_align_3d_backward.register_fake

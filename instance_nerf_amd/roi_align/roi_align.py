@@ -19,10 +19,6 @@ def _workspace(device, nbytes):
     return buf
 
 
-def gin_numel(N, C, W, L, H):
-    return N * C * W * L * H
-
-
 class _RoIAlign3D(torch.autograd.Function):
     @staticmethod
     def forward(ctx, input, rois, roi_inds, out_w, out_l, out_h, spatial_scale):
@@ -47,26 +43,32 @@ class _RoIAlign3D(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad):
-        lib = _lib.load()
         rois, roi_inds = ctx.saved_tensors
-        N, C, W, L, H = ctx.shape
-        ow, ol, oh, scale = ctx.cfg
-        K = rois.shape[0]
-        grad = grad.contiguous().float()
-        # the workspace form (channels-fastest accumulation + transposing copy, fewer and fuller atomic requests) where the
-        # library offers it for these extents; it OVERWRITES grad_input, so no zero fill here
-        need = int(lib.inr_roi_align_3d_backward_workspace_bytes(N, C, W, L, H, K, ow, ol, oh)) if K > 0 and gin_numel(N, C, W, L, H) else 0
-        if need > 0:
-            gin = torch.empty(N, C, W, L, H, dtype=torch.float32, device=grad.device)
-            ws = _workspace(grad.device, need)
-            check(lib.inr_roi_align_3d_backward_ws(ptr(grad), ptr(rois), ptr(roi_inds), N, C, W, L, H, K, ow, ol, oh, scale,
-                                                   ptr(gin), ws.data_ptr(), need, stream_ptr()), "roi_align_3d_backward_ws")
-            return gin, None, None, None, None, None, None
-        gin = torch.zeros(N, C, W, L, H, dtype=torch.float32, device=grad.device)
-        check(lib.inr_roi_align_3d_backward(ptr(grad, allow_none=K == 0), ptr(rois, allow_none=K == 0),
-                                            ptr(roi_inds, allow_none=K == 0), N, C, W, L, H, K, ow, ol, oh, scale,
-                                            ptr(gin, allow_none=gin.numel() == 0), stream_ptr()), "roi_align_3d_backward")
-        return gin, None, None, None, None, None, None
+        return (roi_align_3d_grad_input(grad, rois, roi_inds, ctx.shape, ctx.cfg), None, None, None, None, None, None)
+
+
+def roi_align_3d_grad_input(grad, rois, roi_inds, shape, cfg):
+    """dL/d(input) f32[N,C,W,L,H] for grad f32[K,C,ow,ol,oh]; shape = (N,C,W,L,H), cfg = (ow,ol,oh,spatial_scale).  Shared
+    by the autograd function above and the registered custom op (ops.py)."""
+    lib = _lib.load()
+    N, C, W, L, H = shape
+    ow, ol, oh, scale = cfg
+    K = rois.shape[0]
+    grad = grad.contiguous().float()
+    # the workspace form (channels-fastest accumulation + transposing copy: fewer and fuller atomic requests) where the
+    # library offers it for these extents; it OVERWRITES grad_input, so no zero fill here
+    need = int(lib.inr_roi_align_3d_backward_workspace_bytes(N, C, W, L, H, K, ow, ol, oh)) if K > 0 and N * C * W * L * H else 0
+    if need > 0:
+        gin = torch.empty(N, C, W, L, H, dtype=torch.float32, device=grad.device)
+        ws = _workspace(grad.device, need)
+        check(lib.inr_roi_align_3d_backward_ws(ptr(grad), ptr(rois), ptr(roi_inds), N, C, W, L, H, K, ow, ol, oh, float(scale),
+                                               ptr(gin), ws.data_ptr(), need, stream_ptr()), "roi_align_3d_backward_ws")
+        return gin
+    gin = torch.zeros(N, C, W, L, H, dtype=torch.float32, device=grad.device)
+    check(lib.inr_roi_align_3d_backward(ptr(grad, allow_none=K == 0), ptr(rois, allow_none=K == 0),
+                                        ptr(roi_inds, allow_none=K == 0), N, C, W, L, H, K, ow, ol, oh, float(scale),
+                                        ptr(gin, allow_none=gin.numel() == 0), stream_ptr()), "roi_align_3d_backward")
+    return gin
 
 
 def roi_align_3d(input, rois, roi_inds, out_w, out_l, out_h, spatial_scale):
