@@ -61,7 +61,7 @@ def near_far_from_aabb(rays_o, rays_d, aabb, min_near=0.2, out=None, skip_labels
         nears = torch.empty(N, dtype=F32, device=rays_o.device)
         fars = torch.empty(N, dtype=F32, device=rays_o.device)
     if skip_labels is not None:
-        labels = skip_labels.reshape(-1).contiguous()
+        labels = skip_labels.reshape(-1).contiguous().long()      # (int32 label maps, e.g. match_seg's .npy files, are accepted)
         if labels.shape[0] != N:
             raise RuntimeError(f"near_far_from_aabb: {labels.shape[0]} labels for {N} rays")
         check(lib.inr_near_far_from_aabb_skip(ptr(rays_o, F32, "rays_o"), ptr(rays_d, F32, "rays_d"), ptr(aabb, F32, "aabb"),

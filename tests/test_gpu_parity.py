@@ -1634,6 +1634,8 @@ def test_ray_box_test_with_ignored_labels(rm, room, bits_dev):
         assert bool((n1[~keep] == big).all()) and bool((f1[~keep] == big).all())
         x, d, dl, rays = rm.march_rays_patch(ro, rd, 1.0, bits_dev, 1, 128, n1, f1)
         assert int(rays[~keep, 2].sum()) == 0 and int(rays[keep, 2].sum()) > 0
+    n2, f2 = rm.near_far_from_aabb(ro, rd, aabb, 0.05, skip_labels=labels.to(torch.int32), ignore_index=3)     # any integer dtype
+    assert torch.equal(n2, n1) and torch.equal(f2, f1)
     with pytest.raises(RuntimeError):
         rm.near_far_from_aabb(ro, rd, aabb, 0.05, skip_labels=labels[:-1])
 
