@@ -269,3 +269,32 @@ def test_captured_step_buffer_size_holds_across_small_changes():
     assert t._graph_capacity(4 * a) == 4 * a
     assert t._graph_capacity(2 * a + 1) == 4 * a                 # small sizes: two units of slack
     assert t._graph_capacity(a) == a
+
+
+def test_frame_path_choice_and_pruning_switches_without_a_gpu():
+    """Host logic added in round 5 that needs no device: which frame path `NeRFNetwork.forward_table` takes
+    (`frame_slices`: off / forced / "auto" only for frame-sized calls on a table whose finest level is 8192+), and the
+    instance-stage Trainer's `prune_ignored` plumbing (`_skip_labels`)."""
+    import torch
+    from instance_nerf_amd.nerf import NeRFNetwork
+    from instance_nerf_amd.nerf.utils import Trainer
+    net = NeRFNetwork(bound=1, cuda_ray=False, num_instances=4)
+    assert net.frame_slices == "auto"
+    assert net._use_slices(1 << 22) is False                   # finest level 2048: the fused kernel won every measurement
+    net.frame_slices = True
+    assert net._use_slices(1 << 10) is True and net._use_slices(0) is False
+    net.frame_slices = False
+    assert net._use_slices(1 << 22) is False
+    small = NeRFNetwork(bound=1, cuda_ray=False, encoder_kwargs={"num_levels": 12})
+    small.frame_slices = True
+    assert small._use_slices(1 << 22) is False                 # the sliced path needs the 16-level table
+    big = NeRFNetwork(bound=4, cuda_ray=False)
+    assert int(big.encoder.table["resolutions"][-1]) == 8192 and big.frame_slices == "auto"
+    assert big._use_slices(1 << 10) is False                   # a batch, not a frame
+    data = {"masks": torch.tensor([[0, -1, 2]])}
+    for stage, prune, want in (("instance", True, True), ("instance", False, False), ("nerf", True, False)):
+        n = NeRFNetwork(bound=1, cuda_ray=False, num_instances=4)
+        tr = Trainer("t", None, n, stage=stage, device=torch.device("cpu"), workspace=None, mute=True, prune_ignored=prune)
+        assert tr.prune_ignored is prune
+        assert (tr._skip_labels(data) is data["masks"]) is want
+        assert tr._skip_labels({}) is None
