@@ -9,7 +9,10 @@ poses resident in HBM before the timed region.  Samples = live (occupied) sample
 evaluated.  N > 1 ranks (torchrun, one process per GPU): every rank renders its own views -
 no data-path collective - and value = all samples / max-over-ranks time ("weak" scaling).
 
-Prints ONE JSON line on rank 0.
+Rank 0 prints TWO JSON lines: the full record (every probe's object; also written to
+gpurun_out/bench_full_n<N>.json) and, LAST, the compact contract line (tools/bench_line.py: the contract's keys, the
+`roofline` and `cpu_baseline` objects and one number per secondary leg; never more than 6 KB - round 5's single 20 KB
+line could not be parsed by the driver).
 """
 import argparse
 import json
@@ -26,15 +29,36 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_COPY_GBS = 6290.0           # what a float4 copy kernel reaches on this part (same guide: 79 % of the spec peak)
 BYTES_PER_SAMPLE = 1024         # 16 levels x 8 corners x 2 features x 4 B
+MFMA_PEAK_TFLOPS = 2500.0       # dense bf16 MFMA peak (same guide; AMD's 5 PF headline includes 2:1 sparsity)
+# useful MLP flops per sample: sigma net 32 -> 64 -> 16, colour net 31 -> 64 -> 64 -> 3 (2 flops per multiply-add); the
+# kernel executes each product three times (bf16 hi/lo split: hi.hi + hi.lo + lo.hi) on v_mfma_f32_16x16x32_bf16
+MLP_FLOPS_PER_SAMPLE = 2 * (32 * 64 + 64 * 16 + 31 * 64 + 64 * 64 + 64 * 3)
+MFMA_PASSES = 3
 
 
-TRAFFIC_JSON = os.path.join("profiles", "r05_traffic.json")
+TRAFFIC_JSON = os.path.join("profiles", "r06_traffic.json")
+MFMA_JSON = os.path.join("profiles", "r06_mfma.json")
+
+
+def measured_mfma_busy():
+    """MFMA pipe utilisation of the fused field kernel (and of the two head-backward kernels of the training steps) from
+    the committed PMC profile (profiles/r06_mfma.json, tools/mfma_json.py over the `mfma` pass of tools/pmc_bench.sh /
+    tools/pmc_train.sh): SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE per XCD x 256 CUs x 4 SIMDs) - the counter ticks in
+    cycles per SIMD (MI355X_MICROARCH.md, "s_memtime tick vs SQ PMC units").  Quoted only for the kernel sources it was
+    measured on.  -> dict or None."""
+    from instance_nerf_amd import build
+    path = os.path.join(ROOT, MFMA_JSON)
+    if not os.path.exists(path):
+        return None
+    t = json.load(open(path))
+    return t if t.get("source_sha") == build.source_sha() else None
 
 
 def measured_traffic_bytes_per_sample(res):
     """HBM-side bytes per sample of the fused field kernel from the committed PMC profile
-    (profiles/r05_traffic.json: FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc passes, gfx950 x2
+    (profiles/r06_traffic.json: FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc passes, gfx950 x2
     read correction; written by tools/traffic_json.py from a tools/pmc_bench.sh run).  PMC counters cannot be
     collected from inside this process, so the figure is only quoted for the kernel sources it was measured on (the
     file carries their sha): None if the profile is absent, belongs to other sources, or the workload differs."""
@@ -49,6 +73,7 @@ def measured_traffic_bytes_per_sample(res):
 
 
 sys.path.insert(0, os.path.join(ROOT, "tools"))
+from bench_line import emit  # noqa: E402
 from bench_secondary import (bound_render_probe, build_network, collective_record, config5_probe,  # noqa: E402
                              half_table_probe, instance_render_probe, render_sharded_probe, train_probe,
                              trained_scene_probe)
@@ -127,12 +152,13 @@ def main():
     ap.add_argument("--res", type=int, default=800)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train-probe", action="store_true")
-    ap.add_argument("--train-steps", type=int, default=20, help="timed steps of the secondary training probes")
-    ap.add_argument("--no-trained-scene", action="store_true", help="skip the trained-scene rendering leg (~15 s)")
+    ap.add_argument("--train-steps", type=int, default=100,
+                    help="timed steps of the secondary training probes (round-5 verdict item 4: >= 100; two regions each)")
+    ap.add_argument("--no-trained-scene", action="store_true", help="skip the trained-scene leg (~25 s)")
     ap.add_argument("--pipeline-probe", action="store_true",
                     help="(default since late round 3; kept for old command lines) measure the same frames through "
-                         "FramePipeline (two streams) AFTER the headline's timed region and report them as \"pipelined\"")
-    ap.add_argument("--no-pipeline-probe", action="store_true", help="skip the \"pipelined\" object")
+                         "the other view loop AFTER the headline's timed region")
+    ap.add_argument("--no-pipeline-probe", action="store_true", help="skip the other view loop")
     ap.add_argument("--diagnostics", action="store_true",
                     help="record the GPU's clocks during the timed region and the workgroup-to-XCD map (\"clocks\")")
     ap.add_argument("--pipeline", type=int, default=1,
@@ -150,6 +176,7 @@ def main():
                "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.run(cmd).returncode)
 
+    t_start = time.perf_counter()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:
         print(json.dumps({"error": f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
@@ -167,11 +194,14 @@ def main():
     dev = torch.device("cuda", local_dev)
     backend = os.environ.get("INR_DIST_BACKEND", "nccl")          # "nccl" == RCCL on ROCm
     if world > 1:
+        import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # a collective that a dead rank never joins raises after 5 minutes instead of blocking for the default 10-30
+        tmo = datetime.timedelta(seconds=300)
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=tmo)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=tmo)
     red_dev = dev if backend == "nccl" else torch.device("cpu")
 
     from instance_nerf_amd.nerf.utils import get_rays
@@ -179,10 +209,7 @@ def main():
     poses, intr, H, W = room.cameras(H=args.res, W=args.res, focal=args.res / 2.0)
     poses_d = torch.from_numpy(poses).to(dev)
 
-    # The headline loop renders one view at a time on one stream.  The wrapper carries the timing events around the
-    # dominant kernel, on the stream it is launched on.  (Two alternating streams - FramePipeline, the "pipelined"
-    # object of the line - hide the march and the compositing under the field kernel but slow that kernel down:
-    # profiles/r02_NOTES.txt section 18.)
+    # The wrapper carries the timing events around the dominant kernel, on the stream it is launched on.
     ev_pairs = []
 
     def timed(fn):
@@ -244,7 +271,6 @@ def main():
     gc.disable()               # no collector pause inside the timed region (a frame is 6 ms, a gen-2 pass ~10 ms)
     sclk = None
     if args.diagnostics and rank == 0:         # opt-in: a sampler thread beside the timed region (tools/bench_diagnostics.py)
-        sys.path.insert(0, os.path.join(ROOT, "tools"))
         from bench_diagnostics import SclkSampler, xcd_map_probe
         sclk = SclkSampler(dev)
     barrier()
@@ -271,11 +297,13 @@ def main():
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     elapsed_all, samples_all = float(tmax.item()), float(tot.item())
 
+    line = None
     if rank == 0:
         avg_kernel_s = kernel_ms / 1e3 / max(n_launch, 1)
-        achieved = (n_samples / max(n_launch, 1)) * BYTES_PER_SAMPLE / avg_kernel_s / 1e9
+        per_launch = n_samples / max(n_launch, 1)
+        achieved = per_launch * BYTES_PER_SAMPLE / avg_kernel_s / 1e9
         tbs = measured_traffic_bytes_per_sample(args.res)
-        traffic = None if tbs is None else round((n_samples / max(n_launch, 1)) * tbs / avg_kernel_s / 1e9, 1)
+        traffic = None if tbs is None else round(per_launch * tbs / avg_kernel_s / 1e9, 1)
         line = {
             "metric": "Msamples/sec (train+infer) 3D-FRONT 800x800 at 1/2/4/8 MI355X; PSNR parity",
             "value": round(samples_all / elapsed_all / 1e6, 3),
@@ -283,29 +311,53 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed_all / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
             # gathers, interpolation, SH, marching and compositing are IEEE fp32; the MLP GEMMs run on
             # v_mfma_f32_16x16x32_bf16 with a 3-term bf16 split of both operands (~2^-16 relative, fp32 accumulate)
-            "dtype": "f32 (MLP GEMMs: bf16x3-split MFMA, fp32 accumulate)", "data": "synthetic",
+            "dtype_note": "MLP GEMMs: bf16x3-split MFMA, fp32 accumulate; everything else IEEE fp32",
             "config": {"workload": f"render {args.res}x{args.res} synthetic 3D-FRONT-like room, hash-grid NeRF "
                                    "L=16 F=2 T=6119864 sigma+rgb (BASELINE configs[1]), one view per step per GPU",
                        "samples_per_step": n_samples // args.steps, "rays_per_step": H * W,
                        "parallelism": f"views sharded over {world} GPU(s), no data-path collective"},
-            # ONE definition across rounds (round-4 verdict 12): `frac` = the dominant kernel's algorithmic bytes over its
-            # launch time WITH THE CHIP TO ITSELF - filled in below from the one-stream leg of this same process (events
-            # on its stream); the figure inside the timed (pipelined) region, where the kernel shares the CUs with the
-            # next view's marchers, is kept beside it as `in_timed_region`.  Rounds 1-3 reported the kernel alone (their
-            # headline loop was the one-stream loop), round 4 the shared figure: 0.889 -> 0.820 was that switch.
+            # ONE definition since round 6 (round-5 advisor): `frac` / `achieved` / `avg_launch_ms` are the dominant
+            # kernel's launches INSIDE THE TIMED REGION - the loop `value` and `ms_per_step` come from (algorithmic bytes
+            # per launch over the mean launch time, events on the launch stream; the rocprofv3 kernel trace of the same
+            # command under profiles/ must agree).  With --pipeline 1 the kernel shares the CUs there with the next view's
+            # marchers; the same kernel with the chip to itself (the one-stream loop of this process) is
+            # `frac_kernel_alone`.  Rounds 1-3 and 5 printed the alone figure as `frac`, round 4 this one.
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "definition": "timed region (no one-stream leg in this run)",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "in_timed_region_frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": traffic,
+                         # FETCH_SIZE / WRITE_SIZE count the L2's memory-side (fabric) requests: reads the 256 MB Infinity
+                         # Cache serves are included, so this is fabric traffic, an upper bound on DRAM traffic
+                         "traffic_kind": "fabric (L2 misses; Infinity-Cache hits included)",
+                         "traffic_bytes_per_sample": tbs,
                          "traffic_source": (TRAFFIC_JSON + " (rocprofv3 PMC on these kernel sources, GB/s at this run's "
                                             "launch time)") if traffic is not None else
                          "no PMC profile of these kernel sources under profiles/ (tools/pmc_bench.sh + tools/traffic_json.py)",
+                         # second denominator: what a streaming copy reaches on this part (the algorithmic figure can
+                         # exceed it only because part of the rows come from the L2 / Infinity Cache)
+                         "achievable_copy_peak": HBM_COPY_GBS,
+                         "frac_of_achievable_copy": round(achieved / HBM_COPY_GBS, 4),
+                         "traffic_frac_of_achievable_copy": None if traffic is None else round(traffic / HBM_COPY_GBS, 4),
                          "kernel": "k_nerf_fwd<true,true> (fused hash gather + SH table + MLP)",
                          "avg_launch_ms": round(avg_kernel_s * 1e3, 4), "launches": n_launch,
                          "algorithmic_bytes_per_sample": BYTES_PER_SAMPLE},
             "clocks": clocks,
         }
+        # north_star's second evidence item: MFMA utilisation.  Effective rate from this run's launches, pipe busy
+        # fraction from the committed PMC pass over these kernel sources.
+        tfl = per_launch * MLP_FLOPS_PER_SAMPLE * MFMA_PASSES / avg_kernel_s / 1e12
+        mb = measured_mfma_busy()
+        line["roofline"]["mfma"] = {
+            "tflops": round(tfl, 1), "peak": MFMA_PEAK_TFLOPS, "frac": round(tfl / MFMA_PEAK_TFLOPS, 4),
+            "flops_per_sample": MLP_FLOPS_PER_SAMPLE, "passes": MFMA_PASSES,
+            "busy": None if mb is None else mb["k_nerf_fwd"]["mfma_busy"],
+            "head_bwd_busy": None if mb is None else {k: v["mfma_busy"] for k, v in mb.items()
+                                                      if isinstance(v, dict) and "head_bwd" in k},
+            "what": "tflops = samples x 18 688 useful MLP flops x 3 bf16-split passes / launch time, against the dense bf16 "
+                    "MFMA peak; busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE per XCD x 256 CUs x 4 SIMDs)",
+            "source": (MFMA_JSON if mb is not None else "no PMC profile of these kernel sources (tools/mfma_json.py)")}
         # whole-frame fraction of the roofline: every launch of the loop, not only the field kernel
         line["end_to_end"] = {"achieved": round(samples_all / world / elapsed_all * BYTES_PER_SAMPLE / 1e9, 1),
                               "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -335,131 +387,193 @@ def main():
                              "serialised; march of view i+1 and compositing of view i-1 run under field kernel i") if other
                     else "Trainer.render_sequence(pipeline=False): upstream's loop, one view at a time on one stream"}
                 if not other:
-                    # the dominant kernel with the chip to itself becomes THE roofline figure; the timed (pipelined)
-                    # region's, where it shares the CUs with the next view's marchers, moves beside it
-                    rf = line["roofline"]
-                    rf["in_timed_region"] = {"avg_launch_ms": rf["avg_launch_ms"], "launches": rf["launches"],
-                                             "achieved": rf["achieved"], "frac": rf["frac"], "traffic": rf["traffic"],
-                                             "what": "the launches of the timed (pipelined) loop: the kernel shares the CUs "
-                                                     "with the march of the next view"}
                     alone = ns / n_o * BYTES_PER_SAMPLE / (kms / 1e3) / 1e9
-                    rf.update({"achieved": round(alone, 1), "frac": round(alone / HBM_PEAK_GBS, 4),
-                               "avg_launch_ms": round(kms, 4), "launches": len(ev_pairs),
-                               "traffic": None if tbs is None else round(ns / n_o * tbs / (kms / 1e3) / 1e9, 1),
-                               "definition": "kernel alone: the launches of the one-stream loop (the \"one_stream\" object, "
-                                             "same process, events on the launch stream), algorithmic bytes / launch time"})
-                    rf["kernel_alone"] = {"avg_launch_ms": round(kms, 4), "frac": rf["frac"],
-                                          "what": "= roofline.frac since round 5 (kept for readers of the round-4 line)"}
+                    line["roofline"].update({"frac_kernel_alone": round(alone / HBM_PEAK_GBS, 4),
+                                             "achieved_alone": round(alone, 1), "avg_launch_ms_alone": round(kms, 4)})
             except Exception as e:                            # noqa: BLE001
                 line["pipelined" if not args.pipeline else "one_stream"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"], line["parity"] = cpu_baseline(room, net, step(0)["frame"],
-                                                                render_view0=lambda: step(0)["frame"])
-    watchdog = None
+            try:
+                line["cpu_baseline"], line["parity"] = cpu_baseline(room, net, step(0)["frame"],
+                                                                    render_view0=lambda: step(0)["frame"])
+            except Exception as e:                            # noqa: BLE001
+                line["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    del net
     if world > 1:
-        # Everything from here on contains collectives: a rank that dies or hangs in one leaves the others waiting.  Two
-        # guards keep the headline measurement when that happens: the line is put in a side file first, and a watchdog
-        # THREAD on rank 0 (a blocked collective holds the main thread inside C++, where no signal handler runs) prints
-        # the line as far as it got and exits non-zero if the collective record and the probes have not finished after
-        # 7 minutes.
-        if rank == 0:
-            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-            with open(os.path.join(ROOT, "gpurun_out", f"bench_headline_n{world}.json"), "w") as f:
-                f.write(json.dumps(line) + "\n")
-            import threading
+        secondary_multi(args, line, dev, rank, world, backend, red_dev, t_start)
+    elif not args.no_train_probe:
+        secondary_single(args, line, dev, red_dev)
+    if rank == 0:
+        line["bench_wall_s"] = round(time.perf_counter() - t_start, 1)
+        emit(line, world, ROOT)
+    if world > 1:
+        dist.barrier()             # the ranks leave together (rank 0 alone ran the single-GPU legs after the probes)
+        dist.destroy_process_group()
 
-            def bail():
-                line.setdefault("train_step", {"error": "collectives / training probes did not finish in 420 s"})
-                line.setdefault("train_step_nerf", line["train_step"])
-                print(json.dumps(line), flush=True)
-                # a hung collective is a FAILED run: non-zero, so that the launcher tears the other ranks down and the
-                # caller sees it (the headline is also in gpurun_out/bench_headline_n<N>.json)
-                os._exit(3)
-            watchdog = threading.Timer(420.0, bail)
-            watchdog.daemon = True
-            watchdog.start()
+
+def _try(line, key, fn):
+    """One secondary leg: a failure costs its own key, never the line."""
+    try:
+        line[key] = fn()
+    except Exception as e:                                        # noqa: BLE001
+        line[key] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    return line[key]
+
+
+TRAIN_KEEP = ("ms_per_step", "ms_per_step_median", "ms_per_step_running", "ms_per_step_of_both_timed_regions",
+              "host_enqueue_ms_per_step", "samples_per_step", "msamples_per_s", "occupancy_updates_in_timed_steps",
+              "mode", "graphs_captured", "loss_first", "loss_last", "timed_steps")
+
+
+def secondary_single(args, line, dev, red_dev):
+    """world == 1: every other measurement of the record, each in its own try-block."""
+    def train_legs(stage, key):
+        ts = train_probe(dev, 0, 1, red_dev, steps=args.train_steps, stage=stage)
+        # the same loop as a captured two-stream pipeline (Trainer(use_graph=True, look_ahead=True)): the figure the compact
+        # line quotes (round-5 verdict item 4) - the eager loop's MEAN moves with the host's enqueue time
         try:
-            rec = collective_record(dev, rank, world, backend, red_dev)
-        except Exception as e:                                # noqa: BLE001 - reported; the same code path on every rank
-            rec = {"error": f"{type(e).__name__}: {e}"[:300], "all_ranks_on_distinct_gpus": None}
+            ov = train_probe(dev, 0, 1, red_dev, steps=args.train_steps, stage=stage, mode="pipelined")
+            ts["overlapped"] = {k: ov[k] for k in TRAIN_KEEP if k in ov}
+            ts["overlapped"]["step_frac_of_hbm_peak"] = ov["roofline"]["step"]["frac"]
+        except Exception as e:                                    # noqa: BLE001
+            ts["overlapped"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        if stage == "instance":
+            # upstream's -O on the instance stage (Trainer(fp16=True)): trained parameters stay fp32, the frozen
+            # NeRF's forward gathers from the fp16 table copy and runs the one-pass fp16 MLP
+            try:
+                ov = train_probe(dev, 0, 1, red_dev, steps=args.train_steps, mode="pipelined", fp16=True)
+                ts["overlapped_O"] = {k: ov[k] for k in TRAIN_KEEP if k in ov}
+            except Exception as e:                                # noqa: BLE001
+                ts["overlapped_O"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        return ts
+    _try(line, "train_step", lambda: train_legs("instance", "train_step"))
+    _try(line, "train_step_nerf", lambda: train_legs("nerf", "train_step_nerf"))
+    single_gpu_legs(args, line, dev, red_dev, world=1)
+
+
+def single_gpu_legs(args, line, dev, red_dev, world):
+    """Rank 0 only, no collectives: configs[4] (world 1), the instance / -O renders, the configurations off the tuned one,
+    the trained scene."""
+    if world == 1:
+        _try(line, "extract_roialign", lambda: config5_probe(dev))
+    _try(line, "render_instance", lambda: instance_render_probe(dev))
+    _try(line, "render_half_table", lambda: half_table_probe(dev))
+    _try(line, "render_fast", lambda: half_table_probe(dev, mlp_fp16=True))
+    # off the tuned configuration (round-4 verdict item 1): bound 2 and 4 (cascades, finer level tables), the
+    # render with growing and with constant steps, and both training stages at bound 4
+    for key, kw in (("render_bound2", dict(bound=2, dt_gamma=1.0 / 128)), ("render_bound4", dict(bound=4, dt_gamma=1.0 / 128)),
+                    ("render_bound4_constant_steps", dict(bound=4, dt_gamma=0.0))):
+        _try(line, key, lambda kw=kw: bound_render_probe(dev, **kw))
+    if world == 1:
+        drop = ("ms_of_each_step", "graphs_captured", "allreduce_mb_per_step", "gradient_schedule", "n_gpus")
+        for key, st in (("train_step_bound4", "instance"), ("train_step_nerf_bound4", "nerf")):
+            _try(line, key, lambda st=st: {k: v for k, v in train_probe(
+                dev, 0, 1, red_dev, steps=args.train_steps, stage=st, bound=4, dt_gamma=1.0 / 128).items() if k not in drop})
+        if not args.no_trained_scene:
+            _try(line, "trained_scene", lambda: trained_scene_probe(dev, with_oracle=not args.no_cpu_baseline))
+
+
+def secondary_multi(args, line, dev, rank, world, backend, red_dev, t_start):
+    """world > 1.  Everything here contains collectives: a rank that dies or hangs in one leaves the others waiting.  Guards:
+    (1) the headline is put in a side file first; (2) a watchdog THREAD on rank 0 (a blocked collective holds the main
+    thread inside C++, where no signal handler runs) prints the record as far as it got - full line, then the compact
+    line - and exits non-zero if the legs have not finished after 7 minutes; (3) every leg runs in its own try-block
+    and the ranks agree on its outcome BEFORE the next leg (all_reduce MIN of an ok flag): a leg that failed on any rank
+    poisons only itself, and if a rank is left in a state where it cannot take part in collectives any more the remaining
+    collective legs are skipped on ALL ranks (round-5 advisor: a one-rank exception used to leave the others blocked
+    until the RCCL timeout).  Order (round-5 verdict item 8): collective record, training steps, sharded render,
+    configs[4]; then rank 0's single-GPU legs."""
+    watchdog = None
+    if rank == 0:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", f"bench_headline_n{world}.json"), "w") as f:
+            f.write(json.dumps(line) + "\n")
+        import threading
+
+        def bail():
+            line.setdefault("train_step", {"error": "collectives / training probes did not finish in 420 s"})
+            line["error"] = "watchdog: a collective leg did not finish in 420 s"
+            line["bench_wall_s"] = round(time.perf_counter() - t_start, 1)
+            emit(line, world, ROOT)
+            # a hung collective is a FAILED run: non-zero, so that the launcher tears the other ranks down and the
+            # caller sees it (the headline is also in gpurun_out/bench_headline_n<N>.json)
+            os._exit(3)
+        watchdog = threading.Timer(420.0, bail)
+        watchdog.daemon = True
+        watchdog.start()
+
+    state = {"healthy": True}
+
+    def agree(ok):
+        """all ranks: did the leg succeed everywhere?"""
+        t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item() > 0.5)
+
+    def leg(key, fn, keep=None):
+        """Every rank calls it, in the same order.  -> the leg's object (rank 0 also stores it under line[key])."""
+        if not state["healthy"]:
+            out = {"error": "skipped: an earlier collective leg failed on some rank"}
+        else:
+            try:
+                out = fn()
+                ok = True
+            except Exception as e:                                # noqa: BLE001
+                out = {"error": f"{type(e).__name__}: {e}"[:300]}
+                ok = False
+            try:
+                if not agree(ok):
+                    state["healthy"] = False
+                    if ok:
+                        out = {"error": "failed on another rank", "rank0_result": out if keep is None else None}
+            except Exception as e:                                # noqa: BLE001 - the agreement itself failed: stop collectives
+                state["healthy"] = False
+                out = {"error": f"ranks could not agree after the leg: {type(e).__name__}: {e}"[:300]}
         if rank == 0:
-            line["collective"] = rec
+            line[key] = out if keep is None or "error" in out else {k: out[k] for k in keep if k in out}
+        return out
+
+    try:
+        rec = leg("collective", lambda: collective_record(dev, rank, world, backend, red_dev))
         if backend == "nccl" and rec.get("all_ranks_on_distinct_gpus") is False:
             # an RCCL run whose ranks share GPUs measures nothing about xGMI: fail loudly instead of reporting a curve
             if rank == 0:
                 line["error"] = f"{rec['distinct_devices']} distinct GPUs for {world} ranks"
-                print(json.dumps(line), flush=True)
+                emit(line, world, ROOT)
+            if watchdog is not None:
+                watchdog.cancel()
             dist.barrier()
             dist.destroy_process_group()
             sys.exit(4)
-    if args.no_train_probe and watchdog is not None:
-        watchdog.cancel()
-    if not args.no_train_probe:
-        del net                                       # the probe builds its own (instance-head) network
-        if world == 1:
-            # secondary measurements must never cost the headline line: report a failure instead of dying with it
-            try:
-                ts = train_probe(dev, rank, world, red_dev, steps=args.train_steps)
-                tn = train_probe(dev, rank, world, red_dev, steps=args.train_steps, stage="nerf")
-            except Exception as e:                        # noqa: BLE001
-                ts = tn = {"error": f"{type(e).__name__}: {e}"[:300]}
-            # the same two loops as captured two-stream pipelines (Trainer(use_graph=True, look_ahead=True)); the eager
-            # loop above stays the reference figure
-            keep = ("ms_per_step", "ms_per_step_median", "ms_per_step_running", "ms_per_step_of_both_timed_regions",
-                    "host_enqueue_ms_per_step", "samples_per_step", "msamples_per_s", "occupancy_updates_in_timed_steps",
-                    "mode", "graphs_captured", "loss_first", "loss_last", "ms_of_each_step")
-            for obj, st in ((ts, "instance"), (tn, "nerf")):
-                if "error" in obj:
-                    continue
-                try:
-                    ov = train_probe(dev, rank, world, red_dev, steps=args.train_steps, stage=st, mode="pipelined")
-                    obj["overlapped"] = {k: ov[k] for k in keep if k in ov}
-                    obj["overlapped"]["step_frac_of_hbm_peak"] = ov["roofline"]["step"]["frac"]
-                except Exception as e:                    # noqa: BLE001
-                    obj["overlapped"] = {"error": f"{type(e).__name__}: {e}"[:300]}
-            if "error" not in ts:
-                # upstream's -O on the instance stage (Trainer(fp16=True)): trained parameters stay fp32, the frozen
-                # NeRF's forward gathers from the fp16 table copy and runs the one-pass fp16 MLP
-                try:
-                    ov = train_probe(dev, rank, world, red_dev, steps=args.train_steps, mode="pipelined", fp16=True)
-                    ts["overlapped_O"] = {k: ov[k] for k in keep if k in ov and k != "ms_of_each_step"}
-                except Exception as e:                    # noqa: BLE001
-                    ts["overlapped_O"] = {"error": f"{type(e).__name__}: {e}"[:300]}
-        else:
-            # The probes contain collectives: a rank that swallowed an exception would leave the others waiting in
-            # all_reduce, so exceptions propagate (non-zero exit, the launcher tears the job down); the watchdog started
-            # above covers them.
-            try:
-                from instance_nerf_amd.nerf.utils import grad_sync as _gs
-                default_schedule = _gs.schedule
-                ts = train_probe(dev, rank, world, red_dev, steps=args.train_steps)   # every rank runs it
-                tn = train_probe(dev, rank, world, red_dev, steps=args.train_steps, stage="nerf")
-                # the other gradient schedule, back to back (same bytes on the links, 7/8 of the
-                # optimiser sweep saved per rank): the xGMI box decides which one becomes the default
-                other = "reduce_scatter" if default_schedule != "reduce_scatter" else "all_reduce"
-                to = train_probe(dev, rank, world, red_dev, steps=args.train_steps, schedule=other)
-                _gs.schedule = default_schedule
-                if rank == 0:
-                    line["train_step_other_schedule"] = {k: to[k] for k in (
-                        "ms_per_step", "ms_per_step_median", "ms_per_step_of_both_timed_regions", "samples_per_step",
-                        "msamples_per_s", "gradient_schedule", "allreduce_mb_per_step", "loss_first", "loss_last") if k in to}
-                # strong scaling beside the headline's weak scaling: one frame over all ranks (every rank calls it)
-                rs = render_sharded_probe(dev, rank, world, red_dev, res=args.res)
-                if rank == 0:
-                    line["render_sharded"] = rs
-                # BASELINE configs[4] as the metric states it: N scenes, one per GPU, no collective on the data path -
-                # every rank extracts and pools its own scene; aggregate extraction rate, RoIAlign time max over ranks
+        if not args.no_train_probe:
+            from instance_nerf_amd.nerf.utils import grad_sync as _gs
+            default_schedule = _gs.schedule
+            leg("train_step", lambda: train_probe(dev, rank, world, red_dev, steps=args.train_steps))
+            leg("train_step_nerf", lambda: train_probe(dev, rank, world, red_dev, steps=args.train_steps, stage="nerf"))
+            # the other gradient schedule, back to back (DESIGN.md section 4: same bytes on the links, 7/8 of the
+            # optimiser sweep saved per rank): the xGMI box decides which one becomes the default
+            other = "reduce_scatter" if default_schedule != "reduce_scatter" else "all_reduce"
+            leg("train_step_other_schedule",
+                lambda: train_probe(dev, rank, world, red_dev, steps=args.train_steps, schedule=other),
+                keep=("ms_per_step", "ms_per_step_median", "ms_per_step_of_both_timed_regions", "samples_per_step",
+                      "msamples_per_s", "gradient_schedule", "allreduce_mb_per_step", "loss_first", "loss_last"))
+            _gs.schedule = default_schedule
+            # strong scaling beside the headline's weak scaling: one frame over all ranks
+            leg("render_sharded", lambda: render_sharded_probe(dev, rank, world, red_dev, res=args.res))
+            # BASELINE configs[4] as the metric states it: N scenes, one per GPU, no collective on the data path -
+            # every rank extracts and pools its own scene; aggregate extraction rate, RoIAlign time max over ranks
+
+            def config5_all():
                 try:
                     mine = config5_probe(dev)
-                except Exception as e:                        # noqa: BLE001
+                except Exception as e:                            # noqa: BLE001
                     mine = {"error": f"{type(e).__name__}: {e}"[:300]}
                 every = [None] * world
                 dist.all_gather_object(every, mine)
-                if rank == 0:
-                    ok = [o for o in every if "error" not in o]
-                    line["extract_roialign"] = {"error": f"{world - len(ok)} of {world} ranks failed: " + str(
-                        [o["error"] for o in every if "error" in o][:1])} if len(ok) < world else {
-                        "workload": ok[0]["workload"] + f"; {world} scenes, one per GPU (replicas, no collective)",
+                ok = [o for o in every if "error" not in o]
+                if len(ok) < world:
+                    return {"error": f"{world - len(ok)} of {world} ranks failed: " + str([o["error"] for o in every if "error" in o][:1])}
+                return {"workload": ok[0]["workload"] + f"; {world} scenes, one per GPU (replicas, no collective)",
                         "n_gpus": world,
                         "extract_mvoxels_per_s": round(sum(o["extract_mvoxels_per_s"] for o in ok), 1),
                         "extract_ms_max_over_ranks": max(o["extract_ms"] for o in ok),
@@ -467,61 +581,14 @@ def main():
                         "roi_align_backward_ms_max_over_ranks": max(o["roi_align_backward_ms"] for o in ok),
                         "per_rank": [{k: o[k] for k in ("extract_ms", "extract_mvoxels_per_s", "roi_align_forward_ms",
                                                         "roi_align_backward_ms")} for o in ok]}
-            except Exception as e:                            # noqa: BLE001
-                if rank == 0:
-                    line["train_step"] = line["train_step_nerf"] = {"error": f"{type(e).__name__}: {e}"[:300]}
-                    print(json.dumps(line), flush=True)
-                raise
-            finally:
-                if watchdog is not None:
-                    watchdog.cancel()
-        if rank == 0:
-            line["train_step"] = ts
-            line["train_step_nerf"] = tn
-            if world == 1:
-                try:
-                    line["extract_roialign"] = config5_probe(dev)
-                except Exception as e:                        # noqa: BLE001
-                    line["extract_roialign"] = {"error": f"{type(e).__name__}: {e}"[:300]}
-            try:
-                line["render_instance"] = instance_render_probe(dev)
-            except Exception as e:                            # noqa: BLE001
-                line["render_instance"] = {"error": f"{type(e).__name__}: {e}"[:300]}
-            try:
-                line["render_half_table"] = half_table_probe(dev)
-            except Exception as e:                            # noqa: BLE001
-                line["render_half_table"] = {"error": f"{type(e).__name__}: {e}"[:300]}
-            try:
-                line["render_fast"] = half_table_probe(dev, mlp_fp16=True)
-            except Exception as e:                            # noqa: BLE001
-                line["render_fast"] = {"error": f"{type(e).__name__}: {e}"[:300]}
-            # off the tuned configuration (round-4 verdict item 1): bound 2 and 4 (cascades, finer level tables), the
-            # render with growing and with constant steps, and both training stages at bound 4
-            for key, kw in (("render_bound2", dict(bound=2, dt_gamma=1.0 / 128)), ("render_bound4", dict(bound=4, dt_gamma=1.0 / 128)),
-                            ("render_bound4_constant_steps", dict(bound=4, dt_gamma=0.0))):
-                try:
-                    line[key] = bound_render_probe(dev, **kw)
-                except Exception as e:                        # noqa: BLE001
-                    line[key] = {"error": f"{type(e).__name__}: {e}"[:300]}
-            if world == 1:
-                drop = ("ms_of_each_step", "ms_per_step_of_both_timed_regions", "graphs_captured", "allreduce_mb_per_step",
-                        "gradient_schedule", "n_gpus")
-                for key, st in (("train_step_bound4", "instance"), ("train_step_nerf_bound4", "nerf")):
-                    try:
-                        o = train_probe(dev, rank, world, red_dev, steps=args.train_steps, stage=st, bound=4, dt_gamma=1.0 / 128)
-                        line[key] = {k: v for k, v in o.items() if k not in drop}
-                    except Exception as e:                    # noqa: BLE001
-                        line[key] = {"error": f"{type(e).__name__}: {e}"[:300]}
-            if world == 1 and not args.no_trained_scene:
-                try:
-                    line["trained_scene"] = trained_scene_probe(dev, with_oracle=not args.no_cpu_baseline)
-                except Exception as e:                        # noqa: BLE001
-                    line["trained_scene"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            leg("extract_roialign", config5_all)
+    finally:
+        if watchdog is not None:
+            watchdog.cancel()
     if rank == 0:
-        print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.barrier()             # the ranks leave together (rank 0 alone ran the single-GPU legs after the probes)
-        dist.destroy_process_group()
+        line["collective_legs_wall_s"] = round(time.perf_counter() - t_start, 1)
+        if not args.no_train_probe:
+            single_gpu_legs(args, line, dev, red_dev, world)
 
 
 if __name__ == "__main__":

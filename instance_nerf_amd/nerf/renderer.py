@@ -621,7 +621,8 @@ class NeRFRenderer(nn.Module):
         out = {"n_rays": N, "key": (rays_o.data_ptr(), rays_d.data_ptr(), N), "rays_o": rays_o_in, "rays_d": rays_d_in,
                "nears": nears, "fars": fars, "xyzs": xyzs, "dirs": dirs, "deltas": deltas, "rays": rays, "counter": counter,
                "shaded": shaded, "T_thresh": float(T_thresh), "density_scale": float(self.density_scale),
-               "slot_taken": slot_taken, "slot_index": slot_index, "grid_state": self.iter_density}
+               "slot_taken": slot_taken, "slot_index": slot_index, "grid_state": self.iter_density,
+               "skip_labels": skip_labels}      # the label tensor the march was pruned with (identity-checked by the trainer)
 
         def consume():
             cur = torch.cuda.current_stream()

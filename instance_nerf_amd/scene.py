@@ -131,6 +131,50 @@ class RoomScene:
         rgb = self.palette[best_id] * shade[:, None]
         return rgb.astype(F32), best_id, best_t.astype(F32)
 
+    # ------------------------------------------------------------------ files
+    def write_dataset(self, path, n_views=24, H=400, W=400, seed=1, num_instances=0, ignore_frac=0.1, mask_seed=2):
+        """The room as the files the reference's two training stages read (README.md:58-66): ``images/NNNN.png`` (8-bit
+        rgb of the analytic first hit), ``transforms_train.json`` (instant-ngp convention: Blender camera matrices,
+        ``fl_x/fl_y/cx/cy/w/h``; load with ``NeRFDataset(path, scale=1.0)``) and, with ``num_instances`` > 0,
+        ``matched/NNNN.npy`` - int32 [H, W] labels in the layout of ``Mask2Former_sample/match_seg.py:131-140`` (-1 ignore,
+        0 background, > 0 instance id; ``ignore_frac`` of the pixels carry -1 as unmatched segments do there).
+        -> dict(path, mask_dir, names, poses, intrinsics, ids [n, H, W]).  Data generation (numpy + PIL), used by bench.py
+        and the tests to run the product's loader and training loop from disk."""
+        import json
+        import os
+        from PIL import Image
+        os.makedirs(os.path.join(path, "images"), exist_ok=True)
+        poses, intr, _, _ = self.cameras(n=n_views, seed=seed, H=H, W=W, focal=W / 2.0)
+        fx, fy, cx, cy = intr
+        jj, ii = np.meshgrid(np.arange(H, dtype=np.float64) + 0.5, np.arange(W, dtype=np.float64) + 0.5, indexing="ij")
+        d_cam = np.stack([(ii - cx) / fx, (jj - cy) / fy, np.ones_like(ii)], -1).reshape(-1, 3)
+        d_cam /= np.linalg.norm(d_cam, axis=1, keepdims=True)
+        rng = np.random.default_rng(mask_seed)
+        mask_dir = os.path.join(path, "matched") if num_instances else None
+        if mask_dir:
+            os.makedirs(mask_dir, exist_ok=True)
+        names, frames, all_ids = [], [], []
+        for i, P in enumerate(poses):
+            P64 = P.astype(np.float64)
+            rd = d_cam @ P64[:3, :3].T
+            ro = np.broadcast_to(P64[:3, 3], rd.shape)
+            rgb, ids, _ = self.trace(ro, rd)
+            name = f"{i:04d}"
+            names.append(name)
+            all_ids.append(ids.reshape(H, W))
+            Image.fromarray((rgb.reshape(H, W, 3) * 255.0 + 0.5).astype(np.uint8)).save(os.path.join(path, "images", name + ".png"))
+            T = np.eye(4, dtype=np.float32)     # the file stores the Blender-convention matrix (inverse of nerf_matrix_to_ngp)
+            T[[1, 2, 0], 0], T[[1, 2, 0], 1], T[[1, 2, 0], 2], T[[1, 2, 0], 3] = P[:3, 0], -P[:3, 1], -P[:3, 2], P[:3, 3]
+            frames.append({"file_path": f"images/{name}.png", "transform_matrix": T.tolist()})
+            if mask_dir:
+                lab = (ids % num_instances).astype(np.int32)
+                lab[rng.random(lab.shape[0]) < ignore_frac] = -1
+                np.save(os.path.join(mask_dir, name + ".npy"), lab.reshape(H, W))
+        with open(os.path.join(path, "transforms_train.json"), "w") as f:
+            json.dump({"fl_x": fx, "fl_y": fy, "cx": cx, "cy": cy, "w": W, "h": H, "frames": frames}, f)
+        return {"path": path, "mask_dir": mask_dir, "names": names, "poses": poses, "intrinsics": intr,
+                "ids": np.stack(all_ids)}
+
     def instance_of_points(self, x):
         """Instance id of points (0 = wall/empty, b+1 inside box b; first box wins)."""
         x = np.asarray(x, dtype=np.float64)

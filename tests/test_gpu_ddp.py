@@ -353,8 +353,24 @@ def test_bench_logic_with_eight_ranks_on_one_gpu():
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{") and '"metric"' in l]
-    assert len(lines) == 1, r.stdout[-2000:]
+    # round 6: the full record, then - LAST on stdout - the compact contract line the driver parses (< 6 KB; round 5's
+    # single 20 KB line came back unparsed)
+    assert len(lines) == 2 and r.stdout.strip().splitlines()[-1] == lines[1], r.stdout[-2000:]
+    compact = json.loads(lines[1])
+    assert len(lines[1]) < 6144, len(lines[1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in compact, k
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in compact["roofline"], k
+    assert compact["n_gpus"] == 8 and compact["distinct_devices"] == 1 and compact["allreduce_bus_gb_per_s"] > 0
+    assert compact["render_sharded_value"] > 0 and compact["train_step_ms_ddp"] > 0 and "failed_legs" not in compact, compact
+    assert compact["full"] == os.path.join("gpurun_out", "bench_full_n8.json")
     line = json.loads(lines[0])
+    assert line["full_record"] is True and line["value"] == compact["value"]
+    assert json.load(open(os.path.join(root, compact["full"])))["value"] == compact["value"]
+    # the N = 8 run must fit the driver's patience: this dry run (eight ranks on ONE GPU, 2 CPU threads each) under 10 min
+    assert line["bench_wall_s"] < 600, line["bench_wall_s"]
     assert line["n_gpus"] == 8 and line["scaling"] == "weak" and line["value"] > 0 and line["steps"] == 2
     assert line["config"]["rays_per_step"] == 200 * 200 and "8 GPU" in line["config"]["parallelism"]
     # the self-verifying collective record (round 4): backend, version slot, one device entry per rank, the table-sized

@@ -12,6 +12,8 @@ run() {
   echo "$name rc=$?"
 }
 run grbm GRBM_GUI_ACTIVE
+# round 6: MFMA pipe utilisation - busy cycles (per SIMD) and the kernel's own cycle count from ONE pass (tools/mfma_json.py)
+run mfma GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES
 run hbm_rd FETCH_SIZE
 run hbm_wr WRITE_SIZE
 run rdreq TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum TCC_HIT_sum TCC_MISS_sum

@@ -15,6 +15,8 @@ run() {
   echo "$name rc=$? $(tail -1 $R/gpurun_out/$TAG.$name.log)"
 }
 run grbm GRBM_GUI_ACTIVE TCC_CYCLE_sum TCC_BUSY_sum
+# round 6: MFMA pipe utilisation - busy cycles (per SIMD) and the kernel's own cycle count from ONE pass (tools/mfma_json.py)
+run mfma GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES
 run atom1 TCC_EA0_ATOMIC_sum TCC_EA0_ATOMIC_LEVEL_sum TCC_ATOMIC_sum TCC_REQ_sum
 run atom2 TCP_TCC_ATOMIC_WITHOUT_RET_REQ_sum TCP_TCC_ATOMIC_WITH_RET_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_ATOMIC_TAGCONFLICT_STALL_CYCLES_sum
 run atom3 TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_WRREQ_STALL_sum TCC_EA0_WRREQ_LEVEL_sum
