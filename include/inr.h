@@ -71,6 +71,14 @@ int inr_device_info(int32_t device, int64_t* props);
  * request extra LDS per workgroup, which is how a launch tells the dispatcher to keep one field workgroup and a
  * bounded number of march workgroups per CU.  Results do not change; process-wide; off by default.                */
 int inr_set_overlap_placement(int32_t on);
+/* THREADING / MULTI-DEVICE NOTE for the three mode switches of this header - inr_set_overlap_placement,
+ * inr_set_march_mode, inr_roi_align_3d_set_mode: each writes one plain process-global variable that every later launch
+ * of the library reads, on every device and every stream.  They are meant to be set once, before the work starts, by
+ * the one process that drives one GPU (the deployment this library is written for).  They are NOT thread-safe and NOT
+ * per-device: a host that drives several devices from one process, or flips a mode from one thread while another thread
+ * launches, gets whichever value the launch happens to read (every value selects a correct kernel - results do not
+ * depend on them beyond fp32 summation order in RoIAlign - only the speed and the LDS footprint change).  Everything
+ * else in the library is stateless apart from inr_last_error()'s thread-local message.                              */
 /* No upstream counterpart.  Which marcher inr_march_rays_train_count / _write use: -1 (default) by batch size
  * (wave per ray up to 32768 rays, lane per ray above), 0 lane per ray, 1 wave per ray.  Both produce the same
  * bits; the parity tests run both.  Process-wide.  (The library reads no environment variables.)                  */
@@ -469,6 +477,13 @@ int inr_roi_align_3d_backward(const float* grad_out, const float* rois, const in
  * Mode 3 (added with it) = separable kernels, accumulation in place (the round-4 form) - for A/B tests.             */
 int64_t inr_roi_align_3d_backward_workspace_bytes(int32_t N, int32_t C, int32_t W, int32_t L, int32_t H, int64_t K,
                                                   int32_t out_w, int32_t out_l, int32_t out_h);
+/* Which backward a caller should take (cost model, round 6): 1 = the workspace form is available AND expected to be
+ * faster - it trades fuller atomic requests (16 channels of a voxel instead of ~6 floats of a row) for three extra passes
+ * over the N*C*V volume, which pays only when the voxels inside the RoIs' regions, summed over the RoIs, exceed ~0.6 N*V.
+ * covered_voxels: that sum if known, < 0 = unknown (the lower bound K * min(bins, V) is then used: the workspace form is
+ * never picked for a call it would slow down).  Pure host arithmetic.                                                */
+int inr_roi_align_3d_backward_prefers_workspace(int32_t N, int32_t C, int32_t W, int32_t L, int32_t H, int64_t K,
+                                                int32_t out_w, int32_t out_l, int32_t out_h, int64_t covered_voxels);
 int inr_roi_align_3d_backward_ws(const float* grad_out, const float* rois, const int32_t* roi_inds, int32_t N,
                                  int32_t C, int32_t W, int32_t L, int32_t H, int64_t K, int32_t out_w,
                                  int32_t out_l, int32_t out_h, float spatial_scale, float* grad_input,

@@ -116,6 +116,8 @@ _SIGS = {
                                             c_int32, c_int32, c_float, P, P]),
     "inr_roi_align_3d_backward_workspace_bytes": (c_int64, [c_int32, c_int32, c_int32, c_int32, c_int32, c_int64, c_int32,
                                                             c_int32, c_int32]),
+    "inr_roi_align_3d_backward_prefers_workspace": (c_int32, [c_int32, c_int32, c_int32, c_int32, c_int32, c_int64, c_int32,
+                                                              c_int32, c_int32, c_int64]),
     "inr_roi_align_3d_backward_ws": (c_int32, [P, P, P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int64, c_int32,
                                                c_int32, c_int32, c_float, P, P, c_int64, P]),
     "inr_nerf_render": (c_int32, [P, P, P, P, c_int64, c_int64, c_float, P, POINTER(GridDesc), P, c_float, c_float,

@@ -39,11 +39,22 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define INR_MLP_FP32 0
 #endif
 
-// Ablation builds for profiling only (tools/build_probe.py): 1 = no table gathers (features are
-// synthesised from x), 2 = no MLP (features are summed into sigma).  The shipped library is
-// always built with INR_PROBE_MODE == 0.
-#ifndef INR_PROBE_MODE
-#define INR_PROBE_MODE 0
+// Ablation variants for profiling (no MLP, per-workgroup time stamps, static tile deal, one slow XCD) produce WRONG
+// results.  Their code lives outside the sources build.py compiles - csrc/probe/field_probe.h, which only
+// tools/build_probe.py adds (-DINR_PROBE_BUILD) - and hooks in through the INR_PROBE_* macros below, all empty here
+// (round-5 verdict item 7a: a stray -D must not be able to turn the product into a silently wrong library).
+#ifdef INR_PROBE_BUILD
+#include "probe/field_probe.h"
+#else
+#if defined(INR_PROBE_MODE) || defined(INR_PROBE_STATIC) || defined(INR_PROBE_SLOW_XCD)
+#error "INR_PROBE_* switches need -DINR_PROBE_BUILD (tools/build_probe.py): those variants produce wrong results"
+#endif
+#define INR_PROBE_PROLOGUE()
+#define INR_PROBE_SCHEDULE(steal)
+#define INR_PROBE_TILE()
+#define INR_PROBE_AFTER_GATHER()
+#define INR_PROBE_GEO_IS_OUTPUT 1
+#define INR_PROBE_EPILOGUE()
 #endif
 
 // (ns-1, BASELINE north star "LDS staging of per-level feature tiles": besides the weights and the level records,
@@ -785,9 +796,7 @@ __global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_nerf_fwd(cons
                                                                const float4* __restrict__ shq, NerfSave sv,
                                                                unsigned long long* __restrict__ steal) {
   extern __shared__ __attribute__((aligned(16))) float4 wl[];
-#if INR_PROBE_MODE == 3
-  const unsigned long long probe_t0 = wall_clock64();
-#endif
+  INR_PROBE_PROLOGUE();
   // the field kernel's waves outrank whatever shares the CU with them (FramePipeline: the next view's marchers run
   // at priority 0 and take the issue slots this kernel leaves free); alone on the chip it changes nothing
   __builtin_amdgcn_s_setprio(3);
@@ -804,9 +813,7 @@ __global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_nerf_fwd(cons
   const int64_t n_tiles = (n + 15) >> 4;
   const float rb = 2.0f * bound;
   const float rb_inv = 0.0f;
-#if INR_PROBE_STATIC            // profiling builds (tools/build_probe.py): the static deal again / XCD 3 made slower
-  steal = nullptr;
-#endif
+  INR_PROBE_SCHEDULE(steal);
   TileWalk walk;
   walk.init(make_sched(n_tiles, kWaves, steal != nullptr), steal);
 
@@ -817,9 +824,7 @@ __global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_nerf_fwd(cons
   //  dependent direction-table load wait for a fresh trip through the memory system - was measured twice, in round 1
   //  on the plain feed and in round 2 on this table feed: 0 % and -2 %; removed.)
   for (int64_t tile = walk.next(); tile >= 0; tile = walk.next()) {
-#if INR_PROBE_SLOW_XCD
-    if ((blockIdx.x & 7) == 3) __builtin_amdgcn_s_sleep(127);    // ~3 us per tile on one XCD: what does the schedule do?
-#endif
+    INR_PROBE_TILE();
     const int64_t m = tile * 16 + j;
     const bool valid = m < n;
     TileIn me;
@@ -861,15 +866,7 @@ __global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_nerf_fwd(cons
     if constexpr (!kTable) {               // the table feed comes from the marcher, which clamps to the volume
       if (me.oob) enc[0] = enc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-#if INR_PROBE_MODE == 2
-    {
-      float acc = 0.f;
-      for (int t = 0; t < 4; ++t) acc += enc[0][t] + enc[1][t];
-      acc += __shfl_xor(acc, 16); acc += __shfl_xor(acc, 32);
-      if (valid && q == 0) { sigma[m] = acc; if (rgb) { rgb[m * 3] = acc; rgb[m * 3 + 1] = me.d0; rgb[m * 3 + 2] = me.d1; } }
-      continue;
-    }
-#endif
+    INR_PROBE_AFTER_GATHER();
 
     f32x4 h1[4];
     mlp_layer<4, 2, kFast>(wl + kSig0 / 4, lane, enc, h1);
@@ -880,15 +877,13 @@ __global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_nerf_fwd(cons
 
     if (valid) {
       if (q == 0) sigma[m] = __expf(h2[0][0]) * density_scale;
-#if INR_PROBE_MODE != 3
-      if (geo) {
+      if (INR_PROBE_GEO_IS_OUTPUT && geo) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = 4 * q + r;
           if (row >= 1) geo[m * 15 + row - 1] = h2[0][r];
         }
       }
-#endif
     }
 
     if constexpr (kColor) {
@@ -943,14 +938,7 @@ __global__ void __launch_bounds__(kFieldThreads, kFieldMinWaves) k_nerf_fwd(cons
       }
     }
   }
-#if INR_PROBE_MODE == 3
-  // profiling build only (tools/build_probe.py 3): when does each workgroup run dry?  geo = uint64 [gridDim.x][2]
-  if (geo && (threadIdx.x & 63) == 0) {
-    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(geo);
-    atomicMax(&dbg[2 * blockIdx.x + 1], (unsigned long long)wall_clock64());
-    if (threadIdx.x == 0) dbg[2 * blockIdx.x] = probe_t0;
-  }
-#endif
+  INR_PROBE_EPILOGUE();
 }
 
 // ---- sliced frame path: the finest levels level by level (round 5) ---------------------------------------------------
@@ -2409,7 +2397,10 @@ int inr_nerf_pack_weights_f16(const float* sigma_w0, const float* sigma_w1, cons
   return INR_OK;
 }
 
-int64_t inr_instance_packed_floats(int32_t K) { return (K > 0 && K <= 64 && K % 16 == 0) ? kIns2 + K * 64 : -1; }
+int64_t inr_instance_packed_floats(int32_t K) {
+  INR_REQUIRE(K > 0 && K <= 64 && K % 16 == 0, "K must be 16, 32, 48 or 64");
+  return kIns2 + K * 64;
+}
 
 int inr_instance_pack_weights(const float* w0, const float* w1, const float* w2, int32_t K, float* packed) {
   INR_REQUIRE(w0 && w1 && w2 && packed, "null pointer");

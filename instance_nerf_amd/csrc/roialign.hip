@@ -251,9 +251,6 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #ifndef SEP_NT_STORE
 #define SEP_NT_STORE 1
 #endif
-#ifndef SEP_BWD_PROBE
-#define SEP_BWD_PROBE 0
-#endif
 #ifndef SEP_RUN_BARRIER
 #define SEP_RUN_BARRIER 0
 #endif
@@ -348,11 +345,7 @@ __global__ void __launch_bounds__(SEP_THREADS) k_roi_align3d_sep_fwd(const float
   uint32_t zm[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) zm[j] = (jz + j >= z0 && jz + j <= z1r) ? 0xFFFFFFFFu : 0u;
-#ifdef SEP_NO_ZMASK
-  const bool maskz = false;
-#else
   const bool maskz = tiny_z;      // only regions thinner than the window can leave it: one uniform branch per row otherwise
-#endif
 
   // ---- y role: (pl, ph), plane slot
   const int NS2 = SEP_THREADS / olh;
@@ -722,16 +715,10 @@ __global__ void __launch_bounds__(SEP_THREADS) k_roi_align3d_sep_bwd(const float
         if (moreC)
           for (int p = pfC + 4; p <= plC; ++p) fma4(a, T[2][p * H + z0 + zC], src[p - pfC]);
         float* dst = vol0 + (int64_t)c * WLH + ((x0 + xs + x) * L + (y0 + y)) * H + z0 + zC;
-#if SEP_BWD_PROBE == 1       // profiling builds only: plain stores (wrong results) - what do the atomics cost?
-        dst[0] = a.x; dst[WLH] = a.y; dst[2 * WLH] = a.z; dst[3 * WLH] = a.w;
-#elif SEP_BWD_PROBE == 2     // no global writes at all
-        if (a.x == 12345.678f) dst[0] = a.x + a.y + a.z + a.w;
-#else
         atomicAdd(dst, a.x);
         if (c + 1 < cend) atomicAdd(dst + WLH, a.y);
         if (c + 2 < cend) atomicAdd(dst + 2 * WLH, a.z);
         if (c + 3 < cend) atomicAdd(dst + 3 * WLH, a.w);
-#endif
         y += dyC; x += dxC;
         if (y >= sy) { y -= sy; ++x; }
       }
@@ -782,16 +769,10 @@ __global__ void __launch_bounds__(SEP_THREADS) k_roi_align3d_sep_bwd(const float
           a.x += w * v.x; a.y += w * v.y; a.z += w * v.z; a.w += w * v.w;
         }
         float* dst = vol0 + (int64_t)c * WLH + ((x0 + xs + x) * L + (y0 + y)) * H + cell;
-#if SEP_BWD_PROBE == 1       // profiling builds only: plain stores (wrong results) - what do the atomics cost?
-        dst[0] = a.x; dst[WLH] = a.y; dst[2 * WLH] = a.z; dst[3 * WLH] = a.w;
-#elif SEP_BWD_PROBE == 2     // no global writes at all
-        if (a.x == 12345.678f) dst[0] = a.x + a.y + a.z + a.w;
-#else
         atomicAdd(dst, a.x);
         if (c + 1 < cend) atomicAdd(dst + WLH, a.y);
         if (c + 2 < cend) atomicAdd(dst + 2 * WLH, a.z);
         if (c + 3 < cend) atomicAdd(dst + 3 * WLH, a.w);
-#endif
       }
       // t2 is rewritten by the next slab's first pass while slow waves may still read t1 here, never t2: fine; t1 is
       // rewritten after that pass's barrier
@@ -1125,6 +1106,27 @@ int64_t inr_roi_align_3d_backward_workspace_bytes(int32_t N, int32_t C, int32_t 
     return 0;
   if (sep_cl_lds_bytes(W, L, H, out_w, out_l, out_h, &tmp_floats) == 0) return 0;
   return (int64_t)N * C * V * 4;
+}
+
+// Cost model of the two backward forms (round-5 advisor: the workspace form was taken wherever it was AVAILABLE, and it
+// adds a zero fill of the scratch volume plus a transposing copy - three passes over N*C*V floats - to every call).  Both
+// forms are bound by the memory-side atomic unit (~21 G requests/s of up to 64 bytes): in place a request carries a run of
+// ~6 floats along H of one channel, the channels-fastest scratch packs 16 channels of one voxel into it.  With R = voxels
+// inside the RoIs' regions, summed over the RoIs:   in place  R*C/6 requests;   workspace  R*C/16 requests + 12*N*C*V bytes
+// at ~4 TB/s.  The workspace form wins iff R > ~0.6 * N*V (C cancels); measured both sides of it with
+// tools/roialign_shapes_probe.py (profiles/r06_roialign_bwd_shapes.txt).  covered_voxels: R if the caller knows it (the
+// Python wrapper measures it once per call shape, asynchronously), < 0 = unknown: the lower bound K * min(bins, V) is used,
+// which never picks the workspace form for a call it would slow down.
+int inr_roi_align_3d_backward_prefers_workspace(int32_t N, int32_t C, int32_t W, int32_t L, int32_t H, int64_t K,
+                                                int32_t out_w, int32_t out_l, int32_t out_h, int64_t covered_voxels) {
+  if (inr_roi_align_3d_backward_workspace_bytes(N, C, W, L, H, K, out_w, out_l, out_h) <= 0) return 0;
+  const double V = (double)W * L * H;
+  const double bins = (double)out_w * out_l * out_h;
+  const double R = covered_voxels >= 0 ? (double)covered_voxels : (double)K * (bins < V ? bins : V);
+  const double kAtomicRate = 21.0e9, kCopyRate = 4.0e12;
+  const double t_in_place = R * C / 6.0 / kAtomicRate + 4.0 * N * C * V / kCopyRate;          // + the caller's zero fill
+  const double t_workspace = R * C / 16.0 / kAtomicRate + 12.0 * N * C * V / kCopyRate;
+  return t_workspace < 0.9 * t_in_place ? 1 : 0;
 }
 
 int inr_roi_align_3d_backward_ws(const float* grad_out, const float* rois, const int32_t* roi_inds, int32_t N, int32_t C,

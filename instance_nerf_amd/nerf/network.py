@@ -471,6 +471,7 @@ class NeRFNetwork(NeRFRenderer):
         # bound >= 4 volume), the fused kernel elsewhere
         self.frame_slices = __import__("os").environ.get("INR_FRAME_SLICES", "auto")
         self._slice_probe = None
+        self.last_frame_path = "fused"         # what the last large frame ran on ("fused" | "sliced" [+ " (probing)"])
 
     # ---- packed MFMA weights (cached until a weight tensor changes) ------------------------------
     def _packed_weights(self, which):
@@ -568,45 +569,77 @@ class NeRFNetwork(NeRFRenderer):
               "nerf_forward")
         return sigma, rgb, geo
 
+    # order of the six probing frames: each path three times, in pairs AB / BA / AB, so that under a FramePipeline
+    # (views alternating between two streams) neither path is always timed on the same stream or view parity
+    _SLICE_PROBE_ORDER = (False, True, True, False, False, True)
+
     def _use_slices(self, M):
         """Which frame path this call takes (see ``frame_slices``).  "auto": frames of >= 2^21 samples on the 16-level
-        table with hashed fine levels are timed with events on their stream - two calls on each path, alternating,
-        nothing waits for them - and once all four timings have landed the faster path is kept for this network."""
+        table with hashed fine levels are timed with events on their stream, around the field launches only (the sliced
+        path's workspace is in place before the first event) - three calls on each path in the order AB BA AB, nothing
+        waits for them - and once all six timings have landed the path with the lower MEDIAN time per sample is kept
+        (3 % margin in favour of the fused kernel).  The decision is reopened when the parameters are replaced
+        (``load_state_dict``) and when an occupancy update has moved the mean sample count of a training step by more
+        than 10 % since it was taken; ``last_frame_path`` says what the last frame ran on and ``render()`` reports it."""
         mode = self.frame_slices
+        self.last_frame_path = "fused"
         if mode in (False, 0, "0", "off", "False"):
             return False
         tb = self.encoder.table
         if not (M > 0 and int(tb["num_levels"]) == 16 and bool(tb["hashed"][8:].all())):
             return False
         if mode in (True, 1, "1", "on", "True"):
+            self.last_frame_path = "sliced"
             return True
         if M < (1 << 21):                         # "auto": frames only (a batch has nothing to pipeline)
             return False
         # "auto" only ever probes where the sliced path has a chance: a finest level of 8192+ (bound >= 4 under upstream's
         # 2048 x bound rule).  Below that the fused kernel won every measurement (bound 1: 5.1 vs 6.4 ms, bound 2: 3.2 vs
-        # 3.8 ms, profiles/r05_NOTES.txt 6) and a probe would put two slower frames into somebody's loop for nothing.
+        # 3.8 ms, profiles/r05_NOTES.txt 6) and a probe would put slower frames into somebody's loop for nothing.
         if int(tb["resolutions"][-1]) < 8192:
             return False
         p = self._slice_probe
+        if p is not None and p["choice"] is not None:
+            # the scene the decision was taken on: a later occupancy update that changes the samples per step by > 10 %
+            # means other levels of locality - measure again
+            mc = int(getattr(self, "mean_count", 0) or 0)
+            if (getattr(self, "iter_density", 0) != p["iter_density"] and p["mean_count"] > 0 and mc > 0
+                    and abs(mc - p["mean_count"]) > 0.1 * p["mean_count"]):
+                p = self._slice_probe = None
         if p is None:
-            p = self._slice_probe = {"calls": 0, "pending": [], "ms": {False: [], True: []}, "choice": None}
+            p = self._slice_probe = {"calls": 0, "pending": [], "ms": {False: [], True: []}, "choice": None,
+                                     "iter_density": 0, "mean_count": 0, "decisions": getattr(self, "_slice_decisions", 0)}
         if p["choice"] is not None:
+            self.last_frame_path = "sliced" if p["choice"] else "fused"
             return p["choice"]
         for rec in list(p["pending"]):
             if rec[1].query():
                 p["ms"][rec[2]].append(rec[0].elapsed_time(rec[1]) / max(rec[3], 1))
                 p["pending"].remove(rec)
-        if len(p["ms"][False]) >= 2 and len(p["ms"][True]) >= 2:
-            p["choice"] = min(p["ms"][True]) < 0.97 * min(p["ms"][False])     # (3 % margin: the fused kernel on a tie)
+        if len(p["ms"][False]) >= 3 and len(p["ms"][True]) >= 3:
+            med = {k: sorted(v)[len(v) // 2] for k, v in p["ms"].items()}
+            p["choice"] = med[True] < 0.97 * med[False]              # (3 % margin: the fused kernel on a tie)
+            p["iter_density"] = getattr(self, "iter_density", 0)
+            p["mean_count"] = int(getattr(self, "mean_count", 0) or 0)
+            self._slice_decisions = p["decisions"] + 1
+            self.last_frame_path = "sliced" if p["choice"] else "fused"
             return p["choice"]
-        if p["calls"] >= 8:                       # timings never landed (a stream nobody synchronises): stay fused
+        if p["calls"] >= len(self._SLICE_PROBE_ORDER) + 6:   # timings never landed (a stream nobody synchronises): stay fused
             return False
-        use = bool(p["calls"] % 2)
+        use = self._SLICE_PROBE_ORDER[p["calls"] % len(self._SLICE_PROBE_ORDER)]
         p["calls"] += 1
-        e0 = torch.cuda.Event(enable_timing=True)
-        e0.record()
-        p["open"] = (e0, use, M)
+        p["armed"] = (use, M)
+        self.last_frame_path = ("sliced" if use else "fused") + " (probing)"
         return use
+
+    def _open_slice_probe(self):
+        """Called right before the field launch(es) of a probing frame: the first event of its timing."""
+        p = self._slice_probe
+        if p and p.get("armed") is not None:
+            use, M = p.pop("armed")
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            p["open"] = (e0, use, M)
 
     def _close_slice_probe(self):
         p = self._slice_probe
@@ -615,6 +648,13 @@ class NeRFNetwork(NeRFRenderer):
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
             p["pending"].append((e0, e1, use, M))
+
+    def load_state_dict(self, state_dict, *args, **kwargs):
+        """``nn.Module.load_state_dict`` + the frame-path decision of the OLD parameters is dropped (``frame_slices =
+        "auto"`` measures again on the next large frames: another scene has other levels of locality)."""
+        out = super().load_state_dict(state_dict, *args, **kwargs)
+        self._slice_probe = None
+        return out
 
     @torch.no_grad()
     def sh_table(self, rays_d):
@@ -673,6 +713,7 @@ class NeRFNetwork(NeRFRenderer):
                 # per call cost tens of milliseconds in the allocator on the first frames); consumers run in stream order
                 ws = self.__dict__["_slice_ws"] = torch.empty(int(need * 1.25), dtype=torch.float32, device=dev)
             ws.record_stream(torch.cuda.current_stream())      # FramePipeline: views on two streams share it (inside the gate)
+            self._open_slice_probe()                            # (after the workspace is in place: no allocation inside a timing)
             check(lib.inr_nerf_forward_table_sliced(ptr(x01, torch.float32, "x01"), ptr(ray_ids, torch.int32, "ray_ids"),
                                                     ptr(shq), M, float(self.bound),
                                                     ptr(self.encoder.embeddings.data, torch.float32), self.encoder.desc,
@@ -680,6 +721,7 @@ class NeRFNetwork(NeRFRenderer):
                                                     stream_ptr()), "nerf_forward_table_sliced")
             self._close_slice_probe()
             return sigma, rgb
+        self._open_slice_probe()
         check(lib.inr_nerf_forward_table(ptr(x01, torch.float32, "x01", allow_none=M == 0),
                                          ptr(ray_ids, torch.int32, "ray_ids", allow_none=M == 0), ptr(shq), M,
                                          float(self.bound), ptr(self.encoder.embeddings.data, torch.float32),

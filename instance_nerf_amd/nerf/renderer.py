@@ -324,6 +324,8 @@ class NeRFRenderer(nn.Module):
                 if with_instance:
                     results["instance"] = out[3][:, :self.num_instances].reshape(*prefix, -1)
             results["num_samples"] = counter
+            if table:
+                results["frame_path"] = getattr(self, "last_frame_path", "fused")     # "fused" | "sliced" [+ " (probing)"]
             skipped_frac = (skippable, int(xyzs.shape[0]), False)       # raw counter, marched total (host), "skippable"
         elif self.training or infer_mode == "fused_raymajor":
             if marched is not None:

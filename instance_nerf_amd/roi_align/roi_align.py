@@ -7,16 +7,50 @@ from .._lib import check, ptr, stream_ptr
 
 
 _WS = {}
+_COVER = {}
 
 
 def _workspace(device, nbytes):
-    """Grow-only scratch of the backward's workspace form, one per device and stream (the call zeroes what it uses; a
-    buffer shared between streams would race)."""
+    """Scratch of the backward's workspace form, one per device and stream (the call zeroes what it uses; a buffer shared
+    between streams would race).  Grows on demand and is given back when a call needs less than a quarter of it (round-5
+    advisor: a grow-only cache kept N*C*V*4 bytes alive per stream for the life of the process); ``release_workspace()``
+    drops everything."""
     key = (device, torch.cuda.current_stream(device).cuda_stream)
     buf = _WS.get(key)
-    if buf is None or buf.numel() < nbytes:
+    if buf is None or buf.numel() < nbytes or buf.numel() > 4 * max(nbytes, 1 << 20):
         buf = _WS[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
     return buf
+
+
+def release_workspace():
+    """Frees the cached scratch volumes of the workspace backward (and the cached RoI statistics)."""
+    _WS.clear()
+    _COVER.clear()
+
+
+def _covered_voxels(rois, shape, cfg):
+    """Voxels inside the RoIs' regions, summed over the RoIs - what decides between the two backward forms
+    (``inr_roi_align_3d_backward_prefers_workspace``).  The RoIs live on the device and a read-back per call would
+    synchronise, so the figure is measured ONCE per call shape: the first call queues the reduction and an asynchronous
+    copy to pinned host memory and answers -1 (unknown: the library then assumes the lower bound and keeps the in-place
+    form); later calls of the same shape use the value once the copy has landed.  RoI statistics of a training run are
+    stable from step to step; a shape whose RoIs change character can be re-measured with ``release_workspace()``."""
+    N, C, W, L, H = shape
+    ow, ol, oh, scale = cfg
+    key = (rois.device, N, C, W, L, H, rois.shape[0], ow, ol, oh, float(scale))
+    st = _COVER.get(key)
+    if st is None:
+        ext = ((rois[:, 3:] - rois[:, :3]).float() * float(scale) + 1.0)
+        lim = torch.tensor([W, L, H], dtype=torch.float32, device=rois.device)
+        total = torch.minimum(ext.clamp(min=1.0), lim).prod(1).sum(dtype=torch.float64).reshape(1)
+        host = torch.empty(1, dtype=torch.float64).pin_memory()
+        host.copy_(total, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        st = _COVER[key] = {"host": host, "event": ev, "value": None}
+    if st["value"] is None and st["event"].query():
+        st["value"] = int(st["host"][0])
+    return -1 if st["value"] is None else st["value"]
 
 
 class _RoIAlign3D(torch.autograd.Function):
@@ -57,7 +91,12 @@ def roi_align_3d_grad_input(grad, rois, roi_inds, shape, cfg):
     grad = grad.contiguous().float()
     # the workspace form (channels-fastest accumulation + transposing copy: fewer and fuller atomic requests) where the
     # library offers it for these extents; it OVERWRITES grad_input, so no zero fill here
+    # ... AND expects it to be faster (cost model in the library, fed with the measured RoI coverage of this call shape:
+    # the form adds three passes over the N*C*V volume, which only a large covered fraction pays for)
     need = int(lib.inr_roi_align_3d_backward_workspace_bytes(N, C, W, L, H, K, ow, ol, oh)) if K > 0 and N * C * W * L * H else 0
+    if need > 0 and not lib.inr_roi_align_3d_backward_prefers_workspace(N, C, W, L, H, K, ow, ol, oh,
+                                                                         _covered_voxels(rois, shape, cfg)):
+        need = 0
     if need > 0:
         gin = torch.empty(N, C, W, L, H, dtype=torch.float32, device=grad.device)
         ws = _workspace(grad.device, need)

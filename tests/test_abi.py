@@ -116,3 +116,18 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libinr_hip.so")
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         _lib.load()
+
+
+def test_roi_align_backward_cost_model_is_host_arithmetic():
+    """inr_roi_align_3d_backward_prefers_workspace (round 6): the workspace backward only where the voxels inside the
+    RoIs' regions exceed about half the N*V volume; with the coverage unknown the lower bound K * min(bins, V) decides."""
+    from instance_nerf_amd import _lib
+    lib = _lib.load()
+    f = lib.inr_roi_align_3d_backward_prefers_workspace
+    assert f(1, 256, 40, 40, 40, 256, 10, 10, 10, -1) == 1               # BASELINE configs[4]: 256 k bins over 64 k voxels
+    assert f(1, 256, 80, 80, 80, 64, 7, 7, 7, -1) == 0                   # a fine pyramid level, few small boxes
+    assert f(1, 256, 80, 80, 80, 64, 7, 7, 7, 64 * 343) == 0
+    assert f(1, 256, 80, 80, 80, 512, 7, 7, 7, 512 * 5000) == 1          # the same level under many large boxes
+    assert f(1, 250, 40, 40, 40, 256, 10, 10, 10, -1) == 0               # C % 16 != 0: the form does not exist
+    assert f(1, 256, 40, 40, 40, 0, 10, 10, 10, -1) == 0 and f(-1, 256, 40, 40, 40, 256, 10, 10, 10, -1) == 0
+    assert lib.inr_roi_align_3d_backward_workspace_bytes(1, 256, 80, 80, 80, 64, 7, 7, 7) > 0     # available, not preferred

@@ -1334,6 +1334,12 @@ def test_xcd_sliced_frame_path_is_bit_identical():
             c = net.render(r["rays_o"], r["rays_d"], bg_color=1, infer_mode="fused", dt_gamma=1 / 128)
             torch.cuda.synchronize()
         assert torch.equal(a["image"], c["image"]) and net._slice_probe["choice"] in (True, False)
+        # round 6: three timings per path (AB BA AB), decided on the median; the render says which path it took; new
+        # parameters reopen the decision
+        assert all(len(v) >= 3 for v in net._slice_probe["ms"].values())
+        assert c["frame_path"] == ("sliced" if net._slice_probe["choice"] else "fused")
+        net.load_state_dict(net.state_dict())
+        assert net._slice_probe is None
     small = _network(field.init_params(seed=1, table=hashgrid.level_table(), table_std=1.0, K=0), K=0).eval()
     assert small.frame_slices == "auto" and small._use_slices(1 << 24) is False and small._slice_probe is None
 

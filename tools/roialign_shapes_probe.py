@@ -63,3 +63,43 @@ for K in (64, 512):
     cells = float(((rois[:, 3:] - rois[:, :3]).clamp(max=160).prod(1)).sum())
     print(f"  {K:4d} boxes   auto {ts['auto']:8.4f} ms   lane/output {ts['lane/output']:8.4f} ms   "
           f"(voxels inside the boxes: {cells / 1e6:.1f} M = {cells * 4 / 1e6:.0f} MB read once)")
+
+# Round 6 (round-5 advisor): the BACKWARD's two forms over the same shapes - in place (mode 3: separable kernel, atomics
+# into grad_input after a zero fill) against the workspace form (channels-fastest scratch + transposing copy) - and what
+# the library's cost model picks, with the RoI coverage unknown (-1: lower bound) and known.  A pick that is more than
+# 10 % slower than the other form is flagged.
+from instance_nerf_amd._lib import ptr, stream_ptr                        # noqa: E402
+from instance_nerf_amd.roi_align.roi_align import roi_align_3d_grad_input, release_workspace  # noqa: E402
+
+print(f"\n{'volume':>18} {'boxes':>5} {'out':>4} {'rois':>6}  in place  workspace   covered/NV  pick(-1)  pick(known)   (ms, backward)")
+for C, S in ((256, 80), (256, 40), (256, 20), (64, 40)):
+    for K in (64, 512):
+        for kind, frac in (("small", 0.1), ("large", 0.4)):
+            lo = torch.rand(K, 3, device=dev, generator=gen) * 0.6 * S
+            rois = torch.cat([lo, lo + 1 + torch.rand(K, 3, device=dev, generator=gen) * frac * S], 1)
+            inds = torch.zeros(K, dtype=torch.int32, device=dev)
+            for o in (7, 10):
+                shape, cfg = (1, C, S, S, S), (o, o, o, 1.0)
+                grad = torch.randn(K, C, o, o, o, device=dev)
+                lib.inr_roi_align_3d_set_mode(3)
+                t_in = timed(lambda: roi_align_3d_grad_input(grad, rois, inds, shape, cfg), 5)
+                lib.inr_roi_align_3d_set_mode(0)
+                need = int(lib.inr_roi_align_3d_backward_workspace_bytes(1, C, S, S, S, K, o, o, o))
+                if need > 0:
+                    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+                    gin = torch.empty(1, C, S, S, S, device=dev)
+                    t_ws = timed(lambda: _lib.check(lib.inr_roi_align_3d_backward_ws(
+                        ptr(grad), ptr(rois), ptr(inds), 1, C, S, S, S, K, o, o, o, 1.0, ptr(gin), ws.data_ptr(), need, stream_ptr())), 5)
+                    del ws, gin
+                else:
+                    t_ws = float("nan")
+                ext = (rois[:, 3:] - rois[:, :3] + 1.0).clamp(min=1.0, max=float(S))
+                covered = int(ext.prod(1).sum())
+                p_unknown = lib.inr_roi_align_3d_backward_prefers_workspace(1, C, S, S, S, K, o, o, o, -1)
+                p_known = lib.inr_roi_align_3d_backward_prefers_workspace(1, C, S, S, S, K, o, o, o, covered)
+                best = min(t_in, t_ws) if t_ws == t_ws else t_in
+                took = t_ws if p_known else t_in
+                flag = "   <-- model picks the slower form" if took > 1.1 * best else ""
+                print(f"[1,{C},{S},{S},{S}]".rjust(18), f"{K:5d} {o:4d} {kind:>6}  {t_in:8.4f}   {t_ws:8.4f}   {covered / S ** 3:9.2f}"
+                      f"   {'ws' if p_unknown else 'in place':>8}   {'ws' if p_known else 'in place':>8}{flag}")
+release_workspace()
