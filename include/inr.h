@@ -90,6 +90,21 @@ int inr_set_march_mode(int32_t mode);
 int inr_get_rays(const float* poses, int64_t B, float fx, float fy, float cx, float cy, int32_t W,
                  const int64_t* inds /*[n] nullable*/, int64_t n, float* rays_o, float* rays_d, inr_stream_t s);
 
+/* One training batch of a loader whose images are resident on the device, in ONE launch (round 6; replaces the body of
+ * upstream's nerf/provider.py::NeRFDataset.collate [U] - torch.randint pixel draw, get_rays, image gather, mask gather -
+ * for the loader of the reference's two training stages, /root/reference/README.md:58-66; mask format
+ * /root/reference/Mask2Former_sample/match_seg.py:131-140).  Sample k of step `step` (0 <= step < 2^31) draws the pixel
+ *   inds[k] = ((mix64(seed + 0x9E3779B97F4A7C15 * (step * 2^32 + k)) >> 32) * (H*W)) >> 32      (SplitMix64 finaliser)
+ * of ONE H x W image (H*W < 2^31): a counter-based draw with replacement, reproducible from (seed, step) alone;
+ * rays_o / rays_d [n,3] as inr_get_rays for those pixels of `pose` [4,4] (bit-identical); rgb [n,channels] =
+ * image[inds] (image float [H*W, channels], channels 3 or 4; nullable -> not gathered); labels int64 [n] = mask[inds]
+ * (mask int32 [H*W], nullable; ids >= num_instances have no logit and become -1, -1 stays the ignore label).           */
+int inr_sample_training_batch(const float* pose /*[4,4]*/, float fx, float fy, float cx, float cy, int32_t H, int32_t W,
+                              const float* image /*nullable*/, int32_t channels, const int32_t* mask /*nullable*/,
+                              int32_t num_instances, int64_t seed, int64_t step, int64_t n, int64_t* inds /*[n]*/,
+                              float* rays_o, float* rays_d, float* rgb /*[n,channels]*/, int64_t* labels /*[n]*/,
+                              inr_stream_t s);
+
 int inr_near_far_from_aabb(const float* rays_o, const float* rays_d, const float* aabb /*[6]*/,
                            int64_t N, float min_near, float* nears, float* fars, inr_stream_t s);
 /* The same with per-ray labels (int64 [N]): a ray whose label equals `ignore_index` is reported as a miss (near = far =

@@ -31,6 +31,8 @@ _SIGS = {
     "inr_set_march_mode": (c_int32, [c_int32]),
     "inr_device_info": (c_int32, [c_int32, POINTER(c_int64)]),
     "inr_get_rays": (c_int32, [P, c_int64, c_float, c_float, c_float, c_float, c_int32, P, c_int64, P, P, P]),
+    "inr_sample_training_batch": (c_int32, [P, c_float, c_float, c_float, c_float, c_int32, c_int32, P, c_int32, P, c_int32,
+                                            c_int64, c_int64, c_int64, P, P, P, P, P, P]),
     "inr_near_far_from_aabb": (c_int32, [P, P, P, c_int64, c_float, P, P, P]),
     "inr_near_far_from_aabb_skip": (c_int32, [P, P, P, c_int64, c_float, P, c_int64, P, P, P]),
     "inr_morton3D": (c_int32, [P, c_int64, P, P]),

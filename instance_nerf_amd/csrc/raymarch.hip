@@ -76,6 +76,49 @@ __global__ void __launch_bounds__(kRayBlock) k_get_rays(const float* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------
+// The per-step work of a training loader whose images live on the device, in ONE launch (round 6; replaces the body of
+// upstream's NeRFDataset.collate [U]: torch.randint pixel draw -> get_rays -> image gather -> mask gather, eight small
+// launches per step in front of a 0.75-1.3 ms step): sample k of step `step` draws pixel
+//   pix = (mix64(seed + GOLDEN * (step * 2^32 + k)) >> 32) * (H*W) >> 32          (SplitMix64 finaliser, Lemire range)
+// of ONE H x W image, generates its ray with k_get_rays' arithmetic (bit-identical), and gathers the pixel's colour
+// (C = 3 or 4 floats) and its matched-mask label (int32 -> int64; ids >= num_instances have no logit: -1).
+// Restated bit for bit by oracle/rays.py::sample_training_batch.
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__global__ void __launch_bounds__(kRayBlock) k_sample_batch(const float* __restrict__ pose, float fx, float fy, float cx,
+                                                            float cy, int H, int W, const float* __restrict__ image,
+                                                            int C, const int32_t* __restrict__ mask, int num_instances,
+                                                            uint64_t seed, uint64_t step, int64_t n,
+                                                            int64_t* __restrict__ inds, float* __restrict__ rays_o,
+                                                            float* __restrict__ rays_d, float* __restrict__ rgb,
+                                                            int64_t* __restrict__ labels) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const uint64_t h = mix64(seed + 0x9E3779B97F4A7C15ull * ((step << 32) + (uint64_t)k));
+  const uint64_t pix = ((h >> 32) * (uint64_t)((int64_t)H * W)) >> 32;
+  inds[k] = (int64_t)pix;
+  const float i = (float)(pix % (uint64_t)W) + 0.5f, j = (float)(pix / (uint64_t)W) + 0.5f;
+  const float xs = (i - cx) / fx, ys = (j - cy) / fy;
+  const float nrm = sqrtf(xs * xs + ys * ys + 1.0f * 1.0f);
+  const float dx = xs / nrm, dy = ys / nrm, dz = 1.0f / nrm;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    rays_d[k * 3 + r] = dx * pose[r * 4 + 0] + dy * pose[r * 4 + 1] + dz * pose[r * 4 + 2];
+    rays_o[k * 3 + r] = pose[r * 4 + 3];
+  }
+  if (image) {
+    for (int c = 0; c < C; ++c) rgb[k * C + c] = image[pix * C + c];
+  }
+  if (mask) {
+    const int32_t l = mask[pix];
+    labels[k] = l >= num_instances ? -1 : (int64_t)l;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // a3: morton / packbits
 __global__ void k_morton3D(const int32_t* __restrict__ coords, int64_t N, int32_t* __restrict__ out) {
   const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1732,6 +1775,23 @@ int inr_get_rays(const float* poses, int64_t B, float fx, float fy, float cx, fl
   k_get_rays<<<blocks_for(B * n, kRayBlock), kRayBlock, 0, as_stream(s)>>>(poses, B, fx, fy, cx, cy, W, inds, n, rays_o,
                                                                            rays_d);
   return check_launch("get_rays");
+}
+
+int inr_sample_training_batch(const float* pose, float fx, float fy, float cx, float cy, int32_t H, int32_t W,
+                              const float* image, int32_t channels, const int32_t* mask, int32_t num_instances,
+                              int64_t seed, int64_t step, int64_t n, int64_t* inds, float* rays_o, float* rays_d,
+                              float* rgb, int64_t* labels, inr_stream_t s) {
+  INR_REQUIRE(n >= 0 && H > 0 && W > 0 && (int64_t)H * W < (1ll << 31), "bad sizes");
+  INR_REQUIRE(step >= 0 && step < (1ll << 31), "step out of range (0 .. 2^31 - 1)");
+  INR_REQUIRE(!image || channels == 3 || channels == 4, "channels must be 3 or 4");
+  INR_REQUIRE(!mask || num_instances > 0, "num_instances must be positive with a mask");
+  if (n == 0) return INR_OK;
+  INR_REQUIRE(pose && inds && rays_o && rays_d, "null pointer");
+  INR_REQUIRE((!image || rgb) && (!mask || labels), "null output for a given input");
+  k_sample_batch<<<blocks_for(n, kRayBlock), kRayBlock, 0, as_stream(s)>>>(pose, fx, fy, cx, cy, H, W, image, channels, mask,
+                                                                           num_instances, (uint64_t)seed, (uint64_t)step, n,
+                                                                           inds, rays_o, rays_d, rgb, labels);
+  return check_launch("sample_training_batch");
 }
 
 int inr_near_far_from_aabb(const float* rays_o, const float* rays_d, const float* aabb, int64_t N,

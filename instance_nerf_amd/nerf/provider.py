@@ -167,15 +167,49 @@ class NeRFDataset:
                 raise ValueError(f"masks are {m.shape[1:]}, images {self.H}x{self.W}")
             if m.shape[1:] != (self.H, self.W):
                 m = m[:, ::downscale, ::downscale][:, :self.H, :self.W]            # labels: nearest, never blended
-            self.masks = torch.from_numpy(np.ascontiguousarray(m)).to(dev)
+            self.masks = torch.from_numpy(np.ascontiguousarray(m).astype(np.int32, copy=False)).to(dev)
         self.rng = np.random.default_rng(seed)
+        # training batches of a device-resident dataset come from ONE launch (inr_sample_training_batch): pixel draw, rays,
+        # rgb gather, label gather.  The draw is counter-based: batch number `_draws` of this loader under `seed`.
+        self.seed, self._draws = int(seed), 0
+        self.fused_batches = True
 
     def __len__(self):
         return self.poses.shape[0]
 
+    def _fused_batch(self, index):
+        """One training batch in one launch (``inr_sample_training_batch``, include/inr.h): what the tensor-op path below
+        does in eight launches - ``torch.randint`` draw, ``get_rays``, image gather, ``labels_for_rays`` - with the pixel
+        draw made reproducible from (seed, batch number).  Same dict, same shapes and dtypes."""
+        from .. import _lib
+        lib = _lib.load()
+        n, dev = int(self.num_rays), self.device
+        C = int(self.images.shape[-1])
+        inds = torch.empty(n, dtype=torch.int64, device=dev)
+        rays_o = torch.empty(1, n, 3, dtype=torch.float32, device=dev)
+        rays_d = torch.empty(1, n, 3, dtype=torch.float32, device=dev)
+        rgb = torch.empty(1, n, C, dtype=torch.float32, device=dev)
+        labels = torch.empty(1, n, dtype=torch.int64, device=dev) if self.masks is not None else None
+        fx, fy, cx, cy = self.intrinsics
+        _lib.check(lib.inr_sample_training_batch(
+            _lib.ptr(self.poses[index], torch.float32, "pose"), float(fx), float(fy), float(cx), float(cy), int(self.H),
+            int(self.W), _lib.ptr(self.images[index], torch.float32, "image"), C,
+            _lib.ptr(self.masks[index], torch.int32, "mask") if self.masks is not None else None,
+            int(self.num_instances or (1 << 30)), self.seed, self._draws & 0x7FFFFFFF, n, _lib.ptr(inds), _lib.ptr(rays_o),
+            _lib.ptr(rays_d), _lib.ptr(rgb), _lib.ptr(labels) if labels is not None else None, _lib.stream_ptr()),
+            "sample_training_batch")
+        self._draws += 1
+        out = {"H": self.H, "W": self.W, "rays_o": rays_o, "rays_d": rays_d, "index": [index], "images": rgb}
+        if labels is not None:
+            out["masks"] = labels
+        return out
+
     def __getitem__(self, index):
         from ..masks import labels_for_rays
         index = int(index)
+        if (self.training and self.fused_batches and self.num_rays > 0 and self.device.type == "cuda" and self.images.is_cuda
+                and self.images.dtype == torch.float32 and (self.masks is None or self.masks.is_cuda)):
+            return self._fused_batch(index)
         r = get_rays(self.poses[index:index + 1], self.intrinsics, self.H, self.W, self.num_rays)
         inds = r["inds"][0]
         out = {"H": self.H, "W": self.W, "rays_o": r["rays_o"], "rays_d": r["rays_d"], "index": [index]}

@@ -76,3 +76,42 @@ def near_far_from_aabb(rays_o, rays_d, aabb, min_near=0.2):
     near = np.where(miss, FLT_MAX, near).astype(F32)
     far = np.where(miss, FLT_MAX, far).astype(F32)
     return near, far
+
+
+MASK64 = (1 << 64) - 1
+
+
+def _mix64(z):
+    """SplitMix64 finaliser on Python ints (exact 64-bit wrap-around)."""
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & MASK64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & MASK64
+    return z ^ (z >> 31)
+
+
+def sample_pixels(seed, step, n, H, W):
+    """The counter-based pixel draw of the fused loader launch (include/inr.h ``inr_sample_training_batch``; no upstream
+    counterpart - upstream draws with ``torch.randint``; any i.i.d. uniform draw with replacement is the same loader):
+    inds[k] = ((mix64(seed + GOLDEN * (step * 2^32 + k)) >> 32) * (H*W)) >> 32.  -> int64 [n]."""
+    hw = H * W
+    out = np.empty(n, dtype=np.int64)
+    for k in range(n):
+        h = _mix64((seed + 0x9E3779B97F4A7C15 * ((step << 32) + k)) & MASK64)
+        out[k] = ((h >> 32) * hw) >> 32
+    return out
+
+
+def sample_training_batch(pose, intrinsics, H, W, image, mask, num_instances, seed, step, n):
+    """Restatement of ``inr_sample_training_batch``: pixels by ``sample_pixels``, rays by ``get_rays`` (upstream
+    ``nerf/utils.py::get_rays`` [U]), rgb = image[inds], labels = mask[inds] with ids >= num_instances -> -1 (the
+    loader's view of /root/reference/Mask2Former_sample/match_seg.py:131-140 masks).  image f32 [H,W,C] or None,
+    mask int32 [H,W] or None."""
+    inds = sample_pixels(seed, step, n, H, W)
+    r = get_rays(np.asarray(pose, dtype=F32)[None], intrinsics, H, W, inds=inds)
+    out = {"inds": inds, "rays_o": r["rays_o"][0], "rays_d": r["rays_d"][0]}
+    if image is not None:
+        img = np.asarray(image, dtype=F32)
+        out["rgb"] = img.reshape(H * W, -1)[inds]
+    if mask is not None:
+        lab = np.asarray(mask).reshape(-1)[inds].astype(np.int64)
+        out["labels"] = np.where(lab >= num_instances, -1, lab)
+    return out

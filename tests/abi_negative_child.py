@@ -99,6 +99,10 @@ out["inr_adam_step_multi:n_17"] = call("inr_adam_step_multi", args_for("inr_adam
 out["inr_finish_rays_mse:N_too_large"] = call("inr_finish_rays_mse", args_for("inr_finish_rays_mse", a10=65537))
 out["inr_sh_encode_forward:degree_5"] = call("inr_sh_encode_forward", args_for("inr_sh_encode_forward", a2=5))
 out["inr_linear_wgrad:n_in_65"] = call("inr_linear_wgrad", args_for("inr_linear_wgrad", a3=65))
+out["inr_sample_training_batch:channels_5"] = call("inr_sample_training_batch", args_for("inr_sample_training_batch", a8=5))
+out["inr_sample_training_batch:negative_step"] = call("inr_sample_training_batch", args_for("inr_sample_training_batch", a12=-1))
+out["inr_sample_training_batch:image_too_large"] = call("inr_sample_training_batch", args_for(
+    "inr_sample_training_batch", a5=65536, a6=65536))
 out["inr_set_march_mode:mode_7"] = call("inr_set_march_mode", [7])
 out["inr_roi_align_3d_set_mode:mode_9"] = call("inr_roi_align_3d_set_mode", [9])
 out["inr_roi_align_3d_forward:zero_bins"] = call("inr_roi_align_3d_forward", args_for("inr_roi_align_3d_forward", a9=0))

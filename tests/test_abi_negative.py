@@ -103,6 +103,8 @@ def test_size_queries_never_report_a_size_for_bad_arguments(results):
     ("inr_nerf_forward_dirs:out_misaligned", "misaligned"),
     ("inr_copy_multi:n_9", "8"), ("inr_adam_step_multi:n_17", "16"), ("inr_finish_rays_mse:N_too_large", "N"),
     ("inr_sh_encode_forward:degree_5", "degree"), ("inr_linear_wgrad:n_in_65", "64"),
+    ("inr_sample_training_batch:channels_5", "channels"), ("inr_sample_training_batch:negative_step", "step"),
+    ("inr_sample_training_batch:image_too_large", "size"),
     ("inr_set_march_mode:mode_7", "mode"), ("inr_roi_align_3d_set_mode:mode_9", "mode"),
     ("inr_roi_align_3d_forward:zero_bins", "size"), ("inr_roi_align_3d_backward_ws:workspace_too_small", "workspace"),
     ("inr_nerf_forward_table_sliced:12_levels", "16-level"),

@@ -3143,3 +3143,77 @@ def test_pipelined_step_survives_many_occupancy_updates_and_late_captures():
     a, b = np.asarray(runs[False][0][33:], float), np.asarray(runs[True][0][33:], float)
     assert np.abs(a - b).max() < 0.02 * a.max()
     assert np.isfinite(runs[True][1]).all() and np.allclose(runs[False][1][33:], runs[True][1][33:], rtol=0.1, atol=0.02)
+
+
+# ---------------------------------------------------------------------------------------- fused loader launch (round 6)
+@pytest.mark.parametrize("channels,with_mask", [(3, True), (4, False), (3, False)])
+def test_fused_loader_launch_is_bit_exact_against_the_oracle(channels, with_mask):
+    """inr_sample_training_batch (one launch: pixel draw, rays, rgb gather, label gather) against
+    oracle/rays.py::sample_training_batch: indices, rays, colours and labels bit for bit; and its rays are exactly
+    inr_get_rays' for the pixels it drew."""
+    from instance_nerf_amd import _lib
+    from instance_nerf_amd.nerf.utils import get_rays
+    from oracle import rays as orays
+    lib = _lib.load()
+    rng = np.random.default_rng(9)
+    H, W, K, n = 37, 53, 6, 5000
+    pose = np.eye(4, dtype=np.float32)
+    pose[:3, :3] = np.linalg.qr(rng.normal(size=(3, 3)))[0].astype(np.float32)
+    pose[:3, 3] = rng.normal(size=3).astype(np.float32)
+    intr = (41.5, 40.25, 26.5, 18.5)
+    img = rng.random((H, W, channels)).astype(np.float32)
+    mask = rng.integers(-1, 10, size=(H, W)).astype(np.int32) if with_mask else None
+    for seed, step in ((0, 0), (123456789, 77), (2 ** 40 + 5, 2 ** 31 - 1)):
+        ref = orays.sample_training_batch(pose, intr, H, W, img, mask, K, seed, step, n)
+        P, I = _t(pose), _t(img)
+        Mk = _t(mask) if with_mask else None
+        inds = torch.empty(n, dtype=torch.int64, device=DEV)
+        ro, rd = torch.empty(n, 3, device=DEV), torch.empty(n, 3, device=DEV)
+        rgb = torch.empty(n, channels, device=DEV)
+        lab = torch.empty(n, dtype=torch.int64, device=DEV) if with_mask else None
+        _lib.check(lib.inr_sample_training_batch(_lib.ptr(P), *intr, H, W, _lib.ptr(I), channels,
+                                                 _lib.ptr(Mk) if with_mask else None, K, seed, step, n, _lib.ptr(inds),
+                                                 _lib.ptr(ro), _lib.ptr(rd), _lib.ptr(rgb),
+                                                 _lib.ptr(lab) if with_mask else None, _lib.stream_ptr()))
+        assert (inds.cpu().numpy() == ref["inds"]).all()
+        assert (rd.cpu().numpy() == ref["rays_d"]).all() and (ro.cpu().numpy() == ref["rays_o"]).all()
+        assert (rgb.cpu().numpy() == ref["rgb"]).all()
+        if with_mask:
+            assert (lab.cpu().numpy() == ref["labels"]).all()
+        g = get_rays(P[None], intr, H, W, inds=inds)
+        assert torch.equal(g["rays_d"][0], rd) and torch.equal(g["rays_o"][0], ro)
+    # empty batch: nothing launched, nothing touched; bad arguments come back as codes
+    assert lib.inr_sample_training_batch(None, *intr, H, W, None, 3, None, 0, 0, 0, 0, None, None, None, None, None, None) == 0
+    assert lib.inr_sample_training_batch(_lib.ptr(P), *intr, H, W, _lib.ptr(I), 5, None, 0, 0, 0, n, _lib.ptr(inds), _lib.ptr(ro),
+                                         _lib.ptr(rd), _lib.ptr(rgb), None, None) == -1
+
+
+def test_nerf_dataset_batches_come_from_the_fused_launch_and_match_the_tensor_op_loader(tmp_path, room):
+    """NeRFDataset on the GPU hands out training batches from the fused launch: same keys, shapes and dtypes as the
+    tensor-op loader, the colours and labels of the pixels it drew (checked through the batch's own rays: the ray of a
+    pixel identifies it), reproducible from the seed, and different from batch to batch."""
+    from instance_nerf_amd.nerf.provider import NeRFDataset
+    from instance_nerf_amd.nerf.utils import get_rays
+    from oracle import rays as orays
+    scene = room.write_dataset(str(tmp_path / "s"), n_views=3, H=40, W=48, num_instances=8, ignore_frac=0.2)
+    kw = dict(type="train", device=DEV, scale=1.0, num_rays=512, mask_dir=scene["mask_dir"], num_instances=8, seed=11)
+    ds = NeRFDataset(scene["path"], **kw)
+    b0, b1 = ds[1], ds[1]
+    assert set(b0) == {"H", "W", "rays_o", "rays_d", "index", "images", "masks"}
+    assert b0["rays_o"].shape == (1, 512, 3) and b0["images"].shape == (1, 512, 3) and b0["masks"].shape == (1, 512)
+    assert b0["masks"].dtype == torch.int64 and b0["images"].dtype == torch.float32 and b0["index"] == [1]
+    assert not torch.equal(b0["rays_d"], b1["rays_d"])                     # the batch counter advances
+    again = NeRFDataset(scene["path"], **kw)[1]
+    assert torch.equal(again["rays_d"], b0["rays_d"]) and torch.equal(again["masks"], b0["masks"])
+    # against the restatement, from the files' content
+    ref = orays.sample_training_batch(ds.poses[1].cpu().numpy(), ds.intrinsics, 40, 48, ds.images[1].cpu().numpy(),
+                                      ds.masks[1].cpu().numpy(), 8, 11, 0, 512)
+    assert (b0["rays_d"][0].cpu().numpy() == ref["rays_d"]).all() and (b0["images"][0].cpu().numpy() == ref["rgb"]).all()
+    assert (b0["masks"][0].cpu().numpy() == ref["labels"]).all() and (ref["labels"] == -1).any()
+    # the tensor-op loader (fused_batches = False) keeps working and has the same layout
+    ds.fused_batches = False
+    t = ds[1]
+    assert {k: (tuple(v.shape), v.dtype) for k, v in t.items() if torch.is_tensor(v)} == \
+        {k: (tuple(v.shape), v.dtype) for k, v in b0.items() if torch.is_tensor(v)}
+    g = get_rays(ds.poses[1:2], ds.intrinsics, 40, 48, inds=torch.from_numpy(ref["inds"]).to(DEV))
+    assert torch.equal(g["rays_d"], b0["rays_d"])

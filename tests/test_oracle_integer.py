@@ -182,3 +182,45 @@ def test_march_infer_concatenation_equals_train(room, room_bitfield):
         assert len(got[i]) == cnt
         if cnt:
             assert (np.stack(got[i]) == full["xyzs"][off:off + cnt]).all()
+
+
+# ---------------------------------------------------------------------------------------- fused loader draw (round 6)
+def test_loader_pixel_draw_is_a_pure_function_of_seed_step_and_index():
+    """oracle/rays.py::sample_pixels restates the counter-based draw of inr_sample_training_batch: reproducible from
+    (seed, step), in range, different for other steps and seeds, and pinned by known answers (a change of the hash or of
+    the range reduction changes which pixels every seeded training run sees)."""
+    from oracle import rays
+    a = rays.sample_pixels(7, 3, 4096, 400, 400)
+    assert a.dtype == np.int64 and a.min() >= 0 and a.max() < 160000
+    assert (a == rays.sample_pixels(7, 3, 4096, 400, 400)).all()
+    assert (a != rays.sample_pixels(7, 4, 4096, 400, 400)).mean() > 0.99
+    assert (a != rays.sample_pixels(8, 3, 4096, 400, 400)).mean() > 0.99
+    assert a[:8].tolist() == [159129, 25489, 140597, 83549, 48411, 138873, 78629, 74064]
+    # prefix property: sample k does not depend on n
+    assert (rays.sample_pixels(7, 3, 100, 400, 400) == a[:100]).all()
+    # uniform over the image: chi-square of 64 equal bins over 65536 draws (63 dof: mean 63, sd 11.2)
+    b = rays.sample_pixels(1, 0, 65536, 800, 800)
+    counts = np.bincount(b // 10000, minlength=64).astype(np.float64)
+    chi2 = ((counts - 1024.0) ** 2 / 1024.0).sum()
+    assert chi2 < 63 + 5 * 11.2, chi2
+    assert rays.sample_pixels(0, 0, 16, 1, 1).tolist() == [0] * 16
+
+
+def test_loader_batch_restatement_matches_the_tensor_op_loader():
+    """sample_training_batch = the draw + get_rays + two gathers, label rule of masks.labels_for_rays."""
+    from oracle import rays
+    rng = np.random.default_rng(3)
+    H, W, K = 12, 16, 5
+    pose = np.eye(4, dtype=np.float32)
+    pose[:3, :3] = np.linalg.qr(rng.normal(size=(3, 3)))[0]
+    pose[:3, 3] = rng.normal(size=3)
+    img = rng.random((H, W, 3)).astype(np.float32)
+    mask = rng.integers(-1, 9, size=(H, W)).astype(np.int32)
+    out = rays.sample_training_batch(pose, (20.0, 21.0, 8.0, 6.0), H, W, img, mask, K, seed=5, step=2, n=64)
+    inds = out["inds"]
+    ref = rays.get_rays(pose[None], (20.0, 21.0, 8.0, 6.0), H, W, inds=inds)
+    assert (out["rays_d"] == ref["rays_d"][0]).all() and (out["rays_o"] == ref["rays_o"][0]).all()
+    assert (out["rgb"] == img.reshape(-1, 3)[inds]).all()
+    lab = mask.reshape(-1)[inds]
+    assert (out["labels"] == np.where(lab >= K, -1, lab)).all() and out["labels"].dtype == np.int64
+    assert (out["labels"] == -1).any() and (out["labels"] >= 0).any()

@@ -20,12 +20,12 @@ HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BYTES_PER_SAMPLE = 1024         # 16 levels x 8 corners x 2 features x 4 B
 
 
-SCATTER_JSON = os.path.join("profiles", "r05_scatter_requests.json")
+SCATTER_JSON = os.path.join("profiles", "r06_scatter_requests.json")
 
 
 def scatter_requests(stage):
     """Memory-side atomic requests per sample of the table-gradient scatter and the unit's measured rate, from the
-    committed PMC profile (profiles/r05_scatter_requests.json, tools/pmc_train.sh + tools/scatter_requests_json.py);
+    committed PMC profile (profiles/r06_scatter_requests.json, tools/pmc_train.sh + tools/scatter_requests_json.py);
     quoted only for the kernel sources it was measured on.  -> (requests per sample, unit rate in requests/s) or None."""
     from instance_nerf_amd import build
     path = os.path.join(ROOT, SCATTER_JSON)
@@ -435,12 +435,12 @@ def instance_render_probe(dev, frames=8):
     return out
 
 
-BOUND_TRAFFIC_JSON = os.path.join("profiles", "r05_bound_traffic.json")
+BOUND_TRAFFIC_JSON = os.path.join("profiles", "r06_bound_traffic.json")
 
 
 def bound_traffic(bound, dt_gamma, frame_path="fused"):
     """Fabric read requests per sample of the frame path taken (fused kernel | pre-pass + kernel) at this configuration, from the committed PMC profile
-    (profiles/r05_bound_traffic.json: tools/pmc_bound.sh + tools/bound_traffic_json.py); quoted only for the kernel sources
+    (profiles/r06_bound_traffic.json: tools/pmc_bound.sh + tools/bound_traffic_json.py); quoted only for the kernel sources
     it was measured on.  -> (record of the configuration, random-line rate of the fabric in requests/s) or None."""
     from instance_nerf_amd import build
     path = os.path.join(ROOT, BOUND_TRAFFIC_JSON)

@@ -14,16 +14,18 @@ python -m pytest tests -x -q -m gpu > $O/pytest.txt 2>&1; tail -2 $O/pytest.txt
 # that the bench line of this very call carries `traffic`, `atomic_unit` and `fabric_requests` (copy them into the
 # repository's profiles/ afterwards - they describe exactly these kernel sources)
 bash tools/pmc_bench.sh ${TAG}_pmc > $O/pmc_bench.txt 2>&1
-python tools/traffic_json.py gpurun_out/${TAG}_pmc gpurun_out/${TAG}_pmc.hbm_rd.log $O/r05_traffic.json > /dev/null; echo "traffic rc=$?"
+python tools/traffic_json.py gpurun_out/${TAG}_pmc gpurun_out/${TAG}_pmc.hbm_rd.log $O/r06_traffic.json > /dev/null; echo "traffic rc=$?"
 bash tools/pmc_train.sh ${TAG}_pmct > $O/pmc_train.txt 2>&1
 NO_UPDATE=1 bash tools/pmc_train.sh ${TAG}_pmcn k_grid_bwd tools/train_nerf_probe.py > $O/pmc_train_nerf.txt 2>&1
 # samples per step of the two probes' timed steps: their last output line ("train step ... ms, N samples/step, ...")
 NI=$(grep -o "[0-9]* samples/step" gpurun_out/${TAG}_pmct.atom2.log | tail -1 | cut -d" " -f1)
 NN=$(grep -o "[0-9]* samples/step" gpurun_out/${TAG}_pmcn.atom2.log | tail -1 | cut -d" " -f1)
-python tools/scatter_requests_json.py gpurun_out/${TAG}_pmct ${NI:-209000} gpurun_out/${TAG}_pmcn ${NN:-209000} $O/r05_scatter_requests.json > /dev/null; echo "scatter json rc=$? ($NI / $NN samples per step)"
-bash tools/pmc_bound.sh ${TAG}_pmcb > $O/bound_pmc.txt 2>&1; cp gpurun_out/${TAG}_pmcb.bound_traffic.json $O/r05_bound_traffic.json
-cp $O/r05_traffic.json $O/r05_scatter_requests.json $O/r05_bound_traffic.json $R/profiles/
-python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
+python tools/scatter_requests_json.py gpurun_out/${TAG}_pmct ${NI:-209000} gpurun_out/${TAG}_pmcn ${NN:-209000} $O/r06_scatter_requests.json > /dev/null; echo "scatter json rc=$? ($NI / $NN samples per step)"
+bash tools/pmc_bound.sh ${TAG}_pmcb > $O/bound_pmc.txt 2>&1; cp gpurun_out/${TAG}_pmcb.bound_traffic.json $O/r06_bound_traffic.json
+# round 6: MFMA pipe utilisation of the field kernel and of the head-backward kernels (the `mfma` pass of the three PMC runs above)
+python tools/mfma_json.py gpurun_out/${TAG}_pmc gpurun_out/${TAG}_pmct gpurun_out/${TAG}_pmcn $O/r06_mfma.json > /dev/null; echo "mfma json rc=$?"
+cp $O/r06_traffic.json $O/r06_scatter_requests.json $O/r06_bound_traffic.json $O/r06_mfma.json $R/profiles/
+python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; cp gpurun_out/bench_full_n1.json $O/bench_full_n1.json
 export TMPDIR=/tmp
 cd /tmp
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o bench -- python3 $R/bench.py --steps 20 --warmup 3 \
@@ -63,3 +65,6 @@ python tools/extract_dirs_probe.py 2>&1 | grep -v amdgpu > $O/extract_dirs_probe
 bash tools/pmc_extract.sh ${TAG}_pmcx > $O/extract_pmc.txt 2>&1
 ./tools/micro/roialign_bench bwd > $O/roialign_bwd_sweep.txt 2>&1
 ./tools/micro/level_xcd_bench 19 > $O/level_xcd_bench.txt 2>&1
+# round 6: atomic operand types against the memory-side unit (rates + PMC: which atomics does the L2 forward?)
+./tools/micro/atomic_type_bench > $O/atomic_type_bench.txt 2>&1
+bash tools/pmc_atomic_types.sh ${TAG}_pmcat > $O/atomic_type_pmc.txt 2>&1

@@ -1,8 +1,8 @@
 """The headline kernel's launches in the kernel trace of the profiled default bench command, beside the launch times
 bench.py measured with HIP events in the same run (profiles/r0Xz_bench_timed_launches.txt).
 Sequence of fused frame-kernel launches in bench.py: W warm-up + K timed frames of the pipelined loop (the headline's
-timed region -> roofline.in_timed_region), then 4 warm-up + min(K, 60) timed frames of the one-stream loop
-(-> roofline.frac / avg_launch_ms, the kernel with the chip to itself), then the parity / probe legs.
+timed region -> roofline.frac / avg_launch_ms), then 4 warm-up + min(K, 60) timed frames of the one-stream loop
+(-> roofline.frac_kernel_alone / avg_launch_ms_alone, the kernel with the chip to itself), then the parity / probe legs.
 usage: python tools/timed_launches.py <trace dir> <bench_profiled.json> [warmup=3] [steps=20] > out.txt"""
 import csv
 import glob
@@ -38,9 +38,9 @@ if len(ms) >= b + n_one:
     timed, alone = ms[warmup:a], ms[b:b + n_one]
     rf = d["roofline"]
     print(f"pipelined loop, {steps} timed launches from the trace: mean {sum(timed) / len(timed):.4f} ms;  bench.py "
-          f"roofline.in_timed_region.avg_launch_ms of the same run (HIP events): {rf.get('in_timed_region', {}).get('avg_launch_ms')} ms")
+          f"roofline.avg_launch_ms of the same run (HIP events, the timed region = roofline.frac): {rf.get('avg_launch_ms')} ms")
     print(f"one-stream loop, {n_one} launches from the trace: mean {sum(alone) / len(alone):.4f} ms;  bench.py "
-          f"roofline.avg_launch_ms (the kernel alone, HIP events): {rf['avg_launch_ms']} ms")
+          f"roofline.avg_launch_ms_alone (the kernel alone = roofline.frac_kernel_alone, HIP events): {rf.get('avg_launch_ms_alone')} ms")
 if ms:
     print(f"mean over all {len(ms)} launches (what --stats prints): {sum(ms) / len(ms):.4f} ms")
 else:
