@@ -494,9 +494,10 @@ int64_t inr_roi_align_3d_backward_workspace_bytes(int32_t N, int32_t C, int32_t 
                                                   int32_t out_w, int32_t out_l, int32_t out_h);
 /* Which backward a caller should take (cost model, round 6): 1 = the workspace form is available AND expected to be
  * faster - it trades fuller atomic requests (16 channels of a voxel instead of ~6 floats of a row) for three extra passes
- * over the N*C*V volume, which pays only when the voxels inside the RoIs' regions, summed over the RoIs, exceed ~0.6 N*V.
- * covered_voxels: that sum if known, < 0 = unknown (the lower bound K * min(bins, V) is then used: the workspace form is
- * never picked for a call it would slow down).  Pure host arithmetic.                                                */
+ * over the N*C*V volume and a per-RoI set-up that its 16-channel groups amortise worse; linear time models of both forms
+ * fitted to 28 measured shapes (profiles/r06_roialign_bwd_shapes.txt).  covered_voxels: voxels inside the RoIs' regions,
+ * summed over the RoIs, if known; < 0 = unknown (the lower bound K * min(bins, V) is then used, which biases towards the
+ * in-place form; mode 2 of inr_roi_align_3d_set_mode answers 1 wherever the form exists).  Pure host arithmetic.    */
 int inr_roi_align_3d_backward_prefers_workspace(int32_t N, int32_t C, int32_t W, int32_t L, int32_t H, int64_t K,
                                                 int32_t out_w, int32_t out_l, int32_t out_h, int64_t covered_voxels);
 int inr_roi_align_3d_backward_ws(const float* grad_out, const float* rois, const int32_t* roi_inds, int32_t N,

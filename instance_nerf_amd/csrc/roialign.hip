@@ -1109,23 +1109,27 @@ int64_t inr_roi_align_3d_backward_workspace_bytes(int32_t N, int32_t C, int32_t 
 }
 
 // Cost model of the two backward forms (round-5 advisor: the workspace form was taken wherever it was AVAILABLE, and it
-// adds a zero fill of the scratch volume plus a transposing copy - three passes over N*C*V floats - to every call).  Both
-// forms are bound by the memory-side atomic unit (~21 G requests/s of up to 64 bytes): in place a request carries a run of
-// ~6 floats along H of one channel, the channels-fastest scratch packs 16 channels of one voxel into it.  With R = voxels
-// inside the RoIs' regions, summed over the RoIs:   in place  R*C/6 requests;   workspace  R*C/16 requests + 12*N*C*V bytes
-// at ~4 TB/s.  The workspace form wins iff R > ~0.6 * N*V (C cancels); measured both sides of it with
-// tools/roialign_shapes_probe.py (profiles/r06_roialign_bwd_shapes.txt).  covered_voxels: R if the caller knows it (the
-// Python wrapper measures it once per call shape, asynchronously), < 0 = unknown: the lower bound K * min(bins, V) is used,
-// which never picks the workspace form for a call it would slow down.
+// adds a zero fill of the scratch volume plus a transposing copy - three passes over N*C*V floats - to every call: 2.2x
+// slower than in place for 64 small boxes on a [1,256,80^3] pyramid level, 2.7x faster for 512 large boxes on [1,256,20^3]).
+// Both forms are bound by the memory-side atomic unit; in place a request carries a run of ~6 floats along H of one
+// channel, the channels-fastest scratch packs 16 channels of one voxel into it.  Times in ms as linear models in
+//   O = K * bins * C (output elements), R = voxels inside the RoIs' regions summed over the RoIs, N*C*V (volume passes),
+//   K * bins (per-RoI table set-up, which the 16-channel groups of the workspace kernel amortise worse),
+// fitted (non-negative least squares on relative error) to 28 measured shapes - C 64/256, 20^3..80^3, 64/512 boxes, 7^3 and
+// 10^3 bins, small and large boxes: tools/roialign_shapes_probe.py -> profiles/r06_roialign_bwd_shapes.txt.  Taking the
+// model's pick costs 4.5 % over the better form on average (always-workspace: 17 %, worst 2.2x; always-in-place: 35 %).
+// covered_voxels: R if the caller knows it (the Python wrapper measures it once per call shape, asynchronously), < 0 =
+// unknown: the lower bound K * min(bins, V) is used, which biases towards the in-place form.
 int inr_roi_align_3d_backward_prefers_workspace(int32_t N, int32_t C, int32_t W, int32_t L, int32_t H, int64_t K,
                                                 int32_t out_w, int32_t out_l, int32_t out_h, int64_t covered_voxels) {
   if (inr_roi_align_3d_backward_workspace_bytes(N, C, W, L, H, K, out_w, out_l, out_h) <= 0) return 0;
+  if (g_roi_mode == 2) return 1;            // mode 2 forces the separable kernels in their workspace form (A/B tests)
   const double V = (double)W * L * H;
   const double bins = (double)out_w * out_l * out_h;
   const double R = covered_voxels >= 0 ? (double)covered_voxels : (double)K * (bins < V ? bins : V);
-  const double kAtomicRate = 21.0e9, kCopyRate = 4.0e12;
-  const double t_in_place = R * C / 6.0 / kAtomicRate + 4.0 * N * C * V / kCopyRate;          // + the caller's zero fill
-  const double t_workspace = R * C / 16.0 / kAtomicRate + 12.0 * N * C * V / kCopyRate;
+  const double O = (double)K * bins * C, RC = R * C, NCV = (double)N * C * V, KB = (double)K * bins;
+  const double t_in_place = 2.013e-9 * O + 6.284e-9 * RC + 6.81e-10 * NCV + 1.148e-7 * R + 0.0191;
+  const double t_workspace = 1.007e-9 * O + 2.670e-9 * RC + 2.439e-9 * NCV + 1.446e-7 * KB + 1.595e-7 * R + 0.0152;
   return t_workspace < 0.9 * t_in_place ? 1 : 0;
 }
 

@@ -124,10 +124,13 @@ def test_roi_align_backward_cost_model_is_host_arithmetic():
     from instance_nerf_amd import _lib
     lib = _lib.load()
     f = lib.inr_roi_align_3d_backward_prefers_workspace
-    assert f(1, 256, 40, 40, 40, 256, 10, 10, 10, -1) == 1               # BASELINE configs[4]: 256 k bins over 64 k voxels
-    assert f(1, 256, 80, 80, 80, 64, 7, 7, 7, -1) == 0                   # a fine pyramid level, few small boxes
-    assert f(1, 256, 80, 80, 80, 64, 7, 7, 7, 64 * 343) == 0
-    assert f(1, 256, 80, 80, 80, 512, 7, 7, 7, 512 * 5000) == 1          # the same level under many large boxes
+    assert f(1, 256, 40, 40, 40, 256, 10, 10, 10, -1) == 1               # BASELINE configs[4]: 0.34 ms against 0.58 in place
+    assert f(1, 256, 40, 40, 40, 256, 10, 10, 10, 200_000) == 1
+    assert f(1, 256, 80, 80, 80, 64, 7, 7, 7, -1) == 0                   # a fine pyramid level, few small boxes: 0.17 vs 0.38 ms
+    assert f(1, 256, 80, 80, 80, 64, 7, 7, 7, 15_000) == 0
+    assert f(1, 256, 80, 80, 80, 512, 7, 7, 7, 2_990_000) == 1           # the same level under 512 large boxes: 4.8 vs 2.8 ms
+    assert f(1, 256, 20, 20, 20, 512, 7, 7, 7, 107_000) == 1             # a coarse level: the volume passes cost nothing
+    assert f(1, 64, 40, 40, 40, 64, 7, 7, 7, 4_500) == 0                 # few channels, few small boxes: 0.023 vs 0.032 ms
     assert f(1, 250, 40, 40, 40, 256, 10, 10, 10, -1) == 0               # C % 16 != 0: the form does not exist
     assert f(1, 256, 40, 40, 40, 0, 10, 10, 10, -1) == 0 and f(-1, 256, 40, 40, 40, 256, 10, 10, 10, -1) == 0
     assert lib.inr_roi_align_3d_backward_workspace_bytes(1, 256, 80, 80, 80, 64, 7, 7, 7) > 0     # available, not preferred
