@@ -53,7 +53,7 @@ def measured_mfma_busy():
     if not os.path.exists(path):
         return None
     t = json.load(open(path))
-    return t if t.get("source_sha") == build.source_sha() else None
+    return t if t.get("source_sha") == build.source_sha("field") else None
 
 
 def measured_traffic_bytes_per_sample(res):
@@ -67,7 +67,7 @@ def measured_traffic_bytes_per_sample(res):
     if res != 800 or not os.path.exists(path):
         return None
     t = json.load(open(path))
-    if t.get("source_sha") != build.source_sha():
+    if t.get("source_sha") != build.source_sha("field"):
         return None
     return float(t["read_bytes_per_sample"]) + float(t["write_bytes_per_sample"])
 

@@ -69,7 +69,9 @@ int inr_device_info(int32_t device, int64_t* props);
  * the field kernel of view i on another (NeRFRenderer.run_cuda(shade_stream=...)): on != 0 makes the eval field
  * launch (inr_nerf_forward_table) and the march launches (inr_march_rays_train_count, inr_march_rays_patch_write)
  * request extra LDS per workgroup, which is how a launch tells the dispatcher to keep one field workgroup and a
- * bounded number of march workgroups per CU.  Results do not change; process-wide; off by default.                */
+ * bounded number of march workgroups per CU.  Results do not change; process-wide; off by default.  on >= 1024: the
+ * field workgroup's request in BYTES instead of the default 84 KB (not clamped: a request no CU can satisfy makes the
+ * next field launch return INR_ELAUNCH); negative values and 2..1023 are INR_EINVAL.                               */
 int inr_set_overlap_placement(int32_t on);
 /* THREADING / MULTI-DEVICE NOTE for the three mode switches of this header - inr_set_overlap_placement,
  * inr_set_march_mode, inr_roi_align_3d_set_mode: each writes one plain process-global variable that every later launch

@@ -18,12 +18,22 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function"]
 
 
-def source_sha():
-    """sha256 over the kernel sources and headers the library is built from: profiles that describe a particular
-    build of the kernels (profiles/r0x_traffic.json) carry it, and bench.py only quotes them for the same sources."""
+# which files define which measured kernels: a committed profile belongs to these files only (an edit of the RoIAlign or the
+# marchers, or of a comment in include/inr.h, does not make a measurement of the field kernel stale)
+KERNEL_FILES = {
+    "field": ["field_fused.hip", "common.h", "grid_common.h"],        # k_nerf_fwd, k_instance_fwd, k_*_head_bwd, k_nerf_fwd_dirs
+    "scatter": ["encoders.hip", "common.h", "grid_common.h"],         # k_grid_bwd, k_adam_*
+}
+
+
+def source_sha(kind=None):
+    """sha256 over the kernel sources and headers the library is built from - `kind` None: all of them; "field" /
+    "scatter": the files that define that group of kernels (KERNEL_FILES).  Profiles that describe a particular build of
+    a kernel (profiles/r0x_traffic.json, _mfma, _bound_traffic: "field"; _scatter_requests: "scatter") carry the sha of
+    their group, and bench.py only quotes them while it matches."""
     import hashlib
     h = hashlib.sha256()
-    for f in sorted(SOURCES + HEADERS):
+    for f in sorted(KERNEL_FILES[kind] if kind else SOURCES + HEADERS):
         h.update(f.encode())
         h.update(open(os.path.join(CSRC, f), "rb").read())
     return h.hexdigest()

@@ -1748,7 +1748,13 @@ int inr_set_overlap_placement(int32_t on) {
   // workgroup asks for > 80 KB (so two never share a CU, also not while the next view's march holds registers on some
   // CUs and the dispatcher looks for room elsewhere), a march workgroup for 48 KB on top of its own, which bounds the
   // marchers that can sit beside a field workgroup.  Measured in profiles/r02_NOTES.txt section 18.
-  inr::g_field_lds_min = on ? 84 * 1024 : 0;
+  // on >= 1024: the field workgroup's LDS request in BYTES instead of the 84 KB default (a tuning knob: 54..80 KB lets two
+  // field workgroups share a CU again).  The value is NOT clamped: a request beyond what a CU has makes the next field
+  // launch fail, which comes back from that call as INR_ELAUNCH with the runtime's message - never an abort
+  // (tests/test_gpu_parity.py::test_launch_failure_is_a_return_code).
+  INR_REQUIRE(on >= 0, "on must be 0 (off), 1 (on) or an LDS byte count >= 1024");
+  INR_REQUIRE(on <= 1 || on >= 1024, "on must be 0 (off), 1 (on) or an LDS byte count >= 1024");
+  inr::g_field_lds_min = on >= 1024 ? on : on ? 84 * 1024 : 0;
   inr::g_march_lds_pad = on ? 48 * 1024 : 0;
   return INR_OK;
 }

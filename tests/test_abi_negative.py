@@ -21,7 +21,7 @@ SIZE_QUERIES = {"inr_occ_sample_workspace_bytes", "inr_march_workspace_bytes", "
                 "inr_nerf_forward_table_sliced_workspace_bytes", "inr_nerf_packed_floats", "inr_instance_packed_floats",
                 "inr_roi_align_3d_backward_workspace_bytes", "inr_linear_wgrad_workspace_bytes",
                 "inr_march_write_fills_unowned_rows", "inr_roi_align_3d_backward_prefers_workspace"}
-NO_BAD_VALUE = {"inr_set_overlap_placement"}            # any int32 is a valid on/off switch
+NO_BAD_VALUE = set()
 
 
 @pytest.fixture(scope="module")

@@ -3217,3 +3217,53 @@ def test_nerf_dataset_batches_come_from_the_fused_launch_and_match_the_tensor_op
         {k: (tuple(v.shape), v.dtype) for k, v in b0.items() if torch.is_tensor(v)}
     g = get_rays(ds.poses[1:2], ds.intrinsics, 40, 48, inds=torch.from_numpy(ref["inds"]).to(DEV))
     assert torch.equal(g["rays_d"], b0["rays_d"])
+
+
+def test_launch_failure_is_a_return_code():
+    """"returns a negative code, never exit()" (the habit avoided:
+    /root/reference/nerf_rcnn/model/rotated_iou/cuda_op/cuda_utils.h:26-35 exit()s on a CUDA error).  A launch the
+    runtime refuses - the field kernel asked for 1 MiB of LDS per workgroup through inr_set_overlap_placement, a CU has
+    160 KB - comes back from THAT call as INR_ELAUNCH with the runtime's message; the process lives, the switch can be
+    reset, and the next frame renders the same pixels as before.  In a child process: a broken library must fail this
+    test, not end the session."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, torch
+sys.path.insert(0, %r)
+from instance_nerf_amd import _lib
+from instance_nerf_amd.nerf import NeRFNetwork
+from instance_nerf_amd.nerf.utils import get_rays
+from instance_nerf_amd.scene import RoomScene
+lib = _lib.load()
+dev = "cuda:0"
+torch.manual_seed(0)
+room = RoomScene()
+net = NeRFNetwork(cuda_ray=True, bound=1, min_near=0.05, density_thresh=10).to(dev).eval()
+net.density_bitfield.copy_(torch.from_numpy(room.density_bitfield(128, 1.0)).to(dev))
+with torch.no_grad():
+    net.encoder.embeddings.uniform_(-1.0, 1.0)
+poses, intr, H, W = room.cameras(H=64, W=64, focal=32.0)
+r = get_rays(torch.from_numpy(poses[:1]).to(dev), intr, H, W, patch=4)
+render = lambda: net.render(r["rays_o"], r["rays_d"], bg_color=1, infer_mode="fused")["image"]
+with torch.no_grad():
+    ref = render().clone()
+    assert lib.inr_set_overlap_placement(-5) == -1 and lib.inr_set_overlap_placement(7) == -1
+    assert lib.inr_set_overlap_placement(1 << 20) == 0
+    try:
+        render()
+        raise SystemExit("the over-sized launch was accepted")
+    except RuntimeError as e:
+        msg = str(e)
+    assert "code -2" in msg and "nerf_forward_table" in msg, msg            # INR_ELAUNCH + the runtime's text
+    assert lib.inr_set_overlap_placement(0) == 0
+    torch.cuda.synchronize()
+    again = render()
+    assert torch.equal(again, ref)
+    assert lib.inr_set_overlap_placement(64 * 1024) == 0                    # a legal explicit size: same pixels
+    assert torch.equal(render(), ref)
+    lib.inr_set_overlap_placement(0)
+print("alive")
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and "alive" in res.stdout, (res.returncode, res.stdout[-500:], res.stderr[-1500:])

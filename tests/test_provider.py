@@ -90,3 +90,26 @@ def test_nerf_dataset_errors(tmp_path):
     os.remove(tmp_path / "masks" / "0001.npy")
     with pytest.raises(FileNotFoundError):
         NeRFDataset(str(tmp_path), type="train", mask_dir=str(tmp_path / "masks"))
+
+
+def test_room_written_to_disk_reads_back_through_the_loader(tmp_path):
+    """RoomScene.write_dataset (what bench.py and the GPU tests train from) -> NeRFDataset: the poses survive the
+    Blender-convention round trip exactly, pixels are the analytic colours to 8 bits, labels are the instance ids modulo
+    the class count with the requested fraction set to -1 (the matched-mask layout of match_seg.py:131-140)."""
+    from instance_nerf_amd.nerf.provider import NeRFDataset
+    from instance_nerf_amd.scene import RoomScene
+    room = RoomScene()
+    sc = room.write_dataset(str(tmp_path / "room"), n_views=3, H=24, W=32, num_instances=8, ignore_frac=0.25)
+    assert sorted(os.listdir(tmp_path / "room")) == ["images", "matched", "transforms_train.json"]
+    ds = NeRFDataset(sc["path"], type="train", device="cpu", scale=1.0, num_rays=256, mask_dir=sc["mask_dir"], num_instances=8)
+    assert len(ds) == 3 and (ds.H, ds.W) == (24, 32) and ds.intrinsics == (16.0, 16.0, 16.0, 12.0)
+    assert np.abs(ds.poses.numpy() - sc["poses"]).max() == 0.0
+    b = ds[2]
+    rgb, ids, _ = room.trace(b["rays_o"][0].numpy(), b["rays_d"][0].numpy())
+    assert np.abs(rgb - b["images"][0].numpy()).max() <= 0.5 / 255 + 1e-6
+    lab = b["masks"][0].numpy()
+    keep = lab >= 0
+    assert (lab[keep] == (ids % 8)[keep]).all() and 0.1 < 1 - keep.mean() < 0.4
+    m = np.load(os.path.join(sc["mask_dir"], "0001.npy"))
+    assert m.dtype == np.int32 and m.shape == (24, 32) and m.min() == -1 and m.max() < 8
+    assert ((m == -1) | (m == sc["ids"][1] % 8)).all()

@@ -32,7 +32,7 @@ def scatter_requests(stage):
     if not os.path.exists(path):
         return None
     t = json.load(open(path))
-    if t.get("source_sha") != build.source_sha():
+    if t.get("source_sha") != build.source_sha("scatter"):
         return None
     return float(t["instance_stage" if stage == "instance" else "nerf_stage"]["requests_per_sample"]), float(t["unit_rate_requests_per_s"])
 
@@ -447,7 +447,7 @@ def bound_traffic(bound, dt_gamma, frame_path="fused"):
     if not os.path.exists(path):
         return None
     t = json.load(open(path))
-    if t.get("source_sha") != build.source_sha():
+    if t.get("source_sha") != build.source_sha("field"):
         return None
     key = f"{bound}:{bound}:{int(round(1 / dt_gamma)) if dt_gamma else 0}:0:0" + ("-sliced" if frame_path == "sliced" else "")
     rec = t["configs"].get(key)

@@ -44,7 +44,7 @@ for sub in sorted(glob.glob(os.path.join(d, "*_*_*_*_*"))):
                 "l2_hit_rate": round(mean["TCC_HIT_sum"] / (mean["TCC_HIT_sum"] + mean["TCC_MISS_sum"]), 4),
                 "fabric_read_requests_per_sample": round(mean["TCC_EA0_RDREQ_sum"] / M, 3),
                 "fabric_read_bytes_per_sample": round(mean["TCC_EA0_RDREQ_sum"] * 128 / M, 1)}
-json.dump({"kernel": "k_nerf_fwd<true,true> (fused) | k_grid_fine_slices + k_nerf_fwd<.., kPre> (sliced)", "source_sha": build.source_sha(),
+json.dump({"kernel": "k_nerf_fwd<true,true> (fused) | k_grid_fine_slices + k_nerf_fwd<.., kPre> (sliced)", "source_sha": build.source_sha("field"),
            "source": f"{d} (rocprofv3 --pmc, separate passes, tools/pmc_bound.sh; one 800x800 view per configuration)",
            "fabric_request_bytes": 128,
            "random_line_rate_of_the_fabric_g_per_s": 69.0,

@@ -48,7 +48,7 @@ def kernel_busy(d, sub, last=None):
 
 
 d_bench, d_inst, d_nerf, out = sys.argv[1:5]
-rec = {"source_sha": build.source_sha(),
+rec = {"source_sha": build.source_sha("field"),
        "formula": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE per XCD x 256 CUs x 4 SIMDs); BUSY counts cycles per SIMD",
        "source": f"{d_bench}, {d_inst}, {d_nerf} (rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES ..., tools/pmc_bench.sh / pmc_train.sh)"}
 rec["k_nerf_fwd"] = kernel_busy(d_bench, "k_nerf_fwd")

@@ -9,7 +9,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
-python -m pytest tests -x -q -m gpu > $O/pytest.txt 2>&1; tail -2 $O/pytest.txt
+if [ "${SKIP_PYTEST:-0}" != "1" ]; then python -m pytest tests -x -q -m gpu > $O/pytest.txt 2>&1; tail -2 $O/pytest.txt; fi
 # the PMC passes first: the three sha-keyed json files are installed under profiles/ ON THE BOX before the bench runs, so
 # that the bench line of this very call carries `traffic`, `atomic_unit` and `fabric_requests` (copy them into the
 # repository's profiles/ afterwards - they describe exactly these kernel sources)
@@ -68,3 +68,18 @@ bash tools/pmc_extract.sh ${TAG}_pmcx > $O/extract_pmc.txt 2>&1
 # round 6: atomic operand types against the memory-side unit (rates + PMC: which atomics does the L2 forward?)
 ./tools/micro/atomic_type_bench > $O/atomic_type_bench.txt 2>&1
 bash tools/pmc_atomic_types.sh ${TAG}_pmcat > $O/atomic_type_pmc.txt 2>&1
+# what travels back is capped at 64 MiB: keep the summaries, drop the raw traces and counter dumps
+for t in trace trace_inst trace_nerf; do
+  for f in $(find $O/$t -name "*kernel_stats.csv" 2>/dev/null); do cp $f $O/${t}_kernel_stats.csv; done
+done
+python tools/pmc_summary.py gpurun_out/${TAG}_pmc k_nerf_fwd > $O/bench_pmc_summary.txt 2>&1
+python tools/pmc_summary.py gpurun_out/${TAG}_pmct k_grid_bwd > $O/grid_bwd_pmc_summary.txt 2>&1
+python tools/pmc_summary.py gpurun_out/${TAG}_pmcn k_grid_bwd > $O/grid_bwd_pmc_nerf_summary.txt 2>&1
+python tools/pmc_summary.py gpurun_out/${TAG}_pmct head_bwd > $O/head_bwd_pmc_summary.txt 2>&1
+python tools/pmc_summary.py gpurun_out/${TAG}_pmcn head_bwd > $O/head_bwd_pmc_nerf_summary.txt 2>&1
+rm -rf $O/trace $O/trace_inst $O/trace_nerf $O/trace_eager $O/trace_pipe $O/trace_pipe_shade
+for d in gpurun_out/${TAG}_pmc gpurun_out/${TAG}_pmct gpurun_out/${TAG}_pmcn gpurun_out/${TAG}_pmcb gpurun_out/${TAG}_pmcr gpurun_out/${TAG}_pmcx gpurun_out/${TAG}_pmcat; do
+  rm -rf $d
+done
+find gpurun_out -size +4M -delete
+du -sm gpurun_out

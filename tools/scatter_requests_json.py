@@ -20,7 +20,7 @@ def per_dispatch(d):
 
 d_i, n_i, d_n, n_n, out = sys.argv[1], float(sys.argv[2]), sys.argv[3], float(sys.argv[4]), sys.argv[5]
 r_i, r_n = per_dispatch(d_i), per_dispatch(d_n)
-json.dump({"kernel": "k_grid_bwd", "source_sha": build.source_sha(),
+json.dump({"kernel": "k_grid_bwd", "source_sha": build.source_sha("scatter"),
            "counter": "TCP_TCC_ATOMIC_WITHOUT_RET_REQ (== TCC_EA0_WRREQ_ATOMIC_DRAM: every request goes to the memory side)",
            "instance_stage": {"requests_per_step": round(r_i), "samples_per_step": n_i, "requests_per_sample": round(r_i / n_i, 2)},
            "nerf_stage": {"requests_per_step": round(r_n), "samples_per_step": n_n, "requests_per_sample": round(r_n / n_n, 2)},
