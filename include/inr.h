@@ -301,6 +301,40 @@ int inr_grid_encode_backward_levels(const float* x, const float* grad_out, const
                                     const inr_grid_desc* desc, int64_t M, float bound, float* grad_embeddings,
                                     int32_t level_lo, int32_t level_hi, inr_stream_t s);
 
+/* Fixed-point form of the table-gradient scatter (round 6; no upstream counterpart: upstream's grid_encode_backward uses
+ * fp32 atomicAdd).  Why: on MI355X every atomic is executed by the memory-side unit, which takes int32 adds at 26.9 G
+ * requests/s against 21.0 for fp32 (tools/micro/atomic_type_bench.hip) - the scatter is the largest kernel of a
+ * training step - and integer sums do not depend on the order of arrival: the gradient becomes bit-reproducible.
+ * fx_state: INR_GRID_FX_STATE_FLOATS device floats per table, zero-initialised by the caller once, then owned by these
+ * three calls: [0,16) the scale of each level for the current step (a power of two; 0 = this level uses fp32 atomics),
+ * [16,32) reference magnitudes, [32,48) the last step's largest |row gradient| per level, [48] fixed-point steps so far,
+ * [49] near misses so far, the rest scratch.  A non-finite contribution to a fixed-point level (it has no int32
+ * image) turns that level's WHOLE gradient into NaN in the finishing pass - as loud as the NaN rows fp32 atomics leave.
+ * Per training step, on one stream:
+ *   inr_grid_encode_backward_levels_fx   scatter of a level range; a level with a scale accumulates round(w g scale) as
+ *                                        int32 bit patterns in grad_embeddings (zeroed by the caller), others fp32;
+ *                                        fx_state NULL = inr_grid_encode_backward_levels
+ *   inr_grid_grad_finish_fx              in place: int32 sums -> fp32 gradients (exact: the scale is a power of two) and
+ *                                        the level's largest |gradient|; afterwards grad_embeddings is an ordinary fp32
+ *                                        gradient (call it for every level range that was scattered, fp32 levels too)
+ *   inr_grid_fx_update                   once per step after all ranges: next step's scales = 2^floor(log2(2^30 /
+ *                                        (headroom x reference))), reference = max(this step's max, 0.75 reference).
+ * A level runs on fp32 atomics only while it has no reference: before its first step (the Python host primes the scales
+ * with one extra scatter into a scratch buffer, so that no training step ever depends on the order of arrival) and
+ * after an all-zero or non-finite gradient.  A near miss (a step that used more than 2^28 of the int32 range: 16x
+ * growth against the reference) is counted; a row's FINAL sum that grows more than `headroom` times (64 in the product)
+ * against the reference would wrap (intermediate overflow is harmless: int32 addition is modular).  Quantisation: a row
+ * gradient is a multiple of headroom x reference x 2^-30 (6e-8 of the level's recent largest at 64).
+ * Converged quality equals the fp32 path's within its own run-to-run spread (tools/fixed_point_emulation_probe.py).   */
+#define INR_GRID_FX_STATE_FLOATS 4176
+int inr_grid_encode_backward_levels_fx(const float* x, const float* grad_out, const int32_t* order,
+                                       const inr_grid_desc* desc, int64_t M, float bound, float* grad_embeddings,
+                                       int32_t level_lo, int32_t level_hi, float* fx_state /*nullable*/,
+                                       inr_stream_t s);
+int inr_grid_grad_finish_fx(float* grad_embeddings, const inr_grid_desc* desc /*host*/, int32_t level_lo,
+                            int32_t level_hi, float* fx_state, inr_stream_t s);
+int inr_grid_fx_update(float* fx_state, int32_t num_levels, float headroom, inr_stream_t s);
+
 /* ---- SH (replaces shencoder sh_encode_forward / _backward, a10) ------------------------ */
 int inr_sh_encode_forward(const float* d /*[M,3]*/, int64_t M, int32_t degree, float* out, inr_stream_t s);
 int inr_sh_encode_backward(const float* grad_out, const float* d, int64_t M, int32_t degree,

@@ -15,6 +15,7 @@ import torch  # noqa: F401  (must precede CDLL: shares the HIP runtime)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("INR_LIB_PATH") or os.path.join(_HERE, "csrc", "libinr_hip.so")   # env override: profiling builds only
 MAX_LEVELS = 16
+GRID_FX_STATE_FLOATS = 4176      # include/inr.h INR_GRID_FX_STATE_FLOATS
 
 
 class GridDesc(Structure):
@@ -99,6 +100,9 @@ _SIGS = {
     "inr_grid_encode_backward_ordered": (c_int32, [P, P, P, POINTER(GridDesc), c_int64, c_float, P, P]),
     "inr_grid_encode_backward_input": (c_int32, [P, P, P, POINTER(GridDesc), c_int64, c_float, P, P]),
     "inr_grid_encode_backward_levels": (c_int32, [P, P, P, POINTER(GridDesc), c_int64, c_float, P, c_int32, c_int32, P]),
+    "inr_grid_encode_backward_levels_fx": (c_int32, [P, P, P, POINTER(GridDesc), c_int64, c_float, P, c_int32, c_int32, P, P]),
+    "inr_grid_grad_finish_fx": (c_int32, [P, POINTER(GridDesc), c_int32, c_int32, P, P]),
+    "inr_grid_fx_update": (c_int32, [P, c_int32, c_float, P]),
     "inr_sh_encode_forward": (c_int32, [P, c_int64, c_int32, P, P]),
     "inr_sh_encode_backward": (c_int32, [P, P, c_int64, c_int32, P, P]),
     "inr_nerf_packed_floats": (c_int64, []),

@@ -54,7 +54,20 @@ __global__ void __launch_bounds__(256) k_grid_fwd(const float* __restrict__ x, c
 // instructions each touching its own line.  Equal addresses of consecutive samples (same cell) are
 // first summed inside the wave (segmented scan over lanes 4 apart); only the last lane of a run issues
 // the atomic.
-__device__ __forceinline__ void run_reduce_atomic4(float* __restrict__ gemb, uint32_t addr, bool valid, float v) {
+constexpr int kFxBlocks = 256;      // workgroups per level of the finishing pass
+constexpr int kFxFlags = 64;        // state layout: [64, 80) non-finite flags, [80 + 256 l + b] block maxima
+constexpr int kFxBase = 80;
+
+// Fixed-point form (round 6, `scale` > 0): the run's sum is rounded to a multiple of 1 / scale and added as an INT32
+// (global_atomic_add instead of global_atomic_add_f32).  Every atomic type is forwarded to the memory-side unit, but
+// the unit takes integer adds at 26.9 G requests/s against 21.0 for fp32 (16-byte requests into a 49 MB table:
+// tools/micro/atomic_type_bench.hip, profiles/r06_atomic_type_bench.txt) - and integer addition is associative, so the
+// table gradient no longer depends on the order in which the waves' requests arrive: training steps become
+// bit-reproducible.  scale == 0: the fp32 atomics of rounds 1-5.
+// A non-finite run sum cannot be represented (float -> int saturates, NaN becomes 0): it raises the level's flag instead
+// and the finishing pass turns the WHOLE level's gradient into NaN - as loud as the NaN rows fp32 atomics would leave.
+__device__ __forceinline__ void run_reduce_atomic4(float* __restrict__ gemb, uint32_t addr, bool valid, float v, float scale,
+                                                   float* __restrict__ bad_flag) {
   const int lane = threadIdx.x & 63;
   const uint32_t key = valid ? addr : 0xFFFFFFFFu - (uint32_t)lane;     // invalid lanes never join a run
   const uint32_t prev = __shfl_up(key, 4, 64);
@@ -70,13 +83,19 @@ __device__ __forceinline__ void run_reduce_atomic4(float* __restrict__ gemb, uin
     }
   }
   const bool tail = (lane >= 60) || (next != key);
-  if (valid && tail && v != 0.0f) atomicAdd(gemb + addr, v);
+  if (scale > 0.0f) {
+    const int q = __float2int_rn(v * scale);
+    if (valid && tail && q != 0) atomicAdd(reinterpret_cast<int*>(gemb) + addr, q);
+    if (valid && tail && !(fabsf(v) <= 3.402823466e+38f)) *bad_flag = 1.0f;      // (idempotent plain store)
+  } else if (valid && tail && v != 0.0f) {
+    atomicAdd(gemb + addr, v);
+  }
 }
 
 // `order` (nullable): a permutation of the samples; sample slot m processes sample order[m].
 __global__ void __launch_bounds__(256) k_grid_bwd(const float* __restrict__ x, const float* __restrict__ gout,
                                                   const int32_t* __restrict__ order, GridDesc G, int64_t M, float bound,
-                                                  float* __restrict__ gemb, int level0) {
+                                                  float* __restrict__ gemb, int level0, float* __restrict__ fx) {
   // blockIdx.x = level (the FAST axis of the dispatch order), blockIdx.y = block of 64 samples: at any moment all
   // levels of a window of samples are in flight.  With the level on the slow axis (rounds 1-2) the coarse levels ran
   // alone at the start of the launch, and they are not throughput- but LATENCY-bound: all samples hit the same few
@@ -103,13 +122,88 @@ __global__ void __launch_bounds__(256) k_grid_bwd(const float* __restrict__ x, c
   locate(G, l, x0, x1, x2, c);
   const float g = valid ? gout[(mc * L + l) * 2 + f] : 0.f;
   const uint32_t base = G.offsets[l];
+  const float fx_scale = fx ? fx[l] : 0.0f;         // uniform per workgroup: this level's fixed-point scale (0 = fp32 atomics)
 #pragma unroll
   for (int yz = 0; yz < 4; ++yz) {
     const int k = xb | (yz << 1);                   // corner: bit 0 = x side, bits 1,2 = y, z sides
     const float w = corner_weight(c, k);
     const uint32_t row = base + corner_index(G, l, c, k);
-    run_reduce_atomic4(gemb, 2u * row + (uint32_t)f, valid, w * g);
+    run_reduce_atomic4(gemb, 2u * row + (uint32_t)f, valid, w * g, fx_scale, fx + kFxFlags + l);
   }
+}
+
+// ---- fixed-point table gradient: state, finishing pass, scale update ----------------------------------------------
+// State (device floats, INR_GRID_FX_STATE_FLOATS): [0,16) scale of each level for THIS step (a power of two; 0 = the level
+// is scattered with fp32 atomics), [16,32) reference magnitude (a slowly decaying maximum of the level's largest |row
+// gradient|), [32,48) this step's maximum, [48] steps with at least one fixed-point level, [49] near misses,
+// [64,80) "a non-finite contribution was seen" per level, [80 + 256 l + b] maximum seen by workgroup b of the finishing
+// pass of level l.
+
+// In place over the rows of levels [level0, level0 + gridDim.y): int32 sums -> fp32 gradients (levels with a scale), and
+// the level's largest |gradient| into the workgroup's slot (all levels: the fp32 levels need it to get a scale).
+__global__ void __launch_bounds__(256) k_grid_grad_finish(float* __restrict__ gemb, GridDesc G, int level0, float* __restrict__ fx) {
+  __shared__ float red[4];
+  const int l = level0 + blockIdx.y;
+  const float scale = fx[l];
+  const bool poisoned = fx[kFxFlags + l] != 0.0f;                 // a non-finite contribution in a fixed-point level
+  const float inv = scale > 0.0f ? 1.0f / scale : 0.0f;          // scale is a power of two: exact
+  const size_t lo = (size_t)G.offsets[l] * 2, hi = (size_t)G.offsets[l + 1] * 2;       // floats; multiples of 16
+  float4* p = reinterpret_cast<float4*>(gemb + lo);
+  const size_t n4 = (hi - lo) >> 2;
+  float mx = 0.0f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    float4 v = p[i];
+    if (scale > 0.0f) {
+      v.x = (float)__float_as_int(v.x) * inv; v.y = (float)__float_as_int(v.y) * inv;
+      v.z = (float)__float_as_int(v.z) * inv; v.w = (float)__float_as_int(v.w) * inv;
+      if (poisoned) v.x = v.y = v.z = v.w = __int_as_float(0x7FC00000);
+      p[i] = v;
+    }
+    // NaN / Inf gradients must reach the update as "not finite": fmaxf would drop a NaN
+    const float a = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+    const bool bad = !(v.x == v.x) || !(v.y == v.y) || !(v.z == v.z) || !(v.w == v.w);
+    mx = bad ? __int_as_float(0x7F800000) : fmaxf(mx, a);
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) fx[kFxBase + kFxBlocks * l + blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+// One workgroup, one wave per level: this step's maximum -> the level's scale for the NEXT step.
+//   ref   = max(this step's max, 0.75 ref)                      (small steps shrink the headroom slowly: 64x takes 15 of them)
+//   scale = 2^floor(log2(2^30 / (headroom * ref)))              (so that headroom x the reference still fits in 31 bits)
+// A level runs on fp32 atomics only while it has no reference (before the first step - the host primes it - and after an
+// all-zero or non-finite gradient).  A NEAR MISS - a step whose maximum used more than 2^28 of the 2^31 range, i.e. grew
+// 16x against the reference (64x would have wrapped) - is counted and needs nothing else: the new maximum becomes the
+// reference, so the next step has its full headroom again.  (Should a row ever wrap, its garbage maximum makes the next
+// scale coarser, never finer; the reference then decays back.  Only a row's FINAL sum must fit: int32 addition is
+// modular, intermediate overflow cancels.)
+__global__ void __launch_bounds__(1024) k_grid_fx_update(float* __restrict__ fx, int num_levels, float headroom) {
+  const int l = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (l >= num_levels) return;
+  float m = 0.0f;
+  for (int b = lane; b < kFxBlocks; b += 64) m = fmaxf(m, fx[kFxBase + kFxBlocks * l + b]);
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
+  if (lane != 0) return;
+  const float old_scale = fx[l], old_ref = fx[16 + l];
+  const bool finite = m < __int_as_float(0x7F800000);
+  const bool near_miss = old_scale > 0.0f && finite && m * old_scale > 268435456.0f;          // 2^28
+  float ref = finite ? fmaxf(m, 0.75f * old_ref) : 0.0f;
+  float scale = 0.0f;
+  if (ref > 0.0f && finite) {
+    float e = floorf(log2f(1073741824.0f / (headroom * ref)));                                // 2^30
+    e = fminf(fmaxf(e, -100.0f), 100.0f);
+    scale = exp2f(e);
+  }
+  fx[l] = scale;
+  fx[16 + l] = ref;
+  fx[32 + l] = m;
+  fx[kFxFlags + l] = 0.0f;
+  if (near_miss) atomicAdd(fx + 49, 1.0f);
+  if (l == 0 && old_scale > 0.0f) fx[48] += 1.0f;
 }
 
 // Gradient with respect to the INPUT coordinates (upstream's dy_dx path, used when the positions require grad):
@@ -507,6 +601,35 @@ int inr_grid_encode_backward_ordered(const float* x, const float* grad_out, cons
 int inr_grid_encode_backward_levels(const float* x, const float* grad_out, const int32_t* order,
                                     const inr_grid_desc* desc, int64_t M, float bound, float* grad_embeddings,
                                     int32_t level_lo, int32_t level_hi, inr_stream_t s) {
+  return inr_grid_encode_backward_levels_fx(x, grad_out, order, desc, M, bound, grad_embeddings, level_lo, level_hi, nullptr, s);
+}
+
+int inr_grid_grad_finish_fx(float* grad_embeddings, const inr_grid_desc* desc, int32_t level_lo, int32_t level_hi,
+                            float* fx_state, inr_stream_t s) {
+  INR_REQUIRE(desc && grad_embeddings && fx_state, "null pointer");
+  INR_REQUIRE(level_lo >= 0 && level_lo < level_hi && level_hi <= desc->num_levels, "bad level range");
+  INR_REQUIRE(((uintptr_t)grad_embeddings & 15) == 0, "grad_embeddings must be 16-byte aligned");
+  GridDesc G;
+  int rc = make_grid_desc(desc, G);
+  if (rc) return rc;
+  for (int l = level_lo; l <= level_hi; ++l)
+    INR_REQUIRE((desc->offsets[l] & 7u) == 0, "level offsets must be multiples of 8 rows");
+  const dim3 grid(kFxBlocks, (unsigned)(level_hi - level_lo));
+  k_grid_grad_finish<<<grid, 256, 0, as_stream(s)>>>(grad_embeddings, G, level_lo, fx_state);
+  return check_launch("grid_grad_finish_fx");
+}
+
+int inr_grid_fx_update(float* fx_state, int32_t num_levels, float headroom, inr_stream_t s) {
+  INR_REQUIRE(fx_state, "null pointer");
+  INR_REQUIRE(num_levels >= 1 && num_levels <= INR_MAX_LEVELS, "num_levels out of range");
+  INR_REQUIRE(headroom >= 2.0f && headroom <= 1048576.0f, "headroom must be in [2, 2^20]");
+  k_grid_fx_update<<<1, 1024, 0, as_stream(s)>>>(fx_state, num_levels, headroom);
+  return check_launch("grid_fx_update");
+}
+
+int inr_grid_encode_backward_levels_fx(const float* x, const float* grad_out, const int32_t* order,
+                                       const inr_grid_desc* desc, int64_t M, float bound, float* grad_embeddings,
+                                       int32_t level_lo, int32_t level_hi, float* fx_state, inr_stream_t s) {
   INR_REQUIRE(M >= 0 && desc, "bad argument");
   INR_REQUIRE(level_lo >= 0 && level_lo < level_hi && level_hi <= desc->num_levels, "bad level range");
   if (M == 0) return INR_OK;
@@ -523,7 +646,7 @@ int inr_grid_encode_backward_levels(const float* x, const float* grad_out, const
     const int64_t mc = std::min(chunk, M - m0);
     const dim3 grid((unsigned)(level_hi - level_lo), blocks_for(mc * 4, 256));
     k_grid_bwd<<<grid, 256, 0, as_stream(s)>>>(order ? x : x + m0 * 3, order ? grad_out : grad_out + m0 * G.num_levels * 2,
-                                               order ? order + m0 : nullptr, G, mc, bound, grad_embeddings, level_lo);
+                                               order ? order + m0 : nullptr, G, mc, bound, grad_embeddings, level_lo, fx_state);
   }
   return check_launch("grid_encode_backward");
 }

@@ -106,6 +106,7 @@ class GridEncoder(nn.Module):
         self.register_buffer("offsets", torch.from_numpy(self.table["offsets"].astype(np.int32)))
         self.n_params = self.table["total_rows"] * level_dim
         self.embeddings = nn.Parameter(torch.empty(self.table["total_rows"], level_dim))
+        self.embeddings._is_hash_table = True        # nerf/network.py::fx_state hangs the fixed-point gradient state here
         self.desc = _lib.make_grid_desc(self.table)
         self.reset_parameters()
 

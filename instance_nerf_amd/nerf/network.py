@@ -20,6 +20,8 @@ Execution paths, all HIP:
   encoders with the tiny MLP GEMMs left to rocBLAS through ``nn.Linear`` -
   upstream's default configuration (its ``--ff`` fused MLP is optional there too).
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -59,6 +61,25 @@ class _LinearFn(torch.autograd.Function):
 _before_scatter = {}      # {"hook": callable}: called once, right before the next table-gradient scatter is queued
 
 
+# Fixed-point table-gradient scatter (round 6; include/inr.h "Fixed-point form of the table-gradient scatter"): on by
+# default for every table that is trained through the fused paths - the memory-side atomic unit takes int32 adds 28 %
+# faster than fp32 ones, and the gradient becomes independent of the order in which the waves' requests arrive (training
+# steps are bit-reproducible).  INR_FX_GRAD=0 (or network.FX_GRAD = False) restores the fp32 atomics of rounds 1-5.
+FX_GRAD = os.environ.get("INR_FX_GRAD", "1") != "0"
+FX_HEADROOM = float(os.environ.get("INR_FX_HEADROOM", "64"))
+
+
+def fx_state(emb, create=True):
+    """The table's fixed-point state (device floats, zero = "no scale yet: fp32 atomics"), kept on the Parameter object;
+    created on first use - ``Trainer`` creates it before it captures a step (nothing may be allocated inside a capture)."""
+    st = getattr(emb, "_fx_state", None)
+    if (st is None or st.device != emb.device) and create and emb.is_cuda:
+        st = torch.zeros(_lib.GRID_FX_STATE_FLOATS, dtype=torch.float32, device=emb.device)
+        emb._fx_state = st
+        emb._fx_primed = False
+    return st
+
+
 def _table_backward(lib, x, denc, desc, M, bound, g_emb, emb):
     """Table-gradient scatter; returns the gradient to hand back to autograd (None when it was installed directly).
 
@@ -81,14 +102,31 @@ def _table_backward(lib, x, denc, desc, M, bound, g_emb, emb):
         raise RuntimeError("gradient accumulation over several backward passes is not supported together with the "
                            "overlapped table-gradient all-reduce; set INR_GRAD_OVERLAP=0")
     overlap = grad_sync.active() and L > 8 and emb.grad is None
+    fx = fx_state(emb) if (FX_GRAD and g_emb.is_cuda and g_emb.data_ptr() % 16 == 0) else None
+    if fx is not None and M and not getattr(emb, "_fx_primed", False) and not torch.cuda.is_current_stream_capturing():
+        # The table's very first backward has no scales yet and would run on fp32 atomics - the one step whose result
+        # depends on the order of arrival.  Prime instead: scatter once into a scratch buffer only to learn the levels'
+        # magnitudes (finish + update set the scales), then take the step itself on int32 sums like every later one.
+        scratch = torch.zeros_like(g_emb)
+        check(lib.inr_grid_encode_backward_levels_fx(ptr(x), ptr(denc), None, desc, M, float(bound), ptr(scratch), 0, L,
+                                                     ptr(fx), stream_ptr()), "grid_encode_backward (priming)")
+        check(lib.inr_grid_grad_finish_fx(ptr(scratch), desc, 0, L, ptr(fx), stream_ptr()), "grid_grad_finish_fx (priming)")
+        check(lib.inr_grid_fx_update(ptr(fx), L, FX_HEADROOM, stream_ptr()), "grid_fx_update (priming)")
+        emb._fx_primed = True
+        del scratch
     for lo, hi in (((8, L), (0, 8)) if overlap else ((0, L),)):
         if M:          # a batch without a single sample still takes part in the collectives below (zeros): every rank
             #            must issue the same sequence of all-reduces or the job hangs
-            check(lib.inr_grid_encode_backward_levels(ptr(x), ptr(denc), None, desc, M, float(bound), ptr(g_emb), lo, hi,
-                                                      stream_ptr()), "grid_encode_backward")
+            check(lib.inr_grid_encode_backward_levels_fx(ptr(x), ptr(denc), None, desc, M, float(bound), ptr(g_emb), lo, hi,
+                                                         ptr(fx, allow_none=True), stream_ptr()), "grid_encode_backward")
+        if fx is not None:
+            # int32 sums -> fp32 gradients in place (+ the levels' maxima): from here on g_emb is an ordinary gradient
+            check(lib.inr_grid_grad_finish_fx(ptr(g_emb), desc, lo, hi, ptr(fx), stream_ptr()), "grid_grad_finish_fx")
         if overlap:
             a, b = int(desc.offsets[lo]), int(desc.offsets[hi])
             grad_sync.reduce_async(g_emb[a:b], emb, a * g_emb.shape[1])
+    if fx is not None:
+        check(lib.inr_grid_fx_update(ptr(fx), L, FX_HEADROOM, stream_ptr()), "grid_fx_update")      # next step's scales
     if overlap:
         emb.grad = g_emb
         grad_sync.mark(emb, g_emb)

@@ -1117,6 +1117,9 @@ class Trainer:
             for p in g["params"]:               # (an allocation + zero fill inside it would be replayed every step)
                 if p.requires_grad:
                     opt._moments(p)
+                    if getattr(p, "_is_hash_table", False):
+                        from . import network as _network
+                        _network.fx_state(p)        # the fixed-point gradient state of a table: not inside a capture either
         opt.hyper_tensor(self.device)
         self.optimizer.zero_grad()
         torch.cuda.synchronize()
@@ -1190,6 +1193,9 @@ class Trainer:
             for p in g["params"]:
                 if p.requires_grad:
                     opt._moments(p)
+                    if getattr(p, "_is_hash_table", False):
+                        from . import network as _network
+                        _network.fx_state(p)        # the fixed-point gradient state of a table: not inside a capture either
         opt.hyper_tensor(dev)
         self._pipe = {"key": self._graph_key(data), "sets": sets, "graphs": {}, "turn": 0, "primed": False,
                       "expect": None, "side": torch.cuda.Stream(device=dev)}
@@ -1507,6 +1513,12 @@ class Trainer:
                 state["lr_scheduler"] = self.lr_scheduler.state_dict()
             if self.ema is not None:
                 state["ema"] = self.ema.state_dict()
+            # fixed-point gradient scales of the trained tables (nerf/network.py::fx_state): a resumed run then rounds the
+            # next step's row sums to the same quanta the uninterrupted run does (an extra key; upstream's loader ignores it)
+            fx = {n: p._fx_state[:64].detach().cpu().clone() for n, p in self.model.named_parameters()
+                  if getattr(p, "_fx_state", None) is not None and getattr(p, "_fx_primed", False)}
+            if fx:
+                state["fx_state"] = fx
         if path is None and best:
             results = self.stats["results"]
             if not results:
@@ -1569,6 +1581,16 @@ class Trainer:
         self.epoch = state.get("epoch", self.epoch)
         self.global_step = state.get("global_step", self.global_step)
         self.stats = {**self.stats, **state.get("stats", {})}
+        if "fx_state" in state:
+            from . import network as _network
+            named = dict(self.model.named_parameters())
+            for n, saved in state["fx_state"].items():
+                p = named.get(n)
+                if p is not None and p.is_cuda:
+                    st = _network.fx_state(p)
+                    st.zero_()
+                    st[:64].copy_(saved.to(st.device))
+                    p._fx_primed = True
         for key, obj in (("optimizer", self.optimizer), ("lr_scheduler", self.lr_scheduler), ("ema", self.ema)):
             if obj is not None and key in state:
                 try:

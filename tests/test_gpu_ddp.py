@@ -100,12 +100,29 @@ def _run(stage, overlap, steps=3, payload="fp32"):
     return res
 
 
+@pytest.fixture
+def fx_mode(request):
+    """The table-gradient scatter's two forms (round 6): "1" int32 sums (the default), "0" the fp32 atomics of rounds 1-5 -
+    set for the ranks (INR_FX_GRAD, read at import in the spawned workers) and for this process."""
+    from instance_nerf_amd.nerf import network
+    old_env, old = os.environ.get("INR_FX_GRAD"), network.FX_GRAD
+    os.environ["INR_FX_GRAD"] = request.param
+    network.FX_GRAD = request.param == "1"
+    yield request.param == "1"
+    network.FX_GRAD = old
+    if old_env is None:
+        os.environ.pop("INR_FX_GRAD", None)
+    else:
+        os.environ["INR_FX_GRAD"] = old_env
+
+
+@pytest.mark.parametrize("fx_mode", ["1", "0"], indirect=True)
 @pytest.mark.parametrize("stage", ["nerf", "instance"])
-def test_two_ranks_stay_replicas_and_match_one_process_on_the_union_batch(stage):
+def test_two_ranks_stay_replicas_and_match_one_process_on_the_union_batch(stage, fx_mode):
     """(1) after three steps both ranks hold bit-identical parameters; (2) starting the table-gradient all-reduce
     from inside the backward, in two level ranges (grad_sync), gives the same parameters as reducing after it;
     (3) NeRF stage: the result equals ONE process stepping on the union of the two ranks' batches (mean of the two
-    mean-squared errors = mean over the union, equal batch sizes)."""
+    mean-squared errors = mean over the union, equal batch sizes).  Both forms of the table-gradient scatter."""
     runs = {ov: _run(stage, ov) for ov in (True, False)}
     for ov, res in runs.items():
         for k in res[0][2]:
@@ -130,8 +147,13 @@ def test_two_ranks_stay_replicas_and_match_one_process_on_the_union_batch(stage)
             # turns an entry whose gradient is pure rounding noise into a full +-lr step, and the two runs sum their
             # atomics and partial weight gradients in different orders - tools/ddp_union_probe.py finds ONE such table
             # entry out of 12.2 M (5.5e-3) with the round-3 backward, none (1.4e-4) with the round-2 one
+            # Fixed-point scatter (round 6): every rank rounds its OWN row sums to the level's quantum (6e-8 of the level's
+            # largest row gradient) before the fp32 all-reduce, the single process rounds the union's - entries whose
+            # gradient is about one quantum come out as 0 on one side and +-1 quantum on the other, and Adam turns that
+            # into a +-lr step: 647 of 12.2 M table entries (5.3e-5) measured, none beyond 2.5 steps.
             diff = np.abs(v - ref)
-            assert float(np.mean(diff > 2e-3)) < 1e-6 and diff.max() < 3.5e-2, (k, diff.max(), int((diff > 2e-3).sum()))
+            frac = 2e-4 if (fx_mode and k.endswith("embeddings")) else 1e-6
+            assert float(np.mean(diff > 2e-3)) < frac and diff.max() < 3.5e-2, (k, diff.max(), int((diff > 2e-3).sum()))
 
 
 def _schedule_worker(rank, world, port, q, stage, schedule, overlap, payload, steps):

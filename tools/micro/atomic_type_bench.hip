@@ -52,6 +52,37 @@ __global__ void k_atomic(char* table, uint32_t rows, uint32_t slice_rows, uint64
   if (TYPE == T_U32_RET && sink == 0xFFFFFFFFu) *sink_out = sink;
 }
 
+// The scatter's REAL request shape (k_grid_bwd: 4 lanes per sample = (x side) x (feature) -> the two 8-byte rows of an
+// x-adjacent corner pair = 16 contiguous bytes per 4 lanes, one memory-side request): each group of 4 lanes adds to the 4
+// dwords of one random 16-byte unit of a table of the product's size (6 119 864 rows = 49 MB), f32 against u32.
+template <int TYPE>
+__global__ void k_atomic_quad(char* table, uint32_t units, uint64_t n_ops, uint32_t seed) {
+  uint32_t sink = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_ops; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t h = hash32((uint32_t)(i >> 2) ^ seed);
+    char* p = table + 16 * (size_t)(h % units) + 4 * (i & 3);
+    op<TYPE>(p, sink);
+  }
+}
+
+template <int TYPE>
+static int run_quad(const char* name, char* table, uint64_t n_ops) {
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  const uint32_t units = 6119864u / 2;                       // 16-byte units of the product's table
+  float best = 1e9f;
+  for (int rep = 0; rep < 5; ++rep) {
+    CK(hipMemset(table, 0, (size_t)units * 16));
+    CK(hipEventRecord(e0));
+    k_atomic_quad<TYPE><<<2048, 256>>>(table, units, n_ops, rep);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    if (ms < best) best = ms;
+  }
+  printf("%-22s 16-byte requests (4 lanes x 4 B) into a 49 MB table: %.3f ms  %6.2f G lane-atomics/s = %5.2f G requests/s\n", name, best,
+         n_ops / best / 1e6, n_ops / 4.0 / best / 1e6);
+  return 0;
+}
+
 template <int TYPE>
 static int run(const char* name, char* table, uint32_t rows, uint64_t n_ops, uint32_t* sink, char* host) {
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -104,5 +135,10 @@ int main() {
   if (run<T_F64>("f64 add (agent)", table, rows, n_ops, sink, host)) return 1;
   if (run<T_PKBF16>("pk_add_bf16", table, rows, n_ops, sink, host)) return 1;
   if (run<T_PKF16>("pk_add_f16", table, rows, n_ops, sink, host)) return 1;
+  const uint64_t n_quad = 64000000ull;           // 16 M requests: ~440 k samples x 38 requests, the trained scene's step
+  if (run_quad<T_F32>("f32 add", table, n_quad)) return 1;
+  if (run_quad<T_U32>("u32 add", table, n_quad)) return 1;
+  if (run_quad<T_F32>("f32 add (again)", table, n_quad)) return 1;
+  if (run_quad<T_U32>("u32 add (again)", table, n_quad)) return 1;
   return 0;
 }
