@@ -34,6 +34,10 @@ def scatter_requests(stage):
     t = json.load(open(path))
     if t.get("source_sha") != build.source_sha("scatter"):
         return None
+    from instance_nerf_amd.nerf import network as _network
+    form = "int32 (fixed point)" if _network.FX_GRAD else "fp32 atomics"
+    if t.get("scatter_form", "fp32 atomics") != form:
+        return None                           # measured on the other form of the scatter
     return float(t["instance_stage" if stage == "instance" else "nerf_stage"]["requests_per_sample"]), float(t["unit_rate_requests_per_s"])
 
 
@@ -243,8 +247,8 @@ def train_probe(dev, rank=0, world=1, red_dev=None, steps=20, warmup=5, stage="i
     own_dt = dt
     step_bytes = per_sample * (n / steps) + adam_bytes
     roofline = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
-                "kernel": "k_grid_bwd (table-gradient scatter, fp32 atomics; memory-side atomic request rate, "
-                          "profiles/r03_NOTES.txt)",
+                "kernel": "k_grid_bwd (table-gradient scatter, int32 sums since round 6 / fp32 atomics with INR_FX_GRAD=0; "
+                          "memory-side atomic request rate, profiles/r06_NOTES.txt)",
                 "algorithmic_bytes_per_sample": 2048, "launches": n_scatter,
                 "avg_launch_ms": round(scatter_ms, 4),
                 "achieved": round(2048 * (n / steps) / (scatter_ms / 1e3) / 1e9, 1) if scatter_ms > 0 else None,
@@ -264,7 +268,7 @@ def train_probe(dev, rank=0, world=1, red_dev=None, steps=20, warmup=5, stage="i
                                    "peak_g_requests_per_s": round(sr[1] / 1e9, 1),
                                    "frac": round(req / (scatter_ms / 1e3) / sr[1], 4),
                                    "source": SCATTER_JSON + " (rocprofv3 PMC on these kernel sources; peak from "
-                                             "tools/micro/atomic_width_bench.hip)"}
+                                             "tools/micro/atomic_type_bench.hip)"}
     what = ("instance-field training step, K=64, 4096 rays/batch per GPU, NeRF frozen, parameter EMA 0.95 "
             f"(BASELINE configs[{2 if world == 1 else 3}])") if stage == "instance" else \
         "NeRF training step (MSE on rgb: hash table + sigma/colour nets, parameter EMA 0.95), 4096 rays/batch per GPU"
@@ -651,7 +655,7 @@ def half_table_probe(dev, frames=8, mlp_fp16=False):
     return out
 
 
-def timed_trained_steps(tr, net, ds, stage, n=128):
+def timed_trained_steps(tr, net, ds, stage, n=128, ab=True):
     """Steady-state training steps of a Trainer whose scene is already TRAINED (opaque surfaces, learned occupancy grid:
     2.4x the samples per step of the untrained bench scene), eager loop over pre-made batches of the on-disk loader
     (GPU-resident images and masks): ms per step from device events, samples per step from the march's device counter,
@@ -703,6 +707,21 @@ def timed_trained_steps(tr, net, ds, stage, n=128):
         out["roofline"]["atomic_unit"] = {"requests_per_sample": sr[0], "achieved_g_requests_per_s": round(req / (sc / 1e3) / 1e9, 2),
                                           "peak_g_requests_per_s": round(sr[1] / 1e9, 1), "frac": round(req / (sc / 1e3) / sr[1], 4),
                                           "source": SCATTER_JSON + " (requests per sample measured on the UNTRAINED bench scene)"}
+    # the table gradient is summed as int32 since round 6 (nerf/network.py::FX_GRAD): how often did a level come within
+    # 4x of the int32 range ("near miss": 16x growth against its reference; 64x would wrap), and the same steps on the
+    # fp32 atomics of rounds 1-5 for the A/B
+    table = net.instance_encoder.embeddings if stage == "instance" else net.encoder.embeddings
+    st = getattr(table, "_fx_state", None)
+    out["scatter_form"] = "int32 (fixed point)" if (_network_mod.FX_GRAD and st is not None) else "fp32 atomics"
+    if st is not None and _network_mod.FX_GRAD and ab:
+        h = st[:64].cpu().numpy()
+        out["fixed_point"] = {"steps_so_far": int(h[48]), "near_misses_so_far": int(h[49]), "levels_without_scale": int((h[:16] == 0).sum())}
+        _network_mod.FX_GRAD = False
+        try:
+            other = timed_trained_steps(tr, net, ds, stage, n=64, ab=False)
+            out["fp32_atomics"] = {k: other[k] for k in ("steps", "ms_per_step", "ms_per_step_median", "scatter_ms", "scatter_share_of_step")}
+        finally:
+            _network_mod.FX_GRAD = True
     return out
 
 
