@@ -308,7 +308,8 @@ int inr_grid_encode_backward_levels(const float* x, const float* grad_out, const
  * fx_state: INR_GRID_FX_STATE_FLOATS device floats per table, zero-initialised by the caller once, then owned by these
  * three calls: [0,16) the scale of each level for the current step (a power of two; 0 = this level uses fp32 atomics),
  * [16,32) reference magnitudes, [32,48) the last step's largest |row gradient| per level, [48] fixed-point steps so far,
- * [49] near misses so far, the rest scratch.  A non-finite contribution to a fixed-point level (it has no int32
+ * [49] near misses so far, [80,96) the largest fraction of the int32 range a row sum of each level has used so far, the
+ * rest scratch.  A non-finite contribution to a fixed-point level (it has no int32
  * image) turns that level's WHOLE gradient into NaN in the finishing pass - as loud as the NaN rows fp32 atomics leave.
  * Per training step, on one stream:
  *   inr_grid_encode_backward_levels_fx   scatter of a level range; a level with a scale accumulates round(w g scale) as
@@ -318,15 +319,16 @@ int inr_grid_encode_backward_levels(const float* x, const float* grad_out, const
  *                                        the level's largest |gradient|; afterwards grad_embeddings is an ordinary fp32
  *                                        gradient (call it for every level range that was scattered, fp32 levels too)
  *   inr_grid_fx_update                   once per step after all ranges: next step's scales = 2^floor(log2(2^30 /
- *                                        (headroom x reference))), reference = max(this step's max, 0.75 reference).
+ *                                        (headroom x reference))), reference = max(this step's max, 0.97 reference).
  * A level runs on fp32 atomics only while it has no reference: before its first step (the Python host primes the scales
  * with one extra scatter into a scratch buffer, so that no training step ever depends on the order of arrival) and
- * after an all-zero or non-finite gradient.  A near miss (a step that used more than 2^28 of the int32 range: 16x
- * growth against the reference) is counted; a row's FINAL sum that grows more than `headroom` times (64 in the product)
- * against the reference would wrap (intermediate overflow is harmless: int32 addition is modular).  Quantisation: a row
- * gradient is a multiple of headroom x reference x 2^-30 (6e-8 of the level's recent largest at 64).
+ * after an all-zero or non-finite gradient.  A near miss (a step that used more than 1/8 of the int32 range) is
+ * counted; a row's FINAL sum that grows more than `headroom` times (128 in the product) against the reference - the
+ * largest of the last ~50 steps - would wrap (intermediate overflow is harmless: int32 addition is modular); measured
+ * peak use of the range over 3000 training steps: 0.06.  Quantisation: a row gradient is a multiple of headroom x
+ * reference x 2^-30 (1.2e-7 of the level's recent largest at 128, ~5e-7 of a typical step's).
  * Converged quality equals the fp32 path's within its own run-to-run spread (tools/fixed_point_emulation_probe.py).   */
-#define INR_GRID_FX_STATE_FLOATS 4176
+#define INR_GRID_FX_STATE_FLOATS 4192
 int inr_grid_encode_backward_levels_fx(const float* x, const float* grad_out, const int32_t* order,
                                        const inr_grid_desc* desc, int64_t M, float bound, float* grad_embeddings,
                                        int32_t level_lo, int32_t level_hi, float* fx_state /*nullable*/,

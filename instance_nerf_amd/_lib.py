@@ -15,7 +15,7 @@ import torch  # noqa: F401  (must precede CDLL: shares the HIP runtime)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("INR_LIB_PATH") or os.path.join(_HERE, "csrc", "libinr_hip.so")   # env override: profiling builds only
 MAX_LEVELS = 16
-GRID_FX_STATE_FLOATS = 4176      # include/inr.h INR_GRID_FX_STATE_FLOATS
+GRID_FX_STATE_FLOATS = 4192      # include/inr.h INR_GRID_FX_STATE_FLOATS
 
 
 class GridDesc(Structure):

@@ -66,7 +66,7 @@ _before_scatter = {}      # {"hook": callable}: called once, right before the ne
 # faster than fp32 ones, and the gradient becomes independent of the order in which the waves' requests arrive (training
 # steps are bit-reproducible).  INR_FX_GRAD=0 (or network.FX_GRAD = False) restores the fp32 atomics of rounds 1-5.
 FX_GRAD = os.environ.get("INR_FX_GRAD", "1") != "0"
-FX_HEADROOM = float(os.environ.get("INR_FX_HEADROOM", "64"))
+FX_HEADROOM = float(os.environ.get("INR_FX_HEADROOM", "128"))
 
 
 def fx_state(emb, create=True):

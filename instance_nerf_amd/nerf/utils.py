@@ -1515,7 +1515,7 @@ class Trainer:
                 state["ema"] = self.ema.state_dict()
             # fixed-point gradient scales of the trained tables (nerf/network.py::fx_state): a resumed run then rounds the
             # next step's row sums to the same quanta the uninterrupted run does (an extra key; upstream's loader ignores it)
-            fx = {n: p._fx_state[:64].detach().cpu().clone() for n, p in self.model.named_parameters()
+            fx = {n: p._fx_state[:96].detach().cpu().clone() for n, p in self.model.named_parameters()
                   if getattr(p, "_fx_state", None) is not None and getattr(p, "_fx_primed", False)}
             if fx:
                 state["fx_state"] = fx
@@ -1589,7 +1589,7 @@ class Trainer:
                 if p is not None and p.is_cuda:
                     st = _network.fx_state(p)
                     st.zero_()
-                    st[:64].copy_(saved.to(st.device))
+                    st[:saved.numel()].copy_(saved.to(st.device))
                     p._fx_primed = True
         for key, obj in (("optimizer", self.optimizer), ("lr_scheduler", self.lr_scheduler), ("ema", self.ema)):
             if obj is not None and key in state:

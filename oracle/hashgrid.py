@@ -151,3 +151,29 @@ def encode_input_grad(x, grad_out, embeddings, bound, table):
             out[:, l] = out[:, l] + w[:, None] * embeddings.detach()[idx[:, l, c]]
     (out.reshape(M, L * F) * torch.as_tensor(grad_out, dtype=torch.float32)).sum().backward()
     return x.grad
+
+
+def fx_next_scale(old_ref, step_max, headroom=128.0):
+    """Scale rule of the fixed-point (int32) table-gradient scatter (include/inr.h ``inr_grid_fx_update``; no upstream
+    counterpart - upstream's ``grid_encode_backward`` sums with fp32 ``atomicAdd``): per level, from the largest |row
+    gradient| of the step that has just finished and the running reference,
+        ref'  = max(step_max, 0.97 * ref)         (0 when step_max is not finite)
+        scale = 2 ** floor(log2(2**30 / (headroom * ref')))  clamped to 2**+-100      (0 when ref' == 0)
+    all in float32.  -> (scale, ref') as float32 arrays."""
+    old_ref = np.asarray(old_ref, dtype=np.float32)
+    m = np.asarray(step_max, dtype=np.float32)
+    finite = np.isfinite(m)
+    ref = np.where(finite, np.maximum(m, np.float32(0.97) * old_ref), np.float32(0)).astype(np.float32)
+    with np.errstate(divide="ignore", over="ignore", invalid="ignore"):
+        e = np.floor(np.log2(np.float32(1073741824.0) / (np.float32(headroom) * ref).astype(np.float32)).astype(np.float32))
+    e = np.clip(e, -100.0, 100.0)
+    scale = np.where((ref > 0) & finite, np.exp2(e.astype(np.float64)), 0.0).astype(np.float32)
+    return scale, ref
+
+
+def fx_quantise(grad, scale):
+    """What a level's gradient looks like after the int32 sum when EVERY contribution is rounded once at the end (the
+    kernel rounds each wave's run sums; the difference is below one quantum per contributing wave): round(g * scale) /
+    scale.  Used by tests as the reference point between the fp32 sum and the kernel's result."""
+    g = np.asarray(grad, dtype=np.float64)
+    return (np.rint(g * float(scale)) / float(scale)).astype(np.float32)

@@ -191,3 +191,21 @@ def test_get_rays_error_map_sampling():
     assert (rows[1] // 2 == 100).all() and ((cols[1] // 2 >= 50) & (cols[1] // 2 < 60)).all()
     ref = get_rays(poses[:1], (200.0, 200.0, 128.0, 128.0), H, W, inds=out["inds"][0])
     assert torch.equal(ref["rays_d"][0], out["rays_d"][0])
+
+
+def test_fixed_point_scale_rule():
+    """oracle/hashgrid.py::fx_next_scale: a power of two that leaves `headroom` times the reference inside 31 bits, a
+    reference that follows increases at once and decays by 3 % per step, zero for non-finite or all-zero steps."""
+    from oracle import hashgrid
+    s, r = hashgrid.fx_next_scale([0.0, 1e-3, 1e-3, 1.0, 5.0, 0.0], [2e-4, 1e-5, 4e-3, np.inf, np.nan, 0.0])
+    assert r.tolist() == [np.float32(2e-4), np.float32(0.97) * np.float32(1e-3), np.float32(4e-3), 0.0, 0.0, 0.0]
+    assert s[3] == 0 and s[4] == 0 and s[5] == 0
+    for k in range(3):
+        assert np.log2(s[k]) == np.round(np.log2(s[k]))
+        assert 2.0 ** 29 < 128.0 * r[k] * s[k] <= 2.0 ** 30
+    s8, _ = hashgrid.fx_next_scale([0.0], [2e-4], headroom=8.0)
+    assert s8[0] == 16 * s[0]
+    tiny, _ = hashgrid.fx_next_scale([0.0], [1e-38])
+    assert tiny[0] == np.float32(2.0 ** 100)                         # clamped: never an infinite scale
+    q = hashgrid.fx_quantise([1.0e-6, -2.6e-7, 3.0e-8], 2.0 ** 22)   # quantum 2.4e-7
+    assert np.allclose(q * 2.0 ** 22, [4.0, -1.0, 0.0])

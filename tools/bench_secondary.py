@@ -714,8 +714,11 @@ def timed_trained_steps(tr, net, ds, stage, n=128, ab=True):
     st = getattr(table, "_fx_state", None)
     out["scatter_form"] = "int32 (fixed point)" if (_network_mod.FX_GRAD and st is not None) else "fp32 atomics"
     if st is not None and _network_mod.FX_GRAD and ab:
-        h = st[:64].cpu().numpy()
-        out["fixed_point"] = {"steps_so_far": int(h[48]), "near_misses_so_far": int(h[49]), "levels_without_scale": int((h[:16] == 0).sum())}
+        h = st[:96].cpu().numpy()
+        out["fixed_point"] = {"steps_so_far": int(h[48]), "near_misses_so_far": int(h[49]), "levels_without_scale": int((h[:16] == 0).sum()),
+                              "peak_use_of_the_int32_range": round(float(h[80:96].max()), 4),
+                              "what": "near miss = a level-step whose largest row sum used more than 1/8 of the int32 range; "
+                                      "peak use 1.0 would be a wrap (tools/fx_dynamics_probe.py)"}
         _network_mod.FX_GRAD = False
         try:
             other = timed_trained_steps(tr, net, ds, stage, n=64, ab=False)
