@@ -301,8 +301,8 @@ int inr_grid_encode_backward_levels(const float* x, const float* grad_out, const
                                     const inr_grid_desc* desc, int64_t M, float bound, float* grad_embeddings,
                                     int32_t level_lo, int32_t level_hi, inr_stream_t s);
 
-/* Fixed-point form of the table-gradient scatter (round 6; no upstream counterpart: upstream's grid_encode_backward uses
- * fp32 atomicAdd).  Why: on MI355X every atomic is executed by the memory-side unit, which takes int32 adds at 26.9 G
+/* Fixed-point form of the table-gradient scatter (round 6; OPT-IN - the product's default stays the fp32 atomics of
+ * upstream's grid_encode_backward, see the end of this comment).  Why: on MI355X every atomic is executed by the memory-side unit, which takes int32 adds at 26.9 G
  * requests/s against 21.0 for fp32 (tools/micro/atomic_type_bench.hip) - the scatter is the largest kernel of a
  * training step - and integer sums do not depend on the order of arrival: the gradient becomes bit-reproducible.
  * fx_state: INR_GRID_FX_STATE_FLOATS device floats per table, zero-initialised by the caller once, then owned by these
@@ -327,7 +327,11 @@ int inr_grid_encode_backward_levels(const float* x, const float* grad_out, const
  * largest of the last ~50 steps - would wrap (intermediate overflow is harmless: int32 addition is modular); measured
  * peak use of the range over 3000 training steps: 0.06.  Quantisation: a row gradient is a multiple of headroom x
  * reference x 2^-30 (1.2e-7 of the level's recent largest at 128, ~5e-7 of a typical step's).
- * Converged quality equals the fp32 path's within its own run-to-run spread (tools/fixed_point_emulation_probe.py).   */
+ * Why opt-in: a row whose gradient is below half a quantum gets none, and Adam with eps = 1e-15 (upstream's optimiser)
+ * moves a row by a full lr step whatever its gradient's SIZE - rows fed only by weak samples learn at full speed under
+ * fp32 atomics and not at all here.  Measured: identical PSNR / mIoU after 1500 + 1500 steps on the bench scene, but
+ * held-out mIoU 0.75-0.82 against 0.80-0.86 on the shorter schedule of tests/test_pipeline_e2e.py
+ * (profiles/r06_NOTES.txt 5).  Host switch: INR_FX_GRAD=1 / Trainer(fixed_point_grad=True).                          */
 #define INR_GRID_FX_STATE_FLOATS 4192
 int inr_grid_encode_backward_levels_fx(const float* x, const float* grad_out, const int32_t* order,
                                        const inr_grid_desc* desc, int64_t M, float bound, float* grad_embeddings,

@@ -61,11 +61,13 @@ class _LinearFn(torch.autograd.Function):
 _before_scatter = {}      # {"hook": callable}: called once, right before the next table-gradient scatter is queued
 
 
-# Fixed-point table-gradient scatter (round 6; include/inr.h "Fixed-point form of the table-gradient scatter"): on by
-# default for every table that is trained through the fused paths - the memory-side atomic unit takes int32 adds 28 %
-# faster than fp32 ones, and the gradient becomes independent of the order in which the waves' requests arrive (training
-# steps are bit-reproducible).  INR_FX_GRAD=0 (or network.FX_GRAD = False) restores the fp32 atomics of rounds 1-5.
-FX_GRAD = os.environ.get("INR_FX_GRAD", "1") != "0"
+# Fixed-point table-gradient scatter (round 6; include/inr.h "Fixed-point form of the table-gradient scatter"): OPT-IN,
+# INR_FX_GRAD=1 / Trainer(fixed_point_grad=True) / network.FX_GRAD = True.  The memory-side atomic unit takes int32 adds
+# 28 % faster than fp32 ones and the gradient becomes independent of the order in which the waves' requests arrive
+# (training steps are bit-reproducible) - but rows whose gradient is below the level's quantum get none, where Adam
+# (eps 1e-15) moves them by a full lr step under fp32 atomics: same converged quality, slower early convergence of weakly
+# supervised rows (profiles/r06_NOTES.txt 5).  The default is upstream's arithmetic: fp32 atomics.
+FX_GRAD = os.environ.get("INR_FX_GRAD", "0") == "1"
 FX_HEADROOM = float(os.environ.get("INR_FX_HEADROOM", "128"))
 
 

@@ -793,7 +793,7 @@ class Trainer:
     ``FusedAdam``, lr * 0.1^(step/iters), occupancy update every ``opt.update_extra_interval`` (16) steps.
 
     Keyword-only extensions: ``stage`` ("nerf" | "instance"), ``lr``, ``iters``, ``fused_adam``,
-    ``update_extra_interval``, ``use_graph``.  One process per GPU; with world_size > 1 each rank draws its own rays and
+    ``update_extra_interval``, ``use_graph``, ``look_ahead``, ``prune_ignored``, ``fixed_point_grad``.  One process per GPU; with world_size > 1 each rank draws its own rays and
     gradients are all-reduced (RCCL), the table gradient from inside the backward (``grad_sync``).
     """
 
@@ -802,7 +802,7 @@ class Trainer:
                  workspace="workspace", best_mode="min", use_loss_as_metric=True, report_metric_at_train=False,
                  use_checkpoint="latest", use_tensorboardX=True, scheduler_update_every_step=False, *,
                  lr=1e-2, iters=30000, fused_adam=True, stage="nerf", update_extra_interval=None, use_graph=False,
-                 look_ahead=False, shade_ahead=None, prune_ignored=True):
+                 look_ahead=False, shade_ahead=None, prune_ignored=True, fixed_point_grad=None):
         self.name, self.opt, self.model = name, opt, model
         self.world_size, self.local_rank = world_size, local_rank
         grad_sync.world_size = world_size
@@ -864,6 +864,12 @@ class Trainer:
         # ignore_index -1), so they are reported to the marcher as misses and cost nothing (render(ce_prune=True)):
         # same loss, same gradients; the step's `pred` rows of those rays are zeros instead of rendered logits
         self.prune_ignored = bool(prune_ignored)
+        # opt-in: the table gradient summed as int32 fixed point (nerf/network.py::FX_GRAD - faster scatter, bit-reproducible
+        # steps, rows below the level's quantum get no gradient).  A PROCESS-WIDE switch of the backward functions: None
+        # leaves it as INR_FX_GRAD set it (default off).
+        if fixed_point_grad is not None:
+            from . import network as _network
+            _network.FX_GRAD = bool(fixed_point_grad)
         self.iters = iters
         # upstream: lr_scheduler = lambda optimizer: LambdaLR(optimizer, lambda it: 0.1 ** min(it / opt.iters, 1)),
         # stepped after every optimiser step; without one, exactly that rule is applied to the param groups

@@ -102,7 +102,7 @@ def _run(stage, overlap, steps=3, payload="fp32"):
 
 @pytest.fixture
 def fx_mode(request):
-    """The table-gradient scatter's two forms (round 6): "1" int32 sums (the default), "0" the fp32 atomics of rounds 1-5 -
+    """The table-gradient scatter's two forms (round 6): "0" fp32 atomics (the default), "1" int32 sums (opt-in) -
     set for the ranks (INR_FX_GRAD, read at import in the spawned workers) and for this process."""
     from instance_nerf_amd.nerf import network
     old_env, old = os.environ.get("INR_FX_GRAD"), network.FX_GRAD
@@ -116,7 +116,7 @@ def fx_mode(request):
         os.environ["INR_FX_GRAD"] = old_env
 
 
-@pytest.mark.parametrize("fx_mode", ["1", "0"], indirect=True)
+@pytest.mark.parametrize("fx_mode", ["0", "1"], indirect=True)
 @pytest.mark.parametrize("stage", ["nerf", "instance"])
 def test_two_ranks_stay_replicas_and_match_one_process_on_the_union_batch(stage, fx_mode):
     """(1) after three steps both ranks hold bit-identical parameters; (2) starting the table-gradient all-reduce

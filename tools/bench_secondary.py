@@ -247,7 +247,7 @@ def train_probe(dev, rank=0, world=1, red_dev=None, steps=20, warmup=5, stage="i
     own_dt = dt
     step_bytes = per_sample * (n / steps) + adam_bytes
     roofline = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
-                "kernel": "k_grid_bwd (table-gradient scatter, int32 sums since round 6 / fp32 atomics with INR_FX_GRAD=0; "
+                "kernel": "k_grid_bwd (table-gradient scatter, fp32 atomics; opt-in int32 sums with INR_FX_GRAD=1; "
                           "memory-side atomic request rate, profiles/r06_NOTES.txt)",
                 "algorithmic_bytes_per_sample": 2048, "launches": n_scatter,
                 "avg_launch_ms": round(scatter_ms, 4),
@@ -707,24 +707,25 @@ def timed_trained_steps(tr, net, ds, stage, n=128, ab=True):
         out["roofline"]["atomic_unit"] = {"requests_per_sample": sr[0], "achieved_g_requests_per_s": round(req / (sc / 1e3) / 1e9, 2),
                                           "peak_g_requests_per_s": round(sr[1] / 1e9, 1), "frac": round(req / (sc / 1e3) / sr[1], 4),
                                           "source": SCATTER_JSON + " (requests per sample measured on the UNTRAINED bench scene)"}
-    # the table gradient is summed as int32 since round 6 (nerf/network.py::FX_GRAD): how often did a level come within
-    # 4x of the int32 range ("near miss": 16x growth against its reference; 64x would wrap), and the same steps on the
-    # fp32 atomics of rounds 1-5 for the A/B
+    # opt-in A/B (round 6, nerf/network.py::FX_GRAD): the same steps with the table gradient summed as int32 fixed point - the
+    # memory-side atomic unit takes integer adds 28 % faster and steps become bit-reproducible; how often did a level come
+    # within 8x of the int32 range ("near miss") and how much of the range did the largest row sum ever use
     table = net.instance_encoder.embeddings if stage == "instance" else net.encoder.embeddings
-    st = getattr(table, "_fx_state", None)
-    out["scatter_form"] = "int32 (fixed point)" if (_network_mod.FX_GRAD and st is not None) else "fp32 atomics"
-    if st is not None and _network_mod.FX_GRAD and ab:
-        h = st[:96].cpu().numpy()
-        out["fixed_point"] = {"steps_so_far": int(h[48]), "near_misses_so_far": int(h[49]), "levels_without_scale": int((h[:16] == 0).sum()),
-                              "peak_use_of_the_int32_range": round(float(h[80:96].max()), 4),
-                              "what": "near miss = a level-step whose largest row sum used more than 1/8 of the int32 range; "
-                                      "peak use 1.0 would be a wrap (tools/fx_dynamics_probe.py)"}
-        _network_mod.FX_GRAD = False
+    out["scatter_form"] = "int32 (fixed point)" if _network_mod.FX_GRAD else "fp32 atomics"
+    if ab and not _network_mod.FX_GRAD:
+        _network_mod.FX_GRAD = True
         try:
-            other = timed_trained_steps(tr, net, ds, stage, n=64, ab=False)
-            out["fp32_atomics"] = {k: other[k] for k in ("steps", "ms_per_step", "ms_per_step_median", "scatter_ms", "scatter_share_of_step")}
+            other = timed_trained_steps(tr, net, ds, stage, n=96, ab=False)
+            st = getattr(table, "_fx_state", None)
+            h = st[:96].cpu().numpy() if st is not None else np.zeros(96, np.float32)
+            out["fixed_point"] = {**{k: other[k] for k in ("steps", "ms_per_step", "ms_per_step_median", "scatter_ms", "scatter_share_of_step")},
+                                  "steps_so_far": int(h[48]), "near_misses_so_far": int(h[49]),
+                                  "peak_use_of_the_int32_range": round(float(h[80:96].max()), 4),
+                                  "what": "opt-in (INR_FX_GRAD=1 / Trainer(fixed_point_grad=True)): int32 sums of the table gradient; near "
+                                          "miss = a level-step whose largest row sum used more than 1/8 of the int32 range, peak use 1.0 "
+                                          "would be a wrap (tools/fx_dynamics_probe.py)"}
         finally:
-            _network_mod.FX_GRAD = True
+            _network_mod.FX_GRAD = False
     return out
 
 

@@ -24,9 +24,9 @@ json.dump({"kernel": "k_grid_bwd", "source_sha": build.source_sha("scatter"),
            "counter": "TCP_TCC_ATOMIC_WITHOUT_RET_REQ (== TCC_EA0_WRREQ_ATOMIC_DRAM: every request goes to the memory side)",
            "instance_stage": {"requests_per_step": round(r_i), "samples_per_step": n_i, "requests_per_sample": round(r_i / n_i, 2)},
            "nerf_stage": {"requests_per_step": round(r_n), "samples_per_step": n_n, "requests_per_sample": round(r_n / n_n, 2)},
-           # the probes run the product's default: the int32 (fixed-point) scatter since round 6, unless INR_FX_GRAD=0
-           "scatter_form": "fp32 atomics" if os.environ.get("INR_FX_GRAD", "1") == "0" else "int32 (fixed point)",
-           "unit_rate_requests_per_s": 21.0e9 if os.environ.get("INR_FX_GRAD", "1") == "0" else 26.9e9,
+           # the probes run the product's default - fp32 atomics - unless INR_FX_GRAD=1 (the opt-in int32 form)
+           "scatter_form": "int32 (fixed point)" if os.environ.get("INR_FX_GRAD", "0") == "1" else "fp32 atomics",
+           "unit_rate_requests_per_s": 26.9e9 if os.environ.get("INR_FX_GRAD", "0") == "1" else 21.0e9,
            "unit_rate_source": "tools/micro/atomic_type_bench.hip, profiles/r06_atomic_type_bench.txt: 16-byte requests into a 49 MB "
                                "table, 20.97 G/s fp32 adds, 26.9 G/s int32 adds (all forwarded to the memory side)"},
           open(out, "w"), indent=2)
