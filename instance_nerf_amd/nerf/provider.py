@@ -75,11 +75,12 @@ class NeRFDataset:
     ``Mask2Former_sample/match_seg.py:131-140`` (-1 ignore, 0 background, > 0 instance id).
     Batches (``__getitem__`` / iteration): training -> ``num_rays`` random pixels of ONE image:
     ``rays_o, rays_d [1,N,3]``, ``images [1,N,3]``, ``masks [1,N]`` (if ``mask_dir``), ``H, W, index``;
-    otherwise the full image in row-major order.
+    otherwise the full image in row-major order.  ``seed`` / ``rank``: the view order and the pixel draws are functions of
+    ``seed + 1000 * rank`` (one process per GPU: every rank its own batches).
     """
 
     def __init__(self, path, type="train", device="cpu", downscale=1, scale=0.33, offset=(0, 0, 0), num_rays=4096,
-                 mask_dir=None, num_instances=0, preload=True, seed=0, n_test=10):
+                 mask_dir=None, num_instances=0, preload=True, seed=0, n_test=10, rank=0):
         import json
         import os
         if hasattr(path, "path"):
@@ -98,6 +99,7 @@ class NeRFDataset:
             num_rays, preload = getattr(opt, "num_rays", num_rays), getattr(opt, "preload", preload)
             mask_dir = getattr(opt, "mask_dir", mask_dir)
             num_instances = getattr(opt, "num_instances", num_instances)
+            seed, rank = getattr(opt, "seed", seed), getattr(opt, "local_rank", rank)
             self.opt = opt
         self.root, self.type, self.device = path, type, torch.device(device)
         self.training = type in ("train", "all", "trainval")
@@ -168,10 +170,12 @@ class NeRFDataset:
             if m.shape[1:] != (self.H, self.W):
                 m = m[:, ::downscale, ::downscale][:, :self.H, :self.W]            # labels: nearest, never blended
             self.masks = torch.from_numpy(np.ascontiguousarray(m).astype(np.int32, copy=False)).to(dev)
-        self.rng = np.random.default_rng(seed)
+        # one process per GPU: every rank draws its OWN views and pixels (``rank`` enters both streams of randomness; the
+        # ranks' gradients are averaged, so identical draws on all ranks would be one batch computed N times)
+        self.rng = np.random.default_rng(int(seed) + 1000 * int(rank))
         # training batches of a device-resident dataset come from ONE launch (inr_sample_training_batch): pixel draw, rays,
         # rgb gather, label gather.  The draw is counter-based: batch number `_draws` of this loader under `seed`.
-        self.seed, self._draws = int(seed), 0
+        self.seed, self._draws = int(seed) + 1000 * int(rank), 0
         self.fused_batches = True
 
     def __len__(self):

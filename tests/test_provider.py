@@ -113,3 +113,17 @@ def test_room_written_to_disk_reads_back_through_the_loader(tmp_path):
     m = np.load(os.path.join(sc["mask_dir"], "0001.npy"))
     assert m.dtype == np.int32 and m.shape == (24, 32) and m.min() == -1 and m.max() < 8
     assert ((m == -1) | (m == sc["ids"][1] % 8)).all()
+
+
+def test_every_rank_draws_its_own_views(tmp_path):
+    """One process per GPU: NeRFDataset(rank=r) permutes the views with its own stream (the pixel draw's seed moves with it)."""
+    from instance_nerf_amd.nerf.provider import NeRFDataset
+    _write_scene(str(tmp_path), n=8)
+    orders = []
+    for r in range(3):
+        ds = NeRFDataset(str(tmp_path), type="train", num_rays=16, rank=r, seed=5)
+        orders.append([b["index"][0] for b in ds])
+        assert sorted(orders[-1]) == list(range(8)) and ds.seed == 5 + 1000 * r
+    assert orders[0] != orders[1] and orders[1] != orders[2]
+    again = NeRFDataset(str(tmp_path), type="train", num_rays=16, rank=1, seed=5)
+    assert [b["index"][0] for b in again] == orders[1]
