@@ -43,7 +43,7 @@ ds = SyntheticRoomDataset(dev, H=400, W=400, n_views=24, num_rays=4096, num_inst
 tr = Trainer("room_" + phase, None, net, stage=phase, device=dev, lr=1e-3, iters=10 ** 6,
              **(dict(update_extra_interval=10 ** 9) if inst else {}))
 tr.global_step = 1
-n = 200
+n = int(os.environ.get("N_STEPS", "200"))
 batches = [ds.batch() for _ in range(n)]
 torch.cuda.synchronize()
 t0 = time.perf_counter()
