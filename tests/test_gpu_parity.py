@@ -3454,3 +3454,29 @@ def test_fixed_point_scale_update_matches_the_oracle_rule():
         s_ref, r_ref = hashgrid.fx_next_scale(ref, mx)
         assert (got[:16] == s_ref).all(), (trial, got[:16], s_ref)
         assert (got[16:32] == r_ref).all() and (got[64:80] == 0).all()
+
+
+def test_epoch_with_an_unmatched_image_keeps_training_and_its_statistics(tmp_path, room):
+    """An image in which the 2-D matching explained nothing (every label -1: /root/reference/Mask2Former_sample/
+    match_seg.py:111-138 writes such masks for a camera inside an object) gives batches without a single labelled ray.
+    Their cross entropy is the mean over an empty set - NaN, as torch's - but all rays are pruned, so the step touches no
+    parameter; `train_one_epoch` counts it (`stats['nan_steps']`) and leaves it out of the epoch's mean loss, which it
+    reads from the device once per epoch."""
+    from instance_nerf_amd.nerf import NeRFNetwork
+    from instance_nerf_amd.nerf.provider import NeRFDataset
+    from instance_nerf_amd.nerf.utils import Trainer
+    sc = room.write_dataset(str(tmp_path / "s"), n_views=6, H=48, W=64, num_instances=8, ignore_frac=0.1)
+    np.save(os.path.join(sc["mask_dir"], "0002.npy"), np.full((48, 64), -1, np.int32))
+    ds = NeRFDataset(sc["path"], type="train", device=DEV, scale=1.0, num_rays=1024, mask_dir=sc["mask_dir"], num_instances=8)
+    torch.manual_seed(0)
+    net = NeRFNetwork(cuda_ray=True, bound=1, min_near=0.05, density_thresh=10, num_instances=8).to(DEV)
+    net.density_bitfield.copy_(_t(room.density_bitfield(128, 1.0)))
+    tr = Trainer("nan", None, net, stage="instance", device=torch.device(DEV), lr=1e-2, iters=100, workspace=None, mute=True,
+                 update_extra_interval=10 ** 9)
+    tr.global_step = 1
+    for _ in range(3):
+        tr.train_one_epoch(ds.dataloader())
+    assert tr.stats["nan_steps"] == [1, 1, 1] and len(tr.stats["loss"]) == 3
+    assert all(np.isfinite(v) for v in tr.stats["loss"]) and tr.stats["loss"][-1] < tr.stats["loss"][0]
+    assert all(bool(torch.isfinite(p).all()) for p in net.parameters())
+    assert tr.global_step == 1 + 18
