@@ -16,7 +16,6 @@ line could not be parsed by the driver).
 """
 import argparse
 import json
-import math
 import os
 import sys
 import time
