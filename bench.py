@@ -72,6 +72,7 @@ def measured_traffic_bytes_per_sample(res):
 
 
 sys.path.insert(0, os.path.join(ROOT, "tools"))
+from bench_legs import Legs  # noqa: E402
 from bench_line import emit  # noqa: E402
 from bench_secondary import (bound_render_probe, build_network, collective_record, config5_probe,  # noqa: E402
                              half_table_probe, instance_render_probe, render_sharded_probe, train_probe,
@@ -501,36 +502,8 @@ def secondary_multi(args, line, dev, rank, world, backend, red_dev, t_start):
         watchdog.daemon = True
         watchdog.start()
 
-    state = {"healthy": True}
-
-    def agree(ok):
-        """all ranks: did the leg succeed everywhere?"""
-        t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        return bool(t.item() > 0.5)
-
-    def leg(key, fn, keep=None):
-        """Every rank calls it, in the same order.  -> the leg's object (rank 0 also stores it under line[key])."""
-        if not state["healthy"]:
-            out = {"error": "skipped: an earlier collective leg failed on some rank"}
-        else:
-            try:
-                out = fn()
-                ok = True
-            except Exception as e:                                # noqa: BLE001
-                out = {"error": f"{type(e).__name__}: {e}"[:300]}
-                ok = False
-            try:
-                if not agree(ok):
-                    state["healthy"] = False
-                    if ok:
-                        out = {"error": "failed on another rank", "rank0_result": out if keep is None else None}
-            except Exception as e:                                # noqa: BLE001 - the agreement itself failed: stop collectives
-                state["healthy"] = False
-                out = {"error": f"ranks could not agree after the leg: {type(e).__name__}: {e}"[:300]}
-        if rank == 0:
-            line[key] = out if keep is None or "error" in out else {k: out[k] for k in keep if k in out}
-        return out
+    legs = Legs(rank, world, red_dev, line)
+    leg = legs.run
 
     try:
         rec = leg("collective", lambda: collective_record(dev, rank, world, backend, red_dev))

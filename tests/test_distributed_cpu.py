@@ -237,3 +237,63 @@ def test_bench_diagnostics_never_raise_without_a_gpu(tmp_path):
     time.sleep(0.05)
     out = s.stop()
     assert out["sclk_mhz_median"] == 2151 and out["samples"] >= 1
+
+
+def _legs_worker(rank, world, port, q):
+    import sys
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from bench_legs import Legs
+    line = {} if rank == 0 else None
+    legs = Legs(rank, world, torch.device("cpu"), line)
+
+    def collective_ok():
+        t = torch.tensor([float(rank + 1)])
+        dist.all_reduce(t)
+        return {"sum": float(t), "extra": "dropped by keep"}
+
+    def fails_on_rank_1_before_its_collective():
+        if rank == 1:
+            raise RuntimeError("out of memory on rank 1")
+        return {"value": 7}                       # (rank 0 got through its purely local part)
+
+    calls = []
+
+    def never_runs():
+        calls.append(1)
+        t = torch.zeros(1)
+        dist.all_reduce(t)                        # would hang if only some ranks got here
+        return {"value": 1}
+
+    a = legs.run("first", collective_ok, keep=("sum",))
+    b = legs.run("second", fails_on_rank_1_before_its_collective)
+    c = legs.run("third", never_runs)
+    d = legs.run("fourth", never_runs)
+    dist.barrier()
+    q.put((rank, a, b, c, d, len(calls), legs.healthy, line))
+    dist.destroy_process_group()
+
+
+def test_bench_legs_agree_on_a_one_rank_failure_and_skip_the_rest():
+    """tools/bench_legs.py (bench.py's N > 1 legs): a leg that raises on ONE rank is recorded as failed on every rank - rank
+    0's record says so even though its own call succeeded - and the collective legs after it are skipped on ALL ranks
+    instead of leaving the healthy ranks blocked in a collective the failed one never joins."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_legs_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda r: r[0])
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    for rank, a, b, c, d, n_calls, healthy, line in res:
+        assert a == {"sum": 3.0, "extra": "dropped by keep"}
+        assert "error" in b and ("rank 1" in b["error"] if rank == 1 else b["error"] == "failed on another rank")
+        assert c == d == {"error": "skipped: an earlier collective leg failed on some rank"}
+        assert n_calls == 0 and healthy is False
+    line = res[0][7]
+    assert line["first"] == {"sum": 3.0} and line["second"] == {"error": "failed on another rank"} and "skipped" in line["third"]["error"]
+    assert res[1][7] is None
