@@ -3506,3 +3506,42 @@ def test_epoch_with_an_unmatched_image_keeps_training_and_its_statistics(tmp_pat
     assert all(np.isfinite(v) for v in tr.stats["loss"]) and tr.stats["loss"][-1] < tr.stats["loss"][0]
     assert all(bool(torch.isfinite(p).all()) for p in net.parameters())
     assert tr.global_step == 1 + 18
+
+
+def test_fused_loader_at_full_size():
+    """BASELINE sizes: an 800x800 image, 2^20 draws in one launch - every index against the oracle's draw, all in range,
+    uniform over the image (chi-square of 256 equal bins), rays of unit length, colours and labels those of the drawn
+    pixels, and the draw of one step disjoint in sequence from the next step's."""
+    from instance_nerf_amd import _lib
+    from oracle import rays as orays
+    lib = _lib.load()
+    H = W = 800
+    n = 1 << 20
+    rng = np.random.default_rng(3)
+    pose = np.eye(4, dtype=np.float32)
+    pose[:3, :3] = np.linalg.qr(rng.normal(size=(3, 3)))[0].astype(np.float32)
+    img = torch.rand(H, W, 3, device=DEV)
+    mask = torch.randint(-1, 70, (H, W), device=DEV, dtype=torch.int32)
+    P = _t(pose)
+    outs = []
+    for step in (5, 6):
+        inds = torch.empty(n, dtype=torch.int64, device=DEV)
+        ro, rd = torch.empty(n, 3, device=DEV), torch.empty(n, 3, device=DEV)
+        rgb = torch.empty(n, 3, device=DEV)
+        lab = torch.empty(n, dtype=torch.int64, device=DEV)
+        _lib.check(lib.inr_sample_training_batch(_lib.ptr(P), 400.0, 400.0, 400.0, 400.0, H, W, _lib.ptr(img), 3, _lib.ptr(mask), 64,
+                                                 99, step, n, _lib.ptr(inds), _lib.ptr(ro), _lib.ptr(rd), _lib.ptr(rgb), _lib.ptr(lab),
+                                                 _lib.stream_ptr()))
+        outs.append(inds.clone())
+        if step == 5:
+            ref = orays.sample_pixels(99, 5, n, H, W)
+            assert (inds.cpu().numpy() == ref).all()
+            assert int(inds.min()) >= 0 and int(inds.max()) < H * W
+            counts = torch.bincount(inds // 2500, minlength=256).double()
+            chi2 = float(((counts - n / 256) ** 2 / (n / 256)).sum())
+            assert chi2 < 255 + 5 * (2 * 255) ** 0.5, chi2
+            assert float((rd.norm(dim=-1) - 1).abs().max()) < 2e-6 and torch.equal(ro, P[:3, 3].expand(n, 3))
+            assert torch.equal(rgb, img.view(-1, 3)[inds])
+            m = mask.view(-1)[inds].long()
+            assert torch.equal(lab, torch.where(m >= 64, torch.full_like(m, -1), m))
+    assert float((outs[0] == outs[1]).double().mean()) < 1e-4
