@@ -3545,3 +3545,50 @@ def test_fused_loader_at_full_size():
             m = mask.view(-1)[inds].long()
             assert torch.equal(lab, torch.where(m >= 64, torch.full_like(m, -1), m))
     assert float((outs[0] == outs[1]).double().mean()) < 1e-4
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
+def test_fixed_point_table_gradient_fuzz_over_level_tables(seed):
+    """The int32 form of the scatter over the level tables of the encoder fuzz (2..16 levels, base 4..32, 2^8..2^19 rows,
+    finest level 64..4096, bound 1/2/4, points partly outside the volume): second step on int32 sums against the oracle's
+    scatter-add (1e-5 norm-wise; north_star: 1e-3), multiples of each level's quantum, the same bits when repeated."""
+    from instance_nerf_amd import _lib
+    from instance_nerf_amd.gridencoder import GridEncoder
+    from oracle import hashgrid
+    lib = _lib.load()
+    rng = np.random.default_rng(900 + seed)
+    L = int(rng.choice([2, 5, 8, 13, 16]))
+    base = int(rng.choice([4, 16, 32]))
+    log2_t = int(rng.choice([8, 12, 15, 19]))
+    res = int(rng.choice([64, 512, 2048, 4096]))
+    bound = float(rng.choice([1.0, 2.0, 4.0]))
+    enc = GridEncoder(num_levels=L, base_resolution=base, log2_hashmap_size=log2_t, desired_resolution=res).to(DEV)
+    tb = hashgrid.level_table(num_levels=L, base_resolution=base, log2_hashmap_size=log2_t, desired_resolution=res)
+    T, desc, offs = int(tb["total_rows"]), enc.desc, tb["offsets"]
+    gen = torch.Generator().manual_seed(seed)
+    M = 20000
+    x = ((torch.rand(M, 3, generator=gen) * 2.2 - 1.1) * bound).contiguous()
+    go = (torch.randn(M, 2 * L, generator=gen) * 10.0 ** (torch.rand(M, 1, generator=gen) * 4 - 6)).contiguous()
+    ref = hashgrid.encode_backward_table(x, go, bound, tb)
+    xd, god = x.to(DEV), go.to(DEV)
+    fx = torch.zeros(_lib.GRID_FX_STATE_FLOATS, device=DEV)
+
+    def step():
+        g = torch.zeros(T, 2, device=DEV)
+        _lib.check(lib.inr_grid_encode_backward_levels_fx(_lib.ptr(xd), _lib.ptr(god), None, desc, M, bound, _lib.ptr(g), 0, L,
+                                                          _lib.ptr(fx), _lib.stream_ptr()))
+        _lib.check(lib.inr_grid_grad_finish_fx(_lib.ptr(g), desc, 0, L, _lib.ptr(fx), _lib.stream_ptr()))
+        _lib.check(lib.inr_grid_fx_update(_lib.ptr(fx), L, 128.0, _lib.stream_ptr()))
+        return g
+    step()                                                       # fp32 atomics: sets the scales
+    scales = fx[:16].cpu().numpy().copy()
+    assert (scales[:L] > 0).all() and (scales[L:] == 0).all()
+    saved = fx.clone()
+    g2 = step()
+    nrm = float(ref.norm())
+    assert float((g2.cpu() - ref).norm()) < 1e-5 * nrm, (L, base, log2_t, res, bound)
+    for l in range(L):
+        q = (g2[offs[l]:offs[l + 1]].double() * float(scales[l])).cpu()
+        assert bool((q == q.round()).all()), l
+    fx.copy_(saved)
+    assert torch.equal(step(), g2)
