@@ -134,3 +134,27 @@ def test_roi_align_backward_cost_model_is_host_arithmetic():
     assert f(1, 250, 40, 40, 40, 256, 10, 10, 10, -1) == 0               # C % 16 != 0: the form does not exist
     assert f(1, 256, 40, 40, 40, 0, 10, 10, 10, -1) == 0 and f(-1, 256, 40, 40, 40, 256, 10, 10, 10, -1) == 0
     assert lib.inr_roi_align_3d_backward_workspace_bytes(1, 256, 80, 80, 80, 64, 7, 7, 7) > 0     # available, not preferred
+
+
+def test_probe_switches_cannot_reach_the_product_build():
+    """Round-5 verdict item 7a: ablation variants that produce wrong results (no MLP, plain stores instead of atomics, ...)
+    live outside the sources build.py compiles - csrc/probe/, which only tools/build_probe.py adds by defining
+    INR_PROBE_BUILD - and a stray -DINR_PROBE_* on the product build is a compile error, not a silently wrong library."""
+    import shutil
+    import subprocess
+    from instance_nerf_amd import build
+    for src in build.SOURCES:
+        text = open(os.path.join(build.CSRC, src)).read()
+        assert "SEP_BWD_PROBE" not in text and "SEP_NO_ZMASK" not in text, src
+        assert not re.search(r"#\s*if\s+INR_PROBE_(MODE|STATIC|SLOW_XCD)", text), src      # only the hook macros remain
+    assert os.path.exists(os.path.join(build.CSRC, "probe", "field_probe.h"))
+    assert "probe" not in " ".join(build.SOURCES + build.HEADERS)
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    cmd = [hipcc, "-x", "hip", "-E", os.path.join(build.CSRC, "field_fused.hip"), "-o", os.devnull, "--offload-arch=gfx950",
+           "--cuda-device-only", "-std=c++17"]
+    bad = subprocess.run(cmd + ["-DINR_PROBE_MODE=2"], capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0 and "INR_PROBE_BUILD" in bad.stderr
+    ok = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert ok.returncode == 0, ok.stderr[-500:]
