@@ -123,7 +123,8 @@ def train_probe(dev, rank=0, world=1, red_dev=None, steps=20, warmup=5, stage="i
     tr = Trainer("bench", None, net, stage=stage, device=dev, iters=1000, update_extra_interval=16,
                  local_rank=rank, world_size=world, ema_decay=0.95,     # upstream's main scripts train with the EMA on
                  use_graph=piped, look_ahead=piped, shade_ahead=piped,
-                 fp16=fp16)             # upstream's -O: the frozen NeRF of the instance stage with -O's numerics
+                 fp16=fp16,             # upstream's -O: the frozen NeRF of the instance stage with -O's numerics
+                 workspace=None, use_checkpoint="scratch", mute=True)   # a measurement: no checkpoint look-up, nothing on stdout
     if dt_gamma:
         tr.opt = argparse.Namespace(dt_gamma=float(dt_gamma), max_steps=1024, T_thresh=1e-4)
     # Upstream's loop, occupancy update included: every 16 steps update_extra_state() queries the density of 128^3
