@@ -102,7 +102,9 @@ _SIGS = {
     "inr_grid_encode_backward_levels": (c_int32, [P, P, P, POINTER(GridDesc), c_int64, c_float, P, c_int32, c_int32, P]),
     "inr_grid_encode_backward_levels_fx": (c_int32, [P, P, P, POINTER(GridDesc), c_int64, c_float, P, c_int32, c_int32, P, P]),
     "inr_grid_grad_finish_fx": (c_int32, [P, POINTER(GridDesc), c_int32, c_int32, P, P]),
-    "inr_grid_fx_update": (c_int32, [P, c_int32, c_float, P]),
+    "inr_grid_fx_update": (c_int32, [P, c_int32, c_float, c_int32, P]),
+    "inr_grid_encode_backward_levels_fx64": (c_int32, [P, P, P, POINTER(GridDesc), c_int64, c_float, P, P, c_int32, c_int32, P, P]),
+    "inr_grid_grad_finish_fx64": (c_int32, [P, P, POINTER(GridDesc), c_int32, c_int32, P, P]),
     "inr_sh_encode_forward": (c_int32, [P, c_int64, c_int32, P, P]),
     "inr_sh_encode_backward": (c_int32, [P, P, c_int64, c_int32, P, P]),
     "inr_nerf_packed_floats": (c_int64, []),

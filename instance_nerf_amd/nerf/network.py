@@ -62,13 +62,35 @@ _before_scatter = {}      # {"hook": callable}: called once, right before the ne
 
 
 # Fixed-point table-gradient scatter (round 6; include/inr.h "Fixed-point form of the table-gradient scatter"): OPT-IN,
-# INR_FX_GRAD=1 / Trainer(fixed_point_grad=True) / network.FX_GRAD = True.  The memory-side atomic unit takes int32 adds
-# 28 % faster than fp32 ones and the gradient becomes independent of the order in which the waves' requests arrive
-# (training steps are bit-reproducible) - but rows whose gradient is below the level's quantum get none, where Adam
-# (eps 1e-15) moves them by a full lr step under fp32 atomics: same converged quality, slower early convergence of weakly
-# supervised rows (profiles/r06_NOTES.txt 5).  The default is upstream's arithmetic: fp32 atomics.
-FX_GRAD = os.environ.get("INR_FX_GRAD", "0") == "1"
+# INR_FX_GRAD=32 | 64 (1 = 32) / Trainer(fixed_point_grad=...) / network.FX_GRAD = 32 | 64.  The gradient becomes independent
+# of the order in which the waves' requests arrive (training steps are bit-reproducible).
+#   32: int32 sums - the memory-side atomic unit takes them 28 % faster than fp32 adds - but rows whose gradient is below the
+#       level's quantum (1.2e-7 of its recent maximum) get none, where Adam (eps 1e-15) moves them by a full lr step under
+#       fp32 atomics: same converged quality, slower early convergence of weakly supervised rows (profiles/r06_NOTES.txt 5);
+#   64: int64 sums in a separate accumulator - quantum 2e-16 of the level's maximum, invisible to Adam: the faithful
+#       reproducible form, at about the fp32 scatter's speed.
+# The default is upstream's arithmetic: fp32 atomics.
+def _fx_env():
+    v = os.environ.get("INR_FX_GRAD", "0")
+    return {"0": 0, "": 0, "1": 32, "32": 32, "64": 64}.get(v, 0)
+
+
+FX_GRAD = _fx_env()                    # 0 | 32 | 64 (True counts as 32)
 FX_HEADROOM = float(os.environ.get("INR_FX_HEADROOM", "128"))
+FX_HEADROOM64 = float(os.environ.get("INR_FX_HEADROOM64", "1024"))
+
+
+def fx_bits():
+    return 64 if FX_GRAD == 64 else (32 if FX_GRAD else 0)
+
+
+def fx_acc64(emb, create=True):
+    """The table's int64 accumulator of the 64-bit form ([T,2], zero between steps), kept on the Parameter object."""
+    acc = getattr(emb, "_fx_acc64", None)
+    if (acc is None or acc.device != emb.device or acc.shape != emb.shape) and create and emb.is_cuda:
+        acc = torch.zeros(emb.shape, dtype=torch.int64, device=emb.device)
+        emb._fx_acc64 = acc
+    return acc
 
 
 def fx_state(emb, create=True):
@@ -78,7 +100,7 @@ def fx_state(emb, create=True):
     if (st is None or st.device != emb.device) and create and emb.is_cuda:
         st = torch.zeros(_lib.GRID_FX_STATE_FLOATS, dtype=torch.float32, device=emb.device)
         emb._fx_state = st
-        emb._fx_primed = False
+        emb._fx_primed = 0               # 0 | 32 | 64: the form the scales were primed for
     return st
 
 
@@ -104,31 +126,48 @@ def _table_backward(lib, x, denc, desc, M, bound, g_emb, emb):
         raise RuntimeError("gradient accumulation over several backward passes is not supported together with the "
                            "overlapped table-gradient all-reduce; set INR_GRAD_OVERLAP=0")
     overlap = grad_sync.active() and L > 8 and emb.grad is None
-    fx = fx_state(emb) if (FX_GRAD and g_emb.is_cuda and g_emb.data_ptr() % 16 == 0) else None
-    if fx is not None and M and not getattr(emb, "_fx_primed", False) and not torch.cuda.is_current_stream_capturing():
-        # The table's very first backward has no scales yet and would run on fp32 atomics - the one step whose result
-        # depends on the order of arrival.  Prime instead: scatter once into a scratch buffer only to learn the levels'
-        # magnitudes (finish + update set the scales), then take the step itself on int32 sums like every later one.
+    bits = fx_bits() if (g_emb.is_cuda and g_emb.data_ptr() % 16 == 0) else 0
+    fx = fx_state(emb) if bits else None
+    acc = fx_acc64(emb) if bits == 64 else None
+    headroom = FX_HEADROOM64 if bits == 64 else FX_HEADROOM
+
+    def scatter(dst, lo, hi):
+        if bits == 64:
+            check(lib.inr_grid_encode_backward_levels_fx64(ptr(x), ptr(denc), None, desc, M, float(bound), ptr(dst), ptr(acc), lo, hi,
+                                                           ptr(fx), stream_ptr()), "grid_encode_backward (int64 sums)")
+        else:
+            check(lib.inr_grid_encode_backward_levels_fx(ptr(x), ptr(denc), None, desc, M, float(bound), ptr(dst), lo, hi,
+                                                         ptr(fx, allow_none=True), stream_ptr()), "grid_encode_backward")
+
+    def finish(dst, lo, hi):
+        if bits == 64:
+            check(lib.inr_grid_grad_finish_fx64(ptr(acc), ptr(dst), desc, lo, hi, ptr(fx), stream_ptr()), "grid_grad_finish_fx64")
+        else:
+            check(lib.inr_grid_grad_finish_fx(ptr(dst), desc, lo, hi, ptr(fx), stream_ptr()), "grid_grad_finish_fx")
+
+    if fx is not None and M and getattr(emb, "_fx_primed", 0) != bits and not torch.cuda.is_current_stream_capturing():
+        # The table's very first backward (in this form) has no scales yet and would run on fp32 atomics - the one step
+        # whose result depends on the order of arrival.  Prime instead: scatter once into a scratch buffer only to learn the
+        # levels' magnitudes (finish + update set the scales), then take the step itself on integer sums like every later one.
+        fx.zero_()
         scratch = torch.zeros_like(g_emb)
-        check(lib.inr_grid_encode_backward_levels_fx(ptr(x), ptr(denc), None, desc, M, float(bound), ptr(scratch), 0, L,
-                                                     ptr(fx), stream_ptr()), "grid_encode_backward (priming)")
-        check(lib.inr_grid_grad_finish_fx(ptr(scratch), desc, 0, L, ptr(fx), stream_ptr()), "grid_grad_finish_fx (priming)")
-        check(lib.inr_grid_fx_update(ptr(fx), L, FX_HEADROOM, stream_ptr()), "grid_fx_update (priming)")
-        emb._fx_primed = True
+        scatter(scratch, 0, L)
+        finish(scratch, 0, L)
+        check(lib.inr_grid_fx_update(ptr(fx), L, headroom, bits, stream_ptr()), "grid_fx_update (priming)")
+        emb._fx_primed = bits
         del scratch
     for lo, hi in (((8, L), (0, 8)) if overlap else ((0, L),)):
         if M:          # a batch without a single sample still takes part in the collectives below (zeros): every rank
             #            must issue the same sequence of all-reduces or the job hangs
-            check(lib.inr_grid_encode_backward_levels_fx(ptr(x), ptr(denc), None, desc, M, float(bound), ptr(g_emb), lo, hi,
-                                                         ptr(fx, allow_none=True), stream_ptr()), "grid_encode_backward")
+            scatter(g_emb, lo, hi)
         if fx is not None:
-            # int32 sums -> fp32 gradients in place (+ the levels' maxima): from here on g_emb is an ordinary gradient
-            check(lib.inr_grid_grad_finish_fx(ptr(g_emb), desc, lo, hi, ptr(fx), stream_ptr()), "grid_grad_finish_fx")
+            # integer sums -> fp32 gradients (+ the levels' maxima): from here on g_emb is an ordinary gradient
+            finish(g_emb, lo, hi)
         if overlap:
             a, b = int(desc.offsets[lo]), int(desc.offsets[hi])
             grad_sync.reduce_async(g_emb[a:b], emb, a * g_emb.shape[1])
     if fx is not None:
-        check(lib.inr_grid_fx_update(ptr(fx), L, FX_HEADROOM, stream_ptr()), "grid_fx_update")      # next step's scales
+        check(lib.inr_grid_fx_update(ptr(fx), L, headroom, bits, stream_ptr()), "grid_fx_update")      # next step's scales
     if overlap:
         emb.grad = g_emb
         grad_sync.mark(emb, g_emb)

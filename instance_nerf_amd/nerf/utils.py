@@ -869,7 +869,7 @@ class Trainer:
         # leaves it as INR_FX_GRAD set it (default off).
         if fixed_point_grad is not None:
             from . import network as _network
-            _network.FX_GRAD = bool(fixed_point_grad)
+            _network.FX_GRAD = 64 if fixed_point_grad == 64 else (32 if fixed_point_grad else 0)
         self.iters = iters
         # upstream: lr_scheduler = lambda optimizer: LambdaLR(optimizer, lambda it: 0.1 ** min(it / opt.iters, 1)),
         # stepped after every optimiser step; without one, exactly that rule is applied to the param groups
@@ -1126,6 +1126,8 @@ class Trainer:
                     if getattr(p, "_is_hash_table", False):
                         from . import network as _network
                         _network.fx_state(p)        # the fixed-point gradient state of a table: not inside a capture either
+                        if _network.fx_bits() == 64:
+                            _network.fx_acc64(p)
         opt.hyper_tensor(self.device)
         self.optimizer.zero_grad()
         torch.cuda.synchronize()
@@ -1202,6 +1204,8 @@ class Trainer:
                     if getattr(p, "_is_hash_table", False):
                         from . import network as _network
                         _network.fx_state(p)        # the fixed-point gradient state of a table: not inside a capture either
+                        if _network.fx_bits() == 64:
+                            _network.fx_acc64(p)
         opt.hyper_tensor(dev)
         self._pipe = {"key": self._graph_key(data), "sets": sets, "graphs": {}, "turn": 0, "primed": False,
                       "expect": None, "side": torch.cuda.Stream(device=dev)}
@@ -1539,9 +1543,10 @@ class Trainer:
             # fixed-point gradient scales of the trained tables (nerf/network.py::fx_state): a resumed run then rounds the
             # next step's row sums to the same quanta the uninterrupted run does (an extra key; upstream's loader ignores it)
             fx = {n: p._fx_state[:96].detach().cpu().clone() for n, p in self.model.named_parameters()
-                  if getattr(p, "_fx_state", None) is not None and getattr(p, "_fx_primed", False)}
+                  if getattr(p, "_fx_state", None) is not None and getattr(p, "_fx_primed", 0)}
             if fx:
-                state["fx_state"] = fx
+                from . import network as _network
+                state["fx_state"], state["fx_bits"] = fx, _network.fx_bits()
         if path is None and best:
             results = self.stats["results"]
             if not results:
@@ -1613,7 +1618,7 @@ class Trainer:
                     st = _network.fx_state(p)
                     st.zero_()
                     st[:saved.numel()].copy_(saved.to(st.device))
-                    p._fx_primed = True
+                    p._fx_primed = int(state.get("fx_bits", 32))
         for key, obj in (("optimizer", self.optimizer), ("lr_scheduler", self.lr_scheduler), ("ema", self.ema)):
             if obj is not None and key in state:
                 try:

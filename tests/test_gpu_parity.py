@@ -1075,15 +1075,16 @@ def test_get_rays_patch_order_covers_image():
 # ---------------------------------------------------------------------------- training parity
 @pytest.fixture
 def fx_grad(request):
-    """Both forms of the table-gradient scatter (round 6): False = fp32 atomics (the default), True = int32 sums (opt-in)."""
+    """The forms of the table-gradient scatter (round 6): False = fp32 atomics (the default), True = int32 sums, 64 = int64
+    sums (both opt-in).  Yields 0 / 32 / 64."""
     from instance_nerf_amd.nerf import network
     old = network.FX_GRAD
-    network.FX_GRAD = bool(request.param)
-    yield bool(request.param)
+    network.FX_GRAD = 64 if request.param == 64 else (32 if request.param else 0)
+    yield network.FX_GRAD
     network.FX_GRAD = old
 
 
-@pytest.mark.parametrize("fx_grad", [False, True], indirect=True)
+@pytest.mark.parametrize("fx_grad", [False, True, 64], indirect=True)
 def test_trainer_matches_oracle_training(room, room_bitfield, level_table, fx_grad):
     """NeRF training (MSE on rgb): the HIP Trainer and the CPU oracle, started from the same parameters
     and fed the same ray batches (no jitter), follow the same loss curve - with fp32 atomics
@@ -1131,7 +1132,7 @@ def test_trainer_matches_oracle_training(room, room_bitfield, level_table, fx_gr
     # is the band for the int32 form.
     dw = float((w - p["sigma_w0"].detach()).abs().max())
     print(f"fixed point {fx_grad}: max |sigma_w0 - oracle| after {steps} steps = {dw:.2e}; losses {hip_losses[-1]:.6f} / {ref_losses[-1]:.6f}")
-    assert dw < (1.0e-2 if fx_grad else 2e-3), dw
+    assert dw < (1.0e-2 if fx_grad == 32 else 2e-3), dw          # int64 sums (quantum 2e-16 of the level's maximum): fp32's band
 
 
 def test_linear_wgrad_matches_torch():
@@ -1791,7 +1792,7 @@ def test_config2_instance_step_at_full_size_against_the_oracle(room, room_bitfie
             assert prm.grad is None, name
 
 
-@pytest.mark.parametrize("fx_grad", [False, True], indirect=True)
+@pytest.mark.parametrize("fx_grad", [False, True, 64], indirect=True)
 def test_trainer_checkpoint_roundtrip(tmp_path, room, room_bitfield, level_table, fx_grad):
     """save_checkpoint / load_checkpoint restore model, occupancy state and optimiser moments: two trainers
     continue identically (upstream keys: epoch, global_step, stats, model, optimizer, mean_count, mean_density)."""
@@ -1830,7 +1831,7 @@ def test_trainer_checkpoint_roundtrip(tmp_path, room, room_bitfield, level_table
     if fx_grad:
         # int32 table-gradient sums (opt-in): the checkpoint carries the levels' scales, so the resumed trainer rounds its
         # row sums to the same quanta and continues with the SAME BITS in every parameter
-        assert "fx_state" in state and list(state["fx_state"]) == ["encoder.embeddings"]
+        assert "fx_state" in state and list(state["fx_state"]) == ["encoder.embeddings"] and state["fx_bits"] == fx_grad
         assert la == lb
         for (n, p), (_, q) in zip(a.model.named_parameters(), b.model.named_parameters()):
             assert torch.equal(p, q), n
@@ -2856,7 +2857,7 @@ def test_trainer_runs_on_a_transforms_json_scene(tmp_path, room):
     assert np.isfinite(ce).all() and np.mean(ce[-5:]) < np.mean(ce[:5])
 
 
-@pytest.mark.parametrize("fx_grad", [False, True], indirect=True)
+@pytest.mark.parametrize("fx_grad", [False, True, 64], indirect=True)
 @pytest.mark.parametrize("stage", ["nerf", "instance"])
 def test_captured_training_step_equals_eager(stage, fx_grad):
     """Trainer(use_graph=True): the steady-state step captured once as a hipGraph (march, fields, compositing, loss,
@@ -2899,7 +2900,7 @@ def test_captured_training_step_equals_eager(stage, fx_grad):
         assert torch.linalg.norm(p - q) < 1e-2 * torch.linalg.norm(p)
 
 
-@pytest.mark.parametrize("fx_grad", [False, True], indirect=True)
+@pytest.mark.parametrize("fx_grad", [False, True, 64], indirect=True)
 @pytest.mark.parametrize("stage", ["instance", "instance+shade", "nerf"])
 def test_pipelined_captured_step_equals_eager(stage, fx_grad):
     """Trainer(use_graph=True, look_ahead=True): ONE hipGraph per step holds the step and, forked off before the
@@ -3323,7 +3324,7 @@ def _fx_step(lib, x, go, desc, L, bound, T, fx, ranges=None):
         _lib.check(lib.inr_grid_encode_backward_levels_fx(_lib.ptr(x), _lib.ptr(go), None, desc, x.shape[0], float(bound),
                                                           _lib.ptr(g), lo, hi, _lib.ptr(fx), _lib.stream_ptr()))
         _lib.check(lib.inr_grid_grad_finish_fx(_lib.ptr(g), desc, lo, hi, _lib.ptr(fx), _lib.stream_ptr()))
-    _lib.check(lib.inr_grid_fx_update(_lib.ptr(fx), L, 128.0, _lib.stream_ptr()))
+    _lib.check(lib.inr_grid_fx_update(_lib.ptr(fx), L, 128.0, 32, _lib.stream_ptr()))
     return g
 
 
@@ -3439,11 +3440,12 @@ def test_training_steps_are_bit_reproducible_with_the_fixed_point_scatter(stage,
             return losses, {k: v.clone() for k, v in net.state_dict().items()}, name
         finally:
             network.FX_GRAD = old_fx
-    la, sa, name = run(True)
-    lb, sb, _ = run(True)
-    assert la == lb and la[-1] < la[0]
-    for k in sa:
-        assert torch.equal(sa[k], sb[k]), k
+    for form in (True, 64):
+        la, sa, name = run(form)
+        lb, sb, _ = run(form)
+        assert la == lb and la[-1] < la[0], form
+        for k in sa:
+            assert torch.equal(sa[k], sb[k]), (form, k)
     lc, sc, _ = run(False)
     # the fp32 path trains the same way (losses within a few 1e-3 relative of the fixed-point run's) ...
     assert abs(lc[-1] - la[-1]) < 0.05 * abs(la[-1]) + 1e-6
@@ -3474,14 +3476,14 @@ def test_fixed_point_scale_update_matches_the_oracle_rule():
             slots[rng.integers(0, 256)] = mx[l]
             st[96 + 256 * l:96 + 256 * (l + 1)] = slots
         fx = _t(st)
-        _lib.check(lib.inr_grid_fx_update(_lib.ptr(fx), 16, 128.0, _lib.stream_ptr()))
+        _lib.check(lib.inr_grid_fx_update(_lib.ptr(fx), 16, 128.0, 32, _lib.stream_ptr()))
         got = fx.cpu().numpy()
         s_ref, r_ref = hashgrid.fx_next_scale(ref, mx)
         assert (got[:16] == s_ref).all(), (trial, got[:16], s_ref)
         assert (got[16:32] == r_ref).all() and (got[64:80] == 0).all()
 
 
-@pytest.mark.parametrize("fx_grad", [False, True], indirect=True)
+@pytest.mark.parametrize("fx_grad", [False, True, 64], indirect=True)
 def test_epoch_with_an_unmatched_image_keeps_training_and_its_statistics(tmp_path, room, fx_grad):
     """An image in which the 2-D matching explained nothing (every label -1: /root/reference/Mask2Former_sample/
     match_seg.py:111-138 writes such masks for a camera inside an object) gives batches without a single labelled ray.
@@ -3578,7 +3580,7 @@ def test_fixed_point_table_gradient_fuzz_over_level_tables(seed):
         _lib.check(lib.inr_grid_encode_backward_levels_fx(_lib.ptr(xd), _lib.ptr(god), None, desc, M, bound, _lib.ptr(g), 0, L,
                                                           _lib.ptr(fx), _lib.stream_ptr()))
         _lib.check(lib.inr_grid_grad_finish_fx(_lib.ptr(g), desc, 0, L, _lib.ptr(fx), _lib.stream_ptr()))
-        _lib.check(lib.inr_grid_fx_update(_lib.ptr(fx), L, 128.0, _lib.stream_ptr()))
+        _lib.check(lib.inr_grid_fx_update(_lib.ptr(fx), L, 128.0, 32, _lib.stream_ptr()))
         return g
     step()                                                       # fp32 atomics: sets the scales
     scales = fx[:16].cpu().numpy().copy()
@@ -3592,3 +3594,58 @@ def test_fixed_point_table_gradient_fuzz_over_level_tables(seed):
         assert bool((q == q.round()).all()), l
     fx.copy_(saved)
     assert torch.equal(step(), g2)
+
+
+@pytest.mark.parametrize("bound", [1.0, 4.0])
+def test_int64_table_gradient(level_table, bound):
+    """The 64-bit form of the order-independent scatter (include/inr.h inr_grid_encode_backward_levels_fx64): int64 sums in a
+    separate accumulator with a quantum of ~2e-16 of each level's maximum.  First step without scales: fp32 atomics straight
+    into the gradient; second step: the accumulator - the oracle's scatter-add to fp32 rounding (tighter than the fp32
+    atomics themselves), the SAME BITS when repeated or split into the two level ranges of the N > 1 schedule, the
+    accumulator zero again afterwards; a 500x jump of the gradient is nowhere near the int64 range."""
+    from instance_nerf_amd import _lib
+    from instance_nerf_amd.gridencoder import GridEncoder
+    from oracle import hashgrid
+    lib = _lib.load()
+    tb = level_table if bound == 1.0 else hashgrid.level_table(desired_resolution=8192)
+    enc = GridEncoder(desired_resolution=int(tb["resolutions"][-1])).to(DEV)
+    L, T, desc = 16, int(tb["total_rows"]), enc.desc
+    gen = torch.Generator().manual_seed(31)
+    M = 60000
+    o = (torch.rand(M // 50, 1, 3, generator=gen) * 1.6 - 0.8) * bound
+    d = torch.nn.functional.normalize(torch.randn(M // 50, 1, 3, generator=gen), dim=-1)
+    x = (o + d * torch.linspace(0, 0.5 * bound, 50).view(1, 50, 1)).reshape(-1, 3).clamp(-bound, bound).contiguous()
+    go = (torch.randn(M, 32, generator=gen) * torch.logspace(-12, -2, M).view(-1, 1)[torch.randperm(M, generator=gen)]).contiguous()
+    ref64 = hashgrid.encode_backward_table(x, go, bound, tb)
+    xd, god = x.to(DEV), go.to(DEV)
+    fx = torch.zeros(_lib.GRID_FX_STATE_FLOATS, device=DEV)
+    acc = torch.zeros(T, 2, dtype=torch.int64, device=DEV)
+
+    def step(g_out, ranges=((0, L),)):
+        g = torch.zeros(T, 2, device=DEV)
+        for lo, hi in ranges:
+            _lib.check(lib.inr_grid_encode_backward_levels_fx64(_lib.ptr(xd), _lib.ptr(g_out), None, desc, M, float(bound), _lib.ptr(g),
+                                                                _lib.ptr(acc), lo, hi, _lib.ptr(fx), _lib.stream_ptr()))
+            _lib.check(lib.inr_grid_grad_finish_fx64(_lib.ptr(acc), _lib.ptr(g), desc, lo, hi, _lib.ptr(fx), _lib.stream_ptr()))
+        _lib.check(lib.inr_grid_fx_update(_lib.ptr(fx), L, 1024.0, 64, _lib.stream_ptr()))
+        return g
+    nrm = float(ref64.norm())
+    g1 = step(god)                                            # no scales: fp32 atomics into g
+    assert float((g1.cpu() - ref64).norm()) < 2e-6 * nrm and int(acc.abs().max()) == 0
+    scales = fx[:16].cpu().numpy().astype(np.float64)
+    offs = tb["offsets"]
+    for l in range(16):                                       # 1024 x the level's maximum fits: 2^51 < max * scale <= 2^52
+        mx = float(ref64[offs[l]:offs[l + 1]].abs().max())
+        assert 2.0 ** 51 * 0.999 < mx * scales[l] <= 2.0 ** 52 * 1.001, (l, mx, scales[l])
+    saved = fx.clone()
+    g2 = step(god)
+    assert float((g2.cpu() - ref64).norm()) < 1e-6 * nrm and int(acc.abs().max()) == 0
+    # rows the int32 form would freeze are alive here: every non-zero row of the oracle is non-zero
+    assert float(((ref64 != 0) & (g2.cpu() == 0)).double().mean()) < 1e-3
+    fx.copy_(saved)
+    assert torch.equal(step(god, ranges=((8, L), (0, 8))), g2)
+    g3 = step((god * 500).contiguous())                       # 500 x: half the headroom, no near miss at 1/8 of the range
+    st = fx.cpu().numpy()
+    assert float((g3.cpu() - 500 * ref64).norm()) < 1e-6 * 500 * nrm and st[49] == 0 and st[80:96].max() < 0.3
+    with pytest.raises(RuntimeError):
+        _lib.check(lib.inr_grid_fx_update(_lib.ptr(fx), L, 1024.0, 48, _lib.stream_ptr()))

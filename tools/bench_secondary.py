@@ -35,7 +35,7 @@ def scatter_requests(stage):
     if t.get("source_sha") != build.source_sha("scatter"):
         return None
     from instance_nerf_amd.nerf import network as _network
-    form = "int32 (fixed point)" if _network.FX_GRAD else "fp32 atomics"
+    form = {0: "fp32 atomics", 32: "int32 (fixed point)", 64: "int64 sums"}[_network.fx_bits()]
     if t.get("scatter_form", "fp32 atomics") != form:
         return None                           # measured on the other form of the scatter
     return float(t["instance_stage" if stage == "instance" else "nerf_stage"]["requests_per_sample"]), float(t["unit_rate_requests_per_s"])
@@ -712,21 +712,25 @@ def timed_trained_steps(tr, net, ds, stage, n=128, ab=True):
     # memory-side atomic unit takes integer adds 28 % faster and steps become bit-reproducible; how often did a level come
     # within 8x of the int32 range ("near miss") and how much of the range did the largest row sum ever use
     table = net.instance_encoder.embeddings if stage == "instance" else net.encoder.embeddings
-    out["scatter_form"] = "int32 (fixed point)" if _network_mod.FX_GRAD else "fp32 atomics"
+    out["scatter_form"] = f"int{_network_mod.fx_bits()} sums" if _network_mod.FX_GRAD else "fp32 atomics"
     if ab and not _network_mod.FX_GRAD:
-        _network_mod.FX_GRAD = True
-        try:
-            other = timed_trained_steps(tr, net, ds, stage, n=96, ab=False)
-            st = getattr(table, "_fx_state", None)
-            h = st[:96].cpu().numpy() if st is not None else np.zeros(96, np.float32)
-            out["fixed_point"] = {**{k: other[k] for k in ("steps", "ms_per_step", "ms_per_step_median", "scatter_ms", "scatter_share_of_step")},
-                                  "steps_so_far": int(h[48]), "near_misses_so_far": int(h[49]),
-                                  "peak_use_of_the_int32_range": round(float(h[80:96].max()), 4),
-                                  "what": "opt-in (INR_FX_GRAD=1 / Trainer(fixed_point_grad=True)): int32 sums of the table gradient; near "
-                                          "miss = a level-step whose largest row sum used more than 1/8 of the int32 range, peak use 1.0 "
-                                          "would be a wrap (tools/fx_dynamics_probe.py)"}
-        finally:
-            _network_mod.FX_GRAD = False
+        for key, form in (("fixed_point", 32), ("fixed_point64", 64)):
+            _network_mod.FX_GRAD = form
+            try:
+                other = timed_trained_steps(tr, net, ds, stage, n=96, ab=False)
+                st = getattr(table, "_fx_state", None)
+                h = st[:96].cpu().numpy() if st is not None else np.zeros(96, np.float32)
+                out[key] = {**{k: other[k] for k in ("steps", "ms_per_step", "ms_per_step_median", "scatter_ms", "scatter_share_of_step")},
+                            "near_misses_so_far": int(h[49]), "peak_use_of_the_integer_range": round(float(h[80:96].max()), 4),
+                            "what": f"opt-in (INR_FX_GRAD={form} / Trainer(fixed_point_grad={form})): int{form} sums of the table gradient"
+                                    + ("; near miss = a level-step whose largest row sum used more than 1/8 of the range, peak use 1.0 "
+                                       "would be a wrap (tools/fx_dynamics_probe.py)" if form == 32 else
+                                       " in a separate accumulator: quantum 2e-16 of a level's maximum, invisible to Adam - the faithful "
+                                       "order-independent form")}
+            except Exception as e:                                # noqa: BLE001
+                out[key] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            finally:
+                _network_mod.FX_GRAD = 0
     return out
 
 

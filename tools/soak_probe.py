@@ -45,7 +45,7 @@ def counters(table):
     if st is None or not network.FX_GRAD:
         return ""
     h = st[:96].cpu().numpy()
-    return f", fixed point: {int(h[48])} steps, {int(h[49])} near misses, peak use of the int32 range {h[80:96].max():.3f}"
+    return f", int{network.fx_bits()} sums: {int(h[48])} steps, {int(h[49])} near misses, peak use of the integer range {h[80:96].max():.3f}"
 
 
 ds = NeRFDataset(d, type="train", device=dev, scale=1.0, num_rays=4096, preload=True)
