@@ -3602,7 +3602,7 @@ def test_int64_table_gradient(level_table, bound):
     separate accumulator with a quantum of ~2e-16 of each level's maximum.  First step without scales: fp32 atomics straight
     into the gradient; second step: the accumulator - the oracle's scatter-add to fp32 rounding (tighter than the fp32
     atomics themselves), the SAME BITS when repeated or split into the two level ranges of the N > 1 schedule, the
-    accumulator zero again afterwards; a 500x jump of the gradient is nowhere near the int64 range."""
+    accumulator zero again afterwards; a 100x jump of the gradient uses 0.05 of the int64 range."""
     from instance_nerf_amd import _lib
     from instance_nerf_amd.gridencoder import GridEncoder
     from oracle import hashgrid
@@ -3644,8 +3644,8 @@ def test_int64_table_gradient(level_table, bound):
     assert float(((ref64 != 0) & (g2.cpu() == 0)).double().mean()) < 1e-3
     fx.copy_(saved)
     assert torch.equal(step(god, ranges=((8, L), (0, 8))), g2)
-    g3 = step((god * 500).contiguous())                       # 500 x: half the headroom, no near miss at 1/8 of the range
+    g3 = step((god * 100).contiguous())                       # 100 x against a headroom of 1024: 0.05 of the range, no near miss
     st = fx.cpu().numpy()
-    assert float((g3.cpu() - 500 * ref64).norm()) < 1e-6 * 500 * nrm and st[49] == 0 and st[80:96].max() < 0.3
+    assert float((g3.cpu() - 100 * ref64).norm()) < 1e-6 * 100 * nrm and st[49] == 0 and 0.02 < st[80:96].max() < 0.06
     with pytest.raises(RuntimeError):
         _lib.check(lib.inr_grid_fx_update(_lib.ptr(fx), L, 1024.0, 48, _lib.stream_ptr()))
